@@ -1,0 +1,218 @@
+"""ctypes mirror of include/dlscqp.h (the C ABI of the HIP trajectory optimizer).
+
+Only struct layouts, constants and the loader live here.  The loader fails loudly when the HIP
+library has not been built: there is no CPU fallback in the product path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ABI_VERSION = 1
+
+# API return codes
+SUCCESS = 0
+ERR_INVALID_ARGUMENT = -1
+ERR_HIP = -2
+ERR_NO_DEVICE = -3
+ERR_UNSUPPORTED = -4
+
+# per-agent verdicts
+OK = 0
+INFEASIBLE = 1
+ITERATION_LIMIT = 2
+NUMERICAL = 3
+GOAL_FALLBACK = 16
+
+# MATP::PlannerMode (sp_const.hpp:18-26)
+PLANNER_DLSCGC, PLANNER_DLSC, PLANNER_LSC, PLANNER_BVC, PLANNER_ORCA, PLANNER_RECIPROCALRSFC, PLANNER_CIRCLETEST = range(7)
+# MATP::SlackMode (sp_const.hpp:44-48)
+SLACK_NONE, SLACK_CONTINUITY, SLACK_COLLISIONCONSTRAINT = range(3)
+
+ROW_DYNAMIC = 1
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("world_dimension", C.c_int32),
+        ("M", C.c_int32),
+        ("n", C.c_int32),
+        ("phi", C.c_int32),
+        ("phi_n", C.c_int32),
+        ("planner_mode", C.c_int32),
+        ("slack_mode", C.c_int32),
+        ("world_use_octomap", C.c_int32),
+        ("device", C.c_int32),
+        ("dt", C.c_double),
+        ("control_input_weight", C.c_double),
+        ("terminal_weight", C.c_double),
+        ("slack_collision_weight", C.c_double),
+        ("communication_range", C.c_double),
+        ("world_z_2d", C.c_double),
+        ("slack_threshold", C.c_double),
+        ("world_min", C.c_double * 3),
+        ("world_max", C.c_double * 3),
+    ]
+
+
+class Agent(C.Structure):
+    _fields_ = [
+        ("position", C.c_float * 3),
+        ("velocity", C.c_float * 3),
+        ("acceleration", C.c_float * 3),
+        ("current_goal_point", C.c_float * 3),
+        ("next_waypoint", C.c_float * 3),
+        ("id", C.c_int32),
+        ("n_obs", C.c_int32),
+        ("n_slack_obs", C.c_int32),
+        ("max_vel", C.c_double),
+        ("max_acc", C.c_double),
+        ("radius", C.c_double),
+        ("nominal_velocity", C.c_double),
+    ]
+
+
+class LscRow(C.Structure):
+    _fields_ = [
+        ("normal", C.c_float * 3),
+        ("point", C.c_float * 3),
+        ("d", C.c_double),
+        ("m", C.c_int16),
+        ("i", C.c_int8),
+        ("flags", C.c_uint8),
+        ("obs", C.c_int16),
+        ("slack", C.c_int16),
+    ]
+
+
+class DeviceBatch(C.Structure):
+    _fields_ = [
+        ("n_agents", C.c_int32),
+        ("max_slack_obs", C.c_int32),
+        ("do_goal", C.c_int32),
+        ("do_traj", C.c_int32),
+        ("agents", C.c_void_p),
+        ("row_offsets", C.c_void_p),
+        ("nx", C.c_void_p),
+        ("ny", C.c_void_p),
+        ("nz", C.c_void_p),
+        ("px", C.c_void_p),
+        ("py", C.c_void_p),
+        ("pz", C.c_void_p),
+        ("d", C.c_void_p),
+        ("key", C.c_void_p),
+        ("sfc_boxes", C.c_void_p),
+        ("out_goal", C.c_void_p),
+        ("out_goal_status", C.c_void_p),
+        ("out_ctrl", C.c_void_p),
+        ("out_ctrl_f64", C.c_void_p),
+        ("out_cost", C.c_void_p),
+        ("out_slack_cost", C.c_void_p),
+        ("out_status", C.c_void_p),
+        ("out_iters", C.c_void_p),
+    ]
+
+
+assert C.sizeof(Config) == 144, C.sizeof(Config)
+assert C.sizeof(Agent) == 104, C.sizeof(Agent)
+assert C.sizeof(LscRow) == 40, C.sizeof(LscRow)
+
+AGENT_DTYPE = np.dtype(Agent)
+ROW_DTYPE = np.dtype(LscRow)
+
+
+def make_config(dim=3, M=5, n=5, phi=3, phi_n=1, dt=0.2, control_input_weight=0.01,
+                terminal_weight=1.0, slack_collision_weight=1.0, communication_range=-1.0,
+                world_use_octomap=False, world_min=(-5.0, -5.0, 0.0), world_max=(5.0, 5.0, 2.5),
+                world_z_2d=1.0, slack_threshold=0.1, planner_mode=PLANNER_DLSCGC,
+                slack_mode=SLACK_NONE, device=0):
+    """Config with the values of launch/testall_DLSCGC_empty.launch unless overridden.
+
+    world_min/world_max are rounded through float32 like Mission's point3d (mission.hpp:31)."""
+    c = Config()
+    c.abi_version = ABI_VERSION
+    c.world_dimension = dim
+    c.M, c.n, c.phi, c.phi_n = M, n, phi, phi_n
+    c.planner_mode = planner_mode
+    c.slack_mode = slack_mode
+    c.world_use_octomap = 1 if world_use_octomap else 0
+    c.device = device
+    c.dt = dt
+    c.control_input_weight = control_input_weight
+    c.terminal_weight = terminal_weight
+    c.slack_collision_weight = slack_collision_weight
+    c.communication_range = communication_range
+    c.world_z_2d = world_z_2d
+    c.slack_threshold = slack_threshold
+    for k in range(3):
+        c.world_min[k] = float(np.float32(world_min[k]))
+        c.world_max[k] = float(np.float32(world_max[k]))
+    return c
+
+
+def key_of(m, i, slack, dyn):
+    """DLSCQP_KEY of include/dlscqp.h (vectorised)."""
+    m = np.asarray(m).astype(np.uint32)
+    i = np.asarray(i).astype(np.uint32)
+    slack = np.asarray(slack).astype(np.int64)
+    dyn = np.asarray(dyn).astype(np.uint32)
+    s = np.where(slack < 0, 0xFFFF, slack).astype(np.uint32)
+    return (m & 0xFF) | ((i & 0xF) << 8) | ((dyn & 1) << 12) | (s << 16)
+
+
+_LIB = None
+
+
+def library_path():
+    here = os.path.dirname(os.path.abspath(__file__))
+    return os.path.join(here, "csrc", "libdlscqp.so")
+
+
+def load_library():
+    """Load the HIP library; raise if it has not been built (no CPU fallback exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "dlsc_gc_planner_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+    lib = C.CDLL(path)
+    P = C.POINTER
+    lib.dlscqp_create.argtypes = [P(Config), P(C.c_void_p)]
+    lib.dlscqp_create.restype = C.c_int
+    lib.dlscqp_destroy.argtypes = [C.c_void_p]
+    lib.dlscqp_destroy.restype = None
+    lib.dlscqp_update_param.argtypes = [C.c_void_p, P(Config)]
+    lib.dlscqp_update_param.restype = C.c_int
+    lib.dlscqp_last_error.argtypes = []
+    lib.dlscqp_last_error.restype = C.c_char_p
+    lib.dlscqp_lds_bytes.argtypes = [C.c_void_p, C.c_int]
+    lib.dlscqp_lds_bytes.restype = C.c_int64
+    vp = C.c_void_p
+    lib.dlscqp_solve_batch.argtypes = [vp, C.c_int32, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp]
+    lib.dlscqp_solve_batch.restype = C.c_int
+    lib.dlscqp_goal_batch.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp]
+    lib.dlscqp_goal_batch.restype = C.c_int
+    lib.dlscqp_plan_batch.argtypes = [vp, C.c_int32, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp]
+    lib.dlscqp_plan_batch.restype = C.c_int
+    lib.dlscqp_plan_batch_device.argtypes = [vp, P(DeviceBatch), vp]
+    lib.dlscqp_plan_batch_device.restype = C.c_int
+    lib.dlscqp_rows_to_soa.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.dlscqp_rows_to_soa.restype = None
+    lib.dlscqp_set_timing.argtypes = [vp, C.c_int]
+    lib.dlscqp_set_timing.restype = C.c_int
+    lib.dlscqp_last_kernel_ms.argtypes = [vp, P(C.c_float)]
+    lib.dlscqp_last_kernel_ms.restype = C.c_int
+    _LIB = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "dlscqp_create", "dlscqp_destroy", "dlscqp_update_param", "dlscqp_last_error",
+    "dlscqp_lds_bytes", "dlscqp_solve_batch", "dlscqp_goal_batch", "dlscqp_plan_batch",
+    "dlscqp_plan_batch_device", "dlscqp_rows_to_soa", "dlscqp_set_timing",
+    "dlscqp_last_kernel_ms",
+]

@@ -1,0 +1,211 @@
+/*
+ * dlscqp.h -- C ABI of the MI355X-native batched DLSC-GC trajectory optimizer.
+ *
+ * This is the drop-in boundary for the ONE hot path of qwerty35/dlsc_gc_planner that this
+ * project replaces: the per-agent Bernstein trajectory QP (TrajOptimizer::solve) and its
+ * 1-variable goal LP (GoalOptimizer::solve), which the reference solves with CPLEX one agent
+ * at a time.  All citations are file:line under the reference tree.
+ *
+ *   reference interface                                   replaced by
+ *   ---------------------------------------------------   ---------------------------------
+ *   TrajOptimizer::TrajOptimizer  (traj_optimizer.cpp:4)   dlscqp_create
+ *   TrajOptimizer::updateParam    (traj_optimizer.cpp:167) dlscqp_update_param
+ *   TrajOptimizer::solve          (traj_optimizer.cpp:18)  dlscqp_solve_batch[_device]
+ *   GoalOptimizer::solve          (goal_optimizer.cpp:7)   dlscqp_goal_batch[_device]
+ *   TrajPlanner::goalPlanning + trajOptimization
+ *          (traj_planner.cpp:491-496, 737-744)             dlscqp_plan_batch[_device] (fused)
+ *   throw PlanningReport::QPFAILED (traj_optimizer.cpp:152) status != DLSCQP_OK per agent
+ *
+ * Plain pointers and sizes only; no exceptions cross this boundary; buffers are caller-owned.
+ * The C++ classes in dlsc_gc_planner_amd/include/dlsc_gc_planner_amd/ (MATP::TrajOptimizer,
+ * MATP::GoalOptimizer, MATP::CollisionConstraints) are thin marshalling shims over these calls.
+ */
+#ifndef DLSCQP_H
+#define DLSCQP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DLSCQP_ABI_VERSION 1
+
+/* Return codes of the API calls themselves (not per-agent verdicts). */
+enum {
+    DLSCQP_SUCCESS = 0,
+    DLSCQP_ERR_INVALID_ARGUMENT = -1, /* std::invalid_argument in the reference (traj_optimizer.cpp:209,248) */
+    DLSCQP_ERR_HIP = -2,              /* a HIP runtime call failed; see dlscqp_last_error() */
+    DLSCQP_ERR_NO_DEVICE = -3,
+    DLSCQP_ERR_UNSUPPORTED = -4
+};
+
+/* Per-agent verdicts written to out_status[]. */
+enum {
+    DLSCQP_OK = 0,             /* solved */
+    DLSCQP_INFEASIBLE = 1,     /* CPLEX Infeasible / InfeasibleOrUnbounded -> PlanningReport::QPFAILED */
+    DLSCQP_ITERATION_LIMIT = 2,/* solver did not converge (also mapped to QPFAILED by the shim)        */
+    DLSCQP_NUMERICAL = 3,      /* non positive-definite reduced Hessian / breakdown (QPFAILED)         */
+    DLSCQP_GOAL_FALLBACK = 16  /* goal LP: "numerical error" branch, goal = current_goal_point
+                                  (goal_optimizer.cpp:79-81); not a failure                            */
+};
+
+/* Mirrors MATP::PlannerMode (sp_const.hpp:18-26), same order. */
+enum {
+    DLSCQP_PLANNER_DLSCGC = 0,
+    DLSCQP_PLANNER_DLSC = 1,
+    DLSCQP_PLANNER_LSC = 2,
+    DLSCQP_PLANNER_BVC = 3,
+    DLSCQP_PLANNER_ORCA = 4,
+    DLSCQP_PLANNER_RECIPROCALRSFC = 5,
+    DLSCQP_PLANNER_CIRCLETEST = 6
+};
+
+/* Mirrors MATP::SlackMode (sp_const.hpp:44-48), same order. */
+enum {
+    DLSCQP_SLACK_NONE = 0,
+    DLSCQP_SLACK_CONTINUITY = 1, /* populatebyrow creates no extra variables for it; treated as NONE */
+    DLSCQP_SLACK_COLLISIONCONSTRAINT = 2
+};
+
+/* The subset of MATP::Param (param.hpp) and MATP::Mission (mission.hpp:31) the path reads. */
+typedef struct dlscqp_config {
+    int32_t abi_version;           /* DLSCQP_ABI_VERSION */
+    int32_t world_dimension;       /* param.world_dimension: 2 or 3                   */
+    int32_t M;                     /* param.M  segments                               */
+    int32_t n;                     /* param.n  polynomial degree (only 5)             */
+    int32_t phi;                   /* param.phi (only 3)                              */
+    int32_t phi_n;                 /* param.phi_n (1)                                 */
+    int32_t planner_mode;          /* DLSCQP_PLANNER_*                                */
+    int32_t slack_mode;            /* DLSCQP_SLACK_*                                  */
+    int32_t world_use_octomap;     /* param.world_use_octomap: SFC rows on/off        */
+    int32_t device;                /* HIP device ordinal                              */
+    double dt;                     /* param.dt                                        */
+    double control_input_weight;   /* param.control_input_weight                      */
+    double terminal_weight;        /* param.terminal_weight                           */
+    double slack_collision_weight; /* param.slack_collision_weight                    */
+    double communication_range;    /* param.communication_range (<=0: rows omitted)   */
+    double world_z_2d;             /* param.world_z_2d                                */
+    double slack_threshold;        /* param.slack_threshold (collision alert)         */
+    double world_min[3];           /* mission.world_min                               */
+    double world_max[3];           /* mission.world_max                               */
+} dlscqp_config;
+
+/* The subset of MATP::Agent (sp_const.hpp:147-160) the path reads; float32 = octomap::point3d. */
+typedef struct dlscqp_agent {
+    float position[3];
+    float velocity[3];
+    float acceleration[3];
+    float current_goal_point[3];
+    float next_waypoint[3];
+    int32_t id;
+    int32_t n_obs;       /* constraints.getObsSize()                                              */
+    int32_t n_slack_obs; /* obstacles that own slack variables: dynamic ones, or all of them in
+                            DLSCQP_SLACK_COLLISIONCONSTRAINT mode (traj_optimizer.cpp:272-283)    */
+    double max_vel;
+    double max_acc;
+    double radius;
+    double nominal_velocity;
+} dlscqp_agent;
+
+/* One LSC half-space  normal . (c_{m,i} - point) - d >= 0  (collision_constraints.hpp:19-35),
+ * flattened from CollisionConstraints::getLSC(oi, m, i). */
+typedef struct dlscqp_lsc_row {
+    float normal[3];
+    float point[3];
+    double d;
+    int16_t m;     /* segment index 0..M-1                                                       */
+    int8_t i;      /* control point index 0..n                                                   */
+    uint8_t flags; /* bit0: obstacle is dynamic (type != AGENT, collision_constraints.cpp:582)   */
+    int16_t obs;   /* obstacle index oi                                                          */
+    int16_t slack; /* obs_slack_idx of this obstacle or -1 (traj_optimizer.cpp:413-450)          */
+} dlscqp_lsc_row; /* 40 bytes */
+
+#define DLSCQP_ROW_DYNAMIC 1
+
+typedef struct dlscqp_ctx dlscqp_ctx;
+
+/* ---- lifetime --------------------------------------------------------------------------- */
+int dlscqp_create(const dlscqp_config *cfg, dlscqp_ctx **out_ctx);
+void dlscqp_destroy(dlscqp_ctx *ctx);
+/* TrajOptimizer::updateParam: replaces weights/modes/ranges; M, n, phi, dt, dimension stay as
+ * constructed, exactly like the reference (traj_optimizer.cpp:167-169 does not refresh them). */
+int dlscqp_update_param(dlscqp_ctx *ctx, const dlscqp_config *cfg);
+/* Text of the last error on this thread ("" if none). */
+const char *dlscqp_last_error(void);
+/* Number of 32-bit words of LDS the solver kernel uses per agent for this context and
+ * max_slack_obs; diagnostic. */
+int64_t dlscqp_lds_bytes(const dlscqp_ctx *ctx, int max_slack_obs);
+
+/* ---- host-buffer entry points (H2D + kernel + D2H, synchronous) --------------------------
+ * rows of agent a are rows[row_offsets[a] .. row_offsets[a+1]); sfc_boxes is [n_agents][M][6]
+ * = {min.x,min.y,min.z,max.x,max.y,max.z} per segment (CollisionConstraints::getSFC(m)), and
+ * may be NULL when world_use_octomap == 0.
+ * out_ctrl: [n_agents][M][n+1][3] float32 (2-D: z = world_z_2d, traj_optimizer.cpp:69-83)
+ * out_cost: [n_agents] cplex.getObjValue() equivalent (traj_optimizer.cpp:109)
+ * out_slack_cost: [n_agents][max_slack_obs] sum_m |eps_{s,m}| (traj_optimizer.cpp:85-106) or NULL
+ * out_status: [n_agents] verdicts.  Outputs of failed agents are left untouched (ctrl) / 0.   */
+int dlscqp_solve_batch(dlscqp_ctx *ctx, int32_t n_agents, const dlscqp_agent *agents,
+                       const int64_t *row_offsets, const dlscqp_lsc_row *rows,
+                       const float *sfc_boxes, int32_t max_slack_obs, float *out_ctrl,
+                       double *out_cost, double *out_slack_cost, int32_t *out_status);
+
+/* GoalOptimizer::solve for a batch: out_goal [n_agents][3]. */
+int dlscqp_goal_batch(dlscqp_ctx *ctx, int32_t n_agents, const dlscqp_agent *agents,
+                      const int64_t *row_offsets, const dlscqp_lsc_row *rows,
+                      const float *sfc_boxes, float *out_goal, int32_t *out_goal_status);
+
+/* Fused goal LP -> trajectory QP (the QP uses the LP's goal, traj_planner.cpp:494). */
+int dlscqp_plan_batch(dlscqp_ctx *ctx, int32_t n_agents, const dlscqp_agent *agents,
+                      const int64_t *row_offsets, const dlscqp_lsc_row *rows,
+                      const float *sfc_boxes, int32_t max_slack_obs, float *out_goal,
+                      int32_t *out_goal_status, float *out_ctrl, double *out_cost,
+                      double *out_slack_cost, int32_t *out_status);
+
+/* ---- device-resident entry point ---------------------------------------------------------
+ * Everything already in HBM, constraint rows in structure-of-arrays form so a wavefront reads
+ * 64 consecutive rows with one coalesced load per field.  Asynchronous on `stream`
+ * (a hipStream_t passed as void*); no allocation, no synchronisation inside.               */
+typedef struct dlscqp_device_batch {
+    int32_t n_agents;
+    int32_t max_slack_obs;          /* stride of out_slack_cost                                 */
+    int32_t do_goal;                /* 1: run the goal LP first and use its goal in the QP       */
+    int32_t do_traj;                /* 1: run the trajectory QP                                  */
+    const dlscqp_agent *agents;     /* [n_agents]                                               */
+    const int32_t *row_offsets;     /* [n_agents+1]                                             */
+    const float *nx, *ny, *nz;      /* [total_rows] normal                                      */
+    const float *px, *py, *pz;      /* [total_rows] obstacle control point                      */
+    const double *d;                /* [total_rows] margin                                      */
+    const uint32_t *key;            /* [total_rows] DLSCQP_KEY(m,i,slack,dyn)                   */
+    const float *sfc_boxes;         /* [n_agents][M][6] or NULL                                 */
+    float *out_goal;                /* [n_agents][3] (may be NULL if !do_goal)                  */
+    int32_t *out_goal_status;       /* [n_agents]                                               */
+    float *out_ctrl;                /* [n_agents][M][n+1][3]                                    */
+    double *out_ctrl_f64;           /* optional [n_agents][dim*M*(n+1) + M*max_slack_obs], NULL */
+    double *out_cost;               /* [n_agents]                                               */
+    double *out_slack_cost;         /* [n_agents][max_slack_obs] or NULL                        */
+    int32_t *out_status;            /* [n_agents]                                               */
+    int32_t *out_iters;             /* optional [n_agents][4] {iterations, adds, drops, active} */
+} dlscqp_device_batch;
+
+/* key layout: bits 0-7 m, 8-11 i, 12 dynamic flag, 16-31 slack index (0xFFFF = none). */
+#define DLSCQP_KEY(m, i, slack, dyn)                                                     \
+    ((uint32_t)((m) & 0xFF) | ((uint32_t)((i) & 0xF) << 8) | ((uint32_t)((dyn) & 1) << 12) | \
+     ((uint32_t)((slack) < 0 ? 0xFFFFu : (uint32_t)(slack)) << 16))
+
+int dlscqp_plan_batch_device(dlscqp_ctx *ctx, const dlscqp_device_batch *batch, void *stream);
+
+/* Host helper: convert n_rows AoS rows to the SoA arrays above (host memory, caller-owned). */
+void dlscqp_rows_to_soa(const dlscqp_lsc_row *rows, int64_t n_rows, float *nx, float *ny,
+                        float *nz, float *px, float *py, float *pz, double *d, uint32_t *key);
+
+/* Elapsed GPU time in ms of the last dlscqp_plan_batch_device launch issued with timing
+ * enabled (HIP events on the launch stream); blocks until that launch is done. */
+int dlscqp_set_timing(dlscqp_ctx *ctx, int enable);
+int dlscqp_last_kernel_ms(dlscqp_ctx *ctx, float *ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DLSCQP_H */

@@ -1,0 +1,91 @@
+/*
+ * dlsc_oracle.h -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * Plain-C restatement of the reference's trajectory-QP / goal-LP path
+ * (/root/reference/src/traj_optimizer.cpp, src/goal_optimizer.cpp).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+ * library (dlsc_gc_planner_amd/csrc -> libdlscqp.so) never links, loads or calls it.
+ *
+ * Parity pinning (see DESIGN.md "Oracle"): the arithmetic of this path lives in IBM ILOG CPLEX
+ * 22.1.1 (CMakeLists.txt:33 of the reference), which is proprietary and absent, and the
+ * reference has no tests.  The oracle is pinned against (1) the committed run log
+ * log/result_1742185870.978562_DLSCGC_10agents.csv of the reference (known-answer rows copied
+ * as numbers into tests/golden/kat_log.json) and (2) cross-solver vectors produced in the build
+ * container with scipy's bundled HiGHS QP solver (tests/golden/make_golden.py).
+ *
+ * The model is built dense and in the reference's own variable / row order
+ * (populatebyrow, traj_optimizer.cpp:225-527) and solved with a generic method
+ * (Householder null-space elimination of the equalities + Goldfarb-Idnani 1983 dual active-set
+ * with Givens updates), deliberately unlike the structured GPU solver.
+ */
+#ifndef DLSC_ORACLE_H
+#define DLSC_ORACLE_H
+
+#include "../include/dlscqp.h" /* boundary types only (config, agent, lsc_row, status codes) */
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oracle_model {
+    int nv, neq, nin;
+    int n_ctrl;  /* dim*M*(n+1) */
+    int n_slack; /* M*n_slack_obs */
+    int terminal_segments;
+    double *Q;   /* nv*nv, objective x'Qx + c'x + c0 (no 1/2, traj_optimizer.cpp:286-331) */
+    double *c;   /* nv */
+    double c0;
+    double *Aeq; /* neq*nv row-major */
+    double *beq; /* neq */
+    double *Ain; /* nin*nv row-major, rows in the reference's order */
+    double *lo;  /* nin  lo <= Ain x <= hi, +-ORACLE_INF when one-sided */
+    double *hi;  /* nin */
+    double *lb;  /* nv variable bounds */
+    double *ub;  /* nv */
+} oracle_model;
+
+#define ORACLE_INF 1e300
+
+/* traj_optimizer.cpp:172-187 with B from polynomial.hpp:280-293.  Qb is (n+1)*(n+1). */
+void oracle_build_q_base(int n, int phi, int phi_n, double dt, double *Qb);
+/* traj_optimizer.cpp:189-223.  Aeq_base is ((M-2)*phi) x (M*(n+1)) row-major; returns rows. */
+int oracle_build_aeq_base(int M, int n, int phi, double dt, double *Aeq_base);
+/* traj_optimizer.cpp:543-551 with octomap float32 vector semantics. */
+int oracle_terminal_segments(const dlscqp_config *cfg, const dlscqp_agent *ag);
+
+/* populatebyrow, traj_optimizer.cpp:225-527.  Returns NULL on invalid argument. */
+oracle_model *oracle_model_build(const dlscqp_config *cfg, const dlscqp_agent *ag, int n_rows,
+                                 const dlscqp_lsc_row *rows, const float *sfc /*[M][6]|NULL*/);
+void oracle_model_free(oracle_model *m);
+
+/* Generic dense convex QP solve of a model.  x: nv.  Returns a DLSCQP_* verdict. */
+int oracle_qp_solve(const oracle_model *m, double *x, double *obj, int *iters);
+
+/* TrajOptimizer::solve (traj_optimizer.cpp:18-165).  x_f64 (nv) optional. */
+int oracle_traj_solve(const dlscqp_config *cfg, const dlscqp_agent *ag, int n_rows,
+                      const dlscqp_lsc_row *rows, const float *sfc, float *ctrl /*[M][n+1][3]*/,
+                      double *x_f64, double *cost, double *slack_cost /*[n_slack_obs]*/,
+                      int *iters);
+
+/* GoalOptimizer::solve (goal_optimizer.cpp:7-198).  Returns DLSCQP_OK, DLSCQP_GOAL_FALLBACK or
+ * DLSCQP_INFEASIBLE (the reference throws QPFAILED). */
+int oracle_goal_solve(const dlscqp_config *cfg, const dlscqp_agent *ag, int n_rows,
+                      const dlscqp_lsc_row *rows, const float *sfc, float goal_out[3],
+                      double *t_out);
+
+/* Batch drivers used for the CPU baseline timing (agents solved one after another, like
+ * MultiSyncSimulator::plan, multi_sync_simulator.cpp:516-524). */
+int oracle_plan_batch(const dlscqp_config *cfg, int n_agents, const dlscqp_agent *agents,
+                      const int64_t *row_offsets, const dlscqp_lsc_row *rows, const float *sfc,
+                      int max_slack_obs, float *out_goal, int *out_goal_status, float *out_ctrl,
+                      double *out_x, double *out_cost, double *out_slack_cost, int *out_status,
+                      int do_goal);
+
+/* Trajectory<point3d>::getStateAt (trajectory.cpp:110-199) with float32 point3d semantics.
+ * ctrl [M][n+1][3]; state_out = {pos[3], vel[3], acc[3]}. */
+void oracle_state_at(const float *ctrl, int M, int n, double dt, double time, float state_out[9]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

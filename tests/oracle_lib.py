@@ -1,0 +1,161 @@
+"""ctypes access to oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the
+product package (dlsc_gc_planner_amd/).
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from dlsc_gc_planner_amd import abi  # struct layouts of the boundary only
+
+ORACLE_INF = 1e300
+
+
+class OracleModel(C.Structure):
+    _fields_ = [
+        ("nv", C.c_int), ("neq", C.c_int), ("nin", C.c_int), ("n_ctrl", C.c_int),
+        ("n_slack", C.c_int), ("terminal_segments", C.c_int),
+        ("Q", C.POINTER(C.c_double)), ("c", C.POINTER(C.c_double)), ("c0", C.c_double),
+        ("Aeq", C.POINTER(C.c_double)), ("beq", C.POINTER(C.c_double)),
+        ("Ain", C.POINTER(C.c_double)), ("lo", C.POINTER(C.c_double)), ("hi", C.POINTER(C.c_double)),
+        ("lb", C.POINTER(C.c_double)), ("ub", C.POINTER(C.c_double)),
+    ]
+
+
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    src = os.path.join(ROOT, "oracle", "dlsc_oracle.c")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        build()
+    L = C.CDLL(path)
+    vp = C.c_void_p
+    L.oracle_model_build.argtypes = [C.POINTER(abi.Config), vp, C.c_int, vp, vp]
+    L.oracle_model_build.restype = C.POINTER(OracleModel)
+    L.oracle_model_free.argtypes = [C.POINTER(OracleModel)]
+    L.oracle_qp_solve.argtypes = [C.POINTER(OracleModel), vp, vp, vp]
+    L.oracle_qp_solve.restype = C.c_int
+    L.oracle_traj_solve.argtypes = [C.POINTER(abi.Config), vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    L.oracle_traj_solve.restype = C.c_int
+    L.oracle_goal_solve.argtypes = [C.POINTER(abi.Config), vp, C.c_int, vp, vp, vp, vp]
+    L.oracle_goal_solve.restype = C.c_int
+    L.oracle_plan_batch.argtypes = [C.POINTER(abi.Config), C.c_int, vp, vp, vp, vp, C.c_int,
+                                    vp, vp, vp, vp, vp, vp, vp, C.c_int]
+    L.oracle_plan_batch.restype = C.c_int
+    L.oracle_state_at.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_double, vp]
+    L.oracle_terminal_segments.argtypes = [C.POINTER(abi.Config), vp]
+    L.oracle_terminal_segments.restype = C.c_int
+    L.oracle_build_q_base.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, vp]
+    L.oracle_build_aeq_base.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, vp]
+    L.oracle_build_aeq_base.restype = C.c_int
+    _LIB = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def model_dense(cfg, agent, rows, sfc=None):
+    """Dense model of one agent as numpy arrays (copied out of the C struct)."""
+    L = lib()
+    agent = np.ascontiguousarray(agent, dtype=abi.AGENT_DTYPE).reshape(1)
+    rows = np.ascontiguousarray(rows, dtype=abi.ROW_DTYPE)
+    sfc = None if sfc is None else np.ascontiguousarray(sfc, dtype=np.float32)
+    mp = L.oracle_model_build(C.byref(cfg), _ptr(agent), len(rows), _ptr(rows), _ptr(sfc))
+    if not mp:
+        raise ValueError("oracle_model_build: invalid argument")
+    m = mp.contents
+    nv, neq, nin = m.nv, m.neq, m.nin
+
+    def arr(p, *shape):
+        n = int(np.prod(shape)) if shape else 1
+        if n == 0:
+            return np.zeros(shape)
+        return np.ctypeslib.as_array(p, shape=(n,)).reshape(shape).copy()
+
+    out = dict(nv=nv, neq=neq, nin=nin, n_ctrl=m.n_ctrl, n_slack=m.n_slack,
+               terminal_segments=m.terminal_segments,
+               Q=arr(m.Q, nv, nv), c=arr(m.c, nv), c0=m.c0, Aeq=arr(m.Aeq, neq, nv), beq=arr(m.beq, neq),
+               Ain=arr(m.Ain, nin, nv), lo=arr(m.lo, nin), hi=arr(m.hi, nin), lb=arr(m.lb, nv), ub=arr(m.ub, nv))
+    L.oracle_model_free(mp)
+    return out
+
+
+def traj_solve(cfg, agent, rows, sfc=None):
+    L = lib()
+    agent = np.ascontiguousarray(agent, dtype=abi.AGENT_DTYPE).reshape(1)
+    rows = np.ascontiguousarray(rows, dtype=abi.ROW_DTYPE)
+    sfc = None if sfc is None else np.ascontiguousarray(sfc, dtype=np.float32)
+    M, n, dim = cfg.M, cfg.n, cfg.world_dimension
+    nso = int(agent["n_slack_obs"][0])
+    ctrl = np.zeros((M, n + 1, 3), np.float32)
+    x = np.zeros(dim * M * (n + 1) + M * nso)
+    cost = np.zeros(1)
+    slack = np.zeros(max(nso, 1))
+    iters = np.zeros(1, np.int32)
+    st = L.oracle_traj_solve(C.byref(cfg), _ptr(agent), len(rows), _ptr(rows), _ptr(sfc), _ptr(ctrl),
+                             _ptr(x), _ptr(cost), _ptr(slack), _ptr(iters))
+    return dict(status=st, ctrl=ctrl, x=x, cost=float(cost[0]), slack_cost=slack[:nso], iters=int(iters[0]))
+
+
+def goal_solve(cfg, agent, rows, sfc=None):
+    L = lib()
+    agent = np.ascontiguousarray(agent, dtype=abi.AGENT_DTYPE).reshape(1)
+    rows = np.ascontiguousarray(rows, dtype=abi.ROW_DTYPE)
+    sfc = None if sfc is None else np.ascontiguousarray(sfc, dtype=np.float32)
+    g = np.zeros(3, np.float32)
+    t = np.zeros(1)
+    st = L.oracle_goal_solve(C.byref(cfg), _ptr(agent), len(rows), _ptr(rows), _ptr(sfc), _ptr(g), _ptr(t))
+    return dict(status=st, goal=g, t=float(t[0]))
+
+
+def plan_batch(cfg, agents, row_offsets, rows, sfc=None, max_slack_obs=0, do_goal=True):
+    """oracle_plan_batch: sequential per-agent goal LP + trajectory QP."""
+    L = lib()
+    agents = np.ascontiguousarray(agents, dtype=abi.AGENT_DTYPE)
+    rows = np.ascontiguousarray(rows, dtype=abi.ROW_DTYPE)
+    row_offsets = np.ascontiguousarray(row_offsets, dtype=np.int64)
+    sfc = None if sfc is None else np.ascontiguousarray(sfc, dtype=np.float32)
+    N = len(agents)
+    M, n, dim = cfg.M, cfg.n, cfg.world_dimension
+    nx = dim * M * (n + 1) + M * max_slack_obs
+    out = dict(goal=np.zeros((N, 3), np.float32), goal_status=np.zeros(N, np.int32),
+               ctrl=np.zeros((N, M, n + 1, 3), np.float32), x=np.zeros((N, nx)), cost=np.zeros(N),
+               slack_cost=np.zeros((N, max(max_slack_obs, 1))), status=np.zeros(N, np.int32))
+    L.oracle_plan_batch(C.byref(cfg), N, _ptr(agents), _ptr(row_offsets), _ptr(rows), _ptr(sfc),
+                        max_slack_obs, _ptr(out["goal"]), _ptr(out["goal_status"]), _ptr(out["ctrl"]),
+                        _ptr(out["x"]), _ptr(out["cost"]), _ptr(out["slack_cost"]), _ptr(out["status"]),
+                        1 if do_goal else 0)
+    return out
+
+
+def state_at(ctrl, dt, time):
+    L = lib()
+    ctrl = np.ascontiguousarray(ctrl, dtype=np.float32)
+    M, n1 = ctrl.shape[0], ctrl.shape[1]
+    out = np.zeros(9, np.float32)
+    L.oracle_state_at(_ptr(ctrl), M, n1 - 1, float(dt), float(time), _ptr(out))
+    return out.reshape(3, 3)
+
+
+def terminal_segments(cfg, agent):
+    agent = np.ascontiguousarray(agent, dtype=abi.AGENT_DTYPE).reshape(1)
+    return lib().oracle_terminal_segments(C.byref(cfg), _ptr(agent))
