@@ -1,0 +1,24 @@
+// qp_tables.hpp -- host-side precomputation shared by every agent (see qp_tables.cpp).
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/dlscqp.h"
+#include "qp_types.hpp"
+
+namespace dlscqp {
+
+struct HostTables {
+    KParams kp;                  // table pointers left null; the owner fills them in
+    std::vector<double> tabN;    // [M][P][f]
+    std::vector<double> tabX0s;  // [M][P][3]
+    std::vector<double> tabX0g;  // [M][P]
+    std::vector<Slot> slots;
+};
+
+// dim/M/n/phi/dt are passed separately: TrajOptimizer caches them at construction and
+// updateParam does not refresh them (traj_optimizer.cpp:7-11, 167-169).
+bool build_tables(const dlscqp_config &cfg, int dim, int M, int n, int phi, double dt, HostTables &out,
+                  std::string &err);
+
+}  // namespace dlscqp

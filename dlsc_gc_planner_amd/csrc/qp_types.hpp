@@ -1,0 +1,65 @@
+// qp_types.hpp -- plain data shared by the host table builder and the solver kernel.
+//
+// Layout of the per-agent problem after the host-side elimination:
+//   control points of axis k:  x_k = X0s_T [pos_k vel_k acc_k]' + X0g_T goal_k + N_T w_k
+//   where N_T = Z L_T^{-T} "whitens" the reduced Hessian (objective = 1/2 |w - 0|^2 + const in
+//   w-space) for the agent's number of terminal segments T (traj_optimizer.cpp:543-551).
+#pragma once
+#include <stdint.h>
+
+namespace dlscqp {
+
+enum SlotKind : uint8_t { SLOT_BOUND = 0, SLOT_VEL = 1, SLOT_ACC = 2, SLOT_COMM = 3, SLOT_WAYPOINT = 4 };
+
+// One two-sided structured row  lo[bsel] <= sum_t coef[t] * x[idx[t]] <= hi[bsel]  whose pattern is
+// identical for every agent: variable bounds / SFC box faces (traj_optimizer.cpp:237-270,
+// 385-410), dynamic limits (:453-487) and communication range (:490-513), scaled to metres.
+struct Slot {
+    int16_t idx[3];  // x-space indices k*P + m*(n+1) + i, -1 = unused
+    int8_t coef[3];
+    uint8_t kind;
+    uint16_t bsel;   // index into the per-agent bound table
+    float scale;     // factor back to the reference's row scaling (n/dt, n(n-1)/dt^2, 1)
+};
+static_assert(sizeof(Slot) == 16, "Slot layout");
+
+struct KParams {
+    // dimensions
+    int dim, M, n1, P, f, phi;
+    int n_slots;   // two-sided structured rows
+    int nb;        // entries of the per-agent bound table
+    int has_comm, use_sfc, stop_mode, rsfc_mode;
+    int max_iter;
+    // weights and constants (param.hpp)
+    double dt;
+    double w_c, w_t, w_s;
+    double comm_range;
+    double z_2d;
+    double world_min[3], world_max[3];
+    double vel_scale, acc_scale;  // dt/n, dt^2/(n(n-1))
+    double Qb[36];                // control_input_weight * Q_base (traj_optimizer.cpp:172-187)
+    double sigma[32];             // slack whitening 1/sqrt(2 w_s (M-m)/M), m < M <= 32
+    int t_valid[32];              // reduced Hessian positive definite for T = idx+1
+    // device (or host, in the emulation build) tables
+    const double *tabN;           // [M][P][f]
+    const double *tabX0s;         // [M][P][3]
+    const double *tabX0g;         // [M][P]
+    const Slot *slots;            // [n_slots]
+};
+
+// Tolerances.  VIOL_TOL: a row violated by less than this many metres counts as satisfied.
+// CPLEX_FEAS_TOL: CPLEX 22.1.1 default feasibility tolerance in the reference's own row scaling;
+// a row that cannot be satisfied but is violated by no more than this is accepted, as CPLEX would.
+constexpr double VIOL_TOL = 1e-9;
+constexpr double CPLEX_FEAS_TOL = 1e-6;
+constexpr double DEP_TOL = 1e-20;  // ||d2||^2 <= DEP_TOL ||d||^2  -> normal depends on the active set
+constexpr double SP_EPSILON = 1e-9;        // sp_const.hpp:3
+constexpr double SP_EPSILON_FLOAT = 1e-5;  // sp_const.hpp:4
+
+struct RowsView {  // structure-of-arrays LSC rows of the whole batch (include/dlscqp.h)
+    const float *nx, *ny, *nz, *px, *py, *pz;
+    const double *d;
+    const uint32_t *key;
+};
+
+}  // namespace dlscqp

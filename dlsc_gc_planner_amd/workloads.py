@@ -194,8 +194,8 @@ def _neighbours(pos, J, group):
     return out
 
 
-def generate(cfg, solver, n_swarms=1, swarm_size=64, seed=2000, steps=4, infeasible_frac=0.05,
-             waypoint_ahead=1.5):
+def generate(cfg, solver, n_swarms=1, swarm_size=64, seed=2000, steps=6, infeasible_frac=0.05,
+             waypoint_ahead=5.0):
     """Closed-loop synthetic workload: `n_swarms` independent swarms of `swarm_size` agents.
 
     solver(agents, row_offsets, rows, sfc) -> dict(goal [N,3] f32, ctrl [N,M,6,3] f32,
@@ -234,6 +234,7 @@ def generate(cfg, solver, n_swarms=1, swarm_size=64, seed=2000, steps=4, infeasi
     J = 5 if swarm_size > 5 else max(swarm_size - 1, 1)
     seg_sel = [list(range(M))] * min(J, 4) + ([[M - 2, M - 1]] if J == 5 else [])
     out = None
+    lp_failed = np.zeros(N, bool)
     for step in range(steps + 1):
         init = plan if step == 0 else _shift_plan(plan)
         neigh = _neighbours(pos, J, swarm_size)
@@ -241,6 +242,9 @@ def generate(cfg, solver, n_swarms=1, swarm_size=64, seed=2000, steps=4, infeasi
         dist = np.linalg.norm(to_goal, axis=1)
         ahead = np.minimum(dist, waypoint_ahead)
         wp = (pos + to_goal / np.maximum(dist, 1e-9)[:, None] * ahead[:, None]).astype(np.float32)
+        # an agent whose goal LP was infeasible keeps its sub-goal for one step (in the reference the
+        # grid planner hands out conflict-free waypoints, multi_sync_simulator.cpp:308-466)
+        wp = np.where(lp_failed[:, None], cur_goal, wp).astype(np.float32)
         row_offsets, rows = build_rows(cfg, pos, init, cur_goal, radius, neigh, seg_sel)
         agents = np.zeros(N, abi.AGENT_DTYPE)
         agents["position"], agents["velocity"], agents["acceleration"] = pos, vel, acc
@@ -255,6 +259,7 @@ def generate(cfg, solver, n_swarms=1, swarm_size=64, seed=2000, steps=4, infeasi
         res = solver(agents, row_offsets, rows, None)
         ok = (res["status"] == abi.OK)
         gok = (res["goal_status"] != abi.INFEASIBLE)
+        lp_failed = ~gok
         cur_goal = np.where(gok[:, None], res["goal"], cur_goal).astype(np.float32)
         new_plan = np.where(ok[:, None, None, None], res["ctrl"], init)  # failsafe: traj_planner.cpp:776
         plan = new_plan.astype(np.float32)

@@ -773,12 +773,12 @@ int oracle_goal_solve(const dlscqp_config *cfg, const dlscqp_agent *ag, int n_ro
     int infeasible = 0;
     float diff[3];
     for (int k = 0; k < 3; k++) diff[k] = cg[k] - wp[k]; /* float32, as point3d(k) - point3d(k) */
-#define LP_ROW(a_, b_)                                                  \
-    do {                                                                \
-        double a = (a_), b = (b_);                                      \
-        if (a > 0) { if (-b / a > t_lo) t_lo = -b / a; }                \
-        else if (a < 0) { if (-b / a < t_hi) t_hi = -b / a; }           \
-        else if (b < -CPLEX_FEAS_TOL) infeasible = 1;                   \
+#define LP_ROW(a_, b_)                                                          \
+    do {                                                                        \
+        double lp_a = (a_), lp_b = (b_);                                        \
+        if (lp_a > 0) { if (-lp_b / lp_a > t_lo) t_lo = -lp_b / lp_a; }         \
+        else if (lp_a < 0) { if (-lp_b / lp_a < t_hi) t_hi = -lp_b / lp_a; }    \
+        else if (lp_b < -CPLEX_FEAS_TOL) infeasible = 1;                        \
     } while (0)
     /* SFC rows, :158-173 */
     if (cfg->world_use_octomap && sfc) {

@@ -1,0 +1,124 @@
+// emul.cpp -- TEST INFRASTRUCTURE: lane-serial host build of the solver kernel's source.
+//
+// Compiles dlsc_gc_planner_amd/csrc/gi_core.hpp (the code the gfx950 kernel runs) with a "wave"
+// whose lanes are executed one after another on the CPU, so that the CPU-only test tier
+// (pytest -m "not gpu", no GPU in the build container) can check the algorithm and the host
+// tables against the oracle.  The product library never loads, links or falls back to this.
+// EMUL_REVERSE=1 runs every lane loop backwards: results must not change (no cross-lane hazard
+// inside a lane loop).
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define DQ_FN inline
+#include "../../dlsc_gc_planner_amd/csrc/gi_core.hpp"
+#include "../../dlsc_gc_planner_amd/csrc/qp_tables.hpp"
+
+namespace {
+
+struct WaveCpu {
+    bool reverse;
+    template <class F>
+    void lane_loop(int n, F f) const {
+        if (!reverse)
+            for (int j = 0; j < n; j++) f(j);
+        else
+            for (int j = n - 1; j >= 0; j--) f(j);
+    }
+    void sync() const {}
+    template <class F>
+    double sum(int n, F f) const {
+        double s = 0;
+        for (int j = 0; j < n; j++) s += f(j);
+        return s;
+    }
+    template <class F>
+    double max(int n, F f) const {
+        double s = -1e300;
+        for (int j = 0; j < n; j++) { double v = f(j); if (v > s) s = v; }
+        return s;
+    }
+    template <class F>
+    double min(int n, F f) const {
+        double s = 1e300;
+        for (int j = 0; j < n; j++) { double v = f(j); if (v < s) s = v; }
+        return s;
+    }
+    template <class F>
+    dlscqp::Cand argmax(int n, F f) const {
+        dlscqp::Cand b{-1e300, -1};
+        for (int j = 0; j < n; j++) { dlscqp::Cand c = f(j); if (c.v > b.v) b = c; }
+        return b;
+    }
+    template <class F>
+    dlscqp::Cand argmin(int n, F f) const {
+        dlscqp::Cand b{1e300, -1};
+        for (int j = 0; j < n; j++) { dlscqp::Cand c = f(j); if (c.v < b.v) b = c; }
+        return b;
+    }
+};
+
+}  // namespace
+
+extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dlscqp_agent *agents,
+                               const int64_t *row_offsets, const dlscqp_lsc_row *rows, const float *sfc,
+                               int max_slack_obs, int do_goal, int do_traj, float *out_goal,
+                               int *out_goal_status, float *out_ctrl, double *out_x, double *out_cost,
+                               double *out_slack_cost, int *out_status, int *out_iters) {
+    using namespace dlscqp;
+    HostTables tb;
+    std::string err;
+    if (!build_tables(*cfg, cfg->world_dimension, cfg->M, cfg->n, cfg->phi, cfg->dt, tb, err)) return -1;
+    KParams kp = tb.kp;
+    kp.tabN = tb.tabN.data();
+    kp.tabX0s = tb.tabX0s.data();
+    kp.tabX0g = tb.tabX0g.data();
+    kp.slots = tb.slots.data();
+    const int64_t nrows = row_offsets[n_agents];
+    std::vector<float> nx(nrows + 1), ny(nrows + 1), nz(nrows + 1), px(nrows + 1), py(nrows + 1), pz(nrows + 1);
+    std::vector<double> d(nrows + 1);
+    std::vector<uint32_t> key(nrows + 1);
+    int kmax = 0;
+    for (int a = 0; a < n_agents; a++) kmax = std::max<int>(kmax, (int)(row_offsets[a + 1] - row_offsets[a]));
+    for (int64_t i = 0; i < nrows; i++) {
+        nx[i] = rows[i].normal[0]; ny[i] = rows[i].normal[1]; nz[i] = rows[i].normal[2];
+        px[i] = rows[i].point[0]; py[i] = rows[i].point[1]; pz[i] = rows[i].point[2];
+        d[i] = rows[i].d;
+        key[i] = DLSCQP_KEY(rows[i].m, rows[i].i, rows[i].slack, rows[i].flags & DLSCQP_ROW_DYNAMIC);
+    }
+    RowsView rv{nx.data(), ny.data(), nz.data(), px.data(), py.data(), pz.data(), d.data(), key.data()};
+    MemLayout lay = make_layout(kp, max_slack_obs, kmax);
+    std::vector<unsigned char> mem(lay.bytes + 64);
+    WaveCpu w;
+    const char *rev = std::getenv("EMUL_REVERSE");
+    w.reverse = rev && rev[0] == '1';
+    const int M = cfg->M, n1 = cfg->n + 1, dim = cfg->world_dimension;
+    const size_t xs = (size_t)dim * M * n1 + (size_t)M * max_slack_obs;
+    for (int a = 0; a < n_agents; a++) {
+        std::memset(mem.data(), 0xCD, mem.size());  // poison: nothing may rely on zero-initialised LDS
+        plan_agent(w, kp, lay, mem.data(), agents + a, rv, (int)row_offsets[a],
+                   (int)(row_offsets[a + 1] - row_offsets[a]), sfc ? sfc + (size_t)a * M * 6 : nullptr,
+                   max_slack_obs, do_goal, do_traj, out_goal ? out_goal + (size_t)a * 3 : nullptr,
+                   out_goal_status ? out_goal_status + a : nullptr,
+                   out_ctrl ? out_ctrl + (size_t)a * M * n1 * 3 : nullptr, out_x ? out_x + a * xs : nullptr,
+                   out_cost ? out_cost + a : nullptr,
+                   out_slack_cost ? out_slack_cost + (size_t)a * max_slack_obs : nullptr,
+                   out_status ? out_status + a : nullptr, out_iters ? out_iters + (size_t)a * 4 : nullptr);
+    }
+    return 0;
+}
+
+// Host tables for inspection by the tests: returns f (free dofs per axis), fills sizes.
+extern "C" int emul_table_info(const dlscqp_config *cfg, int *f, int *n_slots, int *nb, int *lds_bytes,
+                               int max_slack_obs, int kmax) {
+    using namespace dlscqp;
+    HostTables tb;
+    std::string err;
+    if (!build_tables(*cfg, cfg->world_dimension, cfg->M, cfg->n, cfg->phi, cfg->dt, tb, err)) return -1;
+    *f = tb.kp.f;
+    *n_slots = tb.kp.n_slots;
+    *nb = tb.kp.nb;
+    *lds_bytes = make_layout(tb.kp, max_slack_obs, kmax).bytes;
+    return 0;
+}
