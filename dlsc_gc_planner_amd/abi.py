@@ -92,6 +92,8 @@ class DeviceBatch(C.Structure):
         ("max_slack_obs", C.c_int32),
         ("do_goal", C.c_int32),
         ("do_traj", C.c_int32),
+        ("max_rows_per_agent", C.c_int32),
+        ("reserved_", C.c_int32),
         ("agents", C.c_void_p),
         ("row_offsets", C.c_void_p),
         ("nx", C.c_void_p),
@@ -189,7 +191,7 @@ def load_library():
     lib.dlscqp_update_param.restype = C.c_int
     lib.dlscqp_last_error.argtypes = []
     lib.dlscqp_last_error.restype = C.c_char_p
-    lib.dlscqp_lds_bytes.argtypes = [C.c_void_p, C.c_int]
+    lib.dlscqp_lds_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.dlscqp_lds_bytes.restype = C.c_int64
     vp = C.c_void_p
     lib.dlscqp_solve_batch.argtypes = [vp, C.c_int32, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp]
@@ -202,10 +204,10 @@ def load_library():
     lib.dlscqp_plan_batch_device.restype = C.c_int
     lib.dlscqp_rows_to_soa.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.dlscqp_rows_to_soa.restype = None
-    lib.dlscqp_set_timing.argtypes = [vp, C.c_int]
+    lib.dlscqp_set_timing.argtypes = [vp, C.c_int32]
     lib.dlscqp_set_timing.restype = C.c_int
-    lib.dlscqp_last_kernel_ms.argtypes = [vp, P(C.c_float)]
-    lib.dlscqp_last_kernel_ms.restype = C.c_int
+    lib.dlscqp_get_kernel_times.argtypes = [vp, vp, C.c_int32, P(C.c_int32)]
+    lib.dlscqp_get_kernel_times.restype = C.c_int
     _LIB = lib
     return lib
 
@@ -214,5 +216,5 @@ EXPORTED_SYMBOLS = [
     "dlscqp_create", "dlscqp_destroy", "dlscqp_update_param", "dlscqp_last_error",
     "dlscqp_lds_bytes", "dlscqp_solve_batch", "dlscqp_goal_batch", "dlscqp_plan_batch",
     "dlscqp_plan_batch_device", "dlscqp_rows_to_soa", "dlscqp_set_timing",
-    "dlscqp_last_kernel_ms",
+    "dlscqp_get_kernel_times",
 ]

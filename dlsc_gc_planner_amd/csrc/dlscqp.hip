@@ -1,0 +1,509 @@
+// dlscqp.hip -- gfx950 kernel + C ABI (include/dlscqp.h) of the batched DLSC-GC trajectory optimizer.
+//
+// One agent per wavefront (64 lanes), one wavefront per workgroup; the agent's working set
+// (orthogonal factor Q, packed R, whitening map N_T, control points, bound table, row flags) is in
+// LDS, the stacked LSC rows are read from HBM in structure-of-arrays form (64 consecutive rows per
+// load instruction), reductions are DPP/shuffle butterflies.  The algorithm itself is in
+// gi_core.hpp; this file supplies the wave primitives, the launch and the host marshalling.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#define DQ_FN __host__ __device__ __forceinline__
+#include "gi_core.hpp"
+#include "qp_tables.hpp"
+
+using namespace dlscqp;
+
+// ---------------------------------------------------------------------------------------------
+// wave primitives
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ double uniform_f64(double v) {
+    // the butterflies below leave the same value in every lane; tell the compiler so that the
+    // control flow that depends on it is scalar
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+struct WaveGpu {
+    int lane;
+    template <class F>
+    __device__ __forceinline__ void lane_loop(int n, F f) const {
+        for (int j = lane; j < n; j += 64) f(j);
+    }
+    __device__ __forceinline__ void sync() const {
+#ifdef DLSCQP_SAFE_SYNC
+        __syncthreads();
+#else
+        // one wavefront per agent: LDS instructions of a wave execute in order, so only the
+        // compiler has to be kept from moving LDS accesses across this point
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+    }
+    template <class F>
+    __device__ __forceinline__ double sum(int n, F f) const {
+        double s = 0;
+        for (int j = lane; j < n; j += 64) s += f(j);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        return uniform_f64(s);
+    }
+    template <class F>
+    __device__ __forceinline__ double max(int n, F f) const {
+        double s = -1e300;
+        for (int j = lane; j < n; j += 64) s = fmax(s, f(j));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_xor(s, o, 64));
+        return uniform_f64(s);
+    }
+    template <class F>
+    __device__ __forceinline__ double min(int n, F f) const {
+        double s = 1e300;
+        for (int j = lane; j < n; j += 64) s = fmin(s, f(j));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s = fmin(s, __shfl_xor(s, o, 64));
+        return uniform_f64(s);
+    }
+    template <class F>
+    __device__ __forceinline__ Cand argmax(int n, F f) const {
+        Cand b{-1e300, -1};
+        for (int j = lane; j < n; j += 64) {
+            Cand c = f(j);
+            if (c.v > b.v) b = c;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            double ov = __shfl_xor(b.v, o, 64);
+            int oc = __shfl_xor(b.code, o, 64);
+            // ties: the smaller code wins, whatever the lane (same answer in every lane)
+            if (ov > b.v || (ov == b.v && (unsigned)oc < (unsigned)b.code)) { b.v = ov; b.code = oc; }
+        }
+        b.v = uniform_f64(b.v);
+        b.code = __builtin_amdgcn_readfirstlane(b.code);
+        return b;
+    }
+    template <class F>
+    __device__ __forceinline__ Cand argmin(int n, F f) const {
+        Cand b{1e300, -1};
+        for (int j = lane; j < n; j += 64) {
+            Cand c = f(j);
+            if (c.v < b.v) b = c;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            double ov = __shfl_xor(b.v, o, 64);
+            int oc = __shfl_xor(b.code, o, 64);
+            if (ov < b.v || (ov == b.v && (unsigned)oc < (unsigned)b.code)) { b.v = ov; b.code = oc; }
+        }
+        b.v = uniform_f64(b.v);
+        b.code = __builtin_amdgcn_readfirstlane(b.code);
+        return b;
+    }
+};
+
+struct KernelArgs {
+    int n_agents, max_slack_obs, do_goal, do_traj;
+    const dlscqp_agent *agents;
+    const int32_t *row_offsets;
+    RowsView rows;
+    const float *sfc;
+    float *out_goal;
+    int32_t *out_goal_status;
+    float *out_ctrl;
+    double *out_x;
+    double *out_cost;
+    double *out_slack_cost;
+    int32_t *out_status;
+    int32_t *out_iters;
+};
+
+__global__ __launch_bounds__(64) void dlscqp_plan_kernel(KParams kp, MemLayout lay, KernelArgs a) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int ag = blockIdx.x;
+    if (ag >= a.n_agents) return;
+    WaveGpu w{(int)threadIdx.x};
+    const int rb = a.row_offsets[ag], re = a.row_offsets[ag + 1];
+    const int M = kp.M, n1 = kp.n1;
+    const size_t xs = (size_t)kp.dim * M * n1 + (size_t)M * a.max_slack_obs;
+    plan_agent(w, kp, lay, smem, a.agents + ag, a.rows, rb, re - rb,
+               a.sfc ? a.sfc + (size_t)ag * M * 6 : nullptr, a.max_slack_obs, a.do_goal, a.do_traj,
+               a.out_goal ? a.out_goal + (size_t)ag * 3 : nullptr,
+               a.out_goal_status ? a.out_goal_status + ag : nullptr,
+               a.out_ctrl ? a.out_ctrl + (size_t)ag * M * n1 * 3 : nullptr,
+               a.out_x ? a.out_x + ag * xs : nullptr, a.out_cost ? a.out_cost + ag : nullptr,
+               a.out_slack_cost ? a.out_slack_cost + (size_t)ag * a.max_slack_obs : nullptr,
+               a.out_status ? a.out_status + ag : nullptr,
+               a.out_iters ? a.out_iters + (size_t)ag * 4 : nullptr);
+}
+
+thread_local std::string g_last_error;
+
+bool hip_ok(hipError_t e, const char *what) {
+    if (e == hipSuccess) return true;
+    g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+#define HIP_TRY(expr)                              \
+    do {                                           \
+        if (!hip_ok((expr), #expr)) return DLSCQP_ERR_HIP; \
+    } while (0)
+
+constexpr int64_t LDS_LIMIT = 160 * 1024;
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+struct dlscqp_ctx {
+    dlscqp_config cfg;
+    int dim, M, n, phi;  // cached at construction like TrajOptimizer (traj_optimizer.cpp:7-11)
+    double dt;
+    HostTables tb;
+    KParams kp;  // with device table pointers
+    double *d_tabN = nullptr, *d_tabX0s = nullptr, *d_tabX0g = nullptr;
+    Slot *d_slots = nullptr;
+    hipStream_t stream = nullptr;
+    int max_dyn_lds = 0;
+    // staging for the host-buffer entry points
+    unsigned char *h_stage = nullptr, *d_stage = nullptr;
+    size_t stage_cap = 0;
+    // event pairs for kernel timing
+    std::vector<hipEvent_t> ev0, ev1;
+    int ev_used = 0;
+};
+
+static int upload_tables(dlscqp_ctx *c) {
+    auto up = [&](void **dptr, const void *src, size_t bytes) -> bool {
+        if (*dptr) { (void)hipFree(*dptr); *dptr = nullptr; }
+        if (!hip_ok(hipMalloc(dptr, std::max<size_t>(bytes, 16)), "hipMalloc(tables)")) return false;
+        return hip_ok(hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice), "hipMemcpy(tables)");
+    };
+    if (!up((void **)&c->d_tabN, c->tb.tabN.data(), c->tb.tabN.size() * 8)) return DLSCQP_ERR_HIP;
+    if (!up((void **)&c->d_tabX0s, c->tb.tabX0s.data(), c->tb.tabX0s.size() * 8)) return DLSCQP_ERR_HIP;
+    if (!up((void **)&c->d_tabX0g, c->tb.tabX0g.data(), c->tb.tabX0g.size() * 8)) return DLSCQP_ERR_HIP;
+    if (!up((void **)&c->d_slots, c->tb.slots.data(), c->tb.slots.size() * sizeof(Slot))) return DLSCQP_ERR_HIP;
+    c->kp = c->tb.kp;
+    c->kp.tabN = c->d_tabN;
+    c->kp.tabX0s = c->d_tabX0s;
+    c->kp.tabX0g = c->d_tabX0g;
+    c->kp.slots = c->d_slots;
+    return DLSCQP_SUCCESS;
+}
+
+extern "C" const char *dlscqp_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int dlscqp_create(const dlscqp_config *cfg, dlscqp_ctx **out_ctx) {
+    g_last_error.clear();
+    if (!cfg || !out_ctx) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (cfg->abi_version != DLSCQP_ABI_VERSION) { g_last_error = "abi_version mismatch"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        g_last_error = "no HIP device: the trajectory optimizer has no CPU path";
+        return DLSCQP_ERR_NO_DEVICE;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_last_error = "device ordinal out of range"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    dlscqp_ctx *c = new dlscqp_ctx();
+    c->cfg = *cfg;
+    c->dim = cfg->world_dimension; c->M = cfg->M; c->n = cfg->n; c->phi = cfg->phi; c->dt = cfg->dt;
+    std::string err;
+    if (!build_tables(*cfg, c->dim, c->M, c->n, c->phi, c->dt, c->tb, err)) {
+        g_last_error = "[TrajOptimizer] " + err;
+        delete c;
+        return DLSCQP_ERR_INVALID_ARGUMENT;
+    }
+    if (hipSetDevice(cfg->device) != hipSuccess) { g_last_error = "hipSetDevice failed"; delete c; return DLSCQP_ERR_HIP; }
+    if (!hip_ok(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return DLSCQP_ERR_HIP; }
+    int rc = upload_tables(c);
+    if (rc != DLSCQP_SUCCESS) { dlscqp_destroy(c); return rc; }
+    *out_ctx = c;
+    return DLSCQP_SUCCESS;
+}
+
+extern "C" void dlscqp_destroy(dlscqp_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto e : c->ev0) (void)hipEventDestroy(e);
+    for (auto e : c->ev1) (void)hipEventDestroy(e);
+    if (c->d_tabN) (void)hipFree(c->d_tabN);
+    if (c->d_tabX0s) (void)hipFree(c->d_tabX0s);
+    if (c->d_tabX0g) (void)hipFree(c->d_tabX0g);
+    if (c->d_slots) (void)hipFree(c->d_slots);
+    if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int dlscqp_update_param(dlscqp_ctx *c, const dlscqp_config *cfg) {
+    g_last_error.clear();
+    if (!c || !cfg) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    // TrajOptimizer::updateParam replaces param but keeps the cached dim/M/n/phi/dt
+    // (traj_optimizer.cpp:167-169 vs :7-11)
+    dlscqp_config merged = *cfg;
+    merged.device = c->cfg.device;
+    HostTables tb;
+    std::string err;
+    if (!build_tables(merged, c->dim, c->M, c->n, c->phi, c->dt, tb, err)) {
+        g_last_error = "[TrajOptimizer] " + err;
+        return DLSCQP_ERR_INVALID_ARGUMENT;
+    }
+    (void)hipSetDevice(c->cfg.device);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->cfg = merged;
+    c->tb = std::move(tb);
+    return upload_tables(c);
+}
+
+extern "C" int64_t dlscqp_lds_bytes(const dlscqp_ctx *c, int32_t max_slack_obs, int32_t max_rows_per_agent) {
+    if (!c) return -1;
+    return make_layout(c->tb.kp, max_slack_obs, max_rows_per_agent).bytes;
+}
+
+extern "C" int dlscqp_set_timing(dlscqp_ctx *c, int32_t capacity) {
+    g_last_error.clear();
+    if (!c || capacity < 0) return DLSCQP_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->cfg.device);
+    while ((int)c->ev0.size() < capacity) {
+        hipEvent_t a, b;
+        HIP_TRY(hipEventCreate(&a));
+        HIP_TRY(hipEventCreate(&b));
+        c->ev0.push_back(a);
+        c->ev1.push_back(b);
+    }
+    while ((int)c->ev0.size() > capacity) {
+        (void)hipEventDestroy(c->ev0.back());
+        (void)hipEventDestroy(c->ev1.back());
+        c->ev0.pop_back();
+        c->ev1.pop_back();
+    }
+    c->ev_used = 0;
+    return DLSCQP_SUCCESS;
+}
+
+extern "C" int dlscqp_get_kernel_times(dlscqp_ctx *c, float *ms_out, int32_t capacity, int32_t *n_out) {
+    g_last_error.clear();
+    if (!c || !n_out) return DLSCQP_ERR_INVALID_ARGUMENT;
+    (void)hipSetDevice(c->cfg.device);
+    int n = std::min<int>(c->ev_used, capacity);
+    for (int i = 0; i < n; i++) {
+        HIP_TRY(hipEventSynchronize(c->ev1[i]));
+        HIP_TRY(hipEventElapsedTime(&ms_out[i], c->ev0[i], c->ev1[i]));
+    }
+    *n_out = n;
+    return DLSCQP_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------------
+// launch
+// ---------------------------------------------------------------------------------------------
+static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t stream) {
+    if (b->n_agents <= 0) return DLSCQP_SUCCESS;
+    if (b->max_slack_obs < 0 || b->max_rows_per_agent < 0) { g_last_error = "negative size"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    MemLayout lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent);
+    if (lay.bytes > LDS_LIMIT) {
+        char msg[256];
+        snprintf(msg, sizeof msg,
+                 "agent working set %d B exceeds the 160 KiB LDS of a gfx950 CU (dim %d, M %d, %d slack obstacles)",
+                 lay.bytes, c->dim, c->M, b->max_slack_obs);
+        g_last_error = msg;
+        return DLSCQP_ERR_UNSUPPORTED;
+    }
+    if (lay.bytes > c->max_dyn_lds) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(dlscqp_plan_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
+        c->max_dyn_lds = lay.bytes;
+    }
+    KernelArgs a;
+    a.n_agents = b->n_agents;
+    a.max_slack_obs = b->max_slack_obs;
+    a.do_goal = b->do_goal;
+    a.do_traj = b->do_traj;
+    a.agents = b->agents;
+    a.row_offsets = b->row_offsets;
+    a.rows = RowsView{b->nx, b->ny, b->nz, b->px, b->py, b->pz, b->d, b->key};
+    a.sfc = c->kp.use_sfc ? b->sfc_boxes : nullptr;
+    a.out_goal = b->out_goal;
+    a.out_goal_status = b->out_goal_status;
+    a.out_ctrl = b->out_ctrl;
+    a.out_x = b->out_ctrl_f64;
+    a.out_cost = b->out_cost;
+    a.out_slack_cost = b->out_slack_cost;
+    a.out_status = b->out_status;
+    a.out_iters = b->out_iters;
+    const bool timed = c->ev_used < (int)c->ev0.size();
+    if (timed) HIP_TRY(hipEventRecord(c->ev0[c->ev_used], stream));
+    hipLaunchKernelGGL(dlscqp_plan_kernel, dim3(b->n_agents), dim3(64), lay.bytes, stream, c->kp, lay, a);
+    HIP_TRY(hipGetLastError());
+    if (timed) {
+        HIP_TRY(hipEventRecord(c->ev1[c->ev_used], stream));
+        c->ev_used++;
+    }
+    return DLSCQP_SUCCESS;
+}
+
+extern "C" int dlscqp_plan_batch_device(dlscqp_ctx *c, const dlscqp_device_batch *b, void *stream) {
+    g_last_error.clear();
+    if (!c || !b) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (!b->agents || !b->row_offsets || !b->out_status) { g_last_error = "null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    (void)hipSetDevice(c->cfg.device);
+    return launch(c, b, stream ? (hipStream_t)stream : c->stream);
+}
+
+extern "C" void dlscqp_rows_to_soa(const dlscqp_lsc_row *rows, int64_t n_rows, float *nx, float *ny, float *nz,
+                                   float *px, float *py, float *pz, double *d, uint32_t *key) {
+    for (int64_t i = 0; i < n_rows; i++) {
+        nx[i] = rows[i].normal[0]; ny[i] = rows[i].normal[1]; nz[i] = rows[i].normal[2];
+        px[i] = rows[i].point[0]; py[i] = rows[i].point[1]; pz[i] = rows[i].point[2];
+        d[i] = rows[i].d;
+        key[i] = DLSCQP_KEY(rows[i].m, rows[i].i, rows[i].slack, rows[i].flags & DLSCQP_ROW_DYNAMIC);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-buffer entry points: marshal into pinned staging, H2D, launch, D2H
+// ---------------------------------------------------------------------------------------------
+namespace {
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+}
+
+static int plan_host(dlscqp_ctx *c, int32_t n_agents, const dlscqp_agent *agents, const int64_t *row_offsets,
+                     const dlscqp_lsc_row *rows, const float *sfc_boxes, int32_t max_slack_obs, int do_goal,
+                     int do_traj, float *out_goal, int32_t *out_goal_status, float *out_ctrl, double *out_cost,
+                     double *out_slack_cost, int32_t *out_status) {
+    g_last_error.clear();
+    if (!c) { g_last_error = "null context"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (n_agents < 0) { g_last_error = "negative n_agents"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (n_agents == 0) return DLSCQP_SUCCESS;
+    if (!agents || !row_offsets) { g_last_error = "null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    const int64_t nrows = row_offsets[n_agents];
+    if (nrows < 0 || nrows >= (int64_t)1 << 31 || (nrows > 0 && !rows)) { g_last_error = "bad row_offsets"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    (void)hipSetDevice(c->cfg.device);
+    const int M = c->M, n1 = c->n + 1;
+    const bool use_sfc = c->kp.use_sfc && sfc_boxes;
+    if (c->kp.use_sfc && !sfc_boxes) { g_last_error = "world_use_octomap is set but sfc_boxes is NULL"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (max_slack_obs < 0) max_slack_obs = 0;
+    // ---- staging layout (inputs then outputs), 256-byte aligned sections
+    size_t o = 0;
+    auto take = [&](size_t bytes) { size_t at = o; o = align_up(o + bytes, 256); return at; };
+    const size_t rpad = (size_t)nrows + 64;
+    const size_t o_agents = take(sizeof(dlscqp_agent) * n_agents);
+    const size_t o_off = take(4 * ((size_t)n_agents + 1));
+    const size_t o_nx = take(4 * rpad), o_ny = take(4 * rpad), o_nz = take(4 * rpad);
+    const size_t o_px = take(4 * rpad), o_py = take(4 * rpad), o_pz = take(4 * rpad);
+    const size_t o_d = take(8 * rpad), o_key = take(4 * rpad);
+    const size_t o_sfc = take(use_sfc ? sizeof(float) * 6 * M * n_agents : 0);
+    const size_t in_bytes = o;
+    const size_t o_goal = take(sizeof(float) * 3 * n_agents);
+    const size_t o_gst = take(4 * (size_t)n_agents);
+    const size_t o_ctrl = take(sizeof(float) * 3 * M * n1 * n_agents);
+    const size_t o_cost = take(8 * (size_t)n_agents);
+    const size_t o_slk = take(8 * (size_t)n_agents * std::max(max_slack_obs, 1));
+    const size_t o_st = take(4 * (size_t)n_agents);
+    const size_t total = o;
+    if (total > c->stage_cap) {
+        if (c->d_stage) (void)hipFree(c->d_stage);
+        if (c->h_stage) (void)hipHostFree(c->h_stage);
+        c->d_stage = nullptr; c->h_stage = nullptr; c->stage_cap = 0;
+        size_t cap = total + total / 2;
+        HIP_TRY(hipMalloc((void **)&c->d_stage, cap));
+        HIP_TRY(hipHostMalloc((void **)&c->h_stage, cap, hipHostMallocDefault));
+        c->stage_cap = cap;
+    }
+    unsigned char *h = c->h_stage, *d = c->d_stage;
+    std::memcpy(h + o_agents, agents, sizeof(dlscqp_agent) * n_agents);
+    int32_t *off32 = reinterpret_cast<int32_t *>(h + o_off);
+    int kmax = 0;
+    for (int a = 0; a <= n_agents; a++) {
+        off32[a] = (int32_t)row_offsets[a];
+        if (a > 0) {
+            int64_t k = row_offsets[a] - row_offsets[a - 1];
+            if (k < 0) { g_last_error = "row_offsets not monotone"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+            kmax = std::max<int>(kmax, (int)k);
+        }
+    }
+    dlscqp_rows_to_soa(rows, nrows, (float *)(h + o_nx), (float *)(h + o_ny), (float *)(h + o_nz), (float *)(h + o_px),
+                       (float *)(h + o_py), (float *)(h + o_pz), (double *)(h + o_d), (uint32_t *)(h + o_key));
+    if (use_sfc) std::memcpy(h + o_sfc, sfc_boxes, sizeof(float) * 6 * M * n_agents);
+    // status defaults: agents the kernel never reaches keep a failure code
+    HIP_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemsetAsync(d + in_bytes, 0, total - in_bytes, c->stream));
+    dlscqp_device_batch b;
+    std::memset(&b, 0, sizeof b);
+    b.n_agents = n_agents;
+    b.max_slack_obs = max_slack_obs;
+    b.do_goal = do_goal;
+    b.do_traj = do_traj;
+    b.max_rows_per_agent = kmax;
+    b.agents = (const dlscqp_agent *)(d + o_agents);
+    b.row_offsets = (const int32_t *)(d + o_off);
+    b.nx = (const float *)(d + o_nx); b.ny = (const float *)(d + o_ny); b.nz = (const float *)(d + o_nz);
+    b.px = (const float *)(d + o_px); b.py = (const float *)(d + o_py); b.pz = (const float *)(d + o_pz);
+    b.d = (const double *)(d + o_d);
+    b.key = (const uint32_t *)(d + o_key);
+    b.sfc_boxes = use_sfc ? (const float *)(d + o_sfc) : nullptr;
+    b.out_goal = (float *)(d + o_goal);
+    b.out_goal_status = (int32_t *)(d + o_gst);
+    b.out_ctrl = (float *)(d + o_ctrl);
+    b.out_cost = (double *)(d + o_cost);
+    b.out_slack_cost = max_slack_obs > 0 ? (double *)(d + o_slk) : nullptr;
+    b.out_status = (int32_t *)(d + o_st);
+    int rc = launch(c, &b, c->stream);
+    if (rc != DLSCQP_SUCCESS) return rc;
+    HIP_TRY(hipMemcpyAsync(h + in_bytes, d + in_bytes, total - in_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const size_t cs = (size_t)3 * M * n1;
+    for (int a = 0; a < n_agents; a++) {
+        const int32_t gst = reinterpret_cast<int32_t *>(h + o_gst)[a];
+        const int32_t st = reinterpret_cast<int32_t *>(h + o_st)[a];
+        if (do_goal) {
+            if (out_goal_status) out_goal_status[a] = gst;
+            if (out_goal && gst != DLSCQP_INFEASIBLE) std::memcpy(out_goal + (size_t)a * 3, h + o_goal + sizeof(float) * 3 * a, sizeof(float) * 3);
+        }
+        if (do_traj) {
+            if (out_status) out_status[a] = st;
+            if (st == DLSCQP_OK) {
+                if (out_ctrl) std::memcpy(out_ctrl + a * cs, h + o_ctrl + sizeof(float) * cs * a, sizeof(float) * cs);
+                if (out_cost) out_cost[a] = reinterpret_cast<double *>(h + o_cost)[a];
+                if (out_slack_cost && max_slack_obs > 0)
+                    std::memcpy(out_slack_cost + (size_t)a * max_slack_obs, h + o_slk + 8 * (size_t)a * max_slack_obs, 8 * (size_t)max_slack_obs);
+            } else {
+                if (out_cost) out_cost[a] = 0;
+            }
+        }
+    }
+    return DLSCQP_SUCCESS;
+}
+
+extern "C" int dlscqp_solve_batch(dlscqp_ctx *ctx, int32_t n_agents, const dlscqp_agent *agents,
+                                  const int64_t *row_offsets, const dlscqp_lsc_row *rows, const float *sfc_boxes,
+                                  int32_t max_slack_obs, float *out_ctrl, double *out_cost, double *out_slack_cost,
+                                  int32_t *out_status) {
+    return plan_host(ctx, n_agents, agents, row_offsets, rows, sfc_boxes, max_slack_obs, 0, 1, nullptr, nullptr,
+                     out_ctrl, out_cost, out_slack_cost, out_status);
+}
+
+extern "C" int dlscqp_goal_batch(dlscqp_ctx *ctx, int32_t n_agents, const dlscqp_agent *agents,
+                                 const int64_t *row_offsets, const dlscqp_lsc_row *rows, const float *sfc_boxes,
+                                 float *out_goal, int32_t *out_goal_status) {
+    return plan_host(ctx, n_agents, agents, row_offsets, rows, sfc_boxes, 0, 1, 0, out_goal, out_goal_status, nullptr,
+                     nullptr, nullptr, nullptr);
+}
+
+extern "C" int dlscqp_plan_batch(dlscqp_ctx *ctx, int32_t n_agents, const dlscqp_agent *agents,
+                                 const int64_t *row_offsets, const dlscqp_lsc_row *rows, const float *sfc_boxes,
+                                 int32_t max_slack_obs, float *out_goal, int32_t *out_goal_status, float *out_ctrl,
+                                 double *out_cost, double *out_slack_cost, int32_t *out_status) {
+    return plan_host(ctx, n_agents, agents, row_offsets, rows, sfc_boxes, max_slack_obs, 1, 1, out_goal,
+                     out_goal_status, out_ctrl, out_cost, out_slack_cost, out_status);
+}

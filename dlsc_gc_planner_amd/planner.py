@@ -1,0 +1,206 @@
+"""Python host-side mirror of the reference's optimizer interface, over the C ABI.
+
+`BatchTrajOptimizer` plays the role of MATP::TrajOptimizer + MATP::GoalOptimizer
+(/root/reference/include/traj_optimizer.hpp:24-33, goal_optimizer.hpp:17-24) for a whole batch of
+agents: same inputs (Agent, the LSC/SFC content of CollisionConstraints), same outputs
+(control points as float32 point3d, total_qp_cost, slack costs, goal point), and the same failure
+convention (a per-agent verdict that the caller maps to PlanningReport::QPFAILED).
+
+All arithmetic happens in the HIP library (csrc/libdlscqp.so); there is no CPU path here.
+torch is used only as plumbing for device-resident buffers and streams.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+
+class DlscqpError(RuntimeError):
+    pass
+
+
+class QPFailed(RuntimeError):
+    """PlanningReport::QPFAILED (traj_optimizer.cpp:152, goal_optimizer.cpp:122)."""
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class BatchTrajOptimizer:
+    def __init__(self, cfg):
+        self.lib = abi.load_library()
+        self.cfg = cfg
+        h = C.c_void_p()
+        rc = self.lib.dlscqp_create(C.byref(cfg), C.byref(h))
+        if rc != abi.SUCCESS:
+            raise DlscqpError("dlscqp_create failed (%d): %s" % (rc, self.lib.dlscqp_last_error().decode()))
+        self.handle = h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.dlscqp_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != abi.SUCCESS:
+            raise DlscqpError("%s failed (%d): %s" % (what, rc, self.lib.dlscqp_last_error().decode()))
+
+    def update_param(self, cfg):
+        """TrajOptimizer::updateParam (traj_optimizer.cpp:167-169)."""
+        self._check(self.lib.dlscqp_update_param(self.handle, C.byref(cfg)), "dlscqp_update_param")
+        self.cfg = cfg
+
+    def lds_bytes(self, max_slack_obs=0, max_rows=0):
+        return int(self.lib.dlscqp_lds_bytes(self.handle, max_slack_obs, max_rows))
+
+    # ---- host-buffer entry points -------------------------------------------------------------
+    def plan(self, agents, row_offsets, rows, sfc=None, max_slack_obs=0, do_goal=True, do_traj=True):
+        """Goal LP and/or trajectory QP for a batch held in host (numpy) memory."""
+        agents = np.ascontiguousarray(agents, dtype=abi.AGENT_DTYPE)
+        rows = np.ascontiguousarray(rows, dtype=abi.ROW_DTYPE)
+        row_offsets = np.ascontiguousarray(row_offsets, dtype=np.int64)
+        sfc = None if sfc is None else np.ascontiguousarray(sfc, dtype=np.float32)
+        N = len(agents)
+        M, n = self.cfg.M, self.cfg.n
+        out = dict(goal=np.zeros((N, 3), np.float32), goal_status=np.zeros(N, np.int32),
+                   ctrl=np.zeros((N, M, n + 1, 3), np.float32), cost=np.zeros(N),
+                   slack_cost=np.zeros((N, max(max_slack_obs, 1))), status=np.full(N, -1, np.int32))
+        if do_goal and do_traj:
+            rc = self.lib.dlscqp_plan_batch(self.handle, N, _ptr(agents), _ptr(row_offsets), _ptr(rows), _ptr(sfc),
+                                            max_slack_obs, _ptr(out["goal"]), _ptr(out["goal_status"]),
+                                            _ptr(out["ctrl"]), _ptr(out["cost"]), _ptr(out["slack_cost"]),
+                                            _ptr(out["status"]))
+            self._check(rc, "dlscqp_plan_batch")
+        elif do_traj:
+            rc = self.lib.dlscqp_solve_batch(self.handle, N, _ptr(agents), _ptr(row_offsets), _ptr(rows), _ptr(sfc),
+                                             max_slack_obs, _ptr(out["ctrl"]), _ptr(out["cost"]),
+                                             _ptr(out["slack_cost"]), _ptr(out["status"]))
+            self._check(rc, "dlscqp_solve_batch")
+        else:
+            rc = self.lib.dlscqp_goal_batch(self.handle, N, _ptr(agents), _ptr(row_offsets), _ptr(rows), _ptr(sfc),
+                                            _ptr(out["goal"]), _ptr(out["goal_status"]))
+            self._check(rc, "dlscqp_goal_batch")
+        return out
+
+    def solve(self, agent, rows, sfc=None):
+        """TrajOptimizer::solve for one agent: returns (ctrl [M][n+1][3] float32, total_qp_cost,
+        slack_cost) or raises QPFailed like the reference (traj_optimizer.cpp:152)."""
+        agent = np.ascontiguousarray(agent, dtype=abi.AGENT_DTYPE).reshape(1)
+        nso = int(agent["n_slack_obs"][0])
+        r = self.plan(agent, np.array([0, len(rows)], np.int64), rows,
+                      None if sfc is None else np.asarray(sfc, np.float32)[None], nso, do_goal=False)
+        if r["status"][0] != abi.OK:
+            raise QPFailed("QPFAILED (verdict %d)" % r["status"][0])
+        return r["ctrl"][0], float(r["cost"][0]), r["slack_cost"][0, :nso]
+
+    def solve_goal(self, agent, rows, sfc=None):
+        """GoalOptimizer::solve for one agent (goal_optimizer.cpp:7-136)."""
+        agent = np.ascontiguousarray(agent, dtype=abi.AGENT_DTYPE).reshape(1)
+        r = self.plan(agent, np.array([0, len(rows)], np.int64), rows,
+                      None if sfc is None else np.asarray(sfc, np.float32)[None], 0, do_goal=True, do_traj=False)
+        if r["goal_status"][0] == abi.INFEASIBLE:
+            raise QPFailed("QPFAILED (goal LP infeasible)")
+        return r["goal"][0]
+
+    # ---- device-resident entry point ------------------------------------------------------------
+    def make_device_batch(self, agents, row_offsets, rows, sfc=None, max_slack_obs=0, want_f64=False,
+                          want_iters=False, device=None):
+        """Upload a batch once (SoA rows) and allocate its outputs in HBM; returns a DeviceBatch
+        that can be launched any number of times without touching the host."""
+        return DeviceBatch(self, agents, row_offsets, rows, sfc, max_slack_obs, want_f64, want_iters, device)
+
+    def set_timing(self, capacity):
+        self._check(self.lib.dlscqp_set_timing(self.handle, int(capacity)), "dlscqp_set_timing")
+
+    def kernel_times_ms(self, capacity):
+        buf = np.zeros(max(capacity, 1), np.float32)
+        n = C.c_int32(0)
+        self._check(self.lib.dlscqp_get_kernel_times(self.handle, _ptr(buf), int(capacity), C.byref(n)),
+                    "dlscqp_get_kernel_times")
+        return buf[:n.value].copy()
+
+
+class DeviceBatch:
+    """A batch resident in HBM (torch tensors as plain device buffers)."""
+
+    def __init__(self, opt, agents, row_offsets, rows, sfc, max_slack_obs, want_f64, want_iters, device):
+        import torch
+        self.torch = torch
+        self.opt = opt
+        cfg = opt.cfg
+        dev = torch.device("cuda", cfg.device if device is None else device)
+        self.device = dev
+        agents = np.ascontiguousarray(agents, dtype=abi.AGENT_DTYPE)
+        rows = np.ascontiguousarray(rows, dtype=abi.ROW_DTYPE)
+        row_offsets = np.ascontiguousarray(row_offsets, dtype=np.int64)
+        N, R = len(agents), len(rows)
+        self.n_agents, self.n_rows = N, R
+        M, n, dim = cfg.M, cfg.n, cfg.world_dimension
+        pad = R + 64
+        soa = dict(nx=np.zeros(pad, np.float32), ny=np.zeros(pad, np.float32), nz=np.zeros(pad, np.float32),
+                   px=np.zeros(pad, np.float32), py=np.zeros(pad, np.float32), pz=np.zeros(pad, np.float32),
+                   d=np.zeros(pad, np.float64), key=np.zeros(pad, np.uint32))
+        opt.lib.dlscqp_rows_to_soa(_ptr(rows), R, *[_ptr(soa[k]) for k in ("nx", "ny", "nz", "px", "py", "pz", "d", "key")])
+
+        def up(a):
+            return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev)
+
+        self.t = dict(agents=up(agents), row_offsets=up(row_offsets.astype(np.int32)))
+        for k, v in soa.items():
+            self.t[k] = up(v)
+        self.t["sfc"] = None if sfc is None else up(np.ascontiguousarray(sfc, dtype=np.float32))
+        self.out_goal = torch.zeros((N, 3), dtype=torch.float32, device=dev)
+        self.out_goal_status = torch.zeros(N, dtype=torch.int32, device=dev)
+        self.out_ctrl = torch.zeros((N, M, n + 1, 3), dtype=torch.float32, device=dev)
+        self.out_cost = torch.zeros(N, dtype=torch.float64, device=dev)
+        self.out_status = torch.full((N,), -1, dtype=torch.int32, device=dev)
+        self.out_slack = torch.zeros((N, max(max_slack_obs, 1)), dtype=torch.float64, device=dev)
+        nxv = dim * M * (n + 1) + M * max_slack_obs
+        self.out_x = torch.zeros((N, nxv), dtype=torch.float64, device=dev) if want_f64 else None
+        self.out_iters = torch.zeros((N, 4), dtype=torch.int32, device=dev) if want_iters else None
+        kmax = int(np.max(np.diff(row_offsets))) if N else 0
+        b = abi.DeviceBatch()
+        b.n_agents, b.max_slack_obs, b.do_goal, b.do_traj = N, max_slack_obs, 1, 1
+        b.max_rows_per_agent = kmax
+        b.agents = self.t["agents"].data_ptr()
+        b.row_offsets = self.t["row_offsets"].data_ptr()
+        for k in ("nx", "ny", "nz", "px", "py", "pz", "d", "key"):
+            setattr(b, k, self.t[k].data_ptr())
+        b.sfc_boxes = None if self.t["sfc"] is None else self.t["sfc"].data_ptr()
+        b.out_goal = self.out_goal.data_ptr()
+        b.out_goal_status = self.out_goal_status.data_ptr()
+        b.out_ctrl = self.out_ctrl.data_ptr()
+        b.out_ctrl_f64 = None if self.out_x is None else self.out_x.data_ptr()
+        b.out_cost = self.out_cost.data_ptr()
+        b.out_slack_cost = self.out_slack.data_ptr() if max_slack_obs > 0 else None
+        b.out_status = self.out_status.data_ptr()
+        b.out_iters = None if self.out_iters is None else self.out_iters.data_ptr()
+        self.c = b
+        self.max_rows = kmax
+        self.max_slack_obs = max_slack_obs
+
+    def launch(self, do_goal=True, do_traj=True, stream=None):
+        """Asynchronous launch on `stream` (default: torch's current stream)."""
+        self.c.do_goal, self.c.do_traj = int(do_goal), int(do_traj)
+        s = self.torch.cuda.current_stream(self.device) if stream is None else stream
+        rc = self.opt.lib.dlscqp_plan_batch_device(self.opt.handle, C.byref(self.c), C.c_void_p(s.cuda_stream))
+        self.opt._check(rc, "dlscqp_plan_batch_device")
+
+    def results(self):
+        self.torch.cuda.synchronize(self.device)
+        out = dict(goal=self.out_goal.cpu().numpy(), goal_status=self.out_goal_status.cpu().numpy(),
+                   ctrl=self.out_ctrl.cpu().numpy(), cost=self.out_cost.cpu().numpy(),
+                   status=self.out_status.cpu().numpy(), slack_cost=self.out_slack.cpu().numpy())
+        if self.out_x is not None:
+            out["x"] = self.out_x.cpu().numpy()
+        if self.out_iters is not None:
+            out["iters"] = self.out_iters.cpu().numpy()
+        return out

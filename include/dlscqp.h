@@ -134,9 +134,8 @@ void dlscqp_destroy(dlscqp_ctx *ctx);
 int dlscqp_update_param(dlscqp_ctx *ctx, const dlscqp_config *cfg);
 /* Text of the last error on this thread ("" if none). */
 const char *dlscqp_last_error(void);
-/* Number of 32-bit words of LDS the solver kernel uses per agent for this context and
- * max_slack_obs; diagnostic. */
-int64_t dlscqp_lds_bytes(const dlscqp_ctx *ctx, int max_slack_obs);
+/* Bytes of LDS one agent (= one wavefront) uses for this context; diagnostic. */
+int64_t dlscqp_lds_bytes(const dlscqp_ctx *ctx, int32_t max_slack_obs, int32_t max_rows_per_agent);
 
 /* ---- host-buffer entry points (H2D + kernel + D2H, synchronous) --------------------------
  * rows of agent a are rows[row_offsets[a] .. row_offsets[a+1]); sfc_boxes is [n_agents][M][6]
@@ -172,6 +171,8 @@ typedef struct dlscqp_device_batch {
     int32_t max_slack_obs;          /* stride of out_slack_cost                                 */
     int32_t do_goal;                /* 1: run the goal LP first and use its goal in the QP       */
     int32_t do_traj;                /* 1: run the trajectory QP                                  */
+    int32_t max_rows_per_agent;     /* max over agents of row_offsets[a+1]-row_offsets[a]        */
+    int32_t reserved_;
     const dlscqp_agent *agents;     /* [n_agents]                                               */
     const int32_t *row_offsets;     /* [n_agents+1]                                             */
     const float *nx, *ny, *nz;      /* [total_rows] normal                                      */
@@ -200,10 +201,12 @@ int dlscqp_plan_batch_device(dlscqp_ctx *ctx, const dlscqp_device_batch *batch, 
 void dlscqp_rows_to_soa(const dlscqp_lsc_row *rows, int64_t n_rows, float *nx, float *ny,
                         float *nz, float *px, float *py, float *pz, double *d, uint32_t *key);
 
-/* Elapsed GPU time in ms of the last dlscqp_plan_batch_device launch issued with timing
- * enabled (HIP events on the launch stream); blocks until that launch is done. */
-int dlscqp_set_timing(dlscqp_ctx *ctx, int enable);
-int dlscqp_last_kernel_ms(dlscqp_ctx *ctx, float *ms);
+/* Kernel timing with HIP events recorded on the launch stream, without synchronising inside the
+ * timed region: dlscqp_set_timing(ctx, capacity) (re)arms `capacity` event pairs (0 = off); every
+ * following dlscqp_plan_batch_device launch records one pair until they are used up;
+ * dlscqp_get_kernel_times waits for the recorded launches and returns their durations in ms. */
+int dlscqp_set_timing(dlscqp_ctx *ctx, int32_t capacity);
+int dlscqp_get_kernel_times(dlscqp_ctx *ctx, float *ms_out, int32_t capacity, int32_t *n_out);
 
 #ifdef __cplusplus
 }
