@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- agent-QP solves/s of the batched DLSC-GC trajectory optimizer on MI355X.
+
+One "step" = one replanning pass of the hot path (goal LP + trajectory QP, one fused kernel
+launch) over a batch of synthetic agents already resident in HBM, followed -- when more than one
+GPU takes part -- by ONE RCCL all-gather of the solved control points (the reference's
+broadcastMsgs, multi_sync_simulator.cpp:468-514).  Workload: BASELINE.json configs[1]
+("synthetic 64-agent batch, 5 segments x degree 5, 120 DLSC inequalities each"), `--swarms`
+independent 64-agent swarms per GPU per step (weak scaling: every rank owns its own swarms).
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 50 --warmup 5
+
+Rank 0 prints one JSON line.  `value` = agent-QPs of all ranks / max-over-ranks wall time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6
+
+
+def algorithmic_bytes_per_qp(dim, M, n, K, use_sfc, n_dyn):
+    """bytes one agent-QP has to move at least."""
+    b = 8 * (3 * dim + dim + dim + 2 * dim + 5)
+    if use_sfc:
+        b += 4 * 6 * M
+    b += K * 36
+    b += 4 * dim * M * (n + 1)
+    b += 8 * (1 + n_dyn) + 4
+    return b
+
+
+def cpu_baseline(cfg, wl, target_seconds=12.0):
+    """The CPU oracle (a port: dense model + generic dual active-set, oracle/dlsc_oracle.c) timed on
+    this host, one thread, on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    agents, ro, rows = wl["agents"], wl["row_offsets"], wl["rows"]
+    N = len(agents)
+    probe = min(N, 64)
+    t0 = time.perf_counter()
+    oracle_lib.plan_batch(cfg, agents[:probe], ro[:probe + 1], rows[:ro[probe]], None, 0, True)
+    dt = time.perf_counter() - t0
+    per = dt / probe
+    n = int(min(N, max(probe, target_seconds / max(per, 1e-6))))
+    t0 = time.perf_counter()
+    oracle_lib.plan_batch(cfg, agents[:n], ro[:n + 1], rows[:ro[n]], None, 0, True)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "QP/s", "cores": 1, "kind": "port",
+            "sample": "first %d agents of the same batch, goal LP + QP each, %.1f s" % (n, dt),
+            "ref_published_qp_per_s": 89.4,
+            "ref_published_note": "reference log: 11.18 ms/QP mean, CPLEX 22.1.1 Threads=6, 2-D M=10, unknown CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--swarms", type=int, default=256, help="64-agent swarms per GPU per step")
+    ap.add_argument("--seed", type=int, default=2000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-swarm host-to-host latency loop")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic_latest.json"))
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the trajectory optimizer has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from dlsc_gc_planner_amd import abi, workloads
+    from dlsc_gc_planner_amd.planner import BatchTrajOptimizer
+
+    cfg = workloads.s64_config(device=local_rank)
+    opt = BatchTrajOptimizer(cfg)
+
+    def solver(agents, ro, rows, sfc):
+        return opt.plan(agents, ro, rows, sfc, 0, True, True)
+
+    t_gen = time.perf_counter()
+    wl = workloads.generate(cfg, solver, n_swarms=args.swarms, swarm_size=64, seed=args.seed + 1000 * rank)
+    t_gen = time.perf_counter() - t_gen
+    N = len(wl["agents"])
+    K = wl["K"]
+    db = opt.make_device_batch(wl["agents"], wl["row_offsets"], wl["rows"], None, 0, want_iters=True)
+    gathered = None
+    if world > 1:
+        gathered = torch.empty((world * N,) + tuple(db.out_ctrl.shape[1:]), dtype=torch.float32, device=dev)
+
+    def step():
+        db.launch(True, True)
+        if world > 1:
+            # the per-step exchange: every agent's solved control points to every rank
+            dist.all_gather_into_tensor(gathered, db.out_ctrl)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    opt.set_timing(args.steps)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kms = opt.kernel_times_ms(args.steps)
+    res = db.results()
+    if world > 1:
+        # the gathered table must hold this rank's own block
+        own = gathered[rank * N:(rank + 1) * N]
+        assert torch.equal(own, db.out_ctrl)
+
+    if rank == 0:
+        ok = res["status"] == abi.OK
+        dim, M, n = cfg.world_dimension, cfg.M, cfg.n
+        bytes_qp = algorithmic_bytes_per_qp(dim, M, n, K, False, 0)
+        avg_kernel_s = float(np.mean(kms)) * 1e-3 if len(kms) else float("nan")
+        achieved = N * bytes_qp / avg_kernel_s / 1e9
+        traffic = None
+        try:
+            with open(args.traffic_json) as fh:
+                tj = json.load(fh)
+            if tj.get("agents_per_launch") == N:
+                traffic = tj.get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+        it = res["iters"]
+        # single-swarm replanning latency through the host-buffer entry (H2D + solve + D2H)
+        a1, r1 = wl["agents"][:64], wl["rows"][:wl["row_offsets"][64]]
+        ro1 = wl["row_offsets"][:65]
+        lat = []
+        for _ in range(0 if args.no_latency else 60):
+            t1 = time.perf_counter()
+            opt.plan(a1, ro1, r1, None, 0, True, True)
+            lat.append((time.perf_counter() - t1) * 1e3)
+        lat = np.array(lat[10:]) if lat else np.array([float("nan")])
+        line = {
+            "metric": "agent-QP solves/sec (goal LP + trajectory QP per agent per replanning step)",
+            "value": world * N * args.steps / elapsed,
+            "unit": "QP/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "S64: %d independent 64-agent swarms per GPU per step (BASELINE.json configs[1]: "
+                            "3-D, 5 segments x degree 5, %d DLSC rows per agent)" % (args.swarms, K),
+                "agents_per_gpu": N, "segments": M, "degree": n, "lsc_rows_per_agent": K,
+                "vars_per_agent": dim * M * (n + 1), "ineq_rows_per_agent": K + 2 * 207,
+                "exchange": "one RCCL all-gather of control points per step" if world > 1 else "none (1 GPU)",
+                "solved_fraction": float(ok.mean()), "mean_active_set_iterations": float(it[:, 0].mean()),
+                "max_active_set_iterations": int(it[:, 0].max()), "seed": args.seed,
+                "workload_generation_s": t_gen,
+            },
+            "p50_replan_ms_one_swarm_host_to_host": float(np.percentile(lat, 50)),
+            "p99_replan_ms_one_swarm_host_to_host": float(np.percentile(lat, 99)),
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "dlscqp_plan_kernel", "avg_kernel_ms": avg_kernel_s * 1e3,
+                "algorithmic_bytes_per_qp": bytes_qp, "qp_per_launch": N,
+                "note": "latency/FP64-VALU bound by construction (SURVEY.md 8d): ~5 KB of traffic per QP",
+            },
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(cfg, wl)
+        print(json.dumps(line))
+    opt.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

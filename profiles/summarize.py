@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 CSV output of `bench.py` runs into profiles/<name>.md + hbm_traffic_latest.json.
+
+usage: python profiles/summarize.py gpurun_out/prof_r01 r01 --steps 30 --agents 16384
+
+Expects sub-directories trace/ (--kernel-trace --stats), fetch/ (--pmc FETCH_SIZE), write/
+(--pmc WRITE_SIZE) and optional sq*/ (SQ counters), each written by a separate rocprofv3 run of the
+same bench command.  Only the LAST `steps` dispatches of dlscqp_plan_kernel (the timed region of
+bench.py; earlier ones are workload generation and warm-up) are averaged.
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are in KiB and on
+gfx950 FETCH_SIZE reports half of the fetched bytes (MI355X_MICROARCH.md, "HBM").
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+KERNEL = "dlscqp_plan_kernel"
+
+
+def read(path):
+    with open(path) as fh:
+        return list(csv.DictReader(fh))
+
+
+def last_dispatches(rows, steps):
+    ids = sorted({int(r["Dispatch_Id"]) for r in rows if KERNEL in r["Kernel_Name"]})
+    return set(ids[-steps:])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("prof_dir")
+    ap.add_argument("name")
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--agents", type=int, default=16384)
+    ap.add_argument("--bytes-per-qp", type=int, default=4900)
+    args = ap.parse_args()
+    out = []
+    summary = {"name": args.name, "agents_per_launch": args.agents}
+    tr = glob.glob(os.path.join(args.prof_dir, "trace", "*", "*_kernel_trace.csv"))
+    if tr:
+        rows = read(tr[0])
+        keep = last_dispatches(rows, args.steps)
+        sel = [r for r in rows if KERNEL in r["Kernel_Name"] and int(r["Dispatch_Id"]) in keep]
+        durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3 for r in sel]
+        avg = sum(durs) / len(durs)
+        r0 = sel[0]
+        summary.update(avg_kernel_us=avg, min_kernel_us=min(durs), max_kernel_us=max(durs), launches=len(durs),
+                       vgpr=int(r0["VGPR_Count"]), sgpr=int(r0["SGPR_Count"]), lds_bytes=int(r0["LDS_Block_Size"]),
+                       scratch=int(r0["Scratch_Size"]), grid=int(r0["Grid_Size_X"]), wg=int(r0["Workgroup_Size_X"]))
+        out.append("## kernel trace (last %d dispatches of %s)\n" % (len(durs), KERNEL))
+        out.append("| avg us | min us | max us | grid | workgroup | VGPR | SGPR | LDS B/WG | scratch B/lane |")
+        out.append("|---|---|---|---|---|---|---|---|---|")
+        out.append("| %.1f | %.1f | %.1f | %d | %d | %d | %d | %d | %d |\n" % (
+            avg, min(durs), max(durs), summary["grid"], summary["wg"], summary["vgpr"], summary["sgpr"],
+            summary["lds_bytes"], summary["scratch"]))
+        alg = args.agents * args.bytes_per_qp
+        summary["algorithmic_bytes_per_launch"] = alg
+        summary["achieved_GBps"] = alg / (avg * 1e-6) / 1e9
+        out.append("algorithmic bytes per launch = %d agents x %d B = %d B -> %.2f GB/s achieved (%.4f of 8000 GB/s)\n" % (
+            args.agents, args.bytes_per_qp, alg, summary["achieved_GBps"], summary["achieved_GBps"] / 8000))
+        st = glob.glob(os.path.join(args.prof_dir, "trace", "*", "*_kernel_stats.csv"))
+        if st:
+            out.append("rocprofv3 --stats (all dispatches of the process, including workload generation):\n")
+            out.append("```")
+            out.extend(l.rstrip() for l in open(st[0]).readlines()[:6])
+            out.append("```\n")
+    counters = defaultdict(list)
+    for sub in sorted(glob.glob(os.path.join(args.prof_dir, "*"))):
+        cc = glob.glob(os.path.join(sub, "*", "*_counter_collection.csv"))
+        if not cc:
+            continue
+        rows = read(cc[0])
+        keep = last_dispatches(rows, args.steps)
+        for r in rows:
+            if KERNEL in r["Kernel_Name"] and int(r["Dispatch_Id"]) in keep:
+                counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if counters:
+        out.append("## PMC counters (average per launch over the timed dispatches, one rocprofv3 run per group)\n")
+        out.append("| counter | avg per launch |")
+        out.append("|---|---|")
+        for k in sorted(counters):
+            v = sum(counters[k]) / len(counters[k])
+            summary["pmc_" + k] = v
+            out.append("| %s | %.6g |" % (k, v))
+        out.append("")
+    if "pmc_FETCH_SIZE" in summary and "pmc_WRITE_SIZE" in summary:
+        hbm = (2 * summary["pmc_FETCH_SIZE"] + summary["pmc_WRITE_SIZE"]) * 1024
+        summary["hbm_bytes_per_launch"] = hbm
+        out.append("HBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = %.4g B (algorithmic %.4g B, ratio %.2f)\n" % (
+            hbm, summary.get("algorithmic_bytes_per_launch", float("nan")),
+            hbm / summary.get("algorithmic_bytes_per_launch", float("nan"))))
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, args.name + ".md"), "w") as fh:
+        fh.write("# rocprofv3 summary %s\n\n" % args.name)
+        fh.write("\n".join(out) + "\n")
+    with open(os.path.join(here, args.name + ".json"), "w") as fh:
+        json.dump(summary, fh, indent=1, sort_keys=True)
+    if "hbm_bytes_per_launch" in summary:
+        with open(os.path.join(here, "hbm_traffic_latest.json"), "w") as fh:
+            json.dump({"agents_per_launch": args.agents, "hbm_bytes_per_launch": summary["hbm_bytes_per_launch"],
+                       "source": args.name}, fh)
+    print("\n".join(out))
+
+
+if __name__ == "__main__":
+    main()

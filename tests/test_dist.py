@@ -1,0 +1,70 @@
+"""CPU tier: the N>1 path (contiguous agent shards + ONE all-gather) with world_size 2 over gloo.
+The per-shard solve is done by the lane-serial test build of the kernel source; the collective and
+the shard arithmetic are the product's (dlsc_gc_planner_amd/sharding.py)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from dlsc_gc_planner_amd import sharding
+
+
+def _worker(rank, world, port, n_agents, q):
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    sys.path.insert(0, here)
+    import emul_lib as E
+    import fixtures
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg, b, _ = fixtures.load("s64")
+    lo, hi = sharding.shard_range(n_agents, rank, world)
+    ro = b["row_offsets"]
+    got = E.plan_batch(cfg, b["agents"][lo:hi], ro[lo:hi + 1] - ro[lo], b["rows"][ro[lo]:ro[hi]], None, 0, True)
+    local = torch.from_numpy(got["ctrl"])
+    table = sharding.gather_plans(local, n_agents, dist, rank, world)
+    q.put((rank, table.numpy().copy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(n_agents):
+    import emul_lib as E
+    import fixtures
+    cfg, b, _ = fixtures.load("s64")
+    ro = b["row_offsets"]
+    full = E.plan_batch(cfg, b["agents"][:n_agents], ro[:n_agents + 1], b["rows"][:ro[n_agents]], None, 0, True)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 200) + n_agents
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_agents, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert res[r].shape == full["ctrl"].shape
+        assert np.array_equal(res[r], full["ctrl"])
+
+
+def test_two_ranks_even_shards():
+    _run(64)
+
+
+def test_two_ranks_uneven_shards():
+    _run(33)
+
+
+def test_shard_ranges_cover_all_agents():
+    for n in (0, 1, 7, 64, 2048, 2049):
+        for w in (1, 2, 3, 8):
+            r = [sharding.shard_range(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1

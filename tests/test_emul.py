@@ -1,0 +1,101 @@
+"""CPU tier: the solver kernel's own source (gi_core.hpp + host tables), built lane-serially for the
+host (tests/emul), against the golden vectors and the oracle.  This is how the device algorithm is
+checked in a container without a GPU; the same comparisons run against the real kernel under -m gpu."""
+import os
+
+import numpy as np
+import pytest
+
+from dlsc_gc_planner_amd import abi
+import emul_lib as E
+import fixtures
+import oracle_lib as O
+import randqp
+
+
+@pytest.mark.parametrize("name", fixtures.NAMES)
+def test_kernel_source_matches_golden(name):
+    cfg, b, ans = fixtures.load(name)
+    got = E.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], b["sfc"], b["max_slack_obs"], True)
+    assert fixtures.check_against_golden(cfg, b, ans, got) >= 8
+
+
+@pytest.mark.parametrize("name", list(randqp.CONFIGS))
+def test_kernel_source_matches_oracle_on_fresh_batches(name):
+    ck, gk = randqp.CONFIGS[name]
+    cfg = abi.make_config(**ck)
+    b = randqp.random_batch(cfg, 30, seed=99, **gk)
+    ref = O.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], b["sfc"], b["max_slack_obs"], True)
+    got = E.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], b["sfc"], b["max_slack_obs"], True)
+    assert np.array_equal(got["goal_status"], ref["goal_status"])
+    gok = ref["goal_status"] != abi.INFEASIBLE
+    assert np.array_equal(got["goal"][gok], ref["goal"][gok])
+    assert np.array_equal(got["status"], ref["status"])
+    ok = ref["status"] == abi.OK
+    assert ok.sum() >= 5
+    assert np.abs(got["x"][ok] - ref["x"][ok]).max() < 1e-8
+    assert np.allclose(got["cost"][ok], ref["cost"][ok], rtol=1e-7, atol=1e-9)
+    if b["max_slack_obs"]:
+        assert np.abs(got["slack_cost"][ok] - ref["slack_cost"][ok]).max() < 1e-8
+
+
+def test_lane_loops_have_no_cross_lane_hazard():
+    """Running every lane loop backwards must not change a single bit."""
+    cfg, b, _ = fixtures.load("forest3d_M5_dyn")
+    fwd = E.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], b["sfc"], b["max_slack_obs"], True)
+    os.environ["EMUL_REVERSE"] = "1"
+    try:
+        rev = E.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], b["sfc"], b["max_slack_obs"], True)
+    finally:
+        del os.environ["EMUL_REVERSE"]
+    for k in ("status", "goal", "x", "cost", "iters"):
+        assert np.array_equal(fwd[k], rev[k]), k
+
+
+def test_goal_only_and_traj_only_entry_points_agree_with_fused():
+    cfg, b, _ = fixtures.load("s64")
+    fused = E.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], None, 0, True, True)
+    g = E.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], None, 0, True, False)
+    assert np.array_equal(g["goal"], fused["goal"]) and np.array_equal(g["goal_status"], fused["goal_status"])
+    ag2 = b["agents"].copy()
+    gok = fused["goal_status"] != abi.INFEASIBLE
+    ag2["current_goal_point"][gok] = fused["goal"][gok]
+    t = E.plan_batch(cfg, ag2, b["row_offsets"], b["rows"], None, 0, False, True)
+    assert np.array_equal(t["x"][gok], fused["x"][gok])
+
+
+def test_host_tables_dimensions():
+    # free Bernstein degrees of freedom per axis after the equalities: 3M - 2 (stop rows) / 3M
+    assert E.table_info(abi.make_config(dim=3, M=5))["f"] == 13
+    assert E.table_info(abi.make_config(dim=2, M=10))["f"] == 28
+    assert E.table_info(abi.make_config(dim=2, M=4, planner_mode=abi.PLANNER_BVC))["f"] == 12
+    i = E.table_info(abi.make_config(dim=3, M=5), 0, 120)
+    assert i["n_slots"] == 81 + 69 + 57 and i["lds_bytes"] < 32 * 1024
+    with pytest.raises(ValueError):
+        E.table_info(abi.make_config(dim=3, M=5, n=4))  # only n=5, phi=3 (traj_optimizer.cpp:209)
+
+
+def test_empty_and_ragged_inputs():
+    cfg = abi.make_config(dim=3, M=5)
+    b = randqp.random_batch(cfg, 6, seed=5, max_rows=40)
+    # agent 2 gets no rows at all, agent 4 only rows that must be ignored
+    keep = []
+    offs = [0]
+    for a in range(6):
+        r = b["rows"][b["row_offsets"][a]:b["row_offsets"][a + 1]].copy()
+        if a == 2:
+            r = r[:0]
+        if a == 4:
+            r["normal"] = 0
+        keep.append(r)
+        offs.append(offs[-1] + len(r))
+    rows = np.concatenate(keep)
+    ref = O.plan_batch(cfg, b["agents"], np.array(offs), rows, None, 0, True)
+    got = E.plan_batch(cfg, b["agents"], np.array(offs), rows, None, 0, True)
+    assert np.array_equal(got["status"], ref["status"])
+    ok = ref["status"] == abi.OK
+    assert ok[2] and ok[4]
+    assert np.abs(got["x"][ok] - ref["x"][ok]).max() < 1e-8
+    # zero agents
+    z = E.plan_batch(cfg, b["agents"][:0], np.array([0]), rows[:0], None, 0, True)
+    assert z["status"].shape == (0,)
