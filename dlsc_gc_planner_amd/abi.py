@@ -113,6 +113,7 @@ class DeviceBatch(C.Structure):
         ("out_slack_cost", C.c_void_p),
         ("out_status", C.c_void_p),
         ("out_iters", C.c_void_p),
+        ("debug_stamps", C.c_void_p),
     ]
 
 
@@ -168,7 +169,8 @@ _LIB = None
 
 def library_path():
     here = os.path.dirname(os.path.abspath(__file__))
-    return os.path.join(here, "csrc", "libdlscqp.so")
+    # DLSCQP_LIB selects another build of the same HIP library (the -DDLSCQP_STAMPS diagnostic build)
+    return os.environ.get("DLSCQP_LIB") or os.path.join(here, "csrc", "libdlscqp.so")
 
 
 def load_library():

@@ -32,12 +32,42 @@ __device__ __forceinline__ double uniform_f64(double v) {
     return __hiloint2double(hi, lo);
 }
 
+__device__ __forceinline__ float readlane_f32(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// One wavefront = one agent.  Reg<T> is a VGPR; each() is the lane itself; cross-lane traffic is
+// v_readlane (broadcasts), ds_bpermute butterflies (reductions) and ballots.
 struct WaveGpu {
     int lane;
-    template <class F>
-    __device__ __forceinline__ void lane_loop(int n, F f) const {
-        for (int j = lane; j < n; j += 64) f(j);
+    template <class T>
+    struct Reg {
+        T v;
+        __device__ __forceinline__ T &at(int) { return v; }
+        __device__ __forceinline__ const T &at(int) const { return v; }
+    };
+#ifdef DLSCQP_STAMPS
+    // diagnostic build only (profiles/stamps.py): cycles per phase of plan_agent, never in the product .so
+    mutable unsigned long long acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    mutable unsigned long long last = 0;
+    __device__ __forceinline__ void stamp(int p) const {
+        unsigned long long t;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+        __builtin_amdgcn_sched_barrier(0);
+        acc[p] += t - last;
+        last = t;
     }
+#else
+    __device__ __forceinline__ void stamp(int) const {}
+#endif
+    template <class F>
+    __device__ __forceinline__ void each(F f) const { f(lane); }
     __device__ __forceinline__ void sync() const {
 #ifdef DLSCQP_SAFE_SYNC
         __syncthreads();
@@ -49,64 +79,55 @@ struct WaveGpu {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #endif
     }
-    template <class F>
-    __device__ __forceinline__ double sum(int n, F f) const {
-        double s = 0;
-        for (int j = lane; j < n; j += 64) s += f(j);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-        return uniform_f64(s);
+    // broadcasts: the source lane is wave-uniform, so v_readlane_b32 (SGPR result, no LDS)
+    __device__ __forceinline__ double bcast(const Reg<double> &r, int l) const {
+        return readlane_f64(r.v, __builtin_amdgcn_readfirstlane(l));
     }
-    template <class F>
-    __device__ __forceinline__ double max(int n, F f) const {
-        double s = -1e300;
-        for (int j = lane; j < n; j += 64) s = fmax(s, f(j));
+    __device__ __forceinline__ float bcast(const Reg<float> &r, int l) const {
+        return readlane_f32(r.v, __builtin_amdgcn_readfirstlane(l));
+    }
+    __device__ __forceinline__ uint32_t bcast(const Reg<uint32_t> &r, int l) const {
+        return (uint32_t)__builtin_amdgcn_readlane((int)r.v, __builtin_amdgcn_readfirstlane(l));
+    }
+    __device__ __forceinline__ int bcast(const Reg<int> &r, int l) const {
+        return __builtin_amdgcn_readlane(r.v, __builtin_amdgcn_readfirstlane(l));
+    }
+    __device__ __forceinline__ double max(const Reg<double> &r) const {
+        double s = r.v;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_xor(s, o, 64));
         return uniform_f64(s);
     }
-    template <class F>
-    __device__ __forceinline__ double min(int n, F f) const {
-        double s = 1e300;
-        for (int j = lane; j < n; j += 64) s = fmin(s, f(j));
+    __device__ __forceinline__ double min(const Reg<double> &r) const {
+        double s = r.v;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) s = fmin(s, __shfl_xor(s, o, 64));
         return uniform_f64(s);
     }
-    template <class F>
-    __device__ __forceinline__ Cand argmax(int n, F f) const {
-        Cand b{-1e300, -1};
-        for (int j = lane; j < n; j += 64) {
-            Cand c = f(j);
-            if (c.v > b.v) b = c;
-        }
+    __device__ __forceinline__ void sum2(const Reg<double> &a, const Reg<double> &b, double &sa, double &sb) const {
+        double x = a.v, y = b.v;
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            double ov = __shfl_xor(b.v, o, 64);
-            int oc = __shfl_xor(b.code, o, 64);
-            // ties: the smaller code wins, whatever the lane (same answer in every lane)
-            if (ov > b.v || (ov == b.v && (unsigned)oc < (unsigned)b.code)) { b.v = ov; b.code = oc; }
+        for (int o = 32; o > 0; o >>= 1) {  // two independent butterflies, interleaved
+            double xo = __shfl_xor(x, o, 64), yo = __shfl_xor(y, o, 64);
+            x += xo;
+            y += yo;
         }
-        b.v = uniform_f64(b.v);
-        b.code = __builtin_amdgcn_readfirstlane(b.code);
-        return b;
+        sa = uniform_f64(x);
+        sb = uniform_f64(y);
     }
-    template <class F>
-    __device__ __forceinline__ Cand argmin(int n, F f) const {
-        Cand b{1e300, -1};
-        for (int j = lane; j < n; j += 64) {
-            Cand c = f(j);
-            if (c.v < b.v) b = c;
+    __device__ __forceinline__ bool any(const Reg<int> &r) const { return __ballot(r.v != 0) != 0ull; }
+    __device__ __forceinline__ int first_lane(const Reg<int> &r) const {
+        unsigned long long m = __ballot(r.v != 0);
+        return m ? __builtin_ctzll(m) : -1;
+    }
+    template <class T>
+    __device__ __forceinline__ void shift_down(const Reg<T> *arr, int c, int nchunks, Reg<T> &out) const {
+        T nxt = __shfl_down(arr[c].v, 1, 64);
+        if (c + 1 < nchunks) {
+            T head = __shfl(arr[c + 1].v, 0, 64);
+            if (lane == 63) nxt = head;
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            double ov = __shfl_xor(b.v, o, 64);
-            int oc = __shfl_xor(b.code, o, 64);
-            if (ov < b.v || (ov == b.v && (unsigned)oc < (unsigned)b.code)) { b.v = ov; b.code = oc; }
-        }
-        b.v = uniform_f64(b.v);
-        b.code = __builtin_amdgcn_readfirstlane(b.code);
-        return b;
+        out.v = nxt;
     }
 };
 
@@ -124,17 +145,23 @@ struct KernelArgs {
     double *out_slack_cost;
     int32_t *out_status;
     int32_t *out_iters;
+    unsigned long long *out_stamps;  // [n_agents][12], diagnostic build only
 };
 
-__global__ __launch_bounds__(64) void dlscqp_plan_kernel(KParams kp, MemLayout lay, KernelArgs a) {
+template <int RC>
+__global__ __launch_bounds__(64, 2) void dlscqp_plan_kernel(KParams kp, MemLayout lay, KernelArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int ag = blockIdx.x;
     if (ag >= a.n_agents) return;
-    WaveGpu w{(int)threadIdx.x};
+    WaveGpu w;
+    w.lane = (int)threadIdx.x;
+#ifdef DLSCQP_STAMPS
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w.last)::"memory");
+#endif
     const int rb = a.row_offsets[ag], re = a.row_offsets[ag + 1];
     const int M = kp.M, n1 = kp.n1;
     const size_t xs = (size_t)kp.dim * M * n1 + (size_t)M * a.max_slack_obs;
-    plan_agent(w, kp, lay, smem, a.agents + ag, a.rows, rb, re - rb,
+    plan_agent<RC>(w, kp, lay, smem, a.agents + ag, a.rows, rb, re - rb,
                a.sfc ? a.sfc + (size_t)ag * M * 6 : nullptr, a.max_slack_obs, a.do_goal, a.do_traj,
                a.out_goal ? a.out_goal + (size_t)ag * 3 : nullptr,
                a.out_goal_status ? a.out_goal_status + ag : nullptr,
@@ -143,6 +170,10 @@ __global__ __launch_bounds__(64) void dlscqp_plan_kernel(KParams kp, MemLayout l
                a.out_slack_cost ? a.out_slack_cost + (size_t)ag * a.max_slack_obs : nullptr,
                a.out_status ? a.out_status + ag : nullptr,
                a.out_iters ? a.out_iters + (size_t)ag * 4 : nullptr);
+#ifdef DLSCQP_STAMPS
+    if (a.out_stamps && threadIdx.x == 0)
+        for (int p = 0; p < 12; p++) a.out_stamps[(size_t)ag * 12 + p] = w.acc[p];
+#endif
 }
 
 thread_local std::string g_last_error;
@@ -173,7 +204,7 @@ struct dlscqp_ctx {
     double *d_tabN = nullptr, *d_tabX0s = nullptr, *d_tabX0g = nullptr;
     Slot *d_slots = nullptr;
     hipStream_t stream = nullptr;
-    int max_dyn_lds = 0;
+    int max_dyn_lds[2] = {0, 0};
     // staging for the host-buffer entry points
     unsigned char *h_stage = nullptr, *d_stage = nullptr;
     size_t stage_cap = 0;
@@ -319,10 +350,16 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         g_last_error = msg;
         return DLSCQP_ERR_UNSUPPORTED;
     }
-    if (lay.bytes > c->max_dyn_lds) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(dlscqp_plan_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
-        c->max_dyn_lds = lay.bytes;
+    if (lay.r_max > 128) {
+        g_last_error = "reduced dimension above 128 (dim*f + M*max_slack_obs) is not supported";
+        return DLSCQP_ERR_UNSUPPORTED;
+    }
+    const int rcsel = lay.r_max <= 64 ? 0 : 1;
+    if (lay.bytes > c->max_dyn_lds[rcsel]) {
+        const void *fn = rcsel == 0 ? reinterpret_cast<const void *>(dlscqp_plan_kernel<1>)
+                                    : reinterpret_cast<const void *>(dlscqp_plan_kernel<2>);
+        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
+        c->max_dyn_lds[rcsel] = lay.bytes;
     }
     KernelArgs a;
     a.n_agents = b->n_agents;
@@ -341,9 +378,13 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
     a.out_slack_cost = b->out_slack_cost;
     a.out_status = b->out_status;
     a.out_iters = b->out_iters;
+    a.out_stamps = (unsigned long long *)b->debug_stamps;
     const bool timed = c->ev_used < (int)c->ev0.size();
     if (timed) HIP_TRY(hipEventRecord(c->ev0[c->ev_used], stream));
-    hipLaunchKernelGGL(dlscqp_plan_kernel, dim3(b->n_agents), dim3(64), lay.bytes, stream, c->kp, lay, a);
+    if (rcsel == 0)
+        hipLaunchKernelGGL(dlscqp_plan_kernel<1>, dim3(b->n_agents), dim3(64), lay.bytes, stream, c->kp, lay, a);
+    else
+        hipLaunchKernelGGL(dlscqp_plan_kernel<2>, dim3(b->n_agents), dim3(64), lay.bytes, stream, c->kp, lay, a);
     HIP_TRY(hipGetLastError());
     if (timed) {
         HIP_TRY(hipEventRecord(c->ev1[c->ev_used], stream));

@@ -5,18 +5,27 @@
 // and the Hessian whitened on the host (qp_tables.cpp), which leaves, per agent, a projection
 // problem  min 1/2 |w|^2  s.t. sparse half-spaces in control-point space, solved here with a
 // Goldfarb-Idnani dual active-set method:
-//   * Q (r x r, orthogonal) and R (packed upper triangle) of the active normals live in LDS;
-//   * a constraint is added with one Householder reflection (a rank-1 update of the trailing
-//     block of Q, no serial chain of rotations) and dropped with Givens rotations;
-//   * every O(r), O(r^2) or O(rows) loop is a lane loop; reductions are wave-level butterflies.
+//   * every constraint row the wave will ever look at is decoded ONCE into registers: lane l owns
+//     LSC rows l, l+64, ... (coalesced SoA loads) and structured slots l, l+64, ...; a scan is then
+//     pure LDS reads of control points + FMAs, followed by one arg-max butterfly;
+//   * the small vectors of the method (whitened normal, d = Q'a, step direction z, R^-1 d, duals,
+//     active list) are one register per lane, broadcast with readlane -- no LDS round trips;
+//   * Q (r x r orthogonal) and R (packed upper triangle) of the active normals live in LDS and are
+//     set up lazily: the ~60 % of agents whose unconstrained optimum is feasible never touch them;
+//   * a row is added with ONE Householder reflection (rank-1 update of the trailing block of Q)
+//     and dropped with Givens rotations.
 //
 // Compiled with -ffp-contract=off: the float32 expressions mirror octomap::point3d arithmetic of
 // the reference and must not be fused; the hot FP64 loops call fma() explicitly.
 //
-// The code is written against a tiny "wave" interface (lane_loop / sync / reductions) so that
-// the very same source also compiles as a lane-serial host build that the CPU-only unit tests
-// use to check the algorithm (tests/emul); that build is test infrastructure and is never
-// loaded by the product library.
+// The code is SPMD over a "wave" interface W: Reg<T> is one value per lane, w.each(f) runs f for
+// every lane, w.bcast / w.sum2 / w.max / w.min / w.any / w.first_lane / w.shift_down are the
+// cross-lane operations.  On the GPU Reg<T> is a VGPR and each() is the lane itself; the very same
+// source also compiles as a lane-serial host build (tests/emul: Reg<T> = T[64]) that the CPU-only
+// unit tests use to check the algorithm.  That build is test infrastructure and is never loaded by
+// the product library.  Rule that keeps both builds equivalent: inside each() only Regs, LDS
+// elements owned by the lane and lambda-local temporaries are written, and nothing written inside
+// an each() is read from another lane before it ends.
 #pragma once
 #include <math.h>
 #include <stdint.h>
@@ -30,16 +39,13 @@
 
 namespace dlscqp {
 
-struct Cand {
-    double v;
-    int code;
-};
+constexpr int KU = 4;   // LSC rows cached in registers per lane (K <= 256; the rest is read from HBM)
+constexpr int SU = 10;  // structured slots cached per lane (n_slots <= 640; the rest from HBM)
 
 struct MemLayout {
     int r_max, nx_max, ldq, nflag;
-    int oQ, oRp, oRinv, oN, oX, oNa, oD, oZ, oRv, oU, oBlo, oBhi;  // in doubles
-    int oA;     // byte offset of the int active list
-    int oFlag;  // byte offset of the row flags
+    int oQ, oRp, oN, oX, oBlo, oBhi;  // in doubles
+    int oFlag;                        // byte offset of the flags of rows beyond the register cache
     int bytes;
 };
 
@@ -49,22 +55,17 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax) {
     L.r_max = kp.dim * kp.f + nslk;
     L.nx_max = kp.dim * kp.P + nslk;
     L.ldq = L.r_max | 1;  // odd leading dimension: conflict-free column and row sweeps
-    L.nflag = kmax + 2 * kp.n_slots + nslk;
+    const int cold_rows = kmax > 64 * KU ? kmax - 64 * KU : 0;
+    const int cold_slots = kp.n_slots > 64 * SU ? kp.n_slots - 64 * SU : 0;
+    L.nflag = cold_rows + 2 * cold_slots;
     int o = 0;
     L.oQ = o; o += L.r_max * L.ldq;
     L.oRp = o; o += L.r_max * (L.r_max + 1) / 2;
-    L.oRinv = o; o += L.r_max;
     L.oN = o; o += kp.P * kp.f;
     L.oX = o; o += L.nx_max;
-    L.oNa = o; o += L.r_max;
-    L.oD = o; o += L.r_max;
-    L.oZ = o; o += L.r_max;
-    L.oRv = o; o += L.r_max;
-    L.oU = o; o += L.r_max + 1;
     L.oBlo = o; o += kp.nb;
     L.oBhi = o; o += kp.nb;
-    L.oA = o * 8;
-    L.oFlag = L.oA + 4 * (L.r_max + 1);
+    L.oFlag = o * 8;
     L.bytes = (L.oFlag + L.nflag + 15) & ~15;
     return L;
 }
@@ -75,14 +76,24 @@ DQ_FN double f32_norm3(float a, float b, float c) {
     return sqrt((double)sq);
 }
 
-#define DQ_RP(i, j) Rp[(j) * ((j) + 1) / 2 + (i)]
+constexpr uint32_t KEY_SKIP = 0xFFFFFFFFu;  // cached LSC row that is not part of the model
 
-template <class W>
+#define DQ_RP(i, j) Rp[(j) * ((j) + 1) / 2 + (i)]
+// element e of a per-lane vector spread over RC registers
+#define DQ_BC(arr, e) (RC == 1 ? w.bcast((arr)[0], (e)) : ((e) < 64 ? w.bcast((arr)[0], (e)) : w.bcast((arr)[RC - 1], (e) - 64)))
+
+template <int RC, class W>
 DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsigned char *mem,
                       const dlscqp_agent *agp, const RowsView &rows, int row_begin, int K,
                       const float *sfc, int max_slack_obs, int do_goal, int do_traj,
                       float *out_goal, int *out_goal_status, float *out_ctrl, double *out_x,
                       double *out_cost, double *out_slack_cost, int *out_status, int *out_iters) {
+    static_assert(RC == 1 || RC == 2, "r <= 128");
+    typedef typename W::template Reg<double> RegD;
+    typedef typename W::template Reg<float> RegF;
+    typedef typename W::template Reg<uint32_t> RegU;
+    typedef typename W::template Reg<int> RegI;
+
     const int dim = kp.dim, M = kp.M, n1 = kp.n1, P = kp.P, f = kp.f;
     const int n = n1 - 1;
     // ---- agent record (uniform) ---------------------------------------------------------------
@@ -105,6 +116,28 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     const float *Rpx = rows.px + row_begin, *Rpy = rows.py + row_begin, *Rpz = rows.pz + row_begin;
     const double *Rd = rows.d + row_begin;
     const uint32_t *Rkey = rows.key + row_begin;
+
+    // ---- LSC rows into registers: lane l owns rows l + 64u (coalesced loads, once) --------------
+    RegF cnx[KU], cny[KU], cnz[KU], cpx[KU], cpy[KU], cpz[KU];
+    RegD cd[KU];
+    RegU ckey[KU];
+    const int Kc = K < 64 * KU ? K : 64 * KU;  // cached rows
+#pragma unroll
+    for (int u = 0; u < KU; u++) {
+        if (u * 64 < Kc) {
+            w.each([&](int l) {
+                const int j = l + 64 * u;
+                if (j < Kc) {
+                    cnx[u].at(l) = Rnx[j]; cny[u].at(l) = Rny[j]; cnz[u].at(l) = Rnz[j];
+                    cpx[u].at(l) = Rpx[j]; cpy[u].at(l) = Rpy[j]; cpz[u].at(l) = Rpz[j];
+                    cd[u].at(l) = Rd[j];
+                    ckey[u].at(l) = Rkey[j];
+                } else {
+                    ckey[u].at(l) = KEY_SKIP;
+                }
+            });
+        }
+    }
 
     // ================================ goal LP ===================================================
     // min t in [0, 1+1e-5] s.t. a_r t + b_r >= 0 (goal_optimizer.cpp:138-198), closed form.
@@ -131,41 +164,47 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     }
                 }
             }
-            // goal_optimizer.cpp:176-195: last control point of the last segment, static obstacles
-            auto lp_row = [&](int j, double &a, double &b) -> bool {
-                uint32_t key = Rkey[j];
+            // goal_optimizer.cpp:176-195: last control point of the last segment, static obstacles.
+            // One pass over the rows: per-lane bounds, then max / min / any across the wave.
+            RegD llo, lhi;
+            RegI lbad, lviol;
+            auto lp_row = [&](uint32_t key, float nx, float ny, float nz, float qx, float qy, float qz, double dd,
+                              double &lo, double &hi, int &bad, int &viol) {
                 int m = key & 0xFF, i = (key >> 8) & 0xF, dyn = (key >> 12) & 1;
-                if (dyn || m != M - 1 || i != n) return false;
-                float nx = Rnx[j], ny = Rny[j], nz = Rnz[j];
-                if (f32_norm3(nx, ny, nz) < SP_EPSILON_FLOAT) return false;
-                float ox = wp[0] - Rpx[j], oy = wp[1] - Rpy[j];
-                a = (double)nx * (double)diff[0] + (double)ny * (double)diff[1];
-                b = -Rd[j] + (double)nx * (double)ox + (double)ny * (double)oy;
+                if (key == KEY_SKIP || dyn || m != M - 1 || i != n) return;
+                if (f32_norm3(nx, ny, nz) < SP_EPSILON_FLOAT) return;
+                float ox = wp[0] - qx, oy = wp[1] - qy;
+                double a = (double)nx * (double)diff[0] + (double)ny * (double)diff[1];
+                double b = -dd + (double)nx * (double)ox + (double)ny * (double)oy;
                 if (dim == 3) {
-                    float oz = wp[2] - Rpz[j];
+                    float oz = wp[2] - qz;
                     a += (double)nz * (double)diff[2];
                     b += (double)nz * (double)oz;
                 }
-                return true;
+                if (a > 0) { if (-b / a > lo) lo = -b / a; }
+                else if (a < 0) { if (-b / a < hi) hi = -b / a; }
+                else if (b < -CPLEX_FEAS_TOL) bad = 1;
+                // exception branch of goal_optimizer.cpp:63-77: does current_goal_point violate the row?
+                float e0 = cg[0] - qx, e1 = cg[1] - qy, e2 = cg[2] - qz;
+                float dot = nx * e0 + ny * e1 + nz * e2;  // float32 dot of float32 differences
+                if ((double)dot - dd < -SP_EPSILON_FLOAT) viol = 1;
             };
-            double lo2 = w.max(K, [&](int j) -> double {
-                double a, b;
-                if (!lp_row(j, a, b)) return -1e300;
-                return a > 0 ? -b / a : -1e300;
+            w.each([&](int l) {
+                double lo = -1e300, hi = 1e300;
+                int bad = 0, viol = 0;
+#pragma unroll
+                for (int u = 0; u < KU; u++)
+                    if (u * 64 < Kc)
+                        lp_row(ckey[u].at(l), cnx[u].at(l), cny[u].at(l), cnz[u].at(l), cpx[u].at(l), cpy[u].at(l),
+                               cpz[u].at(l), cd[u].at(l), lo, hi, bad, viol);
+                for (int j = 64 * KU + l; j < K; j += 64)  // rows beyond the register cache
+                    lp_row(Rkey[j], Rnx[j], Rny[j], Rnz[j], Rpx[j], Rpy[j], Rpz[j], Rd[j], lo, hi, bad, viol);
+                llo.at(l) = lo; lhi.at(l) = hi; lbad.at(l) = bad; lviol.at(l) = viol;
             });
-            double hi2 = w.min(K, [&](int j) -> double {
-                double a, b;
-                if (!lp_row(j, a, b)) return 1e300;
-                return a < 0 ? -b / a : 1e300;
-            });
-            double bad = w.max(K, [&](int j) -> double {
-                double a, b;
-                if (!lp_row(j, a, b)) return 0.0;
-                return (a == 0 && b < -CPLEX_FEAS_TOL) ? 1.0 : 0.0;
-            });
+            const double lo2 = w.max(llo), hi2 = w.min(lhi);
             if (lo2 > t_lo) t_lo = lo2;
             if (hi2 < t_hi) t_hi = hi2;
-            if (bad > 0.5 || t_lo > t_hi + CPLEX_FEAS_TOL) infeasible = 1;
+            if (w.any(lbad) || t_lo > t_hi + CPLEX_FEAS_TOL) infeasible = 1;
             if (!infeasible) {
                 float tf = (float)t_lo;  // Vector3::operator*(float), goal_optimizer.cpp:51
                 for (int k = 0; k < 3; k++) goal[k] = diff[k] * tf + wp[k];
@@ -179,47 +218,33 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                               (double)cg[k] < (double)bmax[k] + SP_EPSILON_FLOAT))
                             numerical_error = 0;
                 }
-                double viol = w.max(K, [&](int j) -> double {
-                    uint32_t key = Rkey[j];
-                    int m = key & 0xFF, i = (key >> 8) & 0xF, dyn = (key >> 12) & 1;
-                    if (dyn || m != M - 1 || i != n) return 0.0;
-                    float nx = Rnx[j], ny = Rny[j], nz = Rnz[j];
-                    if (f32_norm3(nx, ny, nz) < SP_EPSILON_FLOAT) return 0.0;
-                    float e0 = cg[0] - Rpx[j], e1 = cg[1] - Rpy[j], e2 = cg[2] - Rpz[j];
-                    float dot = nx * e0 + ny * e1 + nz * e2;
-                    double delta = (double)dot - Rd[j];
-                    return delta < -SP_EPSILON_FLOAT ? 1.0 : 0.0;
-                });
-                if (viol > 0.5) numerical_error = 0;
-                if (numerical_error) {
-                    goal_status = DLSCQP_GOAL_FALLBACK;  // goal = current_goal_point
-                } else {
-                    goal_status = DLSCQP_INFEASIBLE;
-                }
+                if (w.any(lviol)) numerical_error = 0;
+                goal_status = numerical_error ? DLSCQP_GOAL_FALLBACK : DLSCQP_INFEASIBLE;
             }
         }
-        w.lane_loop(3, [&](int k) { if (out_goal && goal_status != DLSCQP_INFEASIBLE) out_goal[k] = goal[k]; });
-        w.lane_loop(1, [&](int) { if (out_goal_status) *out_goal_status = goal_status; });
-        if (goal_status == DLSCQP_INFEASIBLE) {
+        w.each([&](int l) {
+            if (l < 3 && out_goal && goal_status != DLSCQP_INFEASIBLE) out_goal[l] = goal[l];
+            if (l == 0 && out_goal_status) *out_goal_status = goal_status;
             // the reference throws before trajOptimization is reached (traj_planner.cpp:491-496)
-            w.lane_loop(1, [&](int) { if (do_traj && out_status) *out_status = DLSCQP_INFEASIBLE; });
-            return;
-        }
+            if (l == 0 && goal_status == DLSCQP_INFEASIBLE && do_traj && out_status) *out_status = DLSCQP_INFEASIBLE;
+        });
+        if (goal_status == DLSCQP_INFEASIBLE) return;
     }
+    w.stamp(0);  // agent record, row cache, goal LP
     if (!do_traj) return;
 
     // ================================ trajectory QP =============================================
     double *base = reinterpret_cast<double *>(mem);
-    double *Q = base + lay.oQ, *Rp = base + lay.oRp, *Rinv = base + lay.oRinv, *Nl = base + lay.oN;
-    double *x = base + lay.oX, *na = base + lay.oNa, *d = base + lay.oD, *z = base + lay.oZ;
-    double *rv = base + lay.oRv, *u = base + lay.oU, *blo = base + lay.oBlo, *bhi = base + lay.oBhi;
-    int *A = reinterpret_cast<int *>(mem + lay.oA);
-    unsigned char *flag = mem + lay.oFlag;
+    double *Q = base + lay.oQ, *Rp = base + lay.oRp, *Nl = base + lay.oN, *x = base + lay.oX;
+    double *blo = base + lay.oBlo, *bhi = base + lay.oBhi;
+    unsigned char *cold_flag = mem + lay.oFlag;
     const int ldq = lay.ldq;
     const int rc = dim * f;      // whitened control-point dimension
     const int r = rc + nslk;     // whitened dimension
     const int nxc = dim * P;     // control-point variables
-    const int nflag = K + 2 * kp.n_slots + nslk;
+    const int n_slots = kp.n_slots;
+    const int Sc = n_slots < 64 * SU ? n_slots : 64 * SU;  // cached slots
+    const int cold_rows = K - Kc;
 
     // terminal segments, traj_optimizer.cpp:543-551 (float32 point difference)
     int T;
@@ -232,126 +257,271 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     int status = DLSCQP_OK;
     if (!kp.t_valid[T - 1]) status = DLSCQP_NUMERICAL;
     if (nslk > 0 && !(kp.w_s > 0)) status = DLSCQP_NUMERICAL;
+    if (r > 64 * RC) status = DLSCQP_NUMERICAL;  // the launcher picks RC; defensive
     if (status != DLSCQP_OK) {
-        w.lane_loop(1, [&](int) { if (out_status) *out_status = status; });
+        w.each([&](int l) { if (l == 0 && out_status) *out_status = status; });
         return;
     }
 
     const double *tN = kp.tabN + (size_t)(T - 1) * P * f;
     const double *tXs = kp.tabX0s + (size_t)(T - 1) * P * 3;
     const double *tXg = kp.tabX0g + (size_t)(T - 1) * P;
-    w.lane_loop(P * f, [&](int j) { Nl[j] = tN[j]; });
-    // unconstrained minimiser (start of the dual method)
-    w.lane_loop(nxc, [&](int j) {
-        int k = j / P, p = j - k * P;
-        x[j] = tXs[p * 3 + 0] * (double)pos[k] + tXs[p * 3 + 1] * (double)vel[k] +
-               tXs[p * 3 + 2] * (double)acc[k] + tXg[p] * (double)goal[k];
-    });
-    w.lane_loop(nslk, [&](int s) { x[nxc + s] = 0.0; });
-    w.lane_loop(r * ldq, [&](int j) {
-        int i = j / ldq, c = j - i * ldq;
-        Q[j] = (i == c) ? 1.0 : 0.0;
-    });
-    w.lane_loop(nflag, [&](int j) { flag[j] = 0; });
-    // per-agent bound table: boxes (world ∩ SFC), velocity, acceleration, comm range, waypoint
-    w.lane_loop(kp.nb, [&](int b) {
-        double lo, hi;
-        if (b < dim * M) {
-            int k = b / M, m = b - k * M;
-            lo = kp.world_min[k];
-            hi = kp.world_max[k];
-            if (kp.rsfc_mode && k == 2 && m == 0) { lo = -100; hi = 100; }  // traj_optimizer.cpp:254-258
-            if (kp.use_sfc && sfc) {  // Box::convertToLSCs, collision_constraints.cpp:66-87
-                double smin = (double)sfc[m * 6 + k], smax = (double)sfc[m * 6 + 3 + k];
-                if (smin > lo) lo = smin;
-                if (smax < hi) hi = smax;
-            }
-        } else if (b == dim * M) {
-            hi = max_vel * kp.vel_scale; lo = -hi;
-        } else if (b == dim * M + 1) {
-            hi = max_acc * kp.acc_scale; lo = -hi;
-        } else if (b == dim * M + 2) {
-            hi = 0.5 * kp.comm_range - radius; lo = -hi;  // traj_optimizer.cpp:495-500
-        } else {
-            int k = b - (dim * M + 3);
-            double cw = 0.5 * kp.comm_range - SP_EPSILON_FLOAT;  // traj_optimizer.cpp:507-510
-            lo = (double)wp[k] - cw; hi = (double)wp[k] + cw;
+    const Slot *slots = kp.slots;
+
+    // ---- structured slots into registers, unconstrained minimiser and bound table into LDS ------
+    RegU sidx[SU], scb[SU];  // 3 x 10-bit x-space indices (0x3FF = unused) | 3 x int8 coefficients + bsel
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+        if (u * 64 < Sc) {
+            w.each([&](int l) {
+                const int s = l + 64 * u;
+                uint32_t pi = 0xBFFFFFFFu, pc = 0;  // bit 31: no slot in this register
+                if (s < Sc) {
+                    Slot sl = slots[s];
+                    pi = (uint32_t)(sl.idx[0] & 0x3FF) | ((uint32_t)(sl.idx[1] & 0x3FF) << 10) | ((uint32_t)(sl.idx[2] & 0x3FF) << 20);
+                    pc = (uint32_t)(uint8_t)sl.coef[0] | ((uint32_t)(uint8_t)sl.coef[1] << 8) |
+                         ((uint32_t)(uint8_t)sl.coef[2] << 16) | ((uint32_t)sl.bsel << 24);
+                }
+                sidx[u].at(l) = pi;
+                scb[u].at(l) = pc;
+            });
         }
-        blo[b] = lo;
-        bhi[b] = hi;
+    }
+    w.each([&](int l) {
+        for (int j = l; j < nxc; j += 64) {
+            int k = j / P, p = j - k * P;
+            x[j] = tXs[p * 3 + 0] * (double)pos[k] + tXs[p * 3 + 1] * (double)vel[k] +
+                   tXs[p * 3 + 2] * (double)acc[k] + tXg[p] * (double)goal[k];
+        }
+        for (int s = l; s < nslk; s += 64) x[nxc + s] = 0.0;
+        for (int j = l; j < lay.nflag; j += 64) cold_flag[j] = 0;
+        // per-agent bound table: boxes (world and SFC), velocity, acceleration, comm range, waypoint
+        for (int b = l; b < kp.nb; b += 64) {
+            double lo, hi;
+            if (b < dim * M) {
+                int k = b / M, m = b - k * M;
+                lo = kp.world_min[k];
+                hi = kp.world_max[k];
+                if (kp.rsfc_mode && k == 2 && m == 0) { lo = -100; hi = 100; }  // traj_optimizer.cpp:254-258
+                if (kp.use_sfc && sfc) {  // Box::convertToLSCs, collision_constraints.cpp:66-87
+                    double smin = (double)sfc[m * 6 + k], smax = (double)sfc[m * 6 + 3 + k];
+                    if (smin > lo) lo = smin;
+                    if (smax < hi) hi = smax;
+                }
+            } else if (b == dim * M) {
+                hi = max_vel * kp.vel_scale; lo = -hi;
+            } else if (b == dim * M + 1) {
+                hi = max_acc * kp.acc_scale; lo = -hi;
+            } else if (b == dim * M + 2) {
+                hi = 0.5 * kp.comm_range - radius; lo = -hi;  // traj_optimizer.cpp:495-500
+            } else {
+                int k = b - (dim * M + 3);
+                double cw = 0.5 * kp.comm_range - SP_EPSILON_FLOAT;  // traj_optimizer.cpp:507-510
+                lo = (double)wp[k] - cw; hi = (double)wp[k] + cw;
+            }
+            blo[b] = lo;
+            bhi[b] = hi;
+        }
     });
+    // finish the LSC cache: rhs = d + n.p (traj_optimizer.cpp:427-439), drop rows that are not in the model
+#pragma unroll
+    for (int u = 0; u < KU; u++) {
+        if (u * 64 < Kc) {
+            w.each([&](int l) {
+                uint32_t key = ckey[u].at(l);
+                if (key == KEY_SKIP) return;
+                int m = key & 0xFF, i = (key >> 8) & 0xF;
+                float nx = cnx[u].at(l), ny = cny[u].at(l), nz = cnz[u].at(l);
+                if ((m == 0 && i < kp.phi) || f32_norm3(nx, ny, nz) < SP_EPSILON_FLOAT) {  // :417-424
+                    ckey[u].at(l) = KEY_SKIP;
+                    return;
+                }
+                double rhs = cd[u].at(l) + (double)nx * (double)cpx[u].at(l) + (double)ny * (double)cpy[u].at(l);
+                if (dim == 3) rhs += (double)nz * (double)cpz[u].at(l);
+                cd[u].at(l) = rhs;
+                uint32_t sl = key >> 16;
+                if (sl != 0xFFFFu && (int)sl >= nso) ckey[u].at(l) = key | 0xFFFF0000u;  // no such slack variable
+            });
+        }
+    }
     w.sync();
+    w.stamp(1);  // slot cache, x0, bounds
+
+    // per-lane state of the method
+    RegU fl_lsc, fl_slo, fl_shi, fl_slk;  // "skip" bits of the cached rows: active or accepted-infeasible
+    RegD na[RC], dv[RC], zv[RC], rv[RC], uu[RC], rinv[RC];
+    RegI act[RC];
+    w.each([&](int l) {
+        fl_lsc.at(l) = 0; fl_slo.at(l) = 0; fl_shi.at(l) = 0; fl_slk.at(l) = 0;
+#pragma unroll
+        for (int c = 0; c < RC; c++) {
+            uu[c].at(l) = 0; rinv[c].at(l) = 0; act[c].at(l) = -1; rv[c].at(l) = 0;
+            na[c].at(l) = 0; dv[c].at(l) = 0; zv[c].at(l) = 0;
+        }
+    });
 
     int q = 0, iters = 0, n_add = 0, n_drop = 0;
+    bool factors_ready = false;
     const int max_iter = kp.max_iter > 0 ? kp.max_iter : 20 * (r + 8) + 200;
-    const int n_items = K + kp.n_slots + nslk;
-    const Slot *slots = kp.slots;
+    // unified row codes: [0,K) LSC rows, K + 2 s + side structured slots, K + 2 n_slots + s slack bounds
+    const int code_slack0 = K + 2 * n_slots;
+
+    auto set_skip = [&](int code, bool on) {
+        if (code < Kc) {
+            const int owner = code & 63, u = code >> 6;
+            w.each([&](int l) { if (l == owner) fl_lsc.at(l) = on ? (fl_lsc.at(l) | (1u << u)) : (fl_lsc.at(l) & ~(1u << u)); });
+        } else if (code < K) {
+            w.each([&](int l) { if (l == 0) cold_flag[code - Kc] = on ? 1 : 0; });
+        } else if (code < code_slack0) {
+            const int s = (code - K) >> 1, side = (code - K) & 1;
+            if (s < Sc) {
+                const int owner = s & 63, u = s >> 6;
+                w.each([&](int l) {
+                    if (l == owner) {
+                        uint32_t &fr = side ? fl_shi.at(l) : fl_slo.at(l);
+                        fr = on ? (fr | (1u << u)) : (fr & ~(1u << u));
+                    }
+                });
+            } else {
+                w.each([&](int l) { if (l == 0) cold_flag[cold_rows + 2 * (s - Sc) + side] = on ? 1 : 0; });
+            }
+        } else {
+            const int s = code - code_slack0;
+            const int owner = s & 63, u = s >> 6;
+            w.each([&](int l) { if (l == owner) fl_slk.at(l) = on ? (fl_slk.at(l) | (1u << u)) : (fl_slk.at(l) & ~(1u << u)); });
+        }
+        w.sync();
+    };
 
     for (;;) {
         // ---- most violated inactive row ---------------------------------------------------------
-        Cand best = w.argmax(n_items, [&](int j) -> Cand {
-            Cand c;
-            c.v = -1e300;
-            c.code = -1;
-            if (j < K) {
-                if (flag[j]) return c;
-                uint32_t key = Rkey[j];
-                int m = key & 0xFF, i = (key >> 8) & 0xF;
-                if (m == 0 && i < kp.phi) return c;  // traj_optimizer.cpp:417-419
-                float nx = Rnx[j], ny = Rny[j], nz = Rnz[j];
-                if (f32_norm3(nx, ny, nz) < SP_EPSILON_FLOAT) return c;  // :422-424
-                int p = m * n1 + i;
+        RegD bestv;
+        RegI bestc;
+        w.each([&](int l) {
+            double bv = 0.0;
+            int bc = -1;
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                if (u * 64 < Kc) {
+                    const uint32_t key = ckey[u].at(l);
+                    if (key != KEY_SKIP && !((fl_lsc.at(l) >> u) & 1)) {
+                        const int m = key & 0xFF, i = (key >> 8) & 0xF;
+                        const int p = m * n1 + i;
+                        double val = (double)cnx[u].at(l) * x[p];
+                        val = fma((double)cny[u].at(l), x[P + p], val);
+                        if (dim == 3) val = fma((double)cnz[u].at(l), x[2 * P + p], val);
+                        const uint32_t sl = key >> 16;
+                        if (sl != 0xFFFFu) val -= x[nxc + (int)sl * M + m];
+                        const double v = cd[u].at(l) - val;
+                        if (v > bv) { bv = v; bc = l + 64 * u; }
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < SU; u++) {
+                if (u * 64 < Sc) {
+                    const uint32_t pi = sidx[u].at(l), pc = scb[u].at(l);
+                    if (!(pi & 0x80000000u)) {
+                        const int i0 = pi & 0x3FF, i1 = (pi >> 10) & 0x3FF, i2 = (pi >> 20) & 0x3FF;
+                        double val = (double)(int8_t)(pc & 0xFF) * x[i0];
+                        if (i1 != 0x3FF) val = fma((double)(int8_t)((pc >> 8) & 0xFF), x[i1], val);
+                        if (i2 != 0x3FF) val = fma((double)(int8_t)((pc >> 16) & 0xFF), x[i2], val);
+                        const int bs = pc >> 24;
+                        const double vlo = blo[bs] - val, vhi = val - bhi[bs];
+                        const int s = l + 64 * u;
+                        if (vlo > bv && !((fl_slo.at(l) >> u) & 1)) { bv = vlo; bc = K + 2 * s; }
+                        if (vhi > bv && !((fl_shi.at(l) >> u) & 1)) { bv = vhi; bc = K + 2 * s + 1; }
+                    }
+                }
+            }
+            for (int s = l; s < nslk; s += 64) {  // eps <= 0 (traj_optimizer.cpp:276)
+                const double v = x[nxc + s];
+                if (v > bv && !((fl_slk.at(l) >> (s >> 6)) & 1)) { bv = v; bc = code_slack0 + s; }
+            }
+            // rows beyond the register cache: straight from HBM (rare: K > 256 or > 640 slots)
+            for (int j = Kc + l; j < K; j += 64) {
+                if (cold_flag[j - Kc]) continue;
+                const uint32_t key = Rkey[j];
+                const int m = key & 0xFF, i = (key >> 8) & 0xF;
+                if (m == 0 && i < kp.phi) continue;
+                const float nx = Rnx[j], ny = Rny[j], nz = Rnz[j];
+                if (f32_norm3(nx, ny, nz) < SP_EPSILON_FLOAT) continue;
+                const int p = m * n1 + i;
                 double val = (double)nx * x[p] + (double)ny * x[P + p];
                 double rhs = Rd[j] + (double)nx * (double)Rpx[j] + (double)ny * (double)Rpy[j];
-                if (dim == 3) {
-                    val += (double)nz * x[2 * P + p];
-                    rhs += (double)nz * (double)Rpz[j];
-                }
-                uint32_t sl = key >> 16;
+                if (dim == 3) { val += (double)nz * x[2 * P + p]; rhs += (double)nz * (double)Rpz[j]; }
+                const uint32_t sl = key >> 16;
                 if (sl != 0xFFFFu && (int)sl < nso) val -= x[nxc + (int)sl * M + m];
-                c.v = rhs - val;
-                c.code = j;
-            } else if (j < K + kp.n_slots) {
-                int s = j - K;
-                Slot sl = slots[s];
+                const double v = rhs - val;
+                if (v > bv) { bv = v; bc = j; }
+            }
+            for (int s = Sc + l; s < n_slots; s += 64) {
+                const Slot sl = slots[s];
                 double val = 0;
                 for (int t = 0; t < 3; t++)
                     if (sl.idx[t] >= 0) val += (double)sl.coef[t] * x[sl.idx[t]];
-                double vlo = blo[sl.bsel] - val, vhi = val - bhi[sl.bsel];
-                if (flag[K + 2 * s]) vlo = -1e300;
-                if (flag[K + 2 * s + 1]) vhi = -1e300;
-                if (vlo >= vhi) { c.v = vlo; c.code = K + 2 * s; }
-                else { c.v = vhi; c.code = K + 2 * s + 1; }
-            } else {
-                int s = j - K - kp.n_slots;
-                if (flag[K + 2 * kp.n_slots + s]) return c;
-                c.v = x[nxc + s];  // eps <= 0
-                c.code = K + 2 * kp.n_slots + s;
+                const double vlo = blo[sl.bsel] - val, vhi = val - bhi[sl.bsel];
+                if (vlo > bv && !cold_flag[cold_rows + 2 * (s - Sc)]) { bv = vlo; bc = K + 2 * s; }
+                if (vhi > bv && !cold_flag[cold_rows + 2 * (s - Sc) + 1]) { bv = vhi; bc = K + 2 * s + 1; }
             }
-            return c;
+            bestv.at(l) = bv;
+            bestc.at(l) = bc;
         });
-        if (!(best.v > VIOL_TOL) || best.code < 0) break;  // optimal
+        double viol = w.max(bestv);  // = -(a.x - b) of the most violated row
+        w.stamp(2);                  // row scan + arg-max
+        if (!(viol > VIOL_TOL)) break;  // optimal
+        RegI is_top;
+        w.each([&](int l) { is_top.at(l) = (bestv.at(l) == viol && bestc.at(l) >= 0) ? 1 : 0; });
+        const int owner_lane = w.first_lane(is_top);
+        const int ip = w.bcast(bestc, owner_lane);
+
+        if (!factors_ready) {
+            // first violated row: set up the factors (agents that never get here skip all of this)
+            w.each([&](int l) {
+                for (int j = l; j < P * f; j += 64) Nl[j] = tN[j];
+                for (int j = l; j < r * ldq; j += 64) {
+                    int i = j / ldq, c = j - i * ldq;
+                    Q[j] = (i == c) ? 1.0 : 0.0;
+                }
+            });
+            w.sync();
+            factors_ready = true;
+            w.stamp(1);
+        }
 
         // ---- decode the row into sparse x-space entries (uniform) -------------------------------
-        const int ip = best.code;
-        int cnt = 0, ek[3] = {0, 0, 0}, ep[3] = {0, 0, 0}, sidx = -1;
+        int ek[3] = {-1, -1, -1}, ep[3] = {0, 0, 0}, sidx_row = -1;
         double cf[3] = {0, 0, 0}, row_scale = 1.0;
         int axes_mask = 0;
         if (ip < K) {
-            uint32_t key = Rkey[ip];
-            int m = key & 0xFF, i = (key >> 8) & 0xF;
-            int p = m * n1 + i;
-            float nn[3] = {Rnx[ip], Rny[ip], Rnz[ip]};
+            uint32_t key = 0;
+            float nn[3] = {0, 0, 0};
+            if (ip < Kc) {
+                const int own = ip & 63, u = ip >> 6;
+#pragma unroll
+                for (int uq = 0; uq < KU; uq++)
+                    if (uq == u) {
+                        key = w.bcast(ckey[uq], own);
+                        nn[0] = w.bcast(cnx[uq], own); nn[1] = w.bcast(cny[uq], own); nn[2] = w.bcast(cnz[uq], own);
+                    }
+            } else {
+                key = Rkey[ip];
+                nn[0] = Rnx[ip]; nn[1] = Rny[ip]; nn[2] = Rnz[ip];
+                uint32_t sl = key >> 16;
+                if (sl != 0xFFFFu && (int)sl >= nso) key |= 0xFFFF0000u;
+            }
+            const int m = key & 0xFF, i = (key >> 8) & 0xF;
             for (int k = 0; k < dim; k++) {
-                ek[cnt] = k; ep[cnt] = p; cf[cnt] = (double)nn[k]; cnt++;
+                ek[k] = k; ep[k] = m * n1 + i; cf[k] = (double)nn[k];
                 axes_mask |= 1 << k;
             }
-            uint32_t sl = key >> 16;
-            if (sl != 0xFFFFu && (int)sl < nso) sidx = (int)sl * M + m;
-        } else if (ip < K + 2 * kp.n_slots) {
-            int s = (ip - K) >> 1, side = (ip - K) & 1;
-            Slot sl = slots[s];
-            double sg = side == 0 ? 1.0 : -1.0;  // val >= lo   |   -val >= -hi
+            const uint32_t sl = key >> 16;
+            if (sl != 0xFFFFu) sidx_row = (int)sl * M + m;
+        } else if (ip < code_slack0) {
+            const int s = (ip - K) >> 1, side = (ip - K) & 1;
+            const Slot sl = slots[s];  // uniform load of 16 B (L2-resident table)
+            const double sg = side == 0 ? 1.0 : -1.0;  // val >= lo   |   -val >= -hi
+            int cnt = 0;
             for (int t = 0; t < 3; t++)
                 if (sl.idx[t] >= 0) {
                     int k = sl.idx[t] / P;
@@ -360,75 +530,145 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 }
             row_scale = (double)sl.scale;
         } else {
-            sidx = ip - K - 2 * kp.n_slots;
+            sidx_row = ip - code_slack0;
         }
-        // whitened normal na = N' a  (slack part: -sigma)
-        w.lane_loop(r, [&](int l) {
-            double v = 0;
-            if (l < rc) {
-                int k = l / f, j = l - k * f;
-                for (int e = 0; e < 3; e++)  // unused entries carry cf = 0
-                    if (ek[e] == k) v = fma(cf[e], Nl[ep[e] * f + j], v);
-            } else if (l - rc == sidx) {
-                v = -kp.sigma[sidx % M];
+        // whitened normal na = N' a  (slack part: -sigma), one element per lane
+        w.each([&](int l) {
+#pragma unroll
+            for (int c = 0; c < RC; c++) {
+                const int e = l + 64 * c;
+                double v = 0;
+                if (e < rc) {
+                    const int k = e / f, j = e - k * f;
+#pragma unroll
+                    for (int t = 0; t < 3; t++)
+                        if (ek[t] == k) v = fma(cf[t], Nl[ep[t] * f + j], v);
+                } else if (e - rc == sidx_row) {
+                    v = -kp.sigma[sidx_row % M];
+                }
+                na[c].at(l) = v;
             }
-            na[l] = v;
         });
-        w.sync();
+        w.stamp(3);  // decode + whitened normal
 
-        double viol = best.v;  // = -(a.x - b) > 0
         double uq = 0.0;
         bool resolved = false;
         while (!resolved) {
             if (++iters > max_iter) { status = DLSCQP_ITERATION_LIMIT; break; }
             // d = Q' na   (na is non-zero only in the touched axis blocks and one slack entry)
-            w.lane_loop(r, [&](int j) {
-                double s = 0;
-                for (int k = 0; k < dim; k++)
-                    if (axes_mask & (1 << k)) {
-                        const int i0 = k * f;
-                        for (int i = i0; i < i0 + f; i++) s = fma(Q[i * ldq + j], na[i], s);
-                    }
-                if (sidx >= 0) s = fma(Q[(rc + sidx) * ldq + j], na[rc + sidx], s);
-                d[j] = s;
+            w.each([&](int l) {
+#pragma unroll
+                for (int c = 0; c < RC; c++) dv[c].at(l) = 0.0;
             });
-            w.sync();
-            // z = Q2 d2, |d2|^2, |d|^2
-            w.lane_loop(r, [&](int i) {
-                double s = 0;
-                for (int j = q; j < r; j++) s = fma(Q[i * ldq + j], d[j], s);
-                z[i] = s;
-            });
-            const double dd2 = w.sum(r, [&](int j) -> double { return j >= q ? d[j] * d[j] : 0.0; });
-            const double dall = w.sum(r, [&](int j) -> double { return d[j] * d[j]; });
-            // rv = R^{-1} d1  (column-oriented back substitution)
-            w.lane_loop(q, [&](int i) { rv[i] = d[i]; });
-            w.sync();
-            for (int k = q - 1; k >= 0; k--) {
-                const double rk = rv[k] * Rinv[k];
-                w.sync();
-                w.lane_loop(k + 1, [&](int i) {
-                    if (i == k) rv[k] = rk;
-                    else rv[i] = fma(-DQ_RP(i, k), rk, rv[i]);
-                });
-                w.sync();
+            for (int k = 0; k < dim; k++) {
+                if (!(axes_mask & (1 << k))) continue;
+                for (int i = k * f; i < (k + 1) * f; i++) {
+                    const double nai = DQ_BC(na, i);
+                    w.each([&](int l) {
+#pragma unroll
+                        for (int c = 0; c < RC; c++) {
+                            const int j = l + 64 * c;
+                            if (j < r) dv[c].at(l) = fma(Q[i * ldq + j], nai, dv[c].at(l));
+                        }
+                    });
+                }
             }
-            // step lengths
-            Cand r1 = w.argmin(q, [&](int k) -> Cand {
-                Cand c;
-                c.code = k;
-                c.v = rv[k] > 0 ? u[k] / rv[k] : 1e300;
-                return c;
+            if (sidx_row >= 0) {
+                const int i = rc + sidx_row;
+                const double nai = DQ_BC(na, i);
+                w.each([&](int l) {
+#pragma unroll
+                    for (int c = 0; c < RC; c++) {
+                        const int j = l + 64 * c;
+                        if (j < r) dv[c].at(l) = fma(Q[i * ldq + j], nai, dv[c].at(l));
+                    }
+                });
+            }
+            w.stamp(4);  // d = Q' na
+            // z = Q2 d2, |d2|^2, |d|^2
+            w.each([&](int l) {
+#pragma unroll
+                for (int c = 0; c < RC; c++) zv[c].at(l) = 0.0;
             });
-            const double t1 = (q > 0 && r1.code >= 0) ? r1.v : 1e300;
-            const int l = r1.code;
+            for (int j = q; j < r; j++) {
+                const double dj = DQ_BC(dv, j);
+                w.each([&](int l) {
+#pragma unroll
+                    for (int c = 0; c < RC; c++) {
+                        const int i = l + 64 * c;
+                        if (i < r) zv[c].at(l) = fma(Q[i * ldq + j], dj, zv[c].at(l));
+                    }
+                });
+            }
+            RegD s_d2, s_all;
+            w.each([&](int l) {
+                double a2 = 0, aa = 0;
+#pragma unroll
+                for (int c = 0; c < RC; c++) {
+                    const int j = l + 64 * c;
+                    if (j < r) {
+                        const double t = dv[c].at(l) * dv[c].at(l);
+                        aa += t;
+                        if (j >= q) a2 += t;
+                    }
+                }
+                s_d2.at(l) = a2;
+                s_all.at(l) = aa;
+            });
+            double dd2, dall;
+            w.sum2(s_d2, s_all, dd2, dall);
+            w.stamp(5);  // z, |d2|^2, |d|^2
+            // rv = R^{-1} d1  (column-oriented back substitution, one register per lane)
+            w.each([&](int l) {
+#pragma unroll
+                for (int c = 0; c < RC; c++) rv[c].at(l) = dv[c].at(l);
+            });
+            for (int k = q - 1; k >= 0; k--) {
+                const double rk = DQ_BC(rv, k) * DQ_BC(rinv, k);
+                w.each([&](int l) {
+#pragma unroll
+                    for (int c = 0; c < RC; c++) {
+                        const int i = l + 64 * c;
+                        if (i == k) rv[c].at(l) = rk;
+                        else if (i < k) rv[c].at(l) = fma(-DQ_RP(i, k), rk, rv[c].at(l));
+                    }
+                });
+            }
+            w.stamp(6);  // back substitution
+            // step lengths: t1 = min u_k / r_k over r_k > 0 (dual), t2 = viol / |d2|^2 (primal)
+            double t1 = 1e300;
+            int ldrop = -1;
+            if (q > 0) {
+                RegD lt1;
+                RegI lk;
+                w.each([&](int l) {
+                    double bt = 1e300;
+                    int bk = -1;
+#pragma unroll
+                    for (int c = 0; c < RC; c++) {
+                        const int k = l + 64 * c;
+                        if (k < q && rv[c].at(l) > 0) {
+                            const double t = uu[c].at(l) / rv[c].at(l);
+                            if (t < bt) { bt = t; bk = k; }
+                        }
+                    }
+                    lt1.at(l) = bt;
+                    lk.at(l) = bk;
+                });
+                t1 = w.min(lt1);
+                if (t1 < 1e300) {
+                    RegI is_min;
+                    w.each([&](int l) { is_min.at(l) = (lt1.at(l) == t1 && lk.at(l) >= 0) ? 1 : 0; });
+                    ldrop = w.bcast(lk, w.first_lane(is_min));
+                }
+            }
             const bool dependent = !(dd2 > DEP_TOL * dall) || !(dd2 > 0);
             const double t2 = dependent ? 1e300 : viol / dd2;
+            w.stamp(7);  // ratio test
             if (t1 >= 1e300 && t2 >= 1e300) {
                 // no step possible: infeasible, unless within CPLEX's feasibility tolerance
                 if (viol * row_scale <= CPLEX_FEAS_TOL) {
-                    w.lane_loop(1, [&](int) { flag[ip] = 2; });
-                    w.sync();
+                    set_skip(ip, true);
                     resolved = true;
                     break;
                 }
@@ -438,85 +678,152 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             const double t = t1 < t2 ? t1 : t2;
             if (!dependent) {
                 // primal step  x += t N z
-                w.lane_loop(nxc, [&](int j) {
-                    int k = j / P, p = j - k * P;
-                    double s = 0;
-                    for (int c = 0; c < f; c++) s = fma(Nl[p * f + c], z[k * f + c], s);
-                    x[j] = fma(t, s, x[j]);
+                for (int k = 0; k < dim; k++) {
+                    for (int p0 = 0; p0 < P; p0 += 64) {
+                        RegD sacc;
+                        w.each([&](int l) { sacc.at(l) = 0.0; });
+                        for (int c = 0; c < f; c++) {
+                            const int e = k * f + c;
+                            const double zc = DQ_BC(zv, e);
+                            w.each([&](int l) {
+                                const int p = p0 + l;
+                                if (p < P) sacc.at(l) = fma(Nl[p * f + c], zc, sacc.at(l));
+                            });
+                        }
+                        w.each([&](int l) {
+                            const int p = p0 + l;
+                            if (p < P) x[k * P + p] = fma(t, sacc.at(l), x[k * P + p]);
+                        });
+                    }
+                }
+                w.each([&](int l) {
+#pragma unroll
+                    for (int c = 0; c < RC; c++) {
+                        const int e = l + 64 * c;
+                        if (e >= rc && e < r) {
+                            const int s = e - rc;
+                            x[nxc + s] = fma(t * kp.sigma[s % M], zv[c].at(l), x[nxc + s]);
+                        }
+                    }
                 });
-                w.lane_loop(nslk, [&](int s) { x[nxc + s] += t * kp.sigma[s % M] * z[rc + s]; });
                 viol -= t * dd2;
             }
-            w.lane_loop(q, [&](int k) { u[k] = fma(-t, rv[k], u[k]); });
+            w.each([&](int l) {
+#pragma unroll
+                for (int c = 0; c < RC; c++)
+                    if (l + 64 * c < q) uu[c].at(l) = fma(-t, rv[c].at(l), uu[c].at(l));
+            });
             uq += t;
             w.sync();
+            w.stamp(8);  // primal / dual step
             if (!dependent && t2 <= t1) {
                 // ---- add row ip: Householder reflection of d2 onto e_1 ---------------------------
-                const double dq = d[q];
+                const double dq = DQ_BC(dv, q);
                 const double nrm = sqrt(dd2);
                 const double alpha = dq > 0 ? -nrm : nrm;
                 const double v0 = dq - alpha;
                 const double beta = 1.0 / (nrm * (nrm + fabs(dq)));  // 2 / v'v
-                w.lane_loop(r, [&](int i) {
-                    double *qi = Q + i * ldq;
-                    const double g = beta * (z[i] - alpha * qi[q]);
-                    qi[q] = fma(-g, v0, qi[q]);
-                    for (int j = q + 1; j < r; j++) qi[j] = fma(-g, d[j], qi[j]);
-                });
-                w.lane_loop(q + 1, [&](int i) {
-                    if (i < q) DQ_RP(i, q) = d[i];
-                    else {
-                        DQ_RP(q, q) = alpha;
-                        Rinv[q] = 1.0 / alpha;
-                        u[q] = uq;
-                        A[q] = ip;
-                        flag[ip] = 1;
+                RegD g[RC];
+                w.each([&](int l) {
+#pragma unroll
+                    for (int c = 0; c < RC; c++) {
+                        const int i = l + 64 * c;
+                        g[c].at(l) = 0.0;
+                        if (i < r) {
+                            double *qi = Q + i * ldq;
+                            const double gi = beta * (zv[c].at(l) - alpha * qi[q]);
+                            g[c].at(l) = gi;
+                            qi[q] = fma(-gi, v0, qi[q]);
+                        }
                     }
                 });
-                w.sync();
+                for (int j = q + 1; j < r; j++) {
+                    const double dj = DQ_BC(dv, j);
+                    w.each([&](int l) {
+#pragma unroll
+                        for (int c = 0; c < RC; c++) {
+                            const int i = l + 64 * c;
+                            if (i < r) Q[i * ldq + j] = fma(-g[c].at(l), dj, Q[i * ldq + j]);
+                        }
+                    });
+                }
+                w.each([&](int l) {
+#pragma unroll
+                    for (int c = 0; c < RC; c++) {
+                        const int i = l + 64 * c;
+                        if (i < q) DQ_RP(i, q) = dv[c].at(l);
+                        else if (i == q) {
+                            DQ_RP(q, q) = alpha;
+                            rinv[c].at(l) = 1.0 / alpha;
+                            uu[c].at(l) = uq;
+                            act[c].at(l) = ip;
+                        }
+                    }
+                });
+                set_skip(ip, true);
                 q++;
                 n_add++;
                 resolved = true;
+                w.stamp(9);  // Householder add
             } else {
-                // ---- drop active row l: delete column l of R, restore the triangle with Givens ----
-                w.lane_loop(1, [&](int) { flag[A[l]] = 0; });
-                w.sync();
-                for (int tcol = l; tcol < q - 1; tcol++) {
+                // ---- drop active row ldrop: delete column l of R, restore the triangle with Givens ----
+                const int lcol = ldrop;
+                set_skip(DQ_BC(act, lcol), false);
+                for (int tcol = lcol; tcol < q - 1; tcol++) {
                     // rotation from old column tcol+1, rows (tcol, tcol+1)
                     const double a = DQ_RP(tcol, tcol + 1), b = DQ_RP(tcol + 1, tcol + 1);
                     const double rho = sqrt(a * a + b * b);
                     const double cs = rho > 0 ? a / rho : 1.0, sn = rho > 0 ? b / rho : 0.0;
                     w.sync();
-                    w.lane_loop(q - 1 - tcol, [&](int cc) {  // old columns tcol+1 .. q-1
-                        int c = tcol + 1 + cc;
-                        double r0 = DQ_RP(tcol, c), r1v = DQ_RP(tcol + 1, c);
-                        DQ_RP(tcol, c) = cs * r0 + sn * r1v;
-                        DQ_RP(tcol + 1, c) = -sn * r0 + cs * r1v;
-                    });
-                    w.lane_loop(r, [&](int i) {
-                        double *qi = Q + i * ldq;
-                        double q0 = qi[tcol], q1 = qi[tcol + 1];
-                        qi[tcol] = cs * q0 + sn * q1;
-                        qi[tcol + 1] = -sn * q0 + cs * q1;
+                    w.each([&](int l) {
+                        for (int c = tcol + 1 + l; c < q; c += 64) {  // old columns tcol+1 .. q-1
+                            double r0 = DQ_RP(tcol, c), r1v = DQ_RP(tcol + 1, c);
+                            DQ_RP(tcol, c) = cs * r0 + sn * r1v;
+                            DQ_RP(tcol + 1, c) = -sn * r0 + cs * r1v;
+                        }
+                        for (int i = l; i < r; i += 64) {
+                            double *qi = Q + i * ldq;
+                            double q0 = qi[tcol], q1 = qi[tcol + 1];
+                            qi[tcol] = cs * q0 + sn * q1;
+                            qi[tcol + 1] = -sn * q0 + cs * q1;
+                        }
                     });
                     w.sync();
                 }
-                // shift columns l+1..q-1 left by one (packed storage: serial over columns)
-                for (int c = l + 1; c < q; c++) {
-                    w.lane_loop(c, [&](int i) { Rp[(c - 1) * c / 2 + i] = DQ_RP(i, c); });
+                // shift columns lcol+1..q-1 left by one (packed storage: serial over columns)
+                for (int c = lcol + 1; c < q; c++) {
+                    w.each([&](int l) {
+                        for (int i = l; i < c; i += 64) Rp[(c - 1) * c / 2 + i] = DQ_RP(i, c);
+                    });
                     w.sync();
                 }
-                w.lane_loop(1, [&](int) {
-                    for (int c = l; c < q - 1; c++) {
-                        u[c] = u[c + 1];
-                        A[c] = A[c + 1];
+                // compact the per-lane duals and the active list: element k takes element k+1, k >= lcol
+                {
+                    RegD nu[RC];
+                    RegI nact[RC];
+#pragma unroll
+                    for (int c = 0; c < RC; c++) {
+                        w.shift_down(uu, c, RC, nu[c]);
+                        w.shift_down(act, c, RC, nact[c]);
+                    }
+                    w.each([&](int l) {
+#pragma unroll
+                        for (int c = 0; c < RC; c++) {
+                            const int k = l + 64 * c;
+                            if (k >= lcol && k < q - 1) { uu[c].at(l) = nu[c].at(l); act[c].at(l) = nact[c].at(l); }
+                        }
+                    });
+                }
+                q--;
+                w.each([&](int l) {
+#pragma unroll
+                    for (int c = 0; c < RC; c++) {
+                        const int k = l + 64 * c;
+                        if (k < q) rinv[c].at(l) = 1.0 / DQ_RP(k, k);
                     }
                 });
-                w.sync();
-                q--;
-                w.lane_loop(q, [&](int k) { Rinv[k] = 1.0 / DQ_RP(k, k); });
-                w.sync();
                 n_drop++;
+                w.stamp(10);  // Givens drop
                 // loop again with the same row ip (step 2(a) of Goldfarb-Idnani)
             }
         }
@@ -524,54 +831,69 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     }
 
     // ================================ read-out ==================================================
-    w.lane_loop(1, [&](int) {
-        if (out_status) *out_status = status;
-        if (out_iters) {
-            out_iters[0] = iters;
-            out_iters[1] = n_add;
-            out_iters[2] = n_drop;
-            out_iters[3] = q;
+    w.each([&](int l) {
+        if (l == 0) {
+            if (out_status) *out_status = status;
+            if (out_iters) {
+                out_iters[0] = iters;
+                out_iters[1] = n_add;
+                out_iters[2] = n_drop;
+                out_iters[3] = q;
+            }
         }
     });
     if (status != DLSCQP_OK) return;
-    // traj_optimizer.cpp:69-83: point3d(float) control points, z = world_z_2d in 2-D
-    if (out_ctrl)
-        w.lane_loop(M * n1 * 3, [&](int j) {
-            int p = j / 3, k = j - p * 3;
-            out_ctrl[j] = k < dim ? (float)x[k * P + p] : (float)kp.z_2d;
-        });
-    if (out_x) w.lane_loop(nxc + nslk, [&](int j) { out_x[j] = x[j]; });
-    // traj_optimizer.cpp:85-106
-    if (out_slack_cost)
-        w.lane_loop(max_slack_obs, [&](int s) {
-            double sc = 0;
-            if (s < nso)
-                for (int m = 0; m < M; m++) sc += fabs(x[nxc + s * M + m]);
-            out_slack_cost[s] = sc;
-        });
-    // cplex.getObjValue(), traj_optimizer.cpp:109, objective at :286-331
-    if (out_cost) {
-        double cj = w.sum(nxc, [&](int j) -> double {
-            int k = j / P, p = j - k * P, m = p / n1, i = p - m * n1;
-            const double *seg = x + k * P + m * n1;
-            double s = 0;
-            for (int c = 0; c < n1; c++) s += kp.Qb[i * n1 + c] * seg[c];
-            double term = x[j] * s;
-            if (i == n && m >= M - T) {
-                double e = x[j] - (double)goal[k];
-                term += kp.w_t * e * e;
+    RegD cj, cs2;
+    w.each([&](int l) {
+        // traj_optimizer.cpp:69-83: point3d(float) control points, z = world_z_2d in 2-D
+        if (out_ctrl)
+            for (int j = l; j < M * n1 * 3; j += 64) {
+                int p = j / 3, k = j - p * 3;
+                out_ctrl[j] = k < dim ? (float)x[k * P + p] : (float)kp.z_2d;
             }
-            return term;
-        });
-        double cs = w.sum(nslk, [&](int s) -> double {
-            int m = s % M;
-            double e = x[nxc + s];
-            return kp.w_s * ((double)(M - m) / M) * e * e;
-        });
-        w.lane_loop(1, [&](int) { *out_cost = cj + cs; });
+        if (out_x)
+            for (int j = l; j < nxc + nslk; j += 64) out_x[j] = x[j];
+        // traj_optimizer.cpp:85-106
+        if (out_slack_cost)
+            for (int s = l; s < max_slack_obs; s += 64) {
+                double sc = 0;
+                if (s < nso)
+                    for (int m = 0; m < M; m++) sc += fabs(x[nxc + s * M + m]);
+                out_slack_cost[s] = sc;
+            }
+        // cplex.getObjValue(), traj_optimizer.cpp:109, objective at :286-331
+        double a1 = 0, a2 = 0;
+        if (out_cost) {
+            for (int j = l; j < nxc; j += 64) {
+                int k = j / P, p = j - k * P, m = p / n1, i = p - m * n1;
+                const double *seg = x + k * P + m * n1;
+                double s = 0;
+                for (int c = 0; c < n1; c++) s += kp.Qb[i * n1 + c] * seg[c];
+                double term = x[j] * s;
+                if (i == n && m >= M - T) {
+                    double e = x[j] - (double)goal[k];
+                    term += kp.w_t * e * e;
+                }
+                a1 += term;
+            }
+            for (int s = l; s < nslk; s += 64) {
+                int m = s % M;
+                double e = x[nxc + s];
+                a2 += kp.w_s * ((double)(M - m) / M) * e * e;
+            }
+        }
+        cj.at(l) = a1;
+        cs2.at(l) = a2;
+    });
+    if (out_cost) {
+        double t1c, t2c;
+        w.sum2(cj, cs2, t1c, t2c);
+        w.each([&](int l) { if (l == 0) *out_cost = t1c + t2c; });
     }
+    w.stamp(11);  // read-out
 }
 
 #undef DQ_RP
+#undef DQ_BC
 
 }  // namespace dlscqp

@@ -188,6 +188,8 @@ typedef struct dlscqp_device_batch {
     double *out_slack_cost;         /* [n_agents][max_slack_obs] or NULL                        */
     int32_t *out_status;            /* [n_agents]                                               */
     int32_t *out_iters;             /* optional [n_agents][4] {iterations, adds, drops, active} */
+    uint64_t *debug_stamps;         /* NULL; [n_agents][12] cycle stamps, read only by the separate
+                                       -DDLSCQP_STAMPS diagnostic build (profiles/stamps.py)        */
 } dlscqp_device_batch;
 
 /* key layout: bits 0-7 m, 8-11 i, 12 dynamic flag, 16-31 slack index (0xFFFF = none). */

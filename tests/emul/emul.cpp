@@ -19,43 +19,50 @@ namespace {
 
 struct WaveCpu {
     bool reverse;
+    template <class T>
+    struct Reg {
+        T v[64];
+        T &at(int l) { return v[l]; }
+        const T &at(int l) const { return v[l]; }
+    };
     template <class F>
-    void lane_loop(int n, F f) const {
+    void each(F f) const {
         if (!reverse)
-            for (int j = 0; j < n; j++) f(j);
+            for (int l = 0; l < 64; l++) f(l);
         else
-            for (int j = n - 1; j >= 0; j--) f(j);
+            for (int l = 63; l >= 0; l--) f(l);
     }
     void sync() const {}
-    template <class F>
-    double sum(int n, F f) const {
-        double s = 0;
-        for (int j = 0; j < n; j++) s += f(j);
+    void stamp(int) const {}
+    template <class T>
+    T bcast(const Reg<T> &r, int lane) const { return r.v[lane]; }
+    double max(const Reg<double> &r) const {
+        double s = r.v[0];
+        for (int l = 1; l < 64; l++) s = r.v[l] > s ? r.v[l] : s;
         return s;
     }
-    template <class F>
-    double max(int n, F f) const {
-        double s = -1e300;
-        for (int j = 0; j < n; j++) { double v = f(j); if (v > s) s = v; }
+    double min(const Reg<double> &r) const {
+        double s = r.v[0];
+        for (int l = 1; l < 64; l++) s = r.v[l] < s ? r.v[l] : s;
         return s;
     }
-    template <class F>
-    double min(int n, F f) const {
-        double s = 1e300;
-        for (int j = 0; j < n; j++) { double v = f(j); if (v < s) s = v; }
-        return s;
+    void sum2(const Reg<double> &a, const Reg<double> &b, double &sa, double &sb) const {
+        sa = 0; sb = 0;
+        for (int l = 0; l < 64; l++) { sa += a.v[l]; sb += b.v[l]; }
     }
-    template <class F>
-    dlscqp::Cand argmax(int n, F f) const {
-        dlscqp::Cand b{-1e300, -1};
-        for (int j = 0; j < n; j++) { dlscqp::Cand c = f(j); if (c.v > b.v) b = c; }
-        return b;
+    bool any(const Reg<int> &r) const {
+        for (int l = 0; l < 64; l++) if (r.v[l]) return true;
+        return false;
     }
-    template <class F>
-    dlscqp::Cand argmin(int n, F f) const {
-        dlscqp::Cand b{1e300, -1};
-        for (int j = 0; j < n; j++) { dlscqp::Cand c = f(j); if (c.v < b.v) b = c; }
-        return b;
+    int first_lane(const Reg<int> &r) const {
+        for (int l = 0; l < 64; l++) if (r.v[l]) return l;
+        return -1;
+    }
+    // out[l] = element (l + 64 c) + 1 of the vector spread over `nchunks` registers
+    template <class T>
+    void shift_down(const Reg<T> *arr, int c, int nchunks, Reg<T> &out) const {
+        for (int l = 0; l < 63; l++) out.v[l] = arr[c].v[l + 1];
+        out.v[63] = c + 1 < nchunks ? arr[c + 1].v[0] : arr[c].v[63];
     }
 };
 
@@ -97,7 +104,8 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
     const size_t xs = (size_t)dim * M * n1 + (size_t)M * max_slack_obs;
     for (int a = 0; a < n_agents; a++) {
         std::memset(mem.data(), 0xCD, mem.size());  // poison: nothing may rely on zero-initialised LDS
-        plan_agent(w, kp, lay, mem.data(), agents + a, rv, (int)row_offsets[a],
+        auto fn = lay.r_max <= 64 ? plan_agent<1, WaveCpu> : plan_agent<2, WaveCpu>;
+        fn(w, kp, lay, mem.data(), agents + a, rv, (int)row_offsets[a],
                    (int)(row_offsets[a + 1] - row_offsets[a]), sfc ? sfc + (size_t)a * M * 6 : nullptr,
                    max_slack_obs, do_goal, do_traj, out_goal ? out_goal + (size_t)a * 3 : nullptr,
                    out_goal_status ? out_goal_status + a : nullptr,
