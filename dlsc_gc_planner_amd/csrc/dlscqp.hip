@@ -92,28 +92,47 @@ struct WaveGpu {
     __device__ __forceinline__ int bcast(const Reg<int> &r, int l) const {
         return __builtin_amdgcn_readlane(r.v, __builtin_amdgcn_readfirstlane(l));
     }
+    // Wave reductions on the DPP data path (no LDS crossbar): inclusive combine within each row of 16
+    // lanes (row_shr 1,2,4,8), then row_bcast:15 / row_bcast:31 carry the row totals up; lane 63 ends up
+    // with the result, which v_readlane makes uniform.
+    template <int CTRL, int ROW_MASK>
+    static __device__ __forceinline__ double dpp_f64(double identity, double v) {
+        int lo = __builtin_amdgcn_update_dpp(__double2loint(identity), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+        int hi = __builtin_amdgcn_update_dpp(__double2hiint(identity), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+        return __hiloint2double(hi, lo);
+    }
     __device__ __forceinline__ double max(const Reg<double> &r) const {
+        const double id = -1.7976931348623157e308;
         double s = r.v;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s = fmax(s, __shfl_xor(s, o, 64));
-        return uniform_f64(s);
+        s = fmax(s, dpp_f64<0x111, 0xf>(id, s));
+        s = fmax(s, dpp_f64<0x112, 0xf>(id, s));
+        s = fmax(s, dpp_f64<0x114, 0xf>(id, s));
+        s = fmax(s, dpp_f64<0x118, 0xf>(id, s));
+        s = fmax(s, dpp_f64<0x142, 0xa>(id, s));
+        s = fmax(s, dpp_f64<0x143, 0xc>(id, s));
+        return readlane_f64(s, 63);
     }
     __device__ __forceinline__ double min(const Reg<double> &r) const {
+        const double id = 1.7976931348623157e308;
         double s = r.v;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) s = fmin(s, __shfl_xor(s, o, 64));
-        return uniform_f64(s);
+        s = fmin(s, dpp_f64<0x111, 0xf>(id, s));
+        s = fmin(s, dpp_f64<0x112, 0xf>(id, s));
+        s = fmin(s, dpp_f64<0x114, 0xf>(id, s));
+        s = fmin(s, dpp_f64<0x118, 0xf>(id, s));
+        s = fmin(s, dpp_f64<0x142, 0xa>(id, s));
+        s = fmin(s, dpp_f64<0x143, 0xc>(id, s));
+        return readlane_f64(s, 63);
     }
     __device__ __forceinline__ void sum2(const Reg<double> &a, const Reg<double> &b, double &sa, double &sb) const {
-        double x = a.v, y = b.v;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {  // two independent butterflies, interleaved
-            double xo = __shfl_xor(x, o, 64), yo = __shfl_xor(y, o, 64);
-            x += xo;
-            y += yo;
-        }
-        sa = uniform_f64(x);
-        sb = uniform_f64(y);
+        double x = a.v, y = b.v;  // two independent chains, interleaved
+        x += dpp_f64<0x111, 0xf>(0.0, x); y += dpp_f64<0x111, 0xf>(0.0, y);
+        x += dpp_f64<0x112, 0xf>(0.0, x); y += dpp_f64<0x112, 0xf>(0.0, y);
+        x += dpp_f64<0x114, 0xf>(0.0, x); y += dpp_f64<0x114, 0xf>(0.0, y);
+        x += dpp_f64<0x118, 0xf>(0.0, x); y += dpp_f64<0x118, 0xf>(0.0, y);
+        x += dpp_f64<0x142, 0xa>(0.0, x); y += dpp_f64<0x142, 0xa>(0.0, y);
+        x += dpp_f64<0x143, 0xc>(0.0, x); y += dpp_f64<0x143, 0xc>(0.0, y);
+        sa = readlane_f64(x, 63);
+        sb = readlane_f64(y, 63);
     }
     __device__ __forceinline__ bool any(const Reg<int> &r) const { return __ballot(r.v != 0) != 0ull; }
     __device__ __forceinline__ int first_lane(const Reg<int> &r) const {
@@ -148,7 +167,7 @@ struct KernelArgs {
     unsigned long long *out_stamps;  // [n_agents][12], diagnostic build only
 };
 
-template <int RC>
+template <int RC, int DIMS, int FS, int MS, int KU, int SU>
 __global__ __launch_bounds__(64, 2) void dlscqp_plan_kernel(KParams kp, MemLayout lay, KernelArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int ag = blockIdx.x;
@@ -161,7 +180,7 @@ __global__ __launch_bounds__(64, 2) void dlscqp_plan_kernel(KParams kp, MemLayou
     const int rb = a.row_offsets[ag], re = a.row_offsets[ag + 1];
     const int M = kp.M, n1 = kp.n1;
     const size_t xs = (size_t)kp.dim * M * n1 + (size_t)M * a.max_slack_obs;
-    plan_agent<RC>(w, kp, lay, smem, a.agents + ag, a.rows, rb, re - rb,
+    plan_agent<RC, DIMS, FS, MS, KU, SU>(w, kp, lay, smem, a.agents + ag, a.rows, rb, re - rb,
                a.sfc ? a.sfc + (size_t)ag * M * 6 : nullptr, a.max_slack_obs, a.do_goal, a.do_traj,
                a.out_goal ? a.out_goal + (size_t)ag * 3 : nullptr,
                a.out_goal_status ? a.out_goal_status + ag : nullptr,
@@ -174,6 +193,26 @@ __global__ __launch_bounds__(64, 2) void dlscqp_plan_kernel(KParams kp, MemLayou
     if (a.out_stamps && threadIdx.x == 0)
         for (int p = 0; p < 12; p++) a.out_stamps[(size_t)ag * 12 + p] = w.acc[p];
 #endif
+}
+
+typedef void (*kernel_t)(KParams, MemLayout, KernelArgs);
+struct KernelChoice {
+    kernel_t fn;
+    int id, KU, SU;
+};
+
+// Kernel instantiation: static shapes for the reference's launch files (3-D M=5: f=13; 2-D / 3-D M=10:
+// f=28) with register caches sized to the row counts, runtime-shape kernels for everything else.
+KernelChoice select_kernel(const KParams &kp, int max_slack_obs, int kmax) {
+    const int r_max = kp.dim * kp.f + kp.M * max_slack_obs;
+    if (kp.dim == 3 && kp.f == 13 && kp.M == 5 && r_max <= 64 && kmax <= 128 && kp.n_slots <= 256)
+        return {dlscqp_plan_kernel<1, 3, 13, 5, 2, 4>, 0, 2, 4};
+    if (kp.dim == 3 && kp.f == 13 && kp.M == 5 && r_max <= 64) return {dlscqp_plan_kernel<1, 3, 13, 5, 4, 5>, 1, 4, 5};
+    if (kp.dim == 2 && kp.f == 28 && kp.M == 10 && r_max <= 64) return {dlscqp_plan_kernel<1, 2, 28, 10, 4, 7>, 2, 4, 7};
+    if (kp.dim == 3 && kp.f == 28 && kp.M == 10 && r_max <= 128) return {dlscqp_plan_kernel<2, 3, 28, 10, 4, 10>, 3, 4, 10};
+    if (r_max <= 64) return {dlscqp_plan_kernel<1, 0, 0, 0, 4, 10>, 4, 4, 10};
+    if (r_max <= 128) return {dlscqp_plan_kernel<2, 0, 0, 0, 4, 10>, 5, 4, 10};
+    return {nullptr, -1, 0, 0};
 }
 
 thread_local std::string g_last_error;
@@ -204,7 +243,7 @@ struct dlscqp_ctx {
     double *d_tabN = nullptr, *d_tabX0s = nullptr, *d_tabX0g = nullptr;
     Slot *d_slots = nullptr;
     hipStream_t stream = nullptr;
-    int max_dyn_lds[2] = {0, 0};
+    int max_dyn_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // staging for the host-buffer entry points
     unsigned char *h_stage = nullptr, *d_stage = nullptr;
     size_t stage_cap = 0;
@@ -298,7 +337,9 @@ extern "C" int dlscqp_update_param(dlscqp_ctx *c, const dlscqp_config *cfg) {
 
 extern "C" int64_t dlscqp_lds_bytes(const dlscqp_ctx *c, int32_t max_slack_obs, int32_t max_rows_per_agent) {
     if (!c) return -1;
-    return make_layout(c->tb.kp, max_slack_obs, max_rows_per_agent).bytes;
+    KernelChoice kc = select_kernel(c->tb.kp, max_slack_obs, max_rows_per_agent);
+    if (!kc.fn) return -1;
+    return make_layout(c->tb.kp, max_slack_obs, max_rows_per_agent, kc.KU, kc.SU).bytes;
 }
 
 extern "C" int dlscqp_set_timing(dlscqp_ctx *c, int32_t capacity) {
@@ -341,7 +382,12 @@ extern "C" int dlscqp_get_kernel_times(dlscqp_ctx *c, float *ms_out, int32_t cap
 static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t stream) {
     if (b->n_agents <= 0) return DLSCQP_SUCCESS;
     if (b->max_slack_obs < 0 || b->max_rows_per_agent < 0) { g_last_error = "negative size"; return DLSCQP_ERR_INVALID_ARGUMENT; }
-    MemLayout lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent);
+    KernelChoice kc = select_kernel(c->kp, b->max_slack_obs, b->max_rows_per_agent);
+    if (!kc.fn) {
+        g_last_error = "reduced dimension above 128 (dim*f + M*max_slack_obs) is not supported";
+        return DLSCQP_ERR_UNSUPPORTED;
+    }
+    MemLayout lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU);
     if (lay.bytes > LDS_LIMIT) {
         char msg[256];
         snprintf(msg, sizeof msg,
@@ -350,17 +396,11 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         g_last_error = msg;
         return DLSCQP_ERR_UNSUPPORTED;
     }
-    if (lay.r_max > 128) {
-        g_last_error = "reduced dimension above 128 (dim*f + M*max_slack_obs) is not supported";
-        return DLSCQP_ERR_UNSUPPORTED;
+    if (lay.bytes > c->max_dyn_lds[kc.id]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kc.fn), hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
+        c->max_dyn_lds[kc.id] = lay.bytes;
     }
-    const int rcsel = lay.r_max <= 64 ? 0 : 1;
-    if (lay.bytes > c->max_dyn_lds[rcsel]) {
-        const void *fn = rcsel == 0 ? reinterpret_cast<const void *>(dlscqp_plan_kernel<1>)
-                                    : reinterpret_cast<const void *>(dlscqp_plan_kernel<2>);
-        HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
-        c->max_dyn_lds[rcsel] = lay.bytes;
-    }
+    kernel_t kfn = kc.fn;
     KernelArgs a;
     a.n_agents = b->n_agents;
     a.max_slack_obs = b->max_slack_obs;
@@ -381,10 +421,7 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
     a.out_stamps = (unsigned long long *)b->debug_stamps;
     const bool timed = c->ev_used < (int)c->ev0.size();
     if (timed) HIP_TRY(hipEventRecord(c->ev0[c->ev_used], stream));
-    if (rcsel == 0)
-        hipLaunchKernelGGL(dlscqp_plan_kernel<1>, dim3(b->n_agents), dim3(64), lay.bytes, stream, c->kp, lay, a);
-    else
-        hipLaunchKernelGGL(dlscqp_plan_kernel<2>, dim3(b->n_agents), dim3(64), lay.bytes, stream, c->kp, lay, a);
+    hipLaunchKernelGGL(kfn, dim3(b->n_agents), dim3(64), lay.bytes, stream, c->kp, lay, a);
     HIP_TRY(hipGetLastError());
     if (timed) {
         HIP_TRY(hipEventRecord(c->ev1[c->ev_used], stream));

@@ -39,8 +39,9 @@
 
 namespace dlscqp {
 
-constexpr int KU = 4;   // LSC rows cached in registers per lane (K <= 256; the rest is read from HBM)
-constexpr int SU = 10;  // structured slots cached per lane (n_slots <= 640; the rest from HBM)
+// KU: LSC rows cached in registers per lane (64 KU rows; the rest is read from HBM on every scan)
+// SU: structured slots cached per lane (64 SU slots; the rest from HBM).  Template parameters of
+// plan_agent: the register budget of the wave (256 VGPRs at 2 waves/SIMD) is shared with the unrolled loops.
 
 struct MemLayout {
     int r_max, nx_max, ldq, nflag;
@@ -49,7 +50,7 @@ struct MemLayout {
     int bytes;
 };
 
-DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax) {
+DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int KU, int SU) {
     MemLayout L;
     const int nslk = kp.M * max_slack_obs;
     L.r_max = kp.dim * kp.f + nslk;
@@ -82,7 +83,12 @@ constexpr uint32_t KEY_SKIP = 0xFFFFFFFFu;  // cached LSC row that is not part o
 // element e of a per-lane vector spread over RC registers
 #define DQ_BC(arr, e) (RC == 1 ? w.bcast((arr)[0], (e)) : ((e) < 64 ? w.bcast((arr)[0], (e)) : w.bcast((arr)[RC - 1], (e) - 64)))
 
-template <int RC, class W>
+// RC: registers per per-lane vector (r <= 64 RC).  DIMS/FS/MS: compile-time world dimension, free
+// degrees of freedom per axis and segment count (0 = read them from KParams).  With static shapes every O(r) / O(f) loop
+// below has a constant trip count, is fully unrolled, and its LDS reads are issued back to back instead
+// of one dependent round trip per iteration -- the difference between ~35k and a few thousand cycles per
+// active-set iteration for a single wavefront.
+template <int RC, int DIMS, int FS, int MS, int KU, int SU, class W>
 DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsigned char *mem,
                       const dlscqp_agent *agp, const RowsView &rows, int row_begin, int K,
                       const float *sfc, int max_slack_obs, int do_goal, int do_traj,
@@ -94,7 +100,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     typedef typename W::template Reg<uint32_t> RegU;
     typedef typename W::template Reg<int> RegI;
 
-    const int dim = kp.dim, M = kp.M, n1 = kp.n1, P = kp.P, f = kp.f;
+    const int dim = DIMS > 0 ? DIMS : kp.dim, f = FS > 0 ? FS : kp.f;
+    const int M = MS > 0 ? MS : kp.M;
+    constexpr int n1 = 6;  // n = 5 is the only degree the reference supports (traj_optimizer.cpp:209)
+    const int P = M * n1;
     const int n = n1 - 1;
     // ---- agent record (uniform) ---------------------------------------------------------------
     float pos[3], vel[3], acc[3], cg[3], wp[3];
@@ -124,17 +133,40 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     const int Kc = K < 64 * KU ? K : 64 * KU;  // cached rows
 #pragma unroll
     for (int u = 0; u < KU; u++) {
-        if (u * 64 < Kc) {
+        w.each([&](int l) {
+            const int j = l + 64 * u;
+            cnx[u].at(l) = 0; cny[u].at(l) = 0; cnz[u].at(l) = 0;
+            cpx[u].at(l) = 0; cpy[u].at(l) = 0; cpz[u].at(l) = 0;
+            cd[u].at(l) = 0;
+            ckey[u].at(l) = KEY_SKIP;
+            if (j < Kc) {
+                cnx[u].at(l) = Rnx[j]; cny[u].at(l) = Rny[j]; cnz[u].at(l) = Rnz[j];
+                cpx[u].at(l) = Rpx[j]; cpy[u].at(l) = Rpy[j]; cpz[u].at(l) = Rpz[j];
+                cd[u].at(l) = Rd[j];
+                ckey[u].at(l) = Rkey[j];
+            }
+        });
+    }
+
+    // ---- structured slots into registers (issued here so that all prologue loads are in flight together)
+    const Slot *slots = kp.slots;
+    const int n_slots = kp.n_slots;
+    const int Sc = n_slots < 64 * SU ? n_slots : 64 * SU;  // cached slots
+    RegU sidx[SU], scb[SU];  // 3 x 10-bit x-space indices (0x3FF = unused) | 3 x int8 coefficients + bsel
+#pragma unroll
+    for (int u = 0; u < SU; u++) {
+        {
             w.each([&](int l) {
-                const int j = l + 64 * u;
-                if (j < Kc) {
-                    cnx[u].at(l) = Rnx[j]; cny[u].at(l) = Rny[j]; cnz[u].at(l) = Rnz[j];
-                    cpx[u].at(l) = Rpx[j]; cpy[u].at(l) = Rpy[j]; cpz[u].at(l) = Rpz[j];
-                    cd[u].at(l) = Rd[j];
-                    ckey[u].at(l) = Rkey[j];
-                } else {
-                    ckey[u].at(l) = KEY_SKIP;
+                const int s = l + 64 * u;
+                uint32_t pi = 0xBFFFFFFFu, pc = 0;  // bit 31: no slot in this register
+                if (s < Sc) {
+                    Slot sl = slots[s];
+                    pi = (uint32_t)(sl.idx[0] & 0x3FF) | ((uint32_t)(sl.idx[1] & 0x3FF) << 10) | ((uint32_t)(sl.idx[2] & 0x3FF) << 20);
+                    pc = (uint32_t)(uint8_t)sl.coef[0] | ((uint32_t)(uint8_t)sl.coef[1] << 8) |
+                         ((uint32_t)(uint8_t)sl.coef[2] << 16) | ((uint32_t)sl.bsel << 24);
                 }
+                sidx[u].at(l) = pi;
+                scb[u].at(l) = pc;
             });
         }
     }
@@ -194,7 +226,6 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 int bad = 0, viol = 0;
 #pragma unroll
                 for (int u = 0; u < KU; u++)
-                    if (u * 64 < Kc)
                         lp_row(ckey[u].at(l), cnx[u].at(l), cny[u].at(l), cnz[u].at(l), cpx[u].at(l), cpy[u].at(l),
                                cpz[u].at(l), cd[u].at(l), lo, hi, bad, viol);
                 for (int j = 64 * KU + l; j < K; j += 64)  // rows beyond the register cache
@@ -242,8 +273,6 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     const int rc = dim * f;      // whitened control-point dimension
     const int r = rc + nslk;     // whitened dimension
     const int nxc = dim * P;     // control-point variables
-    const int n_slots = kp.n_slots;
-    const int Sc = n_slots < 64 * SU ? n_slots : 64 * SU;  // cached slots
     const int cold_rows = K - Kc;
 
     // terminal segments, traj_optimizer.cpp:543-551 (float32 point difference)
@@ -257,7 +286,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     int status = DLSCQP_OK;
     if (!kp.t_valid[T - 1]) status = DLSCQP_NUMERICAL;
     if (nslk > 0 && !(kp.w_s > 0)) status = DLSCQP_NUMERICAL;
-    if (r > 64 * RC) status = DLSCQP_NUMERICAL;  // the launcher picks RC; defensive
+    if (r > 64 * RC || dim != kp.dim || f != kp.f || M != kp.M || n1 != kp.n1) status = DLSCQP_NUMERICAL;  // the launcher picks the instantiation; defensive
     if (status != DLSCQP_OK) {
         w.each([&](int l) { if (l == 0 && out_status) *out_status = status; });
         return;
@@ -266,27 +295,8 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     const double *tN = kp.tabN + (size_t)(T - 1) * P * f;
     const double *tXs = kp.tabX0s + (size_t)(T - 1) * P * 3;
     const double *tXg = kp.tabX0g + (size_t)(T - 1) * P;
-    const Slot *slots = kp.slots;
 
-    // ---- structured slots into registers, unconstrained minimiser and bound table into LDS ------
-    RegU sidx[SU], scb[SU];  // 3 x 10-bit x-space indices (0x3FF = unused) | 3 x int8 coefficients + bsel
-#pragma unroll
-    for (int u = 0; u < SU; u++) {
-        if (u * 64 < Sc) {
-            w.each([&](int l) {
-                const int s = l + 64 * u;
-                uint32_t pi = 0xBFFFFFFFu, pc = 0;  // bit 31: no slot in this register
-                if (s < Sc) {
-                    Slot sl = slots[s];
-                    pi = (uint32_t)(sl.idx[0] & 0x3FF) | ((uint32_t)(sl.idx[1] & 0x3FF) << 10) | ((uint32_t)(sl.idx[2] & 0x3FF) << 20);
-                    pc = (uint32_t)(uint8_t)sl.coef[0] | ((uint32_t)(uint8_t)sl.coef[1] << 8) |
-                         ((uint32_t)(uint8_t)sl.coef[2] << 16) | ((uint32_t)sl.bsel << 24);
-                }
-                sidx[u].at(l) = pi;
-                scb[u].at(l) = pc;
-            });
-        }
-    }
+    // ---- unconstrained minimiser and bound table into LDS -------------------------------------------
     w.each([&](int l) {
         for (int j = l; j < nxc; j += 64) {
             int k = j / P, p = j - k * P;
@@ -326,7 +336,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     // finish the LSC cache: rhs = d + n.p (traj_optimizer.cpp:427-439), drop rows that are not in the model
 #pragma unroll
     for (int u = 0; u < KU; u++) {
-        if (u * 64 < Kc) {
+        {
             w.each([&](int l) {
                 uint32_t key = ckey[u].at(l);
                 if (key == KEY_SKIP) return;
@@ -402,36 +412,43 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             int bc = -1;
 #pragma unroll
             for (int u = 0; u < KU; u++) {
-                if (u * 64 < Kc) {
+                {  // everything is select-based (no branches) so that the LDS reads of all rows batch
                     const uint32_t key = ckey[u].at(l);
-                    if (key != KEY_SKIP && !((fl_lsc.at(l) >> u) & 1)) {
-                        const int m = key & 0xFF, i = (key >> 8) & 0xF;
-                        const int p = m * n1 + i;
-                        double val = (double)cnx[u].at(l) * x[p];
-                        val = fma((double)cny[u].at(l), x[P + p], val);
-                        if (dim == 3) val = fma((double)cnz[u].at(l), x[2 * P + p], val);
-                        const uint32_t sl = key >> 16;
-                        if (sl != 0xFFFFu) val -= x[nxc + (int)sl * M + m];
-                        const double v = cd[u].at(l) - val;
-                        if (v > bv) { bv = v; bc = l + 64 * u; }
-                    }
+                    const bool valid = key != KEY_SKIP && !((fl_lsc.at(l) >> u) & 1);
+                    const int m = key & 0xFF, i = (key >> 8) & 0xF;
+                    const int p = valid ? m * n1 + i : 0;
+                    double val = (double)cnx[u].at(l) * x[p];
+                    val = fma((double)cny[u].at(l), x[P + p], val);
+                    if (dim == 3) val = fma((double)cnz[u].at(l), x[2 * P + p], val);
+                    const uint32_t sl = key >> 16;
+                    const bool has_slack = valid && sl != 0xFFFFu;
+                    const double sx = x[nxc + (has_slack ? (int)sl * M + m : 0)];
+                    val -= has_slack ? sx : 0.0;
+                    const double v = valid ? cd[u].at(l) - val : -1.0;
+                    bc = v > bv ? l + 64 * u : bc;
+                    bv = v > bv ? v : bv;
                 }
             }
 #pragma unroll
             for (int u = 0; u < SU; u++) {
-                if (u * 64 < Sc) {
+                {
                     const uint32_t pi = sidx[u].at(l), pc = scb[u].at(l);
-                    if (!(pi & 0x80000000u)) {
-                        const int i0 = pi & 0x3FF, i1 = (pi >> 10) & 0x3FF, i2 = (pi >> 20) & 0x3FF;
-                        double val = (double)(int8_t)(pc & 0xFF) * x[i0];
-                        if (i1 != 0x3FF) val = fma((double)(int8_t)((pc >> 8) & 0xFF), x[i1], val);
-                        if (i2 != 0x3FF) val = fma((double)(int8_t)((pc >> 16) & 0xFF), x[i2], val);
-                        const int bs = pc >> 24;
-                        const double vlo = blo[bs] - val, vhi = val - bhi[bs];
-                        const int s = l + 64 * u;
-                        if (vlo > bv && !((fl_slo.at(l) >> u) & 1)) { bv = vlo; bc = K + 2 * s; }
-                        if (vhi > bv && !((fl_shi.at(l) >> u) & 1)) { bv = vhi; bc = K + 2 * s + 1; }
-                    }
+                    const bool valid = !(pi & 0x80000000u);
+                    int i0 = pi & 0x3FF, i1 = (pi >> 10) & 0x3FF, i2 = (pi >> 20) & 0x3FF;
+                    i0 = i0 == 0x3FF ? 0 : i0;  // unused entries carry coefficient 0
+                    i1 = i1 == 0x3FF ? 0 : i1;
+                    i2 = i2 == 0x3FF ? 0 : i2;
+                    double val = (double)(int8_t)(pc & 0xFF) * x[i0];
+                    val = fma((double)(int8_t)((pc >> 8) & 0xFF), x[i1], val);
+                    val = fma((double)(int8_t)((pc >> 16) & 0xFF), x[i2], val);
+                    const int bs = pc >> 24;
+                    const double vlo = (valid && !((fl_slo.at(l) >> u) & 1)) ? blo[bs] - val : -1.0;
+                    const double vhi = (valid && !((fl_shi.at(l) >> u) & 1)) ? val - bhi[bs] : -1.0;
+                    const int s = l + 64 * u;
+                    bc = vlo > bv ? K + 2 * s : bc;
+                    bv = vlo > bv ? vlo : bv;
+                    bc = vhi > bv ? K + 2 * s + 1 : bc;
+                    bv = vhi > bv ? vhi : bv;
                 }
             }
             for (int s = l; s < nslk; s += 64) {  // eps <= 0 (traj_optimizer.cpp:276)
@@ -499,11 +516,12 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             if (ip < Kc) {
                 const int own = ip & 63, u = ip >> 6;
 #pragma unroll
-                for (int uq = 0; uq < KU; uq++)
-                    if (uq == u) {
-                        key = w.bcast(ckey[uq], own);
-                        nn[0] = w.bcast(cnx[uq], own); nn[1] = w.bcast(cny[uq], own); nn[2] = w.bcast(cnz[uq], own);
-                    }
+                for (int uq = 0; uq < KU; uq++) {  // uniform selects, no branches
+                    const uint32_t kq = w.bcast(ckey[uq], own);
+                    const float a0 = w.bcast(cnx[uq], own), a1 = w.bcast(cny[uq], own), a2 = w.bcast(cnz[uq], own);
+                    key = uq == u ? kq : key;
+                    nn[0] = uq == u ? a0 : nn[0]; nn[1] = uq == u ? a1 : nn[1]; nn[2] = uq == u ? a2 : nn[2];
+                }
             } else {
                 key = Rkey[ip];
                 nn[0] = Rnx[ip]; nn[1] = Rny[ip]; nn[2] = Rnz[ip];
@@ -519,16 +537,37 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             if (sl != 0xFFFFu) sidx_row = (int)sl * M + m;
         } else if (ip < code_slack0) {
             const int s = (ip - K) >> 1, side = (ip - K) & 1;
-            const Slot sl = slots[s];  // uniform load of 16 B (L2-resident table)
+            int sidx3[3], scoef3[3], bs;
+            if (s < Sc) {  // from the owner lane's registers
+                const int own = s & 63, u = s >> 6;
+                uint32_t pi = 0, pc = 0;
+#pragma unroll
+                for (int uq = 0; uq < SU; uq++) {
+                    const uint32_t a0 = w.bcast(sidx[uq], own), a1 = w.bcast(scb[uq], own);
+                    pi = uq == u ? a0 : pi;
+                    pc = uq == u ? a1 : pc;
+                }
+                for (int t = 0; t < 3; t++) {
+                    sidx3[t] = (pi >> (10 * t)) & 0x3FF;
+                    if (sidx3[t] == 0x3FF) sidx3[t] = -1;
+                    scoef3[t] = (int8_t)((pc >> (8 * t)) & 0xFF);
+                }
+                bs = pc >> 24;
+            } else {
+                const Slot sl = slots[s];  // uniform load of 16 B (L2-resident table)
+                for (int t = 0; t < 3; t++) { sidx3[t] = sl.idx[t]; scoef3[t] = sl.coef[t]; }
+                bs = sl.bsel;
+            }
             const double sg = side == 0 ? 1.0 : -1.0;  // val >= lo   |   -val >= -hi
             int cnt = 0;
             for (int t = 0; t < 3; t++)
-                if (sl.idx[t] >= 0) {
-                    int k = sl.idx[t] / P;
-                    ek[cnt] = k; ep[cnt] = sl.idx[t] - k * P; cf[cnt] = sg * (double)sl.coef[t]; cnt++;
+                if (sidx3[t] >= 0) {
+                    int k = sidx3[t] / P;
+                    ek[cnt] = k; ep[cnt] = sidx3[t] - k * P; cf[cnt] = sg * (double)scoef3[t]; cnt++;
                     axes_mask |= 1 << k;
                 }
-            row_scale = (double)sl.scale;
+            // back to the reference's row scaling: n/dt for velocity rows, n(n-1)/dt^2 for acceleration rows
+            row_scale = bs == dim * M ? 1.0 / kp.vel_scale : (bs == dim * M + 1 ? 1.0 / kp.acc_scale : 1.0);
         } else {
             sidx_row = ip - code_slack0;
         }
@@ -558,48 +597,54 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             // d = Q' na   (na is non-zero only in the touched axis blocks and one slack entry)
             w.each([&](int l) {
 #pragma unroll
-                for (int c = 0; c < RC; c++) dv[c].at(l) = 0.0;
-            });
-            for (int k = 0; k < dim; k++) {
-                if (!(axes_mask & (1 << k))) continue;
-                for (int i = k * f; i < (k + 1) * f; i++) {
-                    const double nai = DQ_BC(na, i);
-                    w.each([&](int l) {
+                for (int c = 0; c < RC; c++) {
+                    const int j = l + 64 * c;
+                    double a0 = 0.0, a1 = 0.0;
+                    if (j < r) {
 #pragma unroll
-                        for (int c = 0; c < RC; c++) {
-                            const int j = l + 64 * c;
-                            if (j < r) dv[c].at(l) = fma(Q[i * ldq + j], nai, dv[c].at(l));
+                        for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++) {
+                            if (k < dim && (axes_mask & (1 << k))) {  // uniform
+#pragma unroll
+                                for (int ii = 0; ii < f; ii += 2) {
+                                    const int i = k * f + ii;
+                                    a0 = fma(Q[i * ldq + j], DQ_BC(na, i), a0);
+                                    if (ii + 1 < f) a1 = fma(Q[(i + 1) * ldq + j], DQ_BC(na, i + 1), a1);
+                                }
+                            }
                         }
-                    });
-                }
-            }
-            if (sidx_row >= 0) {
-                const int i = rc + sidx_row;
-                const double nai = DQ_BC(na, i);
-                w.each([&](int l) {
-#pragma unroll
-                    for (int c = 0; c < RC; c++) {
-                        const int j = l + 64 * c;
-                        if (j < r) dv[c].at(l) = fma(Q[i * ldq + j], nai, dv[c].at(l));
+                        if (sidx_row >= 0) {
+                            const int i = rc + sidx_row;
+                            a0 = fma(Q[i * ldq + j], DQ_BC(na, i), a0);
+                        }
                     }
-                });
-            }
+                    dv[c].at(l) = a0 + a1;
+                }
+            });
             w.stamp(4);  // d = Q' na
-            // z = Q2 d2, |d2|^2, |d|^2
+            // z = Q2 d2, |d2|^2, |d|^2.  d2 = d with the first q entries zeroed, as a register of its own, so
+            // that the unrolled loop below is select- and branch-free (its LDS reads then issue back to back)
+            RegD dz[RC];
             w.each([&](int l) {
 #pragma unroll
-                for (int c = 0; c < RC; c++) zv[c].at(l) = 0.0;
+                for (int c = 0; c < RC; c++) dz[c].at(l) = (l + 64 * c >= q) ? dv[c].at(l) : 0.0;
             });
-            for (int j = q; j < r; j++) {
-                const double dj = DQ_BC(dv, j);
-                w.each([&](int l) {
+            w.each([&](int l) {
 #pragma unroll
-                    for (int c = 0; c < RC; c++) {
-                        const int i = l + 64 * c;
-                        if (i < r) zv[c].at(l) = fma(Q[i * ldq + j], dj, zv[c].at(l));
+                for (int c = 0; c < RC; c++) {
+                    const int i = l + 64 * c;
+                    double a0 = 0.0, a1 = 0.0;
+                    if (i < r) {
+                        const double *qi = Q + i * ldq;
+#pragma unroll
+                        for (int j = 0; j < rc; j += 2) {
+                            a0 = fma(qi[j], DQ_BC(dz, j), a0);
+                            if (j + 1 < rc) a1 = fma(qi[j + 1], DQ_BC(dz, j + 1), a1);
+                        }
+                        for (int j = rc; j < r; j++) a0 = fma(qi[j], DQ_BC(dz, j), a0);  // slack columns
                     }
-                });
-            }
+                    zv[c].at(l) = a0 + a1;
+                }
+            });
             RegD s_d2, s_all;
             w.each([&](int l) {
                 double a2 = 0, aa = 0;
@@ -677,25 +722,22 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             }
             const double t = t1 < t2 ? t1 : t2;
             if (!dependent) {
-                // primal step  x += t N z
-                for (int k = 0; k < dim; k++) {
-                    for (int p0 = 0; p0 < P; p0 += 64) {
-                        RegD sacc;
-                        w.each([&](int l) { sacc.at(l) = 0.0; });
+                // primal step  x += t N z  (a row of N is read once and used for every axis)
+                w.each([&](int l) {
+                    for (int p = l; p < P; p += 64) {
+                        double sk[3] = {0.0, 0.0, 0.0};
+#pragma unroll
                         for (int c = 0; c < f; c++) {
-                            const int e = k * f + c;
-                            const double zc = DQ_BC(zv, e);
-                            w.each([&](int l) {
-                                const int p = p0 + l;
-                                if (p < P) sacc.at(l) = fma(Nl[p * f + c], zc, sacc.at(l));
-                            });
+                            const double nv = Nl[p * f + c];
+#pragma unroll
+                            for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++)
+                                if (k < dim) sk[k] = fma(nv, DQ_BC(zv, k * f + c), sk[k]);
                         }
-                        w.each([&](int l) {
-                            const int p = p0 + l;
-                            if (p < P) x[k * P + p] = fma(t, sacc.at(l), x[k * P + p]);
-                        });
+#pragma unroll
+                        for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++)
+                            if (k < dim) x[k * P + p] = fma(t, sk[k], x[k * P + p]);
                     }
-                }
+                });
                 w.each([&](int l) {
 #pragma unroll
                     for (int c = 0; c < RC; c++) {
@@ -723,30 +765,28 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 const double alpha = dq > 0 ? -nrm : nrm;
                 const double v0 = dq - alpha;
                 const double beta = 1.0 / (nrm * (nrm + fabs(dq)));  // 2 / v'v
-                RegD g[RC];
+                // Householder vector v = (0,..,0, d_q - alpha, d_{q+1}, ..) as a register: branch-free loop below
+                RegD hv[RC];
+                w.each([&](int l) {
+#pragma unroll
+                    for (int c = 0; c < RC; c++) {
+                        const int j = l + 64 * c;
+                        hv[c].at(l) = j > q ? dv[c].at(l) : (j == q ? v0 : 0.0);
+                    }
+                });
                 w.each([&](int l) {
 #pragma unroll
                     for (int c = 0; c < RC; c++) {
                         const int i = l + 64 * c;
-                        g[c].at(l) = 0.0;
                         if (i < r) {
                             double *qi = Q + i * ldq;
-                            const double gi = beta * (zv[c].at(l) - alpha * qi[q]);
-                            g[c].at(l) = gi;
-                            qi[q] = fma(-gi, v0, qi[q]);
+                            const double gi = -beta * (zv[c].at(l) - alpha * qi[q]);
+#pragma unroll
+                            for (int j = 0; j < rc; j++) qi[j] = fma(gi, DQ_BC(hv, j), qi[j]);  // Q[i][:] += gi v'
+                            for (int j = rc; j < r; j++) qi[j] = fma(gi, DQ_BC(hv, j), qi[j]);
                         }
                     }
                 });
-                for (int j = q + 1; j < r; j++) {
-                    const double dj = DQ_BC(dv, j);
-                    w.each([&](int l) {
-#pragma unroll
-                        for (int c = 0; c < RC; c++) {
-                            const int i = l + 64 * c;
-                            if (i < r) Q[i * ldq + j] = fma(-g[c].at(l), dj, Q[i * ldq + j]);
-                        }
-                    });
-                }
                 w.each([&](int l) {
 #pragma unroll
                     for (int c = 0; c < RC; c++) {
@@ -864,17 +904,23 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         // cplex.getObjValue(), traj_optimizer.cpp:109, objective at :286-331
         double a1 = 0, a2 = 0;
         if (out_cost) {
-            for (int j = l; j < nxc; j += 64) {
-                int k = j / P, p = j - k * P, m = p / n1, i = p - m * n1;
+            for (int sgm = l; sgm < dim * M; sgm += 64) {  // one Bernstein segment (axis k, segment m) per lane
+                const int k = sgm / M, m = sgm - k * M;
                 const double *seg = x + k * P + m * n1;
-                double s = 0;
-                for (int c = 0; c < n1; c++) s += kp.Qb[i * n1 + c] * seg[c];
-                double term = x[j] * s;
-                if (i == n && m >= M - T) {
-                    double e = x[j] - (double)goal[k];
-                    term += kp.w_t * e * e;
+                double c6[n1];
+#pragma unroll
+                for (int c = 0; c < n1; c++) c6[c] = seg[c];
+#pragma unroll
+                for (int i = 0; i < n1; i++) {
+                    double t = 0;
+#pragma unroll
+                    for (int c = 0; c < n1; c++) t = fma(kp.Qb[i * n1 + c], c6[c], t);
+                    a1 = fma(c6[i], t, a1);
                 }
-                a1 += term;
+                if (m >= M - T) {
+                    const double e = c6[n] - (double)goal[k];
+                    a1 = fma(kp.w_t * e, e, a1);
+                }
             }
             for (int s = l; s < nslk; s += 64) {
                 int m = s % M;

@@ -95,7 +95,19 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
         key[i] = DLSCQP_KEY(rows[i].m, rows[i].i, rows[i].slack, rows[i].flags & DLSCQP_ROW_DYNAMIC);
     }
     RowsView rv{nx.data(), ny.data(), nz.data(), px.data(), py.data(), pz.data(), d.data(), key.data()};
-    MemLayout lay = make_layout(kp, max_slack_obs, kmax);
+    // same instantiation choice as the launcher in dlscqp.hip (select_kernel)
+    int KUsel = 4, SUsel = 10;
+    auto fn = plan_agent<2, 0, 0, 0, 4, 10, WaveCpu>;
+    {
+        const bool generic = std::getenv("EMUL_GENERIC") != nullptr;
+        const int r_max = kp.dim * kp.f + kp.M * max_slack_obs;
+        if (!generic && kp.dim == 3 && kp.f == 13 && kp.M == 5 && r_max <= 64 && kmax <= 128 && kp.n_slots <= 256) { fn = plan_agent<1, 3, 13, 5, 2, 4, WaveCpu>; KUsel = 2; SUsel = 4; }
+        else if (!generic && kp.dim == 3 && kp.f == 13 && kp.M == 5 && r_max <= 64) { fn = plan_agent<1, 3, 13, 5, 4, 5, WaveCpu>; KUsel = 4; SUsel = 5; }
+        else if (!generic && kp.dim == 2 && kp.f == 28 && kp.M == 10 && r_max <= 64) { fn = plan_agent<1, 2, 28, 10, 4, 7, WaveCpu>; KUsel = 4; SUsel = 7; }
+        else if (!generic && kp.dim == 3 && kp.f == 28 && kp.M == 10 && r_max <= 128) { fn = plan_agent<2, 3, 28, 10, 4, 10, WaveCpu>; }
+        else if (r_max <= 64) { fn = plan_agent<1, 0, 0, 0, 4, 10, WaveCpu>; }
+    }
+    MemLayout lay = make_layout(kp, max_slack_obs, kmax, KUsel, SUsel);
     std::vector<unsigned char> mem(lay.bytes + 64);
     WaveCpu w;
     const char *rev = std::getenv("EMUL_REVERSE");
@@ -104,7 +116,6 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
     const size_t xs = (size_t)dim * M * n1 + (size_t)M * max_slack_obs;
     for (int a = 0; a < n_agents; a++) {
         std::memset(mem.data(), 0xCD, mem.size());  // poison: nothing may rely on zero-initialised LDS
-        auto fn = lay.r_max <= 64 ? plan_agent<1, WaveCpu> : plan_agent<2, WaveCpu>;
         fn(w, kp, lay, mem.data(), agents + a, rv, (int)row_offsets[a],
                    (int)(row_offsets[a + 1] - row_offsets[a]), sfc ? sfc + (size_t)a * M * 6 : nullptr,
                    max_slack_obs, do_goal, do_traj, out_goal ? out_goal + (size_t)a * 3 : nullptr,
@@ -127,6 +138,6 @@ extern "C" int emul_table_info(const dlscqp_config *cfg, int *f, int *n_slots, i
     *f = tb.kp.f;
     *n_slots = tb.kp.n_slots;
     *nb = tb.kp.nb;
-    *lds_bytes = make_layout(tb.kp, max_slack_obs, kmax).bytes;
+    *lds_bytes = make_layout(tb.kp, max_slack_obs, kmax, 4, 10).bytes;
     return 0;
 }
