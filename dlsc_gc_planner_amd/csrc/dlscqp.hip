@@ -9,11 +9,13 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #define DQ_FN __host__ __device__ __forceinline__
+#define DQ_KEEP(v) asm volatile("" : "+v"(v))
 #include "gi_core.hpp"
 #include "qp_tables.hpp"
 
@@ -205,6 +207,12 @@ struct KernelChoice {
 // f=28) with register caches sized to the row counts, runtime-shape kernels for everything else.
 KernelChoice select_kernel(const KParams &kp, int max_slack_obs, int kmax) {
     const int r_max = kp.dim * kp.f + kp.M * max_slack_obs;
+    static const bool force_generic = std::getenv("DLSCQP_FORCE_GENERIC") != nullptr;  // debugging aid
+    if (force_generic) {
+        if (r_max <= 64) return {dlscqp_plan_kernel<1, 0, 0, 0, 4, 10>, 4, 4, 10};
+        if (r_max <= 128) return {dlscqp_plan_kernel<2, 0, 0, 0, 4, 10>, 5, 4, 10};
+        return {nullptr, -1, 0, 0};
+    }
     if (kp.dim == 3 && kp.f == 13 && kp.M == 5 && r_max <= 64 && kmax <= 128 && kp.n_slots <= 256)
         return {dlscqp_plan_kernel<1, 3, 13, 5, 2, 4>, 0, 2, 4};
     if (kp.dim == 3 && kp.f == 13 && kp.M == 5 && r_max <= 64) return {dlscqp_plan_kernel<1, 3, 13, 5, 4, 5>, 1, 4, 5};

@@ -36,6 +36,11 @@
 #ifndef DQ_FN
 #define DQ_FN inline
 #endif
+// DQ_KEEP(v): the value must exist here, unconditionally.  On the GPU it stops the compiler from sinking an
+// LDS load into the branch of a later select (which would serialise every load behind its own s_waitcnt).
+#ifndef DQ_KEEP
+#define DQ_KEEP(v) ((void)0)
+#endif
 
 namespace dlscqp {
 
@@ -410,46 +415,50 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         w.each([&](int l) {
             double bv = 0.0;
             int bc = -1;
+            // cached rows: per row, all LDS reads first and unconditionally (DQ_KEEP), then select-based
+            // arithmetic -- no branches, so the reads of consecutive rows issue back to back.
+            // (Staging the loads of all rows in local arrays first miscompiled on gfx950/ROCm 7.2 for SU = 7.)
 #pragma unroll
             for (int u = 0; u < KU; u++) {
-                {  // everything is select-based (no branches) so that the LDS reads of all rows batch
-                    const uint32_t key = ckey[u].at(l);
-                    const bool valid = key != KEY_SKIP && !((fl_lsc.at(l) >> u) & 1);
-                    const int m = key & 0xFF, i = (key >> 8) & 0xF;
-                    const int p = valid ? m * n1 + i : 0;
-                    double val = (double)cnx[u].at(l) * x[p];
-                    val = fma((double)cny[u].at(l), x[P + p], val);
-                    if (dim == 3) val = fma((double)cnz[u].at(l), x[2 * P + p], val);
-                    const uint32_t sl = key >> 16;
-                    const bool has_slack = valid && sl != 0xFFFFu;
-                    const double sx = x[nxc + (has_slack ? (int)sl * M + m : 0)];
-                    val -= has_slack ? sx : 0.0;
-                    const double v = valid ? cd[u].at(l) - val : -1.0;
-                    bc = v > bv ? l + 64 * u : bc;
-                    bv = v > bv ? v : bv;
-                }
+                const uint32_t key = ckey[u].at(l);
+                const bool in_model = key != KEY_SKIP;
+                const int m = key & 0xFF, i = (key >> 8) & 0xF;
+                const int p = in_model ? m * n1 + i : 0;
+                const uint32_t sl = key >> 16;
+                const bool has_slack = in_model && sl != 0xFFFFu;
+                double x0 = x[p], x1 = x[P + p], x2 = dim == 3 ? x[2 * P + p] : 0.0;
+                double x3 = x[nxc + (has_slack ? (int)sl * M + m : 0)];
+                DQ_KEEP(x0); DQ_KEEP(x1); DQ_KEEP(x2); DQ_KEEP(x3);
+                const bool valid = in_model && !((fl_lsc.at(l) >> u) & 1);
+                double val = (double)cnx[u].at(l) * x0;
+                val = fma((double)cny[u].at(l), x1, val);
+                if (dim == 3) val = fma((double)cnz[u].at(l), x2, val);
+                val -= has_slack ? x3 : 0.0;
+                const double v = valid ? cd[u].at(l) - val : -1.0;
+                bc = v > bv ? l + 64 * u : bc;
+                bv = v > bv ? v : bv;
             }
 #pragma unroll
             for (int u = 0; u < SU; u++) {
-                {
-                    const uint32_t pi = sidx[u].at(l), pc = scb[u].at(l);
-                    const bool valid = !(pi & 0x80000000u);
-                    int i0 = pi & 0x3FF, i1 = (pi >> 10) & 0x3FF, i2 = (pi >> 20) & 0x3FF;
-                    i0 = i0 == 0x3FF ? 0 : i0;  // unused entries carry coefficient 0
-                    i1 = i1 == 0x3FF ? 0 : i1;
-                    i2 = i2 == 0x3FF ? 0 : i2;
-                    double val = (double)(int8_t)(pc & 0xFF) * x[i0];
-                    val = fma((double)(int8_t)((pc >> 8) & 0xFF), x[i1], val);
-                    val = fma((double)(int8_t)((pc >> 16) & 0xFF), x[i2], val);
-                    const int bs = pc >> 24;
-                    const double vlo = (valid && !((fl_slo.at(l) >> u) & 1)) ? blo[bs] - val : -1.0;
-                    const double vhi = (valid && !((fl_shi.at(l) >> u) & 1)) ? val - bhi[bs] : -1.0;
-                    const int s = l + 64 * u;
-                    bc = vlo > bv ? K + 2 * s : bc;
-                    bv = vlo > bv ? vlo : bv;
-                    bc = vhi > bv ? K + 2 * s + 1 : bc;
-                    bv = vhi > bv ? vhi : bv;
-                }
+                const uint32_t pi = sidx[u].at(l), pc = scb[u].at(l);
+                const bool valid = !(pi & 0x80000000u);
+                int i0 = pi & 0x3FF, i1 = (pi >> 10) & 0x3FF, i2 = (pi >> 20) & 0x3FF;
+                i0 = i0 == 0x3FF ? 0 : i0;  // unused entries carry coefficient 0
+                i1 = i1 == 0x3FF ? 0 : i1;
+                i2 = i2 == 0x3FF ? 0 : i2;
+                const int bs = pc >> 24;
+                double x0 = x[i0], x1 = x[i1], x2 = x[i2], b0 = blo[bs], b1 = bhi[bs];
+                DQ_KEEP(x0); DQ_KEEP(x1); DQ_KEEP(x2); DQ_KEEP(b0); DQ_KEEP(b1);
+                double val = (double)(int8_t)(pc & 0xFF) * x0;
+                val = fma((double)(int8_t)((pc >> 8) & 0xFF), x1, val);
+                val = fma((double)(int8_t)((pc >> 16) & 0xFF), x2, val);
+                const double vlo = (valid && !((fl_slo.at(l) >> u) & 1)) ? b0 - val : -1.0;
+                const double vhi = (valid && !((fl_shi.at(l) >> u) & 1)) ? val - b1 : -1.0;
+                const int s = l + 64 * u;
+                bc = vlo > bv ? K + 2 * s : bc;
+                bv = vlo > bv ? vlo : bv;
+                bc = vhi > bv ? K + 2 * s + 1 : bc;
+                bv = vhi > bv ? vhi : bv;
             }
             for (int s = l; s < nslk; s += 64) {  // eps <= 0 (traj_optimizer.cpp:276)
                 const double v = x[nxc + s];

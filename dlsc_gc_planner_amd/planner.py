@@ -30,6 +30,13 @@ def _ptr(a):
 
 class BatchTrajOptimizer:
     def __init__(self, cfg):
+        # torch bundles its own HIP runtime; when both are used in one process torch has to initialise
+        # it first (the other order leaves torch with "No HIP GPUs are available")
+        try:
+            import torch
+            torch.cuda.is_available()
+        except ImportError:
+            pass
         self.lib = abi.load_library()
         self.cfg = cfg
         h = C.c_void_p()
