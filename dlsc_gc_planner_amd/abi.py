@@ -113,6 +113,7 @@ class DeviceBatch(C.Structure):
         ("out_slack_cost", C.c_void_p),
         ("out_status", C.c_void_p),
         ("out_iters", C.c_void_p),
+        ("agent_order", C.c_void_p),
         ("debug_stamps", C.c_void_p),
     ]
 

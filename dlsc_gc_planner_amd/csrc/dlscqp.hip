@@ -166,14 +166,16 @@ struct KernelArgs {
     double *out_slack_cost;
     int32_t *out_status;
     int32_t *out_iters;
+    const int32_t *order;            // optional launch permutation
     unsigned long long *out_stamps;  // [n_agents][12], diagnostic build only
 };
 
 template <int RC, int DIMS, int FS, int MS, int KU, int SU>
 __global__ __launch_bounds__(64, 2) void dlscqp_plan_kernel(KParams kp, MemLayout lay, KernelArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int ag = blockIdx.x;
-    if (ag >= a.n_agents) return;
+    if ((int)blockIdx.x >= a.n_agents) return;
+    const int ag = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    if (ag < 0 || ag >= a.n_agents) return;
     WaveGpu w;
     w.lane = (int)threadIdx.x;
 #ifdef DLSCQP_STAMPS
@@ -426,6 +428,7 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
     a.out_slack_cost = b->out_slack_cost;
     a.out_status = b->out_status;
     a.out_iters = b->out_iters;
+    a.order = b->agent_order;
     a.out_stamps = (unsigned long long *)b->debug_stamps;
     const bool timed = c->ev_used < (int)c->ev0.size();
     if (timed) HIP_TRY(hipEventRecord(c->ev0[c->ev_used], stream));

@@ -84,6 +84,10 @@ DQ_FN double f32_norm3(float a, float b, float c) {
 
 constexpr uint32_t KEY_SKIP = 0xFFFFFFFFu;  // cached LSC row that is not part of the model
 
+// v[k] for a per-lane k without dynamic indexing of a register array (which would go through scratch memory)
+template <class T>
+DQ_FN T pick3(const T *v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }
+
 #define DQ_RP(i, j) Rp[(j) * ((j) + 1) / 2 + (i)]
 // element e of a per-lane vector spread over RC registers
 #define DQ_BC(arr, e) (RC == 1 ? w.bcast((arr)[0], (e)) : ((e) < 64 ? w.bcast((arr)[0], (e)) : w.bcast((arr)[RC - 1], (e) - 64)))
@@ -305,8 +309,8 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     w.each([&](int l) {
         for (int j = l; j < nxc; j += 64) {
             int k = j / P, p = j - k * P;
-            x[j] = tXs[p * 3 + 0] * (double)pos[k] + tXs[p * 3 + 1] * (double)vel[k] +
-                   tXs[p * 3 + 2] * (double)acc[k] + tXg[p] * (double)goal[k];
+            x[j] = tXs[p * 3 + 0] * (double)pick3(pos, k) + tXs[p * 3 + 1] * (double)pick3(vel, k) +
+                   tXs[p * 3 + 2] * (double)pick3(acc, k) + tXg[p] * (double)pick3(goal, k);
         }
         for (int s = l; s < nslk; s += 64) x[nxc + s] = 0.0;
         for (int j = l; j < lay.nflag; j += 64) cold_flag[j] = 0;
@@ -315,8 +319,8 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             double lo, hi;
             if (b < dim * M) {
                 int k = b / M, m = b - k * M;
-                lo = kp.world_min[k];
-                hi = kp.world_max[k];
+                lo = pick3(kp.world_min, k);
+                hi = pick3(kp.world_max, k);
                 if (kp.rsfc_mode && k == 2 && m == 0) { lo = -100; hi = 100; }  // traj_optimizer.cpp:254-258
                 if (kp.use_sfc && sfc) {  // Box::convertToLSCs, collision_constraints.cpp:66-87
                     double smin = (double)sfc[m * 6 + k], smax = (double)sfc[m * 6 + 3 + k];
@@ -332,7 +336,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             } else {
                 int k = b - (dim * M + 3);
                 double cw = 0.5 * kp.comm_range - SP_EPSILON_FLOAT;  // traj_optimizer.cpp:507-510
-                lo = (double)wp[k] - cw; hi = (double)wp[k] + cw;
+                lo = (double)pick3(wp, k) - cw; hi = (double)pick3(wp, k) + cw;
             }
             blo[b] = lo;
             bhi[b] = hi;
@@ -538,9 +542,12 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 if (sl != 0xFFFFu && (int)sl >= nso) key |= 0xFFFF0000u;
             }
             const int m = key & 0xFF, i = (key >> 8) & 0xF;
-            for (int k = 0; k < dim; k++) {
-                ek[k] = k; ep[k] = m * n1 + i; cf[k] = (double)nn[k];
-                axes_mask |= 1 << k;
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                if (k < dim) {
+                    ek[k] = k; ep[k] = m * n1 + i; cf[k] = (double)nn[k];
+                    axes_mask |= 1 << k;
+                }
             }
             const uint32_t sl = key >> 16;
             if (sl != 0xFFFFu) sidx_row = (int)sl * M + m;
@@ -556,6 +563,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     pi = uq == u ? a0 : pi;
                     pc = uq == u ? a1 : pc;
                 }
+#pragma unroll
                 for (int t = 0; t < 3; t++) {
                     sidx3[t] = (pi >> (10 * t)) & 0x3FF;
                     if (sidx3[t] == 0x3FF) sidx3[t] = -1;
@@ -564,17 +572,20 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 bs = pc >> 24;
             } else {
                 const Slot sl = slots[s];  // uniform load of 16 B (L2-resident table)
+#pragma unroll
                 for (int t = 0; t < 3; t++) { sidx3[t] = sl.idx[t]; scoef3[t] = sl.coef[t]; }
                 bs = sl.bsel;
             }
             const double sg = side == 0 ? 1.0 : -1.0;  // val >= lo   |   -val >= -hi
-            int cnt = 0;
-            for (int t = 0; t < 3; t++)
-                if (sidx3[t] >= 0) {
-                    int k = sidx3[t] / P;
-                    ek[cnt] = k; ep[cnt] = sidx3[t] - k * P; cf[cnt] = sg * (double)scoef3[t]; cnt++;
-                    axes_mask |= 1 << k;
-                }
+#pragma unroll
+            for (int t = 0; t < 3; t++) {  // fixed positions, unused entries keep ek = -1 / cf = 0
+                const bool used = sidx3[t] >= 0;
+                const int k = used ? sidx3[t] / P : -1;
+                ek[t] = k;
+                ep[t] = used ? sidx3[t] - k * P : 0;
+                cf[t] = used ? sg * (double)scoef3[t] : 0.0;
+                axes_mask |= used ? (1 << k) : 0;
+            }
             // back to the reference's row scaling: n/dt for velocity rows, n(n-1)/dt^2 for acceleration rows
             row_scale = bs == dim * M ? 1.0 / kp.vel_scale : (bs == dim * M + 1 ? 1.0 / kp.acc_scale : 1.0);
         } else {
@@ -927,7 +938,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     a1 = fma(c6[i], t, a1);
                 }
                 if (m >= M - T) {
-                    const double e = c6[n] - (double)goal[k];
+                    const double e = c6[n] - (double)pick3(goal, k);
                     a1 = fma(kp.w_t * e, e, a1);
                 }
             }

@@ -190,9 +190,23 @@ class DeviceBatch:
         b.out_slack_cost = self.out_slack.data_ptr() if max_slack_obs > 0 else None
         b.out_status = self.out_status.data_ptr()
         b.out_iters = None if self.out_iters is None else self.out_iters.data_ptr()
+        b.agent_order = None
+        self.order = None
         self.c = b
         self.max_rows = kmax
         self.max_slack_obs = max_slack_obs
+
+    def set_order(self, order):
+        """Launch permutation (workgroup b plans agent order[b]); None restores the identity.  Meant to be the
+        agents sorted by the previous replanning step's iteration count, most expensive first."""
+        if order is None:
+            self.order = None
+            self.c.agent_order = None
+            return
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        assert order.shape == (self.n_agents,) and np.array_equal(np.sort(order), np.arange(self.n_agents))
+        self.order = self.torch.from_numpy(order).to(self.device)
+        self.c.agent_order = self.order.data_ptr()
 
     def launch(self, do_goal=True, do_traj=True, stream=None):
         """Asynchronous launch on `stream` (default: torch's current stream)."""

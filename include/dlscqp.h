@@ -188,6 +188,10 @@ typedef struct dlscqp_device_batch {
     double *out_slack_cost;         /* [n_agents][max_slack_obs] or NULL                        */
     int32_t *out_status;            /* [n_agents]                                               */
     int32_t *out_iters;             /* optional [n_agents][4] {iterations, adds, drops, active} */
+    const int32_t *agent_order;     /* optional [n_agents] permutation: workgroup b plans agent agent_order[b].
+                                       Agents differ in active-set iterations by 50x; launching the expensive ones
+                                       first (e.g. by the previous step's out_iters) removes the tail of the launch.
+                                       NULL = identity.  Results do not depend on it.                            */
     uint64_t *debug_stamps;         /* NULL; [n_agents][12] cycle stamps, read only by the separate
                                        -DDLSCQP_STAMPS diagnostic build (profiles/stamps.py)        */
 } dlscqp_device_batch;
