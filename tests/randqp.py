@@ -10,7 +10,7 @@ import numpy as np
 from dlsc_gc_planner_amd import abi
 
 
-def random_batch(cfg, n_agents, seed, max_rows=60, n_dyn=0, infeasible_frac=0.1, tight=0.08):
+def random_batch(cfg, n_agents, seed, max_rows=60, n_dyn=0, infeasible_frac=0.1, tight=0.08, n_static_max=3, keep=0.4):
     rng = np.random.default_rng(seed)
     dim, M, n = cfg.world_dimension, cfg.M, cfg.n
     wmin = np.array(cfg.world_min[:])
@@ -47,7 +47,7 @@ def random_batch(cfg, n_agents, seed, max_rows=60, n_dyn=0, infeasible_frac=0.1,
         ag["current_goal_point"], ag["next_waypoint"] = goal, wp
         ag["id"] = a
         ag["max_vel"], ag["max_acc"], ag["radius"], ag["nominal_velocity"] = 1.0, 2.0, 0.15, 1.0
-        n_static = int(rng.integers(0, 4))
+        n_static = int(rng.integers(0, n_static_max + 1))
         nd = int(rng.integers(0, n_dyn + 1)) if n_dyn > 0 else 0
         ag["n_obs"] = n_static + nd
         ag["n_slack_obs"] = nd
@@ -75,7 +75,7 @@ def random_batch(cfg, n_agents, seed, max_rows=60, n_dyn=0, infeasible_frac=0.1,
                 for i in range(n + 1):
                     if len(agent_rows) >= max_rows:
                         break
-                    if rng.random() < 0.6:
+                    if rng.random() >= keep:
                         continue
                     r = np.zeros(1, abi.ROW_DTYPE)[0]
                     r["normal"] = nrm
@@ -124,4 +124,8 @@ CONFIGS = {
     "lsc2d_M4_nostop": (dict(dim=2, M=4, planner_mode=abi.PLANNER_BVC), dict(max_rows=40)),
     "rsfc3d_M5_allslack": (dict(dim=3, M=5, planner_mode=abi.PLANNER_RECIPROCALRSFC,
                                 slack_mode=abi.SLACK_COLLISIONCONSTRAINT), dict(max_rows=60, n_dyn=2)),
+    # more than 256 rows per agent: rows beyond the kernel's register cache are read from HBM on every scan
+    "crowd3d_M5_400rows": (dict(dim=3, M=5), dict(max_rows=400, n_static_max=22, keep=0.75, tight=-0.15, infeasible_frac=0.05)),
+    # M = 12: runtime-shape kernel, 102 reduced dimensions (two registers per vector), > 640 structured slots
+    "long3d_M12_comm": (dict(dim=3, M=12, communication_range=3.0), dict(max_rows=100, tight=0.05)),
 }
