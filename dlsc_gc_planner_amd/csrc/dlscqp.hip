@@ -250,7 +250,7 @@ struct dlscqp_ctx {
     double dt;
     HostTables tb;
     KParams kp;  // with device table pointers
-    double *d_tabN = nullptr, *d_tabX0s = nullptr, *d_tabX0g = nullptr;
+    double *d_tabN = nullptr, *d_tabX0s = nullptr, *d_tabX0g = nullptr, *d_tabNN = nullptr, *d_tabSIW = nullptr;
     Slot *d_slots = nullptr;
     hipStream_t stream = nullptr;
     int max_dyn_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -271,11 +271,15 @@ static int upload_tables(dlscqp_ctx *c) {
     if (!up((void **)&c->d_tabN, c->tb.tabN.data(), c->tb.tabN.size() * 8)) return DLSCQP_ERR_HIP;
     if (!up((void **)&c->d_tabX0s, c->tb.tabX0s.data(), c->tb.tabX0s.size() * 8)) return DLSCQP_ERR_HIP;
     if (!up((void **)&c->d_tabX0g, c->tb.tabX0g.data(), c->tb.tabX0g.size() * 8)) return DLSCQP_ERR_HIP;
+    if (!up((void **)&c->d_tabNN, c->tb.tabNN.data(), c->tb.tabNN.size() * 8)) return DLSCQP_ERR_HIP;
+    if (!up((void **)&c->d_tabSIW, c->tb.tabSIW.data(), c->tb.tabSIW.size() * 8)) return DLSCQP_ERR_HIP;
     if (!up((void **)&c->d_slots, c->tb.slots.data(), c->tb.slots.size() * sizeof(Slot))) return DLSCQP_ERR_HIP;
     c->kp = c->tb.kp;
     c->kp.tabN = c->d_tabN;
     c->kp.tabX0s = c->d_tabX0s;
     c->kp.tabX0g = c->d_tabX0g;
+    c->kp.tabNN = c->d_tabNN;
+    c->kp.tabSIW = c->d_tabSIW;
     c->kp.slots = c->d_slots;
     return DLSCQP_SUCCESS;
 }
@@ -318,6 +322,8 @@ extern "C" void dlscqp_destroy(dlscqp_ctx *c) {
     if (c->d_tabN) (void)hipFree(c->d_tabN);
     if (c->d_tabX0s) (void)hipFree(c->d_tabX0s);
     if (c->d_tabX0g) (void)hipFree(c->d_tabX0g);
+    if (c->d_tabNN) (void)hipFree(c->d_tabNN);
+    if (c->d_tabSIW) (void)hipFree(c->d_tabSIW);
     if (c->d_slots) (void)hipFree(c->d_slots);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->h_stage) (void)hipHostFree(c->h_stage);

@@ -304,6 +304,8 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     const double *tN = kp.tabN + (size_t)(T - 1) * P * f;
     const double *tXs = kp.tabX0s + (size_t)(T - 1) * P * 3;
     const double *tXg = kp.tabX0g + (size_t)(T - 1) * P;
+    const double *tNN = kp.tabNN + (size_t)(T - 1) * P;
+    const double *tSIW = kp.tabSIW + (size_t)(T - 1) * kp.n_slots;
 
     // ---- unconstrained minimiser and bound table into LDS -------------------------------------------
     w.each([&](int l) {
@@ -343,6 +345,15 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         }
     });
     // finish the LSC cache: rhs = d + n.p (traj_optimizer.cpp:427-439), drop rows that are not in the model
+    RegD ciw[KU], siw[SU];
+#pragma unroll
+    for (int u = 0; u < KU; u++) w.each([&](int l) { ciw[u].at(l) = 0.0; });
+#pragma unroll
+    for (int u = 0; u < SU; u++)
+        w.each([&](int l) {
+            const int s = l + 64 * u;
+            siw[u].at(l) = s < Sc ? tSIW[s] : 0.0;
+        });
 #pragma unroll
     for (int u = 0; u < KU; u++) {
         {
@@ -356,10 +367,18 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     return;
                 }
                 double rhs = cd[u].at(l) + (double)nx * (double)cpx[u].at(l) + (double)ny * (double)cpy[u].at(l);
-                if (dim == 3) rhs += (double)nz * (double)cpz[u].at(l);
+                double nsq = (double)nx * (double)nx + (double)ny * (double)ny;
+                if (dim == 3) {
+                    rhs += (double)nz * (double)cpz[u].at(l);
+                    nsq += (double)nz * (double)nz;
+                }
                 cd[u].at(l) = rhs;
                 uint32_t sl = key >> 16;
-                if (sl != 0xFFFFu && (int)sl >= nso) ckey[u].at(l) = key | 0xFFFF0000u;  // no such slack variable
+                if (sl != 0xFFFFu && (int)sl >= nso) { ckey[u].at(l) = key | 0xFFFF0000u; sl = 0xFFFFu; }  // no such slack variable
+                // pivot scaling 1 / |N' a|  (whitened length of the row normal)
+                double wsq = nsq * tNN[m * n1 + i];
+                if (sl != 0xFFFFu) wsq += kp.sigma[m] * kp.sigma[m];
+                ciw[u].at(l) = wsq > 0 ? 1.0 / sqrt(wsq) : 0.0;
             });
         }
     }
@@ -414,10 +433,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 
     for (;;) {
         // ---- most violated inactive row ---------------------------------------------------------
-        RegD bestv;
+        RegD bestv, bests;
         RegI bestc;
         w.each([&](int l) {
-            double bv = 0.0;
+            double bv = 0.0, bs = 0.0;  // violation and pivot score (violation / whitened row length) of the lane's best row
             int bc = -1;
             // cached rows: per row, all LDS reads first and unconditionally (DQ_KEEP), then select-based
             // arithmetic -- no branches, so the reads of consecutive rows issue back to back.
@@ -439,8 +458,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 if (dim == 3) val = fma((double)cnz[u].at(l), x2, val);
                 val -= has_slack ? x3 : 0.0;
                 const double v = valid ? cd[u].at(l) - val : -1.0;
-                bc = v > bv ? l + 64 * u : bc;
-                bv = v > bv ? v : bv;
+                const double sc = v > VIOL_TOL ? v * ciw[u].at(l) : -1.0;
+                bc = sc > bs ? l + 64 * u : bc;
+                bv = sc > bs ? v : bv;
+                bs = sc > bs ? sc : bs;
             }
 #pragma unroll
             for (int u = 0; u < SU; u++) {
@@ -450,8 +471,8 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 i0 = i0 == 0x3FF ? 0 : i0;  // unused entries carry coefficient 0
                 i1 = i1 == 0x3FF ? 0 : i1;
                 i2 = i2 == 0x3FF ? 0 : i2;
-                const int bs = pc >> 24;
-                double x0 = x[i0], x1 = x[i1], x2 = x[i2], b0 = blo[bs], b1 = bhi[bs];
+                const int bsel = pc >> 24;
+                double x0 = x[i0], x1 = x[i1], x2 = x[i2], b0 = blo[bsel], b1 = bhi[bsel];
                 DQ_KEEP(x0); DQ_KEEP(x1); DQ_KEEP(x2); DQ_KEEP(b0); DQ_KEEP(b1);
                 double val = (double)(int8_t)(pc & 0xFF) * x0;
                 val = fma((double)(int8_t)((pc >> 8) & 0xFF), x1, val);
@@ -459,14 +480,20 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 const double vlo = (valid && !((fl_slo.at(l) >> u) & 1)) ? b0 - val : -1.0;
                 const double vhi = (valid && !((fl_shi.at(l) >> u) & 1)) ? val - b1 : -1.0;
                 const int s = l + 64 * u;
-                bc = vlo > bv ? K + 2 * s : bc;
-                bv = vlo > bv ? vlo : bv;
-                bc = vhi > bv ? K + 2 * s + 1 : bc;
-                bv = vhi > bv ? vhi : bv;
+                const double slo = vlo > VIOL_TOL ? vlo * siw[u].at(l) : -1.0;
+                bc = slo > bs ? K + 2 * s : bc;
+                bv = slo > bs ? vlo : bv;
+                bs = slo > bs ? slo : bs;
+                const double shi = vhi > VIOL_TOL ? vhi * siw[u].at(l) : -1.0;
+                bc = shi > bs ? K + 2 * s + 1 : bc;
+                bv = shi > bs ? vhi : bv;
+                bs = shi > bs ? shi : bs;
             }
             for (int s = l; s < nslk; s += 64) {  // eps <= 0 (traj_optimizer.cpp:276)
                 const double v = x[nxc + s];
-                if (v > bv && !((fl_slk.at(l) >> (s >> 6)) & 1)) { bv = v; bc = code_slack0 + s; }
+                const double sg = kp.sigma[s % M];
+                const double sc = (v > VIOL_TOL && sg > 0 && !((fl_slk.at(l) >> (s >> 6)) & 1)) ? v / sg : -1.0;
+                if (sc > bs) { bs = sc; bv = v; bc = code_slack0 + s; }
             }
             // rows beyond the register cache: straight from HBM (rare: K > 256 or > 640 slots)
             for (int j = Kc + l; j < K; j += 64) {
@@ -483,7 +510,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 const uint32_t sl = key >> 16;
                 if (sl != 0xFFFFu && (int)sl < nso) val -= x[nxc + (int)sl * M + m];
                 const double v = rhs - val;
-                if (v > bv) { bv = v; bc = j; }
+                double wsq = ((double)nx * (double)nx + (double)ny * (double)ny + (dim == 3 ? (double)nz * (double)nz : 0.0)) * tNN[p];
+                if (sl != 0xFFFFu && (int)sl < nso) wsq += kp.sigma[m] * kp.sigma[m];
+                const double sc = (v > VIOL_TOL && wsq > 0) ? v / sqrt(wsq) : -1.0;
+                if (sc > bs) { bs = sc; bv = v; bc = j; }
             }
             for (int s = Sc + l; s < n_slots; s += 64) {
                 const Slot sl = slots[s];
@@ -491,19 +521,24 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 for (int t = 0; t < 3; t++)
                     if (sl.idx[t] >= 0) val += (double)sl.coef[t] * x[sl.idx[t]];
                 const double vlo = blo[sl.bsel] - val, vhi = val - bhi[sl.bsel];
-                if (vlo > bv && !cold_flag[cold_rows + 2 * (s - Sc)]) { bv = vlo; bc = K + 2 * s; }
-                if (vhi > bv && !cold_flag[cold_rows + 2 * (s - Sc) + 1]) { bv = vhi; bc = K + 2 * s + 1; }
+                const double iw = tSIW[s];
+                const double slo = (vlo > VIOL_TOL && !cold_flag[cold_rows + 2 * (s - Sc)]) ? vlo * iw : -1.0;
+                if (slo > bs) { bs = slo; bv = vlo; bc = K + 2 * s; }
+                const double shi = (vhi > VIOL_TOL && !cold_flag[cold_rows + 2 * (s - Sc) + 1]) ? vhi * iw : -1.0;
+                if (shi > bs) { bs = shi; bv = vhi; bc = K + 2 * s + 1; }
             }
             bestv.at(l) = bv;
+            bests.at(l) = bs;
             bestc.at(l) = bc;
         });
-        double viol = w.max(bestv);  // = -(a.x - b) of the most violated row
-        w.stamp(2);                  // row scan + arg-max
-        if (!(viol > VIOL_TOL)) break;  // optimal
+        const double top = w.max(bests);  // best pivot score over all violated rows
+        w.stamp(2);                       // row scan + arg-max
+        if (!(top > 0.0)) break;          // no row violated by more than VIOL_TOL: optimal
         RegI is_top;
-        w.each([&](int l) { is_top.at(l) = (bestv.at(l) == viol && bestc.at(l) >= 0) ? 1 : 0; });
+        w.each([&](int l) { is_top.at(l) = (bests.at(l) == top && bestc.at(l) >= 0) ? 1 : 0; });
         const int owner_lane = w.first_lane(is_top);
         const int ip = w.bcast(bestc, owner_lane);
+        double viol = w.bcast(bestv, owner_lane);  // = -(a.x - b) of the chosen row
 
         if (!factors_ready) {
             // first violated row: set up the factors (agents that never get here skip all of this)
@@ -688,16 +723,37 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 #pragma unroll
                 for (int c = 0; c < RC; c++) rv[c].at(l) = dv[c].at(l);
             });
-            for (int k = q - 1; k >= 0; k--) {
-                const double rk = DQ_BC(rv, k) * DQ_BC(rinv, k);
+            {
+                // software-pipelined: the R entry of the NEXT column is already in flight while this column's
+                // r_k travels through readlane -> multiply -> fma (the loop-carried chain)
+                RegD rcol[RC];
                 w.each([&](int l) {
 #pragma unroll
                     for (int c = 0; c < RC; c++) {
                         const int i = l + 64 * c;
-                        if (i == k) rv[c].at(l) = rk;
-                        else if (i < k) rv[c].at(l) = fma(-DQ_RP(i, k), rk, rv[c].at(l));
+                        rcol[c].at(l) = (q > 0 && i < q - 1) ? DQ_RP(i, q - 1) : 0.0;
                     }
                 });
+                for (int k = q - 1; k >= 0; k--) {
+                    RegD rnext[RC];
+                    w.each([&](int l) {
+#pragma unroll
+                        for (int c = 0; c < RC; c++) {
+                            const int i = l + 64 * c;
+                            rnext[c].at(l) = (k > 0 && i < k - 1) ? DQ_RP(i, k - 1) : 0.0;
+                        }
+                    });
+                    const double rk = DQ_BC(rv, k) * DQ_BC(rinv, k);
+                    w.each([&](int l) {
+#pragma unroll
+                        for (int c = 0; c < RC; c++) {
+                            const int i = l + 64 * c;
+                            if (i == k) rv[c].at(l) = rk;
+                            else if (i < k) rv[c].at(l) = fma(-rcol[c].at(l), rk, rv[c].at(l));
+                            rcol[c].at(l) = rnext[c].at(l);
+                        }
+                    });
+                }
             }
             w.stamp(6);  // back substitution
             // step lengths: t1 = min u_k / r_k over r_k > 0 (dual), t2 = viol / |d2|^2 (primal)

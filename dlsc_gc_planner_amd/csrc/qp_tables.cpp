@@ -330,6 +330,30 @@ bool build_tables(const dlscqp_config &cfg, int dim, int M, int n, int phi, doub
             for (int m = 0; m < M; m++) add(SLOT_WAYPOINT, B_WP + k, 1.0f, k * P + m * N + n, 1);
     }
     kp.n_slots = (int)out.slots.size();
+    // pivot scaling: a violated row is ranked by its distance in the whitened space, violation / |N_T' a|
+    // (steepest dual ascent); this roughly halves the active-set iterations of the hard agents
+    out.tabNN.assign((size_t)M * P, 0.0);
+    out.tabSIW.assign((size_t)M * kp.n_slots, 0.0);
+    for (int T = 1; T <= M; T++) {
+        if (!kp.t_valid[T - 1]) continue;
+        const double *oN = &out.tabN[(size_t)(T - 1) * P * f];
+        for (int p = 0; p < P; p++) {
+            double t = 0;
+            for (int a = 0; a < f; a++) t += oN[(size_t)p * f + a] * oN[(size_t)p * f + a];
+            out.tabNN[(size_t)(T - 1) * P + p] = t;
+        }
+        for (int si = 0; si < kp.n_slots; si++) {
+            const Slot &sl = out.slots[si];
+            double t = 0;
+            for (int a = 0; a < f; a++) {
+                double v = 0;
+                for (int e = 0; e < 3; e++)
+                    if (sl.idx[e] >= 0) v += (double)sl.coef[e] * oN[(size_t)(sl.idx[e] % P) * f + a];
+                t += v * v;
+            }
+            out.tabSIW[(size_t)(T - 1) * kp.n_slots + si] = t > 0 ? 1.0 / std::sqrt(t) : 0.0;
+        }
+    }
     kp.max_iter = 0;  // 0: 20 (r + 8) + 200, chosen per agent in plan_agent
     return true;
 }

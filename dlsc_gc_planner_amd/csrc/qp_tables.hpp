@@ -13,6 +13,8 @@ struct HostTables {
     std::vector<double> tabN;    // [M][P][f]
     std::vector<double> tabX0s;  // [M][P][3]
     std::vector<double> tabX0g;  // [M][P]
+    std::vector<double> tabNN;   // [M][P]
+    std::vector<double> tabSIW;  // [M][n_slots]
     std::vector<Slot> slots;
 };
 

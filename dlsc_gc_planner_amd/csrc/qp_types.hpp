@@ -44,6 +44,8 @@ struct KParams {
     const double *tabN;           // [M][P][f]
     const double *tabX0s;         // [M][P][3]
     const double *tabX0g;         // [M][P]
+    const double *tabNN;          // [M][P]        |N_T[p,:]|^2  (pivot scaling of LSC rows)
+    const double *tabSIW;         // [M][n_slots]  1 / |N_T' a_slot|  (pivot scaling of structured rows)
     const Slot *slots;            // [n_slots]
 };
 

@@ -59,6 +59,11 @@ def main():
         for p in range(2, 11):
             print("  %-22s %10.0f" % (PHASES[p], (st[big, p] / iters).mean()))
         print("  total per iteration     %10.0f" % (st[big, 2:11].sum(1) / iters).mean())
+    worst = int(np.argmax(it[:, 0]))
+    print("\nslowest agent: %d iterations (%d adds, %d drops, %d active at exit), %.0f cycles; per phase:" % (
+        it[worst, 0], it[worst, 1], it[worst, 2], it[worst, 3], st[worst].sum()))
+    for p, name in enumerate(PHASES):
+        print("  %-22s %10.0f  (%.0f per iteration)" % (name, st[worst, p], st[worst, p] / max(it[worst, 0], 1)))
     zero = it[:, 0] == 0
     print("\nagents with 0 iterations: %d (%.0f%%), mean cycles %.0f" % (zero.sum(), 100 * zero.mean(), st[zero].sum(1).mean()))
     opt.close()

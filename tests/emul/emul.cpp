@@ -81,6 +81,8 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
     kp.tabN = tb.tabN.data();
     kp.tabX0s = tb.tabX0s.data();
     kp.tabX0g = tb.tabX0g.data();
+    kp.tabNN = tb.tabNN.data();
+    kp.tabSIW = tb.tabSIW.data();
     kp.slots = tb.slots.data();
     const int64_t nrows = row_offsets[n_agents];
     std::vector<float> nx(nrows + 1), ny(nrows + 1), nz(nrows + 1), px(nrows + 1), py(nrows + 1), pz(nrows + 1);
