@@ -136,6 +136,30 @@ struct WaveGpu {
         sa = readlane_f64(x, 63);
         sb = readlane_f64(y, 63);
     }
+    // inclusive prefix sum (the same DPP sequence is a Hillis-Steele scan), carried across registers
+    __device__ __forceinline__ void prefix_sum(Reg<double> *arr, int nchunks) const {
+        double carry = 0.0;
+        for (int c = 0; c < nchunks; c++) {
+            double x = arr[c].v;
+            x += dpp_f64<0x111, 0xf>(0.0, x);
+            x += dpp_f64<0x112, 0xf>(0.0, x);
+            x += dpp_f64<0x114, 0xf>(0.0, x);
+            x += dpp_f64<0x118, 0xf>(0.0, x);
+            x += dpp_f64<0x142, 0xa>(0.0, x);
+            x += dpp_f64<0x143, 0xc>(0.0, x);
+            x += carry;
+            arr[c].v = x;
+            carry = readlane_f64(x, 63);
+        }
+    }
+    template <class T>
+    __device__ __forceinline__ void shift_up(const Reg<T> *arr, int c, int nchunks, Reg<T> &out) const {
+        (void)nchunks;
+        T prv = __shfl_up(arr[c].v, 1, 64);
+        T tail = c > 0 ? __shfl(arr[c - 1].v, 63, 64) : T(0);
+        if (lane == 0) prv = tail;
+        out.v = prv;
+    }
     __device__ __forceinline__ bool any(const Reg<int> &r) const { return __ballot(r.v != 0) != 0ull; }
     __device__ __forceinline__ int first_lane(const Reg<int> &r) const {
         unsigned long long m = __ballot(r.v != 0);

@@ -10,10 +10,12 @@
 //     pure LDS reads of control points + FMAs, followed by one arg-max butterfly;
 //   * the small vectors of the method (whitened normal, d = Q'a, step direction z, R^-1 d, duals,
 //     active list) are one register per lane, broadcast with readlane -- no LDS round trips;
-//   * Q (r x r orthogonal) and R (packed upper triangle) of the active normals live in LDS and are
-//     set up lazily: the ~60 % of agents whose unconstrained optimum is feasible never touch them;
-//   * a row is added with ONE Householder reflection (rank-1 update of the trailing block of Q)
-//     and dropped with Givens rotations.
+//   * Q (r x r orthogonal) and S = R^-1 (packed upper triangle; R = triangular factor of the active
+//     normals) live in LDS and are set up lazily: the ~60 % of agents whose unconstrained optimum is
+//     feasible never touch them.  Keeping the INVERSE turns the O(q)-deep back substitution R^-1 d into
+//     one lane-parallel product, appending a row into writing one column (-S d1 / alpha, 1 / alpha), and
+//     deleting a row into a column-rotation sweep whose angles come from one prefix sum of row l of S;
+//   * a row is added with ONE Householder reflection (rank-1 update of the trailing block of Q).
 //
 // Compiled with -ffp-contract=off: the float32 expressions mirror octomap::point3d arithmetic of
 // the reference and must not be fused; the hot FP64 loops call fma() explicitly.
@@ -387,13 +389,13 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 
     // per-lane state of the method
     RegU fl_lsc, fl_slo, fl_shi, fl_slk;  // "skip" bits of the cached rows: active or accepted-infeasible
-    RegD na[RC], dv[RC], zv[RC], rv[RC], uu[RC], rinv[RC];
+    RegD na[RC], dv[RC], zv[RC], rv[RC], uu[RC];
     RegI act[RC];
     w.each([&](int l) {
         fl_lsc.at(l) = 0; fl_slo.at(l) = 0; fl_shi.at(l) = 0; fl_slk.at(l) = 0;
 #pragma unroll
         for (int c = 0; c < RC; c++) {
-            uu[c].at(l) = 0; rinv[c].at(l) = 0; act[c].at(l) = -1; rv[c].at(l) = 0;
+            uu[c].at(l) = 0; act[c].at(l) = -1; rv[c].at(l) = 0;
             na[c].at(l) = 0; dv[c].at(l) = 0; zv[c].at(l) = 0;
         }
     });
@@ -718,42 +720,31 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             double dd2, dall;
             w.sum2(s_d2, s_all, dd2, dall);
             w.stamp(5);  // z, |d2|^2, |d|^2
-            // rv = R^{-1} d1  (column-oriented back substitution, one register per lane)
-            w.each([&](int l) {
-#pragma unroll
-                for (int c = 0; c < RC; c++) rv[c].at(l) = dv[c].at(l);
-            });
+            // rv = R^{-1} d1 = S d1: lane i accumulates row i of S; no dependence between lanes
             {
-                // software-pipelined: the R entry of the NEXT column is already in flight while this column's
-                // r_k travels through readlane -> multiply -> fma (the loop-carried chain)
-                RegD rcol[RC];
+                RegD dm[RC];
+                w.each([&](int l) {
+#pragma unroll
+                    for (int c = 0; c < RC; c++) dm[c].at(l) = (l + 64 * c < q) ? dv[c].at(l) : 0.0;
+                });
                 w.each([&](int l) {
 #pragma unroll
                     for (int c = 0; c < RC; c++) {
                         const int i = l + 64 * c;
-                        rcol[c].at(l) = (q > 0 && i < q - 1) ? DQ_RP(i, q - 1) : 0.0;
+                        double a0 = 0.0, a1 = 0.0;
+                        int k = 0;
+                        for (; k + 1 < q; k += 2) {  // S(i,k) = 0 below the diagonal (packed storage: mask it)
+                            const double s0 = DQ_RP(i <= k ? i : 0, k), s1 = DQ_RP(i <= k + 1 ? i : 0, k + 1);
+                            a0 = fma(i <= k ? s0 : 0.0, DQ_BC(dm, k), a0);
+                            a1 = fma(i <= k + 1 ? s1 : 0.0, DQ_BC(dm, k + 1), a1);
+                        }
+                        if (k < q) {
+                            const double s0 = DQ_RP(i <= k ? i : 0, k);
+                            a0 = fma(i <= k ? s0 : 0.0, DQ_BC(dm, k), a0);
+                        }
+                        rv[c].at(l) = a0 + a1;
                     }
                 });
-                for (int k = q - 1; k >= 0; k--) {
-                    RegD rnext[RC];
-                    w.each([&](int l) {
-#pragma unroll
-                        for (int c = 0; c < RC; c++) {
-                            const int i = l + 64 * c;
-                            rnext[c].at(l) = (k > 0 && i < k - 1) ? DQ_RP(i, k - 1) : 0.0;
-                        }
-                    });
-                    const double rk = DQ_BC(rv, k) * DQ_BC(rinv, k);
-                    w.each([&](int l) {
-#pragma unroll
-                        for (int c = 0; c < RC; c++) {
-                            const int i = l + 64 * c;
-                            if (i == k) rv[c].at(l) = rk;
-                            else if (i < k) rv[c].at(l) = fma(-rcol[c].at(l), rk, rv[c].at(l));
-                            rcol[c].at(l) = rnext[c].at(l);
-                        }
-                    });
-                }
             }
             w.stamp(6);  // back substitution
             // step lengths: t1 = min u_k / r_k over r_k > 0 (dual), t2 = viol / |d2|^2 (primal)
@@ -841,6 +832,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 const double alpha = dq > 0 ? -nrm : nrm;
                 const double v0 = dq - alpha;
                 const double beta = 1.0 / (nrm * (nrm + fabs(dq)));  // 2 / v'v
+                const double inv_alpha = 1.0 / alpha;
                 // Householder vector v = (0,..,0, d_q - alpha, d_{q+1}, ..) as a register: branch-free loop below
                 RegD hv[RC];
                 w.each([&](int l) {
@@ -867,10 +859,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 #pragma unroll
                     for (int c = 0; c < RC; c++) {
                         const int i = l + 64 * c;
-                        if (i < q) DQ_RP(i, q) = dv[c].at(l);
+                        // R gains the column (d1; alpha)  <=>  S = R^-1 gains the column (-S d1 / alpha; 1 / alpha)
+                        if (i < q) DQ_RP(i, q) = -rv[c].at(l) * inv_alpha;
                         else if (i == q) {
-                            DQ_RP(q, q) = alpha;
-                            rinv[c].at(l) = 1.0 / alpha;
+                            DQ_RP(q, q) = inv_alpha;
                             uu[c].at(l) = uq;
                             act[c].at(l) = ip;
                         }
@@ -885,34 +877,77 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 // ---- drop active row ldrop: delete column l of R, restore the triangle with Givens ----
                 const int lcol = ldrop;
                 set_skip(DQ_BC(act, lcol), false);
-                for (int tcol = lcol; tcol < q - 1; tcol++) {
-                    // rotation from old column tcol+1, rows (tcol, tcol+1)
-                    const double a = DQ_RP(tcol, tcol + 1), b = DQ_RP(tcol + 1, tcol + 1);
-                    const double rho = sqrt(a * a + b * b);
-                    const double cs = rho > 0 ? a / rho : 1.0, sn = rho > 0 ? b / rho : 0.0;
-                    w.sync();
+                // Deleting column lcol of R: the rotations G of columns (t, t+1), t = lcol..q-2, that restore the
+                // triangle are those that sweep row lcol of S into its last entry; S' = (S without row lcol) G'
+                // without its last column, Q' = Q G'.  All angles come from one prefix sum of squares.
+                RegD srow[RC], pre[RC], gc[RC], gs[RC];
+                w.each([&](int l) {
+#pragma unroll
+                    for (int c = 0; c < RC; c++) {
+                        const int k = l + 64 * c;
+                        const double v = (k >= lcol && k < q) ? DQ_RP(lcol, k) : 0.0;
+                        srow[c].at(l) = v;
+                        pre[c].at(l) = v * v;
+                    }
+                });
+                w.prefix_sum(pre, RC);
+                {
+                    RegD pprev[RC];
+#pragma unroll
+                    for (int c = 0; c < RC; c++) w.shift_up(pre, c, RC, pprev[c]);  // element k-1
+                    const double s_first = DQ_BC(srow, lcol);  // the first pivot keeps its sign, later ones are norms
                     w.each([&](int l) {
-                        for (int c = tcol + 1 + l; c < q; c += 64) {  // old columns tcol+1 .. q-1
-                            double r0 = DQ_RP(tcol, c), r1v = DQ_RP(tcol + 1, c);
-                            DQ_RP(tcol, c) = cs * r0 + sn * r1v;
-                            DQ_RP(tcol + 1, c) = -sn * r0 + cs * r1v;
+#pragma unroll
+                        for (int c = 0; c < RC; c++) {
+                            // lane k = t+1 holds the rotation of step t: (a, b) = (|s_lcol..s_t|, s_{t+1}) -> (0, |..|)
+                            const int k = l + 64 * c;
+                            const double sig = sqrt(pre[c].at(l));
+                            const double a = k == lcol + 1 ? s_first : (k > lcol ? sqrt(pprev[c].at(l)) : 0.0);
+                            const bool ok = k > lcol && k < q && sig > 0;
+                            gc[c].at(l) = ok ? srow[c].at(l) / sig : 1.0;
+                            gs[c].at(l) = ok ? a / sig : 0.0;
                         }
-                        for (int i = l; i < r; i += 64) {
-                            double *qi = Q + i * ldq;
-                            double q0 = qi[tcol], q1 = qi[tcol + 1];
-                            qi[tcol] = cs * q0 + sn * q1;
-                            qi[tcol + 1] = -sn * q0 + cs * q1;
+                    });
+                }
+                RegD yS[RC], yQ[RC];
+                w.each([&](int l) {
+#pragma unroll
+                    for (int c = 0; c < RC; c++) {
+                        const int i = l + 64 * c;
+                        yS[c].at(l) = i <= lcol ? DQ_RP(i, lcol) : 0.0;
+                        yQ[c].at(l) = i < r ? Q[i * ldq + lcol] : 0.0;
+                    }
+                });
+                for (int t = lcol; t < q - 1; t++) {
+                    const double cs = DQ_BC(gc, t + 1), sn = DQ_BC(gs, t + 1);
+                    w.each([&](int l) {
+#pragma unroll
+                        for (int c = 0; c < RC; c++) {
+                            const int i = l + 64 * c;
+                            // S: old column t+1 has rows 0..t+1; row lcol is deleted, rows below it move up
+                            const double cS = i <= t + 1 ? DQ_RP(i, t + 1) : 0.0;
+                            const double oS = cs * yS[c].at(l) - sn * cS;
+                            yS[c].at(l) = sn * yS[c].at(l) + cs * cS;
+                            const int inew = i < lcol ? i : i - 1;
+                            if (i != lcol && inew <= t) DQ_RP(inew, t) = oS;
+                            if (i < r) {
+                                double *qi = Q + i * ldq;
+                                const double cQ = qi[t + 1];
+                                qi[t] = cs * yQ[c].at(l) - sn * cQ;
+                                yQ[c].at(l) = sn * yQ[c].at(l) + cs * cQ;
+                            }
                         }
                     });
                     w.sync();
                 }
-                // shift columns lcol+1..q-1 left by one (packed storage: serial over columns)
-                for (int c = lcol + 1; c < q; c++) {
-                    w.each([&](int l) {
-                        for (int i = l; i < c; i += 64) Rp[(c - 1) * c / 2 + i] = DQ_RP(i, c);
-                    });
-                    w.sync();
-                }
+                w.each([&](int l) {
+#pragma unroll
+                    for (int c = 0; c < RC; c++) {
+                        const int i = l + 64 * c;
+                        if (i < r) Q[i * ldq + q - 1] = yQ[c].at(l);
+                    }
+                });
+                w.sync();
                 // compact the per-lane duals and the active list: element k takes element k+1, k >= lcol
                 {
                     RegD nu[RC];
@@ -931,13 +966,6 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     });
                 }
                 q--;
-                w.each([&](int l) {
-#pragma unroll
-                    for (int c = 0; c < RC; c++) {
-                        const int k = l + 64 * c;
-                        if (k < q) rinv[c].at(l) = 1.0 / DQ_RP(k, k);
-                    }
-                });
                 n_drop++;
                 w.stamp(10);  // Givens drop
                 // loop again with the same row ip (step 2(a) of Goldfarb-Idnani)

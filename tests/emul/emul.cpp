@@ -58,6 +58,19 @@ struct WaveCpu {
         for (int l = 0; l < 64; l++) if (r.v[l]) return l;
         return -1;
     }
+    // inclusive prefix sum over the elements of a vector spread over `nchunks` registers
+    void prefix_sum(Reg<double> *arr, int nchunks) const {
+        double run = 0;
+        for (int c = 0; c < nchunks; c++)
+            for (int l = 0; l < 64; l++) { run += arr[c].v[l]; arr[c].v[l] = run; }
+    }
+    // out[l] = element (l + 64 c) - 1 (0 for the very first element)
+    template <class T>
+    void shift_up(const Reg<T> *arr, int c, int nchunks, Reg<T> &out) const {
+        (void)nchunks;
+        for (int l = 63; l >= 1; l--) out.v[l] = arr[c].v[l - 1];
+        out.v[0] = c > 0 ? arr[c - 1].v[63] : T(0);
+    }
     // out[l] = element (l + 64 c) + 1 of the vector spread over `nchunks` registers
     template <class T>
     void shift_down(const Reg<T> *arr, int c, int nchunks, Reg<T> &out) const {
