@@ -118,6 +118,26 @@ class DeviceBatch(C.Structure):
     ]
 
 
+class LscGen(C.Structure):
+    _fields_ = [
+        ("n_local", C.c_int32),
+        ("first_plan", C.c_int32),
+        ("local_ids", C.c_void_p),
+        ("plans", C.c_void_p),
+        ("position", C.c_void_p),
+        ("velocity", C.c_void_p),
+        ("goals", C.c_void_p),
+        ("radius", C.c_void_p),
+        ("downwash", C.c_void_p),
+        ("nbr_offsets", C.c_void_p),
+        ("nbr_ids", C.c_void_p),
+        ("nx", C.c_void_p), ("ny", C.c_void_p), ("nz", C.c_void_p),
+        ("px", C.c_void_p), ("py", C.c_void_p), ("pz", C.c_void_p),
+        ("d", C.c_void_p),
+        ("key", C.c_void_p),
+    ]
+
+
 assert C.sizeof(Config) == 144, C.sizeof(Config)
 assert C.sizeof(Agent) == 104, C.sizeof(Agent)
 assert C.sizeof(LscRow) == 40, C.sizeof(LscRow)
@@ -205,6 +225,8 @@ def load_library():
     lib.dlscqp_plan_batch.restype = C.c_int
     lib.dlscqp_plan_batch_device.argtypes = [vp, P(DeviceBatch), vp]
     lib.dlscqp_plan_batch_device.restype = C.c_int
+    lib.dlscqp_generate_lsc_device.argtypes = [vp, P(LscGen), vp]
+    lib.dlscqp_generate_lsc_device.restype = C.c_int
     lib.dlscqp_rows_to_soa.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.dlscqp_rows_to_soa.restype = None
     lib.dlscqp_set_timing.argtypes = [vp, C.c_int32]
@@ -218,6 +240,6 @@ def load_library():
 EXPORTED_SYMBOLS = [
     "dlscqp_create", "dlscqp_destroy", "dlscqp_update_param", "dlscqp_last_error",
     "dlscqp_lds_bytes", "dlscqp_solve_batch", "dlscqp_goal_batch", "dlscqp_plan_batch",
-    "dlscqp_plan_batch_device", "dlscqp_rows_to_soa", "dlscqp_set_timing",
+    "dlscqp_plan_batch_device", "dlscqp_generate_lsc_device", "dlscqp_rows_to_soa", "dlscqp_set_timing",
     "dlscqp_get_kernel_times",
 ]

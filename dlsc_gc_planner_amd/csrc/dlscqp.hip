@@ -17,6 +17,7 @@
 #define DQ_FN __host__ __device__ __forceinline__
 #define DQ_KEEP(v) asm volatile("" : "+v"(v))
 #include "gi_core.hpp"
+#include "lsc_core.hpp"
 #include "qp_tables.hpp"
 
 using namespace dlscqp;
@@ -221,6 +222,21 @@ __global__ __launch_bounds__(64, 2) void dlscqp_plan_kernel(KParams kp, MemLayou
     if (a.out_stamps && threadIdx.x == 0)
         for (int p = 0; p < 12; p++) a.out_stamps[(size_t)ag * 12 + p] = w.acc[p];
 #endif
+}
+
+// one wavefront per local agent, lanes over its (neighbour, segment) items; every item is
+// independent and writes its own 6 (3) rows of the SoA arrays (lsc_core.hpp).
+__global__ __launch_bounds__(64) void dlscqp_lsc_kernel(LscGenArgs g) {
+    const int k = blockIdx.x;
+    if (k >= g.n_local) return;
+    const int self = g.local_ids ? g.local_ids[k] : k;
+    const int p0 = g.nbr_offsets[k], p1 = g.nbr_offsets[k + 1];
+    const int per = g.M * g.n1 - g.phi;
+    const int items = (p1 - p0) * g.M;
+    for (int it = threadIdx.x; it < items; it += 64) {
+        const int j = it / g.M, m = it - j * g.M;
+        lsc_item(g, self, g.nbr_ids[p0 + j], m, (size_t)per * (size_t)(p0 + j));
+    }
 }
 
 typedef void (*kernel_t)(KParams, MemLayout, KernelArgs);
@@ -477,6 +493,30 @@ extern "C" int dlscqp_plan_batch_device(dlscqp_ctx *c, const dlscqp_device_batch
     if (!b->agents || !b->row_offsets || !b->out_status) { g_last_error = "null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
     (void)hipSetDevice(c->cfg.device);
     return launch(c, b, stream ? (hipStream_t)stream : c->stream);
+}
+
+extern "C" int dlscqp_generate_lsc_device(dlscqp_ctx *c, const dlscqp_lsc_gen *gen, void *stream) {
+    g_last_error.clear();
+    if (!c || !gen) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (gen->n_local <= 0) return DLSCQP_SUCCESS;
+    if (!gen->goals || !gen->radius || !gen->downwash || !gen->nbr_offsets || !gen->nbr_ids || !gen->nx || !gen->d || !gen->key ||
+        (gen->first_plan ? (!gen->position || !gen->velocity) : !gen->plans)) {
+        g_last_error = "null buffer";
+        return DLSCQP_ERR_INVALID_ARGUMENT;
+    }
+    (void)hipSetDevice(c->cfg.device);
+    LscGenArgs g;
+    g.n_local = gen->n_local; g.first_plan = gen->first_plan;
+    g.M = c->M; g.n1 = c->n + 1; g.phi = c->phi; g.dt = c->dt;
+    g.local_ids = gen->local_ids;
+    g.plans = gen->plans; g.position = gen->position; g.velocity = gen->velocity; g.goals = gen->goals;
+    g.radius = gen->radius; g.downwash = gen->downwash;
+    g.nbr_offsets = gen->nbr_offsets; g.nbr_ids = gen->nbr_ids;
+    g.nx = gen->nx; g.ny = gen->ny; g.nz = gen->nz; g.px = gen->px; g.py = gen->py; g.pz = gen->pz;
+    g.d = gen->d; g.key = gen->key;
+    hipLaunchKernelGGL(dlscqp_lsc_kernel, dim3(gen->n_local), dim3(64), 0, stream ? (hipStream_t)stream : c->stream, g);
+    HIP_TRY(hipGetLastError());
+    return DLSCQP_SUCCESS;
 }
 
 extern "C" void dlscqp_rows_to_soa(const dlscqp_lsc_row *rows, int64_t n_rows, float *nx, float *ny, float *nz,

@@ -1,0 +1,299 @@
+// lsc_core.hpp -- DLSC-GC half-spaces between two agents for one trajectory segment.
+//
+// Replaces, per (agent, neighbouring agent, segment m), the body of TrajPlanner::generateDLSCGC
+// (/root/reference/src/traj_planner.cpp:603-666) and what it calls:
+//   initialTrajPlanningPrevSol / obstaclePredictionWithPrevSol  (:409-421, :304-314)  shift of the previous plans
+//   Trajectory::planConstVelTraj                                (trajectory.cpp:78-91) first replanning step
+//   downwashBetween / coordinateTransform                       (:1150-1161, :1183-1187, trajectory.cpp:206-219)
+//   normalVectorBetweenPolys -> closestPointsBetweenPointAndConvexHull -> openGJK (:1102-1127, geometry.hpp:276-306)
+//   closestPointsBetweenLineSegments / Lines / PointAndLineSegment                 (geometry.hpp:76-274)
+// One work item = one (pair, segment): independent of every other item, so the kernel is a flat grid and each
+// lane writes the 6 (3 for segment 0) rows of its item straight into the SoA row arrays the QP kernel reads.
+// The reference computes in octomap::point3d (three float32, float32 operators; dot/norm return double) and
+// calls openGJK in double; the same precisions are used here.  The point-to-hull problem is solved exactly by
+// enumerating the hull's tetrahedra (containment), triangles, edges and vertices -- branch-light, no
+// iteration count, identical to what GJK converges to (tests pin it against the reference's openGJK).
+// Compiled with -ffp-contract=off.
+#pragma once
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/dlscqp.h"
+
+#ifndef DQ_FN
+#define DQ_FN inline
+#endif
+
+namespace dlscqp {
+
+struct F3 {
+    float x, y, z;
+};
+DQ_FN F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
+DQ_FN F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+DQ_FN F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+DQ_FN F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+DQ_FN double dot(F3 a, F3 b) { float s = a.x * b.x + a.y * b.y + a.z * b.z; return (double)s; }  // float32 inside
+DQ_FN double norm(F3 a) { float s = a.x * a.x + a.y * a.y + a.z * a.z; return sqrt((double)s); }
+DQ_FN double distance(F3 a, F3 b) {  // float32 differences, double squares (octomath::Vector3::distance)
+    double dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    return sqrt(dx * dx + dy * dy + dz * dz);
+}
+DQ_FN F3 cross(F3 a, F3 b) { return f3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+DQ_FN F3 normalized(F3 a) {
+    double len = norm(a);
+    if (len > 0) { float f = (float)len; a.x /= f; a.y /= f; a.z /= f; }
+    return a;
+}
+DQ_FN bool same(F3 a, F3 b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+
+// ---- closest point of conv{p_0..p_5} to the origin, exact ------------------------------------------------
+struct D3 {
+    double x, y, z;
+};
+DQ_FN D3 d3(double x, double y, double z) { D3 r; r.x = x; r.y = y; r.z = z; return r; }
+DQ_FN D3 operator-(D3 a, D3 b) { return d3(a.x - b.x, a.y - b.y, a.z - b.z); }
+DQ_FN double ddot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+DQ_FN double det3(D3 a, D3 b, D3 c) {
+    return a.x * (b.y * c.z - b.z * c.y) - a.y * (b.x * c.z - b.z * c.x) + a.z * (b.x * c.y - b.y * c.x);
+}
+
+DQ_FN D3 hull6_closest_to_origin(const D3 p[6]) {
+    D3 best = p[0];
+    double bd = ddot(best, best);
+    bool inside = false;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        const double da = ddot(p[a], p[a]);
+        if (da < bd) { bd = da; best = p[a]; }
+#pragma unroll
+        for (int b = a + 1; b < 6; b++) {
+            const D3 ab = p[b] - p[a];
+            const double den = ddot(ab, ab), num = -ddot(p[a], ab);
+            if (den > 0) {
+                const double t = num / den;
+                if (t > 0 && t < 1) {
+                    const D3 c = d3(p[a].x + t * ab.x, p[a].y + t * ab.y, p[a].z + t * ab.z);
+                    const double dc = ddot(c, c);
+                    if (dc < bd) { bd = dc; best = c; }
+                }
+            }
+#pragma unroll
+            for (int ci = b + 1; ci < 6; ci++) {
+                const D3 ac = p[ci] - p[a];
+                const double g11 = den, g12 = ddot(ab, ac), g22 = ddot(ac, ac);
+                const double r1 = num, r2 = -ddot(p[a], ac);
+                const double det = g11 * g22 - g12 * g12;
+                if (det > 1e-14 * g11 * g22) {
+                    const double u = (r1 * g22 - r2 * g12) / det, w = (g11 * r2 - g12 * r1) / det;
+                    if (u > 0 && w > 0 && u + w < 1) {
+                        const D3 c = d3(p[a].x + u * ab.x + w * ac.x, p[a].y + u * ab.y + w * ac.y, p[a].z + u * ab.z + w * ac.z);
+                        const double dc = ddot(c, c);
+                        if (dc < bd) { bd = dc; best = c; }
+                    }
+                }
+#pragma unroll
+                for (int di = ci + 1; di < 6; di++) {  // origin inside this tetrahedron => inside the hull
+                    const D3 ad = p[di] - p[a];
+                    const D3 oa = d3(-p[a].x, -p[a].y, -p[a].z);
+                    const double vol = det3(ab, ac, ad);
+                    if (fabs(vol) >= 1e-300) {
+                        const double l1 = det3(oa, ac, ad) / vol, l2 = det3(ab, oa, ad) / vol, l3 = det3(ab, ac, oa) / vol;
+                        if (l1 >= 0 && l2 >= 0 && l3 >= 0 && l1 + l2 + l3 <= 1) inside = true;
+                    }
+                }
+            }
+        }
+    }
+    return inside ? d3(0, 0, 0) : best;
+}
+
+// ---- geometry.hpp:76-111 ---------------------------------------------------------------------------------
+struct Closest {
+    double dist;
+    F3 p1, p2;
+};
+
+DQ_FN Closest point_segment(F3 point, F3 ls, F3 le) {
+    const F3 a = ls - point, b = le - point;
+    F3 rel = a;
+    double dist_min = norm(a);
+    if (!same(a, b)) {
+        double dist = norm(b);
+        if (dist_min > dist) { dist_min = dist; rel = b; }
+        const F3 n_line = normalized(b - a);
+        const F3 c = a - n_line * (float)dot(a, n_line);
+        dist = norm(c);
+        if (dot(c - a, c - b) < 0 && dist_min > dist) { dist_min = dist; rel = c; }
+    }
+    Closest r;
+    r.dist = dist_min;
+    r.p1 = point;
+    r.p2 = rel + point;
+    return r;
+}
+
+// geometry.hpp:139-182 (Eigen::Matrix3f::inverse() = cofactors / determinant)
+DQ_FN Closest lines(F3 s1, F3 e1, F3 s2, F3 e2) {
+    Closest r;
+    const F3 n1 = normalized(e1 - s1), n2 = normalized(e2 - s2);
+    if (distance(n1, n2) < 1e-5 || distance(n1, f3(-n2.x, -n2.y, -n2.z)) < 1e-5) {
+        F3 delta = s2 - s1;
+        delta = delta - n1 * (float)dot(delta, n1);
+        r.dist = norm(delta);
+        r.p1 = s1;
+        r.p2 = s1 + delta;
+    } else {
+        const F3 delta = s2 - s1;
+        const F3 n3 = normalized(cross(n2, n1));
+        // A = [n1 | -n2 | n3] (columns); alphas = A^{-1} delta
+        const float a00 = n1.x, a01 = -n2.x, a02 = n3.x, a10 = n1.y, a11 = -n2.y, a12 = n3.y, a20 = n1.z, a21 = -n2.z, a22 = n3.z;
+        const float c00 = a11 * a22 - a12 * a21, c01 = a12 * a20 - a10 * a22, c02 = a10 * a21 - a11 * a20;
+        const float c10 = a21 * a02 - a22 * a01, c11 = a22 * a00 - a20 * a02, c12 = a20 * a01 - a21 * a00;
+        const float c20 = a01 * a12 - a02 * a11, c21 = a02 * a10 - a00 * a12, c22 = a00 * a11 - a01 * a10;
+        const float det = a00 * c00 + a10 * c10 + a20 * c20;
+        const float invdet = 1.0f / det;
+        const float al0 = (c00 * invdet) * delta.x + (c10 * invdet) * delta.y + (c20 * invdet) * delta.z;
+        const float al1 = (c01 * invdet) * delta.x + (c11 * invdet) * delta.y + (c21 * invdet) * delta.z;
+        const float al2 = (c02 * invdet) * delta.x + (c12 * invdet) * delta.y + (c22 * invdet) * delta.z;
+        r.dist = fabs((double)al2);
+        r.p1 = s1 + n1 * al0;
+        r.p2 = s2 + n2 * al1;
+    }
+    return r;
+}
+
+// geometry.hpp:184-274
+DQ_FN Closest segments(F3 s1, F3 e1, F3 s2, F3 e2) {
+    Closest r;
+    if (distance(s1, e1) < 1e-5) {
+        r = point_segment(s1, s2, e2);
+    } else if (distance(s2, e2) < 1e-5) {
+        r = point_segment(s2, s1, e1);
+        const F3 t = r.p1; r.p1 = r.p2; r.p2 = t;
+    } else {
+        const F3 v1 = e1 - s1, v2 = e2 - s2;
+        const double l1 = norm(v1), l2 = norm(v2);
+        const F3 n1 = v1 * (float)(1 / l1), n2 = v2 * (float)(1 / l2);
+        if (norm(cross(n1, n2)) < 1e-5) {  // parallel segments
+            double bound_min = dot(s2 - s1, n1), bound_max = dot(e2 - s1, n1);
+            F3 p2_min = s2, p2_max = e2;
+            if (bound_max < bound_min) {
+                const double t = bound_min; bound_min = bound_max; bound_max = t;
+                const F3 tv = p2_min; p2_min = p2_max; p2_max = tv;
+            }
+            F3 delta = s2 - s1;
+            delta = delta - n1 * (float)dot(delta, n1);
+            if (l1 < bound_min) { r.p1 = e1; r.p2 = p2_min; }
+            else if (bound_max < 0) { r.p1 = s1; r.p2 = p2_max; }
+            else if (bound_min < 0) { r.p1 = s1; r.p2 = s1 + delta; }
+            else { r.p1 = p2_min - delta; r.p2 = p2_min; }
+            r.dist = distance(r.p1, r.p2);
+        } else {
+            r = lines(s1, e1, s2, e2);
+            const double alpha1 = dot(r.p1 - s1, n1) / l1, alpha2 = dot(r.p2 - s2, n2) / l2;
+            if (alpha1 < 0) r.p1 = s1; else if (alpha1 > 1) r.p1 = e1;
+            if (alpha2 < 0) r.p2 = s2; else if (alpha2 > 1) r.p2 = e2;
+            if (alpha1 < 0 || alpha1 > 1) {
+                double dt = dot(n2, r.p1 - s2);
+                dt = dt < 0 ? 0 : (dt > l2 ? l2 : dt);
+                r.p2 = s2 + n2 * (float)dt;
+            }
+            if (alpha2 < 0 || alpha2 > 1) {
+                double dt = dot(n1, r.p2 - s1);
+                dt = dt < 0 ? 0 : (dt > l1 ? l1 : dt);
+                r.p1 = s1 + n1 * (float)dt;
+            }
+            r.dist = distance(r.p1, r.p2);
+        }
+    }
+    return r;
+}
+
+// ---- trajectories the half-spaces are built from ---------------------------------------------------------
+struct LscGenArgs {  // device mirror of dlscqp_lsc_gen (include/dlscqp.h)
+    int n_local, first_plan, M, n1, phi;
+    double dt;
+    const int32_t *local_ids;
+    const float *plans, *position, *velocity, *goals;
+    const double *radius, *downwash;
+    const int32_t *nbr_offsets, *nbr_ids;
+    float *nx, *ny, *nz, *px, *py, *pz;
+    double *d;
+    uint32_t *key;
+};
+
+// control point i of segment m of agent `id`'s initial trajectory (= what the others predict for it)
+DQ_FN F3 initial_point(const LscGenArgs &g, int id, int m, int i) {
+    const int n = g.n1 - 1;
+    if (g.first_plan) {  // planConstVelTraj: time advances by dt / n after every control point
+        const float *p = g.position + 3 * (size_t)id, *v = g.velocity + 3 * (size_t)id;
+        double time = 0;
+        const int steps = m * g.n1 + i;
+        for (int s = 0; s < steps; s++) time += g.dt / n;
+        const float tf = (float)time;
+        return f3(p[0] + v[0] * tf, p[1] + v[1] * tf, p[2] + v[2] * tf);
+    }
+    const float *pl = g.plans + (size_t)id * g.M * g.n1 * 3;
+    const int mm = m < g.M - 1 ? m + 1 : g.M - 1, ii = m < g.M - 1 ? i : n;
+    const float *c = pl + ((size_t)mm * g.n1 + ii) * 3;
+    return f3(c[0], c[1], c[2]);
+}
+
+// One (pair, segment) item.  `row0`: index of the pair's first row in the SoA arrays.
+DQ_FN void lsc_item(const LscGenArgs &g, int self, int other, int m, size_t row0) {
+    const int n = g.n1 - 1, M = g.M;
+    const double r_self = g.radius[self], r_oth = g.radius[other];
+    const double collision_dist = r_oth + r_self;                                                       // :605
+    const double downwash = (g.downwash[self] * r_self + g.downwash[other] * r_oth) / (r_self + r_oth);  // :1150-1153
+    const float dwf = (float)downwash;
+    // rows of segment 0 start at i = phi (the others are never part of the model, traj_optimizer.cpp:417-419)
+    const size_t rbase = row0 + (m == 0 ? 0 : (size_t)(g.n1 - g.phi) + (size_t)(m - 1) * g.n1);
+    if (m < M - 1) {
+        F3 rel[6], pred[6];
+        D3 pts[6];
+        for (int i = 0; i < 6; i++) {
+            F3 a = initial_point(g, self, m, i);
+            pred[i] = initial_point(g, other, m, i);
+            F3 b = pred[i];
+            a.z = a.z / dwf;  // Trajectory::coordinateTransform, trajectory.cpp:206-219
+            b.z = b.z / dwf;
+            rel[i] = a - b;
+            pts[i] = d3(rel[i].x, rel[i].y, rel[i].z);
+        }
+        const D3 v = hull6_closest_to_origin(pts);
+        F3 cp = f3((float)v.x, (float)v.y, (float)v.z);
+        cp = f3(0, 0, 0) + cp;
+        const F3 nt = normalized(cp);
+        const F3 nrm = f3(nt.x, nt.y, (float)((double)nt.z / downwash));  // :634-636
+        for (int i = (m == 0 ? g.phi : 0); i < g.n1; i++) {
+            const size_t r = rbase + (size_t)(i - (m == 0 ? g.phi : 0));
+            g.nx[r] = nrm.x; g.ny[r] = nrm.y; g.nz[r] = nrm.z;
+            g.px[r] = pred[i].x; g.py[r] = pred[i].y; g.pz[r] = pred[i].z;
+            g.d[r] = 0.5 * (collision_dist + dot(rel[i], nt));  // :639-640
+            g.key[r] = DLSCQP_KEY(m, i, -1, 0);
+        }
+    } else {
+        F3 l1s = initial_point(g, other, M - 1, n), l2s = initial_point(g, self, M - 1, n);
+        l1s.z = l1s.z / dwf;
+        l2s.z = l2s.z / dwf;
+        const float *go = g.goals + 3 * (size_t)other, *gs = g.goals + 3 * (size_t)self;
+        // TrajPlanner::coordinateTransform of a point: double division, :1183-1187
+        const F3 obs_goal = f3(go[0], go[1], (float)((double)go[2] / downwash));
+        const F3 agent_goal = f3(gs[0], gs[1], (float)((double)gs[2] / downwash));
+        const Closest c = segments(l1s, obs_goal, l2s, agent_goal);
+        const F3 nt = normalized(c.p2 - c.p1);
+        const double dd = 0.5 * (collision_dist + c.dist);
+        const F3 nrm = f3(nt.x, nt.y, (float)((double)nt.z / downwash));
+        const F3 pt = f3(c.p1.x, c.p1.y, (float)((double)c.p1.z * downwash));
+        for (int i = 0; i < g.n1; i++) {
+            const size_t r = rbase + (size_t)i;
+            g.nx[r] = nrm.x; g.ny[r] = nrm.y; g.nz[r] = nrm.z;
+            g.px[r] = pt.x; g.py[r] = pt.y; g.pz[r] = pt.z;
+            g.d[r] = dd;
+            g.key[r] = DLSCQP_KEY(m, i, -1, 0);
+        }
+    }
+}
+
+}  // namespace dlscqp

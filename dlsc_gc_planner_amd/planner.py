@@ -124,6 +124,10 @@ class BatchTrajOptimizer:
         that can be launched any number of times without touching the host."""
         return DeviceBatch(self, agents, row_offsets, rows, sfc, max_slack_obs, want_f64, want_iters, device)
 
+    def make_lsc_generator(self, n_total, nbr_offsets, nbr_ids, radius, downwash, local_ids=None, device=None):
+        """Device-resident DLSC-GC half-space generator for a fixed neighbour structure."""
+        return LscGenerator(self, n_total, nbr_offsets, nbr_ids, radius, downwash, local_ids, device)
+
     def set_timing(self, capacity):
         self._check(self.lib.dlscqp_set_timing(self.handle, int(capacity)), "dlscqp_set_timing")
 
@@ -225,3 +229,70 @@ class DeviceBatch:
         if self.out_iters is not None:
             out["iters"] = self.out_iters.cpu().numpy()
         return out
+
+
+class LscGenerator:
+    """DLSC-GC half-spaces of the local agents against their neighbours, generated in HBM from the table of
+    previous plans (the all-gathered control points) and sub-goals; feeds DeviceBatch without a host round trip.
+    Mirrors TrajPlanner::constructLSC -> generateDLSCGC (traj_planner.cpp:498-515, 603-666) for agent obstacles."""
+
+    def __init__(self, opt, n_total, nbr_offsets, nbr_ids, radius, downwash, local_ids, device):
+        import torch
+        self.torch = torch
+        self.opt = opt
+        cfg = opt.cfg
+        dev = torch.device("cuda", cfg.device if device is None else device)
+        self.device = dev
+        nbr_offsets = np.ascontiguousarray(nbr_offsets, dtype=np.int32)
+        self.n_local = len(nbr_offsets) - 1
+        self.per = cfg.M * (cfg.n + 1) - cfg.phi
+        self.n_rows = self.per * int(nbr_offsets[-1])
+        self.row_offsets = (self.per * nbr_offsets.astype(np.int64))
+        up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)  # noqa: E731
+        self.t = dict(nbr_offsets=up(nbr_offsets, np.int32), nbr_ids=up(nbr_ids if len(nbr_ids) else np.zeros(1), np.int32),
+                      radius=up(radius, np.float64), downwash=up(downwash, np.float64),
+                      local_ids=None if local_ids is None else up(local_ids, np.int32))
+        pad = self.n_rows + 64
+        self.soa = {k: torch.zeros(pad, dtype=torch.float32, device=dev) for k in ("nx", "ny", "nz", "px", "py", "pz")}
+        self.soa["d"] = torch.zeros(pad, dtype=torch.float64, device=dev)
+        self.soa["key"] = torch.zeros(pad, dtype=torch.int32, device=dev)
+        g = abi.LscGen()
+        g.n_local = self.n_local
+        g.local_ids = None if self.t["local_ids"] is None else self.t["local_ids"].data_ptr()
+        g.radius, g.downwash = self.t["radius"].data_ptr(), self.t["downwash"].data_ptr()
+        g.nbr_offsets, g.nbr_ids = self.t["nbr_offsets"].data_ptr(), self.t["nbr_ids"].data_ptr()
+        for k in ("nx", "ny", "nz", "px", "py", "pz", "d", "key"):
+            setattr(g, k, self.soa[k].data_ptr())
+        self.c = g
+        self.n_total = n_total
+
+    def generate(self, goals, plans=None, position=None, velocity=None, stream=None):
+        """goals [n_total,3] f32 and either plans [n_total,M,n+1,3] f32 (previous plans) or position/velocity
+        (first replanning step): CUDA tensors.  Asynchronous."""
+        g = self.c
+        g.first_plan = 1 if plans is None else 0
+        g.plans = None if plans is None else plans.data_ptr()
+        g.position = None if position is None else position.data_ptr()
+        g.velocity = None if velocity is None else velocity.data_ptr()
+        g.goals = goals.data_ptr()
+        self._keep = (goals, plans, position, velocity)
+        s = self.torch.cuda.current_stream(self.device) if stream is None else stream
+        rc = self.opt.lib.dlscqp_generate_lsc_device(self.opt.handle, C.byref(g), C.c_void_p(s.cuda_stream))
+        self.opt._check(rc, "dlscqp_generate_lsc_device")
+
+    def rows_host(self):
+        """Download the rows as AoS records (tests)."""
+        self.torch.cuda.synchronize(self.device)
+        R = self.n_rows
+        soa = {k: v.cpu().numpy() for k, v in self.soa.items()}
+        rows = np.zeros(R, abi.ROW_DTYPE)
+        for c, k in enumerate(("nx", "ny", "nz")):
+            rows["normal"][:, c] = soa[k][:R]
+        for c, k in enumerate(("px", "py", "pz")):
+            rows["point"][:, c] = soa[k][:R]
+        rows["d"] = soa["d"][:R]
+        key = soa["key"][:R].view(np.uint32)
+        rows["m"], rows["i"], rows["flags"] = key & 0xFF, (key >> 8) & 0xF, (key >> 12) & 1
+        sl = (key >> 16).astype(np.int64)
+        rows["slack"] = np.where(sl == 0xFFFF, -1, sl)
+        return self.row_offsets, rows

@@ -203,6 +203,33 @@ typedef struct dlscqp_device_batch {
 
 int dlscqp_plan_batch_device(dlscqp_ctx *ctx, const dlscqp_device_batch *batch, void *stream);
 
+/* ---- DLSC-GC half-space generation on the device --------------------------------------
+ * TrajPlanner::generateDLSCGC for neighbouring AGENTS (traj_planner.cpp:603-666) together with the shift of the
+ * previous plans that precedes it (initialTrajPlanningPrevSol / obstaclePredictionWithPrevSol, :409-421,
+ * :304-314; constant-velocity trajectories on the first replanning step, :293-303, :410-411).  Input is the
+ * table every rank holds after the per-step all-gather (previous plans + sub-goals of ALL agents) and a
+ * neighbour list per local agent; output are the SoA rows dlscqp_plan_batch_device reads, so the rows never
+ * cross PCIe.  Local agent k's rows are [per*nbr_offsets[k], per*nbr_offsets[k+1]), per = M*(n+1) - phi, in
+ * populatebyrow's order (neighbour, segment, control point).  Asynchronous on `stream`. */
+typedef struct dlscqp_lsc_gen {
+    int32_t n_local;            /* agents to generate rows for                                      */
+    int32_t first_plan;         /* 1: planner_seq < 2, constant-velocity trajectories from position/velocity */
+    const int32_t *local_ids;   /* [n_local] ids into the tables, NULL = 0..n_local-1               */
+    const float *plans;         /* [n_total][M][n+1][3] previous plans (unused when first_plan)     */
+    const float *position;      /* [n_total][3] (first_plan only)                                   */
+    const float *velocity;      /* [n_total][3] (first_plan only)                                   */
+    const float *goals;         /* [n_total][3] current_goal_point of every agent                   */
+    const double *radius;       /* [n_total]                                                        */
+    const double *downwash;     /* [n_total]                                                        */
+    const int32_t *nbr_offsets; /* [n_local+1]                                                      */
+    const int32_t *nbr_ids;     /* [nbr_offsets[n_local]] neighbour ids, = obstacle order oi        */
+    float *nx, *ny, *nz, *px, *py, *pz; /* outputs, [per * nbr_offsets[n_local]]                    */
+    double *d;
+    uint32_t *key;
+} dlscqp_lsc_gen;
+
+int dlscqp_generate_lsc_device(dlscqp_ctx *ctx, const dlscqp_lsc_gen *gen, void *stream);
+
 /* Host helper: convert n_rows AoS rows to the SoA arrays above (host memory, caller-owned). */
 void dlscqp_rows_to_soa(const dlscqp_lsc_row *rows, int64_t n_rows, float *nx, float *ny,
                         float *nz, float *px, float *py, float *pz, double *d, uint32_t *key);

@@ -85,6 +85,36 @@ int oracle_plan_batch(const dlscqp_config *cfg, int n_agents, const dlscqp_agent
  * ctrl [M][n+1][3]; state_out = {pos[3], vel[3], acc[3]}. */
 void oracle_state_at(const float *ctrl, int M, int n, double dt, double time, float state_out[9]);
 
+
+/* ---------------------------------------------------------------------------------------------
+ * Row N1 of SURVEY.md section 8(f): DLSC-GC half-space generation for neighbouring agents,
+ * TrajPlanner::generateDLSCGC (traj_planner.cpp:603-666) with its helpers
+ *   initialTrajPlanningPrevSol / obstaclePredictionWithPrevSol   (:290-327, :409-421)
+ *   planConstVelTraj                                            (trajectory.cpp:78-91)
+ *   downwashBetween, coordinateTransform                        (:1150-1161, :1183-1187)
+ *   normalVectorBetweenPolys                                    (:1102-1127)
+ *   closestPointsBetweenPointAndConvexHull -> openGJK           (geometry.hpp:276-306)
+ *   closestPointsBetweenLineSegments / Lines / PointAndLineSegment (geometry.hpp:76-274)
+ * restated with octomath::Vector3 float32 semantics.  The point-to-hull distance sub-problem is
+ * solved by exact enumeration of the hull's vertices, edges and triangles unless a GJK callback is
+ * installed with oracle_set_gjk(); tests install the reference's own openGJK, compiled from
+ * /root/reference into oracle/_ref/libref_gjk.so, to pin the enumeration against it. */
+typedef double (*oracle_gjk_fn)(const double *pts /*[n][3]*/, int n, double v[3]);
+void oracle_set_gjk(oracle_gjk_fn fn);
+double oracle_hull_closest_point(const double *pts, int n, double v[3]);
+
+/* plan [M][n+1][3] float32 -> shifted plan (initial trajectory of the agent = prediction of it by others) */
+void oracle_shift_plan(const float *prev, int M, int n, float *out);
+void oracle_const_vel_plan(const float pos[3], const float vel[3], int M, int n, double dt, float *out);
+
+/* All DLSC-GC rows of one agent against `n_nbr` neighbouring agents.  init_* are the (already shifted or
+ * constant-velocity) trajectories.  rows_out gets n_nbr * (M*(n+1) - phi) rows in populatebyrow's order
+ * (obstacle, segment, control point; rows with m = 0, i < phi are not emitted).  Returns the row count. */
+int oracle_generate_dlscgc(const dlscqp_config *cfg, const float *init_self, const float goal_self[3],
+                           double radius_self, double downwash_self, int n_nbr, const float *const *init_nbr,
+                           const float *goal_nbr /*[n_nbr][3]*/, const double *radius_nbr,
+                           const double *downwash_nbr, dlscqp_lsc_row *rows_out);
+
 #ifdef __cplusplus
 }
 #endif

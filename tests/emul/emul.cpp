@@ -13,6 +13,7 @@
 
 #define DQ_FN inline
 #include "../../dlsc_gc_planner_amd/csrc/gi_core.hpp"
+#include "../../dlsc_gc_planner_amd/csrc/lsc_core.hpp"
 #include "../../dlsc_gc_planner_amd/csrc/qp_tables.hpp"
 
 namespace {
@@ -154,5 +155,26 @@ extern "C" int emul_table_info(const dlscqp_config *cfg, int *f, int *n_slots, i
     *n_slots = tb.kp.n_slots;
     *nb = tb.kp.nb;
     *lds_bytes = make_layout(tb.kp, max_slack_obs, kmax, 4, 10).bytes;
+    return 0;
+}
+
+// Row N1: the device code of lsc_core.hpp run item by item on the host (same source as dlscqp_lsc_kernel).
+extern "C" int emul_generate_lsc(const dlscqp_config *cfg, const dlscqp_lsc_gen *gen) {
+    using namespace dlscqp;
+    LscGenArgs g;
+    g.n_local = gen->n_local; g.first_plan = gen->first_plan;
+    g.M = cfg->M; g.n1 = cfg->n + 1; g.phi = cfg->phi; g.dt = cfg->dt;
+    g.local_ids = gen->local_ids;
+    g.plans = gen->plans; g.position = gen->position; g.velocity = gen->velocity; g.goals = gen->goals;
+    g.radius = gen->radius; g.downwash = gen->downwash;
+    g.nbr_offsets = gen->nbr_offsets; g.nbr_ids = gen->nbr_ids;
+    g.nx = gen->nx; g.ny = gen->ny; g.nz = gen->nz; g.px = gen->px; g.py = gen->py; g.pz = gen->pz;
+    g.d = gen->d; g.key = gen->key;
+    const int per = g.M * g.n1 - g.phi;
+    for (int k = 0; k < g.n_local; k++) {
+        const int self = g.local_ids ? g.local_ids[k] : k;
+        for (int p = g.nbr_offsets[k]; p < g.nbr_offsets[k + 1]; p++)
+            for (int m = 0; m < g.M; m++) lsc_item(g, self, g.nbr_ids[p], m, (size_t)per * (size_t)p);
+    }
     return 0;
 }

@@ -63,3 +63,62 @@ def table_info(cfg, max_slack_obs=0, kmax=0):
     if rc != 0:
         raise ValueError("invalid configuration")
     return dict(f=v[0].value, n_slots=v[1].value, nb=v[2].value, lds_bytes=v[3].value)
+
+
+def generate_lsc(cfg, plans, goals, radius, downwash, nbr_offsets, nbr_ids, local_ids=None, position=None, velocity=None):
+    """Row N1 through the host build of lsc_core.hpp.  Returns (row_offsets, rows as ROW_DTYPE)."""
+    L = lib()
+    L.emul_generate_lsc.argtypes = [C.POINTER(abi.Config), C.POINTER(abi.LscGen)]
+    L.emul_generate_lsc.restype = C.c_int
+    return _run_lsc_gen(cfg, lambda g: L.emul_generate_lsc(C.byref(cfg), C.byref(g)), plans, goals, radius, downwash,
+                        nbr_offsets, nbr_ids, local_ids, position, velocity)
+
+
+def _run_lsc_gen(cfg, call, plans, goals, radius, downwash, nbr_offsets, nbr_ids, local_ids, position, velocity):
+    first = plans is None
+    keep = []
+
+    def arr(a, dt):
+        if a is None:
+            return None, None
+        b = np.ascontiguousarray(a, dtype=dt)
+        keep.append(b)
+        return b, b.ctypes.data
+
+    g = abi.LscGen()
+    nbr_offsets = np.ascontiguousarray(nbr_offsets, dtype=np.int32)
+    nbr_ids_a = np.ascontiguousarray(nbr_ids, dtype=np.int32)
+    n_local = len(nbr_offsets) - 1
+    g.n_local, g.first_plan = n_local, 1 if first else 0
+    _, g.local_ids = arr(local_ids, np.int32)
+    _, g.plans = arr(plans, np.float32)
+    _, g.position = arr(position, np.float32)
+    _, g.velocity = arr(velocity, np.float32)
+    _, g.goals = arr(goals, np.float32)
+    _, g.radius = arr(radius, np.float64)
+    _, g.downwash = arr(downwash, np.float64)
+    g.nbr_offsets, g.nbr_ids = nbr_offsets.ctypes.data, nbr_ids_a.ctypes.data
+    per = cfg.M * (cfg.n + 1) - cfg.phi
+    R = per * int(nbr_offsets[-1])
+    out = {k: np.zeros(R + 1, np.float32) for k in ("nx", "ny", "nz", "px", "py", "pz")}
+    out["d"] = np.zeros(R + 1)
+    out["key"] = np.zeros(R + 1, np.uint32)
+    for k, v in out.items():
+        setattr(g, k, v.ctypes.data)
+    rc = call(g)
+    assert rc == 0
+    return (per * nbr_offsets.astype(np.int64)), soa_to_rows(out, R)
+
+
+def soa_to_rows(soa, R):
+    rows = np.zeros(R, abi.ROW_DTYPE)
+    rows["normal"][:, 0], rows["normal"][:, 1], rows["normal"][:, 2] = soa["nx"][:R], soa["ny"][:R], soa["nz"][:R]
+    rows["point"][:, 0], rows["point"][:, 1], rows["point"][:, 2] = soa["px"][:R], soa["py"][:R], soa["pz"][:R]
+    rows["d"] = soa["d"][:R]
+    key = soa["key"][:R]
+    rows["m"] = key & 0xFF
+    rows["i"] = (key >> 8) & 0xF
+    rows["flags"] = (key >> 12) & 1
+    sl = (key >> 16).astype(np.int64)
+    rows["slack"] = np.where(sl == 0xFFFF, -1, sl)
+    return rows

@@ -1,0 +1,45 @@
+"""Inputs for the DLSC-GC half-space generation tests (row N1): previous plans of a small swarm."""
+import numpy as np
+
+
+def random_swarm(cfg, n_agents, seed, spread=2.5, first=False):
+    """Previous plans (smooth random quintic pieces), sub-goals, radii, downwash and neighbour lists."""
+    rng = np.random.default_rng(seed)
+    M, n = cfg.M, cfg.n
+    pos = rng.uniform(-spread, spread, (n_agents, 3)).astype(np.float32)
+    pos[:, 2] = rng.uniform(0.5, 2.0, n_agents)
+    vel = rng.uniform(-0.8, 0.8, (n_agents, 3)).astype(np.float32)
+    plans = np.zeros((n_agents, M, n + 1, 3), np.float32)
+    for a in range(n_agents):
+        p = pos[a].astype(np.float64)
+        v = vel[a].astype(np.float64)
+        for m in range(M):
+            for i in range(n + 1):
+                plans[a, m, i] = p + v * cfg.dt * (m + i / n) + rng.normal(0, 0.01, 3)
+            if m + 1 < M:
+                v = v + rng.normal(0, 0.15, 3)
+        # C0 continuity like a real plan
+        for m in range(1, M):
+            plans[a, m, 0] = plans[a, m - 1, n]
+    goals = (plans[:, -1, -1] + rng.uniform(-1.5, 1.5, (n_agents, 3))).astype(np.float32)
+    # a few special cases: goal == last point (degenerate segment), parallel goal segments, shared goal
+    if n_agents >= 4:
+        goals[0] = plans[0, -1, -1]
+        goals[1] = plans[1, -1, -1] + np.float32([1, 0, 0])
+        plans[2, -1, -1] = plans[1, -1, -1] + np.float32([0, 0.7, 0])
+        goals[2] = plans[2, -1, -1] + np.float32([2, 0, 0])
+        goals[3] = goals[1]
+    radius = np.full(n_agents, 0.15)
+    radius[::3] = 0.2
+    downwash = np.full(n_agents, 2.0)
+    downwash[1::4] = 1.0
+    offs = [0]
+    ids = []
+    for a in range(n_agents):
+        others = [j for j in range(n_agents) if j != a]
+        k = int(rng.integers(0, len(others) + 1))
+        nb = rng.choice(others, k, replace=False) if k else []
+        ids.extend(int(x) for x in nb)
+        offs.append(len(ids))
+    return dict(plans=plans, goals=goals, radius=radius, downwash=downwash, nbr_offsets=np.array(offs, np.int32),
+                nbr_ids=np.array(ids, np.int32), position=pos, velocity=vel)

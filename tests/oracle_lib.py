@@ -159,3 +159,94 @@ def state_at(ctrl, dt, time):
 def terminal_segments(cfg, agent):
     agent = np.ascontiguousarray(agent, dtype=abi.AGENT_DTYPE).reshape(1)
     return lib().oracle_terminal_segments(C.byref(cfg), _ptr(agent))
+
+
+# ---- row N1: DLSC-GC half-space generation ---------------------------------------------------------
+GJK_FN = C.CFUNCTYPE(C.c_double, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double))
+_REF_GJK = None
+
+
+def ref_gjk():
+    """The reference's own openGJK (oracle/_ref/libref_gjk.so, built from /root/reference by oracle/Makefile),
+    or None where it has not been built."""
+    global _REF_GJK
+    if _REF_GJK is None:
+        path = os.path.join(ROOT, "oracle", "_ref", "libref_gjk.so")
+        if not os.path.exists(path):
+            return None
+        _REF_GJK = C.CDLL(path)
+        _REF_GJK.ref_gjk_point_hull.argtypes = [C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double)]
+        _REF_GJK.ref_gjk_point_hull.restype = C.c_double
+    return _REF_GJK
+
+
+def use_reference_gjk(on):
+    """Route the oracle's point-to-hull sub-problem through the reference's openGJK (True) or its own
+    exact enumeration (False)."""
+    L = lib()
+    L.oracle_set_gjk.argtypes = [C.c_void_p]
+    if on:
+        r = ref_gjk()
+        if r is None:
+            raise RuntimeError("oracle/_ref/libref_gjk.so is not built")
+        L.oracle_set_gjk(C.cast(r.ref_gjk_point_hull, C.c_void_p))
+    else:
+        L.oracle_set_gjk(None)
+
+
+def hull_closest_point(pts):
+    L = lib()
+    L.oracle_hull_closest_point.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.oracle_hull_closest_point.restype = C.c_double
+    pts = np.ascontiguousarray(pts, dtype=np.float64)
+    v = np.zeros(3)
+    d = L.oracle_hull_closest_point(_ptr(pts), len(pts), _ptr(v))
+    return d, v
+
+
+def shift_plan(prev):
+    L = lib()
+    L.oracle_shift_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    prev = np.ascontiguousarray(prev, dtype=np.float32)
+    out = np.zeros_like(prev)
+    L.oracle_shift_plan(_ptr(prev), prev.shape[0], prev.shape[1] - 1, _ptr(out))
+    return out
+
+
+def const_vel_plan(pos, vel, M, n, dt):
+    L = lib()
+    L.oracle_const_vel_plan.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    out = np.zeros((M, n + 1, 3), np.float32)
+    L.oracle_const_vel_plan(_ptr(np.ascontiguousarray(pos, np.float32)), _ptr(np.ascontiguousarray(vel, np.float32)), M, n, dt, _ptr(out))
+    return out
+
+
+def generate_dlscgc(cfg, init, goals, radius, downwash, nbr_offsets, nbr_ids, local_ids=None):
+    """DLSC-GC rows of the agents `local_ids` (default: all) against their neighbour lists.
+    init [N][M][n+1][3] float32 (shifted plans of ALL agents), goals [N][3].  Returns (row_offsets, rows)."""
+    L = lib()
+    L.oracle_generate_dlscgc.argtypes = [C.POINTER(abi.Config), C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.oracle_generate_dlscgc.restype = C.c_int
+    init = np.ascontiguousarray(init, dtype=np.float32)
+    goals = np.ascontiguousarray(goals, dtype=np.float32)
+    radius = np.ascontiguousarray(radius, dtype=np.float64)
+    downwash = np.ascontiguousarray(downwash, dtype=np.float64)
+    N = init.shape[0]
+    ids = np.arange(N) if local_ids is None else np.asarray(local_ids)
+    per = cfg.M * (cfg.n + 1) - cfg.phi
+    offs = [0]
+    out = []
+    for k, a in enumerate(ids):
+        nb = np.asarray(nbr_ids[nbr_offsets[k]:nbr_offsets[k + 1]], dtype=np.int64)
+        rows = np.zeros(len(nb) * per, abi.ROW_DTYPE)
+        ptrs = (C.c_void_p * max(len(nb), 1))(*[init[j].ctypes.data for j in nb])
+        g = np.ascontiguousarray(goals[nb])
+        rr = np.ascontiguousarray(radius[nb])
+        dw = np.ascontiguousarray(downwash[nb])
+        cnt = L.oracle_generate_dlscgc(C.byref(cfg), _ptr(init[a]), _ptr(goals[a]), float(radius[a]), float(downwash[a]),
+                                       len(nb), ptrs, _ptr(g), _ptr(rr), _ptr(dw), _ptr(rows))
+        assert cnt == len(rows)
+        out.append(rows)
+        offs.append(offs[-1] + cnt)
+    return np.array(offs, np.int64), (np.concatenate(out) if out else np.zeros(0, abi.ROW_DTYPE))
