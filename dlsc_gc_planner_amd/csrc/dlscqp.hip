@@ -492,7 +492,9 @@ extern "C" int dlscqp_plan_batch_device(dlscqp_ctx *c, const dlscqp_device_batch
     if (!c || !b) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
     if (!b->agents || !b->row_offsets || !b->out_status) { g_last_error = "null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
     (void)hipSetDevice(c->cfg.device);
-    return launch(c, b, stream ? (hipStream_t)stream : c->stream);
+    // the caller's stream exactly as given: NULL is the HIP null stream (e.g. torch's default stream), not the
+    // context's private stream -- launching elsewhere would race with the caller's stream-ordered work
+    return launch(c, b, (hipStream_t)stream);
 }
 
 extern "C" int dlscqp_generate_lsc_device(dlscqp_ctx *c, const dlscqp_lsc_gen *gen, void *stream) {
@@ -514,7 +516,7 @@ extern "C" int dlscqp_generate_lsc_device(dlscqp_ctx *c, const dlscqp_lsc_gen *g
     g.nbr_offsets = gen->nbr_offsets; g.nbr_ids = gen->nbr_ids;
     g.nx = gen->nx; g.ny = gen->ny; g.nz = gen->nz; g.px = gen->px; g.py = gen->py; g.pz = gen->pz;
     g.d = gen->d; g.key = gen->key;
-    hipLaunchKernelGGL(dlscqp_lsc_kernel, dim3(gen->n_local), dim3(64), 0, stream ? (hipStream_t)stream : c->stream, g);
+    hipLaunchKernelGGL(dlscqp_lsc_kernel, dim3(gen->n_local), dim3(64), 0, (hipStream_t)stream, g);
     HIP_TRY(hipGetLastError());
     return DLSCQP_SUCCESS;
 }

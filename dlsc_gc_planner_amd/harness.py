@@ -1,0 +1,103 @@
+"""Closed-loop replanning harness on the device (first slice).
+
+Reproduces the data flow of MultiSyncSimulator::run (/root/reference/src/multi_sync_simulator.cpp:70-141) for
+agents in obstacle-free worlds: doStep (state := plan(t + dt)), broadcastMsgs (every agent sees every other
+agent's previous plan and sub-goal), then for ALL agents at once: previous-plan shift -> DLSC-GC half-spaces
+-> goal LP -> trajectory QP -> fail-safe.  Everything stays in HBM between steps: the half-spaces are generated
+by dlscqp_generate_lsc_device, consumed by dlscqp_plan_batch_device, and the new plans become the next step's
+plan table.  torch is plumbing only (state bookkeeping: a handful of elementwise ops per step).
+
+Not reproduced (out of scope): the grid planner / PIBT that hands out waypoints in the
+reference (N4) -- the waypoint here is the point `waypoint_step` metres ahead on the straight line to the
+desired goal -- and static / dynamic obstacles (N2).
+"""
+import numpy as np
+
+from . import abi
+from .planner import BatchTrajOptimizer
+
+
+class ClosedLoop:
+    def __init__(self, cfg, start, goal, radius=0.15, downwash=2.0, max_vel=1.0, max_acc=2.0, nominal_velocity=1.0,
+                 waypoint_step=0.5, device=0):
+        import torch
+        self.torch = torch
+        self.cfg = cfg
+        self.opt = BatchTrajOptimizer(cfg)
+        dev = torch.device("cuda", device)
+        self.dev = dev
+        N = len(start)
+        self.N = N
+        M, n = cfg.M, cfg.n
+        f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)  # noqa: E731
+        self.pos = f32(start)
+        self.vel = torch.zeros((N, 3), dtype=torch.float32, device=dev)
+        self.acc = torch.zeros((N, 3), dtype=torch.float32, device=dev)
+        self.desired_goal = f32(goal)
+        self.cur_goal = self.pos.clone()  # agent_manager.cpp:9
+        self.plans = torch.zeros((N, M, n + 1, 3), dtype=torch.float32, device=dev)
+        self.radius, self.downwash = float(radius), float(downwash)
+        self.waypoint_step = waypoint_step
+        self.seq = 0
+        # every agent is every other agent's obstacle (communication range -1 in testall_DLSCGC_empty.launch)
+        ids = np.arange(N)
+        nbr_ids = np.concatenate([np.delete(ids, a) for a in range(N)]) if N > 1 else np.zeros(0, np.int32)
+        nbr_offsets = np.arange(N + 1) * (N - 1)
+        self.gen = self.opt.make_lsc_generator(N, nbr_offsets, nbr_ids, np.full(N, radius), np.full(N, downwash), device=device)
+        # agent records: static fields once, the five float3 fields are refreshed every step
+        agents = np.zeros(N, abi.AGENT_DTYPE)
+        agents["id"] = ids
+        agents["n_obs"] = N - 1
+        agents["max_vel"], agents["max_acc"], agents["radius"], agents["nominal_velocity"] = max_vel, max_acc, radius, nominal_velocity
+        ro = self.gen.row_offsets
+        self.batch = self.opt.make_device_batch(agents, ro, np.zeros(0, abi.ROW_DTYPE), None, 0, want_iters=True, device=device)
+        for k in ("nx", "ny", "nz", "px", "py", "pz", "d", "key"):
+            setattr(self.batch.c, k, self.gen.soa[k].data_ptr())
+        self.ro32 = torch.from_numpy(ro.astype(np.int32)).to(dev)
+        self.batch.c.row_offsets = self.ro32.data_ptr()
+        self.batch.c.max_rows_per_agent = int(np.diff(ro).max()) if N else 0
+        self.agent_f32 = self.batch.t["agents"].view(torch.float32).view(N, abi.AGENT_DTYPE.itemsize // 4)
+        self.history = []
+
+    def close(self):
+        self.opt.close()
+
+    def step(self):
+        """One replanning step of every agent; returns (status [N] tensor, iterations tensor)."""
+        torch, cfg = self.torch, self.cfg
+        n, dt = cfg.n, cfg.dt
+        # waypoint: straight ahead towards the desired goal (stands in for the grid planner, see module doc)
+        to_goal = self.desired_goal - self.pos
+        dist = to_goal.norm(dim=1, keepdim=True)
+        wp = torch.where(dist <= self.waypoint_step, self.desired_goal, self.pos + to_goal / dist.clamp_min(1e-9) * self.waypoint_step)
+        a = self.agent_f32
+        a[:, 0:3], a[:, 3:6], a[:, 6:9], a[:, 9:12], a[:, 12:15] = self.pos, self.vel, self.acc, self.cur_goal, wp
+        first = self.seq < 1  # planner_seq < 2 in the reference counts from 1
+        if first:
+            self.gen.generate(self.cur_goal, position=self.pos, velocity=self.vel)
+            init = self.pos[:, None, None, :].expand(-1, cfg.M, n + 1, -1) + 0 * self.plans  # zero velocity
+        else:
+            self.gen.generate(self.cur_goal, plans=self.plans)
+            init = torch.cat([self.plans[:, 1:], self.plans[:, -1:, -1:].expand(-1, 1, n + 1, -1)], dim=1)
+        self.batch.launch(True, True)
+        ok = (self.batch.out_status == abi.OK)
+        gok = (self.batch.out_goal_status != abi.INFEASIBLE)
+        # fail-safe: keep the shifted previous plan (traj_planner.cpp:776); sub-goal from the LP (traj_planner.cpp:494)
+        self.plans = torch.where(ok[:, None, None, None], self.batch.out_ctrl, init).contiguous()
+        self.cur_goal = torch.where(gok[:, None], self.batch.out_goal, self.cur_goal).contiguous()
+        # doStep of the next iteration: state = desired_traj.getStateAt(dt) = start of segment 1, float32 differences
+        c0, c1, c2 = self.plans[:, 1, 0], self.plans[:, 1, 1], self.plans[:, 1, 2]
+        s1, s2 = np.float32(n / dt), np.float32((n - 1) / dt)
+        v0, v1 = (c1 - c0) * s1, (c2 - c1) * s1
+        self.pos, self.vel, self.acc = c0.clone(), v0, (v1 - v0) * s2
+        self.seq += 1
+        return self.batch.out_status, self.batch.out_iters
+
+    def min_separation(self):
+        """Smallest pairwise distance in the downwash metric divided by the collision distance (>= 1: no collision),
+        the reference's safety_ratio_agent (multi_sync_simulator.cpp:652-690)."""
+        torch = self.torch
+        d = self.pos[:, None, :] - self.pos[None, :, :]
+        d = d * torch.tensor([1.0, 1.0, 1.0 / self.downwash], device=self.dev)
+        dist = d.norm(dim=2) + torch.eye(self.N, device=self.dev) * 1e9
+        return float(dist.min() / (2 * self.radius))

@@ -165,7 +165,8 @@ int dlscqp_plan_batch(dlscqp_ctx *ctx, int32_t n_agents, const dlscqp_agent *age
 /* ---- device-resident entry point ---------------------------------------------------------
  * Everything already in HBM, constraint rows in structure-of-arrays form so a wavefront reads
  * 64 consecutive rows with one coalesced load per field.  Asynchronous on `stream`
- * (a hipStream_t passed as void*); no allocation, no synchronisation inside.               */
+ * (a hipStream_t passed as void*; NULL = the HIP null stream, exactly as for hipLaunchKernel);
+ * no allocation, no synchronisation inside.                                                 */
 typedef struct dlscqp_device_batch {
     int32_t n_agents;
     int32_t max_slack_obs;          /* stride of out_slack_cost                                 */

@@ -4,6 +4,7 @@
     python tests/golden/make_golden.py
 
 Writes next to this file:
+  missions_empty.json  start / goal / vehicle numbers of missions/empty10/..._1.json and missions/empty60/..._1.json
   kat_log.json       known-answer values copied (as numbers) out of the reference's own run log
                      /root/reference/log/result_1742185870.978562_DLSCGC_10agents.csv -- the only
                      artifact of the reference that pins results of the trajectory QP -- together
@@ -65,6 +66,21 @@ def make_kat():
     out["summary"] = dict(zip(srow[0], srow[1]))
     json.dump(out, open(os.path.join(HERE, "kat_log.json"), "w"), indent=1)
     print("kat_log.json written")
+
+
+def make_missions():
+    """Start/goal/vehicle numbers of two of the reference's mission files (inputs for the closed-loop test)."""
+    out = {}
+    for name, path in (("empty10_1", "/root/reference/missions/empty10/multi_random_10agents_1.json"),
+                       ("empty60_1", "/root/reference/missions/empty60/multi_random_60agents_1.json")):
+        m = json.load(open(path))
+        q = m["quadrotors"]["crazyflie"]
+        out[name] = dict(source="missions/" + path.split("/missions/")[1], world=m["world"][0]["dimension"],
+                         start=[a["start"] for a in m["agents"]], goal=[a["goal"] for a in m["agents"]],
+                         max_vel=q["max_vel"][0], max_acc=q["max_acc"][0], radius=q["radius"], downwash=q["downwash"],
+                         nominal_velocity=q["nominal_velocity"])
+    json.dump(out, open(os.path.join(HERE, "missions_empty.json"), "w"))
+    print("missions_empty.json written")
 
 
 def solve_batch_highs(cfg, batch):
@@ -137,6 +153,7 @@ def save(name, cfg_kwargs, cfg, batch, ans):
 
 def main():
     make_kat()
+    make_missions()
     # S64 (BASELINE.json configs[1]) closed loop driven by the oracle
     cfg = workloads.s64_config()
 
