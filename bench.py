@@ -73,6 +73,11 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the single-swarm host-to-host latency loop")
     ap.add_argument("--no-order-hint", action="store_true",
                     help="launch agents in id order instead of most-expensive-first (previous step's iteration counts)")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N>1: one launch + one all-gather per step instead of the two-chunk overlapped exchange")
+    ap.add_argument("--hard-fraction", type=float, default=0.125,
+                    help="N>1 overlapped exchange: share of the agents (most expensive first) in the straggler chunk")
+    ap.add_argument("--force-dist", action="store_true", help="(test) create the process group even for one rank")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic_latest.json"))
     args = ap.parse_args()
 
@@ -85,7 +90,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -106,48 +112,93 @@ def main():
     N = len(wl["agents"])
     K = wl["K"]
     db = opt.make_device_batch(wl["agents"], wl["row_offsets"], wl["rows"], None, 0, want_iters=True)
-    gathered = None
-    if world > 1:
-        gathered = torch.empty((world * N,) + tuple(db.out_ctrl.shape[1:]), dtype=torch.float32, device=dev)
-
-    def step():
-        db.launch(True, True)
-        if world > 1:
-            # the per-step exchange: every agent's solved control points to every rank
-            dist.all_gather_into_tensor(gathered, db.out_ctrl)
+    overlap = use_dist and not args.no_overlap and not args.no_order_hint
+    shape1 = tuple(db.out_ctrl.shape[1:])
 
     for _ in range(args.warmup):
-        step()
+        db.launch(True, True)
     torch.cuda.synchronize(dev)
+    H = 0
     if not args.no_order_hint:
         # closed-loop planners replan the same agents every 0.2 s and an agent's difficulty changes slowly:
         # launch the agents that needed most active-set iterations in the previous step first
         prev_iters = db.out_iters.cpu().numpy()[:, 0]
-        db.set_order(np.argsort(-prev_iters, kind="stable").astype(np.int32))
+        order = np.argsort(-prev_iters, kind="stable").astype(np.int32)
+        if overlap:
+            # N>1: keep the batch itself in that order (slot == index), so that a contiguous range of the
+            # output table is final as soon as its chunk's launch retires and can be all-gathered while the
+            # stragglers of the other chunk are still iterating
+            pa, pro, prows = workloads.permute_batch(wl["agents"], wl["row_offsets"], wl["rows"], order)
+            wl = dict(wl, agents=pa, row_offsets=pro, rows=prows)
+            db = opt.make_device_batch(pa, pro, prows, None, 0, want_iters=True)
+            H = max(64, int(N * args.hard_fraction)) if N > 128 else N // 2
+        else:
+            db.set_order(order)
+    if use_dist:
+        if overlap:
+            g_hard = torch.empty((world, H) + shape1, dtype=torch.float32, device=dev)
+            g_easy = torch.empty((world, N - H) + shape1, dtype=torch.float32, device=dev)
+            s_hard = torch.cuda.Stream(dev, priority=-1)
+            s_easy = torch.cuda.Stream(dev)
+        else:
+            gathered = torch.empty((world * N,) + shape1, dtype=torch.float32, device=dev)
+
+    def step():
+        if not use_dist:
+            db.launch(True, True)
+        elif not overlap:
+            db.launch(True, True)
+            # the per-step exchange: every agent's solved control points to every rank
+            dist.all_gather_into_tensor(gathered, db.out_ctrl)
+        else:
+            cur = torch.cuda.current_stream(dev)
+            s_hard.wait_stream(cur)
+            s_easy.wait_stream(cur)
+            with torch.cuda.stream(s_hard):
+                db.launch(True, True, offset=0, count=H)
+            with torch.cuda.stream(s_easy):
+                db.launch(True, True, offset=H, count=N - H)
+                dist.all_gather_into_tensor(g_easy.view((world * (N - H),) + shape1), db.out_ctrl[H:])
+            with torch.cuda.stream(s_hard):
+                dist.all_gather_into_tensor(g_hard.view((world * H,) + shape1), db.out_ctrl[:H])
+            cur.wait_stream(s_hard)
+            cur.wait_stream(s_easy)
+
+    for _ in range(2):
         step()
-        torch.cuda.synchronize(dev)
-    opt.set_timing(args.steps)
-    if world > 1:
+    torch.cuda.synchronize(dev)
+    opt.set_timing(0 if overlap else args.steps)
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    kms = opt.kernel_times_ms(args.steps)
-    res = db.results()
-    if world > 1:
+    if use_dist:
         # the gathered table must hold this rank's own block
-        own = gathered[rank * N:(rank + 1) * N]
-        assert torch.equal(own, db.out_ctrl)
+        if overlap:
+            assert torch.equal(g_hard[rank], db.out_ctrl[:H]) and torch.equal(g_easy[rank], db.out_ctrl[H:])
+        else:
+            assert torch.equal(gathered[rank * N:(rank + 1) * N], db.out_ctrl)
+    if overlap:
+        # roofline leg: the chunks of the timed steps overlap each other, so time whole-batch launches
+        opt.set_timing(10)
+        for _ in range(10):
+            db.launch(True, True)
+        torch.cuda.synchronize(dev)
+        kms = opt.kernel_times_ms(10)
+    else:
+        kms = opt.kernel_times_ms(args.steps)
+    res = db.results()
 
     if rank == 0:
         ok = res["status"] == abi.OK
@@ -191,7 +242,10 @@ def main():
                             "3-D, 5 segments x degree 5, %d DLSC rows per agent)" % (args.swarms, K),
                 "agents_per_gpu": N, "segments": M, "degree": n, "lsc_rows_per_agent": K,
                 "vars_per_agent": dim * M * (n + 1), "ineq_rows_per_agent": K + 2 * 207,
-                "exchange": "one RCCL all-gather of control points per step" if world > 1 else "none (1 GPU)",
+                "exchange": ("none (1 GPU)" if not use_dist else
+                             "RCCL all-gather of control points per step, in two chunks (easy %d agents first, "
+                             "overlapping the %d stragglers)" % (N - H, H) if overlap else
+                             "one RCCL all-gather of control points per step"),
                 "launch_order": "id" if args.no_order_hint else "previous step's iteration count, descending",
                 "solved_fraction": float(ok.mean()), "mean_active_set_iterations": float(it[:, 0].mean()),
                 "max_active_set_iterations": int(it[:, 0].max()), "seed": args.seed,
@@ -211,7 +265,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(cfg, wl)
         print(json.dumps(line))
     opt.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -93,6 +93,8 @@ class DeviceBatch(C.Structure):
         ("do_goal", C.c_int32),
         ("do_traj", C.c_int32),
         ("max_rows_per_agent", C.c_int32),
+        ("launch_offset", C.c_int32),
+        ("launch_count", C.c_int32),
         ("reserved_", C.c_int32),
         ("agents", C.c_void_p),
         ("row_offsets", C.c_void_p),

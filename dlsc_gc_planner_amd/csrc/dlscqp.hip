@@ -16,6 +16,9 @@
 
 #define DQ_FN __host__ __device__ __forceinline__
 #define DQ_KEEP(v) asm volatile("" : "+v"(v))
+#ifdef DLSCQP_TRACE_LDS
+#define DLSCQP_TRACE
+#endif
 #include "gi_core.hpp"
 #include "lsc_core.hpp"
 #include "qp_tables.hpp"
@@ -68,6 +71,19 @@ struct WaveGpu {
     }
 #else
     __device__ __forceinline__ void stamp(int) const {}
+#endif
+#ifdef DLSCQP_TRACE
+    // debug build only: lane 0 logs (tag, 4 doubles) records of this agent's solve into the stamps buffer
+    double *tr = nullptr;
+    mutable int trn = 0;
+    __device__ __forceinline__ void trace(int tag, double a, double b, double c, double d) const {
+        if (tr && lane == 0 && trn < 200) {
+            double *o = tr + 1 + trn * 5;
+            o[0] = tag; o[1] = a; o[2] = b; o[3] = c; o[4] = d;
+            tr[0] = trn + 1;
+        }
+        trn++;
+    }
 #endif
     template <class F>
     __device__ __forceinline__ void each(F f) const { f(lane); }
@@ -156,10 +172,9 @@ struct WaveGpu {
     template <class T>
     __device__ __forceinline__ void shift_up(const Reg<T> *arr, int c, int nchunks, Reg<T> &out) const {
         (void)nchunks;
-        T prv = __shfl_up(arr[c].v, 1, 64);
-        T tail = c > 0 ? __shfl(arr[c - 1].v, 63, 64) : T(0);
-        if (lane == 0) prv = tail;
-        out.v = prv;
+        const T prv = __shfl_up(arr[c].v, 1, 64);
+        const T tail = c > 0 ? __shfl(arr[c - 1].v, 63, 64) : T(0);
+        out.v = lane == 0 ? tail : prv;
     }
     __device__ __forceinline__ bool any(const Reg<int> &r) const { return __ballot(r.v != 0) != 0ull; }
     __device__ __forceinline__ int first_lane(const Reg<int> &r) const {
@@ -169,9 +184,9 @@ struct WaveGpu {
     template <class T>
     __device__ __forceinline__ void shift_down(const Reg<T> *arr, int c, int nchunks, Reg<T> &out) const {
         T nxt = __shfl_down(arr[c].v, 1, 64);
-        if (c + 1 < nchunks) {
-            T head = __shfl(arr[c + 1].v, 0, 64);
-            if (lane == 63) nxt = head;
+        if (c + 1 < nchunks) {  // uniform
+            const T head = __shfl(arr[c + 1].v, 0, 64);
+            nxt = lane == 63 ? head : nxt;
         }
         out.v = nxt;
     }
@@ -179,6 +194,7 @@ struct WaveGpu {
 
 struct KernelArgs {
     int n_agents, max_slack_obs, do_goal, do_traj;
+    int slot0, n_slots_launch;  // launch slots [slot0, slot0 + n_slots_launch)
     const dlscqp_agent *agents;
     const int32_t *row_offsets;
     RowsView rows;
@@ -198,13 +214,22 @@ struct KernelArgs {
 template <int RC, int DIMS, int FS, int MS, int KU, int SU>
 __global__ __launch_bounds__(64, 2) void dlscqp_plan_kernel(KParams kp, MemLayout lay, KernelArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
-    if ((int)blockIdx.x >= a.n_agents) return;
-    const int ag = a.order ? a.order[blockIdx.x] : (int)blockIdx.x;
+    if ((int)blockIdx.x >= a.n_slots_launch) return;
+    const int slot = a.slot0 + (int)blockIdx.x;
+    const int ag = a.order ? a.order[slot] : slot;
     if (ag < 0 || ag >= a.n_agents) return;
     WaveGpu w;
     w.lane = (int)threadIdx.x;
 #ifdef DLSCQP_STAMPS
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w.last)::"memory");
+#endif
+#ifdef DLSCQP_TRACE
+#ifdef DLSCQP_TRACE_LDS
+    w.tr = reinterpret_cast<double *>(smem + lay.bytes);  // into LDS, dumped by DLSCQP_PM_LDS
+    if (threadIdx.x == 0) w.tr[0] = 0;
+#else
+    if (a.out_stamps) w.tr = reinterpret_cast<double *>(a.out_stamps) + (size_t)ag * 1001;
+#endif
 #endif
     const int rb = a.row_offsets[ag], re = a.row_offsets[ag + 1];
     const int M = kp.M, n1 = kp.n1;
@@ -221,6 +246,22 @@ __global__ __launch_bounds__(64, 2) void dlscqp_plan_kernel(KParams kp, MemLayou
 #ifdef DLSCQP_STAMPS
     if (a.out_stamps && threadIdx.x == 0)
         for (int p = 0; p < 12; p++) a.out_stamps[(size_t)ag * 12 + p] = w.acc[p];
+#endif
+#ifdef DLSCQP_PM_LDS
+    // debug build only: image of the agent's LDS working set when the solve returns (layout header + doubles)
+    if (a.out_stamps) {
+        unsigned long long *o = a.out_stamps + (size_t)ag * 20992;
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(smem);
+        if (threadIdx.x == 0) {
+            o[0] = lay.bytes; o[1] = lay.oQ; o[2] = lay.oRp; o[3] = lay.oN; o[4] = lay.oX; o[5] = lay.oBlo; o[6] = lay.oBhi;
+            o[7] = lay.oFlag; o[8] = lay.ldq; o[9] = lay.r_max;
+        }
+        int nd = lay.bytes / 8;
+#ifdef DLSCQP_TRACE_LDS
+        nd += 1001;
+#endif
+        for (int i = threadIdx.x; i < nd; i += 64) o[16 + i] = src[i];
+    }
 #endif
 }
 
@@ -250,6 +291,9 @@ struct KernelChoice {
 KernelChoice select_kernel(const KParams &kp, int max_slack_obs, int kmax) {
     const int r_max = kp.dim * kp.f + kp.M * max_slack_obs;
     static const bool force_generic = std::getenv("DLSCQP_FORCE_GENERIC") != nullptr;  // debugging aid
+#ifdef DLSCQP_ONLY_G2  // debugging aid: compile only the generic two-register instantiation
+    return {dlscqp_plan_kernel<2, 0, 0, 0, 4, 10>, 5, 4, 10};
+#else
     if (force_generic) {
         if (r_max <= 64) return {dlscqp_plan_kernel<1, 0, 0, 0, 4, 10>, 4, 4, 10};
         if (r_max <= 128) return {dlscqp_plan_kernel<2, 0, 0, 0, 4, 10>, 5, 4, 10};
@@ -263,6 +307,7 @@ KernelChoice select_kernel(const KParams &kp, int max_slack_obs, int kmax) {
     if (r_max <= 64) return {dlscqp_plan_kernel<1, 0, 0, 0, 4, 10>, 4, 4, 10};
     if (r_max <= 128) return {dlscqp_plan_kernel<2, 0, 0, 0, 4, 10>, 5, 4, 10};
     return {nullptr, -1, 0, 0};
+#endif
 }
 
 thread_local std::string g_last_error;
@@ -459,6 +504,9 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
     kernel_t kfn = kc.fn;
     KernelArgs a;
     a.n_agents = b->n_agents;
+    a.slot0 = b->launch_count > 0 ? b->launch_offset : 0;
+    a.n_slots_launch = b->launch_count > 0 ? b->launch_count : b->n_agents;
+    if (a.slot0 < 0 || a.slot0 + a.n_slots_launch > b->n_agents) { g_last_error = "launch slots out of range"; return DLSCQP_ERR_INVALID_ARGUMENT; }
     a.max_slack_obs = b->max_slack_obs;
     a.do_goal = b->do_goal;
     a.do_traj = b->do_traj;
@@ -478,7 +526,12 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
     a.out_stamps = (unsigned long long *)b->debug_stamps;
     const bool timed = c->ev_used < (int)c->ev0.size();
     if (timed) HIP_TRY(hipEventRecord(c->ev0[c->ev_used], stream));
-    hipLaunchKernelGGL(kfn, dim3(b->n_agents), dim3(64), lay.bytes, stream, c->kp, lay, a);
+#ifdef DLSCQP_TRACE_LDS
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kc.fn), hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes + 8016));
+    hipLaunchKernelGGL(kfn, dim3(a.n_slots_launch), dim3(64), lay.bytes + 8016, stream, c->kp, lay, a);
+#else
+    hipLaunchKernelGGL(kfn, dim3(a.n_slots_launch), dim3(64), lay.bytes, stream, c->kp, lay, a);
+#endif
     HIP_TRY(hipGetLastError());
     if (timed) {
         HIP_TRY(hipEventRecord(c->ev1[c->ev_used], stream));

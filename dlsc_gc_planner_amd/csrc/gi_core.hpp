@@ -53,6 +53,7 @@ namespace dlscqp {
 struct MemLayout {
     int r_max, nx_max, ldq, nflag;
     int oQ, oRp, oN, oX, oBlo, oBhi;  // in doubles
+    int oDump;                        // 64 doubles: where lanes that have nothing to store put their value
     int oFlag;                        // byte offset of the flags of rows beyond the register cache
     int bytes;
 };
@@ -67,14 +68,15 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
     const int cold_slots = kp.n_slots > 64 * SU ? kp.n_slots - 64 * SU : 0;
     L.nflag = cold_rows + 2 * cold_slots;
     int o = 0;
-    L.oQ = o; o += L.r_max * L.ldq;
+    L.oQ = o; o += (L.r_max + 1) * L.ldq;  // + one row for the lanes beyond r (see "no divergence" below)
     L.oRp = o; o += L.r_max * (L.r_max + 1) / 2;
     L.oN = o; o += kp.P * kp.f;
     L.oX = o; o += L.nx_max;
     L.oBlo = o; o += kp.nb;
     L.oBhi = o; o += kp.nb;
+    L.oDump = o; o += 64;
     L.oFlag = o * 8;
-    L.bytes = (L.oFlag + L.nflag + 15) & ~15;
+    L.bytes = (L.oFlag + L.nflag + 1 + 15) & ~15;  // + one flag byte as the dump of the flag array
     return L;
 }
 
@@ -88,7 +90,13 @@ constexpr uint32_t KEY_SKIP = 0xFFFFFFFFu;  // cached LSC row that is not part o
 
 // v[k] for a per-lane k without dynamic indexing of a register array (which would go through scratch memory)
 template <class T>
-DQ_FN T pick3(const T *v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2]); }
+DQ_FN T pick3(const T *v, int k) {
+    const T v0 = v[0], v1 = v[1], v2 = v[2];  // flat selects: nested ?: came out as EXEC-masked branches
+    T r = v2;
+    r = k == 1 ? v1 : r;
+    r = k == 0 ? v0 : r;
+    return r;
+}
 
 #define DQ_RP(i, j) Rp[(j) * ((j) + 1) / 2 + (i)]
 // element e of a per-lane vector spread over RC registers
@@ -99,6 +107,22 @@ DQ_FN T pick3(const T *v, int k) { return k == 0 ? v[0] : (k == 1 ? v[1] : v[2])
 // below has a constant trip count, is fully unrolled, and its LDS reads are issued back to back instead
 // of one dependent round trip per iteration -- the difference between ~35k and a few thousand cycles per
 // active-set iteration for a single wavefront.
+//
+// NO DIVERGENCE.  Every lane executes every instruction of plan_agent: there is no branch and no loop bound that
+// depends on the lane.  Lanes that have no element to work on use a clamped (valid) index for their loads,
+// mask the result with a select, and send their stores to a dump slot (MemLayout::oDump, the extra row of Q).
+// This is a correctness rule, not a style: the solver keeps ~100 VGPRs of per-lane state and wave-uniform
+// values (LDS addresses, cached rows) alive across the whole iteration, and when the register allocator
+// splits or spills such a live range INSIDE a lane-divergent region, the copy runs under the region's EXEC
+// mask and the inactive lanes come back as garbage after the region (seen on gfx950 / ROCm 7.2: lanes
+// >= r - 64 of the two-register generic instantiation, depending on unrelated source changes).  Branches on
+// wave-uniform conditions do not touch EXEC and are fine.
+#ifdef DLSCQP_TRACE
+#define DQ_TRACE(tag, a, b, c, d) w.trace(tag, a, b, c, d)  // debug builds only (tests/trace_gpu.py)
+#else
+#define DQ_TRACE(tag, a, b, c, d)
+#endif
+
 template <int RC, int DIMS, int FS, int MS, int KU, int SU, class W>
 DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsigned char *mem,
                       const dlscqp_agent *agp, const RowsView &rows, int row_begin, int K,
@@ -145,18 +169,25 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 #pragma unroll
     for (int u = 0; u < KU; u++) {
         w.each([&](int l) {
-            const int j = l + 64 * u;
             cnx[u].at(l) = 0; cny[u].at(l) = 0; cnz[u].at(l) = 0;
             cpx[u].at(l) = 0; cpy[u].at(l) = 0; cpz[u].at(l) = 0;
             cd[u].at(l) = 0;
             ckey[u].at(l) = KEY_SKIP;
-            if (j < Kc) {
-                cnx[u].at(l) = Rnx[j]; cny[u].at(l) = Rny[j]; cnz[u].at(l) = Rnz[j];
-                cpx[u].at(l) = Rpx[j]; cpy[u].at(l) = Rpy[j]; cpz[u].at(l) = Rpz[j];
-                cd[u].at(l) = Rd[j];
-                ckey[u].at(l) = Rkey[j];
-            }
         });
+        if (64 * u < Kc) {  // uniform
+            w.each([&](int l) {
+                const int j = l + 64 * u;
+                const bool in = j < Kc;
+                const int jc = in ? j : Kc - 1;  // clamped: every lane loads, lanes beyond the rows drop the value
+                const float a0 = Rnx[jc], a1 = Rny[jc], a2 = Rnz[jc], b0 = Rpx[jc], b1 = Rpy[jc], b2 = Rpz[jc];
+                const double dd = Rd[jc];
+                const uint32_t kk = Rkey[jc];
+                cnx[u].at(l) = in ? a0 : 0.0f; cny[u].at(l) = in ? a1 : 0.0f; cnz[u].at(l) = in ? a2 : 0.0f;
+                cpx[u].at(l) = in ? b0 : 0.0f; cpy[u].at(l) = in ? b1 : 0.0f; cpz[u].at(l) = in ? b2 : 0.0f;
+                cd[u].at(l) = in ? dd : 0.0;
+                ckey[u].at(l) = in ? kk : KEY_SKIP;
+            });
+        }
     }
 
     // ---- structured slots into registers (issued here so that all prologue loads are in flight together)
@@ -168,17 +199,22 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     for (int u = 0; u < SU; u++) {
         {
             w.each([&](int l) {
-                const int s = l + 64 * u;
-                uint32_t pi = 0xBFFFFFFFu, pc = 0;  // bit 31: no slot in this register
-                if (s < Sc) {
-                    Slot sl = slots[s];
-                    pi = (uint32_t)(sl.idx[0] & 0x3FF) | ((uint32_t)(sl.idx[1] & 0x3FF) << 10) | ((uint32_t)(sl.idx[2] & 0x3FF) << 20);
-                    pc = (uint32_t)(uint8_t)sl.coef[0] | ((uint32_t)(uint8_t)sl.coef[1] << 8) |
-                         ((uint32_t)(uint8_t)sl.coef[2] << 16) | ((uint32_t)sl.bsel << 24);
-                }
-                sidx[u].at(l) = pi;
-                scb[u].at(l) = pc;
+                sidx[u].at(l) = 0xBFFFFFFFu;  // bit 31: no slot in this register
+                scb[u].at(l) = 0;
             });
+            if (64 * u < Sc) {  // uniform
+                w.each([&](int l) {
+                    const int s = l + 64 * u;
+                    const bool in = s < Sc;
+                    const Slot sl = slots[in ? s : Sc - 1];
+                    const uint32_t pi = (uint32_t)(sl.idx[0] & 0x3FF) | ((uint32_t)(sl.idx[1] & 0x3FF) << 10) |
+                                        ((uint32_t)(sl.idx[2] & 0x3FF) << 20);
+                    const uint32_t pc = (uint32_t)(uint8_t)sl.coef[0] | ((uint32_t)(uint8_t)sl.coef[1] << 8) |
+                                        ((uint32_t)(uint8_t)sl.coef[2] << 16) | ((uint32_t)sl.bsel << 24);
+                    sidx[u].at(l) = in ? pi : 0xBFFFFFFFu;
+                    scb[u].at(l) = in ? pc : 0u;
+                });
+            }
         }
     }
 
@@ -213,24 +249,26 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             RegI lbad, lviol;
             auto lp_row = [&](uint32_t key, float nx, float ny, float nz, float qx, float qy, float qz, double dd,
                               double &lo, double &hi, int &bad, int &viol) {
-                int m = key & 0xFF, i = (key >> 8) & 0xF, dyn = (key >> 12) & 1;
-                if (key == KEY_SKIP || dyn || m != M - 1 || i != n) return;
-                if (f32_norm3(nx, ny, nz) < SP_EPSILON_FLOAT) return;
-                float ox = wp[0] - qx, oy = wp[1] - qy;
+                // select form (no lane-dependent branch): rows that are not part of the LP leave lo/hi/bad/viol as they are
+                const int m = key & 0xFF, i = (key >> 8) & 0xF, dyn = (key >> 12) & 1;
+                double nrm = f32_norm3(nx, ny, nz);
+                DQ_KEEP(nrm);  // computed by every lane: no short-circuit branch around the sqrt
+                const bool in_lp = (key != KEY_SKIP) & (dyn == 0) & (m == M - 1) & (i == n) & !(nrm < SP_EPSILON_FLOAT);
+                const float ox = wp[0] - qx, oy = wp[1] - qy, oz = wp[2] - qz;
                 double a = (double)nx * (double)diff[0] + (double)ny * (double)diff[1];
                 double b = -dd + (double)nx * (double)ox + (double)ny * (double)oy;
-                if (dim == 3) {
-                    float oz = wp[2] - qz;
-                    a += (double)nz * (double)diff[2];
-                    b += (double)nz * (double)oz;
-                }
-                if (a > 0) { if (-b / a > lo) lo = -b / a; }
-                else if (a < 0) { if (-b / a < hi) hi = -b / a; }
-                else if (b < -CPLEX_FEAS_TOL) bad = 1;
+                const double a3 = a + (double)nz * (double)diff[2], b3 = b + (double)nz * (double)oz;
+                a = dim == 3 ? a3 : a;
+                b = dim == 3 ? b3 : b;
+                double tq = -b / a;  // not finite when a == 0: never selected then
+                DQ_KEEP(tq);
+                lo = (in_lp & (a > 0) & (tq > lo)) ? tq : lo;
+                hi = (in_lp & (a < 0) & (tq < hi)) ? tq : hi;
+                bad = (in_lp & !(a > 0) & !(a < 0) & (b < -CPLEX_FEAS_TOL)) ? 1 : bad;
                 // exception branch of goal_optimizer.cpp:63-77: does current_goal_point violate the row?
-                float e0 = cg[0] - qx, e1 = cg[1] - qy, e2 = cg[2] - qz;
-                float dot = nx * e0 + ny * e1 + nz * e2;  // float32 dot of float32 differences
-                if ((double)dot - dd < -SP_EPSILON_FLOAT) viol = 1;
+                const float e0 = cg[0] - qx, e1 = cg[1] - qy, e2 = cg[2] - qz;
+                const float dot = nx * e0 + ny * e1 + nz * e2;  // float32 dot of float32 differences
+                viol = (in_lp & ((double)dot - dd < -SP_EPSILON_FLOAT)) ? 1 : viol;
             };
             w.each([&](int l) {
                 double lo = -1e300, hi = 1e300;
@@ -239,8 +277,13 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 for (int u = 0; u < KU; u++)
                         lp_row(ckey[u].at(l), cnx[u].at(l), cny[u].at(l), cnz[u].at(l), cpx[u].at(l), cpy[u].at(l),
                                cpz[u].at(l), cd[u].at(l), lo, hi, bad, viol);
-                for (int j = 64 * KU + l; j < K; j += 64)  // rows beyond the register cache
-                    lp_row(Rkey[j], Rnx[j], Rny[j], Rnz[j], Rpx[j], Rpy[j], Rpz[j], Rd[j], lo, hi, bad, viol);
+                for (int j0 = 64 * KU; j0 < K; j0 += 64) {  // rows beyond the register cache (uniform trip count)
+                    const int j = j0 + l;
+                    const bool in = j < K;
+                    const int jc = in ? j : K - 1;
+                    const uint32_t kk = Rkey[jc];
+                    lp_row(in ? kk : KEY_SKIP, Rnx[jc], Rny[jc], Rnz[jc], Rpx[jc], Rpy[jc], Rpz[jc], Rd[jc], lo, hi, bad, viol);
+                }
                 llo.at(l) = lo; lhi.at(l) = hi; lbad.at(l) = bad; lviol.at(l) = viol;
             });
             const double lo2 = w.max(llo), hi2 = w.min(lhi);
@@ -265,10 +308,12 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             }
         }
         w.each([&](int l) {
-            if (l < 3 && out_goal && goal_status != DLSCQP_INFEASIBLE) out_goal[l] = goal[l];
-            if (l == 0 && out_goal_status) *out_goal_status = goal_status;
+            // no lane guard: lanes beyond the third repeat lane 2's store, and all lanes store the same status word
+            const int lc = l < 3 ? l : 2;
+            if (out_goal && goal_status != DLSCQP_INFEASIBLE) out_goal[lc] = pick3(goal, lc);
+            if (out_goal_status) *out_goal_status = goal_status;
             // the reference throws before trajOptimization is reached (traj_planner.cpp:491-496)
-            if (l == 0 && goal_status == DLSCQP_INFEASIBLE && do_traj && out_status) *out_status = DLSCQP_INFEASIBLE;
+            if (goal_status == DLSCQP_INFEASIBLE && do_traj && out_status) *out_status = DLSCQP_INFEASIBLE;
         });
         if (goal_status == DLSCQP_INFEASIBLE) return;
     }
@@ -279,12 +324,15 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     double *base = reinterpret_cast<double *>(mem);
     double *Q = base + lay.oQ, *Rp = base + lay.oRp, *Nl = base + lay.oN, *x = base + lay.oX;
     double *blo = base + lay.oBlo, *bhi = base + lay.oBhi;
+    const int odump = lay.oDump;  // 64 doubles, one per lane: base[odump + l]
     unsigned char *cold_flag = mem + lay.oFlag;
     const int ldq = lay.ldq;
     const int rc = dim * f;      // whitened control-point dimension
     const int r = rc + nslk;     // whitened dimension
     const int nxc = dim * P;     // control-point variables
     const int cold_rows = K - Kc;
+    const int qdummy = lay.r_max;  // spare row of Q for the lanes beyond r
+    const int odump_rp = lay.oDump - lay.oRp;  // the dump slots as indices of Rp
 
     // terminal segments, traj_optimizer.cpp:543-551 (float32 point difference)
     int T;
@@ -299,7 +347,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     if (nslk > 0 && !(kp.w_s > 0)) status = DLSCQP_NUMERICAL;
     if (r > 64 * RC || dim != kp.dim || f != kp.f || M != kp.M || n1 != kp.n1) status = DLSCQP_NUMERICAL;  // the launcher picks the instantiation; defensive
     if (status != DLSCQP_OK) {
-        w.each([&](int l) { if (l == 0 && out_status) *out_status = status; });
+        w.each([&](int) { if (out_status) *out_status = status; });
         return;
     }
 
@@ -310,79 +358,102 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     const double *tSIW = kp.tabSIW + (size_t)(T - 1) * kp.n_slots;
 
     // ---- unconstrained minimiser and bound table into LDS -------------------------------------------
+    // (uniform trip counts; a lane past the end computes a clamped element and stores it to the dump slot)
     w.each([&](int l) {
-        for (int j = l; j < nxc; j += 64) {
-            int k = j / P, p = j - k * P;
-            x[j] = tXs[p * 3 + 0] * (double)pick3(pos, k) + tXs[p * 3 + 1] * (double)pick3(vel, k) +
-                   tXs[p * 3 + 2] * (double)pick3(acc, k) + tXg[p] * (double)pick3(goal, k);
+        for (int j0 = 0; j0 < nxc; j0 += 64) {
+            const int j = j0 + l;
+            const bool in = j < nxc;
+            const int jc = in ? j : nxc - 1;
+            const int k = jc / P, p = jc - k * P;
+            const double v = tXs[p * 3 + 0] * (double)pick3(pos, k) + tXs[p * 3 + 1] * (double)pick3(vel, k) +
+                             tXs[p * 3 + 2] * (double)pick3(acc, k) + tXg[p] * (double)pick3(goal, k);
+            base[in ? lay.oX + j : odump + l] = v;
         }
-        for (int s = l; s < nslk; s += 64) x[nxc + s] = 0.0;
-        for (int j = l; j < lay.nflag; j += 64) cold_flag[j] = 0;
+        for (int s0 = 0; s0 < nslk; s0 += 64) {
+            const int s2 = s0 + l;
+            base[s2 < nslk ? lay.oX + nxc + s2 : odump + l] = 0.0;
+        }
+        for (int j0 = 0; j0 < lay.nflag; j0 += 64) {
+            const int j = j0 + l;
+            cold_flag[j < lay.nflag ? j : lay.nflag] = 0;  // [nflag] is the dump byte
+        }
         // per-agent bound table: boxes (world and SFC), velocity, acceleration, comm range, waypoint
-        for (int b = l; b < kp.nb; b += 64) {
-            double lo, hi;
-            if (b < dim * M) {
-                int k = b / M, m = b - k * M;
-                lo = pick3(kp.world_min, k);
-                hi = pick3(kp.world_max, k);
-                if (kp.rsfc_mode && k == 2 && m == 0) { lo = -100; hi = 100; }  // traj_optimizer.cpp:254-258
-                if (kp.use_sfc && sfc) {  // Box::convertToLSCs, collision_constraints.cpp:66-87
-                    double smin = (double)sfc[m * 6 + k], smax = (double)sfc[m * 6 + 3 + k];
-                    if (smin > lo) lo = smin;
-                    if (smax < hi) hi = smax;
-                }
-            } else if (b == dim * M) {
-                hi = max_vel * kp.vel_scale; lo = -hi;
-            } else if (b == dim * M + 1) {
-                hi = max_acc * kp.acc_scale; lo = -hi;
-            } else if (b == dim * M + 2) {
-                hi = 0.5 * kp.comm_range - radius; lo = -hi;  // traj_optimizer.cpp:495-500
-            } else {
-                int k = b - (dim * M + 3);
-                double cw = 0.5 * kp.comm_range - SP_EPSILON_FLOAT;  // traj_optimizer.cpp:507-510
-                lo = (double)pick3(wp, k) - cw; hi = (double)pick3(wp, k) + cw;
+        for (int b0 = 0; b0 < kp.nb; b0 += 64) {
+            const int b = b0 + l;
+            const bool in = b < kp.nb;
+            const int bc = in ? b : 0;
+            // box entry (axis k, segment m)
+            const bool is_box = bc < dim * M;
+            const int bb = is_box ? bc : 0;
+            const int k = bb / M, m = bb - k * M;
+            double blo_box = pick3(kp.world_min, k), bhi_box = pick3(kp.world_max, k);
+            const bool rsfc = kp.rsfc_mode && k == 2 && m == 0;  // traj_optimizer.cpp:254-258
+            blo_box = rsfc ? -100.0 : blo_box;
+            bhi_box = rsfc ? 100.0 : bhi_box;
+            if (kp.use_sfc && sfc) {  // uniform.  Box::convertToLSCs, collision_constraints.cpp:66-87
+                const double smin = (double)sfc[m * 6 + k], smax = (double)sfc[m * 6 + 3 + k];
+                blo_box = smin > blo_box ? smin : blo_box;
+                bhi_box = smax < bhi_box ? smax : bhi_box;
             }
-            blo[b] = lo;
-            bhi[b] = hi;
+            const double hv = max_vel * kp.vel_scale, ha = max_acc * kp.acc_scale;
+            const double hc = 0.5 * kp.comm_range - radius;  // traj_optimizer.cpp:495-500
+            const int kw = bc - (dim * M + 3);
+            const double cw = 0.5 * kp.comm_range - SP_EPSILON_FLOAT;  // traj_optimizer.cpp:507-510
+            const double wpk = (double)pick3(wp, kw < 0 ? 0 : kw);
+            double lo = wpk - cw, hi = wpk + cw;
+            lo = bc == dim * M + 2 ? -hc : lo; hi = bc == dim * M + 2 ? hc : hi;
+            lo = bc == dim * M + 1 ? -ha : lo; hi = bc == dim * M + 1 ? ha : hi;
+            lo = bc == dim * M ? -hv : lo;     hi = bc == dim * M ? hv : hi;
+            lo = is_box ? blo_box : lo;        hi = is_box ? bhi_box : hi;
+            base[in ? lay.oBlo + b : odump + l] = lo;
+            base[in ? lay.oBhi + b : odump + l] = hi;
         }
     });
     // finish the LSC cache: rhs = d + n.p (traj_optimizer.cpp:427-439), drop rows that are not in the model
     RegD ciw[KU], siw[SU];
 #pragma unroll
-    for (int u = 0; u < KU; u++) w.each([&](int l) { ciw[u].at(l) = 0.0; });
-#pragma unroll
-    for (int u = 0; u < SU; u++)
-        w.each([&](int l) {
-            const int s = l + 64 * u;
-            siw[u].at(l) = s < Sc ? tSIW[s] : 0.0;
-        });
-#pragma unroll
-    for (int u = 0; u < KU; u++) {
-        {
+    for (int u = 0; u < SU; u++) {
+        w.each([&](int l) { siw[u].at(l) = 0.0; });
+        if (64 * u < Sc) {  // uniform
             w.each([&](int l) {
-                uint32_t key = ckey[u].at(l);
-                if (key == KEY_SKIP) return;
-                int m = key & 0xFF, i = (key >> 8) & 0xF;
-                float nx = cnx[u].at(l), ny = cny[u].at(l), nz = cnz[u].at(l);
-                if ((m == 0 && i < kp.phi) || f32_norm3(nx, ny, nz) < SP_EPSILON_FLOAT) {  // :417-424
-                    ckey[u].at(l) = KEY_SKIP;
-                    return;
-                }
-                double rhs = cd[u].at(l) + (double)nx * (double)cpx[u].at(l) + (double)ny * (double)cpy[u].at(l);
-                double nsq = (double)nx * (double)nx + (double)ny * (double)ny;
-                if (dim == 3) {
-                    rhs += (double)nz * (double)cpz[u].at(l);
-                    nsq += (double)nz * (double)nz;
-                }
-                cd[u].at(l) = rhs;
-                uint32_t sl = key >> 16;
-                if (sl != 0xFFFFu && (int)sl >= nso) { ckey[u].at(l) = key | 0xFFFF0000u; sl = 0xFFFFu; }  // no such slack variable
-                // pivot scaling 1 / |N' a|  (whitened length of the row normal)
-                double wsq = nsq * tNN[m * n1 + i];
-                if (sl != 0xFFFFu) wsq += kp.sigma[m] * kp.sigma[m];
-                ciw[u].at(l) = wsq > 0 ? 1.0 / sqrt(wsq) : 0.0;
+                const int s = l + 64 * u;
+                const double v = tSIW[s < Sc ? s : Sc - 1];
+                siw[u].at(l) = s < Sc ? v : 0.0;
             });
         }
+    }
+#pragma unroll
+    for (int u = 0; u < KU; u++) {
+        w.each([&](int l) {
+            const uint32_t key = ckey[u].at(l);
+            const bool have = key != KEY_SKIP;
+            const int m = have ? (int)(key & 0xFF) : 0, i = have ? (int)((key >> 8) & 0xF) : 0;
+            const float nx = cnx[u].at(l), ny = cny[u].at(l), nz = cnz[u].at(l);
+            // rows the reference leaves out of the model (:417-424)
+            double nrm = f32_norm3(nx, ny, nz);
+            DQ_KEEP(nrm);
+            const bool in_model = have & !(((m == 0) & (i < kp.phi)) | (nrm < SP_EPSILON_FLOAT));
+            double rhs = cd[u].at(l) + (double)nx * (double)cpx[u].at(l) + (double)ny * (double)cpy[u].at(l);
+            double nsq = (double)nx * (double)nx + (double)ny * (double)ny;
+            const double rhs3 = rhs + (double)nz * (double)cpz[u].at(l), nsq3 = nsq + (double)nz * (double)nz;
+            rhs = dim == 3 ? rhs3 : rhs;
+            nsq = dim == 3 ? nsq3 : nsq;
+            uint32_t sl = key >> 16;
+            const bool no_such_slack = sl != 0xFFFFu && (int)sl >= nso;
+            const uint32_t key2 = no_such_slack ? (key | 0xFFFF0000u) : key;
+            sl = no_such_slack ? 0xFFFFu : sl;
+            // pivot scaling 1 / |N' a|  (whitened length of the row normal)
+            const int mi = m * n1 + i;
+            double wsq = nsq * tNN[mi < P ? mi : 0];
+            double sg = kp.sigma[m < M ? m : 0];
+            DQ_KEEP(sg);
+            wsq = sl != 0xFFFFu ? wsq + sg * sg : wsq;
+            double iw = 1.0 / sqrt(wsq > 0 ? wsq : 1.0);
+            DQ_KEEP(iw);
+            cd[u].at(l) = in_model ? rhs : cd[u].at(l);
+            ckey[u].at(l) = in_model ? key2 : KEY_SKIP;
+            ciw[u].at(l) = (in_model & (wsq > 0)) ? iw : 0.0;
+        });
     }
     w.sync();
     w.stamp(1);  // slot cache, x0, bounds
@@ -406,29 +477,29 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     // unified row codes: [0,K) LSC rows, K + 2 s + side structured slots, K + 2 n_slots + s slack bounds
     const int code_slack0 = K + 2 * n_slots;
 
-    auto set_skip = [&](int code, bool on) {
+    auto set_skip = [&](int code, bool on) {  // code and on are uniform; the owner lane is picked by a select
+        auto upd = [&](RegU &fr, int owner, int u) {
+            w.each([&](int l) {
+                const uint32_t cur = fr.at(l), bit = 1u << u;
+                const uint32_t nv = on ? (cur | bit) : (cur & ~bit);
+                fr.at(l) = l == owner ? nv : cur;
+            });
+        };
         if (code < Kc) {
-            const int owner = code & 63, u = code >> 6;
-            w.each([&](int l) { if (l == owner) fl_lsc.at(l) = on ? (fl_lsc.at(l) | (1u << u)) : (fl_lsc.at(l) & ~(1u << u)); });
+            upd(fl_lsc, code & 63, code >> 6);
         } else if (code < K) {
-            w.each([&](int l) { if (l == 0) cold_flag[code - Kc] = on ? 1 : 0; });
+            w.each([&](int) { cold_flag[code - Kc] = on ? 1 : 0; });  // every lane, same byte, same value
         } else if (code < code_slack0) {
             const int s = (code - K) >> 1, side = (code - K) & 1;
             if (s < Sc) {
-                const int owner = s & 63, u = s >> 6;
-                w.each([&](int l) {
-                    if (l == owner) {
-                        uint32_t &fr = side ? fl_shi.at(l) : fl_slo.at(l);
-                        fr = on ? (fr | (1u << u)) : (fr & ~(1u << u));
-                    }
-                });
+                if (side) upd(fl_shi, s & 63, s >> 6);
+                else upd(fl_slo, s & 63, s >> 6);
             } else {
-                w.each([&](int l) { if (l == 0) cold_flag[cold_rows + 2 * (s - Sc) + side] = on ? 1 : 0; });
+                w.each([&](int) { cold_flag[cold_rows + 2 * (s - Sc) + side] = on ? 1 : 0; });
             }
         } else {
             const int s = code - code_slack0;
-            const int owner = s & 63, u = s >> 6;
-            w.each([&](int l) { if (l == owner) fl_slk.at(l) = on ? (fl_slk.at(l) | (1u << u)) : (fl_slk.at(l) & ~(1u << u)); });
+            upd(fl_slk, s & 63, s >> 6);
         }
         w.sync();
     };
@@ -491,43 +562,82 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 bv = shi > bs ? vhi : bv;
                 bs = shi > bs ? shi : bs;
             }
-            for (int s = l; s < nslk; s += 64) {  // eps <= 0 (traj_optimizer.cpp:276)
-                const double v = x[nxc + s];
-                const double sg = kp.sigma[s % M];
-                const double sc = (v > VIOL_TOL && sg > 0 && !((fl_slk.at(l) >> (s >> 6)) & 1)) ? v / sg : -1.0;
-                if (sc > bs) { bs = sc; bv = v; bc = code_slack0 + s; }
+            for (int s0 = 0; s0 < nslk; s0 += 64) {  // eps <= 0 (traj_optimizer.cpp:276); uniform trip count
+                const int s = s0 + l;
+                const bool in = s < nslk;
+                const int sc2 = in ? s : 0;
+                double v = x[nxc + sc2];
+                double sg = kp.sigma[sc2 % M];
+                DQ_KEEP(v); DQ_KEEP(sg);
+                const bool cand = in & (v > VIOL_TOL) & (sg > 0) & !((fl_slk.at(l) >> (s0 >> 6)) & 1);
+                double qv = v / (sg > 0 ? sg : 1.0);
+                DQ_KEEP(qv);
+                const double sc = cand ? qv : -1.0;
+                bc = sc > bs ? code_slack0 + s : bc;
+                bv = sc > bs ? v : bv;
+                bs = sc > bs ? sc : bs;
             }
             // rows beyond the register cache: straight from HBM (rare: K > 256 or > 640 slots)
-            for (int j = Kc + l; j < K; j += 64) {
-                if (cold_flag[j - Kc]) continue;
-                const uint32_t key = Rkey[j];
+            for (int j0 = Kc; j0 < K; j0 += 64) {
+                const int j = j0 + l;
+                const bool in = j < K;
+                const int jc = in ? j : K - 1;
+                const uint32_t key = Rkey[jc];
                 const int m = key & 0xFF, i = (key >> 8) & 0xF;
-                if (m == 0 && i < kp.phi) continue;
-                const float nx = Rnx[j], ny = Rny[j], nz = Rnz[j];
-                if (f32_norm3(nx, ny, nz) < SP_EPSILON_FLOAT) continue;
-                const int p = m * n1 + i;
+                const float nx = Rnx[jc], ny = Rny[jc], nz = Rnz[jc];
+                int cf0 = cold_flag[jc - Kc];
+                double nrm = f32_norm3(nx, ny, nz);
+                DQ_KEEP(cf0); DQ_KEEP(nrm);
+                const bool in_model = in & (cf0 == 0) & !((m == 0) & (i < kp.phi)) & !(nrm < SP_EPSILON_FLOAT);
+                const int p = in_model ? m * n1 + i : 0;
                 double val = (double)nx * x[p] + (double)ny * x[P + p];
-                double rhs = Rd[j] + (double)nx * (double)Rpx[j] + (double)ny * (double)Rpy[j];
-                if (dim == 3) { val += (double)nz * x[2 * P + p]; rhs += (double)nz * (double)Rpz[j]; }
+                double rhs = Rd[jc] + (double)nx * (double)Rpx[jc] + (double)ny * (double)Rpy[jc];
+                const double val3 = val + (double)nz * x[(dim == 3 ? 2 : 0) * P + p], rhs3 = rhs + (double)nz * (double)Rpz[jc];
+                val = dim == 3 ? val3 : val;
+                rhs = dim == 3 ? rhs3 : rhs;
                 const uint32_t sl = key >> 16;
-                if (sl != 0xFFFFu && (int)sl < nso) val -= x[nxc + (int)sl * M + m];
+                const bool has_slack = in_model & (sl != 0xFFFFu) & ((int)sl < nso);
+                double xs = x[nxc + (has_slack ? (int)sl * M + m : 0)];
+                DQ_KEEP(xs);
+                val = has_slack ? val - xs : val;
                 const double v = rhs - val;
                 double wsq = ((double)nx * (double)nx + (double)ny * (double)ny + (dim == 3 ? (double)nz * (double)nz : 0.0)) * tNN[p];
-                if (sl != 0xFFFFu && (int)sl < nso) wsq += kp.sigma[m] * kp.sigma[m];
-                const double sc = (v > VIOL_TOL && wsq > 0) ? v / sqrt(wsq) : -1.0;
-                if (sc > bs) { bs = sc; bv = v; bc = j; }
+                double sg = kp.sigma[in_model ? m : 0];
+                DQ_KEEP(sg);
+                wsq = has_slack ? wsq + sg * sg : wsq;
+                double qv = v / sqrt(wsq > 0 ? wsq : 1.0);
+                DQ_KEEP(qv);
+                const double sc = (in_model & (v > VIOL_TOL) & (wsq > 0)) ? qv : -1.0;
+                bc = sc > bs ? j : bc;
+                bv = sc > bs ? v : bv;
+                bs = sc > bs ? sc : bs;
             }
-            for (int s = Sc + l; s < n_slots; s += 64) {
-                const Slot sl = slots[s];
+            for (int s0 = Sc; s0 < n_slots; s0 += 64) {
+                const int s = s0 + l;
+                const bool in = s < n_slots;
+                const int sc2 = in ? s : n_slots - 1;
+                const Slot sl = slots[sc2];
                 double val = 0;
-                for (int t = 0; t < 3; t++)
-                    if (sl.idx[t] >= 0) val += (double)sl.coef[t] * x[sl.idx[t]];
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    const bool used = sl.idx[t] >= 0;
+                    double xv = x[used ? sl.idx[t] : 0];
+                    DQ_KEEP(xv);
+                    val = used ? val + (double)sl.coef[t] * xv : val;
+                }
                 const double vlo = blo[sl.bsel] - val, vhi = val - bhi[sl.bsel];
-                const double iw = tSIW[s];
-                const double slo = (vlo > VIOL_TOL && !cold_flag[cold_rows + 2 * (s - Sc)]) ? vlo * iw : -1.0;
-                if (slo > bs) { bs = slo; bv = vlo; bc = K + 2 * s; }
-                const double shi = (vhi > VIOL_TOL && !cold_flag[cold_rows + 2 * (s - Sc) + 1]) ? vhi * iw : -1.0;
-                if (shi > bs) { bs = shi; bv = vhi; bc = K + 2 * s + 1; }
+                const double iw = tSIW[sc2];
+                const int fo = cold_rows + 2 * (sc2 - Sc);
+                int f_lo = cold_flag[fo], f_hi = cold_flag[fo + 1];
+                DQ_KEEP(f_lo); DQ_KEEP(f_hi);
+                const double slo = (in & (vlo > VIOL_TOL) & (f_lo == 0)) ? vlo * iw : -1.0;
+                bc = slo > bs ? K + 2 * s : bc;
+                bv = slo > bs ? vlo : bv;
+                bs = slo > bs ? slo : bs;
+                const double shi = (in & (vhi > VIOL_TOL) & (f_hi == 0)) ? vhi * iw : -1.0;
+                bc = shi > bs ? K + 2 * s + 1 : bc;
+                bv = shi > bs ? vhi : bv;
+                bs = shi > bs ? shi : bs;
             }
             bestv.at(l) = bv;
             bests.at(l) = bs;
@@ -541,14 +651,23 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         const int owner_lane = w.first_lane(is_top);
         const int ip = w.bcast(bestc, owner_lane);
         double viol = w.bcast(bestv, owner_lane);  // = -(a.x - b) of the chosen row
+        DQ_TRACE(1, (double)ip, viol, top, (double)q);
 
         if (!factors_ready) {
             // first violated row: set up the factors (agents that never get here skip all of this)
             w.each([&](int l) {
-                for (int j = l; j < P * f; j += 64) Nl[j] = tN[j];
-                for (int j = l; j < r * ldq; j += 64) {
-                    int i = j / ldq, c = j - i * ldq;
-                    Q[j] = (i == c) ? 1.0 : 0.0;
+                for (int j0 = 0; j0 < P * f; j0 += 64) {
+                    const int j = j0 + l;
+                    const bool in = j < P * f;
+                    const double v = tN[in ? j : P * f - 1];
+                    base[in ? lay.oN + j : odump + l] = v;
+                }
+                // identity, and zeros in the spare row qdummy that lanes beyond r work on
+                const int nq = (lay.r_max + 1) * ldq;
+                for (int j0 = 0; j0 < nq; j0 += 64) {
+                    const int j = j0 + l;
+                    const int i = j / ldq, c = j - i * ldq;
+                    base[j < nq ? lay.oQ + j : odump + l] = ((i == c) & (i < r)) ? 1.0 : 0.0;
                 }
             });
             w.sync();
@@ -634,14 +753,16 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             for (int c = 0; c < RC; c++) {
                 const int e = l + 64 * c;
                 double v = 0;
-                if (e < rc) {
-                    const int k = e / f, j = e - k * f;
+                const bool in_ctrl = e < rc;
+                const int ec = in_ctrl ? e : 0;
+                const int k = ec / f, j = ec - k * f;
 #pragma unroll
-                    for (int t = 0; t < 3; t++)
-                        if (ek[t] == k) v = fma(cf[t], Nl[ep[t] * f + j], v);
-                } else if (e - rc == sidx_row) {
-                    v = -kp.sigma[sidx_row % M];
+                for (int t = 0; t < 3; t++) {  // ep[t] is a valid row of N for unused entries too (0)
+                    const double nv = Nl[ep[t] * f + j];
+                    v = (in_ctrl && ek[t] == k) ? fma(cf[t], nv, v) : v;
                 }
+                const double sgm = -kp.sigma[(sidx_row < 0 ? 0 : sidx_row) % M];
+                v = (!in_ctrl && e - rc == sidx_row) ? sgm : v;
                 na[c].at(l) = v;
             }
         });
@@ -657,24 +778,23 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 for (int c = 0; c < RC; c++) {
                     const int j = l + 64 * c;
                     double a0 = 0.0, a1 = 0.0;
-                    if (j < r) {
+                    const int jc = j < r ? j : 0;  // lanes beyond r read column 0 and drop the sum
 #pragma unroll
-                        for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++) {
-                            if (k < dim && (axes_mask & (1 << k))) {  // uniform
+                    for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++) {
+                        if (k < dim && (axes_mask & (1 << k))) {  // uniform
 #pragma unroll
-                                for (int ii = 0; ii < f; ii += 2) {
-                                    const int i = k * f + ii;
-                                    a0 = fma(Q[i * ldq + j], DQ_BC(na, i), a0);
-                                    if (ii + 1 < f) a1 = fma(Q[(i + 1) * ldq + j], DQ_BC(na, i + 1), a1);
-                                }
+                            for (int ii = 0; ii < f; ii += 2) {
+                                const int i = k * f + ii;
+                                a0 = fma(Q[i * ldq + jc], DQ_BC(na, i), a0);
+                                if (ii + 1 < f) a1 = fma(Q[(i + 1) * ldq + jc], DQ_BC(na, i + 1), a1);
                             }
                         }
-                        if (sidx_row >= 0) {
-                            const int i = rc + sidx_row;
-                            a0 = fma(Q[i * ldq + j], DQ_BC(na, i), a0);
-                        }
                     }
-                    dv[c].at(l) = a0 + a1;
+                    if (sidx_row >= 0) {  // uniform
+                        const int i = rc + sidx_row;
+                        a0 = fma(Q[i * ldq + jc], DQ_BC(na, i), a0);
+                    }
+                    dv[c].at(l) = j < r ? a0 + a1 : 0.0;
                 }
             });
             w.stamp(4);  // d = Q' na
@@ -690,16 +810,14 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 for (int c = 0; c < RC; c++) {
                     const int i = l + 64 * c;
                     double a0 = 0.0, a1 = 0.0;
-                    if (i < r) {
-                        const double *qi = Q + i * ldq;
+                    const double *qi = Q + (i < r ? i : qdummy) * ldq;  // lanes beyond r: the spare row
 #pragma unroll
-                        for (int j = 0; j < rc; j += 2) {
-                            a0 = fma(qi[j], DQ_BC(dz, j), a0);
-                            if (j + 1 < rc) a1 = fma(qi[j + 1], DQ_BC(dz, j + 1), a1);
-                        }
-                        for (int j = rc; j < r; j++) a0 = fma(qi[j], DQ_BC(dz, j), a0);  // slack columns
+                    for (int j = 0; j < rc; j += 2) {
+                        a0 = fma(qi[j], DQ_BC(dz, j), a0);
+                        if (j + 1 < rc) a1 = fma(qi[j + 1], DQ_BC(dz, j + 1), a1);
                     }
-                    zv[c].at(l) = a0 + a1;
+                    for (int j = rc; j < r; j++) a0 = fma(qi[j], DQ_BC(dz, j), a0);  // slack columns
+                    zv[c].at(l) = i < r ? a0 + a1 : 0.0;
                 }
             });
             RegD s_d2, s_all;
@@ -708,11 +826,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 #pragma unroll
                 for (int c = 0; c < RC; c++) {
                     const int j = l + 64 * c;
-                    if (j < r) {
-                        const double t = dv[c].at(l) * dv[c].at(l);
-                        aa += t;
-                        if (j >= q) a2 += t;
-                    }
+                    const double t = dv[c].at(l) * dv[c].at(l);  // dv is zero beyond r
+                    aa += t;
+                    a2 += j >= q ? t : 0.0;
                 }
                 s_d2.at(l) = a2;
                 s_all.at(l) = aa;
@@ -759,10 +875,12 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 #pragma unroll
                     for (int c = 0; c < RC; c++) {
                         const int k = l + 64 * c;
-                        if (k < q && rv[c].at(l) > 0) {
-                            const double t = uu[c].at(l) / rv[c].at(l);
-                            if (t < bt) { bt = t; bk = k; }
-                        }
+                        const double rk = rv[c].at(l);
+                        const bool cand = k < q && rk > 0;
+                        const double t = uu[c].at(l) / (cand ? rk : 1.0);
+                        const bool better = cand && t < bt;
+                        bt = better ? t : bt;
+                        bk = better ? k : bk;
                     }
                     lt1.at(l) = bt;
                     lk.at(l) = bk;
@@ -776,6 +894,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             }
             const bool dependent = !(dd2 > DEP_TOL * dall) || !(dd2 > 0);
             const double t2 = dependent ? 1e300 : viol / dd2;
+            DQ_TRACE(2, dd2, dall, t1, (double)ldrop);
             w.stamp(7);  // ratio test
             if (t1 >= 1e300 && t2 >= 1e300) {
                 // no step possible: infeasible, unless within CPLEX's feasibility tolerance
@@ -791,36 +910,46 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             if (!dependent) {
                 // primal step  x += t N z  (a row of N is read once and used for every axis)
                 w.each([&](int l) {
-                    for (int p = l; p < P; p += 64) {
+                    for (int p0 = 0; p0 < P; p0 += 64) {  // uniform trip count
+                        const int p = p0 + l;
+                        const bool in = p < P;
+                        const int pc = in ? p : P - 1;
                         double sk[3] = {0.0, 0.0, 0.0};
 #pragma unroll
                         for (int c = 0; c < f; c++) {
-                            const double nv = Nl[p * f + c];
+                            const double nv = Nl[pc * f + c];
 #pragma unroll
                             for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++)
                                 if (k < dim) sk[k] = fma(nv, DQ_BC(zv, k * f + c), sk[k]);
                         }
 #pragma unroll
                         for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++)
-                            if (k < dim) x[k * P + p] = fma(t, sk[k], x[k * P + p]);
+                            if (k < dim) {  // uniform
+                                const double xn = fma(t, sk[k], x[k * P + pc]);
+                                base[in ? lay.oX + k * P + p : odump + l] = xn;
+                            }
                     }
                 });
-                w.each([&](int l) {
+                if (nslk > 0) {  // uniform
+                    w.each([&](int l) {
 #pragma unroll
-                    for (int c = 0; c < RC; c++) {
-                        const int e = l + 64 * c;
-                        if (e >= rc && e < r) {
-                            const int s = e - rc;
-                            x[nxc + s] = fma(t * kp.sigma[s % M], zv[c].at(l), x[nxc + s]);
+                        for (int c = 0; c < RC; c++) {
+                            const int e = l + 64 * c;
+                            const bool in = e >= rc && e < r;
+                            const int s = in ? e - rc : 0;
+                            const double xn = fma(t * kp.sigma[s % M], zv[c].at(l), x[nxc + s]);
+                            base[in ? lay.oX + nxc + s : odump + l] = xn;
                         }
-                    }
-                });
+                    });
+                }
                 viol -= t * dd2;
             }
             w.each([&](int l) {
 #pragma unroll
-                for (int c = 0; c < RC; c++)
-                    if (l + 64 * c < q) uu[c].at(l) = fma(-t, rv[c].at(l), uu[c].at(l));
+                for (int c = 0; c < RC; c++) {
+                    const double un = fma(-t, rv[c].at(l), uu[c].at(l));
+                    uu[c].at(l) = l + 64 * c < q ? un : uu[c].at(l);
+                }
             });
             uq += t;
             w.sync();
@@ -846,13 +975,11 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 #pragma unroll
                     for (int c = 0; c < RC; c++) {
                         const int i = l + 64 * c;
-                        if (i < r) {
-                            double *qi = Q + i * ldq;
-                            const double gi = -beta * (zv[c].at(l) - alpha * qi[q]);
+                        double *qi = Q + (i < r ? i : qdummy) * ldq;  // lanes beyond r update the spare row
+                        const double gi = -beta * (zv[c].at(l) - alpha * qi[q]);
 #pragma unroll
-                            for (int j = 0; j < rc; j++) qi[j] = fma(gi, DQ_BC(hv, j), qi[j]);  // Q[i][:] += gi v'
-                            for (int j = rc; j < r; j++) qi[j] = fma(gi, DQ_BC(hv, j), qi[j]);
-                        }
+                        for (int j = 0; j < rc; j++) qi[j] = fma(gi, DQ_BC(hv, j), qi[j]);  // Q[i][:] += gi v'
+                        for (int j = rc; j < r; j++) qi[j] = fma(gi, DQ_BC(hv, j), qi[j]);
                     }
                 });
                 w.each([&](int l) {
@@ -860,12 +987,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     for (int c = 0; c < RC; c++) {
                         const int i = l + 64 * c;
                         // R gains the column (d1; alpha)  <=>  S = R^-1 gains the column (-S d1 / alpha; 1 / alpha)
-                        if (i < q) DQ_RP(i, q) = -rv[c].at(l) * inv_alpha;
-                        else if (i == q) {
-                            DQ_RP(q, q) = inv_alpha;
-                            uu[c].at(l) = uq;
-                            act[c].at(l) = ip;
-                        }
+                        const double sv = i < q ? -rv[c].at(l) * inv_alpha : inv_alpha;
+                        Rp[i <= q ? q * (q + 1) / 2 + i : odump_rp + l] = sv;
+                        uu[c].at(l) = i == q ? uq : uu[c].at(l);
+                        act[c].at(l) = i == q ? ip : act[c].at(l);
                     }
                 });
                 set_skip(ip, true);
@@ -885,7 +1010,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 #pragma unroll
                     for (int c = 0; c < RC; c++) {
                         const int k = l + 64 * c;
-                        const double v = (k >= lcol && k < q) ? DQ_RP(lcol, k) : 0.0;
+                        const bool in = k >= lcol && k < q;
+                        const double sv = DQ_RP(lcol, in ? k : lcol);
+                        const double v = in ? sv : 0.0;
                         srow[c].at(l) = v;
                         pre[c].at(l) = v * v;
                     }
@@ -902,7 +1029,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                             // lane k = t+1 holds the rotation of step t: (a, b) = (|s_lcol..s_t|, s_{t+1}) -> (0, |..|)
                             const int k = l + 64 * c;
                             const double sig = sqrt(pre[c].at(l));
-                            const double a = k == lcol + 1 ? s_first : (k > lcol ? sqrt(pprev[c].at(l)) : 0.0);
+                            double sp = sqrt(pprev[c].at(l));  // prefix sums of squares: never negative
+                            DQ_KEEP(sp);
+                            double a = k > lcol ? sp : 0.0;
+                            a = k == lcol + 1 ? s_first : a;
                             const bool ok = k > lcol && k < q && sig > 0;
                             gc[c].at(l) = ok ? srow[c].at(l) / sig : 1.0;
                             gs[c].at(l) = ok ? a / sig : 0.0;
@@ -914,8 +1044,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 #pragma unroll
                     for (int c = 0; c < RC; c++) {
                         const int i = l + 64 * c;
-                        yS[c].at(l) = i <= lcol ? DQ_RP(i, lcol) : 0.0;
-                        yQ[c].at(l) = i < r ? Q[i * ldq + lcol] : 0.0;
+                        const double s0 = DQ_RP(i <= lcol ? i : 0, lcol), q0 = Q[(i < r ? i : qdummy) * ldq + lcol];
+                        yS[c].at(l) = i <= lcol ? s0 : 0.0;
+                        yQ[c].at(l) = q0;
                     }
                 });
                 for (int t = lcol; t < q - 1; t++) {
@@ -925,17 +1056,16 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                         for (int c = 0; c < RC; c++) {
                             const int i = l + 64 * c;
                             // S: old column t+1 has rows 0..t+1; row lcol is deleted, rows below it move up
-                            const double cS = i <= t + 1 ? DQ_RP(i, t + 1) : 0.0;
+                            const double cS0 = DQ_RP(i <= t + 1 ? i : 0, t + 1);
+                            const double cS = i <= t + 1 ? cS0 : 0.0;
                             const double oS = cs * yS[c].at(l) - sn * cS;
                             yS[c].at(l) = sn * yS[c].at(l) + cs * cS;
                             const int inew = i < lcol ? i : i - 1;
-                            if (i != lcol && inew <= t) DQ_RP(inew, t) = oS;
-                            if (i < r) {
-                                double *qi = Q + i * ldq;
-                                const double cQ = qi[t + 1];
-                                qi[t] = cs * yQ[c].at(l) - sn * cQ;
-                                yQ[c].at(l) = sn * yQ[c].at(l) + cs * cQ;
-                            }
+                            Rp[((i != lcol) & (inew <= t)) ? t * (t + 1) / 2 + inew : odump_rp + l] = oS;
+                            double *qi = Q + (i < r ? i : qdummy) * ldq;
+                            const double cQ = qi[t + 1];
+                            qi[t] = cs * yQ[c].at(l) - sn * cQ;
+                            yQ[c].at(l) = sn * yQ[c].at(l) + cs * cQ;
                         }
                     });
                     w.sync();
@@ -944,7 +1074,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 #pragma unroll
                     for (int c = 0; c < RC; c++) {
                         const int i = l + 64 * c;
-                        if (i < r) Q[i * ldq + q - 1] = yQ[c].at(l);
+                        Q[(i < r ? i : qdummy) * ldq + q - 1] = yQ[c].at(l);
                     }
                 });
                 w.sync();
@@ -961,7 +1091,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 #pragma unroll
                         for (int c = 0; c < RC; c++) {
                             const int k = l + 64 * c;
-                            if (k >= lcol && k < q - 1) { uu[c].at(l) = nu[c].at(l); act[c].at(l) = nact[c].at(l); }
+                            const bool mv = k >= lcol && k < q - 1;
+                            uu[c].at(l) = mv ? nu[c].at(l) : uu[c].at(l);
+                            act[c].at(l) = mv ? nact[c].at(l) : act[c].at(l);
                         }
                     });
                 }
@@ -975,71 +1107,93 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     }
 
     // ================================ read-out ==================================================
-    w.each([&](int l) {
-        if (l == 0) {
-            if (out_status) *out_status = status;
-            if (out_iters) {
-                out_iters[0] = iters;
-                out_iters[1] = n_add;
-                out_iters[2] = n_drop;
-                out_iters[3] = q;
-            }
+    // Verdict and counters: every lane stores the same words (no lane guard).
+    w.each([&](int) {
+        if (out_status) *out_status = status;
+        if (out_iters) {
+            out_iters[0] = iters;
+            out_iters[1] = n_add;
+            out_iters[2] = n_drop;
+            out_iters[3] = q;
         }
     });
     if (status != DLSCQP_OK) return;
-    RegD cj, cs2;
-    w.each([&](int l) {
-        // traj_optimizer.cpp:69-83: point3d(float) control points, z = world_z_2d in 2-D
-        if (out_ctrl)
-            for (int j = l; j < M * n1 * 3; j += 64) {
-                int p = j / 3, k = j - p * 3;
-                out_ctrl[j] = k < dim ? (float)x[k * P + p] : (float)kp.z_2d;
-            }
-        if (out_x)
-            for (int j = l; j < nxc + nslk; j += 64) out_x[j] = x[j];
-        // traj_optimizer.cpp:85-106
-        if (out_slack_cost)
-            for (int s = l; s < max_slack_obs; s += 64) {
-                double sc = 0;
-                if (s < nso)
-                    for (int m = 0; m < M; m++) sc += fabs(x[nxc + s * M + m]);
-                out_slack_cost[s] = sc;
-            }
-        // cplex.getObjValue(), traj_optimizer.cpp:109, objective at :286-331
-        double a1 = 0, a2 = 0;
-        if (out_cost) {
-            for (int sgm = l; sgm < dim * M; sgm += 64) {  // one Bernstein segment (axis k, segment m) per lane
-                const int k = sgm / M, m = sgm - k * M;
+    // cplex.getObjValue(), traj_optimizer.cpp:109, objective at :286-331 -- before the guarded stores below, so
+    // that nothing computed later is live across them
+    if (out_cost) {
+        RegD cj, cs2;
+        w.each([&](int l) {
+            double a1 = 0, a2 = 0;
+            for (int g0 = 0; g0 < dim * M; g0 += 64) {  // one Bernstein segment (axis k, segment m) per lane
+                const int sgm = g0 + l;
+                const bool in = sgm < dim * M;
+                const int sc = in ? sgm : 0;
+                const int k = sc / M, m = sc - k * M;
                 const double *seg = x + k * P + m * n1;
                 double c6[n1];
 #pragma unroll
                 for (int c = 0; c < n1; c++) c6[c] = seg[c];
+                double e1 = 0;
 #pragma unroll
                 for (int i = 0; i < n1; i++) {
                     double t = 0;
 #pragma unroll
                     for (int c = 0; c < n1; c++) t = fma(kp.Qb[i * n1 + c], c6[c], t);
-                    a1 = fma(c6[i], t, a1);
+                    e1 = fma(c6[i], t, e1);
                 }
-                if (m >= M - T) {
-                    const double e = c6[n] - (double)pick3(goal, k);
-                    a1 = fma(kp.w_t * e, e, a1);
-                }
+                const double e = c6[n] - (double)pick3(goal, k);
+                const double e1t = fma(kp.w_t * e, e, e1);
+                e1 = m >= M - T ? e1t : e1;
+                a1 += in ? e1 : 0.0;
             }
-            for (int s = l; s < nslk; s += 64) {
-                int m = s % M;
-                double e = x[nxc + s];
-                a2 += kp.w_s * ((double)(M - m) / M) * e * e;
+            for (int s0 = 0; s0 < nslk; s0 += 64) {
+                const int s = s0 + l;
+                const bool in = s < nslk;
+                const int sc = in ? s : 0;
+                const int m = sc % M;
+                const double e = x[nxc + sc];
+                double wv = kp.w_s * ((double)(M - m) / M) * e * e;
+                DQ_KEEP(wv);
+                a2 += in ? wv : 0.0;
             }
-        }
-        cj.at(l) = a1;
-        cs2.at(l) = a2;
-    });
-    if (out_cost) {
+            cj.at(l) = a1;
+            cs2.at(l) = a2;
+        });
         double t1c, t2c;
         w.sum2(cj, cs2, t1c, t2c);
-        w.each([&](int l) { if (l == 0) *out_cost = t1c + t2c; });
+        w.each([&](int) { *out_cost = t1c + t2c; });
     }
+    // Per-lane results: the only lane-guarded instructions of the kernel are these final global stores.
+    w.each([&](int l) {
+        // traj_optimizer.cpp:69-83: point3d(float) control points, z = world_z_2d in 2-D
+        if (out_ctrl)
+            for (int j0 = 0; j0 < M * n1 * 3; j0 += 64) {
+                const int j = j0 + l;
+                const bool in = j < M * n1 * 3;
+                const int jc = in ? j : 0;
+                const int p = jc / 3, k = jc - p * 3;
+                const double xv = x[(k < dim ? k : 0) * P + p];
+                const float v = k < dim ? (float)xv : (float)kp.z_2d;
+                if (in) out_ctrl[j] = v;
+            }
+        if (out_x)
+            for (int j0 = 0; j0 < nxc + nslk; j0 += 64) {
+                const int j = j0 + l;
+                const bool in = j < nxc + nslk;
+                const double v = x[in ? j : 0];
+                if (in) out_x[j] = v;
+            }
+        // traj_optimizer.cpp:85-106
+        if (out_slack_cost)
+            for (int s0 = 0; s0 < max_slack_obs; s0 += 64) {
+                const int s = s0 + l;
+                const bool in = s < max_slack_obs;
+                const bool live = in & (s < nso);
+                double sc = 0;
+                for (int m = 0; m < M; m++) sc += fabs(x[nxc + (live ? s * M + m : 0)]);
+                if (in) out_slack_cost[s] = live ? sc : 0.0;
+            }
+    });
     w.stamp(11);  // read-out
 }
 

@@ -14,6 +14,7 @@
 #include "qp_tables.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace dlscqp {
@@ -355,6 +356,7 @@ bool build_tables(const dlscqp_config &cfg, int dim, int M, int n, int phi, doub
         }
     }
     kp.max_iter = 0;  // 0: 20 (r + 8) + 200, chosen per agent in plan_agent
+    if (const char *dbg = std::getenv("DLSCQP_DEBUG_MAX_ITER")) kp.max_iter = std::atoi(dbg);  // debugging aid
     return true;
 }
 

@@ -212,9 +212,11 @@ class DeviceBatch:
         self.order = self.torch.from_numpy(order).to(self.device)
         self.c.agent_order = self.order.data_ptr()
 
-    def launch(self, do_goal=True, do_traj=True, stream=None):
-        """Asynchronous launch on `stream` (default: torch's current stream)."""
+    def launch(self, do_goal=True, do_traj=True, stream=None, offset=0, count=0):
+        """Asynchronous launch on `stream` (default: torch's current stream); `offset`/`count` restrict it to a
+        range of launch slots (count = 0: the whole batch)."""
         self.c.do_goal, self.c.do_traj = int(do_goal), int(do_traj)
+        self.c.launch_offset, self.c.launch_count = int(offset), int(count)
         s = self.torch.cuda.current_stream(self.device) if stream is None else stream
         rc = self.opt.lib.dlscqp_plan_batch_device(self.opt.handle, C.byref(self.c), C.c_void_p(s.cuda_stream))
         self.opt._check(rc, "dlscqp_plan_batch_device")

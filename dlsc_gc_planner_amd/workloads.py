@@ -294,3 +294,17 @@ def generate(cfg, solver, n_swarms=1, swarm_size=64, seed=2000, steps=6, infeasi
         out["rows"] = np.ascontiguousarray(rows.reshape(-1))
     out["infeasible_mask"] = bad
     return out
+
+
+def permute_batch(agents, row_offsets, rows, perm):
+    """The same batch with agent `perm[s]` stored at index `s` (agent records and their CSR row blocks).
+    Planners that keep their local agents sorted by expected cost (previous step's iteration count) get the
+    most-expensive-first launch order without an indirection, and contiguous output ranges per cost class."""
+    perm = np.asarray(perm, dtype=np.int64)
+    ro = np.asarray(row_offsets, dtype=np.int64)
+    cnt = (ro[1:] - ro[:-1])[perm]
+    new_ro = np.zeros(len(perm) + 1, dtype=np.asarray(row_offsets).dtype)
+    np.cumsum(cnt, out=new_ro[1:])
+    # gather index of every row: start of its source block + position inside the block
+    src = np.repeat(ro[:-1][perm], cnt) + (np.arange(int(cnt.sum())) - np.repeat(new_ro[:-1].astype(np.int64), cnt))
+    return agents[perm].copy(), new_ro, rows[src].copy()

@@ -173,6 +173,10 @@ typedef struct dlscqp_device_batch {
     int32_t do_goal;                /* 1: run the goal LP first and use its goal in the QP       */
     int32_t do_traj;                /* 1: run the trajectory QP                                  */
     int32_t max_rows_per_agent;     /* max over agents of row_offsets[a+1]-row_offsets[a]        */
+    int32_t launch_offset;          /* plan only launch slots [launch_offset, launch_offset+launch_count); */
+    int32_t launch_count;           /* 0 = all n_agents.  Lets a caller split one step into chunks on separate
+                                       streams (e.g. to overlap the all-gather of a finished chunk with the
+                                       stragglers of another).  All arrays keep their full-batch indexing.   */
     int32_t reserved_;
     const dlscqp_agent *agents;     /* [n_agents]                                               */
     const int32_t *row_offsets;     /* [n_agents+1]                                             */

@@ -6,6 +6,7 @@
 // tables against the oracle.  The product library never loads, links or falls back to this.
 // EMUL_REVERSE=1 runs every lane loop backwards: results must not change (no cross-lane hazard
 // inside a lane loop).
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -18,11 +19,15 @@
 
 namespace {
 
+std::vector<double> *g_trace = nullptr;
+std::vector<unsigned char> g_last_lds;  // debug: LDS image of the last agent solved  // -DDLSCQP_TRACE builds: records of the agent being solved
+
 struct WaveCpu {
     bool reverse;
     template <class T>
     struct Reg {
         T v[64];
+        Reg() { std::memset(v, 0xCD, sizeof v); }  // poison: a lane value nobody wrote must not be used
         T &at(int l) { return v[l]; }
         const T &at(int l) const { return v[l]; }
     };
@@ -35,6 +40,9 @@ struct WaveCpu {
     }
     void sync() const {}
     void stamp(int) const {}
+    void trace(int tag, double a, double b, double c, double d) const {
+        if (g_trace) { g_trace->push_back(tag); g_trace->push_back(a); g_trace->push_back(b); g_trace->push_back(c); g_trace->push_back(d); }
+    }
     template <class T>
     T bcast(const Reg<T> &r, int lane) const { return r.v[lane]; }
     double max(const Reg<double> &r) const {
@@ -140,11 +148,28 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
                    out_cost ? out_cost + a : nullptr,
                    out_slack_cost ? out_slack_cost + (size_t)a * max_slack_obs : nullptr,
                    out_status ? out_status + a : nullptr, out_iters ? out_iters + (size_t)a * 4 : nullptr);
+        g_last_lds = mem;
     }
     return 0;
 }
 
 // Host tables for inspection by the tests: returns f (free dofs per axis), fills sizes.
+// debug: trace of ONE agent (the last of the last emul_plan_batch call made with tracing on)
+extern "C" int emul_trace(int enable, double *out, int cap) {
+    static std::vector<double> buf;
+    if (enable == 1) { buf.clear(); g_trace = &buf; return 0; }
+    if (enable == 0) { g_trace = nullptr; return 0; }
+    int n = (int)std::min<size_t>(buf.size(), (size_t)cap);
+    for (int i = 0; i < n; i++) out[i] = buf[i];
+    return n;
+}
+
+extern "C" int emul_last_lds(unsigned char *out, int cap) {
+    int n = (int)std::min<size_t>(g_last_lds.size(), (size_t)cap);
+    std::memcpy(out, g_last_lds.data(), n);
+    return n;
+}
+
 extern "C" int emul_table_info(const dlscqp_config *cfg, int *f, int *n_slots, int *nb, int *lds_bytes,
                                int max_slack_obs, int kmax) {
     using namespace dlscqp;

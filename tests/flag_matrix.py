@@ -1,0 +1,81 @@
+"""TEST INFRASTRUCTURE (manual, needs a GPU and hipcc on the box): rebuild the solver library under a list of
+compiler configurations that perturb scheduling / register allocation and check every build against the
+golden vectors.  A kernel whose results depend on such flags has a latent codegen problem (this is how the
+lane-divergence rule of gi_core.hpp was found and verified: before it about half of these builds gave wrong
+verdicts for the two-register generic instantiation, after it none).
+
+    python tests/flag_matrix.py            # only the generic two-register instantiation (4 s per build)
+    python tests/flag_matrix.py --full     # all instantiations, checks every golden batch (30 s per build)
+"""
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "dlsc_gc_planner_amd", "csrc")
+FLAGS = ["", "-O2", "-O1", "-fno-unroll-loops",
+         "-mllvm -amdgpu-waitcnt-forcezero=1", "-mllvm -amdgpu-dpp-combine=false", "-mllvm -enable-misched=false",
+         "-mllvm -enable-post-misched=false", "-mllvm -amdgpu-load-store-vectorizer=false",
+         "-mllvm -amdgpu-scalarize-global-loads=false", "-mllvm -amdgpu-sdwa-peephole=false",
+         "-mllvm -amdgpu-opt-exec-mask-pre-ra=false", "-mllvm -disable-machine-licm", "-mllvm -disable-machine-sink",
+         "-mllvm -disable-machine-cse", "-mllvm -disable-peephole", "-mllvm -disable-branch-fold",
+         "-mllvm -vgpr-regalloc=fast", "-mllvm -vgpr-regalloc=basic", "-mllvm -sgpr-regalloc=basic",
+         "-mllvm -amdgpu-enable-rewrite-partial-reg-uses=false", "-mllvm -amdgpu-use-aa-in-codegen=false",
+         "-mllvm -amdgpu-opt-vgpr-liverange=false", "-mllvm -split-spill-mode=size", "-mllvm -split-spill-mode=speed",
+         "-mllvm -greedy-reverse-local-assignment", "-mllvm -join-liveintervals=false"]
+
+CHECK = r'''
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(root)r + "/tests")
+import numpy as np, fixtures
+from dlsc_gc_planner_amd import abi
+from dlsc_gc_planner_amd.planner import BatchTrajOptimizer
+names = %(names)r
+out = []
+for name in names:
+    cfg, b, ans = fixtures.load(name)
+    opt = BatchTrajOptimizer(cfg)
+    db = opt.make_device_batch(b["agents"], b["row_offsets"], b["rows"], b["sfc"], b["max_slack_obs"], want_f64=True, want_iters=True)
+    db.launch()
+    got = db.results()
+    reached = ans["qp_status"] >= 0
+    bad = int((reached & ((got["status"] != abi.OK) != (ans["qp_status"] != abi.OK))).sum())
+    ok = reached & (ans["qp_status"] == abi.OK) & (got["status"] == abi.OK)
+    err = float(np.abs(got["x"][ok] - ans["x"][ok]).max()) if ok.any() else 0.0
+    out.append("%%s:%%d bad,%%.0e" %% (name.split("_")[0], bad, err))
+    opt.close()
+print("RESULT", " ".join(out))
+'''
+
+
+def main():
+    full = "--full" in sys.argv
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import fixtures
+    names = list(fixtures.NAMES) if full else ["forest3d_M10_dyn", "long3d_M12_comm"]
+    n_bad = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for i, flags in enumerate(FLAGS):
+            so = os.path.join(tmp, "v%d.so" % i)
+            cmd = "hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -ffp-contract=off %s %s -o %s dlscqp.hip qp_tables.cpp" % (
+                "" if full else "-DDLSCQP_ONLY_G2", flags, so)
+            t0 = time.time()
+            p = subprocess.run(cmd, shell=True, cwd=CSRC, capture_output=True, text=True)
+            if p.returncode != 0:
+                print("[%2d] %-60s compile failed" % (i, flags))
+                continue
+            q = subprocess.run([sys.executable, "-c", CHECK % dict(root=ROOT, names=names)],
+                               env=dict(os.environ, DLSCQP_LIB=so), capture_output=True, text=True)
+            r = [l for l in q.stdout.splitlines() if l.startswith("RESULT")]
+            line = r[0] if r else "RUN FAILED " + (q.stderr or "")[-300:]
+            wrong = (not r) or any(not tok.split(":")[1].startswith("0 bad") for tok in line.split()[1:])
+            n_bad += wrong
+            print("[%2d] %-60s %s %s (%.0f s)" % (i, flags or "(default)", "WRONG" if wrong else "ok   ", line, time.time() - t0), flush=True)
+    print("%d of %d configurations wrong" % (n_bad, len(FLAGS)))
+    return 1 if n_bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

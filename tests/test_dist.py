@@ -68,3 +68,17 @@ def test_shard_ranges_cover_all_agents():
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[k][1] == r[k + 1][0] for k in range(w - 1))
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+def test_permute_batch_moves_agents_with_their_rows():
+    import fixtures
+    from dlsc_gc_planner_amd import workloads
+    cfg, b, _ = fixtures.load("s64")
+    ro = b["row_offsets"]
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(len(b["agents"]))
+    pa, pro, prows = workloads.permute_batch(b["agents"], ro, b["rows"], perm)
+    assert pro[0] == 0 and pro[-1] == ro[-1] and pro.dtype == ro.dtype
+    for s, a in enumerate(perm):
+        assert pa[s].tobytes() == b["agents"][a].tobytes()
+        assert prows[pro[s]:pro[s + 1]].tobytes() == b["rows"][ro[a]:ro[a + 1]].tobytes()

@@ -1,0 +1,23 @@
+"""CPU tier (cross-compile only): the solver kernels contain no lane-divergent region except the guards of the
+final per-lane global stores.  See "NO DIVERGENCE" in dlsc_gc_planner_amd/csrc/gi_core.hpp for why this is a
+correctness rule of this code base and tests/flag_matrix.py for the GPU-side evidence."""
+import shutil
+
+import pytest
+
+import divergence_check
+
+ALLOWED = ("if (in) out_ctrl[j] = v;", "if (in) out_x[j] = v;", "if (in) out_slack_cost[s] =")
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
+def test_only_the_final_stores_are_lane_guarded():
+    res = divergence_check.regions()
+    assert len(res) == 6, sorted(res)  # every instantiation of dlscqp_plan_kernel
+    offenders = []
+    for kernel, counts in res.items():
+        for (f, line), n in counts.items():
+            src = divergence_check.source_line(f, line) if f == "gi_core.hpp" else "?"
+            if not src.startswith(ALLOWED):
+                offenders.append((kernel[-40:], f, line, n, src[:80]))
+    assert not offenders, offenders
