@@ -211,8 +211,11 @@ struct KernelArgs {
     unsigned long long *out_stamps;  // [n_agents][12], diagnostic build only
 };
 
-template <int RC, int DIMS, int FS, int MS, int KU, int SU>
-__global__ __launch_bounds__(64, 2) void dlscqp_plan_kernel(KParams kp, MemLayout lay, KernelArgs a) {
+#ifndef DQ_KERNEL_ATTR
+#define DQ_KERNEL_ATTR __launch_bounds__(64, 2)
+#endif
+template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK>
+__global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, KernelArgs a) {
     extern __shared__ __align__(16) unsigned char smem[];
     if ((int)blockIdx.x >= a.n_slots_launch) return;
     const int slot = a.slot0 + (int)blockIdx.x;
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(64, 2) void dlscqp_plan_kernel(KParams kp, MemLayou
     const int rb = a.row_offsets[ag], re = a.row_offsets[ag + 1];
     const int M = kp.M, n1 = kp.n1;
     const size_t xs = (size_t)kp.dim * M * n1 + (size_t)M * a.max_slack_obs;
-    plan_agent<RC, DIMS, FS, MS, KU, SU>(w, kp, lay, smem, a.agents + ag, a.rows, rb, re - rb,
+    plan_agent<RC, DIMS, FS, MS, KU, SU, SLK>(w, kp, lay, smem, a.agents + ag, a.rows, rb, re - rb,
                a.sfc ? a.sfc + (size_t)ag * M * 6 : nullptr, a.max_slack_obs, a.do_goal, a.do_traj,
                a.out_goal ? a.out_goal + (size_t)ag * 3 : nullptr,
                a.out_goal_status ? a.out_goal_status + ag : nullptr,
@@ -286,27 +289,21 @@ struct KernelChoice {
     int id, KU, SU;
 };
 
-// Kernel instantiation: static shapes for the reference's launch files (3-D M=5: f=13; 2-D / 3-D M=10:
-// f=28) with register caches sized to the row counts, runtime-shape kernels for everything else.
+// Kernel instantiation for a batch: the shared table in gi_core.hpp (DQ_INSTANCES / select_instance).
 KernelChoice select_kernel(const KParams &kp, int max_slack_obs, int kmax) {
-    const int r_max = kp.dim * kp.f + kp.M * max_slack_obs;
     static const bool force_generic = std::getenv("DLSCQP_FORCE_GENERIC") != nullptr;  // debugging aid
 #ifdef DLSCQP_ONLY_G2  // debugging aid: compile only the generic two-register instantiation
-    return {dlscqp_plan_kernel<2, 0, 0, 0, 4, 10>, 5, 4, 10};
+    (void)force_generic;
+    return {dlscqp_plan_kernel<2, 0, 0, 0, 4, 10, -1>, 7, 4, 10};
 #else
-    if (force_generic) {
-        if (r_max <= 64) return {dlscqp_plan_kernel<1, 0, 0, 0, 4, 10>, 4, 4, 10};
-        if (r_max <= 128) return {dlscqp_plan_kernel<2, 0, 0, 0, 4, 10>, 5, 4, 10};
-        return {nullptr, -1, 0, 0};
+    const InstanceChoice ic = select_instance(kp, max_slack_obs, kmax, force_generic);
+    switch (ic.id) {
+#define DQ_CASE(ID, RC, DIMS, FS, MS, KU, SU, SLK) \
+    case ID: return {dlscqp_plan_kernel<RC, DIMS, FS, MS, KU, SU, SLK>, ID, KU, SU};
+        DQ_INSTANCES(DQ_CASE)
+#undef DQ_CASE
+    default: return {nullptr, -1, 0, 0};
     }
-    if (kp.dim == 3 && kp.f == 13 && kp.M == 5 && r_max <= 64 && kmax <= 128 && kp.n_slots <= 256)
-        return {dlscqp_plan_kernel<1, 3, 13, 5, 2, 4>, 0, 2, 4};
-    if (kp.dim == 3 && kp.f == 13 && kp.M == 5 && r_max <= 64) return {dlscqp_plan_kernel<1, 3, 13, 5, 4, 5>, 1, 4, 5};
-    if (kp.dim == 2 && kp.f == 28 && kp.M == 10 && r_max <= 64) return {dlscqp_plan_kernel<1, 2, 28, 10, 4, 7>, 2, 4, 7};
-    if (kp.dim == 3 && kp.f == 28 && kp.M == 10 && r_max <= 128) return {dlscqp_plan_kernel<2, 3, 28, 10, 4, 10>, 3, 4, 10};
-    if (r_max <= 64) return {dlscqp_plan_kernel<1, 0, 0, 0, 4, 10>, 4, 4, 10};
-    if (r_max <= 128) return {dlscqp_plan_kernel<2, 0, 0, 0, 4, 10>, 5, 4, 10};
-    return {nullptr, -1, 0, 0};
 #endif
 }
 
@@ -338,7 +335,7 @@ struct dlscqp_ctx {
     double *d_tabN = nullptr, *d_tabX0s = nullptr, *d_tabX0g = nullptr, *d_tabNN = nullptr, *d_tabSIW = nullptr;
     Slot *d_slots = nullptr;
     hipStream_t stream = nullptr;
-    int max_dyn_lds[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int max_dyn_lds[DQ_N_INSTANCES] = {};
     // staging for the host-buffer entry points
     unsigned char *h_stage = nullptr, *d_stage = nullptr;
     size_t stage_cap = 0;

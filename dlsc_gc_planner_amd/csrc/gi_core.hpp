@@ -72,12 +72,48 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
     L.oRp = o; o += L.r_max * (L.r_max + 1) / 2;
     L.oN = o; o += kp.P * kp.f;
     L.oX = o; o += L.nx_max;
+    L.oDump = o; o += 64;
     L.oBlo = o; o += kp.nb;
     L.oBhi = o; o += kp.nb;
-    L.oDump = o; o += 64;
     L.oFlag = o * 8;
     L.bytes = (L.oFlag + L.nflag + 1 + 15) & ~15;  // + one flag byte as the dump of the flag array
     return L;
+}
+
+// Instantiations of plan_agent: id, RC, DIMS, FS, MS, KU, SU, SLK.  Static shapes for the reference's launch
+// files (3-D M=5: f=13; 2-D / 3-D M=10: f=28) with register caches sized to the row counts, with and without
+// slack (dynamic) obstacles; runtime-shape instantiations for everything else.  One list for the HIP launcher
+// and for the lane-serial test build.
+#define DQ_INSTANCES(X)          \
+    X(0, 1, 3, 13, 5, 2, 4, 0)   \
+    X(1, 1, 3, 13, 5, 4, 5, 0)   \
+    X(2, 1, 3, 13, 5, 4, 5, -1)  \
+    X(3, 1, 2, 28, 10, 4, 7, 0)  \
+    X(4, 2, 3, 28, 10, 4, 10, 0) \
+    X(5, 2, 3, 28, 10, 4, 10, -1) \
+    X(6, 1, 0, 0, 0, 4, 10, -1)  \
+    X(7, 2, 0, 0, 0, 4, 10, -1)
+constexpr int DQ_N_INSTANCES = 8;
+
+struct InstanceChoice {
+    int id, KU, SU;  // id < 0: unsupported (reduced dimension above 128)
+};
+
+// Which instantiation plans a batch (r_max = dim f + M max_slack_obs, kmax = most LSC rows of one agent).
+inline InstanceChoice select_instance(const KParams &kp, int max_slack_obs, int kmax, bool force_generic) {
+    const int r_max = kp.dim * kp.f + kp.M * max_slack_obs;
+    const bool ns = max_slack_obs == 0;
+    if (!force_generic) {
+        if (kp.dim == 3 && kp.f == 13 && kp.M == 5 && r_max <= 64) {
+            if (ns && kmax <= 128 && kp.n_slots <= 256) return {0, 2, 4};
+            return {ns ? 1 : 2, 4, 5};
+        }
+        if (kp.dim == 2 && kp.f == 28 && kp.M == 10 && ns) return {3, 4, 7};
+        if (kp.dim == 3 && kp.f == 28 && kp.M == 10 && r_max <= 128) return {ns ? 4 : 5, 4, 10};
+    }
+    if (r_max <= 64) return {6, 4, 10};
+    if (r_max <= 128) return {7, 4, 10};
+    return {-1, 0, 0};
 }
 
 // octomath::Vector3 semantics: float32 products and sum, sqrt in double
@@ -87,6 +123,13 @@ DQ_FN double f32_norm3(float a, float b, float c) {
 }
 
 constexpr uint32_t KEY_SKIP = 0xFFFFFFFFu;  // cached LSC row that is not part of the model
+
+// cond ? a : b on indices with mask arithmetic: the index of a store that a lane may have to send to the dump slot
+// (written as ?: the compiler turned some of these into EXEC-masked branches around the store)
+DQ_FN int blend_idx(bool cond, int a, int b) {
+    const int m = -(int)cond;
+    return b ^ ((a ^ b) & m);
+}
 
 // v[k] for a per-lane k without dynamic indexing of a register array (which would go through scratch memory)
 template <class T>
@@ -123,7 +166,10 @@ DQ_FN T pick3(const T *v, int k) {
 #define DQ_TRACE(tag, a, b, c, d)
 #endif
 
-template <int RC, int DIMS, int FS, int MS, int KU, int SU, class W>
+// SLK: compile-time number of slack obstacles of the batch (0), or -1 = read it from the arguments.  With
+// DIMS > 0 and SLK = 0 the whole LDS layout up to the bound table (ldq, offsets of S, N, x, dump) and the whitened
+// dimension r are constants: LDS addresses become "lane part + immediate", no address arithmetic in the loops.
+template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK, class W>
 DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsigned char *mem,
                       const dlscqp_agent *agp, const RowsView &rows, int row_begin, int K,
                       const float *sfc, int max_slack_obs, int do_goal, int do_traj,
@@ -151,9 +197,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     }
     const double max_vel = agp->max_vel, max_acc = agp->max_acc, radius = agp->radius;
     const double nominal_velocity = agp->nominal_velocity;
-    int nso = agp->n_slack_obs;
-    if (nso > max_slack_obs) nso = max_slack_obs;
-    if (nso < 0) nso = 0;
+    int nso_rt = agp->n_slack_obs;
+    if (nso_rt > max_slack_obs) nso_rt = max_slack_obs;
+    if (nso_rt < 0) nso_rt = 0;
+    const int nso = SLK == 0 ? 0 : nso_rt;
     const int nslk = M * nso;
 
     const float *Rnx = rows.nx + row_begin, *Rny = rows.ny + row_begin, *Rnz = rows.nz + row_begin;
@@ -322,17 +369,28 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 
     // ================================ trajectory QP =============================================
     double *base = reinterpret_cast<double *>(mem);
-    double *Q = base + lay.oQ, *Rp = base + lay.oRp, *Nl = base + lay.oN, *x = base + lay.oX;
-    double *blo = base + lay.oBlo, *bhi = base + lay.oBhi;
-    const int odump = lay.oDump;  // 64 doubles, one per lane: base[odump + l]
+    // layout (make_layout): compile-time for static shapes without slack obstacles, else from the arguments
+    constexpr int FB = FS > 0 ? FS : 8;  // block of LDS reads issued together in the O(r) loops
+    constexpr bool ST = DIMS > 0 && SLK == 0;
+    constexpr int R_ST = DIMS * FS, LDQ_ST = (DIMS * FS) | 1;
+    const int r_max = ST ? R_ST : lay.r_max;
+    const int ldq = ST ? LDQ_ST : lay.ldq;
+    const int oQ = 0;
+    const int oRp = ST ? (R_ST + 1) * LDQ_ST : lay.oRp;
+    const int oN = ST ? (R_ST + 1) * LDQ_ST + R_ST * (R_ST + 1) / 2 : lay.oN;
+    const int oX = ST ? (R_ST + 1) * LDQ_ST + R_ST * (R_ST + 1) / 2 + MS * 6 * FS : lay.oX;
+    const int odump = ST ? (R_ST + 1) * LDQ_ST + R_ST * (R_ST + 1) / 2 + MS * 6 * FS + DIMS * MS * 6 : lay.oDump;  // 64 doubles, one per lane
+    const int oBlo = ST ? (R_ST + 1) * LDQ_ST + R_ST * (R_ST + 1) / 2 + MS * 6 * FS + DIMS * MS * 6 + 64 : lay.oBlo;
+    const int oBhi = lay.oBhi;
+    double *Q = base + oQ, *Rp = base + oRp, *Nl = base + oN, *x = base + oX;
+    double *blo = base + oBlo, *bhi = base + oBhi;
     unsigned char *cold_flag = mem + lay.oFlag;
-    const int ldq = lay.ldq;
     const int rc = dim * f;      // whitened control-point dimension
     const int r = rc + nslk;     // whitened dimension
     const int nxc = dim * P;     // control-point variables
     const int cold_rows = K - Kc;
-    const int qdummy = lay.r_max;  // spare row of Q for the lanes beyond r
-    const int odump_rp = lay.oDump - lay.oRp;  // the dump slots as indices of Rp
+    const int qdummy = r_max;  // spare row of Q for the lanes beyond r
+    const int odump_rp = odump - oRp;  // the dump slots as indices of Rp
 
     // terminal segments, traj_optimizer.cpp:543-551 (float32 point difference)
     int T;
@@ -367,11 +425,11 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             const int k = jc / P, p = jc - k * P;
             const double v = tXs[p * 3 + 0] * (double)pick3(pos, k) + tXs[p * 3 + 1] * (double)pick3(vel, k) +
                              tXs[p * 3 + 2] * (double)pick3(acc, k) + tXg[p] * (double)pick3(goal, k);
-            base[in ? lay.oX + j : odump + l] = v;
+            base[blend_idx(in, oX + j, odump + l)] = v;
         }
         for (int s0 = 0; s0 < nslk; s0 += 64) {
             const int s2 = s0 + l;
-            base[s2 < nslk ? lay.oX + nxc + s2 : odump + l] = 0.0;
+            base[blend_idx(s2 < nslk, oX + nxc + s2, odump + l)] = 0.0;
         }
         for (int j0 = 0; j0 < lay.nflag; j0 += 64) {
             const int j = j0 + l;
@@ -405,8 +463,8 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             lo = bc == dim * M + 1 ? -ha : lo; hi = bc == dim * M + 1 ? ha : hi;
             lo = bc == dim * M ? -hv : lo;     hi = bc == dim * M ? hv : hi;
             lo = is_box ? blo_box : lo;        hi = is_box ? bhi_box : hi;
-            base[in ? lay.oBlo + b : odump + l] = lo;
-            base[in ? lay.oBhi + b : odump + l] = hi;
+            base[blend_idx(in, oBlo + b, odump + l)] = lo;
+            base[blend_idx(in, oBhi + b, odump + l)] = hi;
         }
     });
     // finish the LSC cache: rhs = d + n.p (traj_optimizer.cpp:427-439), drop rows that are not in the model
@@ -450,6 +508,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             wsq = sl != 0xFFFFu ? wsq + sg * sg : wsq;
             double iw = 1.0 / sqrt(wsq > 0 ? wsq : 1.0);
             DQ_KEEP(iw);
+            DQ_KEEP(rhs);
             cd[u].at(l) = in_model ? rhs : cd[u].at(l);
             ckey[u].at(l) = in_model ? key2 : KEY_SKIP;
             ciw[u].at(l) = (in_model & (wsq > 0)) ? iw : 0.0;
@@ -660,14 +719,14 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     const int j = j0 + l;
                     const bool in = j < P * f;
                     const double v = tN[in ? j : P * f - 1];
-                    base[in ? lay.oN + j : odump + l] = v;
+                    base[blend_idx(in, oN + j, odump + l)] = v;
                 }
                 // identity, and zeros in the spare row qdummy that lanes beyond r work on
-                const int nq = (lay.r_max + 1) * ldq;
+                const int nq = (r_max + 1) * ldq;
                 for (int j0 = 0; j0 < nq; j0 += 64) {
                     const int j = j0 + l;
                     const int i = j / ldq, c = j - i * ldq;
-                    base[j < nq ? lay.oQ + j : odump + l] = ((i == c) & (i < r)) ? 1.0 : 0.0;
+                    base[blend_idx(j < nq, oQ + j, odump + l)] = ((i == c) & (i < r)) ? 1.0 : 0.0;
                 }
             });
             w.sync();
@@ -782,11 +841,19 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 #pragma unroll
                     for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++) {
                         if (k < dim && (axes_mask & (1 << k))) {  // uniform
+                            // blocks of FB rows: all LDS reads of a block are issued before the first use
+                            for (int i0 = 0; i0 < f; i0 += FB) {
+                                const int nv = f - i0 < FB ? f - i0 : FB;  // uniform; == FB for static shapes
+                                double tq[FB];
 #pragma unroll
-                            for (int ii = 0; ii < f; ii += 2) {
-                                const int i = k * f + ii;
-                                a0 = fma(Q[i * ldq + jc], DQ_BC(na, i), a0);
-                                if (ii + 1 < f) a1 = fma(Q[(i + 1) * ldq + jc], DQ_BC(na, i + 1), a1);
+                                for (int u = 0; u < FB; u++) tq[u] = Q[(k * f + i0 + (u < nv ? u : 0)) * ldq + jc];
+#pragma unroll
+                                for (int u = 0; u < FB; u++) DQ_KEEP(tq[u]);
+#pragma unroll
+                                for (int u = 0; u < FB; u += 2) {
+                                    if (u < nv) a0 = fma(tq[u], DQ_BC(na, k * f + i0 + u), a0);
+                                    if (u + 1 < FB && u + 1 < nv) a1 = fma(tq[u + 1], DQ_BC(na, k * f + i0 + u + 1), a1);
+                                }
                             }
                         }
                     }
@@ -811,10 +878,19 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     const int i = l + 64 * c;
                     double a0 = 0.0, a1 = 0.0;
                     const double *qi = Q + (i < r ? i : qdummy) * ldq;  // lanes beyond r: the spare row
+                    for (int j0 = 0; j0 < rc; j0 += FB) {
+                        if (j0 + FB <= q) continue;  // uniform: d2 is zero in the first q columns
+                        const int nv = rc - j0 < FB ? rc - j0 : FB;  // uniform; == FB for static shapes
+                        double tq[FB];
 #pragma unroll
-                    for (int j = 0; j < rc; j += 2) {
-                        a0 = fma(qi[j], DQ_BC(dz, j), a0);
-                        if (j + 1 < rc) a1 = fma(qi[j + 1], DQ_BC(dz, j + 1), a1);
+                        for (int u = 0; u < FB; u++) tq[u] = qi[j0 + (u < nv ? u : 0)];
+#pragma unroll
+                        for (int u = 0; u < FB; u++) DQ_KEEP(tq[u]);
+#pragma unroll
+                        for (int u = 0; u < FB; u += 2) {
+                            if (u < nv) a0 = fma(tq[u], DQ_BC(dz, j0 + u), a0);
+                            if (u + 1 < FB && u + 1 < nv) a1 = fma(tq[u + 1], DQ_BC(dz, j0 + u + 1), a1);
+                        }
                     }
                     for (int j = rc; j < r; j++) a0 = fma(qi[j], DQ_BC(dz, j), a0);  // slack columns
                     zv[c].at(l) = i < r ? a0 + a1 : 0.0;
@@ -915,18 +991,27 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                         const bool in = p < P;
                         const int pc = in ? p : P - 1;
                         double sk[3] = {0.0, 0.0, 0.0};
+                        for (int c0 = 0; c0 < f; c0 += FB) {
+                            const int nvb = f - c0 < FB ? f - c0 : FB;  // uniform; == FB for static shapes
+                            double tn[FB];
 #pragma unroll
-                        for (int c = 0; c < f; c++) {
-                            const double nv = Nl[pc * f + c];
+                            for (int u = 0; u < FB; u++) tn[u] = Nl[pc * f + c0 + (u < nvb ? u : 0)];
 #pragma unroll
-                            for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++)
-                                if (k < dim) sk[k] = fma(nv, DQ_BC(zv, k * f + c), sk[k]);
+                            for (int u = 0; u < FB; u++) DQ_KEEP(tn[u]);
+#pragma unroll
+                            for (int u = 0; u < FB; u++) {
+                                if (u < nvb) {  // uniform
+#pragma unroll
+                                    for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++)
+                                        if (k < dim) sk[k] = fma(tn[u], DQ_BC(zv, k * f + c0 + u), sk[k]);
+                                }
+                            }
                         }
 #pragma unroll
                         for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++)
                             if (k < dim) {  // uniform
                                 const double xn = fma(t, sk[k], x[k * P + pc]);
-                                base[in ? lay.oX + k * P + p : odump + l] = xn;
+                                base[blend_idx(in, oX + k * P + p, odump + l)] = xn;
                             }
                     }
                 });
@@ -938,7 +1023,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                             const bool in = e >= rc && e < r;
                             const int s = in ? e - rc : 0;
                             const double xn = fma(t * kp.sigma[s % M], zv[c].at(l), x[nxc + s]);
-                            base[in ? lay.oX + nxc + s : odump + l] = xn;
+                            base[blend_idx(in, oX + nxc + s, odump + l)] = xn;
                         }
                     });
                 }
@@ -977,8 +1062,20 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                         const int i = l + 64 * c;
                         double *qi = Q + (i < r ? i : qdummy) * ldq;  // lanes beyond r update the spare row
                         const double gi = -beta * (zv[c].at(l) - alpha * qi[q]);
+                        for (int j0 = 0; j0 < rc; j0 += FB) {  // Q[i][:] += gi v', in blocks of FB columns
+                            if (j0 + FB <= q) continue;  // uniform: v is zero in the first q columns
+                            const int nv = rc - j0 < FB ? rc - j0 : FB;  // uniform; == FB for static shapes
+                            double tq[FB];
 #pragma unroll
-                        for (int j = 0; j < rc; j++) qi[j] = fma(gi, DQ_BC(hv, j), qi[j]);  // Q[i][:] += gi v'
+                            for (int u = 0; u < FB; u++) tq[u] = qi[j0 + (u < nv ? u : 0)];
+#pragma unroll
+                            for (int u = 0; u < FB; u++) DQ_KEEP(tq[u]);
+#pragma unroll
+                            for (int u = 0; u < FB; u++) tq[u] = fma(gi, DQ_BC(hv, j0 + (u < nv ? u : 0)), tq[u]);
+#pragma unroll
+                            for (int u = 0; u < FB; u++)
+                                if (u < nv) qi[j0 + u] = tq[u];  // uniform condition
+                        }
                         for (int j = rc; j < r; j++) qi[j] = fma(gi, DQ_BC(hv, j), qi[j]);
                     }
                 });
@@ -988,7 +1085,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                         const int i = l + 64 * c;
                         // R gains the column (d1; alpha)  <=>  S = R^-1 gains the column (-S d1 / alpha; 1 / alpha)
                         const double sv = i < q ? -rv[c].at(l) * inv_alpha : inv_alpha;
-                        Rp[i <= q ? q * (q + 1) / 2 + i : odump_rp + l] = sv;
+                        Rp[blend_idx(i <= q, q * (q + 1) / 2 + i, odump_rp + l)] = sv;
                         uu[c].at(l) = i == q ? uq : uu[c].at(l);
                         act[c].at(l) = i == q ? ip : act[c].at(l);
                     }
@@ -1061,7 +1158,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                             const double oS = cs * yS[c].at(l) - sn * cS;
                             yS[c].at(l) = sn * yS[c].at(l) + cs * cS;
                             const int inew = i < lcol ? i : i - 1;
-                            Rp[((i != lcol) & (inew <= t)) ? t * (t + 1) / 2 + inew : odump_rp + l] = oS;
+                            Rp[blend_idx((i != lcol) & (inew <= t), t * (t + 1) / 2 + inew, odump_rp + l)] = oS;
                             double *qi = Q + (i < r ? i : qdummy) * ldq;
                             const double cQ = qi[t + 1];
                             qi[t] = cs * yQ[c].at(l) - sn * cQ;

@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "dlsc_gc_planner_amd", "csrc")
-LIB = os.path.join(CSRC, "libdlscqp_stamps.so")
+LIB = os.environ.get("DLSCQP_STAMPS_LIB", os.path.join(CSRC, "libdlscqp_stamps.so"))
 
 PHASES = ["agent+goalLP", "init(LDS tables,Q=I)", "scan+argmax", "decode+normal", "d=Q'na", "z,|d2|,|d|",
           "backsub", "ratio test", "primal/dual step", "householder add", "givens drop", "readout"]

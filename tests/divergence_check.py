@@ -60,7 +60,7 @@ def source_line(file, line):
 if __name__ == "__main__":
     r = regions(sys.argv[2:] if len(sys.argv) > 2 else ())
     for k, c in r.items():
-        t = re.search(r"ILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", k)
+        t = re.search(r"ILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(n?\d+)E", k)
         print("kernel <%s>: %d EXEC regions" % (",".join(t.groups()) if t else k, sum(c.values())))
         if "-v" in sys.argv[1:2]:
             for (f, ln), n in sorted(c.items(), key=lambda kv: (str(kv[0][0]), kv[0][1])):

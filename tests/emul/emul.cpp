@@ -119,17 +119,19 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
         key[i] = DLSCQP_KEY(rows[i].m, rows[i].i, rows[i].slack, rows[i].flags & DLSCQP_ROW_DYNAMIC);
     }
     RowsView rv{nx.data(), ny.data(), nz.data(), px.data(), py.data(), pz.data(), d.data(), key.data()};
-    // same instantiation choice as the launcher in dlscqp.hip (select_kernel)
-    int KUsel = 4, SUsel = 10;
-    auto fn = plan_agent<2, 0, 0, 0, 4, 10, WaveCpu>;
-    {
-        const bool generic = std::getenv("EMUL_GENERIC") != nullptr;
-        const int r_max = kp.dim * kp.f + kp.M * max_slack_obs;
-        if (!generic && kp.dim == 3 && kp.f == 13 && kp.M == 5 && r_max <= 64 && kmax <= 128 && kp.n_slots <= 256) { fn = plan_agent<1, 3, 13, 5, 2, 4, WaveCpu>; KUsel = 2; SUsel = 4; }
-        else if (!generic && kp.dim == 3 && kp.f == 13 && kp.M == 5 && r_max <= 64) { fn = plan_agent<1, 3, 13, 5, 4, 5, WaveCpu>; KUsel = 4; SUsel = 5; }
-        else if (!generic && kp.dim == 2 && kp.f == 28 && kp.M == 10 && r_max <= 64) { fn = plan_agent<1, 2, 28, 10, 4, 7, WaveCpu>; KUsel = 4; SUsel = 7; }
-        else if (!generic && kp.dim == 3 && kp.f == 28 && kp.M == 10 && r_max <= 128) { fn = plan_agent<2, 3, 28, 10, 4, 10, WaveCpu>; }
-        else if (r_max <= 64) { fn = plan_agent<1, 0, 0, 0, 4, 10, WaveCpu>; }
+    // same instantiation choice as the launcher in dlscqp.hip (select_instance in gi_core.hpp)
+    const InstanceChoice ic = select_instance(kp, max_slack_obs, kmax, std::getenv("EMUL_GENERIC") != nullptr);
+    if (ic.id < 0) return -2;
+    const int KUsel = ic.KU, SUsel = ic.SU;
+    typedef void (*fn_t)(const WaveCpu &, const KParams &, const MemLayout &, unsigned char *, const dlscqp_agent *,
+                         const RowsView &, int, int, const float *, int, int, int, float *, int *, float *, double *,
+                         double *, double *, int *, int *);
+    fn_t fn = nullptr;
+    switch (ic.id) {
+#define DQ_CASE(ID, RC, DIMS, FS, MS, KU, SU, SLK) \
+    case ID: fn = plan_agent<RC, DIMS, FS, MS, KU, SU, SLK, WaveCpu>; break;
+        DQ_INSTANCES(DQ_CASE)
+#undef DQ_CASE
     }
     MemLayout lay = make_layout(kp, max_slack_obs, kmax, KUsel, SUsel);
     std::vector<unsigned char> mem(lay.bytes + 64);
