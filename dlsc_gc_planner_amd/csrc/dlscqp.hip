@@ -16,6 +16,7 @@
 
 #define DQ_FN __host__ __device__ __forceinline__
 #define DQ_KEEP(v) asm volatile("" : "+v"(v))
+#define DQ_MARK(text) asm volatile("; " text)
 #ifdef DLSCQP_TRACE_LDS
 #define DLSCQP_TRACE
 #endif

@@ -43,6 +43,10 @@
 #ifndef DQ_KEEP
 #define DQ_KEEP(v) ((void)0)
 #endif
+// DQ_MARK(text): a comment in the generated assembly (tests/divergence_check.py recognises the exit stores by it)
+#ifndef DQ_MARK
+#define DQ_MARK(text) ((void)0)
+#endif
 
 namespace dlscqp {
 
@@ -53,7 +57,7 @@ namespace dlscqp {
 struct MemLayout {
     int r_max, nx_max, ldq, nflag;
     int oQ, oRp, oN, oX, oBlo, oBhi;  // in doubles
-    int oDump;                        // 64 doubles: where lanes that have nothing to store put their value
+    int oDump;                        // 32 dump slots (lane & 31) for the lanes that have nothing to store: the spare row of Q
     int oFlag;                        // byte offset of the flags of rows beyond the register cache
     int bytes;
 };
@@ -69,10 +73,11 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
     L.nflag = cold_rows + 2 * cold_slots;
     int o = 0;
     L.oQ = o; o += (L.r_max + 1) * L.ldq;  // + one row for the lanes beyond r (see "no divergence" below)
+    L.oDump = L.oQ + L.r_max * L.ldq;      // that row doubles as the dump slots: its content is never used
+    if (L.ldq < 32) o += 32 - L.ldq;
     L.oRp = o; o += L.r_max * (L.r_max + 1) / 2;
     L.oN = o; o += kp.P * kp.f;
     L.oX = o; o += L.nx_max;
-    L.oDump = o; o += 64;
     L.oBlo = o; o += kp.nb;
     L.oBhi = o; o += kp.nb;
     L.oFlag = o * 8;
@@ -354,33 +359,59 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 goal_status = numerical_error ? DLSCQP_GOAL_FALLBACK : DLSCQP_INFEASIBLE;
             }
         }
+    }
+    // Scalar results (sub-goal, verdicts, counters, cost) are stored by lane 0 (lanes 0-2 for the sub-goal) in
+    // exit_stores(), which every exit path calls as its LAST action: a lane-guarded store is a divergent region,
+    // allowed only where nothing is live after it (see "NO DIVERGENCE").
+    auto exit_stores = [&](int st_traj, bool have_traj, int it0, int it1, int it2, int it3, bool have_cost, double fval) {
+        DQ_MARK("DQ_EXIT_STORES");
         w.each([&](int l) {
-            // no lane guard: lanes beyond the third repeat lane 2's store, and all lanes store the same status word
-            const int lc = l < 3 ? l : 2;
-            if (out_goal && goal_status != DLSCQP_INFEASIBLE) out_goal[lc] = pick3(goal, lc);
-            if (out_goal_status) *out_goal_status = goal_status;
-            // the reference throws before trajOptimization is reached (traj_planner.cpp:491-496)
-            if (goal_status == DLSCQP_INFEASIBLE && do_traj && out_status) *out_status = DLSCQP_INFEASIBLE;
+            if (do_goal) {
+                if (l < 3 && out_goal && goal_status != DLSCQP_INFEASIBLE) out_goal[l] = pick3(goal, l);
+                if (l == 0 && out_goal_status) *out_goal_status = goal_status;
+            }
+            if (l == 0 && have_traj) {
+                if (out_status) *out_status = st_traj;
+                if (out_iters) { out_iters[0] = it0; out_iters[1] = it1; out_iters[2] = it2; out_iters[3] = it3; }
+                if (have_cost && out_cost) *out_cost = fval;
+            }
         });
-        if (goal_status == DLSCQP_INFEASIBLE) return;
+    };
+    if (do_goal && goal_status == DLSCQP_INFEASIBLE) {
+        // the reference throws before trajOptimization is reached (traj_planner.cpp:491-496)
+        exit_stores(DLSCQP_INFEASIBLE, do_traj != 0, 0, 0, 0, 0, false, 0.0);
+        return;
     }
     w.stamp(0);  // agent record, row cache, goal LP
-    if (!do_traj) return;
+    if (!do_traj) {
+        exit_stores(0, false, 0, 0, 0, 0, false, 0.0);
+        return;
+    }
 
     // ================================ trajectory QP =============================================
     double *base = reinterpret_cast<double *>(mem);
     // layout (make_layout): compile-time for static shapes without slack obstacles, else from the arguments
+#ifndef DQ_STAGE_Z
+#define DQ_STAGE_Z 1
+#endif
+#ifndef DQ_STAGE_S
+#define DQ_STAGE_S 1
+#endif
+#ifndef DQ_STAGE_H
+#define DQ_STAGE_H 1
+#endif
     constexpr int FB = FS > 0 ? FS : 8;  // block of LDS reads issued together in the O(r) loops
     constexpr bool ST = DIMS > 0 && SLK == 0;
     constexpr int R_ST = DIMS * FS, LDQ_ST = (DIMS * FS) | 1;
+    static_assert(!ST || LDQ_ST >= 32, "the spare row of Q holds the 32 dump slots");
     const int r_max = ST ? R_ST : lay.r_max;
     const int ldq = ST ? LDQ_ST : lay.ldq;
     const int oQ = 0;
     const int oRp = ST ? (R_ST + 1) * LDQ_ST : lay.oRp;
     const int oN = ST ? (R_ST + 1) * LDQ_ST + R_ST * (R_ST + 1) / 2 : lay.oN;
     const int oX = ST ? (R_ST + 1) * LDQ_ST + R_ST * (R_ST + 1) / 2 + MS * 6 * FS : lay.oX;
-    const int odump = ST ? (R_ST + 1) * LDQ_ST + R_ST * (R_ST + 1) / 2 + MS * 6 * FS + DIMS * MS * 6 : lay.oDump;  // 64 doubles, one per lane
-    const int oBlo = ST ? (R_ST + 1) * LDQ_ST + R_ST * (R_ST + 1) / 2 + MS * 6 * FS + DIMS * MS * 6 + 64 : lay.oBlo;
+    const int odump = ST ? R_ST * LDQ_ST : lay.oDump;  // 32 dump slots in the spare row of Q, base[odump + (lane & 31)]
+    const int oBlo = ST ? (R_ST + 1) * LDQ_ST + R_ST * (R_ST + 1) / 2 + MS * 6 * FS + DIMS * MS * 6 : lay.oBlo;
     const int oBhi = lay.oBhi;
     double *Q = base + oQ, *Rp = base + oRp, *Nl = base + oN, *x = base + oX;
     double *blo = base + oBlo, *bhi = base + oBhi;
@@ -405,7 +436,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     if (nslk > 0 && !(kp.w_s > 0)) status = DLSCQP_NUMERICAL;
     if (r > 64 * RC || dim != kp.dim || f != kp.f || M != kp.M || n1 != kp.n1) status = DLSCQP_NUMERICAL;  // the launcher picks the instantiation; defensive
     if (status != DLSCQP_OK) {
-        w.each([&](int) { if (out_status) *out_status = status; });
+        exit_stores(status, true, 0, 0, 0, 0, false, 0.0);
         return;
     }
 
@@ -425,11 +456,11 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             const int k = jc / P, p = jc - k * P;
             const double v = tXs[p * 3 + 0] * (double)pick3(pos, k) + tXs[p * 3 + 1] * (double)pick3(vel, k) +
                              tXs[p * 3 + 2] * (double)pick3(acc, k) + tXg[p] * (double)pick3(goal, k);
-            base[blend_idx(in, oX + j, odump + l)] = v;
+            base[blend_idx(in, oX + j, odump + (l & 31))] = v;
         }
         for (int s0 = 0; s0 < nslk; s0 += 64) {
             const int s2 = s0 + l;
-            base[blend_idx(s2 < nslk, oX + nxc + s2, odump + l)] = 0.0;
+            base[blend_idx(s2 < nslk, oX + nxc + s2, odump + (l & 31))] = 0.0;
         }
         for (int j0 = 0; j0 < lay.nflag; j0 += 64) {
             const int j = j0 + l;
@@ -463,8 +494,8 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             lo = bc == dim * M + 1 ? -ha : lo; hi = bc == dim * M + 1 ? ha : hi;
             lo = bc == dim * M ? -hv : lo;     hi = bc == dim * M ? hv : hi;
             lo = is_box ? blo_box : lo;        hi = is_box ? bhi_box : hi;
-            base[blend_idx(in, oBlo + b, odump + l)] = lo;
-            base[blend_idx(in, oBhi + b, odump + l)] = hi;
+            base[blend_idx(in, oBlo + b, odump + (l & 31))] = lo;
+            base[blend_idx(in, oBhi + b, odump + (l & 31))] = hi;
         }
     });
     // finish the LSC cache: rhs = d + n.p (traj_optimizer.cpp:427-439), drop rows that are not in the model
@@ -535,6 +566,85 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     const int max_iter = kp.max_iter > 0 ? kp.max_iter : 20 * (r + 8) + 200;
     // unified row codes: [0,K) LSC rows, K + 2 s + side structured slots, K + 2 n_slots + s slack bounds
     const int code_slack0 = K + 2 * n_slots;
+
+    // objective value of the current iterate x (cplex.getObjValue(), traj_optimizer.cpp:109, objective at :286-331)
+    auto objective = [&]() -> double {
+        RegD cj, cs2;
+        w.each([&](int l) {
+            double a1 = 0, a2 = 0;
+            for (int g0 = 0; g0 < dim * M; g0 += 64) {  // one Bernstein segment (axis k, segment m) per lane
+                const int sgm = g0 + l;
+                const bool in = sgm < dim * M;
+                const int sc = in ? sgm : 0;
+                const int k = sc / M, m = sc - k * M;
+                const double *seg = x + k * P + m * n1;
+                double c6[n1];
+#pragma unroll
+                for (int c = 0; c < n1; c++) c6[c] = seg[c];
+                double e1 = 0;
+#pragma unroll
+                for (int i = 0; i < n1; i++) {
+                    double t = 0;
+#pragma unroll
+                    for (int c = 0; c < n1; c++) t = fma(kp.Qb[i * n1 + c], c6[c], t);
+                    e1 = fma(c6[i], t, e1);
+                }
+                const double e = c6[n] - (double)pick3(goal, k);
+                const double e1t = fma(kp.w_t * e, e, e1);
+                e1 = m >= M - T ? e1t : e1;
+                a1 += in ? e1 : 0.0;
+            }
+            for (int s0 = 0; s0 < nslk; s0 += 64) {
+                const int s = s0 + l;
+                const bool in = s < nslk;
+                const int sc = in ? s : 0;
+                const int m = sc % M;
+                const double e = x[nxc + sc];
+                double wv = kp.w_s * ((double)(M - m) / M) * e * e;
+                DQ_KEEP(wv);
+                a2 += in ? wv : 0.0;
+            }
+            cj.at(l) = a1;
+            cs2.at(l) = a2;
+        });
+        double t1c, t2c;
+        w.sum2(cj, cs2, t1c, t2c);
+        return t1c + t2c;
+    };
+
+    // Upper bound of the objective over all points that satisfy the box rows (world / SFC, T3a, T3e) and the
+    // acceleration rows (T3g); only meaningful without slack variables.
+    //   jerk term: the acceleration of a segment is a cubic Bernstein polynomial whose control points are bounded by
+    //   a = max(max_acc, |initial acceleration|), so |jerk| <= 3/dt * 2a and  c'Qb c = w_c * integral jerk^2 <= w_c 36 a^2 / dt
+    //   per axis and segment;  terminal term: w_t * (largest distance of the box of that segment to the goal)^2.
+    auto objective_upper_bound = [&]() -> double {
+        double amax = max_acc;
+        for (int k = 0; k < 3; k++) amax = fabs((double)acc[k]) > amax ? fabs((double)acc[k]) : amax;
+        const double jerk = kp.w_c * 36.0 * amax * amax / kp.dt * (double)(dim * M);
+        RegD tj, zero;
+        w.each([&](int l) {
+            double a1 = 0;
+            for (int g0 = 0; g0 < dim * M; g0 += 64) {
+                const int sgm = g0 + l;
+                const bool in = sgm < dim * M;
+                const int sc = in ? sgm : 0;
+                const int k = sc / M, m = sc - k * M;
+                const double g = (double)pick3(goal, k);
+                const double dl = fabs(blo[sc] - g), dh = fabs(bhi[sc] - g);
+                const double dm2 = dl > dh ? dl : dh;
+                double tv = kp.w_t * dm2 * dm2;
+                DQ_KEEP(tv);
+                a1 += (in & (m >= M - T)) ? tv : 0.0;
+            }
+            tj.at(l) = a1;
+            zero.at(l) = 0.0;
+        });
+        double term, unused;
+        w.sum2(tj, zero, term, unused);
+        return jerk + term;
+    };
+    int n_price = 0;
+    double f_max = -1.0;  // computed when first needed
 
     auto set_skip = [&](int code, bool on) {  // code and on are uniform; the owner lane is picked by a select
         auto upd = [&](RegU &fr, int owner, int u) {
@@ -705,28 +815,51 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         const double top = w.max(bests);  // best pivot score over all violated rows
         w.stamp(2);                       // row scan + arg-max
         if (!(top > 0.0)) break;          // no row violated by more than VIOL_TOL: optimal
+        // ---- infeasibility by weak duality ------------------------------------------------------
+        // x minimises the objective over the active rows with non-negative multipliers, so f(x) is a lower bound
+        // of the optimum.  Every feasible point obeys the box and acceleration rows, which bound the objective
+        // from above by f_max (objective_upper_bound).  f(x) > f_max therefore proves the QP infeasible, usually
+        // after 5-20 rows instead of the ~r rows the active set needs to run out of dimensions (the launch is as
+        // slow as its slowest agent, and those were the infeasible ones).  Checked every fourth pricing pass.
+        n_price++;
+        if (nslk == 0 && n_price >= 8 && (n_price & 3) == 0) {
+            if (n_price == 8) f_max = objective_upper_bound();  // first check of this agent
+            const double f_now = objective();
+            DQ_TRACE(4, f_now, f_max, (double)n_price, (double)q);
+            if (f_now > f_max + 0.5 * f_max + 1.0) {  // generous margin (1.5 f_max + 1): f(x) grows by orders of magnitude
+                status = DLSCQP_INFEASIBLE;
+                break;
+            }
+        }
         RegI is_top;
         w.each([&](int l) { is_top.at(l) = (bests.at(l) == top && bestc.at(l) >= 0) ? 1 : 0; });
         const int owner_lane = w.first_lane(is_top);
         const int ip = w.bcast(bestc, owner_lane);
         double viol = w.bcast(bestv, owner_lane);  // = -(a.x - b) of the chosen row
         DQ_TRACE(1, (double)ip, viol, top, (double)q);
+#ifdef DLSCQP_TRACE
+        DQ_TRACE(3, objective(), 0.0, 0.0, 0.0);
+#endif
 
         if (!factors_ready) {
             // first violated row: set up the factors (agents that never get here skip all of this)
-            w.each([&](int l) {
+            w.each([&](int l0) {
+                // the lane index through an opaque copy: the addresses below must be computed here, not hoisted
+                // out of the iteration loop (where ~25 loop-invariant address registers were kept alive in scratch)
+                int l = l0;
+                DQ_KEEP(l);
                 for (int j0 = 0; j0 < P * f; j0 += 64) {
                     const int j = j0 + l;
                     const bool in = j < P * f;
                     const double v = tN[in ? j : P * f - 1];
-                    base[blend_idx(in, oN + j, odump + l)] = v;
+                    base[blend_idx(in, oN + j, odump + (l & 31))] = v;
                 }
                 // identity, and zeros in the spare row qdummy that lanes beyond r work on
                 const int nq = (r_max + 1) * ldq;
                 for (int j0 = 0; j0 < nq; j0 += 64) {
                     const int j = j0 + l;
                     const int i = j / ldq, c = j - i * ldq;
-                    base[blend_idx(j < nq, oQ + j, odump + l)] = ((i == c) & (i < r)) ? 1.0 : 0.0;
+                    base[blend_idx(j < nq, oQ + j, odump + (l & 31))] = ((i == c) & (i < r)) ? 1.0 : 0.0;
                 }
             });
             w.sync();
@@ -878,6 +1011,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     const int i = l + 64 * c;
                     double a0 = 0.0, a1 = 0.0;
                     const double *qi = Q + (i < r ? i : qdummy) * ldq;  // lanes beyond r: the spare row
+#if DQ_STAGE_Z
                     for (int j0 = 0; j0 < rc; j0 += FB) {
                         if (j0 + FB <= q) continue;  // uniform: d2 is zero in the first q columns
                         const int nv = rc - j0 < FB ? rc - j0 : FB;  // uniform; == FB for static shapes
@@ -892,6 +1026,14 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                             if (u + 1 < FB && u + 1 < nv) a1 = fma(tq[u + 1], DQ_BC(dz, j0 + u + 1), a1);
                         }
                     }
+#else
+#pragma unroll
+                    for (int j = 0; j < rc; j += 2) {
+                        a0 = fma(qi[j], DQ_BC(dz, j), a0);
+                        if (j + 1 < rc) a1 = fma(qi[j + 1], DQ_BC(dz, j + 1), a1);
+                    }
+#endif
+
                     for (int j = rc; j < r; j++) a0 = fma(qi[j], DQ_BC(dz, j), a0);  // slack columns
                     zv[c].at(l) = i < r ? a0 + a1 : 0.0;
                 }
@@ -991,6 +1133,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                         const bool in = p < P;
                         const int pc = in ? p : P - 1;
                         double sk[3] = {0.0, 0.0, 0.0};
+#if DQ_STAGE_S
                         for (int c0 = 0; c0 < f; c0 += FB) {
                             const int nvb = f - c0 < FB ? f - c0 : FB;  // uniform; == FB for static shapes
                             double tn[FB];
@@ -1007,11 +1150,21 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                                 }
                             }
                         }
+#else
+#pragma unroll
+                        for (int c = 0; c < f; c++) {
+                            const double nv = Nl[pc * f + c];
+#pragma unroll
+                            for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++)
+                                if (k < dim) sk[k] = fma(nv, DQ_BC(zv, k * f + c), sk[k]);
+                        }
+#endif
+
 #pragma unroll
                         for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++)
                             if (k < dim) {  // uniform
                                 const double xn = fma(t, sk[k], x[k * P + pc]);
-                                base[blend_idx(in, oX + k * P + p, odump + l)] = xn;
+                                base[blend_idx(in, oX + k * P + p, odump + (l & 31))] = xn;
                             }
                     }
                 });
@@ -1023,7 +1176,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                             const bool in = e >= rc && e < r;
                             const int s = in ? e - rc : 0;
                             const double xn = fma(t * kp.sigma[s % M], zv[c].at(l), x[nxc + s]);
-                            base[blend_idx(in, oX + nxc + s, odump + l)] = xn;
+                            base[blend_idx(in, oX + nxc + s, odump + (l & 31))] = xn;
                         }
                     });
                 }
@@ -1062,6 +1215,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                         const int i = l + 64 * c;
                         double *qi = Q + (i < r ? i : qdummy) * ldq;  // lanes beyond r update the spare row
                         const double gi = -beta * (zv[c].at(l) - alpha * qi[q]);
+#if DQ_STAGE_H
                         for (int j0 = 0; j0 < rc; j0 += FB) {  // Q[i][:] += gi v', in blocks of FB columns
                             if (j0 + FB <= q) continue;  // uniform: v is zero in the first q columns
                             const int nv = rc - j0 < FB ? rc - j0 : FB;  // uniform; == FB for static shapes
@@ -1076,6 +1230,11 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                             for (int u = 0; u < FB; u++)
                                 if (u < nv) qi[j0 + u] = tq[u];  // uniform condition
                         }
+#else
+#pragma unroll
+                        for (int j = 0; j < rc; j++) qi[j] = fma(gi, DQ_BC(hv, j), qi[j]);  // Q[i][:] += gi v'
+#endif
+
                         for (int j = rc; j < r; j++) qi[j] = fma(gi, DQ_BC(hv, j), qi[j]);
                     }
                 });
@@ -1085,7 +1244,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                         const int i = l + 64 * c;
                         // R gains the column (d1; alpha)  <=>  S = R^-1 gains the column (-S d1 / alpha; 1 / alpha)
                         const double sv = i < q ? -rv[c].at(l) * inv_alpha : inv_alpha;
-                        Rp[blend_idx(i <= q, q * (q + 1) / 2 + i, odump_rp + l)] = sv;
+                        Rp[blend_idx(i <= q, q * (q + 1) / 2 + i, odump_rp + (l & 31))] = sv;
                         uu[c].at(l) = i == q ? uq : uu[c].at(l);
                         act[c].at(l) = i == q ? ip : act[c].at(l);
                     }
@@ -1158,7 +1317,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                             const double oS = cs * yS[c].at(l) - sn * cS;
                             yS[c].at(l) = sn * yS[c].at(l) + cs * cS;
                             const int inew = i < lcol ? i : i - 1;
-                            Rp[blend_idx((i != lcol) & (inew <= t), t * (t + 1) / 2 + inew, odump_rp + l)] = oS;
+                            Rp[blend_idx((i != lcol) & (inew <= t), t * (t + 1) / 2 + inew, odump_rp + (l & 31))] = oS;
                             double *qi = Q + (i < r ? i : qdummy) * ldq;
                             const double cQ = qi[t + 1];
                             qi[t] = cs * yQ[c].at(l) - sn * cQ;
@@ -1204,62 +1363,12 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     }
 
     // ================================ read-out ==================================================
-    // Verdict and counters: every lane stores the same words (no lane guard).
-    w.each([&](int) {
-        if (out_status) *out_status = status;
-        if (out_iters) {
-            out_iters[0] = iters;
-            out_iters[1] = n_add;
-            out_iters[2] = n_drop;
-            out_iters[3] = q;
-        }
-    });
-    if (status != DLSCQP_OK) return;
-    // cplex.getObjValue(), traj_optimizer.cpp:109, objective at :286-331 -- before the guarded stores below, so
-    // that nothing computed later is live across them
-    if (out_cost) {
-        RegD cj, cs2;
-        w.each([&](int l) {
-            double a1 = 0, a2 = 0;
-            for (int g0 = 0; g0 < dim * M; g0 += 64) {  // one Bernstein segment (axis k, segment m) per lane
-                const int sgm = g0 + l;
-                const bool in = sgm < dim * M;
-                const int sc = in ? sgm : 0;
-                const int k = sc / M, m = sc - k * M;
-                const double *seg = x + k * P + m * n1;
-                double c6[n1];
-#pragma unroll
-                for (int c = 0; c < n1; c++) c6[c] = seg[c];
-                double e1 = 0;
-#pragma unroll
-                for (int i = 0; i < n1; i++) {
-                    double t = 0;
-#pragma unroll
-                    for (int c = 0; c < n1; c++) t = fma(kp.Qb[i * n1 + c], c6[c], t);
-                    e1 = fma(c6[i], t, e1);
-                }
-                const double e = c6[n] - (double)pick3(goal, k);
-                const double e1t = fma(kp.w_t * e, e, e1);
-                e1 = m >= M - T ? e1t : e1;
-                a1 += in ? e1 : 0.0;
-            }
-            for (int s0 = 0; s0 < nslk; s0 += 64) {
-                const int s = s0 + l;
-                const bool in = s < nslk;
-                const int sc = in ? s : 0;
-                const int m = sc % M;
-                const double e = x[nxc + sc];
-                double wv = kp.w_s * ((double)(M - m) / M) * e * e;
-                DQ_KEEP(wv);
-                a2 += in ? wv : 0.0;
-            }
-            cj.at(l) = a1;
-            cs2.at(l) = a2;
-        });
-        double t1c, t2c;
-        w.sum2(cj, cs2, t1c, t2c);
-        w.each([&](int) { *out_cost = t1c + t2c; });
+    if (status != DLSCQP_OK) {
+        exit_stores(status, true, iters, n_add, n_drop, q, false, 0.0);
+        return;
     }
+    // objective before the guarded stores below, so that nothing computed later is live across them
+    const double fval = out_cost ? objective() : 0.0;
     // Per-lane results: the only lane-guarded instructions of the kernel are these final global stores.
     w.each([&](int l) {
         // traj_optimizer.cpp:69-83: point3d(float) control points, z = world_z_2d in 2-D
@@ -1291,6 +1400,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 if (in) out_slack_cost[s] = live ? sc : 0.0;
             }
     });
+    exit_stores(status, true, iters, n_add, n_drop, q, true, fval);
     w.stamp(11);  // read-out
 }
 

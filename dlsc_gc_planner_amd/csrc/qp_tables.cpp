@@ -14,6 +14,7 @@
 #include "qp_tables.hpp"
 
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 

@@ -27,6 +27,7 @@ def regions(extra_flags=()):
     res = {}
     kernel = None
     cur = None
+    since_mark = 10 ** 9
     for l in lines:
         m = re.match(r'\s*\.file\s+(\d+)\s+"([^"]*)"(?:\s+"([^"]*)")?', l)
         if m:
@@ -44,9 +45,16 @@ def regions(extra_flags=()):
         m = re.match(r'\s*\.loc\s+(\d+)\s+(\d+)', l)
         if m:
             cur = (files.get(m.group(1), m.group(1)), int(m.group(2)))
+        if "DQ_EXIT_STORES" in l:
+            since_mark = 0
         op = l.strip().split(" ")[0] if l.strip() else ""
+        if op and not op.startswith((";", ".")):
+            since_mark += 1
+        if op == "s_endpgm":
+            since_mark = 10 ** 9
         if op.startswith(EXEC_OPS):
-            res[kernel][cur] += 1
+            # the lane-0 stores of exit_stores() directly follow its marker comment
+            res[kernel][("exit_stores", 0) if since_mark < 300 else cur] += 1
     return res
 
 

@@ -107,9 +107,9 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
     kp.tabSIW = tb.tabSIW.data();
     kp.slots = tb.slots.data();
     const int64_t nrows = row_offsets[n_agents];
-    std::vector<float> nx(nrows + 1), ny(nrows + 1), nz(nrows + 1), px(nrows + 1), py(nrows + 1), pz(nrows + 1);
-    std::vector<double> d(nrows + 1);
-    std::vector<uint32_t> key(nrows + 1);
+    std::vector<float> nx(nrows), ny(nrows), nz(nrows), px(nrows), py(nrows), pz(nrows);
+    std::vector<double> d(nrows);
+    std::vector<uint32_t> key(nrows);
     int kmax = 0;
     for (int a = 0; a < n_agents; a++) kmax = std::max<int>(kmax, (int)(row_offsets[a + 1] - row_offsets[a]));
     for (int64_t i = 0; i < nrows; i++) {

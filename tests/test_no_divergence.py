@@ -17,6 +17,8 @@ def test_only_the_final_stores_are_lane_guarded():
     offenders = []
     for kernel, counts in res.items():
         for (f, line), n in counts.items():
+            if f == "exit_stores":  # lane-0 stores that every exit path issues as its last action
+                continue
             src = divergence_check.source_line(f, line) if f == "gi_core.hpp" else "?"
             if not src.startswith(ALLOWED):
                 offenders.append((kernel[-40:], f, line, n, src[:80]))
