@@ -137,6 +137,14 @@ class LscGen(C.Structure):
         ("px", C.c_void_p), ("py", C.c_void_p), ("pz", C.c_void_p),
         ("d", C.c_void_p),
         ("key", C.c_void_p),
+        ("n_dyn", C.c_int32),
+        ("dyn_size_prediction", C.c_int32),
+        ("dyn_uncertainty_horizon", C.c_double),
+        ("dyn_position", C.c_void_p),
+        ("dyn_velocity", C.c_void_p),
+        ("dyn_radius", C.c_void_p),
+        ("dyn_max_acc", C.c_void_p),
+        ("dyn_downwash", C.c_void_p),
     ]
 
 

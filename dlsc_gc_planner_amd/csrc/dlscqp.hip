@@ -277,10 +277,15 @@ __global__ __launch_bounds__(64) void dlscqp_lsc_kernel(LscGenArgs g) {
     const int self = g.local_ids ? g.local_ids[k] : k;
     const int p0 = g.nbr_offsets[k], p1 = g.nbr_offsets[k + 1];
     const int per = g.M * g.n1 - g.phi;
+    const size_t pair0 = (size_t)p0 + (size_t)k * g.n_dyn;  // pairs (agent, obstacle) before this agent's
     const int items = (p1 - p0) * g.M;
     for (int it = threadIdx.x; it < items; it += 64) {
         const int j = it / g.M, m = it - j * g.M;
-        lsc_item(g, self, g.nbr_ids[p0 + j], m, (size_t)per * (size_t)(p0 + j));
+        lsc_item(g, self, g.nbr_ids[p0 + j], m, (size_t)per * (pair0 + j));
+    }
+    for (int it = threadIdx.x; it < g.n_dyn * g.M; it += 64) {  // dynamic obstacles after the neighbour agents
+        const int o = it / g.M, m = it - o * g.M;
+        lsc_dyn_item(g, self, o, m, (size_t)per * (pair0 + (p1 - p0) + o));
     }
 }
 
@@ -567,6 +572,15 @@ extern "C" int dlscqp_generate_lsc_device(dlscqp_ctx *c, const dlscqp_lsc_gen *g
     g.nbr_offsets = gen->nbr_offsets; g.nbr_ids = gen->nbr_ids;
     g.nx = gen->nx; g.ny = gen->ny; g.nz = gen->nz; g.px = gen->px; g.py = gen->py; g.pz = gen->pz;
     g.d = gen->d; g.key = gen->key;
+    g.n_dyn = gen->n_dyn > 0 ? gen->n_dyn : 0;
+    if (g.n_dyn > 0 && (!gen->dyn_position || !gen->dyn_velocity || !gen->dyn_radius || !gen->dyn_max_acc || !gen->dyn_downwash)) {
+        g_last_error = "null dynamic-obstacle buffer";
+        return DLSCQP_ERR_INVALID_ARGUMENT;
+    }
+    g.dyn_size_prediction = gen->dyn_size_prediction;
+    g.dyn_uncertainty_horizon = gen->dyn_uncertainty_horizon;
+    g.dyn_position = gen->dyn_position; g.dyn_velocity = gen->dyn_velocity;
+    g.dyn_radius = gen->dyn_radius; g.dyn_max_acc = gen->dyn_max_acc; g.dyn_downwash = gen->dyn_downwash;
     hipLaunchKernelGGL(dlscqp_lsc_kernel, dim3(gen->n_local), dim3(64), 0, (hipStream_t)stream, g);
     HIP_TRY(hipGetLastError());
     return DLSCQP_SUCCESS;

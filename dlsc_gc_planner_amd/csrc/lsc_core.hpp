@@ -221,6 +221,10 @@ struct LscGenArgs {  // device mirror of dlscqp_lsc_gen (include/dlscqp.h)
     float *nx, *ny, *nz, *px, *py, *pz;
     double *d;
     uint32_t *key;
+    int n_dyn, dyn_size_prediction;
+    double dyn_uncertainty_horizon;
+    const float *dyn_position, *dyn_velocity;
+    const double *dyn_radius, *dyn_max_acc, *dyn_downwash;
 };
 
 // control point i of segment m of agent `id`'s initial trajectory (= what the others predict for it)
@@ -293,6 +297,73 @@ DQ_FN void lsc_item(const LscGenArgs &g, int self, int other, int m, size_t row0
             g.d[r] = dd;
             g.key[r] = DLSCQP_KEY(m, i, -1, 0);
         }
+    }
+}
+
+// planConstVelTraj (trajectory.cpp:78-91): control point (m, i) of the constant-velocity prediction; time advances
+// by dt / n after every control point, the last of a segment included
+DQ_FN F3 const_vel_point(const float *p, const float *v, double dt, int n1, int m, int i) {
+    double time = 0;
+    const int steps = m * n1 + i;
+    for (int s = 0; s < steps; s++) time += dt / (n1 - 1);
+    const float tf = (float)time;
+    return f3(p[0] + v[0] * tf, p[1] + v[1] * tf, p[2] + v[2] * tf);
+}
+
+// closestPointsBetweenLinePaths (geometry.hpp:113-137): the two points at the common parameter alpha where the
+// straight paths line1 and line2 are closest
+DQ_FN Closest line_paths(F3 s1, F3 e1, F3 s2, F3 e2) {
+    const F3 rs = s2 - s1, re = e2 - e1;  // Line operator-
+    const Closest rel = point_segment(f3(0, 0, 0), rs, re);
+    const double len = distance(rs, re);  // Line::length
+    const double alpha = len > 0 ? norm(rel.p2 - rs) / len : 0.0;
+    Closest c;
+    c.dist = rel.dist;
+    c.p1 = s1 + (e1 - s1) * (float)alpha;
+    c.p2 = s2 + (e2 - s2) * (float)alpha;
+    return c;
+}
+
+// One (agent, dynamic obstacle, segment) item: traj_planner.cpp:616-627.  `row0`: first row of the pair.
+DQ_FN void lsc_dyn_item(const LscGenArgs &g, int self, int o, int m, size_t row0) {
+    const int n = g.n1 - 1, M = g.M;
+    const double r_self = g.radius[self], r_obs = g.dyn_radius[o];
+    const double downwash = (r_self + g.dyn_downwash[o] * r_obs) / (r_self + r_obs);  // :1155-1157
+    const float *op = g.dyn_position + 3 * (size_t)o, *ov = g.dyn_velocity + 3 * (size_t)o;
+    // normalVectorDynamicObs (:1129-1148) -> normalVectorBetweenLines (:1080-1100), untransformed coordinates
+    const F3 os = const_vel_point(op, ov, g.dt, g.n1, m, 0), oe = const_vel_point(op, ov, g.dt, g.n1, m, n);
+    const F3 as = initial_point(g, self, m, 0), ae = initial_point(g, self, m, n);
+    const Closest c = line_paths(os, oe, as, ae);
+    F3 nt = normalized(c.p2 - c.p1);
+    if (norm(nt) == 0) {  // the reference's heuristic for coinciding paths
+        const F3 a = as - os, b = ae - oe;
+        nt = (norm(a) == 0 && norm(b) == 0) ? f3(1, 0, 0) : cross(b - a, f3(0, 0, 1));
+    }
+    const F3 nrm = f3(nt.x, nt.y, (float)((double)nt.z / downwash));  // :618-620
+    // obstacleSizePredictionWithConstAcc (:338-368): radius + 0.5 a t^2 up to the uncertainty horizon, as Bernstein
+    // control points (coef * B_inv with B_inv(k, i) = C(i,k) / C(n,k))
+    int Mu = (int)((g.dyn_uncertainty_horizon + 1e-9) / g.dt);
+    Mu = Mu < M ? Mu : M;
+    const double amax = g.dyn_max_acc[o];
+    const size_t rbase = row0 + (m == 0 ? 0 : (size_t)(g.n1 - g.phi) + (size_t)(m - 1) * g.n1);
+    for (int i = (m == 0 ? g.phi : 0); i < g.n1; i++) {
+        double size = r_obs;
+        if (g.dyn_size_prediction) {
+            if (m < Mu) {
+                const double mt = m * g.dt;
+                const double c0 = 0.5 * amax * (mt * mt), c1 = amax * m * g.dt * g.dt, c2 = 0.5 * amax * (g.dt * g.dt);
+                size = r_obs + (c0 + c1 * ((double)i / n) + c2 * ((double)(i * (i - 1)) / (double)(n * (n - 1))));
+            } else {
+                const double mt = Mu * g.dt;
+                size = r_obs + 0.5 * amax * (mt * mt);
+            }
+        }
+        const F3 pt = const_vel_point(op, ov, g.dt, g.n1, m, i);
+        const size_t r = rbase + (size_t)(i - (m == 0 ? g.phi : 0));
+        g.nx[r] = nrm.x; g.ny[r] = nrm.y; g.nz[r] = nrm.z;
+        g.px[r] = pt.x; g.py[r] = pt.y; g.pz[r] = pt.z;
+        g.d[r] = size + r_self;  // :623
+        g.key[r] = DLSCQP_KEY(m, i, o, 1);
     }
 }
 

@@ -124,9 +124,10 @@ class BatchTrajOptimizer:
         that can be launched any number of times without touching the host."""
         return DeviceBatch(self, agents, row_offsets, rows, sfc, max_slack_obs, want_f64, want_iters, device)
 
-    def make_lsc_generator(self, n_total, nbr_offsets, nbr_ids, radius, downwash, local_ids=None, device=None):
-        """Device-resident DLSC-GC half-space generator for a fixed neighbour structure."""
-        return LscGenerator(self, n_total, nbr_offsets, nbr_ids, radius, downwash, local_ids, device)
+    def make_lsc_generator(self, n_total, nbr_offsets, nbr_ids, radius, downwash, local_ids=None, device=None, dyn=None):
+        """Device-resident DLSC-GC half-space generator for a fixed neighbour structure; `dyn`
+        describes the dynamic obstacles every agent sees (radius, max_acc, downwash, size_prediction, horizon)."""
+        return LscGenerator(self, n_total, nbr_offsets, nbr_ids, radius, downwash, local_ids, device, dyn)
 
     def set_timing(self, capacity):
         self._check(self.lib.dlscqp_set_timing(self.handle, int(capacity)), "dlscqp_set_timing")
@@ -238,7 +239,7 @@ class LscGenerator:
     previous plans (the all-gathered control points) and sub-goals; feeds DeviceBatch without a host round trip.
     Mirrors TrajPlanner::constructLSC -> generateDLSCGC (traj_planner.cpp:498-515, 603-666) for agent obstacles."""
 
-    def __init__(self, opt, n_total, nbr_offsets, nbr_ids, radius, downwash, local_ids, device):
+    def __init__(self, opt, n_total, nbr_offsets, nbr_ids, radius, downwash, local_ids, device, dyn=None):
         import torch
         self.torch = torch
         self.opt = opt
@@ -248,8 +249,11 @@ class LscGenerator:
         nbr_offsets = np.ascontiguousarray(nbr_offsets, dtype=np.int32)
         self.n_local = len(nbr_offsets) - 1
         self.per = cfg.M * (cfg.n + 1) - cfg.phi
-        self.n_rows = self.per * int(nbr_offsets[-1])
-        self.row_offsets = (self.per * nbr_offsets.astype(np.int64))
+        # dynamic obstacles (dict: radius, max_acc, downwash [D]; size_prediction, horizon) follow every agent's neighbours
+        self.n_dyn = 0 if dyn is None else len(dyn["radius"])
+        pairs = nbr_offsets.astype(np.int64) + self.n_dyn * np.arange(self.n_local + 1)
+        self.n_rows = self.per * int(pairs[-1])
+        self.row_offsets = self.per * pairs
         up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)  # noqa: E731
         self.t = dict(nbr_offsets=up(nbr_offsets, np.int32), nbr_ids=up(nbr_ids if len(nbr_ids) else np.zeros(1), np.int32),
                       radius=up(radius, np.float64), downwash=up(downwash, np.float64),
@@ -265,13 +269,25 @@ class LscGenerator:
         g.nbr_offsets, g.nbr_ids = self.t["nbr_offsets"].data_ptr(), self.t["nbr_ids"].data_ptr()
         for k in ("nx", "ny", "nz", "px", "py", "pz", "d", "key"):
             setattr(g, k, self.soa[k].data_ptr())
+        if self.n_dyn:
+            self.t.update(dyn_radius=up(dyn["radius"], np.float64), dyn_max_acc=up(dyn["max_acc"], np.float64),
+                          dyn_downwash=up(dyn["downwash"], np.float64))
+            g.n_dyn = self.n_dyn
+            g.dyn_size_prediction = int(dyn.get("size_prediction", 1))
+            g.dyn_uncertainty_horizon = float(dyn.get("horizon", 1.0))
+            g.dyn_radius, g.dyn_max_acc = self.t["dyn_radius"].data_ptr(), self.t["dyn_max_acc"].data_ptr()
+            g.dyn_downwash = self.t["dyn_downwash"].data_ptr()
         self.c = g
         self.n_total = n_total
 
-    def generate(self, goals, plans=None, position=None, velocity=None, stream=None):
+    def generate(self, goals, plans=None, position=None, velocity=None, stream=None, dyn_position=None, dyn_velocity=None):
         """goals [n_total,3] f32 and either plans [n_total,M,n+1,3] f32 (previous plans) or position/velocity
-        (first replanning step): CUDA tensors.  Asynchronous."""
+        (first replanning step); dyn_position / dyn_velocity [n_dyn,3] f32 when the generator has dynamic obstacles:
+        CUDA tensors.  Asynchronous."""
         g = self.c
+        if self.n_dyn:
+            g.dyn_position, g.dyn_velocity = dyn_position.data_ptr(), dyn_velocity.data_ptr()
+            self._keep_dyn = (dyn_position, dyn_velocity)
         g.first_plan = 1 if plans is None else 0
         g.plans = None if plans is None else plans.data_ptr()
         g.position = None if position is None else position.data_ptr()

@@ -228,9 +228,23 @@ typedef struct dlscqp_lsc_gen {
     const double *downwash;     /* [n_total]                                                        */
     const int32_t *nbr_offsets; /* [n_local+1]                                                      */
     const int32_t *nbr_ids;     /* [nbr_offsets[n_local]] neighbour ids, = obstacle order oi        */
-    float *nx, *ny, *nz, *px, *py, *pz; /* outputs, [per * nbr_offsets[n_local]]                    */
+    float *nx, *ny, *nz, *px, *py, *pz; /* outputs, [per * (nbr_offsets[n_local] + n_local * n_dyn)]  */
     double *d;
     uint32_t *key;
+    /* Dynamic (non-agent) obstacles, seen by every local agent: generateDLSCGC's branch for
+     * ObstacleType != AGENT (traj_planner.cpp:616-627) with normalVectorDynamicObs (:1129-1148), the
+     * constant-velocity prediction (:293-303) and obstacleSizePredictionWithConstAcc (:338-368).  Local agent k's
+     * rows are [per*(nbr_offsets[k] + k*n_dyn), per*(nbr_offsets[k+1] + (k+1)*n_dyn)): its neighbour agents
+     * first, then the dynamic obstacles in order; obstacle s uses slack variable s and the DYNAMIC flag.
+     * n_dyn = 0 (and NULL pointers) keeps the agents-only behaviour. */
+    int32_t n_dyn;
+    int32_t dyn_size_prediction;      /* param.obs_size_prediction                                       */
+    double dyn_uncertainty_horizon;   /* param.obs_uncertainty_horizon                                   */
+    const float *dyn_position;        /* [n_dyn][3]                                                      */
+    const float *dyn_velocity;        /* [n_dyn][3]                                                      */
+    const double *dyn_radius;         /* [n_dyn]                                                         */
+    const double *dyn_max_acc;        /* [n_dyn]                                                         */
+    const double *dyn_downwash;       /* [n_dyn]                                                         */
 } dlscqp_lsc_gen;
 
 int dlscqp_generate_lsc_device(dlscqp_ctx *ctx, const dlscqp_lsc_gen *gen, void *stream);

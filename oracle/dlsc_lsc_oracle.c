@@ -8,6 +8,7 @@
 #include "dlsc_oracle.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #define SP_EPSILON_FLOAT 1e-5
@@ -299,5 +300,84 @@ int oracle_generate_dlscgc(const dlscqp_config *cfg, const float *init_self, con
             }
         }
     }
+    return nr;
+}
+
+
+/* ---- dynamic (non-agent) obstacles: traj_planner.cpp:616-627 ------------------------------------------------ */
+
+/* closestPointsBetweenLinePaths, geometry.hpp:113-137 */
+static closest_t line_paths(v3 s1, v3 e1, v3 s2, v3 e2) {
+    v3 rs = v3_sub(s2, s1), re = v3_sub(e2, e1); /* Line operator-, geometry.hpp:32-34 */
+    v3 origin = {0, 0, 0};
+    closest_t rel = point_segment(origin, rs, re);
+    double len = v3_dist(rs, re); /* Line::length */
+    double alpha = len > 0 ? v3_norm(v3_sub(rel.p2, rs)) / len : 0.0;
+    closest_t c;
+    c.dist = rel.dist;
+    c.p1 = v3_add(s1, v3_mulf(v3_sub(e1, s1), (float)alpha));
+    c.p2 = v3_add(s2, v3_mulf(v3_sub(e2, s2), (float)alpha));
+    return c;
+}
+
+int oracle_generate_dlscgc_dynamic(const dlscqp_config *cfg, const float *init_self, double radius_self, int n_dyn,
+                                   const float *dyn_position, const float *dyn_velocity, const double *dyn_radius,
+                                   const double *dyn_max_acc, const double *dyn_downwash, int size_prediction,
+                                   double uncertainty_horizon, int obs_base, dlscqp_lsc_row *rows_out) {
+    const int M = cfg->M, n = cfg->n, N = n + 1, phi = cfg->phi;
+    float *pred = (float *)malloc(sizeof(float) * M * N * 3);
+    double *size = (double *)malloc(sizeof(double) * M * N);
+    int nr = 0;
+    /* B_inv of polynomial.hpp:280-293 restated: power basis -> Bernstein, B_inv(k, i) = C(i,k) / C(n,k) */
+    for (int o = 0; o < n_dyn; o++) {
+        const double downwash = (radius_self + dyn_downwash[o] * dyn_radius[o]) / (radius_self + dyn_radius[o]); /* :1155-1157 */
+        oracle_const_vel_plan(dyn_position + 3 * o, dyn_velocity + 3 * o, M, n, cfg->dt, pred); /* :293-303 */
+        /* obstacleSizePredictionWithConstAcc, :338-368 */
+        int Mu = (int)((uncertainty_horizon + 1e-9) / cfg->dt);
+        if (Mu > M) Mu = M;
+        for (int m = 0; m < M; m++)
+            for (int i = 0; i < N; i++) {
+                double sz = dyn_radius[o];
+                if (size_prediction) {
+                    if (m < Mu) {
+                        double coef[3] = {0.5 * dyn_max_acc[o] * pow(m * cfg->dt, 2), dyn_max_acc[o] * m * cfg->dt * cfg->dt,
+                                          0.5 * dyn_max_acc[o] * pow(cfg->dt, 2)};
+                        double cp = 0, cik = 1, cnk = 1; /* C(i,k), C(n,k) */
+                        for (int k = 0; k < 3; k++) {
+                            if (k > 0) { cik = cik * (i - k + 1) / k; cnk = cnk * (n - k + 1) / k; }
+                            cp += coef[k] * (i >= k ? cik / cnk : 0.0);
+                        }
+                        sz = dyn_radius[o] + cp;
+                    } else {
+                        sz = dyn_radius[o] + 0.5 * dyn_max_acc[o] * pow(Mu * cfg->dt, 2);
+                    }
+                }
+                size[m * N + i] = sz;
+            }
+        for (int m = 0; m < M; m++) {
+            /* normalVectorDynamicObs :1129-1148 -> normalVectorBetweenLines :1080-1100 */
+            v3 os = ld(pred + (m * N) * 3), oe = ld(pred + (m * N + n) * 3);
+            v3 as = ld(init_self + (m * N) * 3), ae = ld(init_self + (m * N + n) * 3);
+            closest_t c = line_paths(os, oe, as, ae);
+            v3 nt = v3_normalized(v3_sub(c.p2, c.p1));
+            if (v3_norm(nt) == 0) {
+                v3 a = v3_sub(as, os), b = v3_sub(ae, oe), ez = {0, 0, 1}, ex = {1, 0, 0};
+                nt = (v3_norm(a) == 0 && v3_norm(b) == 0) ? ex : v3_cross(v3_sub(b, a), ez);
+            }
+            v3 nrm = {nt.x, nt.y, (float)((double)nt.z / downwash)}; /* :618-620 */
+            for (int i = 0; i < N; i++) {
+                if (m == 0 && i < phi) continue;
+                dlscqp_lsc_row *r = &rows_out[nr++];
+                memset(r, 0, sizeof *r);
+                r->normal[0] = nrm.x; r->normal[1] = nrm.y; r->normal[2] = nrm.z;
+                for (int k = 0; k < 3; k++) r->point[k] = pred[(m * N + i) * 3 + k];
+                r->d = size[m * N + i] + radius_self; /* :623 */
+                r->m = (int16_t)m; r->i = (int8_t)i; r->obs = (int16_t)(obs_base + o); r->slack = (int16_t)o;
+                r->flags = DLSCQP_ROW_DYNAMIC;
+            }
+        }
+    }
+    free(pred);
+    free(size);
     return nr;
 }

@@ -115,6 +115,14 @@ int oracle_generate_dlscgc(const dlscqp_config *cfg, const float *init_self, con
                            const float *goal_nbr /*[n_nbr][3]*/, const double *radius_nbr,
                            const double *downwash_nbr, dlscqp_lsc_row *rows_out);
 
+/* The same for `n_dyn` dynamic (non-agent) obstacles: constant-velocity prediction (:293-303), size prediction with
+ * constant acceleration (:338-368), normalVectorDynamicObs (:1129-1148), rows at :616-627.  Obstacle o gets slack
+ * index o, obs index obs_base + o and the DYNAMIC flag.  Returns the row count, n_dyn * (M*(n+1) - phi). */
+int oracle_generate_dlscgc_dynamic(const dlscqp_config *cfg, const float *init_self, double radius_self, int n_dyn,
+                                   const float *dyn_position, const float *dyn_velocity, const double *dyn_radius,
+                                   const double *dyn_max_acc, const double *dyn_downwash, int size_prediction,
+                                   double uncertainty_horizon, int obs_base, dlscqp_lsc_row *rows_out);
+
 #ifdef __cplusplus
 }
 #endif

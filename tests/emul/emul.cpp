@@ -197,11 +197,20 @@ extern "C" int emul_generate_lsc(const dlscqp_config *cfg, const dlscqp_lsc_gen 
     g.nbr_offsets = gen->nbr_offsets; g.nbr_ids = gen->nbr_ids;
     g.nx = gen->nx; g.ny = gen->ny; g.nz = gen->nz; g.px = gen->px; g.py = gen->py; g.pz = gen->pz;
     g.d = gen->d; g.key = gen->key;
+    g.n_dyn = gen->n_dyn > 0 ? gen->n_dyn : 0;
+    g.dyn_size_prediction = gen->dyn_size_prediction;
+    g.dyn_uncertainty_horizon = gen->dyn_uncertainty_horizon;
+    g.dyn_position = gen->dyn_position; g.dyn_velocity = gen->dyn_velocity;
+    g.dyn_radius = gen->dyn_radius; g.dyn_max_acc = gen->dyn_max_acc; g.dyn_downwash = gen->dyn_downwash;
     const int per = g.M * g.n1 - g.phi;
-    for (int k = 0; k < g.n_local; k++) {
+    for (int k = 0; k < g.n_local; k++) {  // same item -> row mapping as dlscqp_lsc_kernel
         const int self = g.local_ids ? g.local_ids[k] : k;
-        for (int p = g.nbr_offsets[k]; p < g.nbr_offsets[k + 1]; p++)
-            for (int m = 0; m < g.M; m++) lsc_item(g, self, g.nbr_ids[p], m, (size_t)per * (size_t)p);
+        const int p0 = g.nbr_offsets[k], p1 = g.nbr_offsets[k + 1];
+        const size_t pair0 = (size_t)p0 + (size_t)k * g.n_dyn;
+        for (int p = p0; p < p1; p++)
+            for (int m = 0; m < g.M; m++) lsc_item(g, self, g.nbr_ids[p], m, (size_t)per * (pair0 + (p - p0)));
+        for (int o = 0; o < g.n_dyn; o++)
+            for (int m = 0; m < g.M; m++) lsc_dyn_item(g, self, o, m, (size_t)per * (pair0 + (p1 - p0) + o));
     }
     return 0;
 }

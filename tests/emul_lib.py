@@ -65,16 +65,18 @@ def table_info(cfg, max_slack_obs=0, kmax=0):
     return dict(f=v[0].value, n_slots=v[1].value, nb=v[2].value, lds_bytes=v[3].value)
 
 
-def generate_lsc(cfg, plans, goals, radius, downwash, nbr_offsets, nbr_ids, local_ids=None, position=None, velocity=None):
-    """Row N1 through the host build of lsc_core.hpp.  Returns (row_offsets, rows as ROW_DTYPE)."""
+def generate_lsc(cfg, plans, goals, radius, downwash, nbr_offsets, nbr_ids, local_ids=None, position=None, velocity=None,
+                 dyn=None):
+    """Row N1 through the host build of lsc_core.hpp.  Returns (row_offsets, rows as ROW_DTYPE).
+    dyn: None or dict(position [D,3], velocity [D,3], radius [D], max_acc [D], downwash [D], size_prediction, horizon)."""
     L = lib()
     L.emul_generate_lsc.argtypes = [C.POINTER(abi.Config), C.POINTER(abi.LscGen)]
     L.emul_generate_lsc.restype = C.c_int
     return _run_lsc_gen(cfg, lambda g: L.emul_generate_lsc(C.byref(cfg), C.byref(g)), plans, goals, radius, downwash,
-                        nbr_offsets, nbr_ids, local_ids, position, velocity)
+                        nbr_offsets, nbr_ids, local_ids, position, velocity, dyn)
 
 
-def _run_lsc_gen(cfg, call, plans, goals, radius, downwash, nbr_offsets, nbr_ids, local_ids, position, velocity):
+def _run_lsc_gen(cfg, call, plans, goals, radius, downwash, nbr_offsets, nbr_ids, local_ids, position, velocity, dyn=None):
     first = plans is None
     keep = []
 
@@ -99,7 +101,18 @@ def _run_lsc_gen(cfg, call, plans, goals, radius, downwash, nbr_offsets, nbr_ids
     _, g.downwash = arr(downwash, np.float64)
     g.nbr_offsets, g.nbr_ids = nbr_offsets.ctypes.data, nbr_ids_a.ctypes.data
     per = cfg.M * (cfg.n + 1) - cfg.phi
-    R = per * int(nbr_offsets[-1])
+    n_dyn = 0 if dyn is None else len(dyn["radius"])
+    if n_dyn:
+        g.n_dyn = n_dyn
+        g.dyn_size_prediction = int(dyn.get("size_prediction", 1))
+        g.dyn_uncertainty_horizon = float(dyn.get("horizon", 1.0))
+        _, g.dyn_position = arr(dyn["position"], np.float32)
+        _, g.dyn_velocity = arr(dyn["velocity"], np.float32)
+        _, g.dyn_radius = arr(dyn["radius"], np.float64)
+        _, g.dyn_max_acc = arr(dyn["max_acc"], np.float64)
+        _, g.dyn_downwash = arr(dyn["downwash"], np.float64)
+    pairs = nbr_offsets.astype(np.int64) + n_dyn * np.arange(n_local + 1)
+    R = per * int(pairs[-1])
     out = {k: np.zeros(R + 1, np.float32) for k in ("nx", "ny", "nz", "px", "py", "pz")}
     out["d"] = np.zeros(R + 1)
     out["key"] = np.zeros(R + 1, np.uint32)
@@ -107,7 +120,7 @@ def _run_lsc_gen(cfg, call, plans, goals, radius, downwash, nbr_offsets, nbr_ids
         setattr(g, k, v.ctypes.data)
     rc = call(g)
     assert rc == 0
-    return (per * nbr_offsets.astype(np.int64)), soa_to_rows(out, R)
+    return per * pairs, soa_to_rows(out, R)
 
 
 def soa_to_rows(soa, R):

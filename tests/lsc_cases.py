@@ -43,3 +43,19 @@ def random_swarm(cfg, n_agents, seed, spread=2.5, first=False):
         offs.append(len(ids))
     return dict(plans=plans, goals=goals, radius=radius, downwash=downwash, nbr_offsets=np.array(offs, np.int32),
                 nbr_ids=np.array(ids, np.int32), position=pos, velocity=vel)
+
+
+def random_dynamic_obstacles(n_dyn, seed, spread=2.5, first_at=None):
+    """Spin-obstacle-like dynamic obstacles (position, velocity, radius, max_acc, downwash) plus the two planner
+    parameters of the size prediction.  `first_at`: a (position, velocity) pair that obstacle 0 copies, to hit the
+    reference's heuristic for coinciding paths."""
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(-spread, spread, (n_dyn, 3)).astype(np.float32)
+    pos[:, 2] = rng.uniform(0.5, 2.0, n_dyn)
+    vel = rng.uniform(-1.0, 1.0, (n_dyn, 3)).astype(np.float32)
+    if n_dyn > 1:
+        vel[1] = 0  # a standing obstacle: degenerate (zero-length) obstacle path
+    if first_at is not None and n_dyn > 0:
+        pos[0], vel[0] = first_at
+    return dict(position=pos, velocity=vel, radius=rng.uniform(0.1, 0.4, n_dyn), max_acc=rng.uniform(0.0, 3.0, n_dyn),
+                downwash=rng.choice([1.0, 2.0, 3.0], n_dyn), size_prediction=1, horizon=0.6)

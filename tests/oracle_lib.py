@@ -221,10 +221,21 @@ def const_vel_plan(pos, vel, M, n, dt):
     return out
 
 
-def generate_dlscgc(cfg, init, goals, radius, downwash, nbr_offsets, nbr_ids, local_ids=None):
-    """DLSC-GC rows of the agents `local_ids` (default: all) against their neighbour lists.
+def generate_dlscgc(cfg, init, goals, radius, downwash, nbr_offsets, nbr_ids, local_ids=None, dyn=None):
+    """DLSC-GC rows of the agents `local_ids` (default: all) against their neighbour lists, followed by the rows of the
+    dynamic obstacles `dyn` (dict as in emul_lib.generate_lsc) if any.
     init [N][M][n+1][3] float32 (shifted plans of ALL agents), goals [N][3].  Returns (row_offsets, rows)."""
     L = lib()
+    L.oracle_generate_dlscgc_dynamic.argtypes = [C.POINTER(abi.Config), C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_void_p]
+    L.oracle_generate_dlscgc_dynamic.restype = C.c_int
+    n_dyn = 0 if dyn is None else len(dyn["radius"])
+    if n_dyn:
+        dpos = np.ascontiguousarray(dyn["position"], dtype=np.float32)
+        dvel = np.ascontiguousarray(dyn["velocity"], dtype=np.float32)
+        drad = np.ascontiguousarray(dyn["radius"], dtype=np.float64)
+        dacc = np.ascontiguousarray(dyn["max_acc"], dtype=np.float64)
+        ddw = np.ascontiguousarray(dyn["downwash"], dtype=np.float64)
     L.oracle_generate_dlscgc.argtypes = [C.POINTER(abi.Config), C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_int,
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.oracle_generate_dlscgc.restype = C.c_int
@@ -248,5 +259,13 @@ def generate_dlscgc(cfg, init, goals, radius, downwash, nbr_offsets, nbr_ids, lo
                                        len(nb), ptrs, _ptr(g), _ptr(rr), _ptr(dw), _ptr(rows))
         assert cnt == len(rows)
         out.append(rows)
+        if n_dyn:
+            drows = np.zeros(n_dyn * per, abi.ROW_DTYPE)
+            c2 = L.oracle_generate_dlscgc_dynamic(C.byref(cfg), _ptr(init[a]), float(radius[a]), n_dyn, _ptr(dpos), _ptr(dvel),
+                                                  _ptr(drad), _ptr(dacc), _ptr(ddw), int(dyn.get("size_prediction", 1)),
+                                                  float(dyn.get("horizon", 1.0)), len(nb), _ptr(drows))
+            assert c2 == len(drows)
+            out.append(drows)
+            cnt += c2
         offs.append(offs[-1] + cnt)
     return np.array(offs, np.int64), (np.concatenate(out) if out else np.zeros(0, abi.ROW_DTYPE))

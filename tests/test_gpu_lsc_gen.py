@@ -75,3 +75,72 @@ def test_generated_rows_feed_the_qp_kernel_directly(gpu_required):
     ok = same & (ref["status"] == abi.OK)
     assert ok.sum() > 10
     assert np.abs(got["x"][ok] - ref["x"][ok]).max() < 1e-4
+
+
+@pytest.mark.parametrize("M,dim,first", [(5, 3, False), (10, 2, False), (5, 3, True)])
+def test_device_rows_match_oracle_with_dynamic_obstacles(gpu_required, M, dim, first):
+    cfg = abi.make_config(dim=dim, M=M)
+    sw = lsc_cases.random_swarm(cfg, 32, seed=700 + M + dim)
+    dyn = lsc_cases.random_dynamic_obstacles(5, seed=70 + M, first_at=(sw["position"][0], sw["velocity"][0]) if first else None)
+    ro, rows = _oracle_rows(cfg, sw, first, dyn=dyn)
+    opt = BatchTrajOptimizer(cfg)
+    try:
+        gen = opt.make_lsc_generator(32, sw["nbr_offsets"], sw["nbr_ids"], sw["radius"], sw["downwash"], dyn=dyn)
+        goals = torch.from_numpy(sw["goals"]).cuda()
+        dp, dv = torch.from_numpy(dyn["position"]).cuda(), torch.from_numpy(dyn["velocity"]).cuda()
+        if first:
+            gen.generate(goals, position=torch.from_numpy(sw["position"]).cuda(), velocity=torch.from_numpy(sw["velocity"]).cuda(),
+                         dyn_position=dp, dyn_velocity=dv)
+        else:
+            gen.generate(goals, plans=torch.from_numpy(sw["plans"]).cuda(), dyn_position=dp, dyn_velocity=dv)
+        go, grows = gen.rows_host()
+    finally:
+        opt.close()
+    assert np.array_equal(go, ro)
+    assert (grows["flags"] == abi.ROW_DYNAMIC).sum() == 32 * 5 * (M * (cfg.n + 1) - cfg.phi)
+    _cmp_rows(grows, rows)
+
+
+def test_generated_rows_with_dynamic_obstacles_feed_the_qp_kernel(gpu_required):
+    """The same chain with two dynamic obstacles: their rows carry slack variables (soft constraints), the batch is
+    planned by the slack-capable instantiation, and the slack cost per obstacle matches the oracle chain."""
+    cfg = abi.make_config(dim=3, M=5, slack_collision_weight=100.0)
+    N, D = 24, 2
+    sw = lsc_cases.random_swarm(cfg, N, seed=78, spread=3.0)
+    dyn = lsc_cases.random_dynamic_obstacles(D, seed=8, spread=3.0)
+    rng = np.random.default_rng(6)
+    agents = np.zeros(N, abi.AGENT_DTYPE)
+    init = np.stack([O.shift_plan(p) for p in sw["plans"]])
+    n = cfg.n
+    agents["position"] = init[:, 0, 0]
+    agents["velocity"] = (init[:, 0, 1] - init[:, 0, 0]) * np.float32(n / cfg.dt)
+    agents["acceleration"] = ((init[:, 0, 2] - init[:, 0, 1]) - (init[:, 0, 1] - init[:, 0, 0])) * np.float32(n * (n - 1) / cfg.dt ** 2)
+    agents["current_goal_point"] = sw["goals"]
+    agents["next_waypoint"] = sw["goals"] + rng.uniform(-0.3, 0.3, (N, 3)).astype(np.float32)
+    agents["max_vel"], agents["max_acc"], agents["radius"], agents["nominal_velocity"] = 2.0, 20.0, 0.15, 1.0
+    agents["n_obs"] = np.diff(sw["nbr_offsets"]) + D
+    agents["n_slack_obs"] = D
+    ro, rows = _oracle_rows(cfg, sw, dyn=dyn)
+    ref = O.plan_batch(cfg, agents, ro, rows, None, D, True)
+    opt = BatchTrajOptimizer(cfg)
+    try:
+        gen = opt.make_lsc_generator(N, sw["nbr_offsets"], sw["nbr_ids"], sw["radius"], sw["downwash"], dyn=dyn)
+        gen.generate(torch.from_numpy(sw["goals"]).cuda(), plans=torch.from_numpy(sw["plans"]).cuda(),
+                     dyn_position=torch.from_numpy(dyn["position"]).cuda(), dyn_velocity=torch.from_numpy(dyn["velocity"]).cuda())
+        db = opt.make_device_batch(agents, ro, rows[:0], None, D, want_f64=True)
+        for k in ("nx", "ny", "nz", "px", "py", "pz", "d", "key"):
+            setattr(db.c, k, gen.soa[k].data_ptr())
+        ro32 = torch.from_numpy(ro.astype(np.int32)).cuda()
+        db.c.row_offsets = ro32.data_ptr()
+        db.c.max_rows_per_agent = int(np.diff(ro).max())
+        db.launch()
+        got = db.results()
+    finally:
+        opt.close()
+    assert np.array_equal(got["goal_status"], ref["goal_status"])
+    same = got["status"] == ref["status"]
+    assert same.mean() > 0.9
+    ok = same & (ref["status"] == abi.OK)
+    assert ok.sum() > 8
+    assert np.abs(got["x"][ok] - ref["x"][ok]).max() < 1e-4
+    assert np.abs(got["slack_cost"][ok] - ref["slack_cost"][ok]).max() < 1e-4

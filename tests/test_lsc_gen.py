@@ -25,12 +25,12 @@ def _cmp_rows(a, b, nrm_tol=NRM_TOL, d_tol=D_TOL):
     assert np.abs(a["d"] - b["d"]).max() <= d_tol
 
 
-def _oracle_rows(cfg, sw, first=False):
+def _oracle_rows(cfg, sw, first=False, dyn=None):
     if first:
         init = np.stack([O.const_vel_plan(sw["position"][a], sw["velocity"][a], cfg.M, cfg.n, cfg.dt) for a in range(len(sw["goals"]))])
     else:
         init = np.stack([O.shift_plan(p) for p in sw["plans"]])
-    return O.generate_dlscgc(cfg, init, sw["goals"], sw["radius"], sw["downwash"], sw["nbr_offsets"], sw["nbr_ids"])
+    return O.generate_dlscgc(cfg, init, sw["goals"], sw["radius"], sw["downwash"], sw["nbr_offsets"], sw["nbr_ids"], dyn=dyn)
 
 
 def test_hull_enumeration_equals_reference_opengjk():
@@ -107,3 +107,62 @@ def test_shifted_plans_satisfy_their_own_half_spaces():
         cp = init[a][r["m"], r["i"]].astype(np.float64)
         lhs = np.einsum("kd,kd->k", r["normal"].astype(np.float64), cp - r["point"].astype(np.float64)) - r["d"]
         assert lhs.min() > -1e-6
+
+
+# ---- dynamic (non-agent) obstacles -------------------------------------------------------------------------------
+def _binom(a, b):
+    from math import comb
+    return comb(a, b)
+
+
+def test_power_to_bernstein_closed_form_is_b_inverse():
+    """The size prediction multiplies power-basis coefficients by B_inv (traj_planner.cpp:352-358); oracle and device
+    use B_inv(k, i) = C(i,k) / C(n,k).  B as in polynomial.hpp:280-293."""
+    n = 5
+    B = np.zeros((n + 1, n + 1))
+    for i in range(n + 1):
+        for j in range(i, n + 1):
+            B[i, j] = _binom(n, i) * _binom(n - i, n - j) * (-1) ** (j - i)
+    Binv = np.linalg.inv(B)
+    closed = np.array([[(_binom(i, k) / _binom(n, k)) if i >= k else 0.0 for i in range(n + 1)] for k in range(n + 1)])
+    assert np.abs(Binv - closed).max() < 1e-12
+
+
+@pytest.mark.parametrize("M,dim,first", [(5, 3, False), (10, 3, False), (10, 2, False), (5, 3, True)])
+def test_device_source_matches_oracle_with_dynamic_obstacles(M, dim, first):
+    cfg = abi.make_config(dim=dim, M=M)
+    sw = lsc_cases.random_swarm(cfg, 12, seed=300 + M + dim)
+    # obstacle 0 moves exactly like agent 0's path in the first-plan case (coinciding paths -> the reference's heuristic)
+    dyn = lsc_cases.random_dynamic_obstacles(4, seed=9 + M, first_at=(sw["position"][0], sw["velocity"][0]) if first else None)
+    ro, rows = _oracle_rows(cfg, sw, first, dyn=dyn)
+    kw = dict(position=sw["position"], velocity=sw["velocity"]) if first else {}
+    eo, erows = E.generate_lsc(cfg, None if first else sw["plans"], sw["goals"], sw["radius"], sw["downwash"], sw["nbr_offsets"],
+                               sw["nbr_ids"], dyn=dyn, **kw)
+    assert np.array_equal(ro, eo)
+    per = cfg.M * (cfg.n + 1) - cfg.phi
+    assert len(rows) == per * (int(sw["nbr_offsets"][-1]) + 12 * 4)
+    _cmp_rows(erows, rows)
+    dynrows = rows[rows["flags"] == abi.ROW_DYNAMIC]
+    assert len(dynrows) == 12 * 4 * per and set(np.unique(dynrows["slack"])) == {0, 1, 2, 3}
+    assert np.isfinite(dynrows["normal"]).all() and (np.linalg.norm(dynrows["normal"], axis=1) > 0).all()
+
+
+def test_dynamic_obstacle_size_prediction_profile():
+    """d = predicted size + agent radius: radius + 0.5 a t^2 sampled as Bernstein control points up to the uncertainty
+    horizon, constant afterwards (traj_planner.cpp:338-368)."""
+    cfg = abi.make_config(dim=3, M=5)
+    sw = lsc_cases.random_swarm(cfg, 2, seed=1)
+    sw["nbr_offsets"], sw["nbr_ids"] = np.zeros(3, np.int32), np.zeros(0, np.int32)
+    dyn = dict(position=np.float32([[0, 0, 1]]), velocity=np.float32([[0.5, 0, 0]]), radius=np.array([0.3]),
+               max_acc=np.array([2.0]), downwash=np.array([1.0]), size_prediction=1, horizon=0.6)
+    _, rows = _oracle_rows(cfg, sw, dyn=dyn)
+    r0 = rows[:cfg.M * (cfg.n + 1) - cfg.phi]
+    ra = sw["radius"][0]
+    t_end = {m: (m + 1) * cfg.dt for m in range(cfg.M)}
+    for m in range(cfg.M):
+        last = r0[(r0["m"] == m) & (r0["i"] == cfg.n)]["d"][0]  # last control point = value at the end of the segment
+        t = min(t_end[m], 0.6)
+        assert abs(last - (0.3 + 0.5 * 2.0 * t * t + ra)) < 1e-12
+    off = dict(dyn, size_prediction=0)
+    _, rows2 = _oracle_rows(cfg, sw, dyn=off)
+    assert np.allclose(rows2[:len(r0)]["d"], 0.3 + ra)
