@@ -62,6 +62,41 @@ def cpu_baseline(cfg, wl, target_seconds=12.0):
             "ref_published_note": "reference log: 11.18 ms/QP mean, CPLEX 22.1.1 Threads=6, 2-D M=10, unknown CPU"}
 
 
+def closed_loop_latency(device):
+    """p50 / p99 wall time of one replanning step of the reference's empty10 / empty60 missions (BASELINE.json
+    configs[0] and [2]) flown by the device-resident closed loop: half-space generation + goal LP + QP + state update
+    for all agents of the mission, synchronised after every step (dlsc_gc_planner_amd/harness.py)."""
+    import torch
+    from dlsc_gc_planner_amd import abi
+    from dlsc_gc_planner_amd.harness import ClosedLoop
+    path = os.path.join(ROOT, "tests", "golden", "missions_empty.json")
+    if not os.path.exists(path):
+        return None
+    missions = json.load(open(path))
+    out = {}
+    for name in ("empty10_1", "empty60_1"):
+        m = missions[name]
+        w = m["world"]
+        cfg = abi.make_config(dim=3, M=5, dt=0.2, control_input_weight=0.01, terminal_weight=1.0, communication_range=-1.0,
+                              world_use_octomap=False, world_min=tuple(w[:3]), world_max=tuple(w[3:]), device=device)
+        sim = ClosedLoop(cfg, np.array(m["start"], np.float32), np.array(m["goal"], np.float32), radius=m["radius"],
+                         downwash=m["downwash"], max_vel=m["max_vel"], max_acc=m["max_acc"],
+                         nominal_velocity=m["nominal_velocity"], device=device)
+        ts, fails = [], 0
+        for k in range(60):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            status, _ = sim.step()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+            fails += int((status != abi.OK).sum())
+        sim.close()
+        ts = np.array(ts[10:])
+        out[name] = {"agents": len(m["start"]), "lsc_rows_per_agent": (len(m["start"]) - 1) * 27, "steps": len(ts),
+                     "p50_ms": float(np.percentile(ts, 50)), "p99_ms": float(np.percentile(ts, 99)), "qp_failsafes": fails}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -224,6 +259,9 @@ def main():
             opt.plan(a1, ro1, r1, None, 0, True, True)
             lat.append((time.perf_counter() - t1) * 1e3)
         lat = np.array(lat[10:]) if lat else np.array([float("nan")])
+        closed = None
+        if not args.no_latency and world == 1:
+            closed = closed_loop_latency(local_rank)
         line = {
             "metric": "agent-QP solves/sec (goal LP + trajectory QP per agent per replanning step)",
             "value": world * N * args.steps / elapsed,
@@ -253,6 +291,7 @@ def main():
             },
             "p50_replan_ms_one_swarm_host_to_host": float(np.percentile(lat, 50)),
             "p99_replan_ms_one_swarm_host_to_host": float(np.percentile(lat, 99)),
+            "closed_loop_replan_ms": closed,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

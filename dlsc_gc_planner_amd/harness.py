@@ -9,17 +9,77 @@ plan table.  torch is plumbing only (state bookkeeping: a handful of elementwise
 
 Not reproduced (out of scope): the grid planner / PIBT that hands out waypoints in the
 reference (N4) -- the waypoint here is the point `waypoint_step` metres ahead on the straight line to the
-desired goal -- and static / dynamic obstacles (N2).
+desired goal -- and static obstacles (N2).  Dynamic obstacles: `dyn` (constant-velocity obstacles, rows from
+dlscqp_generate_lsc_device's dynamic branch, soft constraints with slack variables).
+
+ResultCsv writes the reference's log/result_*.csv layout (multi_sync_simulator.cpp:735-850), so that its replay and
+analysis scripts can read a run of this harness.
 """
+import time
+
 import numpy as np
 
 from . import abi
 from .planner import BatchTrajOptimizer
 
 
+def plan_state_at(plans, n, dt, tau):
+    """Position, velocity, acceleration of every agent `tau` seconds into segment 0 of `plans` [N, M, n+1, 3]
+    (Trajectory<point3d>::getStateAt, trajectory.cpp:110-199: float32 control-point differences, Bernstein weights).
+    Works on numpy arrays and torch tensors alike."""
+    from math import comb
+    c = plans[:, 0]
+    s = tau / dt
+
+    def bern(ctrl, deg):
+        w = [comb(deg, i) * s ** i * (1 - s) ** (deg - i) for i in range(deg + 1)]
+        out = ctrl[:, 0] * np.float32(w[0])
+        for i in range(1, deg + 1):
+            out = out + ctrl[:, i] * np.float32(w[i])
+        return out
+
+    v = (c[:, 1:] - c[:, :-1]) * np.float32(n / dt)
+    a = (v[:, 1:] - v[:, :-1]) * np.float32((n - 1) / dt)
+    return bern(c, n), bern(v, n - 1), bern(a, n - 2)
+
+
+class ResultCsv:
+    """The reference's result file: one header, then per replanning step one line per recorded time (future_time =
+    0, save_time_step, ... < dt), each line `id,t,px,py,pz,vx,vy,vz,ax,ay,az,planning_time` for every agent followed by
+    `obs_id,t,px,py,pz,size` for every dynamic obstacle.  Numbers as C++ iostreams print them (%g, 6 digits)."""
+
+    def __init__(self, path, n_agents, n_obs=0, save_time_step=0.1):
+        self.fh = open(path, "w")
+        self.n_agents, self.n_obs, self.save_time_step = n_agents, n_obs, save_time_step
+        cols = ["id,t,px,py,pz,vx,vy,vz,ax,ay,az,planning_time"] * n_agents + ["obs_id,t,px,py,pz,size"] * n_obs
+        self.fh.write(",".join(cols) + "\n")
+
+    def write_step(self, t, plans, n, dt, planning_time, obs_state=None):
+        """plans: numpy [N, M, n+1, 3] just planned at simulation time t; obs_state(tau) -> (pos [D,3], size [D])."""
+        tau = 0.0
+        while tau < dt - 1e-12:
+            p, v, a = plan_state_at(plans, n, dt, tau)
+            cells = []
+            for q in range(self.n_agents):
+                vals = [q, t + tau, *p[q], *v[q], *a[q], planning_time]
+                cells.append(",".join("%g" % float(x) for x in vals))
+            if self.n_obs:
+                op, osz = obs_state(tau)
+                for o in range(self.n_obs):
+                    cells.append(",".join("%g" % float(x) for x in (o, t + tau, *op[o], osz[o])))
+            self.fh.write(",".join(cells) + "\n")
+            tau += self.save_time_step
+
+    def close(self):
+        self.fh.close()
+
+
 class ClosedLoop:
     def __init__(self, cfg, start, goal, radius=0.15, downwash=2.0, max_vel=1.0, max_acc=2.0, nominal_velocity=1.0,
-                 waypoint_step=0.5, device=0):
+                 waypoint_step=0.5, device=0, dyn=None, result_csv=None):
+        """dyn: None or dict(position [D,3], velocity [D,3], radius, max_acc, downwash [D], size_prediction, horizon) --
+        obstacles that keep their velocity (obstacle.hpp: straight-line dynamic obstacles).  result_csv: path of a
+        result file in the reference's layout."""
         import torch
         self.torch = torch
         self.cfg = cfg
@@ -43,14 +103,22 @@ class ClosedLoop:
         ids = np.arange(N)
         nbr_ids = np.concatenate([np.delete(ids, a) for a in range(N)]) if N > 1 else np.zeros(0, np.int32)
         nbr_offsets = np.arange(N + 1) * (N - 1)
-        self.gen = self.opt.make_lsc_generator(N, nbr_offsets, nbr_ids, np.full(N, radius), np.full(N, downwash), device=device)
+        self.dyn = dyn
+        self.D = 0 if dyn is None else len(dyn["radius"])
+        if self.D:
+            self.dyn_pos, self.dyn_vel = f32(dyn["position"]), f32(dyn["velocity"])
+        self.gen = self.opt.make_lsc_generator(N, nbr_offsets, nbr_ids, np.full(N, radius), np.full(N, downwash), device=device,
+                                               dyn=dyn)
+        self.csv = ResultCsv(result_csv, N, self.D) if result_csv else None
+        self.sim_time = 0.0
         # agent records: static fields once, the five float3 fields are refreshed every step
         agents = np.zeros(N, abi.AGENT_DTYPE)
         agents["id"] = ids
-        agents["n_obs"] = N - 1
+        agents["n_obs"] = N - 1 + self.D
+        agents["n_slack_obs"] = self.D
         agents["max_vel"], agents["max_acc"], agents["radius"], agents["nominal_velocity"] = max_vel, max_acc, radius, nominal_velocity
         ro = self.gen.row_offsets
-        self.batch = self.opt.make_device_batch(agents, ro, np.zeros(0, abi.ROW_DTYPE), None, 0, want_iters=True, device=device)
+        self.batch = self.opt.make_device_batch(agents, ro, np.zeros(0, abi.ROW_DTYPE), None, self.D, want_iters=True, device=device)
         for k in ("nx", "ny", "nz", "px", "py", "pz", "d", "key"):
             setattr(self.batch.c, k, self.gen.soa[k].data_ptr())
         self.ro32 = torch.from_numpy(ro.astype(np.int32)).to(dev)
@@ -60,6 +128,8 @@ class ClosedLoop:
         self.history = []
 
     def close(self):
+        if self.csv:
+            self.csv.close()
         self.opt.close()
 
     def step(self):
@@ -73,11 +143,13 @@ class ClosedLoop:
         a = self.agent_f32
         a[:, 0:3], a[:, 3:6], a[:, 6:9], a[:, 9:12], a[:, 12:15] = self.pos, self.vel, self.acc, self.cur_goal, wp
         first = self.seq < 1  # planner_seq < 2 in the reference counts from 1
+        t_wall = time.perf_counter() if self.csv else 0.0
+        dkw = dict(dyn_position=self.dyn_pos, dyn_velocity=self.dyn_vel) if self.D else {}
         if first:
-            self.gen.generate(self.cur_goal, position=self.pos, velocity=self.vel)
+            self.gen.generate(self.cur_goal, position=self.pos, velocity=self.vel, **dkw)
             init = self.pos[:, None, None, :].expand(-1, cfg.M, n + 1, -1) + 0 * self.plans  # zero velocity
         else:
-            self.gen.generate(self.cur_goal, plans=self.plans)
+            self.gen.generate(self.cur_goal, plans=self.plans, **dkw)
             init = torch.cat([self.plans[:, 1:], self.plans[:, -1:, -1:].expand(-1, 1, n + 1, -1)], dim=1)
         self.batch.launch(True, True)
         ok = (self.batch.out_status == abi.OK)
@@ -89,7 +161,16 @@ class ClosedLoop:
         c0, c1, c2 = self.plans[:, 1, 0], self.plans[:, 1, 1], self.plans[:, 1, 2]
         s1, s2 = np.float32(n / dt), np.float32((n - 1) / dt)
         v0, v1 = (c1 - c0) * s1, (c2 - c1) * s1
+        if self.csv:
+            torch.cuda.synchronize(self.dev)
+            dyn_now = (self.dyn_pos.cpu().numpy(), self.dyn_vel.cpu().numpy()) if self.D else None
+            self.csv.write_step(self.sim_time, self.plans.cpu().numpy(), n, dt, time.perf_counter() - t_wall,
+                                None if dyn_now is None else
+                                (lambda tau: (dyn_now[0] + dyn_now[1] * np.float32(tau), self.dyn["radius"])))
         self.pos, self.vel, self.acc = c0.clone(), v0, (v1 - v0) * s2
+        if self.D:
+            self.dyn_pos = self.dyn_pos + self.dyn_vel * np.float32(dt)
+        self.sim_time += dt
         self.seq += 1
         return self.batch.out_status, self.batch.out_iters
 

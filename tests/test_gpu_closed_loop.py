@@ -47,3 +47,66 @@ def test_empty_mission_closed_loop_is_collision_free(gpu_required, name, steps):
         assert (dist < 0.15).mean() >= 0.7
     else:
         assert dist.mean() < 0.7 * d0  # 60 agents in 3 x 3 x 2 m without a waypoint planner: progress, not arrival
+
+
+def test_result_file_reproduces_the_first_rows_of_the_reference_log(gpu_required, tmp_path):
+    """The reference's committed run (maze10_dense mission, 2-D, M = 10): its result file's rows at t = 0.1 and
+    t = 0.2 are the first plan sampled at 0.1 s and the state after the first step.  The harness, started from the same
+    states with the same first waypoints (one grid cell ahead), writes the same numbers into the same columns."""
+    import fixtures
+    k = fixtures.kat()
+    c = k["config"]
+    cfg = abi.make_config(dim=c["dim"], M=c["M"], n=c["n"], dt=c["dt"], control_input_weight=c["control_input_weight"],
+                          terminal_weight=c["terminal_weight"], communication_range=c["communication_range"],
+                          world_min=tuple(c["world_min"]), world_max=tuple(c["world_max"]), world_z_2d=c["world_z_2d"],
+                          world_use_octomap=False)
+    start = np.array([a["start"] for a in k["agents"]], np.float32)
+    goal = start.copy()
+    goal[:, 0] = np.where(start[:, 0] < 2.0, 5.0, -1.0)  # the two columns of agents swap sides
+    path = tmp_path / "result.csv"
+    sim = ClosedLoop(cfg, start, goal, radius=c["radius"], downwash=2.0, max_vel=c["max_vel"], max_acc=c["max_acc"],
+                     nominal_velocity=c["nominal_velocity"], waypoint_step=c["grid_resolution"], result_csv=str(path))
+    try:
+        for _ in range(2):
+            status, _ = sim.step()
+            assert int((status != abi.OK).sum()) == 0
+    finally:
+        sim.close()
+    lines = open(path).read().strip().split("\n")
+    assert lines[0].count("planning_time") == len(start)
+    rows = [np.array(l.split(","), float).reshape(len(start), 12) for l in lines[1:]]
+    assert [round(r[0, 1], 6) for r in rows] == [0.0, 0.1, 0.2, 0.3]
+    for a in k["agents"]:
+        q = a["id"]
+        for row, key in ((rows[1], "t0.1"), (rows[2], "t0.2")):
+            exp = a[key]
+            assert row[q, 0] == q
+            # both files print 6 significant digits
+            assert np.allclose(row[q, 2:5], exp["pos"], rtol=3e-6, atol=2e-6), (q, key, row[q, 2:5], exp["pos"])
+            assert np.allclose(row[q, 5:8], exp["vel"], rtol=3e-5, atol=2e-6), (q, key, row[q, 5:8], exp["vel"])
+            assert np.allclose(row[q, 8:11], exp["acc"], rtol=2e-4, atol=2e-5), (q, key, row[q, 8:11], exp["acc"])
+
+
+def test_closed_loop_with_dynamic_obstacles(gpu_required):
+    """empty10 with two obstacles crossing the arena at constant velocity: rows from the device generator's dynamic
+    branch (slack variables), agents keep clear of the obstacles and of each other."""
+    cfg, m = _mission("empty10_1")
+    cfg.slack_collision_weight = 100.0
+    dyn = dict(position=np.float32([[-3.0, 0.3, 1.0], [0.4, 3.0, 1.2]]), velocity=np.float32([[0.3, 0.0, 0.0], [0.0, -0.25, 0.0]]),
+               radius=np.array([0.3, 0.25]), max_acc=np.array([0.0, 0.0]), downwash=np.array([1.0, 1.0]), size_prediction=1, horizon=1.0)
+    sim = ClosedLoop(cfg, np.array(m["start"], np.float32), np.array(m["goal"], np.float32), radius=m["radius"],
+                     downwash=m["downwash"], max_vel=m["max_vel"], max_acc=m["max_acc"], nominal_velocity=m["nominal_velocity"], dyn=dyn)
+    try:
+        worst_agents, worst_obs, fails = 1e9, 1e9, 0
+        for _ in range(80):
+            status, _ = sim.step()
+            fails += int((status != abi.OK).sum())
+            worst_agents = min(worst_agents, sim.min_separation())
+            d = (sim.pos[:, None, :] - sim.dyn_pos[None, :, :]).norm(dim=2).cpu().numpy()
+            worst_obs = min(worst_obs, float((d / (m["radius"] + dyn["radius"])[None, :]).min()))
+    finally:
+        sim.close()
+    print("dynamic obstacles: min agent ratio", worst_agents, "min obstacle ratio", worst_obs, "fail-safes", fails)
+    assert worst_agents >= 0.999
+    assert worst_obs >= 0.98  # soft constraints (slack variables): clearance up to the slack the QP bought
+    assert fails <= 0.05 * 80 * sim.N
