@@ -308,3 +308,74 @@ def permute_batch(agents, row_offsets, rows, perm):
     # gather index of every row: start of its source block + position inside the block
     src = np.repeat(ro[:-1][perm], cnt) + (np.arange(int(cnt.sum())) - np.repeat(new_ro[:-1].astype(np.int64), cnt))
     return agents[perm].copy(), new_ro, rows[src].copy()
+
+
+def x2048(cfg, n_agents=2048, seed=5000, spacing=0.85, jitter=0.15, sense=3.0):
+    """BASELINE.json configs[4] ("stress: 2048 synthetic agents, maze10_dense-style constraint density"): agents on a
+    jittered grid in 2-D, each with a smooth previous plan, every agent within L-infinity `sense` metres is a neighbour
+    (about 50 neighbours -> ~2 800 DLSC-GC rows per agent once generated), one safe-flight-corridor box per segment
+    around the shifted previous plan (0.25-0.75 m margins, the corridor widths of maze10_dense), communication range
+    from `cfg`.  Returns the inputs of the device generator (plans, goals, neighbour lists) and of the optimizer
+    (agent records consistent with the shifted plans, SFC boxes).  The shifted previous plan satisfies every box,
+    velocity/acceleration and communication row, so the QPs are feasible unless the neighbours squeeze an agent."""
+    rng = np.random.default_rng(seed)
+    M, n = cfg.M, cfg.n
+    side = int(np.ceil(np.sqrt(n_agents)))
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side), indexing="ij")
+    cell = np.stack([gx.ravel(), gy.ravel()], 1)[:n_agents].astype(np.float64)
+    z = float(cfg.world_z_2d)
+    origin = -0.5 * spacing * (side - 1)
+    p0 = np.zeros((n_agents, 3))
+    p0[:, :2] = origin + cell * spacing + rng.uniform(-jitter, jitter, (n_agents, 2))
+    p0[:, 2] = z
+    # previous plans: rest-to-rest quintic moves p0 + D s(t / T), s(u) = 10u^3 - 15u^4 + 6u^5, like real plans of the
+    # reference (which end with a full stop, traj_optimizer.cpp:515-524): the shifted plan is then itself a feasible
+    # trajectory, the premise of the DLSC feasibility guarantee.  |D| <= 0.12 keeps every pair beyond the collision
+    # distance (grid spacing - 2 jitter - 2 |D| > 0.3).  Control points: exact Bernstein form of each segment.
+    D = np.zeros((n_agents, 3))
+    D[:, :2] = rng.uniform(-0.12, 0.12, (n_agents, 2))
+    T = M * cfg.dt
+    tau = np.arange(n + 1) / n
+    from math import comb
+    colloc = np.array([[comb(n, i) * t ** i * (1 - t) ** (n - i) for i in range(n + 1)] for t in tau])
+    plans = np.zeros((n_agents, M, n + 1, 3), np.float32)
+    for m in range(M):
+        u = (m + tau) * cfg.dt / T
+        sv = 10 * u ** 3 - 15 * u ** 4 + 6 * u ** 5          # samples of the quintic at 6 nodes of the segment
+        ctrl = np.linalg.solve(colloc, sv)                    # its 6 Bernstein control points (exact: degree 5)
+        plans[:, m] = (p0[:, None, :] + D[:, None, :] * ctrl[None, :, None]).astype(np.float32)
+    plans[:, 1:, 0] = plans[:, :-1, n]
+    goals = plans[:, -1, -1] + 0.0
+    goals[:, :2] += rng.uniform(-0.2, 0.2, (n_agents, 2)).astype(np.float32)  # inside the last corridor box (margin >= 0.25)
+    # neighbours within the sensing box (multi_sync_simulator.cpp:489-491 applies the communication range the same way)
+    order = np.argsort(p0[:, 0], kind="stable")
+    xs = p0[order, 0]
+    offs, ids = [0], []
+    for a in range(n_agents):
+        lo, hi = np.searchsorted(xs, p0[a, 0] - sense), np.searchsorted(xs, p0[a, 0] + sense, side="right")
+        cand = order[lo:hi]
+        cand = cand[(np.abs(p0[cand, 1] - p0[a, 1]) <= sense) & (cand != a)]
+        ids.append(np.sort(cand))
+        offs.append(offs[-1] + len(cand))
+    nbr_ids = np.concatenate(ids).astype(np.int32)
+    # shifted plans = what every agent starts from (traj_planner.cpp:412-421)
+    init = np.concatenate([plans[:, 1:], np.repeat(plans[:, -1:, -1:], n + 1, axis=2)], axis=1)
+    agents = np.zeros(n_agents, abi.AGENT_DTYPE)
+    agents["id"] = np.arange(n_agents)
+    agents["position"] = init[:, 0, 0]
+    agents["velocity"] = (init[:, 0, 1] - init[:, 0, 0]) * np.float32(n / cfg.dt)
+    agents["acceleration"] = ((init[:, 0, 2] - init[:, 0, 1]) - (init[:, 0, 1] - init[:, 0, 0])) * np.float32(n * (n - 1) / cfg.dt ** 2)
+    agents["current_goal_point"] = goals
+    # the grid planner's waypoint lies in the last corridor box too (goal LP: the sub-goal slides from the waypoint
+    # towards the current goal inside that box, goal_optimizer.cpp:138-198)
+    wp = goals.copy()
+    wp[:, :2] += rng.uniform(-0.04, 0.04, (n_agents, 2))
+    agents["next_waypoint"] = wp.astype(np.float32)
+    agents["max_vel"], agents["max_acc"], agents["radius"], agents["nominal_velocity"] = 1.0, 2.0, 0.15, 1.0
+    agents["n_obs"] = np.diff(offs)
+    margin = rng.uniform(0.25, 0.75, (n_agents, M, 1, 3)).astype(np.float32)
+    sfc = np.concatenate([init.min(axis=2, keepdims=True) - margin, init.max(axis=2, keepdims=True) + margin], axis=3)
+    sfc = sfc.reshape(n_agents, M, 6).astype(np.float32)
+    return dict(plans=plans, init=init, goals=goals.astype(np.float32), radius=np.full(n_agents, 0.15),
+                downwash=np.full(n_agents, DOWNWASH), nbr_offsets=np.array(offs, np.int32), nbr_ids=nbr_ids,
+                agents=agents, sfc=np.ascontiguousarray(sfc))

@@ -1,0 +1,78 @@
+"""-m gpu: BASELINE.json configs[4], the 2048-agent stress case (2-D, M = 10, SFC boxes, communication range 3, about
+2 500 DLSC-GC rows per agent, i.e. ten times the kernel's register cache: the rows are scanned from HBM).  The rows are
+generated on the device (row N1) and never visit the host, except for a sample of agents that the oracle re-solves."""
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from dlsc_gc_planner_amd import abi, workloads
+from dlsc_gc_planner_amd.planner import BatchTrajOptimizer
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_x2048_stress_batch(gpu_required):
+    cfg = workloads.x2048_config()
+    w = workloads.x2048(cfg)
+    N = len(w["agents"])
+    opt = BatchTrajOptimizer(cfg)
+    try:
+        gen = opt.make_lsc_generator(N, w["nbr_offsets"], w["nbr_ids"], w["radius"], w["downwash"])
+        plans, goals = torch.from_numpy(w["plans"]).cuda(), torch.from_numpy(w["goals"]).cuda()
+        gen.generate(goals, plans=plans)
+        ro = gen.row_offsets
+        db = opt.make_device_batch(w["agents"], ro, np.zeros(0, abi.ROW_DTYPE), w["sfc"], 0, want_f64=True, want_iters=True)
+        for k in ("nx", "ny", "nz", "px", "py", "pz", "d", "key"):
+            setattr(db.c, k, gen.soa[k].data_ptr())
+        ro32 = torch.from_numpy(ro.astype(np.int32)).cuda()
+        db.c.row_offsets = ro32.data_ptr()
+        db.c.max_rows_per_agent = int(np.diff(ro).max())
+        db.launch()
+        got = db.results()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            gen.generate(goals, plans=plans)
+            db.launch()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 5 * 1e3
+        _, rows = gen.rows_host()
+    finally:
+        opt.close()
+    ok = got["status"] == abi.OK
+    print("x2048: rows/agent %.0f, solved %.3f, iterations mean %.2f max %d, generation + LP + QP %.2f ms per step (%.0f agent-QP/s)"
+          % (np.diff(ro).mean(), ok.mean(), got["iters"][:, 0].mean(), got["iters"][:, 0].max(), ms, N / ms * 1e3))
+    assert ok.mean() > 0.9
+    # ---- oracle on a sample of agents (same rows, downloaded) ---------------------------------------------------
+    sample = np.random.default_rng(1).choice(N, 24, replace=False)
+    for a in sample:
+        r = rows[ro[a]:ro[a + 1]]
+        ref = O.plan_batch(cfg, w["agents"][a:a + 1], np.array([0, len(r)], np.int64), r, w["sfc"][a:a + 1], 0, True)
+        assert ref["goal_status"][0] == got["goal_status"][a]
+        assert ref["status"][0] == got["status"][a], (a, ref["status"][0], got["status"][a])
+        if ref["status"][0] == abi.OK:
+            assert np.abs(ref["x"][0] - got["x"][a]).max() < 1e-6
+            assert np.abs(ref["ctrl"][0] - got["ctrl"][a]).max() <= 1e-6
+    # ---- size-independent properties on all 2048 agents ---------------------------------------------------------
+    dim, M, n = cfg.world_dimension, cfg.M, cfg.n
+    x = got["x"][ok].reshape(-1, dim, M, n + 1)
+    ag, sfc = w["agents"][ok], w["sfc"][ok]
+    assert np.abs(x[:, :, 0, 0] - ag["position"][:, :dim]).max() < 1e-9
+    assert np.abs(x[:, :, 1:, 0] - x[:, :, :-1, n]).max() < 1e-9  # C0
+    assert np.abs(x[:, :, -1, n] - x[:, :, -1, n - 2]).max() < 1e-9  # terminal stop
+    v = (x[:, :, :, 1:] - x[:, :, :, :-1]) * n / cfg.dt
+    v[:, :, 0, :2] = 0
+    assert np.abs(v).max() <= 1.0 + 1e-6
+    # safe flight corridor: every control point of segment m inside box m (first three points of segment 0 are fixed)
+    lo, hi = sfc[:, :, :dim].transpose(0, 2, 1)[..., None], sfc[:, :, 3:3 + dim].transpose(0, 2, 1)[..., None]
+    inside = (x >= lo - 1e-6) & (x <= hi + 1e-6)
+    inside[:, :, 0, :3] = True
+    assert inside.all()
+    # communication range (traj_optimizer.cpp:490-513): segment end points stay within range/2 - r of every earlier start
+    lim = 0.5 * cfg.communication_range - 0.15
+    for m in range(M):
+        for mi in range(m + 1):
+            assert np.abs(x[:, :, m, n] - x[:, :, mi, 0]).max() <= lim + 1e-6
