@@ -108,8 +108,12 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the single-swarm host-to-host latency loop")
     ap.add_argument("--no-order-hint", action="store_true",
                     help="launch agents in id order instead of most-expensive-first (previous step's iteration counts)")
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="N>1: one launch + one all-gather per step instead of the two-chunk overlapped exchange")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N>1: chunked launches with the all-gather of each chunk overlapping the next launches, instead "
+                         "of one launch + one all-gather per step (pays only when a launch has a long straggler tail)")
+    ap.add_argument("--bulk-chunks", type=int, default=4,
+                    help="N>1 overlapped exchange: the agents outside the straggler chunk are planned in this many "
+                         "consecutive launches, each followed by the all-gather of its part of the plan table")
     ap.add_argument("--hard-fraction", type=float, default=0.125,
                     help="N>1 overlapped exchange: share of the agents (most expensive first) in the straggler chunk")
     ap.add_argument("--force-dist", action="store_true", help="(test) create the process group even for one rank")
@@ -147,7 +151,7 @@ def main():
     N = len(wl["agents"])
     K = wl["K"]
     db = opt.make_device_batch(wl["agents"], wl["row_offsets"], wl["rows"], None, 0, want_iters=True)
-    overlap = use_dist and not args.no_overlap and not args.no_order_hint
+    overlap = use_dist and args.overlap and not args.no_order_hint
     shape1 = tuple(db.out_ctrl.shape[1:])
 
     for _ in range(args.warmup):
@@ -171,10 +175,16 @@ def main():
             db.set_order(order)
     if use_dist:
         if overlap:
-            g_hard = torch.empty((world, H) + shape1, dtype=torch.float32, device=dev)
-            g_easy = torch.empty((world, N - H) + shape1, dtype=torch.float32, device=dev)
+            # chunk 0: the stragglers (most expensive agents) on a high-priority stream; chunks 1..B: the rest, in
+            # consecutive launches on a second stream.  Every launch is followed by the asynchronous all-gather of its
+            # contiguous part of the plan table, so the exchange of chunk k runs while chunk k+1 (and the stragglers)
+            # are still being planned; all ranks issue the collectives in the same order.
+            B = max(1, min(args.bulk_chunks, (N - H) // 64))
+            edges = [0, H] + [H + (N - H) * (b + 1) // B for b in range(B)]
+            chunks = [(edges[c], edges[c + 1] - edges[c]) for c in range(B + 1)]
+            g_parts = [torch.empty((world, cnt) + shape1, dtype=torch.float32, device=dev) for _, cnt in chunks]
             s_hard = torch.cuda.Stream(dev, priority=-1)
-            s_easy = torch.cuda.Stream(dev)
+            s_bulk = torch.cuda.Stream(dev)
         else:
             gathered = torch.empty((world * N,) + shape1, dtype=torch.float32, device=dev)
 
@@ -188,16 +198,24 @@ def main():
         else:
             cur = torch.cuda.current_stream(dev)
             s_hard.wait_stream(cur)
-            s_easy.wait_stream(cur)
+            s_bulk.wait_stream(cur)
+            works = []
             with torch.cuda.stream(s_hard):
-                db.launch(True, True, offset=0, count=H)
-            with torch.cuda.stream(s_easy):
-                db.launch(True, True, offset=H, count=N - H)
-                dist.all_gather_into_tensor(g_easy.view((world * (N - H),) + shape1), db.out_ctrl[H:])
+                db.launch(True, True, offset=chunks[0][0], count=chunks[0][1])
+            with torch.cuda.stream(s_bulk):
+                for c in range(1, len(chunks)):
+                    o, cnt = chunks[c]
+                    db.launch(True, True, offset=o, count=cnt)
+                    works.append(dist.all_gather_into_tensor(g_parts[c].view((world * cnt,) + shape1), db.out_ctrl[o:o + cnt],
+                                                             async_op=True))
             with torch.cuda.stream(s_hard):
-                dist.all_gather_into_tensor(g_hard.view((world * H,) + shape1), db.out_ctrl[:H])
+                o, cnt = chunks[0]
+                works.append(dist.all_gather_into_tensor(g_parts[0].view((world * cnt,) + shape1), db.out_ctrl[o:o + cnt],
+                                                         async_op=True))
+            for wk in works:
+                wk.wait()  # stream-level wait of the current stream, not a host block
             cur.wait_stream(s_hard)
-            cur.wait_stream(s_easy)
+            cur.wait_stream(s_bulk)
 
     for _ in range(2):
         step()
@@ -221,7 +239,8 @@ def main():
     if use_dist:
         # the gathered table must hold this rank's own block
         if overlap:
-            assert torch.equal(g_hard[rank], db.out_ctrl[:H]) and torch.equal(g_easy[rank], db.out_ctrl[H:])
+            for (o, cnt), gp in zip(chunks, g_parts):
+                assert torch.equal(gp[rank], db.out_ctrl[o:o + cnt])
         else:
             assert torch.equal(gathered[rank * N:(rank + 1) * N], db.out_ctrl)
     if overlap:
@@ -281,8 +300,9 @@ def main():
                 "agents_per_gpu": N, "segments": M, "degree": n, "lsc_rows_per_agent": K,
                 "vars_per_agent": dim * M * (n + 1), "ineq_rows_per_agent": K + 2 * 207,
                 "exchange": ("none (1 GPU)" if not use_dist else
-                             "RCCL all-gather of control points per step, in two chunks (easy %d agents first, "
-                             "overlapping the %d stragglers)" % (N - H, H) if overlap else
+                             "RCCL all-gather of control points per step in %d chunks overlapping the launches (%d "
+                             "stragglers on a high-priority stream, the other %d agents in %d consecutive launches)"
+                             % (len(chunks), H, N - H, len(chunks) - 1) if overlap else
                              "one RCCL all-gather of control points per step"),
                 "launch_order": "id" if args.no_order_hint else "previous step's iteration count, descending",
                 "solved_fraction": float(ok.mean()), "mean_active_set_iterations": float(it[:, 0].mean()),
