@@ -443,7 +443,7 @@ extern "C" int64_t dlscqp_lds_bytes(const dlscqp_ctx *c, int32_t max_slack_obs, 
     if (!c) return -1;
     KernelChoice kc = select_kernel(c->tb.kp, max_slack_obs, max_rows_per_agent);
     if (!kc.fn) return -1;
-    return make_layout(c->tb.kp, max_slack_obs, max_rows_per_agent, kc.KU, kc.SU).bytes;
+    return make_layout(c->tb.kp, max_slack_obs, max_rows_per_agent, kc.KU, kc.SU, instance_n_in_lds(kc.id)).bytes;
 }
 
 extern "C" int dlscqp_set_timing(dlscqp_ctx *c, int32_t capacity) {
@@ -491,7 +491,7 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         g_last_error = "reduced dimension above 128 (dim*f + M*max_slack_obs) is not supported";
         return DLSCQP_ERR_UNSUPPORTED;
     }
-    MemLayout lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU);
+    MemLayout lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, instance_n_in_lds(kc.id));
     if (lay.bytes > LDS_LIMIT) {
         char msg[256];
         snprintf(msg, sizeof msg,

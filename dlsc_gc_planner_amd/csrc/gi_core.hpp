@@ -62,7 +62,7 @@ struct MemLayout {
     int bytes;
 };
 
-DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int KU, int SU) {
+DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int KU, int SU, bool n_in_lds = true) {
     MemLayout L;
     const int nslk = kp.M * max_slack_obs;
     L.r_max = kp.dim * kp.f + nslk;
@@ -76,7 +76,7 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
     L.oDump = L.oQ + L.r_max * L.ldq;      // that row doubles as the dump slots: its content is never used
     if (L.ldq < 32) o += 32 - L.ldq;
     L.oRp = o; o += L.r_max * (L.r_max + 1) / 2;
-    L.oN = o; o += kp.P * kp.f;
+    L.oN = o; o += n_in_lds ? kp.P * kp.f : 0;  // instantiations that keep N_T's rows in registers need no copy
     L.oX = o; o += L.nx_max;
     L.oBlo = o; o += kp.nb;
     L.oBhi = o; o += kp.nb;
@@ -103,6 +103,20 @@ constexpr int DQ_N_INSTANCES = 8;
 struct InstanceChoice {
     int id, KU, SU;  // id < 0: unsupported (reduced dimension above 128)
 };
+
+// Instantiations with f <= 16 and at most 64 control points per axis (the 3-D M = 5 ones) keep lane p's row of N_T
+// in registers and read the three rows of a constraint normal straight from the (L2-resident) table: no copy of N_T
+// in LDS, which is what fits an eighth agent on a CU.
+constexpr bool n_in_registers(int FS, int MS) { return FS > 0 && FS <= 16 && MS * 6 <= 64; }
+inline bool instance_n_in_lds(int id) {
+    switch (id) {
+#define DQ_CASE(ID, RC, DIMS, FS, MS, KU, SU, SLK) \
+    case ID: return !n_in_registers(FS, MS);
+        DQ_INSTANCES(DQ_CASE)
+#undef DQ_CASE
+    default: return true;
+    }
+}
 
 // Which instantiation plans a batch (r_max = dim f + M max_slack_obs, kmax = most LSC rows of one agent).
 inline InstanceChoice select_instance(const KParams &kp, int max_slack_obs, int kmax, bool force_generic) {
@@ -401,6 +415,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 #define DQ_STAGE_H 1
 #endif
     constexpr int FB = FS > 0 ? FS : 8;  // block of LDS reads issued together in the O(r) loops
+    constexpr bool NREG = n_in_registers(FS, MS);  // lane p holds row p of N_T in registers, no LDS copy
     constexpr bool ST = DIMS > 0 && SLK == 0;
     constexpr int R_ST = DIMS * FS, LDQ_ST = (DIMS * FS) | 1;
     static_assert(!ST || LDQ_ST >= 32, "the spare row of Q holds the 32 dump slots");
@@ -409,9 +424,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     const int oQ = 0;
     const int oRp = ST ? (R_ST + 1) * LDQ_ST : lay.oRp;
     const int oN = ST ? (R_ST + 1) * LDQ_ST + R_ST * (R_ST + 1) / 2 : lay.oN;
-    const int oX = ST ? (R_ST + 1) * LDQ_ST + R_ST * (R_ST + 1) / 2 + MS * 6 * FS : lay.oX;
+    const int oX = ST ? (R_ST + 1) * LDQ_ST + R_ST * (R_ST + 1) / 2 + (NREG ? 0 : MS * 6 * FS) : lay.oX;
     const int odump = ST ? R_ST * LDQ_ST : lay.oDump;  // 32 dump slots in the spare row of Q, base[odump + (lane & 31)]
-    const int oBlo = ST ? (R_ST + 1) * LDQ_ST + R_ST * (R_ST + 1) / 2 + MS * 6 * FS + DIMS * MS * 6 : lay.oBlo;
+    const int oBlo = ST ? (R_ST + 1) * LDQ_ST + R_ST * (R_ST + 1) / 2 + (NREG ? 0 : MS * 6 * FS) + DIMS * MS * 6 : lay.oBlo;
     const int oBhi = lay.oBhi;
     double *Q = base + oQ, *Rp = base + oRp, *Nl = base + oN, *x = base + oX;
     double *blo = base + oBlo, *bhi = base + oBhi;
@@ -563,6 +578,8 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 
     int q = 0, iters = 0, n_add = 0, n_drop = 0;
     bool factors_ready = false;
+    RegD nrow[NREG ? FB : 1];  // NREG: row (lane) of N_T, loaded with the factors
+    w.each([&](int l) { for (int u = 0; u < (NREG ? FB : 1); u++) nrow[u].at(l) = 0.0; });
     const int max_iter = kp.max_iter > 0 ? kp.max_iter : 20 * (r + 8) + 200;
     // unified row codes: [0,K) LSC rows, K + 2 s + side structured slots, K + 2 n_slots + s slack bounds
     const int code_slack0 = K + 2 * n_slots;
@@ -848,11 +865,13 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 // out of the iteration loop (where ~25 loop-invariant address registers were kept alive in scratch)
                 int l = l0;
                 DQ_KEEP(l);
-                for (int j0 = 0; j0 < P * f; j0 += 64) {
-                    const int j = j0 + l;
-                    const bool in = j < P * f;
-                    const double v = tN[in ? j : P * f - 1];
-                    base[blend_idx(in, oN + j, odump + (l & 31))] = v;
+                if (!NREG) {
+                    for (int j0 = 0; j0 < P * f; j0 += 64) {
+                        const int j = j0 + l;
+                        const bool in = j < P * f;
+                        const double v = tN[in ? j : P * f - 1];
+                        base[blend_idx(in, oN + j, odump + (l & 31))] = v;
+                    }
                 }
                 // identity, and zeros in the spare row qdummy that lanes beyond r work on
                 const int nq = (r_max + 1) * ldq;
@@ -862,6 +881,13 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     base[blend_idx(j < nq, oQ + j, odump + (l & 31))] = ((i == c) & (i < r)) ? 1.0 : 0.0;
                 }
             });
+            if (NREG) {
+                w.each([&](int l) {
+                    const int pc = l < P ? l : P - 1;
+#pragma unroll
+                    for (int u = 0; u < (NREG ? FB : 1); u++) nrow[u].at(l) = tN[pc * f + u];
+                });
+            }
             w.sync();
             factors_ready = true;
             w.stamp(1);
@@ -950,11 +976,13 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 const int k = ec / f, j = ec - k * f;
 #pragma unroll
                 for (int t = 0; t < 3; t++) {  // ep[t] is a valid row of N for unused entries too (0)
-                    const double nv = Nl[ep[t] * f + j];
-                    v = (in_ctrl && ek[t] == k) ? fma(cf[t], nv, v) : v;
+                    double nv = NREG ? tN[ep[t] * f + j] : Nl[ep[t] * f + j];
+                    DQ_KEEP(nv);
+                    v = (in_ctrl & (ek[t] == k)) ? fma(cf[t], nv, v) : v;
                 }
-                const double sgm = -kp.sigma[(sidx_row < 0 ? 0 : sidx_row) % M];
-                v = (!in_ctrl && e - rc == sidx_row) ? sgm : v;
+                double sgm = -kp.sigma[(sidx_row < 0 ? 0 : sidx_row) % M];
+                DQ_KEEP(sgm);
+                v = (!in_ctrl & (e - rc == sidx_row)) ? sgm : v;
                 na[c].at(l) = v;
             }
         });
@@ -1134,6 +1162,13 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                         const int pc = in ? p : P - 1;
                         double sk[3] = {0.0, 0.0, 0.0};
 #if DQ_STAGE_S
+                        if (NREG) {  // row p of N_T is in this lane's registers (p = lane: P <= 64)
+#pragma unroll
+                            for (int u = 0; u < (NREG ? FB : 1); u++)
+#pragma unroll
+                                for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++)
+                                    if (k < dim) sk[k] = fma(nrow[NREG ? u : 0].at(l), DQ_BC(zv, k * f + u), sk[k]);
+                        } else
                         for (int c0 = 0; c0 < f; c0 += FB) {
                             const int nvb = f - c0 < FB ? f - c0 : FB;  // uniform; == FB for static shapes
                             double tn[FB];

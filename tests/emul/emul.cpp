@@ -133,7 +133,7 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
         DQ_INSTANCES(DQ_CASE)
 #undef DQ_CASE
     }
-    MemLayout lay = make_layout(kp, max_slack_obs, kmax, KUsel, SUsel);
+    MemLayout lay = make_layout(kp, max_slack_obs, kmax, KUsel, SUsel, instance_n_in_lds(ic.id));
     std::vector<unsigned char> mem(lay.bytes + 64);
     WaveCpu w;
     const char *rev = std::getenv("EMUL_REVERSE");
@@ -181,7 +181,8 @@ extern "C" int emul_table_info(const dlscqp_config *cfg, int *f, int *n_slots, i
     *f = tb.kp.f;
     *n_slots = tb.kp.n_slots;
     *nb = tb.kp.nb;
-    *lds_bytes = make_layout(tb.kp, max_slack_obs, kmax, 4, 10).bytes;
+    const InstanceChoice ic = select_instance(tb.kp, max_slack_obs, kmax, false);
+    *lds_bytes = ic.id < 0 ? -1 : make_layout(tb.kp, max_slack_obs, kmax, ic.KU, ic.SU, instance_n_in_lds(ic.id)).bytes;
     return 0;
 }
 
