@@ -633,7 +633,8 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     // acceleration rows (T3g); only meaningful without slack variables.
     //   jerk term: the acceleration of a segment is a cubic Bernstein polynomial whose control points are bounded by
     //   a = max(max_acc, |initial acceleration|), so |jerk| <= 3/dt * 2a and  c'Qb c = w_c * integral jerk^2 <= w_c 36 a^2 / dt
-    //   per axis and segment;  terminal term: w_t * (largest distance of the box of that segment to the goal)^2.
+    //   per axis and segment;  terminal term: w_t * (largest distance to the goal of a point of that segment's box that the
+    //   velocity rows allow the segment's end point to reach)^2.
     auto objective_upper_bound = [&]() -> double {
         double amax = max_acc;
         for (int k = 0; k < 3; k++) amax = fabs((double)acc[k]) > amax ? fabs((double)acc[k]) : amax;
@@ -648,7 +649,15 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 const int k = sc / M, m = sc - k * M;
                 const double g = (double)pick3(goal, k);
                 const double dl = fabs(blo[sc] - g), dh = fabs(bhi[sc] - g);
-                const double dm2 = dl > dh ? dl : dh;
+                const double dbox = dl > dh ? dl : dh;
+                // the end point of segment m is p((m+1) dt) = pos + integral of the velocity, whose control points are
+                // bounded by max_vel except the two that the initial state fixes (v0 = vel, v1 = vel + acc dt / (n-1))
+                const double v0 = fabs((double)pick3(vel, k));
+                const double v1 = fabs((double)pick3(vel, k) + (double)pick3(acc, k) * kp.dt / (double)(n - 1));
+                double vb = max_vel > v0 ? max_vel : v0;
+                vb = vb > v1 ? vb : v1;
+                const double dreach = fabs((double)pick3(pos, k) - g) + vb * (double)(m + 1) * kp.dt;
+                const double dm2 = dbox < dreach ? dbox : dreach;
                 double tv = kp.w_t * dm2 * dm2;
                 DQ_KEEP(tv);
                 a1 += (in & (m >= M - T)) ? tv : 0.0;
@@ -837,13 +846,14 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         // of the optimum.  Every feasible point obeys the box and acceleration rows, which bound the objective
         // from above by f_max (objective_upper_bound).  f(x) > f_max therefore proves the QP infeasible, usually
         // after 5-20 rows instead of the ~r rows the active set needs to run out of dimensions (the launch is as
-        // slow as its slowest agent, and those were the infeasible ones).  Checked every fourth pricing pass.
+        // slow as its slowest agent, and those were the infeasible ones).  Checked every second pricing pass from the
+        // eighth on.
         n_price++;
-        if (nslk == 0 && n_price >= 8 && (n_price & 3) == 0) {
+        if (nslk == 0 && n_price >= 8 && (n_price & 1) == 0) {
             if (n_price == 8) f_max = objective_upper_bound();  // first check of this agent
             const double f_now = objective();
             DQ_TRACE(4, f_now, f_max, (double)n_price, (double)q);
-            if (f_now > f_max + 0.5 * f_max + 1.0) {  // generous margin (1.5 f_max + 1): f(x) grows by orders of magnitude
+            if (f_now > f_max + 1.0) {  // margin 1 (about 1 % of f_max with the reference's weights); f(x) grows by orders of magnitude
                 status = DLSCQP_INFEASIBLE;
                 break;
             }

@@ -84,7 +84,11 @@ def test_bound_is_above_every_feasible_optimum(name):
                     lo, hi = -100.0, 100.0
                 if cfg.world_use_octomap and b["sfc"] is not None:
                     lo, hi = max(lo, float(b["sfc"][a, m, k])), min(hi, float(b["sfc"][a, m, 3 + k]))
-                f_max += cfg.terminal_weight * max(abs(lo - goal[k]), abs(hi - goal[k])) ** 2
+                dbox = max(abs(lo - goal[k]), abs(hi - goal[k]))
+                v0 = abs(float(ag["velocity"][k]))
+                v1 = abs(float(ag["velocity"][k]) + float(ag["acceleration"][k]) * cfg.dt / (cfg.n - 1))
+                dreach = abs(float(ag["position"][k]) - goal[k]) + max(float(ag["max_vel"]), v0, v1) * (m + 1) * cfg.dt
+                f_max += cfg.terminal_weight * min(dbox, dreach) ** 2
         assert res["cost"][a] <= f_max, (a, res["cost"][a], f_max)
         n_checked += 1
     assert n_checked >= 5
