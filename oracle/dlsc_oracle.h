@@ -123,6 +123,24 @@ int oracle_generate_dlscgc_dynamic(const dlscqp_config *cfg, const float *init_s
                                    const double *dyn_max_acc, const double *dyn_downwash, int size_prediction,
                                    double uncertainty_horizon, int obs_base, dlscqp_lsc_row *rows_out);
 
+/* ---------------------------------------------------------------------------------------------
+ * Row N2: safe-flight-corridor boxes on a dense occupancy grid (oracle/dlsc_sfc_oracle.c; PARITY UNPINNED, see the
+ * header of that file).  Boxes are {min x,y,z, max x,y,z} float32. */
+typedef struct oracle_world oracle_world;
+oracle_world *oracle_world_from_boxes(const double *boxes /*[n][6] centre, size*/, int n_boxes, double resolution,
+                                      const float world_min[3], const float world_max[3]);
+void oracle_world_free(oracle_world *w);
+int oracle_sfc_obstacle_in_box(const oracle_world *w, const float bmin[3], const float bmax[3], double margin);
+int oracle_sfc_expand(const oracle_world *w, const float init[6], double margin, double grid_resolution, double agent_max_vel,
+                      double dt, float out[6]);
+int oracle_sfc_from_hull(const oracle_world *w, const float *pts, int n_pts, const float *prev /*NULL or [6]*/, double margin,
+                         double grid_resolution, double agent_max_vel, double dt, float out[6]);
+int oracle_sfc_initialize(const oracle_world *w, const float pos[3], int M, double margin, double grid_resolution,
+                          double agent_max_vel, double dt, float *sfcs /*[M][6]*/);
+int oracle_sfc_construct(const oracle_world *w, const float *initial_traj /*[M][n+1][3]*/, int M, int n, const float goal[3],
+                         const float waypoint[3], double margin, double grid_resolution, double agent_max_vel, double dt,
+                         float *sfcs /*[M][6] in/out*/);
+
 #ifdef __cplusplus
 }
 #endif

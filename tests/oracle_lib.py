@@ -269,3 +269,59 @@ def generate_dlscgc(cfg, init, goals, radius, downwash, nbr_offsets, nbr_ids, lo
             cnt += c2
         offs.append(offs[-1] + cnt)
     return np.array(offs, np.int64), (np.concatenate(out) if out else np.zeros(0, abi.ROW_DTYPE))
+
+
+# ---- row N2: safe-flight-corridor boxes (oracle/dlsc_sfc_oracle.c, parity unpinned) ---------------------------------
+class SfcWorld:
+    """Dense occupancy grid built like MapManager::updateOctreeFromCSV + the SFC routines of CollisionConstraints."""
+
+    def __init__(self, boxes, resolution, world_min, world_max, margin, grid_resolution, max_vel, dt):
+        L = lib()
+        vp = C.c_void_p
+        L.oracle_world_from_boxes.restype = vp
+        L.oracle_world_from_boxes.argtypes = [vp, C.c_int, C.c_double, vp, vp]
+        L.oracle_world_free.argtypes = [vp]
+        L.oracle_sfc_obstacle_in_box.argtypes = [vp, vp, vp, C.c_double]
+        L.oracle_sfc_expand.argtypes = [vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, vp]
+        L.oracle_sfc_from_hull.argtypes = [vp, vp, C.c_int, vp, C.c_double, C.c_double, C.c_double, C.c_double, vp]
+        L.oracle_sfc_initialize.argtypes = [vp, vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, vp]
+        L.oracle_sfc_construct.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_double, C.c_double, C.c_double, C.c_double, vp]
+        self.L = L
+        b = np.ascontiguousarray(boxes, dtype=np.float64).reshape(-1, 6)
+        self.wmin = np.ascontiguousarray(world_min, dtype=np.float32)
+        self.wmax = np.ascontiguousarray(world_max, dtype=np.float32)
+        self.res = resolution
+        self.par = (float(margin), float(grid_resolution), float(max_vel), float(dt))
+        self.h = L.oracle_world_from_boxes(_ptr(b), len(b), resolution, _ptr(self.wmin), _ptr(self.wmax))
+
+    def close(self):
+        if self.h:
+            self.L.oracle_world_free(self.h)
+            self.h = None
+
+    def obstacle_in_box(self, box, margin=None):
+        b = np.ascontiguousarray(box, dtype=np.float32)
+        return bool(self.L.oracle_sfc_obstacle_in_box(self.h, _ptr(b[:3].copy()), _ptr(b[3:].copy()), self.par[0] if margin is None else margin))
+
+    def expand(self, box):
+        b, out = np.ascontiguousarray(box, dtype=np.float32), np.zeros(6, np.float32)
+        ok = self.L.oracle_sfc_expand(self.h, _ptr(b), *self.par, _ptr(out))
+        return bool(ok), out
+
+    def from_hull(self, pts, prev=None):
+        p, out = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 3), np.zeros(6, np.float32)
+        pv = None if prev is None else np.ascontiguousarray(prev, dtype=np.float32)
+        ok = self.L.oracle_sfc_from_hull(self.h, _ptr(p), len(p), _ptr(pv), *self.par, _ptr(out))
+        return bool(ok), out
+
+    def initialize(self, pos, M):
+        p, out = np.ascontiguousarray(pos, dtype=np.float32), np.zeros((M, 6), np.float32)
+        ok = self.L.oracle_sfc_initialize(self.h, _ptr(p), M, *self.par, _ptr(out))
+        return bool(ok), out
+
+    def construct(self, initial_traj, goal, waypoint, sfcs):
+        t = np.ascontiguousarray(initial_traj, dtype=np.float32)
+        s = np.ascontiguousarray(sfcs, dtype=np.float32).copy()
+        g, wpt = np.ascontiguousarray(goal, dtype=np.float32), np.ascontiguousarray(waypoint, dtype=np.float32)
+        code = self.L.oracle_sfc_construct(self.h, _ptr(t), t.shape[0], t.shape[1] - 1, _ptr(g), _ptr(wpt), *self.par, _ptr(s))
+        return code, s
