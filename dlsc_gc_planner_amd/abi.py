@@ -148,6 +148,22 @@ class LscGen(C.Structure):
     ]
 
 
+class SfcGen(C.Structure):
+    _fields_ = [
+        ("n_agents", C.c_int32),
+        ("initialize", C.c_int32),
+        ("grid_resolution", C.c_double),
+        ("radius", C.c_void_p),
+        ("max_vel", C.c_void_p),
+        ("position", C.c_void_p),
+        ("initial_traj", C.c_void_p),
+        ("goals", C.c_void_p),
+        ("waypoints", C.c_void_p),
+        ("sfcs", C.c_void_p),
+        ("out_code", C.c_void_p),
+    ]
+
+
 assert C.sizeof(Config) == 144, C.sizeof(Config)
 assert C.sizeof(Agent) == 104, C.sizeof(Agent)
 assert C.sizeof(LscRow) == 40, C.sizeof(LscRow)
@@ -251,5 +267,5 @@ EXPORTED_SYMBOLS = [
     "dlscqp_create", "dlscqp_destroy", "dlscqp_update_param", "dlscqp_last_error",
     "dlscqp_lds_bytes", "dlscqp_solve_batch", "dlscqp_goal_batch", "dlscqp_plan_batch",
     "dlscqp_plan_batch_device", "dlscqp_generate_lsc_device", "dlscqp_rows_to_soa", "dlscqp_set_timing",
-    "dlscqp_get_kernel_times",
+    "dlscqp_get_kernel_times", "dlscqp_world_create", "dlscqp_world_destroy", "dlscqp_generate_sfc_device",
 ]

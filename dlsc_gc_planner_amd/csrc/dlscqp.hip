@@ -23,6 +23,8 @@
 #include "gi_core.hpp"
 #include "lsc_core.hpp"
 #include "qp_tables.hpp"
+#include "sfc_core.hpp"
+#include "sfc_world.hpp"
 
 using namespace dlscqp;
 
@@ -287,6 +289,72 @@ __global__ __launch_bounds__(64) void dlscqp_lsc_kernel(LscGenArgs g) {
         const int o = it / g.M, m = it - o * g.M;
         lsc_dyn_item(g, self, o, m, (size_t)per * (pair0 + (p1 - p0) + o));
     }
+}
+
+// one wavefront per agent grows / shifts its corridor boxes (sfc_core.hpp).  Control flow is
+// wave-uniform; the lanes share the lattice points of the slab under test.
+struct WaveSfc {
+    int lane;
+    template <class F>
+    __device__ __forceinline__ bool any_of(int n, F f) const {
+        for (int base = 0; base < n; base += 64) {
+            const int idx = base + lane;
+            const bool v = f(idx < n ? idx : n - 1) & (idx < n);  // every lane evaluates a valid point
+            if (__ballot(v) != 0ull) return true;
+        }
+        return false;
+    }
+    __device__ __forceinline__ void load6(const float *src, float *dst) const {
+        for (int k = 0; k < 6; k++) dst[k] = src[k];
+    }
+    __device__ __forceinline__ void store6(float *dst, const float *src) const {
+        // src is the same in every lane; every lane stores component lane % 6 (no lane-guarded region: the uniform state
+        // of sfc_core.hpp lives in VGPRs, see "NO DIVERGENCE" in gi_core.hpp)
+        const int k = lane % 6;
+        float v = src[5];
+        v = k == 4 ? src[4] : v;
+        v = k == 3 ? src[3] : v;
+        v = k == 2 ? src[2] : v;
+        v = k == 1 ? src[1] : v;
+        v = k == 0 ? src[0] : v;
+        dst[k] = v;
+    }
+    __device__ __forceinline__ void fence() const {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+};
+
+struct SfcGenArgs {
+    SfcWorldView world;
+    int n_agents, initialize, M, n1;
+    double grid_resolution, dt;
+    const double *radius, *max_vel;
+    const float *position, *initial_traj, *goals, *waypoints;
+    float *sfcs;
+    int32_t *out_code;
+};
+
+__global__ __launch_bounds__(64) void dlscqp_sfc_kernel(SfcGenArgs a) {
+    const int ag = blockIdx.x;
+    if (ag >= a.n_agents) return;
+    WaveSfc w;
+    w.lane = (int)threadIdx.x;
+    SfcParams p;
+    p.margin = a.radius[ag];
+    p.grid_resolution = a.grid_resolution;
+    p.agent_max_vel = a.max_vel[ag];
+    p.dt = a.dt;
+    float *sfcs = a.sfcs + (size_t)ag * a.M * 6;
+    int code;
+    if (a.initialize) {
+        code = sfc_initialize(w, a.world, p, a.position + 3 * (size_t)ag, a.M, sfcs) ? 0 : -1;
+    } else {
+        code = sfc_construct(w, a.world, p, a.initial_traj + (size_t)ag * a.M * a.n1 * 3, a.M, a.n1, a.goals + 3 * (size_t)ag,
+                             a.waypoints + 3 * (size_t)ag, sfcs);
+    }
+    if (a.out_code) a.out_code[ag] = code;  // every lane, same word
 }
 
 typedef void (*kernel_t)(KParams, MemLayout, KernelArgs);
@@ -582,6 +650,82 @@ extern "C" int dlscqp_generate_lsc_device(dlscqp_ctx *c, const dlscqp_lsc_gen *g
     g.dyn_position = gen->dyn_position; g.dyn_velocity = gen->dyn_velocity;
     g.dyn_radius = gen->dyn_radius; g.dyn_max_acc = gen->dyn_max_acc; g.dyn_downwash = gen->dyn_downwash;
     hipLaunchKernelGGL(dlscqp_lsc_kernel, dim3(gen->n_local), dim3(64), 0, (hipStream_t)stream, g);
+    HIP_TRY(hipGetLastError());
+    return DLSCQP_SUCCESS;
+}
+
+struct dlscqp_world {
+    int device;
+    SfcWorldView view;  // device pointers
+    void *d_near_d2, *d_near_off, *d_near_n;
+};
+
+extern "C" int dlscqp_world_create(dlscqp_ctx *c, const double *boxes, int32_t n_boxes, double resolution,
+                                   const float world_min[3], const float world_max[3], dlscqp_world **out) {
+    g_last_error.clear();
+    if (!c || !out || (n_boxes > 0 && !boxes) || !(resolution > 0) || !world_min || !world_max) {
+        g_last_error = "null or invalid argument";
+        return DLSCQP_ERR_INVALID_ARGUMENT;
+    }
+    (void)hipSetDevice(c->cfg.device);
+    SfcWorldHost hw;
+    build_sfc_world(boxes, n_boxes, resolution, world_min, world_max, hw);
+    dlscqp_world *w = new dlscqp_world();
+    w->device = c->cfg.device;
+    w->d_near_d2 = w->d_near_off = w->d_near_n = nullptr;
+    const size_t nc = hw.cells();
+    auto fail = [&](hipError_t e, const char *what) {
+        g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+        dlscqp_world_destroy(w);
+        return DLSCQP_ERR_HIP;
+    };
+    hipError_t e;
+    if ((e = hipMalloc(&w->d_near_d2, nc * sizeof(int))) != hipSuccess) return fail(e, "hipMalloc");
+    if ((e = hipMalloc(&w->d_near_off, nc * 24)) != hipSuccess) return fail(e, "hipMalloc");
+    if ((e = hipMalloc(&w->d_near_n, nc)) != hipSuccess) return fail(e, "hipMalloc");
+    if ((e = hipMemcpy(w->d_near_d2, hw.near_d2.data(), nc * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
+    if ((e = hipMemcpy(w->d_near_off, hw.near_off.data(), nc * 24, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
+    if ((e = hipMemcpy(w->d_near_n, hw.near_n.data(), nc, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
+    w->view.res = hw.res;
+    for (int k = 0; k < 3; k++) {
+        w->view.wmin[k] = hw.wmin[k]; w->view.wmax[k] = hw.wmax[k];
+        w->view.lo[k] = hw.lo[k]; w->view.n[k] = hw.n[k];
+    }
+    w->view.near_d2 = (const int *)w->d_near_d2;
+    w->view.near_off = (const signed char *)w->d_near_off;
+    w->view.near_n = (const unsigned char *)w->d_near_n;
+    *out = w;
+    return DLSCQP_SUCCESS;
+}
+
+extern "C" void dlscqp_world_destroy(dlscqp_world *w) {
+    if (!w) return;
+    (void)hipSetDevice(w->device);
+    if (w->d_near_d2) (void)hipFree(w->d_near_d2);
+    if (w->d_near_off) (void)hipFree(w->d_near_off);
+    if (w->d_near_n) (void)hipFree(w->d_near_n);
+    delete w;
+}
+
+extern "C" int dlscqp_generate_sfc_device(dlscqp_ctx *c, const dlscqp_world *world, const dlscqp_sfc_gen *gen, void *stream) {
+    g_last_error.clear();
+    if (!c || !world || !gen) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (gen->n_agents <= 0) return DLSCQP_SUCCESS;
+    if (!gen->radius || !gen->max_vel || !gen->sfcs ||
+        (gen->initialize ? !gen->position : (!gen->initial_traj || !gen->goals || !gen->waypoints))) {
+        g_last_error = "null buffer";
+        return DLSCQP_ERR_INVALID_ARGUMENT;
+    }
+    (void)hipSetDevice(c->cfg.device);
+    SfcGenArgs a;
+    a.world = world->view;
+    a.n_agents = gen->n_agents; a.initialize = gen->initialize;
+    a.M = c->M; a.n1 = c->n + 1;
+    a.grid_resolution = gen->grid_resolution; a.dt = c->dt;
+    a.radius = gen->radius; a.max_vel = gen->max_vel;
+    a.position = gen->position; a.initial_traj = gen->initial_traj; a.goals = gen->goals; a.waypoints = gen->waypoints;
+    a.sfcs = gen->sfcs; a.out_code = gen->out_code;
+    hipLaunchKernelGGL(dlscqp_sfc_kernel, dim3(gen->n_agents), dim3(64), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return DLSCQP_SUCCESS;
 }

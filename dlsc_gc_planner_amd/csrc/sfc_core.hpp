@@ -1,0 +1,249 @@
+// sfc_core.hpp -- safe-flight-corridor boxes, the code one wavefront runs for one agent.
+//
+// CollisionConstraints::initializeSFC / constructSFCFromInitialTraj / expandSFCFromConvexHull /
+// expandSFCIncrementally / isObstacleInSFC / isSFCInBoundary of the reference
+// (src/collision_constraints.cpp:435-452, 502-536, 781-901, 1023-1093) on a dense occupancy grid: the octomap +
+// DynamicEDT3D query "closest occupied cell of a point" is a table, built once per world on the host
+// (sfc_world.cpp), of the occupied cells nearest to each grid cell.  Control flow is wave-uniform (one box at a
+// time, exactly the reference's sequence of trial expansions); the lanes share the lattice points of the slab
+// that is being tested.  Float32 boxes / double parameters as in the reference.  Included by dlscqp.hip (GPU) and by
+// tests/emul/emul.cpp (lanes run one after another on the host).
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#ifndef DQ_FN
+#define DQ_FN inline
+#endif
+
+namespace dlscqp {
+
+constexpr double SFC_EPS_F = 1e-5;  // SP_EPSILON_FLOAT, sp_const.hpp:4
+
+struct SfcWorldView {  // device (or host) pointers of a world built by build_sfc_world (sfc_world.cpp)
+    double res;
+    float wmin[3], wmax[3];
+    int lo[3], n[3];            // cell index range per axis; cell i covers [i res, (i+1) res)
+    const int *near_d2;         // [cell] squared index distance to the nearest occupied cell, -1: none within 1 m
+    const signed char *near_off;  // [cell][8][3] offsets of up to 8 cells at that distance
+    const unsigned char *near_n;  // [cell] how many
+};
+
+struct SfcParams {
+    double margin;           // agent radius
+    double grid_resolution;  // param.grid_resolution
+    double agent_max_vel;
+    double dt;
+};
+
+// getDistanceAndClosestObstacle + collision_constraints.cpp:878-886 for one search point.  Written without
+// lane-dependent branches (clamped table index, fixed trip count, selects): the lanes of a wave test different points.
+DQ_FN bool sfc_point_blocked(const SfcWorldView &w, const float sp[3], double margin) {
+    int c[3];
+    for (int k = 0; k < 3; k++) c[k] = (int)floor((1.0 / w.res) * (double)sp[k]);  // OcTreeBaseImpl::coordToKey
+    const int i = c[0] - w.lo[0], j = c[1] - w.lo[1], kk = c[2] - w.lo[2];
+    const bool inside = (i >= 0) & (j >= 0) & (kk >= 0) & (i < w.n[0]) & (j < w.n[1]) & (kk < w.n[2]);
+    // clamped cell for the table reads of points outside the grid (masked by `inside` at the end); written with
+    // min/max, not with ?: on the whole index -- that came out as an EXEC-masked branch
+    const int ic = i < 0 ? 0 : (i >= w.n[0] ? w.n[0] - 1 : i);
+    const int jc = j < 0 ? 0 : (j >= w.n[1] ? w.n[1] - 1 : j);
+    const int kc = kk < 0 ? 0 : (kk >= w.n[2] ? w.n[2] - 1 : kk);
+    const size_t q = ((size_t)ic * w.n[1] + jc) * w.n[2] + kc;
+    const int d2 = w.near_d2[q];
+    const int nt = w.near_n[q];
+    double best = 1e30;
+    for (int t = 0; t < 8; t++) {
+        double linf = 0;
+        for (int k = 0; k < 3; k++) {
+            const int cell = c[k] + w.near_off[q * 24 + 3 * t + k];
+            const float centre = (float)((cell + 0.5) * w.res);  // keyToCoord
+            const float delta = (float)(0.5 * w.res);
+            const float lo = centre - delta, hi = centre + delta;
+            const float cp = sp[k] < lo ? lo : (sp[k] > hi ? hi : sp[k]);  // Box::closestPoint
+            const double dd = fabsf(cp - sp[k]);                             // LInfinityDistance, util.hpp:131-140
+            linf = linf < dd ? dd : linf;
+        }
+        best = (t < nt) & (linf < best) ? linf : best;
+    }
+    const float dist = (float)(sqrt((double)(d2 < 0 ? 0 : d2)) * w.res);
+    return inside & (d2 >= 0) & (dist < 1) & (best < margin + SFC_EPS_F);
+}
+
+// isObstacleInSFC (:859-892): the lattice points of the box, 64 at a time, one per lane.  W::any_of(n, f): true if
+// f(i) holds for some i in [0, n) (GPU: ballot over the lanes, host: a loop).
+template <class W>
+DQ_FN bool sfc_obstacle_in_box(const W &w, const SfcWorldView &g, const float *b, double margin) {
+    int mi[3];
+    for (int k = 0; k < 3; k++) mi[k] = (int)floor((b[3 + k] - b[k] + SFC_EPS_F) / g.res) + 1;
+    const int total = mi[0] * mi[1] * mi[2];
+    return w.any_of(total, [&](int idx) {
+        const int c3 = idx % mi[2], ab = idx / mi[2], b2 = ab % mi[1], a1 = ab / mi[1];
+        const int it[3] = {a1, b2, c3};
+        float sp[3];
+        for (int k = 0; k < 3; k++) sp[k] = (float)(b[k] + it[k] * g.res);
+        return sfc_point_blocked(g, sp, margin);
+    });
+}
+
+DQ_FN bool sfc_in_boundary(const SfcWorldView &g, const float *b, double margin) {  // isSFCInBoundary, :894-901
+    for (int k = 0; k < 3; k++)
+        if (!(b[k] > g.wmin[k] + margin - SFC_EPS_F && b[3 + k] < g.wmax[k] - margin + SFC_EPS_F)) return false;
+    return true;
+}
+
+// expandSFCIncrementally, :1023-1093
+template <class W>
+DQ_FN bool sfc_expand(const W &w, const SfcWorldView &g, const SfcParams &p, const float *init, float *out) {
+    if (sfc_obstacle_in_box(w, g, init, p.margin)) return false;
+    float sfc[6], cand[6], upd[6];
+    int axis_cand[6] = {0, 1, 2, 3, 4, 5}, n_cand = 6;  // -x -y -z +x +y +z
+    const double mx = 2 * p.grid_resolution > p.agent_max_vel * p.dt ? 2 * p.grid_resolution : p.agent_max_vel * p.dt;
+    const int max_iter = (int)round(mx / g.res) + 1;
+    int axis_iter[6] = {0, 0, 0, 0, 0, 0};
+    int i = -1;
+    for (int k = 0; k < 6; k++) sfc[k] = init[k];
+    while (n_cand > 0) {
+        for (int k = 0; k < 6; k++) { cand[k] = sfc[k]; upd[k] = sfc[k]; }
+        while (sfc_in_boundary(g, upd, 0) && !sfc_obstacle_in_box(w, g, upd, p.margin)) {
+            i++;
+            if (i >= n_cand) i = 0;
+            // axis_cand[i] without dynamic indexing of a local array
+            int axis = 0;
+            for (int t = 0; t < 6; t++) axis = t == i ? axis_cand[t] : axis;
+            for (int k = 0; k < 6; k++) { sfc[k] = cand[k]; upd[k] = cand[k]; }
+            for (int k = 0; k < 3; k++) {
+                if (axis == k) {  // -k: the new slab is [min - res, min]
+                    upd[3 + k] = cand[k];
+                    cand[k] = (float)(cand[k] - g.res);
+                    upd[k] = cand[k];
+                }
+                if (axis == 3 + k) {  // +k
+                    upd[k] = cand[3 + k];
+                    cand[3 + k] = (float)(cand[3 + k] + g.res);
+                    upd[3 + k] = cand[3 + k];
+                }
+            }
+            bool over = false;
+            for (int t = 0; t < 6; t++)
+                if (t == axis) { axis_iter[t]++; over = axis_iter[t] > max_iter; }
+            if (over) break;
+        }
+        for (int t = 0; t < 5; t++)  // axis_cand.erase(begin + i)
+            if (t >= i && t + 1 < n_cand) axis_cand[t] = axis_cand[t + 1];
+        n_cand--;
+        if (i > 0) i--; else i = n_cand - 1;
+    }
+    const double delta = p.margin - ((int)(p.margin / g.res) * g.res);  // SFC margin compensation
+    for (int k = 0; k < 3; k++) {
+        if (sfc[k] > g.wmin[k] + SFC_EPS_F) sfc[k] = (float)(sfc[k] - delta);
+        if (sfc[3 + k] < g.wmax[k] - SFC_EPS_F) sfc[3 + k] = (float)(sfc[3 + k] + delta);
+    }
+    for (int k = 0; k < 6; k++) out[k] = sfc[k];
+    return true;
+}
+
+DQ_FN bool sfc_point_in_box(const float *b, const float *pt) {  // Box::isPointInBox, :109-116
+    for (int k = 0; k < 3; k++)
+        if (!(pt[k] > b[k] - SFC_EPS_F && pt[k] < b[3 + k] + SFC_EPS_F)) return false;
+    return true;
+}
+
+DQ_FN bool sfc_superset_of_hull(const float *b, const float *pts, int n) {  // Box::isSuperSetOfConvexHull, :170-185
+    for (int k = 0; k < 3; k++) {
+        float mn = pts[k], mxv = pts[k];
+        for (int q = 1; q < n; q++) {
+            mn = pts[3 * q + k] < mn ? pts[3 * q + k] : mn;
+            mxv = pts[3 * q + k] > mxv ? pts[3 * q + k] : mxv;
+        }
+        if (mn < b[k] - SFC_EPS_F || mxv > b[3 + k] + SFC_EPS_F) return false;
+    }
+    return true;
+}
+
+// expandSFCFromConvexHull, both overloads (:781-857); prev == nullptr: the first
+template <class W>
+DQ_FN bool sfc_from_hull(const W &w, const SfcWorldView &g, const SfcParams &p, const float *pts, int n_pts, const float *prev,
+                         float *out) {
+    float b[6];
+    for (int k = 0; k < 3; k++) b[k] = b[3 + k] = pts[k];
+    for (int q = 0; q < n_pts; q++)
+        for (int k = 0; k < 3; k++) {
+            b[k] = pts[3 * q + k] < b[k] ? pts[3 * q + k] : b[k];
+            b[3 + k] = pts[3 * q + k] > b[3 + k] ? pts[3 * q + k] : b[3 + k];
+        }
+    if (!prev) {
+        for (int k = 0; k < 3; k++) {
+            b[k] = (float)(round(b[k] / g.res) * g.res);
+            b[3 + k] = (float)(round(b[3 + k] / g.res) * g.res);
+        }
+        bool ok = sfc_expand(w, g, p, b, out);
+        if (ok && !sfc_superset_of_hull(out, pts, n_pts)) ok = false;
+        return ok;
+    }
+    for (int k = 0; k < 3; k++) {
+        b[k] = (float)(floor(b[k] / g.res) * g.res);
+        b[3 + k] = (float)(ceil(b[3 + k] / g.res) * g.res);
+    }
+    if (!(sfc_point_in_box(prev, b) && sfc_point_in_box(prev, b + 3))) {  // not sfc_prev.include(sfc_initial)
+        for (int k = 0; k < 3; k++) {
+            const float lo = prev[k] > b[k] ? prev[k] : b[k], hi = prev[3 + k] < b[3 + k] ? prev[3 + k] : b[3 + k];
+            b[k] = (float)(ceil((lo - SFC_EPS_F) / g.res) * g.res);
+            b[3 + k] = (float)(floor((hi + SFC_EPS_F) / g.res) * g.res);
+        }
+    }
+    return sfc_expand(w, g, p, b, out);
+}
+
+// initializeSFC (:435-452): M copies of the box grown from the cell of the agent's position.  sfcs: [M][6] in
+// global memory, written by W::store6 (one lane).  Returns false where the reference throws.
+template <class W>
+DQ_FN bool sfc_initialize(const W &w, const SfcWorldView &g, const SfcParams &p, const float *pos, int M, float *sfcs) {
+    float b[6], e[6];
+    for (int k = 0; k < 3; k++) {
+        b[k] = (float)(floor(pos[k] / g.res) * g.res);
+        b[3 + k] = (float)(ceil(pos[k] / g.res) * g.res);
+    }
+    if (!sfc_expand(w, g, p, b, e)) return false;
+    for (int m = 0; m < M; m++) w.store6(sfcs + 6 * m, e);
+    return true;
+}
+
+// constructSFCFromInitialTraj (:502-536).  initial_traj [M][n1][3]; sfcs [M][6] in/out.
+// Returns 0: greedy box (hull incl. waypoint), 1: box inside the previous one, 2: previous box reused.
+template <class W>
+DQ_FN int sfc_construct(const W &w, const SfcWorldView &g, const SfcParams &p, const float *initial_traj, int M, int n1,
+                        const float *goal, const float *waypoint, float *sfcs) {
+    float cur[6], nxt[6];
+    for (int m = 0; m < M - 1; m++) {  // shift, then the minor refinement reads the shifted boxes
+        w.load6(sfcs + 6 * (m + 1), nxt);
+        w.store6(sfcs + 6 * m, nxt);
+    }
+    w.fence();
+    for (int m = 0; m < M - 2; m++) {
+        w.load6(sfcs + 6 * (m + 1), nxt);
+        if (sfc_superset_of_hull(nxt, initial_traj + (size_t)m * n1 * 3, n1)) {
+            w.store6(sfcs + 6 * m, nxt);
+            w.fence();
+        }
+    }
+    float hull[9];
+    for (int k = 0; k < 3; k++) {
+        hull[k] = initial_traj[((size_t)(M - 1) * n1 + (n1 - 1)) * 3 + k];  // lastPoint
+        hull[3 + k] = goal[k];
+        hull[6 + k] = waypoint[k];
+    }
+    float upd[6];
+    int code = 0;
+    w.load6(sfcs + 6 * (M - 1), cur);
+    if (!sfc_from_hull(w, g, p, hull, 3, (const float *)nullptr, upd)) {
+        code = 1;
+        if (!sfc_from_hull(w, g, p, hull, 2, cur, upd)) {
+            code = 2;
+            for (int k = 0; k < 6; k++) upd[k] = cur[k];
+        }
+    }
+    w.store6(sfcs + 6 * (M - 1), upd);
+    return code;
+}
+
+}  // namespace dlscqp

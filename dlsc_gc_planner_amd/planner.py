@@ -129,6 +129,10 @@ class BatchTrajOptimizer:
         describes the dynamic obstacles every agent sees (radius, max_acc, downwash, size_prediction, horizon)."""
         return LscGenerator(self, n_total, nbr_offsets, nbr_ids, radius, downwash, local_ids, device, dyn)
 
+    def make_sfc_generator(self, boxes, resolution, world_min, world_max, radius, max_vel, grid_resolution, device=None):
+        """Device-resident safe-flight-corridor generator for a world given as axis-aligned boxes."""
+        return SfcGenerator(self, boxes, resolution, world_min, world_max, radius, max_vel, grid_resolution, device)
+
     def set_timing(self, capacity):
         self._check(self.lib.dlscqp_set_timing(self.handle, int(capacity)), "dlscqp_set_timing")
 
@@ -285,7 +289,13 @@ class LscGenerator:
         (first replanning step); dyn_position / dyn_velocity [n_dyn,3] f32 when the generator has dynamic obstacles:
         CUDA tensors.  Asynchronous."""
         g = self.c
+        # raw pointers below: the layout must be the dense one
+        goals = goals.contiguous()
+        plans = None if plans is None else plans.contiguous()
+        position = None if position is None else position.contiguous()
+        velocity = None if velocity is None else velocity.contiguous()
         if self.n_dyn:
+            dyn_position, dyn_velocity = dyn_position.contiguous(), dyn_velocity.contiguous()
             g.dyn_position, g.dyn_velocity = dyn_position.data_ptr(), dyn_velocity.data_ptr()
             self._keep_dyn = (dyn_position, dyn_velocity)
         g.first_plan = 1 if plans is None else 0
@@ -314,3 +324,60 @@ class LscGenerator:
         sl = (key >> 16).astype(np.int64)
         rows["slack"] = np.where(sl == 0xFFFF, -1, sl)
         return self.row_offsets, rows
+
+
+class SfcGenerator:
+    """Corridor boxes of every agent, kept in HBM ([N, M, 6] float32) and updated in place once per replanning step;
+    the tensor is what DeviceBatch takes as sfc boxes.  Mirrors CollisionConstraints::initializeSFC /
+    constructSFCFromInitialTraj (collision_constraints.cpp:435-452, 502-536)."""
+
+    def __init__(self, opt, boxes, resolution, world_min, world_max, radius, max_vel, grid_resolution, device):
+        import torch
+        self.torch, self.opt = torch, opt
+        cfg = opt.cfg
+        self.device = torch.device("cuda", cfg.device if device is None else device)
+        b = np.ascontiguousarray(boxes, dtype=np.float64).reshape(-1, 6)
+        wmin, wmax = np.ascontiguousarray(world_min, dtype=np.float32), np.ascontiguousarray(world_max, dtype=np.float32)
+        self.world = C.c_void_p()
+        lib = opt.lib
+        lib.dlscqp_world_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+        lib.dlscqp_world_destroy.argtypes = [C.c_void_p]
+        lib.dlscqp_generate_sfc_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(abi.SfcGen), C.c_void_p]
+        opt._check(lib.dlscqp_world_create(opt.handle, b.ctypes.data, len(b), float(resolution), wmin.ctypes.data, wmax.ctypes.data,
+                                           C.byref(self.world)), "dlscqp_world_create")
+        N = len(radius)
+        self.N = N
+        up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(self.device)  # noqa: E731
+        self.radius, self.max_vel = up(radius, np.float64), up(max_vel, np.float64)
+        self.sfcs = torch.zeros((N, cfg.M, 6), dtype=torch.float32, device=self.device)
+        self.codes = torch.zeros(N, dtype=torch.int32, device=self.device)
+        g = abi.SfcGen()
+        g.n_agents, g.grid_resolution = N, float(grid_resolution)
+        g.radius, g.max_vel = self.radius.data_ptr(), self.max_vel.data_ptr()
+        g.sfcs, g.out_code = self.sfcs.data_ptr(), self.codes.data_ptr()
+        self.c = g
+
+    def _launch(self, stream):
+        s = self.torch.cuda.current_stream(self.device) if stream is None else stream
+        rc = self.opt.lib.dlscqp_generate_sfc_device(self.opt.handle, self.world, C.byref(self.c), C.c_void_p(s.cuda_stream))
+        self.opt._check(rc, "dlscqp_generate_sfc_device")
+
+    def initialize(self, position, stream=None):
+        """position [N,3] f32 CUDA tensor: initializeSFC for every agent."""
+        position = position.contiguous()  # raw pointers below: the layout must be the dense one
+        self.c.initialize, self.c.position = 1, position.data_ptr()
+        self._keep = (position,)
+        self._launch(stream)
+
+    def update(self, initial_traj, goals, waypoints, stream=None):
+        """initial_traj [N,M,n+1,3], goals, waypoints [N,3] f32 CUDA tensors: one constructSFCFromInitialTraj step."""
+        initial_traj, goals, waypoints = initial_traj.contiguous(), goals.contiguous(), waypoints.contiguous()
+        self.c.initialize = 0
+        self.c.initial_traj, self.c.goals, self.c.waypoints = initial_traj.data_ptr(), goals.data_ptr(), waypoints.data_ptr()
+        self._keep = (initial_traj, goals, waypoints)
+        self._launch(stream)
+
+    def close(self):
+        if self.world:
+            self.opt.lib.dlscqp_world_destroy(self.world)
+            self.world = C.c_void_p()

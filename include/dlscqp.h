@@ -249,6 +249,39 @@ typedef struct dlscqp_lsc_gen {
 
 int dlscqp_generate_lsc_device(dlscqp_ctx *ctx, const dlscqp_lsc_gen *gen, void *stream);
 
+/* Row N2 of SURVEY.md section 8(f): safe-flight-corridor (SFC) boxes on the device.
+ * A world is a list of axis-aligned boxes (the rows of the reference's world CSV: centre x,y,z, size x,y,z,
+ * MapManager::updateOctreeFromCSV, map_manager.cpp:264-316) rasterised to an occupancy grid of `resolution` metres
+ * (param.world_resolution) together with, for every cell, the occupied cells nearest to it within 1 m -- what the
+ * reference asks octomap + DynamicEDT3D for (DynamicEDTOctomap::getDistanceAndClosestObstacle).  Built once on the
+ * host, resident in HBM afterwards. */
+typedef struct dlscqp_world dlscqp_world;
+int dlscqp_world_create(dlscqp_ctx *ctx, const double *boxes /*[n_boxes][6]*/, int32_t n_boxes, double resolution,
+                        const float world_min[3], const float world_max[3], dlscqp_world **out);
+void dlscqp_world_destroy(dlscqp_world *world);
+
+/* One replanning step of CollisionConstraints' corridor logic for n_agents agents, one wavefront each, device pointers:
+ *   initialize != 0: initializeSFC (collision_constraints.cpp:435-452) from `position`; out_code 0 = ok, -1 = the start
+ *                    cell is blocked (the reference throws std::invalid_argument);
+ *   initialize == 0: constructSFCFromInitialTraj (:502-536): boxes shift by one segment, the last box is grown from
+ *                    {last point of initial_traj, current goal, next waypoint}; out_code 0 = that box, 1 = the box grown
+ *                    inside the previous one without the waypoint, 2 = previous box kept.
+ * sfcs: [n_agents][M][6] float32 {min x,y,z, max x,y,z}, in/out; feeds dlscqp_device_batch.sfc_boxes directly. */
+typedef struct dlscqp_sfc_gen {
+    int32_t n_agents;
+    int32_t initialize;
+    double grid_resolution;      /* param.grid_resolution                                  */
+    const double *radius;        /* [n_agents] margin of the corridor = agent radius       */
+    const double *max_vel;       /* [n_agents]                                             */
+    const float *position;       /* [n_agents][3]            (initialize)                  */
+    const float *initial_traj;   /* [n_agents][M][n+1][3]    (construct)                   */
+    const float *goals;          /* [n_agents][3] current_goal_point (construct)           */
+    const float *waypoints;      /* [n_agents][3] next_waypoint      (construct)           */
+    float *sfcs;                 /* [n_agents][M][6]                                       */
+    int32_t *out_code;           /* [n_agents]                                             */
+} dlscqp_sfc_gen;
+int dlscqp_generate_sfc_device(dlscqp_ctx *ctx, const dlscqp_world *world, const dlscqp_sfc_gen *gen, void *stream);
+
 /* Host helper: convert n_rows AoS rows to the SoA arrays above (host memory, caller-owned). */
 void dlscqp_rows_to_soa(const dlscqp_lsc_row *rows, int64_t n_rows, float *nx, float *ny,
                         float *nz, float *px, float *py, float *pz, double *d, uint32_t *key);

@@ -16,6 +16,8 @@
 #include "../../dlsc_gc_planner_amd/csrc/gi_core.hpp"
 #include "../../dlsc_gc_planner_amd/csrc/lsc_core.hpp"
 #include "../../dlsc_gc_planner_amd/csrc/qp_tables.hpp"
+#include "../../dlsc_gc_planner_amd/csrc/sfc_core.hpp"
+#include "../../dlsc_gc_planner_amd/csrc/sfc_world.hpp"
 
 namespace {
 
@@ -212,6 +214,46 @@ extern "C" int emul_generate_lsc(const dlscqp_config *cfg, const dlscqp_lsc_gen 
             for (int m = 0; m < g.M; m++) lsc_item(g, self, g.nbr_ids[p], m, (size_t)per * (pair0 + (p - p0)));
         for (int o = 0; o < g.n_dyn; o++)
             for (int m = 0; m < g.M; m++) lsc_dyn_item(g, self, o, m, (size_t)per * (pair0 + (p1 - p0) + o));
+    }
+    return 0;
+}
+
+
+// Row N2: the device code of sfc_core.hpp with the lanes of a wave run one after another, on the world table that
+// the product's host code (sfc_world.cpp) builds.
+namespace {
+struct WaveSfcCpu {
+    template <class F>
+    bool any_of(int n, F f) const {
+        for (int i = 0; i < n; i++)
+            if (f(i)) return true;
+        return false;
+    }
+    void load6(const float *src, float *dst) const { for (int k = 0; k < 6; k++) dst[k] = src[k]; }
+    void store6(float *dst, const float *src) const { for (int k = 0; k < 6; k++) dst[k] = src[k]; }
+    void fence() const {}
+};
+}  // namespace
+
+extern "C" int emul_generate_sfc(const dlscqp_config *cfg, const double *boxes, int n_boxes, double resolution,
+                                 const float *world_min, const float *world_max, const dlscqp_sfc_gen *gen) {
+    using namespace dlscqp;
+    SfcWorldHost hw;
+    build_sfc_world(boxes, n_boxes, resolution, world_min, world_max, hw);
+    SfcWorldView v;
+    v.res = hw.res;
+    for (int k = 0; k < 3; k++) { v.wmin[k] = hw.wmin[k]; v.wmax[k] = hw.wmax[k]; v.lo[k] = hw.lo[k]; v.n[k] = hw.n[k]; }
+    v.near_d2 = hw.near_d2.data(); v.near_off = hw.near_off.data(); v.near_n = hw.near_n.data();
+    WaveSfcCpu w;
+    const int M = cfg->M, n1 = cfg->n + 1;
+    for (int a = 0; a < gen->n_agents; a++) {
+        SfcParams p{gen->radius[a], gen->grid_resolution, gen->max_vel[a], cfg->dt};
+        float *sfcs = gen->sfcs + (size_t)a * M * 6;
+        int code;
+        if (gen->initialize) code = sfc_initialize(w, v, p, gen->position + 3 * (size_t)a, M, sfcs) ? 0 : -1;
+        else code = sfc_construct(w, v, p, gen->initial_traj + (size_t)a * M * n1 * 3, M, n1, gen->goals + 3 * (size_t)a,
+                                  gen->waypoints + 3 * (size_t)a, sfcs);
+        if (gen->out_code) gen->out_code[a] = code;
     }
     return 0;
 }

@@ -135,3 +135,35 @@ def soa_to_rows(soa, R):
     sl = (key >> 16).astype(np.int64)
     rows["slack"] = np.where(sl == 0xFFFF, -1, sl)
     return rows
+
+
+def generate_sfc(cfg, world, radius, max_vel, grid_resolution, sfcs=None, position=None, initial_traj=None, goals=None, waypoints=None):
+    """Row N2 through the host build of sfc_core.hpp + sfc_world.cpp.  world: dict(boxes, resolution, world_min, world_max).
+    position given: initializeSFC; else constructSFCFromInitialTraj on `sfcs` [N][M][6].  Returns (sfcs, codes)."""
+    L = lib()
+    L.emul_generate_sfc.argtypes = [C.POINTER(abi.Config), C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.POINTER(abi.SfcGen)]
+    L.emul_generate_sfc.restype = C.c_int
+    N = len(radius)
+    g = abi.SfcGen()
+    keep = []
+
+    def arr(a, dt):
+        b = np.ascontiguousarray(a, dtype=dt)
+        keep.append(b)
+        return b.ctypes.data
+
+    g.n_agents, g.initialize, g.grid_resolution = N, 1 if position is not None else 0, grid_resolution
+    g.radius, g.max_vel = arr(radius, np.float64), arr(max_vel, np.float64)
+    out = np.zeros((N, cfg.M, 6), np.float32) if sfcs is None else np.ascontiguousarray(sfcs, dtype=np.float32).copy()
+    codes = np.zeros(N, np.int32)
+    g.sfcs, g.out_code = out.ctypes.data, codes.ctypes.data
+    if position is not None:
+        g.position = arr(position, np.float32)
+    else:
+        g.initial_traj, g.goals, g.waypoints = arr(initial_traj, np.float32), arr(goals, np.float32), arr(waypoints, np.float32)
+    boxes = np.ascontiguousarray(world["boxes"], dtype=np.float64).reshape(-1, 6)
+    wmin = np.ascontiguousarray(world["world_min"], dtype=np.float32)
+    wmax = np.ascontiguousarray(world["world_max"], dtype=np.float32)
+    rc = L.emul_generate_sfc(C.byref(cfg), boxes.ctypes.data, len(boxes), world["resolution"], wmin.ctypes.data, wmax.ctypes.data, C.byref(g))
+    assert rc == 0
+    return out, codes

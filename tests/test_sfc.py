@@ -132,3 +132,50 @@ def test_corridor_follows_a_flight_through_the_maze(maze):
         for b in sfcs:
             assert _clearance(b.astype(np.float64), occ) >= 0.1 - 1e-5
     assert 0 in codes
+
+
+# ---- the device source (sfc_core.hpp + sfc_world.cpp, host build) against the oracle ------------------------------
+def _flights(m, n_agents=10, steps=8, M=10, n=5, seed=3):
+    """Agents starting at the mission's start cells and creeping towards a neighbouring free cell: per step the
+    shifted plan, sub-goal and waypoint that constructSFCFromInitialTraj sees."""
+    rng = np.random.default_rng(seed)
+    start = np.array(m["start"], np.float32)[:n_agents]
+    goal = np.array(m["goal"], np.float32)[:n_agents]
+    frames = []
+    pos = start.copy()
+    for s in range(steps):
+        dirn = goal - pos
+        dirn[:, 2] = 0
+        dirn /= np.maximum(np.linalg.norm(dirn, axis=1, keepdims=True), 1e-6)
+        nxt = (pos + 0.12 * dirn + rng.normal(0, 0.01, pos.shape)).astype(np.float32)
+        traj = np.ascontiguousarray(np.linspace(pos, nxt, M * (n + 1)).transpose(1, 0, 2).reshape(n_agents, M, n + 1, 3), dtype=np.float32)
+        ahead = np.where(np.arange(n_agents) % 2 == 0, 0.2, 0.5)[:, None]  # near and far waypoints: greedy and fallback boxes
+        frames.append((traj, (nxt + 0.15 * dirn).astype(np.float32), (nxt + ahead * dirn).astype(np.float32)))
+        pos = nxt
+    return start, frames
+
+
+def test_device_source_matches_oracle_bit_for_bit(maze):
+    import emul_lib as E
+    from dlsc_gc_planner_amd import abi
+    m, w, occ = maze
+    cfg = abi.make_config(dim=2, M=10, dt=0.2, world_use_octomap=True, world_min=tuple(m["world"][:3]), world_max=tuple(m["world"][3:]))
+    world = dict(boxes=m["boxes"], resolution=m["world_resolution"], world_min=m["world"][:3], world_max=m["world"][3:])
+    start, frames = _flights(m)
+    N = len(start)
+    radius, vmax = np.full(N, m["radius"]), np.full(N, m["max_vel"])
+    dev, codes = E.generate_sfc(cfg, world, radius, vmax, m["grid_resolution"], position=start)
+    ref = np.stack([w.initialize(p, cfg.M)[1] for p in start])
+    assert (codes == 0).all() and np.array_equal(dev, ref)
+    seen = set()
+    for traj, goals, wps in frames:
+        dev, codes = E.generate_sfc(cfg, world, radius, vmax, m["grid_resolution"], sfcs=dev, initial_traj=traj, goals=goals, waypoints=wps)
+        for a in range(N):
+            code, ref[a] = w.construct(traj[a], goals[a], wps[a], ref[a])
+            assert code == codes[a], (a, code, codes[a])
+            seen.add(code)
+        assert np.array_equal(dev, ref)
+    assert 0 in seen and len(seen) >= 2  # greedy boxes and at least one fallback
+    # a blocked start cell is reported, not thrown
+    _, codes = E.generate_sfc(cfg, world, radius[:1], vmax[:1], m["grid_resolution"], position=np.float32([[0.0, 0.0, 1.0]]))
+    assert codes[0] == -1
