@@ -76,10 +76,11 @@ class ResultCsv:
 
 class ClosedLoop:
     def __init__(self, cfg, start, goal, radius=0.15, downwash=2.0, max_vel=1.0, max_acc=2.0, nominal_velocity=1.0,
-                 waypoint_step=0.5, device=0, dyn=None, result_csv=None):
+                 waypoint_step=0.5, device=0, dyn=None, result_csv=None, world=None):
         """dyn: None or dict(position [D,3], velocity [D,3], radius, max_acc, downwash [D], size_prediction, horizon) --
         obstacles that keep their velocity (obstacle.hpp: straight-line dynamic obstacles).  result_csv: path of a
-        result file in the reference's layout."""
+        result file in the reference's layout.  world: None or dict(boxes [K,6] centre+size, resolution, grid_resolution)
+        -- static obstacles: corridor boxes from the device generator (row N2) and waypoints from GridWaypoints."""
         import torch
         self.torch = torch
         self.cfg = cfg
@@ -109,6 +110,13 @@ class ClosedLoop:
             self.dyn_pos, self.dyn_vel = f32(dyn["position"]), f32(dyn["velocity"])
         self.gen = self.opt.make_lsc_generator(N, nbr_offsets, nbr_ids, np.full(N, radius), np.full(N, downwash), device=device,
                                                dyn=dyn)
+        self.world = world
+        self.sfc = None
+        if world is not None:
+            wmin, wmax = np.array(cfg.world_min[:], np.float32), np.array(cfg.world_max[:], np.float32)
+            self.sfc = self.opt.make_sfc_generator(world["boxes"], world["resolution"], wmin, wmax, np.full(N, radius),
+                                                   np.full(N, max_vel), world["grid_resolution"], device=device)
+            self.grid = GridWaypoints(world["boxes"], world["grid_resolution"], wmin, wmax, np.asarray(goal, np.float64), radius)
         self.csv = ResultCsv(result_csv, N, self.D) if result_csv else None
         self.sim_time = 0.0
         # agent records: static fields once, the five float3 fields are refreshed every step
@@ -118,7 +126,10 @@ class ClosedLoop:
         agents["n_slack_obs"] = self.D
         agents["max_vel"], agents["max_acc"], agents["radius"], agents["nominal_velocity"] = max_vel, max_acc, radius, nominal_velocity
         ro = self.gen.row_offsets
-        self.batch = self.opt.make_device_batch(agents, ro, np.zeros(0, abi.ROW_DTYPE), None, self.D, want_iters=True, device=device)
+        sfc0 = None if self.sfc is None else np.zeros((N, M, 6), np.float32)
+        self.batch = self.opt.make_device_batch(agents, ro, np.zeros(0, abi.ROW_DTYPE), sfc0, self.D, want_iters=True, device=device)
+        if self.sfc is not None:
+            self.batch.c.sfc_boxes = self.sfc.sfcs.data_ptr()  # the generator's tensor is the QP's SFC input
         for k in ("nx", "ny", "nz", "px", "py", "pz", "d", "key"):
             setattr(self.batch.c, k, self.gen.soa[k].data_ptr())
         self.ro32 = torch.from_numpy(ro.astype(np.int32)).to(dev)
@@ -128,6 +139,8 @@ class ClosedLoop:
         self.history = []
 
     def close(self):
+        if self.sfc is not None:
+            self.sfc.close()
         if self.csv:
             self.csv.close()
         self.opt.close()
@@ -137,9 +150,15 @@ class ClosedLoop:
         torch, cfg = self.torch, self.cfg
         n, dt = cfg.n, cfg.dt
         # waypoint: straight ahead towards the desired goal (stands in for the grid planner, see module doc)
-        to_goal = self.desired_goal - self.pos
-        dist = to_goal.norm(dim=1, keepdim=True)
-        wp = torch.where(dist <= self.waypoint_step, self.desired_goal, self.pos + to_goal / dist.clamp_min(1e-9) * self.waypoint_step)
+        if self.world is not None:
+            # static obstacles: the next cell of a shortest grid path (stands in for the reference's grid planner: paths are
+            # per agent, without PIBT's conflict resolution)
+            wp = torch.from_numpy(self.grid.next_waypoints(self.pos.cpu().numpy())).to(self.dev)
+        else:
+            to_goal = self.desired_goal - self.pos
+            dist = to_goal.norm(dim=1, keepdim=True)
+            wp = torch.where(dist <= self.waypoint_step, self.desired_goal,
+                             self.pos + to_goal / dist.clamp_min(1e-9) * self.waypoint_step)
         a = self.agent_f32
         a[:, 0:3], a[:, 3:6], a[:, 6:9], a[:, 9:12], a[:, 12:15] = self.pos, self.vel, self.acc, self.cur_goal, wp
         first = self.seq < 1  # planner_seq < 2 in the reference counts from 1
@@ -151,6 +170,10 @@ class ClosedLoop:
         else:
             self.gen.generate(self.cur_goal, plans=self.plans, **dkw)
             init = torch.cat([self.plans[:, 1:], self.plans[:, -1:, -1:].expand(-1, 1, n + 1, -1)], dim=1)
+        if self.sfc is not None:  # TrajPlanner::constructSFC (traj_planner.cpp:517-520): initializeSFC once, then one shift per step
+            if first:
+                self.sfc.initialize(self.pos)
+            self.sfc.update(init.contiguous(), self.cur_goal, wp)
         self.batch.launch(True, True)
         ok = (self.batch.out_status == abi.OK)
         gok = (self.batch.out_goal_status != abi.INFEASIBLE)
@@ -182,3 +205,62 @@ class ClosedLoop:
         d = d * torch.tensor([1.0, 1.0, 1.0 / self.downwash], device=self.dev)
         dist = d.norm(dim=2) + torch.eye(self.N, device=self.dev) * 1e9
         return float(dist.min() / (2 * self.radius))
+
+
+class GridWaypoints:
+    """Host-side stand-in for the reference's grid-based waypoint planner (grid_based_planner.cpp; SURVEY row N4 stays on
+    the host): a 2-D grid of `grid_resolution` cells over the world, a cell is blocked if an obstacle box comes within the
+    agent radius of its centre; per agent a breadth-first distance field from its goal cell.  next_waypoints() returns, for
+    every agent, the centre of the neighbouring cell (4-connected) with the smallest distance to the goal -- the goal
+    itself once the agent is in the goal cell.  No conflict resolution between agents (that is PIBT's job in the reference)."""
+
+    def __init__(self, boxes, grid_resolution, world_min, world_max, goals, radius):
+        from collections import deque
+        g = float(grid_resolution)
+        self.g = g
+        self.i0 = np.ceil(np.asarray(world_min[:2], np.float64) / g).astype(int)
+        self.n = np.floor(np.asarray(world_max[:2], np.float64) / g).astype(int) - self.i0 + 1
+        b = np.asarray(boxes, np.float64).reshape(-1, 6)
+        cx = (self.i0[0] + np.arange(self.n[0])) * g
+        cy = (self.i0[1] + np.arange(self.n[1])) * g
+        X, Y = np.meshgrid(cx, cy, indexing="ij")
+        free = np.ones(X.shape, bool)
+        for c in b:
+            free &= ~((np.abs(X - c[0]) < 0.5 * c[3] + radius) & (np.abs(Y - c[1]) < 0.5 * c[4] + radius))
+        self.free = free
+        self.goals = np.asarray(goals, np.float64)
+        self.dist = []
+        for gl in self.goals:
+            d = np.full(free.shape, -1, int)
+            c0 = self._cell(gl)
+            q = deque([c0])
+            d[c0] = 0
+            while q:
+                i, j = q.popleft()
+                for di, dj in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+                    a, bb = i + di, j + dj
+                    if 0 <= a < self.n[0] and 0 <= bb < self.n[1] and free[a, bb] and d[a, bb] < 0:
+                        d[a, bb] = d[i, j] + 1
+                        q.append((a, bb))
+            self.dist.append(d)
+
+    def _cell(self, p):
+        c = np.rint(np.asarray(p[:2], np.float64) / self.g).astype(int) - self.i0
+        return (int(np.clip(c[0], 0, self.n[0] - 1)), int(np.clip(c[1], 0, self.n[1] - 1)))
+
+    def next_waypoints(self, pos):
+        out = np.array(pos, np.float32)
+        for a, p in enumerate(pos):
+            i, j = self._cell(p)
+            d = self.dist[a]
+            if d[i, j] == 0:
+                out[a, :2] = self.goals[a, :2]
+                continue
+            best, bc = None, (i, j)
+            for di, dj in ((1, 0), (-1, 0), (0, 1), (0, -1)):
+                x, y = i + di, j + dj
+                if 0 <= x < self.n[0] and 0 <= y < self.n[1] and d[x, y] >= 0 and (best is None or d[x, y] < best):
+                    best, bc = d[x, y], (x, y)
+            out[a, 0] = (self.i0[0] + bc[0]) * self.g
+            out[a, 1] = (self.i0[1] + bc[1]) * self.g
+        return out

@@ -110,3 +110,51 @@ def test_closed_loop_with_dynamic_obstacles(gpu_required):
     assert worst_agents >= 0.999
     assert worst_obs >= 0.98  # soft constraints (slack variables): clearance up to the slack the QP bought
     assert fails <= 0.05 * 80 * sim.N
+
+
+def _maze():
+    m = json.load(open(os.path.join(HERE, "golden", "world_maze1.json")))
+    # launch/simulation.launch: 2-D, M = 10, communication range 3, octomap on
+    cfg = abi.make_config(dim=2, M=10, dt=0.2, control_input_weight=0.01, terminal_weight=1.0, communication_range=3.0,
+                          world_use_octomap=True, world_min=tuple(m["world"][:3]), world_max=tuple(m["world"][3:]), world_z_2d=1.0)
+    world = dict(boxes=m["boxes"], resolution=m["world_resolution"], grid_resolution=m["grid_resolution"])
+    return m, cfg, world
+
+
+def _wall_clearance(pos, boxes):
+    b = np.array(boxes)
+    d = np.maximum(np.abs(pos[:, None, :2] - b[None, :, :2]) - 0.5 * b[None, :, 3:5], 0)
+    return float(np.linalg.norm(d, axis=2).min())
+
+
+@pytest.mark.parametrize("agents,steps", [([0], 250), ([0, 1, 2, 3, 4], 200)])
+def test_maze_mission_with_device_corridors(gpu_required, agents, steps):
+    """The reference's default mission (maze10_dense, simulation.launch) with static obstacles: corridor boxes from the
+    device generator (row N2), half-spaces (N1), goal LP + QP, all resident in HBM; waypoints from a host-side grid
+    search (the reference's planner minus PIBT, so only agents flying in the same direction are used).  Checked: never
+    closer to a pillar than the agent radius, never closer to each other than the collision distance, no QP fail-safe,
+    the single agent arrives, the group of five crosses the maze."""
+    m, cfg, world = _maze()
+    start, goal = np.array(m["start"], np.float32)[agents], np.array(m["goal"], np.float32)[agents]
+    sim = ClosedLoop(cfg, start, goal, radius=m["radius"], downwash=2.0, max_vel=m["max_vel"], max_acc=m["max_acc"],
+                     nominal_velocity=1.0, waypoint_step=m["grid_resolution"], world=world)
+    try:
+        d0 = float(np.linalg.norm(goal - start, axis=1).mean())
+        worst, wall, fails = 1e9, 1e9, 0
+        for _ in range(steps):
+            status, _ = sim.step()
+            fails += int((status != abi.OK).sum())
+            if len(agents) > 1:
+                worst = min(worst, sim.min_separation())
+            wall = min(wall, _wall_clearance(sim.pos.cpu().numpy(), m["boxes"]))
+        dist = (sim.pos - sim.desired_goal).norm(dim=1).cpu().numpy()
+    finally:
+        sim.close()
+    print("maze", agents, "wall clearance", wall, "agent ratio", worst, "fail-safes", fails, "dist", dist, "of", d0)
+    assert wall >= m["radius"] - 1e-4
+    assert worst >= 0.999
+    assert fails == 0
+    if len(agents) == 1:
+        assert dist[0] < 0.15  # arrived (goal_threshold 0.1 of the launch file + float slack)
+    else:
+        assert dist.mean() < 0.4 * d0  # through the maze; the rest is the goal-column swap that needs PIBT
