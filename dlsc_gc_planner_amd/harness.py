@@ -116,7 +116,11 @@ class ClosedLoop:
             wmin, wmax = np.array(cfg.world_min[:], np.float32), np.array(cfg.world_max[:], np.float32)
             self.sfc = self.opt.make_sfc_generator(world["boxes"], world["resolution"], wmin, wmax, np.full(N, radius),
                                                    np.full(N, max_vel), world["grid_resolution"], device=device)
-            self.grid = GridWaypoints(world["boxes"], world["grid_resolution"], wmin, wmax, np.asarray(goal, np.float64), radius)
+            if world.get("pibt", False):
+                self.grid = PibtWaypoints(world["boxes"], world["grid_resolution"], wmin, wmax, np.asarray(start, np.float64),
+                                          np.asarray(goal, np.float64), radius)
+            else:
+                self.grid = GridWaypoints(world["boxes"], world["grid_resolution"], wmin, wmax, np.asarray(goal, np.float64), radius)
         self.csv = ResultCsv(result_csv, N, self.D) if result_csv else None
         self.sim_time = 0.0
         # agent records: static fields once, the five float3 fields are refreshed every step
@@ -153,7 +157,13 @@ class ClosedLoop:
         if self.world is not None:
             # static obstacles: the next cell of a shortest grid path (stands in for the reference's grid planner: paths are
             # per agent, without PIBT's conflict resolution)
-            wp = torch.from_numpy(self.grid.next_waypoints(self.pos.cpu().numpy())).to(self.dev)
+            if isinstance(self.grid, PibtWaypoints):
+                anchors = torch.cat([self.pos[:, None, :], self.plans[:, :, 0, :], self.plans[:, -1:, -1, :]], dim=1) \
+                    if self.seq > 0 else self.pos[:, None, :]
+                wp = torch.from_numpy(self.grid.step(self.cur_goal.cpu().numpy(), anchors.cpu().numpy(),
+                                                     float(cfg.communication_range))).to(self.dev)
+            else:
+                wp = torch.from_numpy(self.grid.next_waypoints(self.pos.cpu().numpy())).to(self.dev)
         else:
             to_goal = self.desired_goal - self.pos
             dist = to_goal.norm(dim=1, keepdim=True)
@@ -263,4 +273,113 @@ class GridWaypoints:
                     best, bc = d[x, y], (x, y)
             out[a, 0] = (self.i0[0] + bc[0]) * self.g
             out[a, 1] = (self.i0[1] + bc[1]) * self.g
+        return out
+
+
+class PibtWaypoints(GridWaypoints):
+    """GridWaypoints plus the conflict resolution of the reference's planner: waypoints are grid nodes, no two agents hold
+    the same node or swap nodes, and who yields is decided by priority inheritance with backtracking (PIBT, Okumura et al.;
+    reference: src/mapf/pibt.cpp:119-190, one step of it per replanning step, multi_sync_simulator.cpp:308-466).  An agent's
+    waypoint advances only when its sub-goal has reached the waypoint it holds; the others keep theirs.  Priorities: steps
+    since the agent last stood on its goal node, ties by initial path length, then id (pibt.cpp:14-21 without the obstacle
+    term).  Host-side and simplified (SURVEY row N4 stays on the host): not a restatement of the reference's update rules."""
+
+    def __init__(self, boxes, grid_resolution, world_min, world_max, start, goals, radius):
+        super().__init__(boxes, grid_resolution, world_min, world_max, goals, radius)
+        self.node = [self._cell(p) for p in np.asarray(start, np.float64)]
+        self.goal_node = [self._cell(g) for g in self.goals]
+        self.elapsed = [0] * len(self.node)
+        self.init_d = [int(self.dist[a][self.node[a]]) for a in range(len(self.node))]
+
+    def _pos(self, node):
+        return ((self.i0[0] + node[0]) * self.g, (self.i0[1] + node[1]) * self.g)
+
+    def step(self, sub_goals, anchors=None, comm_range=-1.0, reach=0.02):
+        """sub_goals [N,3]: current_goal_point of every agent; anchors [N,K,3]: current position and the segment start / end
+        points of the current plan -- with a communication range the next waypoint must stay within range/2 (L-infinity) of
+        all of them (multi_sync_simulator.cpp:384-407; the QP has the matching rows, traj_optimizer.cpp:490-513).
+        Returns the waypoints [N,3] float32."""
+        N = len(self.node)
+        sub_goals = np.asarray(sub_goals, np.float64)
+        # an agent resting on its goal node does not start a move, but can be pushed aside by priority inheritance
+        movable = [np.hypot(*(sub_goals[a, :2] - (self.goals[a, :2] if self.node[a] == self.goal_node[a] else self._pos(self.node[a])))) <= reach
+                   for a in range(N)]
+        if comm_range > 0 and anchors is not None:
+            anchors = np.asarray(anchors, np.float64)
+            for a in range(N):
+                if movable[a]:  # any neighbouring node is at most one cell further away than the node held now
+                    far = np.abs(anchors[a, :, :2] - np.array(self._pos(self.node[a]))).max()
+                    movable[a] = far + self.g <= 0.5 * comm_range - 1e-5
+        now = {self.node[a]: a for a in range(N)}
+        nxt, v_next = {}, [None] * N
+        for a in range(N):  # agents that are still on their way to their waypoint keep it
+            if not movable[a]:
+                v_next[a] = self.node[a]
+                nxt[self.node[a]] = a
+
+        def choose(a):
+            i, j = self.node[a]
+            cand = [(i + 1, j), (i - 1, j), (i, j + 1), (i, j - 1), (i, j)]
+            best, key = None, None
+            for u in cand:
+                if not (0 <= u[0] < self.n[0] and 0 <= u[1] < self.n[1]) or self.dist[a][u] < 0:
+                    continue
+                if u in nxt:
+                    continue  # vertex conflict
+                b = now.get(u)
+                if b is not None and b != a and v_next[b] == self.node[a]:
+                    continue  # swap conflict
+                gx, gy = self._pos(self.goal_node[a])
+                ux, uy = self._pos(u)
+                k = (int(self.dist[a][u]), 1 if (b is not None and b != a) else 0, np.hypot(ux - gx, uy - gy))
+                if key is None or k < key:
+                    best, key = u, k
+            return best
+
+        def pibt(a):
+            v = choose(a)
+            while v is not None:
+                nxt[v] = a
+                v_next[a] = v
+                b = now.get(v)
+                if b is not None and b != a and v_next[b] is None:
+                    if not pibt(b):  # the agent in the way could not move: try another node
+                        del nxt[v]
+                        v_next[a] = None
+                        v = choose_excluding(a, v)
+                        continue
+                return True
+            v_next[a] = self.node[a]
+            nxt[self.node[a]] = a
+            return False
+
+        banned = {}
+
+        def choose_excluding(a, v):
+            banned.setdefault(a, set()).add(v)
+            saved = dict(nxt)
+            for u in banned[a]:
+                nxt.setdefault(u, -1)
+            r = choose(a)
+            for u in list(nxt):
+                if nxt[u] == -1:
+                    del nxt[u]
+            nxt.update({k2: v2 for k2, v2 in saved.items() if k2 not in nxt})
+            return r
+
+        order = sorted(range(N), key=lambda a: (-self.elapsed[a], self.init_d[a], a))
+        for a in order:
+            if v_next[a] is None and self.node[a] != self.goal_node[a]:
+                pibt(a)
+        for a in range(N):  # resting agents that nobody pushed
+            if v_next[a] is None:
+                v_next[a] = self.node[a]
+        out = np.array(sub_goals, np.float32)
+        for a in range(N):
+            self.node[a] = v_next[a]
+            self.elapsed[a] = 0 if self.node[a] == self.goal_node[a] else self.elapsed[a] + 1
+            if self.node[a] == self.goal_node[a]:
+                out[a, :2] = self.goals[a, :2]
+            else:
+                out[a, :2] = self._pos(self.node[a])
         return out

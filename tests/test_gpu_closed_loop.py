@@ -158,3 +158,35 @@ def test_maze_mission_with_device_corridors(gpu_required, agents, steps):
         assert dist[0] < 0.15  # arrived (goal_threshold 0.1 of the launch file + float slack)
     else:
         assert dist.mean() < 0.4 * d0  # through the maze; the rest is the goal-column swap that needs PIBT
+
+
+def test_full_maze_mission_with_pibt_waypoints(gpu_required, tmp_path):
+    """All ten agents of the reference's default mission (two groups crossing the maze head-on through single-lane
+    corridors): waypoints from the host-side PIBT stand-in (harness.PibtWaypoints), everything else on the device.  The
+    reference's committed run of this mission reports safety_ratio_agent 1.00058 and every agent at its goal
+    (log/summary_DLSCGC_10agents.csv); here: every agent arrives, the safety ratio stays above 1, no agent comes closer
+    to a pillar than its radius, no QP fail-safe, and the run is written in the reference's result layout."""
+    m, cfg, world = _maze()
+    world = dict(world, pibt=True)
+    path = tmp_path / "result_maze10.csv"
+    sim = ClosedLoop(cfg, np.array(m["start"], np.float32), np.array(m["goal"], np.float32), radius=m["radius"], downwash=2.0,
+                     max_vel=m["max_vel"], max_acc=m["max_acc"], nominal_velocity=1.0, waypoint_step=m["grid_resolution"],
+                     world=world, result_csv=str(path))
+    try:
+        worst, wall, fails, done = 1e9, 1e9, 0, None
+        for k in range(450):
+            status, _ = sim.step()
+            fails += int((status != abi.OK).sum())
+            worst = min(worst, sim.min_separation())
+            p = sim.pos.cpu().numpy()
+            wall = min(wall, _wall_clearance(p, m["boxes"]))
+            if done is None and (np.linalg.norm(p - np.array(m["goal"]), axis=1) < 0.1).all():
+                done = (k + 1) * cfg.dt
+                break
+    finally:
+        sim.close()
+    print("maze10 with PIBT: all agents at their goals after", done, "s; safety ratio", worst, "wall clearance", wall, "fail-safes", fails)
+    assert done is not None and done < 90.0
+    assert worst >= 1.0 and wall >= m["radius"] - 1e-4 and fails == 0
+    lines = open(path).read().strip().split("\n")
+    assert lines[0].count("planning_time") == 10 and len(lines) == 1 + 2 * int(round(done / cfg.dt))
