@@ -108,14 +108,10 @@ def main():
     ap.add_argument("--no-latency", action="store_true", help="skip the single-swarm host-to-host latency loop")
     ap.add_argument("--no-order-hint", action="store_true",
                     help="launch agents in id order instead of most-expensive-first (previous step's iteration counts)")
-    ap.add_argument("--overlap", action="store_true",
-                    help="N>1: chunked launches with the all-gather of each chunk overlapping the next launches, instead "
-                         "of one launch + one all-gather per step (pays only when a launch has a long straggler tail)")
-    ap.add_argument("--bulk-chunks", type=int, default=4,
-                    help="N>1 overlapped exchange: the agents outside the straggler chunk are planned in this many "
-                         "consecutive launches, each followed by the all-gather of its part of the plan table")
-    ap.add_argument("--hard-fraction", type=float, default=0.125,
-                    help="N>1 overlapped exchange: share of the agents (most expensive first) in the straggler chunk")
+    ap.add_argument("--exchange", choices=("pipelined", "serial"), default="pipelined",
+                    help="N>1: 'pipelined' posts the all-gather of step k on a communication stream so that it runs while "
+                         "step k+1 plans the agents whose neighbours are all local (every agent of this workload: shards "
+                         "are whole swarms); 'serial' runs launch and all-gather back to back on one stream")
     ap.add_argument("--force-dist", action="store_true", help="(test) create the process group even for one rank")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic_latest.json"))
     args = ap.parse_args()
@@ -151,76 +147,45 @@ def main():
     N = len(wl["agents"])
     K = wl["K"]
     db = opt.make_device_batch(wl["agents"], wl["row_offsets"], wl["rows"], None, 0, want_iters=True)
-    overlap = use_dist and args.overlap and not args.no_order_hint
     shape1 = tuple(db.out_ctrl.shape[1:])
 
     for _ in range(args.warmup):
         db.launch(True, True)
     torch.cuda.synchronize(dev)
-    H = 0
     if not args.no_order_hint:
         # closed-loop planners replan the same agents every 0.2 s and an agent's difficulty changes slowly:
         # launch the agents that needed most active-set iterations in the previous step first
         prev_iters = db.out_iters.cpu().numpy()[:, 0]
-        order = np.argsort(-prev_iters, kind="stable").astype(np.int32)
-        if overlap:
-            # N>1: keep the batch itself in that order (slot == index), so that a contiguous range of the
-            # output table is final as soon as its chunk's launch retires and can be all-gathered while the
-            # stragglers of the other chunk are still iterating
-            pa, pro, prows = workloads.permute_batch(wl["agents"], wl["row_offsets"], wl["rows"], order)
-            wl = dict(wl, agents=pa, row_offsets=pro, rows=prows)
-            db = opt.make_device_batch(pa, pro, prows, None, 0, want_iters=True)
-            H = max(64, int(N * args.hard_fraction)) if N > 128 else N // 2
-        else:
-            db.set_order(order)
+        db.set_order(np.argsort(-prev_iters, kind="stable").astype(np.int32))
+    pipelined = False
     if use_dist:
-        if overlap:
-            # chunk 0: the stragglers (most expensive agents) on a high-priority stream; chunks 1..B: the rest, in
-            # consecutive launches on a second stream.  Every launch is followed by the asynchronous all-gather of its
-            # contiguous part of the plan table, so the exchange of chunk k runs while chunk k+1 (and the stragglers)
-            # are still being planned; all ranks issue the collectives in the same order.
-            B = max(1, min(args.bulk_chunks, (N - H) // 64))
-            edges = [0, H] + [H + (N - H) * (b + 1) // B for b in range(B)]
-            chunks = [(edges[c], edges[c + 1] - edges[c]) for c in range(B + 1)]
-            g_parts = [torch.empty((world, cnt) + shape1, dtype=torch.float32, device=dev) for _, cnt in chunks]
-            s_hard = torch.cuda.Stream(dev, priority=-1)
-            s_bulk = torch.cuda.Stream(dev)
+        from dlsc_gc_planner_amd import sharding
+        # Which agents of step k+1 need the gathered table of step k?  Those with a neighbour on another rank.  Every
+        # rank owns whole swarms here (an agent's neighbours are the other 63 agents of its swarm), so there are none:
+        # the exchange of step k may run while step k+1 is planned.
+        lo = rank * N
+        members = lo + (np.arange(N) // 64 * 64)[:, None] + np.arange(64)[None, :]  # [N, 64] ids of the agent's swarm
+        nbr_ids = members[members != (lo + np.arange(N))[:, None]]                 # ... without the agent itself
+        halo = sharding.halo_agents(np.arange(N + 1) * 63, nbr_ids, lo, lo + N)
+        pipelined = args.exchange == "pipelined" and len(halo) == 0
+        if pipelined:
+            xchg = sharding.PlanExchange(dist, world, N, shape1, torch.float32, dev)
         else:
             gathered = torch.empty((world * N,) + shape1, dtype=torch.float32, device=dev)
 
     def step():
-        if not use_dist:
-            db.launch(True, True)
-        elif not overlap:
-            db.launch(True, True)
+        db.launch(True, True)
+        if pipelined:
+            # exchange of this step's plans, asynchronous: complete before the step after the next is posted
+            xchg.post(db.out_ctrl)
+        elif use_dist:
             # the per-step exchange: every agent's solved control points to every rank
             dist.all_gather_into_tensor(gathered, db.out_ctrl)
-        else:
-            cur = torch.cuda.current_stream(dev)
-            s_hard.wait_stream(cur)
-            s_bulk.wait_stream(cur)
-            works = []
-            with torch.cuda.stream(s_hard):
-                db.launch(True, True, offset=chunks[0][0], count=chunks[0][1])
-            with torch.cuda.stream(s_bulk):
-                for c in range(1, len(chunks)):
-                    o, cnt = chunks[c]
-                    db.launch(True, True, offset=o, count=cnt)
-                    works.append(dist.all_gather_into_tensor(g_parts[c].view((world * cnt,) + shape1), db.out_ctrl[o:o + cnt],
-                                                             async_op=True))
-            with torch.cuda.stream(s_hard):
-                o, cnt = chunks[0]
-                works.append(dist.all_gather_into_tensor(g_parts[0].view((world * cnt,) + shape1), db.out_ctrl[o:o + cnt],
-                                                         async_op=True))
-            for wk in works:
-                wk.wait()  # stream-level wait of the current stream, not a host block
-            cur.wait_stream(s_hard)
-            cur.wait_stream(s_bulk)
 
     for _ in range(2):
         step()
     torch.cuda.synchronize(dev)
-    opt.set_timing(0 if overlap else args.steps)
+    opt.set_timing(args.steps)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -238,20 +203,10 @@ def main():
         elapsed = float(tt.item())
     if use_dist:
         # the gathered table must hold this rank's own block
-        if overlap:
-            for (o, cnt), gp in zip(chunks, g_parts):
-                assert torch.equal(gp[rank], db.out_ctrl[o:o + cnt])
-        else:
-            assert torch.equal(gathered[rank * N:(rank + 1) * N], db.out_ctrl)
-    if overlap:
-        # roofline leg: the chunks of the timed steps overlap each other, so time whole-batch launches
-        opt.set_timing(10)
-        for _ in range(10):
-            db.launch(True, True)
+        table = xchg.table() if pipelined else gathered
         torch.cuda.synchronize(dev)
-        kms = opt.kernel_times_ms(10)
-    else:
-        kms = opt.kernel_times_ms(args.steps)
+        assert torch.equal(table[rank * N:(rank + 1) * N], db.out_ctrl)
+    kms = opt.kernel_times_ms(args.steps)
     res = db.results()
 
     if rank == 0:
@@ -300,10 +255,9 @@ def main():
                 "agents_per_gpu": N, "segments": M, "degree": n, "lsc_rows_per_agent": K,
                 "vars_per_agent": dim * M * (n + 1), "ineq_rows_per_agent": K + 2 * 207,
                 "exchange": ("none (1 GPU)" if not use_dist else
-                             "RCCL all-gather of control points per step in %d chunks overlapping the launches (%d "
-                             "stragglers on a high-priority stream, the other %d agents in %d consecutive launches)"
-                             % (len(chunks), H, N - H, len(chunks) - 1) if overlap else
-                             "one RCCL all-gather of control points per step"),
+                             "one RCCL all-gather of control points per step, posted on a communication stream: runs "
+                             "while the next step plans the agents without remote neighbours (all of them here)"
+                             if pipelined else "one RCCL all-gather of control points per step, after the launch"),
                 "launch_order": "id" if args.no_order_hint else "previous step's iteration count, descending",
                 "solved_fraction": float(ok.mean()), "mean_active_set_iterations": float(it[:, 0].mean()),
                 "max_active_set_iterations": int(it[:, 0].max()), "seed": args.seed,

@@ -212,16 +212,27 @@ struct KernelArgs {
     int32_t *out_iters;
     const int32_t *order;            // optional launch permutation
     unsigned long long *out_stamps;  // [n_agents][12], diagnostic build only
+    unsigned char *work;             // HBM working sets [n_agents][work_stride] of the WS_HBM kernel, else null
+    size_t work_stride;
 };
 
 #ifndef DQ_KERNEL_ATTR
 #define DQ_KERNEL_ATTR __launch_bounds__(64, 2)
 #endif
-template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK>
+// WS_HBM: the agent's working set (Q, S, x, bound table: MemLayout) lives in a per-slot HBM buffer instead of LDS -- for
+// the shapes whose working set exceeds the 160 KiB of a CU (3-D, M = 10 with four or more slack obstacles: r > 110,
+// > 200 KB).  Same code, same layout; what was an LDS round trip becomes an L1/L2 round trip (the buffer of a running
+// agent stays cache-resident), so an iteration costs several times more -- a capability path for the reference's
+// ten-agent forest missions, not a throughput path.  One wavefront owns a buffer and a wavefront's memory operations
+// are performed in program order, so no fences are needed between its lanes.
+template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK, bool WS_HBM = false>
 __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, KernelArgs a) {
-    extern __shared__ __align__(16) unsigned char smem[];
+    extern __shared__ __align__(16) unsigned char lds[];
     if ((int)blockIdx.x >= a.n_slots_launch) return;
     const int slot = a.slot0 + (int)blockIdx.x;
+    unsigned char *smem;
+    if constexpr (WS_HBM) smem = a.work + (size_t)slot * a.work_stride;
+    else smem = lds;
     const int ag = a.order ? a.order[slot] : slot;
     if (ag < 0 || ag >= a.n_agents) return;
     WaveGpu w;
@@ -362,6 +373,8 @@ struct KernelChoice {
     kernel_t fn;
     int id, KU, SU;
 };
+constexpr int DQ_ID_HBM = 7;  // the runtime-shape two-register instantiation is the one that also exists as WS_HBM
+const kernel_t dlscqp_plan_kernel_hbm = dlscqp_plan_kernel<2, 0, 0, 0, 4, 10, -1, true>;
 
 // Kernel instantiation for a batch: the shared table in gi_core.hpp (DQ_INSTANCES / select_instance).
 KernelChoice select_kernel(const KParams &kp, int max_slack_obs, int kmax) {
@@ -410,6 +423,8 @@ struct dlscqp_ctx {
     Slot *d_slots = nullptr;
     hipStream_t stream = nullptr;
     int max_dyn_lds[DQ_N_INSTANCES] = {};
+    void *work = nullptr;  // working sets of the WS_HBM kernel
+    size_t work_bytes = 0;
     // staging for the host-buffer entry points
     unsigned char *h_stage = nullptr, *d_stage = nullptr;
     size_t stage_cap = 0;
@@ -482,6 +497,7 @@ extern "C" void dlscqp_destroy(dlscqp_ctx *c) {
     if (c->d_tabSIW) (void)hipFree(c->d_tabSIW);
     if (c->d_slots) (void)hipFree(c->d_slots);
     if (c->d_stage) (void)hipFree(c->d_stage);
+    if (c->work) (void)hipFree(c->work);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -560,20 +576,31 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         return DLSCQP_ERR_UNSUPPORTED;
     }
     MemLayout lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, instance_n_in_lds(kc.id));
-    if (lay.bytes > LDS_LIMIT) {
-        char msg[256];
-        snprintf(msg, sizeof msg,
-                 "agent working set %d B exceeds the 160 KiB LDS of a gfx950 CU (dim %d, M %d, %d slack obstacles)",
-                 lay.bytes, c->dim, c->M, b->max_slack_obs);
-        g_last_error = msg;
-        return DLSCQP_ERR_UNSUPPORTED;
-    }
-    if (lay.bytes > c->max_dyn_lds[kc.id]) {
+    const bool ws_hbm = lay.bytes > LDS_LIMIT;
+    KernelArgs a;
+    a.work = nullptr;
+    a.work_stride = 0;
+    if (ws_hbm) {
+        // working set beyond the LDS of a CU: the runtime-shape kernel with per-slot working sets in HBM.  The buffer
+        // belongs to the context: launches of one context that use it must not overlap.
+        kc = KernelChoice{dlscqp_plan_kernel_hbm, DQ_ID_HBM, 4, 10};
+        lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, true);
+        a.work_stride = ((size_t)lay.bytes + 255) & ~(size_t)255;
+        const size_t need = a.work_stride * (size_t)b->n_agents;
+        if (need > c->work_bytes) {
+            HIP_TRY(hipDeviceSynchronize());
+            if (c->work) (void)hipFree(c->work);
+            c->work = nullptr;
+            c->work_bytes = 0;
+            HIP_TRY(hipMalloc(&c->work, need));
+            c->work_bytes = need;
+        }
+        a.work = static_cast<unsigned char *>(c->work);
+    } else if (lay.bytes > c->max_dyn_lds[kc.id]) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kc.fn), hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
         c->max_dyn_lds[kc.id] = lay.bytes;
     }
     kernel_t kfn = kc.fn;
-    KernelArgs a;
     a.n_agents = b->n_agents;
     a.slot0 = b->launch_count > 0 ? b->launch_offset : 0;
     a.n_slots_launch = b->launch_count > 0 ? b->launch_count : b->n_agents;
@@ -601,7 +628,7 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kc.fn), hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes + 8016));
     hipLaunchKernelGGL(kfn, dim3(a.n_slots_launch), dim3(64), lay.bytes + 8016, stream, c->kp, lay, a);
 #else
-    hipLaunchKernelGGL(kfn, dim3(a.n_slots_launch), dim3(64), lay.bytes, stream, c->kp, lay, a);
+    hipLaunchKernelGGL(kfn, dim3(a.n_slots_launch), dim3(64), ws_hbm ? 0 : lay.bytes, stream, c->kp, lay, a);
 #endif
     HIP_TRY(hipGetLastError());
     if (timed) {

@@ -74,6 +74,41 @@ class ResultCsv:
         self.fh.close()
 
 
+class SpinObstacles:
+    """The reference's spinning obstacles (SpinObstacle::getSpinObstacle, obstacle.hpp:113-149): obstacle o circles the axis
+    (axis_position, axis_ori) through its start point with tangential speed `speed`; state(t) returns what the planner is
+    told at time t -- position and velocity, float32 [D,3] (it then extrapolates with constant velocity)."""
+
+    def __init__(self, obstacles):
+        """obstacles: the mission file's "obstacles" entries of type "spin"."""
+        o = [ob for ob in obstacles if ob["type"] == "spin"]
+        self.axis = np.array([ob["axis_position"] for ob in o], np.float64)
+        n = np.array([ob["axis_ori"] for ob in o], np.float64)
+        self.n = n / np.linalg.norm(n, axis=1, keepdims=True)
+        self.a = np.array([ob["start"] for ob in o], np.float64) - self.axis
+        r = self.a - (self.a * self.n).sum(1, keepdims=True) * self.n
+        self.w = np.array([ob["speed"] for ob in o], np.float64) / np.linalg.norm(r, axis=1)
+        self.radius = np.array([ob["size"] for ob in o], np.float64)
+        self.max_acc = np.array([ob["max_acc"] for ob in o], np.float64)
+        self.downwash = np.array([ob["downwash"] if ob["downwash"] != 0 else 1.0 for ob in o], np.float64)
+
+    @staticmethod
+    def _rotate(v, n, theta):  # Rodrigues; the reference conjugates with the unit quaternion of the same rotation
+        c, s = np.cos(theta)[:, None], np.sin(theta)[:, None]
+        return v * c + np.cross(n, v) * s + n * (n * v).sum(1, keepdims=True) * (1 - c)
+
+    def state(self, t):
+        p = self._rotate(self.a, self.n, self.w * t)
+        v = self.w[:, None] * self._rotate(p, self.n, np.full(len(self.w), np.pi / 2))
+        return (self.axis + p).astype(np.float32), v.astype(np.float32)
+
+    def dyn(self, size_prediction=1, horizon=1.0, duration=-1.0):
+        """The `dyn` argument of ClosedLoop for these obstacles."""
+        p, v = self.state(0.0)
+        return dict(position=p, velocity=v, radius=self.radius, max_acc=self.max_acc, downwash=self.downwash,
+                    size_prediction=size_prediction, horizon=horizon, model=self, duration=duration)
+
+
 class ClosedLoop:
     def __init__(self, cfg, start, goal, radius=0.15, downwash=2.0, max_vel=1.0, max_acc=2.0, nominal_velocity=1.0,
                  waypoint_step=0.5, device=0, dyn=None, result_csv=None, world=None):
@@ -106,6 +141,7 @@ class ClosedLoop:
         nbr_offsets = np.arange(N + 1) * (N - 1)
         self.dyn = dyn
         self.D = 0 if dyn is None else len(dyn["radius"])
+        self.dyn_model = None if dyn is None else dyn.get("model")
         if self.D:
             self.dyn_pos, self.dyn_vel = f32(dyn["position"]), f32(dyn["velocity"])
         self.gen = self.opt.make_lsc_generator(N, nbr_offsets, nbr_ids, np.full(N, radius), np.full(N, downwash), device=device,
@@ -160,8 +196,12 @@ class ClosedLoop:
             if isinstance(self.grid, PibtWaypoints):
                 anchors = torch.cat([self.pos[:, None, :], self.plans[:, :, 0, :], self.plans[:, -1:, -1, :]], dim=1) \
                     if self.seq > 0 else self.pos[:, None, :]
+                gdyn = None
+                if self.D:
+                    gdyn = dict(position=self.dyn_pos.cpu().numpy(), velocity=self.dyn_vel.cpu().numpy(), radius=self.dyn["radius"],
+                                max_acc=self.dyn["max_acc"], horizon=cfg.M * cfg.dt, uncertainty_horizon=self.dyn.get("horizon", 1.0))
                 wp = torch.from_numpy(self.grid.step(self.cur_goal.cpu().numpy(), anchors.cpu().numpy(),
-                                                     float(cfg.communication_range))).to(self.dev)
+                                                     float(cfg.communication_range), dyn=gdyn)).to(self.dev)
             else:
                 wp = torch.from_numpy(self.grid.next_waypoints(self.pos.cpu().numpy())).to(self.dev)
         else:
@@ -197,15 +237,45 @@ class ClosedLoop:
         if self.csv:
             torch.cuda.synchronize(self.dev)
             dyn_now = (self.dyn_pos.cpu().numpy(), self.dyn_vel.cpu().numpy()) if self.D else None
+            if self.dyn_model is not None:
+                obs_state = lambda tau: (self.dyn_model.state(self.sim_time + tau)[0], self.dyn["radius"])  # noqa: E731
+            else:
+                obs_state = lambda tau: (dyn_now[0] + dyn_now[1] * np.float32(tau), self.dyn["radius"])  # noqa: E731
             self.csv.write_step(self.sim_time, self.plans.cpu().numpy(), n, dt, time.perf_counter() - t_wall,
-                                None if dyn_now is None else
-                                (lambda tau: (dyn_now[0] + dyn_now[1] * np.float32(tau), self.dyn["radius"])))
+                                None if dyn_now is None else obs_state)
         self.pos, self.vel, self.acc = c0.clone(), v0, (v1 - v0) * s2
-        if self.D:
-            self.dyn_pos = self.dyn_pos + self.dyn_vel * np.float32(dt)
         self.sim_time += dt
+        if self.D and 0 < self.dyn.get("duration", -1.0) < self.sim_time:
+            self.dyn_model = None
+            self.dyn_pos = torch.full_like(self.dyn_pos, 1000.0)
+            self.dyn_vel = torch.zeros_like(self.dyn_vel)
+        elif self.dyn_model is not None:
+            p, v = self.dyn_model.state(self.sim_time)
+            self.dyn_pos, self.dyn_vel = torch.from_numpy(p).to(self.dev), torch.from_numpy(v).to(self.dev)
+        elif self.D:
+            self.dyn_pos = self.dyn_pos + self.dyn_vel * np.float32(dt)
         self.seq += 1
         return self.batch.out_status, self.batch.out_iters
+
+    def step_inputs(self):
+        """Host copies of what the last step's launch read -- (agents, row_offsets, rows, sfc or None, max_slack_obs) in the
+        layout of BatchTrajOptimizer.plan -- for checking a closed-loop step against another solver (tests)."""
+        self.torch.cuda.synchronize(self.dev)
+        agents = self.batch.t["agents"].cpu().numpy().view(abi.AGENT_DTYPE).reshape(-1).copy()
+        ro, rows = self.gen.rows_host()
+        sfc = None if self.sfc is None else self.sfc.sfcs.cpu().numpy().copy()
+        return agents, ro, rows, sfc, self.D
+
+    def min_obstacle_separation(self):
+        """Smallest agent-to-dynamic-obstacle distance in the pair's downwash metric divided by the sum of the radii (the
+        reference's safety_ratio_obs, multi_sync_simulator.cpp:686-712)."""
+        torch = self.torch
+        r_o = torch.tensor(self.dyn["radius"], dtype=torch.float32, device=self.dev)
+        dw_o = torch.tensor(self.dyn["downwash"], dtype=torch.float32, device=self.dev)
+        dw = (r_o * dw_o + self.radius * self.downwash) / (self.radius + r_o)
+        d = self.pos[:, None, :] - self.dyn_pos[None, :, :]
+        d = torch.stack([d[..., 0], d[..., 1], d[..., 2] / dw[None, :]], dim=-1)
+        return float((d.norm(dim=2) / (self.radius + r_o)[None, :]).min())
 
     def min_separation(self):
         """Smallest pairwise distance in the downwash metric divided by the collision distance (>= 1: no collision),
@@ -286,6 +356,7 @@ class PibtWaypoints(GridWaypoints):
 
     def __init__(self, boxes, grid_resolution, world_min, world_max, start, goals, radius):
         super().__init__(boxes, grid_resolution, world_min, world_max, goals, radius)
+        self.radius = float(radius)
         self.node = [self._cell(p) for p in np.asarray(start, np.float64)]
         self.goal_node = [self._cell(g) for g in self.goals]
         self.elapsed = [0] * len(self.node)
@@ -294,15 +365,33 @@ class PibtWaypoints(GridWaypoints):
     def _pos(self, node):
         return ((self.i0[0] + node[0]) * self.g, (self.i0[1] + node[1]) * self.g)
 
-    def step(self, sub_goals, anchors=None, comm_range=-1.0, reach=0.02):
+    def step(self, sub_goals, anchors=None, comm_range=-1.0, reach=0.02, dyn=None):
         """sub_goals [N,3]: current_goal_point of every agent; anchors [N,K,3]: current position and the segment start / end
         points of the current plan -- with a communication range the next waypoint must stay within range/2 (L-infinity) of
         all of them (multi_sync_simulator.cpp:384-407; the QP has the matching rows, traj_optimizer.cpp:490-513).
-        Returns the waypoints [N,3] float32."""
+        dyn: None or dict(position, velocity [D,3], radius, max_acc [D], horizon, uncertainty_horizon): nodes inside the
+        region a dynamic obstacle can reach within the planning horizon are "warning" nodes (Obstacle::isCollided,
+        obstacle.hpp:26-37; grid_based_planner.cpp:140-154): an agent holding one may move on at once, and free nodes are
+        preferred to warning nodes before anything else.  Returns the waypoints [N,3] float32."""
         N = len(self.node)
         sub_goals = np.asarray(sub_goals, np.float64)
+        if dyn is not None and len(dyn["radius"]):
+            h = float(dyn["horizon"])
+            ts = np.arange(0.0, h + 1e-12, min(0.1 * h, 0.1))
+            grow = 0.5 * np.asarray(dyn["max_acc"], np.float64)[:, None] * np.minimum(ts, dyn["uncertainty_horizon"])[None, :] ** 2
+            reach_r = self.radius + np.asarray(dyn["radius"], np.float64)[:, None] + grow  # [D,T]
+            track = np.asarray(dyn["position"], np.float64)[:, None, :] + np.asarray(dyn["velocity"], np.float64)[:, None, :] * ts[None, :, None]
+
+            def warn(a, u):
+                pt = np.array([*self._pos(u), sub_goals[a, 2]])
+                return bool((np.linalg.norm(track - pt, axis=2) < reach_r).any())
+        else:
+            def warn(a, u):
+                return False
         # an agent resting on its goal node does not start a move, but can be pushed aside by priority inheritance
-        movable = [np.hypot(*(sub_goals[a, :2] - (self.goals[a, :2] if self.node[a] == self.goal_node[a] else self._pos(self.node[a])))) <= reach
+        threatened = [warn(a, self.node[a]) for a in range(N)]
+        movable = [threatened[a] or
+                   np.hypot(*(sub_goals[a, :2] - (self.goals[a, :2] if self.node[a] == self.goal_node[a] else self._pos(self.node[a])))) <= reach
                    for a in range(N)]
         if comm_range > 0 and anchors is not None:
             anchors = np.asarray(anchors, np.float64)
@@ -310,6 +399,7 @@ class PibtWaypoints(GridWaypoints):
                 if movable[a]:  # any neighbouring node is at most one cell further away than the node held now
                     far = np.abs(anchors[a, :, :2] - np.array(self._pos(self.node[a]))).max()
                     movable[a] = far + self.g <= 0.5 * comm_range - 1e-5
+        threatened = [t and m for t, m in zip(threatened, movable)]
         now = {self.node[a]: a for a in range(N)}
         nxt, v_next = {}, [None] * N
         for a in range(N):  # agents that are still on their way to their waypoint keep it
@@ -331,7 +421,7 @@ class PibtWaypoints(GridWaypoints):
                     continue  # swap conflict
                 gx, gy = self._pos(self.goal_node[a])
                 ux, uy = self._pos(u)
-                k = (int(self.dist[a][u]), 1 if (b is not None and b != a) else 0, np.hypot(ux - gx, uy - gy))
+                k = (1 if warn(a, u) else 0, int(self.dist[a][u]), 1 if (b is not None and b != a) else 0, np.hypot(ux - gx, uy - gy))
                 if key is None or k < key:
                     best, key = u, k
             return best
@@ -369,7 +459,7 @@ class PibtWaypoints(GridWaypoints):
 
         order = sorted(range(N), key=lambda a: (-self.elapsed[a], self.init_d[a], a))
         for a in order:
-            if v_next[a] is None and self.node[a] != self.goal_node[a]:
+            if v_next[a] is None and (self.node[a] != self.goal_node[a] or threatened[a]):
                 pibt(a)
         for a in range(N):  # resting agents that nobody pushed
             if v_next[a] is None:

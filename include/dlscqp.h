@@ -134,7 +134,9 @@ void dlscqp_destroy(dlscqp_ctx *ctx);
 int dlscqp_update_param(dlscqp_ctx *ctx, const dlscqp_config *cfg);
 /* Text of the last error on this thread ("" if none). */
 const char *dlscqp_last_error(void);
-/* Bytes of LDS one agent (= one wavefront) uses for this context; diagnostic. */
+/* Bytes of the working set of one agent (= one wavefront) for this context; diagnostic.  Up to 160 KiB it lives in LDS;
+ * above (3-D, M = 10 with four or more slack obstacles) the launch uses per-agent working sets in HBM owned by the
+ * context -- slower per iteration, and launches of one context that need them must not overlap. */
 int64_t dlscqp_lds_bytes(const dlscqp_ctx *ctx, int32_t max_slack_obs, int32_t max_rows_per_agent);
 
 /* ---- host-buffer entry points (H2D + kernel + D2H, synchronous) --------------------------

@@ -5,6 +5,11 @@
 
 Writes next to this file:
   missions_empty.json  start / goal / vehicle numbers of missions/empty10/..._1.json and missions/empty60/..._1.json
+  world_maze1.json, world_forest1.json
+                     obstacle boxes of world/maze_icra2023/dense/maze1.csv and world/forest_tro2022/forest1.csv with the
+                     start / goal / vehicle / obstacle numbers of the first mission file that the reference pairs with
+                     them (maze10_dense/maze10_1.json; forest10_spin4_100/forest_spin4_100_1.json) and the launch
+                     parameters of simulation.launch / testall_DLSCGC_3D.launch
   kat_log.json       known-answer values copied (as numbers) out of the reference's own run log
                      /root/reference/log/result_1742185870.978562_DLSCGC_10agents.csv -- the only
                      artifact of the reference that pins results of the trajectory QP -- together
@@ -83,6 +88,30 @@ def make_missions():
     print("missions_empty.json written")
 
 
+def make_worlds():
+    """Obstacle boxes + mission numbers of the two obstacle worlds the closed-loop tests fly (data only)."""
+    ref = "/root/reference/"
+    for name, world, mission, extra in (
+            ("world_maze1.json", "world/maze_icra2023/dense/maze1.csv", "missions/maze10_dense/maze10_1.json", {}),
+            ("world_forest1.json", "world/forest_tro2022/forest1.csv", "missions/forest10_spin4_100/forest_spin4_100_1.json",
+             # launch/testall_DLSCGC_3D.launch
+             dict(dim=3, M=10, dt=0.2, communication_range=3.0, slack_collision_weight=100.0, uncertainty_horizon=0.7,
+                  obs_duration=60.0, goal_threshold=0.6))):
+        boxes = [[float(x) for x in row] for row in csv.reader(open(ref + world)) if row]
+        m = json.load(open(ref + mission))
+        q = m["quadrotors"]["crazyflie"]
+        out = dict(source="%s (rows: centre x,y,z, size x,y,z) and %s of the reference" % (world, mission),
+                   world_resolution=0.1, grid_resolution=0.5, world=m["world"][0]["dimension"], boxes=boxes,
+                   start=[a["start"] for a in m["agents"]], goal=[a["goal"] for a in m["agents"]],
+                   radius=q["radius"], max_vel=q["max_vel"][0], max_acc=q["max_acc"][0])
+        if m.get("obstacles"):
+            out["downwash"] = q["downwash"]
+            out["obstacles"] = m["obstacles"]
+        out.update(extra)
+        json.dump(out, open(os.path.join(HERE, name), "w"))
+        print(name, "written:", len(boxes), "boxes,", len(out["start"]), "agents,", len(m.get("obstacles", [])), "obstacles")
+
+
 def solve_batch_highs(cfg, batch):
     """Independent answers: goal LP by linprog(highs), QP by HiGHS on the numpy twin model."""
     from scipy.optimize import linprog
@@ -154,6 +183,7 @@ def save(name, cfg_kwargs, cfg, batch, ans):
 def main():
     make_kat()
     make_missions()
+    make_worlds()
     # S64 (BASELINE.json configs[1]) closed loop driven by the oracle
     cfg = workloads.s64_config()
 

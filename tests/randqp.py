@@ -119,6 +119,10 @@ CONFIGS = {
                                  world_min=(-2.0, -0.3, 0.0), world_max=(6.0, 4.3, 2.5)), dict(max_rows=120)),
     "forest3d_M10_dyn": (dict(dim=3, M=10, communication_range=3.0, world_use_octomap=True,
                               slack_collision_weight=100.0), dict(max_rows=150, n_dyn=2)),
+    # the reference's forest10_spin4 launch shape: four slack obstacles at M = 10 -> 124 reduced dimensions, a 203 KB working
+    # set: beyond the LDS of a CU, planned by the kernel variant that keeps its working set in HBM
+    "forest3d_M10_dyn4": (dict(dim=3, M=10, communication_range=3.0, world_use_octomap=True,
+                               slack_collision_weight=100.0), dict(max_rows=150, n_dyn=4)),
     "forest3d_M5_dyn": (dict(dim=3, M=5, communication_range=3.0, world_use_octomap=True,
                              slack_collision_weight=100.0), dict(max_rows=90, n_dyn=3)),
     "lsc2d_M4_nostop": (dict(dim=2, M=4, planner_mode=abi.PLANNER_BVC), dict(max_rows=40)),

@@ -82,3 +82,54 @@ def test_permute_batch_moves_agents_with_their_rows():
     for s, a in enumerate(perm):
         assert pa[s].tobytes() == b["agents"][a].tobytes()
         assert prows[pro[s]:pro[s + 1]].tobytes() == b["rows"][ro[a]:ro[a + 1]].tobytes()
+
+
+def _exchange_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_local, tail = 5, (2, 3)
+    x = sharding.PlanExchange(dist, world, n_local, tail, torch.float32, torch.device("cpu"))
+    seen = []
+    local = torch.zeros((n_local,) + tail)
+    for k in range(5):
+        # "step k": the rank's own output; overwritten in place right after the post, like the kernel's output buffer
+        local[:] = 100.0 * rank + k + torch.arange(n_local, dtype=torch.float32)[:, None, None]
+        x.post(local)
+        local.fill_(-1.0)  # step k+1 writes the output buffer while exchange k is in flight
+        if k % 2 == 1 or k == 4:
+            seen.append((k, x.table().clone().numpy()))
+    q.put((rank, seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_plan_exchange_over_gloo():
+    """PlanExchange: exchange k is posted asynchronously and snapshots the output of step k; table() returns the gathered
+    table of the most recent post on every rank, also when the output buffer has been overwritten meanwhile."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29850 + (os.getpid() % 100)
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert [k for k, _ in res[r]] == [1, 3, 4]
+        for k, tab in res[r]:
+            exp = np.concatenate([np.broadcast_to((100.0 * g + k + np.arange(5, dtype=np.float32))[:, None, None], (5, 2, 3)) for g in range(2)])
+            assert np.array_equal(tab, exp), (r, k)
+
+
+def test_halo_agents_are_the_ones_with_remote_neighbours():
+    # two swarms of three agents, everyone sees everyone in its swarm; a seventh agent sees agent 0 and agent 5
+    nbr = {0: [1, 2], 1: [0, 2], 2: [0, 1], 3: [4, 5], 4: [3, 5], 5: [3, 4], 6: [0, 5]}
+    for lo, hi, exp in ((0, 3, []), (3, 6, []), (0, 4, [3]), (3, 7, [3]), (0, 7, [])):
+        ids, off = [], [0]
+        for a in range(lo, hi):
+            ids += nbr[a]
+            off.append(len(ids))
+        assert sharding.halo_agents(off, ids, lo, hi) == exp, (lo, hi)
