@@ -130,7 +130,10 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # RCCL's kernels on a high-priority stream: with the pipelined exchange they share the GPU with the plan kernel of
+        # the next step and should get the first free workgroup slots
+        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=opts)
 
     from dlsc_gc_planner_amd import abi, workloads
     from dlsc_gc_planner_amd.planner import BatchTrajOptimizer
