@@ -41,23 +41,58 @@ def algorithmic_bytes_per_qp(dim, M, n, K, use_sfc, n_dyn):
 
 
 def cpu_baseline(cfg, wl, target_seconds=12.0):
-    """The CPU oracle (a port: dense model + generic dual active-set, oracle/dlsc_oracle.c) timed on
-    this host, one thread, on a bounded sample of the same workload."""
+    """The CPU oracle (a port: dense model + generic dual active-set, oracle/dlsc_oracle.c) timed on this host on a
+    bounded sample of the same workload: one thread first, then one thread per host core over disjoint agent ranges
+    (the oracle is re-entrant and ctypes releases the GIL).  `value` is the all-core rate."""
+    from concurrent.futures import ThreadPoolExecutor
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     agents, ro, rows = wl["agents"], wl["row_offsets"], wl["rows"]
     N = len(agents)
-    probe = min(N, 64)
+
+    def solve(lo, hi):
+        oracle_lib.plan_batch(cfg, agents[lo:hi], ro[lo:hi + 1] - ro[lo], rows[ro[lo]:ro[hi]], None, 0, True)
+
+    probe = min(N, 256)
     t0 = time.perf_counter()
-    oracle_lib.plan_batch(cfg, agents[:probe], ro[:probe + 1], rows[:ro[probe]], None, 0, True)
-    dt = time.perf_counter() - t0
-    per = dt / probe
-    n = int(min(N, max(probe, target_seconds / max(per, 1e-6))))
-    t0 = time.perf_counter()
-    oracle_lib.plan_batch(cfg, agents[:n], ro[:n + 1], rows[:ro[n]], None, 0, True)
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "QP/s", "cores": 1, "kind": "port",
-            "sample": "first %d agents of the same batch, goal LP + QP each, %.1f s" % (n, dt),
+    solve(0, probe)
+    one = probe / (time.perf_counter() - t0)
+    cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    for fq, fp in (("/sys/fs/cgroup/cpu.max", None), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+        try:  # a container's CPU quota, if any, is what the threads can really use
+            if fp is None:
+                quota, period = open(fq).read().split()
+            else:
+                quota, period = open(fq).read().strip(), open(fp).read().strip()
+            if quota not in ("max", "-1"):
+                cores = max(1, min(cores, int(float(quota) / float(period) + 0.5)))
+            break
+        except (OSError, ValueError):
+            pass
+    # time-bounded: every thread walks its own range of the batch in chunks of 16 agents until the deadline
+    per = max(16, N // cores)
+    deadline = time.perf_counter() + target_seconds
+    done = [0] * cores
+
+    def work(c):
+        lo0 = (c * per) % max(N - per + 1, 1)
+        pos = 0
+        while time.perf_counter() < deadline:
+            lo = lo0 + pos
+            hi = min(lo + 16, lo0 + per, N)
+            solve(lo, hi)
+            done[c] += hi - lo
+            pos = (pos + 16) % per
+
+    with ThreadPoolExecutor(cores) as pool:
+        t0 = time.perf_counter()
+        list(pool.map(work, range(cores)))
+        dt = time.perf_counter() - t0
+    n = sum(done)
+    return {"value": n / dt, "unit": "QP/s", "cores": cores, "kind": "port",
+            "sample": "%d agent-QPs (goal LP + QP each) of the same batch in %.1f s: %d threads, each walking its own range of "
+                      "the batch" % (n, dt, cores),
+            "one_core_qp_per_s": one,
             "ref_published_qp_per_s": 89.4,
             "ref_published_note": "reference log: 11.18 ms/QP mean, CPLEX 22.1.1 Threads=6, 2-D M=10, unknown CPU"}
 
@@ -171,19 +206,23 @@ def main():
         nbr_ids = members[members != (lo + np.arange(N))[:, None]]                 # ... without the agent itself
         halo = sharding.halo_agents(np.arange(N + 1) * 63, nbr_ids, lo, lo + N)
         pipelined = args.exchange == "pipelined" and len(halo) == 0
-        if pipelined:
-            xchg = sharding.PlanExchange(dist, world, N, shape1, torch.float32, dev)
-        else:
-            gathered = torch.empty((world * N,) + shape1, dtype=torch.float32, device=dev)
+        # per agent: control points, sub-goal, status (376 B at S64) -- the broadcast payload of the reference
+        xchg = sharding.PlanExchange(dist, world, N, (int(np.prod(shape1)), 3, 1), dev)
 
     def step():
-        db.launch(True, True)
-        if pipelined:
-            # exchange of this step's plans, asynchronous: complete before the step after the next is posted
-            xchg.post(db.out_ctrl)
-        elif use_dist:
-            # the per-step exchange: every agent's solved control points to every rank
-            dist.all_gather_into_tensor(gathered, db.out_ctrl)
+        if not use_dist:
+            db.launch(True, True)
+        elif pipelined:
+            # outputs double-buffered: the exchange of step k (packing included) runs on the communication stream while
+            # step k+1 writes the other set; it is complete before the step after the next is posted
+            db.flip_outputs()
+            xchg.before_overwrite()
+            db.launch(True, True)
+            xchg.post(db.out_ctrl, db.out_goal, db.out_status, pack_on_comm=True)
+        else:
+            db.launch(True, True)
+            xchg.post(db.out_ctrl, db.out_goal, db.out_status)
+            xchg.table()  # the next launch waits for the exchange
 
     for _ in range(2):
         step()
@@ -206,9 +245,11 @@ def main():
         elapsed = float(tt.item())
     if use_dist:
         # the gathered table must hold this rank's own block
-        table = xchg.table() if pipelined else gathered
+        ctrl_all, goal_all, status_all = xchg.unpack(xchg.table(), (torch.float32, torch.float32, torch.int32))
         torch.cuda.synchronize(dev)
-        assert torch.equal(table[rank * N:(rank + 1) * N], db.out_ctrl)
+        own = slice(rank * N, (rank + 1) * N)
+        assert torch.equal(ctrl_all[own], db.out_ctrl.view(N, -1)) and torch.equal(goal_all[own], db.out_goal)
+        assert torch.equal(status_all[own].flatten(), db.out_status)
     kms = opt.kernel_times_ms(args.steps)
     res = db.results()
 
@@ -227,6 +268,12 @@ def main():
         except Exception:
             pass
         it = res["iters"]
+        R_rows, r_dim = K + 2 * 207, dim * (M * (n + 1) - 17)
+        # n_W grows from 0 to `active` over the adds: sum over iterations ~ iterations * active / 2
+        flops_qp = float((it[:, 0] * (6.0 * R_rows + 2.0 * r_dim * r_dim) + 6.0 * r_dim * it[:, 0] * it[:, 3] / 2.0).mean()
+                         + 6.0 * R_rows)  # + the scan that finds no violated row
+        fp64 = {"flops_per_qp_model": flops_qp, "achieved_tflops": N * flops_qp / avg_kernel_s / 1e12,
+                "peak_tflops": FP64_VALU_PEAK_TFLOPS, "frac": N * flops_qp / avg_kernel_s / 1e12 / FP64_VALU_PEAK_TFLOPS}
         # single-swarm replanning latency through the host-buffer entry (H2D + solve + D2H)
         a1, r1 = wl["agents"][:64], wl["rows"][:wl["row_offsets"][64]]
         ro1 = wl["row_offsets"][:65]
@@ -258,9 +305,9 @@ def main():
                 "agents_per_gpu": N, "segments": M, "degree": n, "lsc_rows_per_agent": K,
                 "vars_per_agent": dim * M * (n + 1), "ineq_rows_per_agent": K + 2 * 207,
                 "exchange": ("none (1 GPU)" if not use_dist else
-                             "one RCCL all-gather of control points per step, posted on a communication stream: runs "
+                             "one RCCL all-gather of control points, sub-goal and status per step, posted on a communication stream: runs "
                              "while the next step plans the agents without remote neighbours (all of them here)"
-                             if pipelined else "one RCCL all-gather of control points per step, after the launch"),
+                             if pipelined else "one RCCL all-gather of control points, sub-goal and status per step, after the launch"),
                 "launch_order": "id" if args.no_order_hint else "previous step's iteration count, descending",
                 "solved_fraction": float(ok.mean()), "mean_active_set_iterations": float(it[:, 0].mean()),
                 "max_active_set_iterations": int(it[:, 0].max()), "seed": args.seed,
@@ -269,6 +316,9 @@ def main():
             "p50_replan_ms_one_swarm_host_to_host": float(np.percentile(lat, 50)),
             "p99_replan_ms_one_swarm_host_to_host": float(np.percentile(lat, 99)),
             "closed_loop_replan_ms": closed,
+            # SURVEY.md 8(d) flop model: per active-set iteration 6 R (row residuals) + 2 r^2 (two r x r sweeps) + 6 r n_W
+            # (factor update at working-set size n_W), R = inequality rows, r = reduced dimension
+            "fp64_valu": fp64,
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

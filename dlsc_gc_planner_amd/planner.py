@@ -217,6 +217,18 @@ class DeviceBatch:
         self.order = self.torch.from_numpy(order).to(self.device)
         self.c.agent_order = self.order.data_ptr()
 
+    def flip_outputs(self):
+        """Double-buffer the outputs another stream reads (control points, sub-goal, status): after the call `out_ctrl`,
+        `out_goal` and `out_status` are the set the NEXT launch writes, and the previous set stays untouched until the
+        flip after next -- time for a plan exchange on a communication stream to read it."""
+        torch = self.torch
+        if not hasattr(self, "_alt"):
+            self._alt = (torch.zeros_like(self.out_ctrl), torch.zeros_like(self.out_goal), torch.full_like(self.out_status, -1))
+        cur = (self.out_ctrl, self.out_goal, self.out_status)
+        self.out_ctrl, self.out_goal, self.out_status = self._alt
+        self._alt = cur
+        self.c.out_ctrl, self.c.out_goal, self.c.out_status = self.out_ctrl.data_ptr(), self.out_goal.data_ptr(), self.out_status.data_ptr()
+
     def launch(self, do_goal=True, do_traj=True, stream=None, offset=0, count=0):
         """Asynchronous launch on `stream` (default: torch's current stream); `offset`/`count` restrict it to a
         range of launch slots (count = 0: the whole batch)."""

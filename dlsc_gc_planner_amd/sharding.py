@@ -57,35 +57,68 @@ def halo_agents(nbr_offsets, nbr_ids, lo, hi):
 
 
 class PlanExchange:
-    """The per-step all-gather of solved control points, posted asynchronously and double-buffered.
+    """The per-step all-gather of the solved plans, posted asynchronously and double-buffered.
 
-    post(local_ctrl) snapshots the rank's [n_local, M, n+1, 3] output of step k and starts ONE
-    all_gather_into_tensor of it on a communication stream (RCCL over xGMI; gloo in the CPU tests), so the exchange of
-    step k runs while the launch of step k+1 plans the interior agents; table() makes the current stream (CUDA) or the
-    host (CPU) wait for the most recent exchange and returns the gathered [world * n_local, ...] table -- what the halo
-    agents of step k+1, the host log and any consumer of other ranks' plans read.  Two buffer pairs: the exchange of
-    step k must be complete before step k+2 is posted, which the class enforces itself."""
+    post(ctrl, goal, status) packs the rank's output of step k -- per agent the dim*M*(n+1) float32 control points, the
+    float32 sub-goal and the int32 status: what AgentManager::getAgent broadcasts (agent_manager.cpp:249-263) and what the
+    other ranks' half-space generators need -- into one [n_local, width] buffer and starts ONE all_gather_into_tensor of
+    it on a communication stream (RCCL over xGMI; gloo in the CPU tests), so the exchange of step k runs while the launch
+    of step k+1 plans the interior agents; table() makes the current stream (CUDA) or the host (CPU) wait for the most
+    recent exchange and returns the gathered [world * n_local, width] table (unpack() splits it) -- what the halo agents of
+    step k+1, the host log and any consumer of other ranks' plans read.  Two buffer pairs: the exchange of step k must
+    be complete before step k+2 is posted, which the class enforces itself.
+    post(..., pack_on_comm=True) (CUDA) also moves the packing to the communication stream, so the compute stream gets
+    nothing but an event; the caller then keeps the posted tensors untouched until it has called before_overwrite()
+    ahead of the launch after next (DeviceBatch.flip_outputs double-buffers the outputs for that)."""
 
-    def __init__(self, dist, world, n_local, tail, dtype, device):
+    def __init__(self, dist, world, n_local, widths, device):
         import torch
         self.torch, self.dist, self.device = torch, dist, device
         self.cuda = device.type == "cuda"
-        self.send = [torch.empty((n_local,) + tuple(tail), dtype=dtype, device=device) for _ in range(2)]
-        self.recv = [torch.empty((world * n_local,) + tuple(tail), dtype=dtype, device=device) for _ in range(2)]
+        self.widths = tuple(int(w) for w in widths)
+        width = sum(self.widths)
+        self.send = [torch.empty((n_local, width), dtype=torch.float32, device=device) for _ in range(2)]
+        self.recv = [torch.empty((world * n_local, width), dtype=torch.float32, device=device) for _ in range(2)]
         self.done = [None, None]  # CUDA: event on the communication stream; CPU: Work handle
+        self.packed = [None, None]  # CUDA, pack_on_comm: the inputs of post k have been read
         self.comm = torch.cuda.Stream(device) if self.cuda else None
         self.k = 0
         self.last = None
 
-    def post(self, local_ctrl):
+    def _pack(self, b, parts):
+        torch = self.torch
+        flat = []
+        for p, w in zip(parts, self.widths):
+            p = p.reshape(p.shape[0], -1)
+            if p.dtype != torch.float32:
+                p = p.view(torch.float32)  # int32 status travels as raw bits
+            assert p.shape[1] == w
+            flat.append(p)
+        torch.cat(flat, dim=1, out=self.send[b])
+
+    def before_overwrite(self):
+        """pack_on_comm: make the current stream wait until the tensors of the post before last have been read."""
+        e = self.packed[self.k & 1]
+        if e is not None:
+            self.torch.cuda.current_stream(self.device).wait_event(e)
+
+    def post(self, *parts, pack_on_comm=False):
         torch = self.torch
         b = self.k & 1
         self.k += 1
-        if self.cuda:
+        if self.cuda and pack_on_comm:
+            ready = torch.cuda.current_stream(self.device).record_event()
+            with torch.cuda.stream(self.comm):  # in order behind exchange k-2, which used the same buffers
+                self.comm.wait_event(ready)
+                self._pack(b, parts)
+                self.packed[b] = self.comm.record_event()
+                self.dist.all_gather_into_tensor(self.recv[b], self.send[b])
+                self.done[b] = self.comm.record_event()
+        elif self.cuda:
             cur = torch.cuda.current_stream(self.device)
             if self.done[b] is not None:
                 cur.wait_event(self.done[b])  # exchange k-2 has read send[b] and filled recv[b]
-            self.send[b].copy_(local_ctrl)
+            self._pack(b, parts)
             ready = cur.record_event()
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(ready)
@@ -94,7 +127,7 @@ class PlanExchange:
         else:
             if self.done[b] is not None:
                 self.done[b].wait()
-            self.send[b].copy_(local_ctrl)
+            self._pack(b, parts)
             self.done[b] = self.dist.all_gather_into_tensor(self.recv[b], self.send[b], async_op=True)
         self.last = b
 
@@ -105,3 +138,14 @@ class PlanExchange:
         else:
             self.done[b].wait()
         return self.recv[b]
+
+    def unpack(self, table, dtypes=None):
+        """Columns of a gathered table as the parts that were posted (dtypes: per part, default float32)."""
+        out, o = [], 0
+        for i, w in enumerate(self.widths):
+            col = table[:, o:o + w]
+            if dtypes is not None and dtypes[i] != self.torch.float32:
+                col = col.contiguous().view(dtypes[i])
+            out.append(col)
+            o += w
+        return out

@@ -89,16 +89,25 @@ def _exchange_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     n_local, tail = 5, (2, 3)
-    x = sharding.PlanExchange(dist, world, n_local, tail, torch.float32, torch.device("cpu"))
+    x = sharding.PlanExchange(dist, world, n_local, (6, 3, 1), torch.device("cpu"))
     seen = []
     local = torch.zeros((n_local,) + tail)
+    goal = torch.zeros((n_local, 3))
+    status = torch.zeros(n_local, dtype=torch.int32)
     for k in range(5):
-        # "step k": the rank's own output; overwritten in place right after the post, like the kernel's output buffer
+        # "step k": the rank's own output; overwritten in place right after the post, like the kernel's output buffers
         local[:] = 100.0 * rank + k + torch.arange(n_local, dtype=torch.float32)[:, None, None]
-        x.post(local)
-        local.fill_(-1.0)  # step k+1 writes the output buffer while exchange k is in flight
+        goal[:] = -local[:, 0, :]
+        status[:] = -7 * rank - k
+        x.post(local, goal, status)
+        local.fill_(-1.0)  # step k+1 writes the output buffers while exchange k is in flight
+        goal.fill_(-1.0)
+        status.fill_(99)
         if k % 2 == 1 or k == 4:
-            seen.append((k, x.table().clone().numpy()))
+            ctrl, g, st = x.unpack(x.table(), (torch.float32, torch.float32, torch.int32))
+            assert torch.equal(g, -ctrl[:, :3])
+            assert st.flatten().tolist() == [-7 * r - k for r in range(world) for _ in range(n_local)]
+            seen.append((k, ctrl.reshape((-1,) + tail).clone().numpy()))
     q.put((rank, seen))
     dist.barrier()
     dist.destroy_process_group()
