@@ -137,7 +137,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--swarms", type=int, default=256, help="64-agent swarms per GPU per step")
+    ap.add_argument("--swarms", type=int, default=512, help="64-agent swarms per GPU per step")
     ap.add_argument("--seed", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-swarm host-to-host latency loop")

@@ -8,7 +8,7 @@ NAME=${1:-r01}
 OUT=gpurun_out/prof_$NAME
 STEPS=30
 export TMPDIR=/tmp
-B="python3 bench.py --steps $STEPS --warmup 3 --swarms 256 --no-cpu-baseline --no-latency"
+B="python3 bench.py --steps $STEPS --warmup 3 --swarms 512 --no-cpu-baseline --no-latency"
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $B > $OUT/fetch.log 2>&1
@@ -17,7 +17,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_AN
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d $OUT/sq2 -- $B > $OUT/sq2.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/sq3 -- $B > $OUT/sq3.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $OUT/sq4 -- $B > $OUT/sq4.log 2>&1
-python3 profiles/summarize.py $OUT $NAME --steps $STEPS --agents 16384 > $OUT/summary.txt 2>&1
+python3 profiles/summarize.py $OUT $NAME --steps $STEPS --agents 32768 > $OUT/summary.txt 2>&1
 cp profiles/$NAME.md profiles/$NAME.json profiles/hbm_traffic_latest.json $OUT/ 2>/dev/null
 python3 profiles/stamps.py > $OUT/stamps.txt 2>&1
 tail -5 $OUT/summary.txt
