@@ -132,6 +132,9 @@ class ClosedLoop:
         self.desired_goal = f32(goal)
         self.cur_goal = self.pos.clone()  # agent_manager.cpp:9
         self.plans = torch.zeros((N, M, n + 1, 3), dtype=torch.float32, device=dev)
+        self.wp = self.pos.clone()  # next_waypoint of every agent
+        self.init_buf = torch.zeros_like(self.plans)  # initial trajectory handed to the corridor generator
+        self.graph = None
         self.radius, self.downwash = float(radius), float(downwash)
         self.waypoint_step = waypoint_step
         self.seq = 0
@@ -185,34 +188,35 @@ class ClosedLoop:
             self.csv.close()
         self.opt.close()
 
-    def step(self):
-        """One replanning step of every agent; returns (status [N] tensor, iterations tensor)."""
+    def _waypoints_host(self):
+        """Waypoints from the host-side grid planner stand-ins (worlds with static obstacles)."""
+        torch, cfg = self.torch, self.cfg
+        if isinstance(self.grid, PibtWaypoints):
+            anchors = torch.cat([self.pos[:, None, :], self.plans[:, :, 0, :], self.plans[:, -1:, -1, :]], dim=1) \
+                if self.seq > 0 else self.pos[:, None, :]
+            gdyn = None
+            if self.D:
+                gdyn = dict(position=self.dyn_pos.cpu().numpy(), velocity=self.dyn_vel.cpu().numpy(), radius=self.dyn["radius"],
+                            max_acc=self.dyn["max_acc"], horizon=cfg.M * cfg.dt, uncertainty_horizon=self.dyn.get("horizon", 1.0))
+            return torch.from_numpy(self.grid.step(self.cur_goal.cpu().numpy(), anchors.cpu().numpy(),
+                                                   float(cfg.communication_range), dyn=gdyn))
+        return torch.from_numpy(self.grid.next_waypoints(self.pos.cpu().numpy()))
+
+    def _body(self, first):
+        """The device work of one step: waypoint (empty worlds), agent records, half-spaces, corridors, goal LP + QP,
+        fail-safe, state update.  Reads and writes the state tensors (pos, vel, acc, cur_goal, plans, wp) in place, calls
+        nothing that synchronises: the steady-state form (first = False) is what enable_graph() captures."""
         torch, cfg = self.torch, self.cfg
         n, dt = cfg.n, cfg.dt
-        # waypoint: straight ahead towards the desired goal (stands in for the grid planner, see module doc)
-        if self.world is not None:
-            # static obstacles: the next cell of a shortest grid path (stands in for the reference's grid planner: paths are
-            # per agent, without PIBT's conflict resolution)
-            if isinstance(self.grid, PibtWaypoints):
-                anchors = torch.cat([self.pos[:, None, :], self.plans[:, :, 0, :], self.plans[:, -1:, -1, :]], dim=1) \
-                    if self.seq > 0 else self.pos[:, None, :]
-                gdyn = None
-                if self.D:
-                    gdyn = dict(position=self.dyn_pos.cpu().numpy(), velocity=self.dyn_vel.cpu().numpy(), radius=self.dyn["radius"],
-                                max_acc=self.dyn["max_acc"], horizon=cfg.M * cfg.dt, uncertainty_horizon=self.dyn.get("horizon", 1.0))
-                wp = torch.from_numpy(self.grid.step(self.cur_goal.cpu().numpy(), anchors.cpu().numpy(),
-                                                     float(cfg.communication_range), dyn=gdyn)).to(self.dev)
-            else:
-                wp = torch.from_numpy(self.grid.next_waypoints(self.pos.cpu().numpy())).to(self.dev)
-        else:
+        if self.world is None:
+            # waypoint: straight ahead towards the desired goal (stands in for the grid planner, see module doc)
             to_goal = self.desired_goal - self.pos
             dist = to_goal.norm(dim=1, keepdim=True)
-            wp = torch.where(dist <= self.waypoint_step, self.desired_goal,
-                             self.pos + to_goal / dist.clamp_min(1e-9) * self.waypoint_step)
+            self.wp.copy_(torch.where(dist <= self.waypoint_step, self.desired_goal,
+                                      self.pos + to_goal / dist.clamp_min(1e-9) * self.waypoint_step))
+        wp = self.wp
         a = self.agent_f32
         a[:, 0:3], a[:, 3:6], a[:, 6:9], a[:, 9:12], a[:, 12:15] = self.pos, self.vel, self.acc, self.cur_goal, wp
-        first = self.seq < 1  # planner_seq < 2 in the reference counts from 1
-        t_wall = time.perf_counter() if self.csv else 0.0
         dkw = dict(dyn_position=self.dyn_pos, dyn_velocity=self.dyn_vel) if self.D else {}
         if first:
             self.gen.generate(self.cur_goal, position=self.pos, velocity=self.vel, **dkw)
@@ -223,17 +227,58 @@ class ClosedLoop:
         if self.sfc is not None:  # TrajPlanner::constructSFC (traj_planner.cpp:517-520): initializeSFC once, then one shift per step
             if first:
                 self.sfc.initialize(self.pos)
-            self.sfc.update(init.contiguous(), self.cur_goal, wp)
+            self.init_buf.copy_(init)
+            self.sfc.update(self.init_buf, self.cur_goal, wp)
         self.batch.launch(True, True)
         ok = (self.batch.out_status == abi.OK)
         gok = (self.batch.out_goal_status != abi.INFEASIBLE)
         # fail-safe: keep the shifted previous plan (traj_planner.cpp:776); sub-goal from the LP (traj_planner.cpp:494)
-        self.plans = torch.where(ok[:, None, None, None], self.batch.out_ctrl, init).contiguous()
-        self.cur_goal = torch.where(gok[:, None], self.batch.out_goal, self.cur_goal).contiguous()
+        self.plans.copy_(torch.where(ok[:, None, None, None], self.batch.out_ctrl, init))
+        self.cur_goal.copy_(torch.where(gok[:, None], self.batch.out_goal, self.cur_goal))
         # doStep of the next iteration: state = desired_traj.getStateAt(dt) = start of segment 1, float32 differences
         c0, c1, c2 = self.plans[:, 1, 0], self.plans[:, 1, 1], self.plans[:, 1, 2]
         s1, s2 = np.float32(n / dt), np.float32((n - 1) / dt)
         v0, v1 = (c1 - c0) * s1, (c2 - c1) * s1
+        self.pos.copy_(c0)
+        self.vel.copy_(v0)
+        self.acc.copy_((v1 - v0) * s2)
+
+    def enable_graph(self):
+        """Capture the steady-state step in a HIP graph (torch.cuda.CUDAGraph): a ten-agent step is a chain of about
+        thirty small launches and launch-bound; replaying it as one graph removes the per-launch host cost.  Call after at
+        least one step; result files and the host-side waypoint planners keep working (they run outside the graph)."""
+        torch = self.torch
+        assert self.seq >= 1, "the first step differs (constant-velocity prediction, corridor initialisation)"
+        torch.cuda.synchronize(self.dev)
+        state = [self.pos, self.vel, self.acc, self.cur_goal, self.plans, self.wp]
+        if self.sfc is not None:
+            state.append(self.sfc.sfcs)  # the corridor boxes are shifted in place every step
+        keep = [t.clone() for t in state]
+        side = torch.cuda.Stream(self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):  # warm-up on a side stream, as torch asks before a capture
+            self._body(False)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._body(False)
+        torch.cuda.synchronize(self.dev)
+        for t, k in zip(state, keep):
+            t.copy_(k)  # the warm-up advanced the state: put it back
+        self.graph = g
+
+    def step(self):
+        """One replanning step of every agent; returns (status [N] tensor, iterations tensor)."""
+        torch, cfg = self.torch, self.cfg
+        n, dt = cfg.n, cfg.dt
+        first = self.seq < 1  # planner_seq < 2 in the reference counts from 1
+        t_wall = time.perf_counter() if self.csv else 0.0
+        if self.world is not None:
+            self.wp.copy_(self._waypoints_host())
+        if self.graph is not None and not first:
+            self.graph.replay()
+        else:
+            self._body(first)
         if self.csv:
             torch.cuda.synchronize(self.dev)
             dyn_now = (self.dyn_pos.cpu().numpy(), self.dyn_vel.cpu().numpy()) if self.D else None
@@ -243,17 +288,17 @@ class ClosedLoop:
                 obs_state = lambda tau: (dyn_now[0] + dyn_now[1] * np.float32(tau), self.dyn["radius"])  # noqa: E731
             self.csv.write_step(self.sim_time, self.plans.cpu().numpy(), n, dt, time.perf_counter() - t_wall,
                                 None if dyn_now is None else obs_state)
-        self.pos, self.vel, self.acc = c0.clone(), v0, (v1 - v0) * s2
         self.sim_time += dt
         if self.D and 0 < self.dyn.get("duration", -1.0) < self.sim_time:
             self.dyn_model = None
-            self.dyn_pos = torch.full_like(self.dyn_pos, 1000.0)
-            self.dyn_vel = torch.zeros_like(self.dyn_vel)
+            self.dyn_pos.fill_(1000.0)
+            self.dyn_vel.zero_()
         elif self.dyn_model is not None:
             p, v = self.dyn_model.state(self.sim_time)
-            self.dyn_pos, self.dyn_vel = torch.from_numpy(p).to(self.dev), torch.from_numpy(v).to(self.dev)
+            self.dyn_pos.copy_(torch.from_numpy(p))
+            self.dyn_vel.copy_(torch.from_numpy(v))
         elif self.D:
-            self.dyn_pos = self.dyn_pos + self.dyn_vel * np.float32(dt)
+            self.dyn_pos.add_(self.dyn_vel * np.float32(dt))
         self.seq += 1
         return self.batch.out_status, self.batch.out_iters
 

@@ -260,3 +260,41 @@ def test_forest_mission_with_spinning_obstacles(gpu_required):
     assert worst >= 1.0 and wall >= m["radius"] - 1e-4
     assert fails <= 0.01 * 500 * sim.N
     assert done is not None and done <= 100.0
+
+
+@pytest.mark.parametrize("with_world", [False, True])
+def test_hip_graph_step_equals_eager_step(gpu_required, with_world):
+    """ClosedLoop.enable_graph(): the steady-state step captured once in a HIP graph and replayed gives the same plans,
+    states and verdicts, bit for bit, as the eager sequence of launches -- in an empty world (waypoints inside the graph)
+    and in the maze (corridor generator inside the graph, waypoints from the host outside)."""
+    import torch
+    if with_world:
+        m, cfg, world = _maze()
+        kw = dict(radius=m["radius"], downwash=2.0, max_vel=m["max_vel"], max_acc=m["max_acc"], nominal_velocity=1.0,
+                  waypoint_step=m["grid_resolution"], world=dict(world, pibt=True))
+        start, goal = np.array(m["start"], np.float32), np.array(m["goal"], np.float32)
+    else:
+        cfg, m = _mission("empty10_1")
+        kw = dict(radius=m["radius"], downwash=m["downwash"], max_vel=m["max_vel"], max_acc=m["max_acc"],
+                  nominal_velocity=m["nominal_velocity"])
+        start, goal = np.array(m["start"], np.float32), np.array(m["goal"], np.float32)
+    runs = []
+    for use_graph in (False, True):
+        sim = ClosedLoop(cfg, start, goal, **kw)
+        try:
+            hist = []
+            for k in range(40):
+                if use_graph and k == 3:
+                    sim.enable_graph()
+                status, iters = sim.step()
+                hist.append((sim.plans.cpu().numpy().copy(), sim.pos.cpu().numpy().copy(), sim.cur_goal.cpu().numpy().copy(),
+                             status.cpu().numpy().copy()))
+            assert (sim.graph is not None) == use_graph
+        finally:
+            sim.close()
+        runs.append(hist)
+    for k, (e, g) in enumerate(zip(*runs)):
+        for x, y in zip(e, g):
+            assert np.array_equal(x, y), k
+    moved = np.linalg.norm(runs[1][-1][1] - start, axis=1)
+    assert moved.mean() > 1.0  # the agents did fly
