@@ -164,6 +164,23 @@ class SfcGen(C.Structure):
     ]
 
 
+class Advance(C.Structure):
+    _fields_ = [
+        ("n_agents", C.c_int32),
+        ("status", C.c_void_p),
+        ("goal_status", C.c_void_p),
+        ("ctrl", C.c_void_p),
+        ("goal", C.c_void_p),
+        ("plans", C.c_void_p),
+        ("current_goal", C.c_void_p),
+        ("initial_traj", C.c_void_p),
+        ("agents", C.c_void_p),
+        ("waypoints", C.c_void_p),
+        ("desired_goal", C.c_void_p),
+        ("waypoint_step", C.c_double),
+    ]
+
+
 assert C.sizeof(Config) == 144, C.sizeof(Config)
 assert C.sizeof(Agent) == 104, C.sizeof(Agent)
 assert C.sizeof(LscRow) == 40, C.sizeof(LscRow)
@@ -253,6 +270,8 @@ def load_library():
     lib.dlscqp_plan_batch_device.restype = C.c_int
     lib.dlscqp_generate_lsc_device.argtypes = [vp, P(LscGen), vp]
     lib.dlscqp_generate_lsc_device.restype = C.c_int
+    lib.dlscqp_advance_device.argtypes = [vp, P(Advance), vp]
+    lib.dlscqp_advance_device.restype = C.c_int
     lib.dlscqp_rows_to_soa.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.dlscqp_rows_to_soa.restype = None
     lib.dlscqp_set_timing.argtypes = [vp, C.c_int32]
@@ -268,4 +287,5 @@ EXPORTED_SYMBOLS = [
     "dlscqp_lds_bytes", "dlscqp_solve_batch", "dlscqp_goal_batch", "dlscqp_plan_batch",
     "dlscqp_plan_batch_device", "dlscqp_generate_lsc_device", "dlscqp_rows_to_soa", "dlscqp_set_timing",
     "dlscqp_get_kernel_times", "dlscqp_world_create", "dlscqp_world_destroy", "dlscqp_generate_sfc_device",
+    "dlscqp_advance_device",
 ]

@@ -681,6 +681,104 @@ extern "C" int dlscqp_generate_lsc_device(dlscqp_ctx *c, const dlscqp_lsc_gen *g
     return DLSCQP_SUCCESS;
 }
 
+// ---------------------------------------------------------------------------------------------
+// between two launches (include/dlscqp.h: dlscqp_advance)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct AdvanceArgs {
+    dlscqp_advance a;
+    int M, n1;
+    float s1, s2;  // n / dt and (n - 1) / dt in float32 (Trajectory::getStateAt differences)
+};
+
+// one wavefront per agent; E = M (n+1) 3 floats of a plan, lane l owns elements l, l + 64, ...
+__global__ __launch_bounds__(64) void dlscqp_advance_kernel(AdvanceArgs g) {
+    const int ag = (int)blockIdx.x, l = (int)threadIdx.x;
+    const dlscqp_advance &a = g.a;
+    const int M = g.M, n1 = g.n1, seg = n1 * 3, E = M * seg;
+    float *plan = a.plans + (size_t)ag * E;
+    const float *ctrl = a.ctrl + (size_t)ag * E;
+    const bool ok = a.status[ag] == DLSCQP_OK;
+    // element e of a plan shifted by one segment: segment m+1, the last segment repeats its end point
+    auto shifted = [&](int e) {
+        const int m = e / seg, k = e % 3;
+        return m < M - 1 ? e + seg : (M - 1) * seg + (n1 - 1) * 3 + k;
+    };
+    constexpr int U = 8;  // E <= 512 (M <= 28 at n = 5)
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int e = l + 64 * u;
+        v[u] = e < E ? (ok ? ctrl[e] : plan[shifted(e)]) : 0.0f;  // every read of the old plan happens before ...
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int e = l + 64 * u;
+        if (e < E) plan[e] = v[u];  // ... the first write (one wavefront: memory operations in program order)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the new plan is in memory before other lanes' elements are read back
+    if (a.initial_traj) {
+        float *init = a.initial_traj + (size_t)ag * E;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = l + 64 * u;
+            if (e < E) init[e] = plan[shifted(e)];
+        }
+    }
+    if (l < 3) {
+        const int k = l;
+        const bool gok = a.goal_status[ag] != DLSCQP_INFEASIBLE;
+        const float cg = gok ? a.goal[(size_t)ag * 3 + k] : a.current_goal[(size_t)ag * 3 + k];
+        a.current_goal[(size_t)ag * 3 + k] = cg;
+        // state at dt: first three control points of segment 1 (M >= 2, dlscqp_create)
+        const int b = seg;
+        const float c0 = plan[b + k], c1 = plan[b + 3 + k], c2 = plan[b + 6 + k];
+        const float v0 = (c1 - c0) * g.s1, v1 = (c2 - c1) * g.s1;
+        const float p = c0, vel = v0, acc = (v1 - v0) * g.s2;
+        dlscqp_agent *rec = a.agents + ag;
+        rec->position[k] = p;
+        rec->velocity[k] = vel;
+        rec->acceleration[k] = acc;
+        rec->current_goal_point[k] = cg;
+        if (a.waypoints) {
+            rec->next_waypoint[k] = a.waypoints[(size_t)ag * 3 + k];
+        } else if (a.desired_goal) {
+            const float *dg = a.desired_goal + (size_t)ag * 3;
+            // the other two axes of the new position: recomputed by this lane (three lanes, three axes each)
+            float d3[3], p3[3];
+            for (int j = 0; j < 3; j++) {
+                p3[j] = plan[b + j];
+                d3[j] = dg[j] - p3[j];
+            }
+            const double dist = dlscqp::f32_norm3(d3[0], d3[1], d3[2]);
+            const float stepf = (float)a.waypoint_step, distf = (float)(dist > 1e-9 ? dist : 1e-9);
+            rec->next_waypoint[k] = dist <= a.waypoint_step ? dg[k] : p3[k] + d3[k] / distf * stepf;
+        }
+    }
+}
+}  // namespace
+
+extern "C" int dlscqp_advance_device(dlscqp_ctx *c, const dlscqp_advance *adv, void *stream) {
+    g_last_error.clear();
+    if (!c || !adv) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (adv->n_agents <= 0) return DLSCQP_SUCCESS;
+    if (!adv->status || !adv->goal_status || !adv->ctrl || !adv->goal || !adv->plans || !adv->current_goal || !adv->agents) {
+        g_last_error = "null buffer";
+        return DLSCQP_ERR_INVALID_ARGUMENT;
+    }
+    if (c->M * (c->n + 1) * 3 > 512) { g_last_error = "plans of more than 512 floats are not supported"; return DLSCQP_ERR_UNSUPPORTED; }
+    (void)hipSetDevice(c->cfg.device);
+    AdvanceArgs g;
+    g.a = *adv;
+    g.M = c->M;
+    g.n1 = c->n + 1;
+    g.s1 = (float)((double)c->n / c->dt);
+    g.s2 = (float)((double)(c->n - 1) / c->dt);
+    hipLaunchKernelGGL(dlscqp_advance_kernel, dim3(adv->n_agents), dim3(64), 0, (hipStream_t)stream, g);
+    HIP_TRY(hipGetLastError());
+    return DLSCQP_SUCCESS;
+}
+
 struct dlscqp_world {
     int device;
     SfcWorldView view;  // device pointers

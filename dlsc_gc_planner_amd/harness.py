@@ -126,15 +126,12 @@ class ClosedLoop:
         self.N = N
         M, n = cfg.M, cfg.n
         f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)  # noqa: E731
-        self.pos = f32(start)
-        self.vel = torch.zeros((N, 3), dtype=torch.float32, device=dev)
-        self.acc = torch.zeros((N, 3), dtype=torch.float32, device=dev)
         self.desired_goal = f32(goal)
-        self.cur_goal = self.pos.clone()  # agent_manager.cpp:9
+        self.cur_goal = f32(start)  # agent_manager.cpp:9
         self.plans = torch.zeros((N, M, n + 1, 3), dtype=torch.float32, device=dev)
-        self.wp = self.pos.clone()  # next_waypoint of every agent
-        self.init_buf = torch.zeros_like(self.plans)  # initial trajectory handed to the corridor generator
+        self.init_buf = torch.zeros_like(self.plans)  # initial trajectory: the previous plan shifted by one segment
         self.graph = None
+        self.keep_inputs = False  # tests: keep a copy of the agent records each launch read (step_inputs)
         self.radius, self.downwash = float(radius), float(downwash)
         self.waypoint_step = waypoint_step
         self.seq = 0
@@ -179,6 +176,22 @@ class ClosedLoop:
         self.batch.c.row_offsets = self.ro32.data_ptr()
         self.batch.c.max_rows_per_agent = int(np.diff(ro).max()) if N else 0
         self.agent_f32 = self.batch.t["agents"].view(torch.float32).view(N, abi.AGENT_DTYPE.itemsize // 4)
+        # position, velocity, acceleration and next_waypoint live in the agent records (views); dlscqp_advance_device
+        # rewrites them after every launch
+        a = self.agent_f32
+        self.pos, self.vel, self.acc, self.wp = a[:, 0:3], a[:, 3:6], a[:, 6:9], a[:, 12:15]
+        a[:, 0:3], a[:, 9:12], a[:, 12:15] = self.cur_goal, self.cur_goal, self.cur_goal
+        if world is None:
+            # waypoint: straight ahead towards the desired goal (stands in for the grid planner, see module doc); the
+            # first one here, the following ones by dlscqp_advance_device
+            to_goal = self.desired_goal - self.pos
+            dist = to_goal.norm(dim=1, keepdim=True)
+            self.wp.copy_(torch.where(dist <= waypoint_step, self.desired_goal,
+                                      self.pos + to_goal / dist.clamp_min(1e-9) * waypoint_step))
+        self.advance = self.opt.make_advance(self.batch, self.plans, self.cur_goal, self.init_buf,
+                                             desired_goal=self.desired_goal if world is None else None,
+                                             waypoint_step=waypoint_step if world is None else 0.0)
+        self.records_in = torch.zeros_like(self.batch.t["agents"])
         self.history = []
 
     def close(self):
@@ -203,54 +216,39 @@ class ClosedLoop:
         return torch.from_numpy(self.grid.next_waypoints(self.pos.cpu().numpy()))
 
     def _body(self, first):
-        """The device work of one step: waypoint (empty worlds), agent records, half-spaces, corridors, goal LP + QP,
-        fail-safe, state update.  Reads and writes the state tensors (pos, vel, acc, cur_goal, plans, wp) in place, calls
-        nothing that synchronises: the steady-state form (first = False) is what enable_graph() captures."""
-        torch, cfg = self.torch, self.cfg
-        n, dt = cfg.n, cfg.dt
-        if self.world is None:
-            # waypoint: straight ahead towards the desired goal (stands in for the grid planner, see module doc)
-            to_goal = self.desired_goal - self.pos
-            dist = to_goal.norm(dim=1, keepdim=True)
-            self.wp.copy_(torch.where(dist <= self.waypoint_step, self.desired_goal,
-                                      self.pos + to_goal / dist.clamp_min(1e-9) * self.waypoint_step))
-        wp = self.wp
-        a = self.agent_f32
-        a[:, 0:3], a[:, 3:6], a[:, 6:9], a[:, 9:12], a[:, 12:15] = self.pos, self.vel, self.acc, self.cur_goal, wp
+        """The device work of one step: half-spaces, corridors, goal LP + QP, then dlscqp_advance_device (fail-safe,
+        sub-goal, state := plan(dt), the next step's agent records, waypoint in empty worlds, initial trajectory).  Three or
+        four launches that read and write fixed buffers and never synchronise: the steady-state form (first = False) is
+        what enable_graph() captures."""
+        cfg = self.cfg
         dkw = dict(dyn_position=self.dyn_pos, dyn_velocity=self.dyn_vel) if self.D else {}
         if first:
-            self.gen.generate(self.cur_goal, position=self.pos, velocity=self.vel, **dkw)
-            init = self.pos[:, None, None, :].expand(-1, cfg.M, n + 1, -1) + 0 * self.plans  # zero velocity
+            pos = self.pos.contiguous()
+            self.gen.generate(self.cur_goal, position=pos, velocity=self.vel.contiguous(), **dkw)
+            # "previous plan" of the first step: hovering at the start (zero velocity), so that its shift is itself
+            self.plans.copy_(pos[:, None, None, :].expand(-1, cfg.M, cfg.n + 1, -1))
+            self.init_buf.copy_(self.plans)
+            if self.sfc is not None:  # TrajPlanner::constructSFC (traj_planner.cpp:517-520): initializeSFC once, then one shift per step
+                self.sfc.initialize(pos)
         else:
             self.gen.generate(self.cur_goal, plans=self.plans, **dkw)
-            init = torch.cat([self.plans[:, 1:], self.plans[:, -1:, -1:].expand(-1, 1, n + 1, -1)], dim=1)
-        if self.sfc is not None:  # TrajPlanner::constructSFC (traj_planner.cpp:517-520): initializeSFC once, then one shift per step
-            if first:
-                self.sfc.initialize(self.pos)
-            self.init_buf.copy_(init)
-            self.sfc.update(self.init_buf, self.cur_goal, wp)
+        if self.sfc is not None:
+            self.sfc.update(self.init_buf, self.cur_goal, self.wp)
+        if self.keep_inputs:
+            self.records_in.copy_(self.batch.t["agents"])
         self.batch.launch(True, True)
-        ok = (self.batch.out_status == abi.OK)
-        gok = (self.batch.out_goal_status != abi.INFEASIBLE)
-        # fail-safe: keep the shifted previous plan (traj_planner.cpp:776); sub-goal from the LP (traj_planner.cpp:494)
-        self.plans.copy_(torch.where(ok[:, None, None, None], self.batch.out_ctrl, init))
-        self.cur_goal.copy_(torch.where(gok[:, None], self.batch.out_goal, self.cur_goal))
+        # fail-safe: keep the shifted previous plan (traj_planner.cpp:776); sub-goal from the LP (traj_planner.cpp:494);
         # doStep of the next iteration: state = desired_traj.getStateAt(dt) = start of segment 1, float32 differences
-        c0, c1, c2 = self.plans[:, 1, 0], self.plans[:, 1, 1], self.plans[:, 1, 2]
-        s1, s2 = np.float32(n / dt), np.float32((n - 1) / dt)
-        v0, v1 = (c1 - c0) * s1, (c2 - c1) * s1
-        self.pos.copy_(c0)
-        self.vel.copy_(v0)
-        self.acc.copy_((v1 - v0) * s2)
+        self.advance()
 
     def enable_graph(self):
-        """Capture the steady-state step in a HIP graph (torch.cuda.CUDAGraph): a ten-agent step is a chain of about
-        thirty small launches and launch-bound; replaying it as one graph removes the per-launch host cost.  Call after at
+        """Capture the steady-state step in a HIP graph (torch.cuda.CUDAGraph): a ten-agent step is three or four small
+        launches and launch-bound; replaying it as one graph removes the per-launch host cost.  Call after at
         least one step; result files and the host-side waypoint planners keep working (they run outside the graph)."""
         torch = self.torch
         assert self.seq >= 1, "the first step differs (constant-velocity prediction, corridor initialisation)"
         torch.cuda.synchronize(self.dev)
-        state = [self.pos, self.vel, self.acc, self.cur_goal, self.plans, self.wp]
+        state = [self.batch.t["agents"], self.cur_goal, self.plans, self.init_buf]
         if self.sfc is not None:
             state.append(self.sfc.sfcs)  # the corridor boxes are shifted in place every step
         keep = [t.clone() for t in state]
@@ -306,7 +304,8 @@ class ClosedLoop:
         """Host copies of what the last step's launch read -- (agents, row_offsets, rows, sfc or None, max_slack_obs) in the
         layout of BatchTrajOptimizer.plan -- for checking a closed-loop step against another solver (tests)."""
         self.torch.cuda.synchronize(self.dev)
-        agents = self.batch.t["agents"].cpu().numpy().view(abi.AGENT_DTYPE).reshape(-1).copy()
+        assert self.keep_inputs, "set keep_inputs before stepping: the records are rewritten after every launch"
+        agents = self.records_in.cpu().numpy().view(abi.AGENT_DTYPE).reshape(-1).copy()
         ro, rows = self.gen.rows_host()
         sfc = None if self.sfc is None else self.sfc.sfcs.cpu().numpy().copy()
         return agents, ro, rows, sfc, self.D

@@ -133,6 +133,36 @@ class BatchTrajOptimizer:
         """Device-resident safe-flight-corridor generator for a world given as axis-aligned boxes."""
         return SfcGenerator(self, boxes, resolution, world_min, world_max, radius, max_vel, grid_resolution, device)
 
+    def make_advance(self, batch, plans, current_goal, initial_traj=None, waypoints=None, desired_goal=None,
+                     waypoint_step=0.0):
+        """The bookkeeping between two launches of `batch` as one kernel (dlscqp_advance_device): fail-safe, sub-goal,
+        state := plan(dt), the next step's agent records and initial trajectory.  All arguments are CUDA tensors that
+        stay where they are (float32; plans / initial_traj [N, M, n+1, 3], current_goal / waypoints / desired_goal
+        [N, 3]); returns a callable(stream=None)."""
+        a = abi.Advance()
+        a.n_agents = batch.n_agents
+        a.status, a.goal_status = batch.out_status.data_ptr(), batch.out_goal_status.data_ptr()
+        a.ctrl, a.goal = batch.out_ctrl.data_ptr(), batch.out_goal.data_ptr()
+        for t in (plans, current_goal, initial_traj, waypoints, desired_goal):
+            assert t is None or (t.is_contiguous() and t.dtype == self._torch().float32)
+        a.plans, a.current_goal = plans.data_ptr(), current_goal.data_ptr()
+        a.initial_traj = None if initial_traj is None else initial_traj.data_ptr()
+        a.agents = batch.t["agents"].data_ptr()
+        a.waypoints = None if waypoints is None else waypoints.data_ptr()
+        a.desired_goal = None if desired_goal is None else desired_goal.data_ptr()
+        a.waypoint_step = float(waypoint_step)
+        keep = (batch, plans, current_goal, initial_traj, waypoints, desired_goal)
+        torch = self._torch()
+
+        def run(stream=None, _keep=keep):
+            s = torch.cuda.current_stream(batch.device) if stream is None else stream
+            self._check(self.lib.dlscqp_advance_device(self.handle, C.byref(a), C.c_void_p(s.cuda_stream)), "dlscqp_advance_device")
+        return run
+
+    def _torch(self):
+        import torch
+        return torch
+
     def set_timing(self, capacity):
         self._check(self.lib.dlscqp_set_timing(self.handle, int(capacity)), "dlscqp_set_timing")
 

@@ -251,6 +251,38 @@ typedef struct dlscqp_lsc_gen {
 
 int dlscqp_generate_lsc_device(dlscqp_ctx *ctx, const dlscqp_lsc_gen *gen, void *stream);
 
+/* ---- what happens between two launches, on the device ----------------------------------------
+ * One kernel for the bookkeeping that follows dlscqp_plan_batch_device in a closed loop, so that a replanning step is
+ * three or four launches (half-spaces, corridors, LP + QP, this) and can be replayed as one HIP graph:
+ *   - fail-safe: an agent whose QP failed keeps its previous plan shifted by one segment (TrajPlanner::plan,
+ *     traj_planner.cpp:776 with the shift of initialTrajPlanningPrevSol, :412-421);
+ *   - the sub-goal becomes the goal LP's result unless the LP was infeasible (traj_planner.cpp:493-495);
+ *   - the agent moves on by one replanning period: position / velocity / acceleration := the state of the new plan
+ *     at time dt, i.e. the start of segment 1, from float32 control-point differences (AgentManager::doStep,
+ *     agent_manager.cpp:51-57, 224-227; Trajectory::getStateAt, trajectory.cpp:110-199);
+ *   - the agent records of the NEXT step are written (position, velocity, acceleration, current_goal_point and,
+ *     if given, next_waypoint), and the next step's initial trajectory (the new plan shifted by one segment), which
+ *     the corridor generator reads.
+ * `plans` and `current_goal` are updated in place.  Asynchronous on `stream`. */
+typedef struct dlscqp_advance {
+    int32_t n_agents;
+    const int32_t *status;       /* [n] out_status of the launch                                          */
+    const int32_t *goal_status;  /* [n] out_goal_status                                                   */
+    const float *ctrl;           /* [n][M][n+1][3] out_ctrl                                               */
+    const float *goal;           /* [n][3] out_goal                                                       */
+    float *plans;                /* [n][M][n+1][3] in: previous plans, out: the plans of this step        */
+    float *current_goal;         /* [n][3] in/out                                                         */
+    float *initial_traj;         /* optional [n][M][n+1][3] out: the new plans shifted by one segment     */
+    dlscqp_agent *agents;        /* [n] in/out: the five float3 fields are rewritten for the next step    */
+    const float *waypoints;      /* optional [n][3] -> next_waypoint                                      */
+    /* without a waypoint planner (no `waypoints`): next_waypoint := the point `waypoint_step` metres ahead on the
+     * straight line from the new position to desired_goal, desired_goal itself when it is nearer (optional) */
+    const float *desired_goal;   /* optional [n][3]                                                       */
+    double waypoint_step;
+} dlscqp_advance;
+
+int dlscqp_advance_device(dlscqp_ctx *ctx, const dlscqp_advance *adv, void *stream);
+
 /* Row N2 of SURVEY.md section 8(f): safe-flight-corridor (SFC) boxes on the device.
  * A world is a list of axis-aligned boxes (the rows of the reference's world CSV: centre x,y,z, size x,y,z,
  * MapManager::updateOctreeFromCSV, map_manager.cpp:264-316) rasterised to an occupancy grid of `resolution` metres

@@ -228,6 +228,7 @@ def test_forest_mission_with_spinning_obstacles(gpu_required):
                      dyn=spin.dyn(size_prediction=1, horizon=m["uncertainty_horizon"], duration=m["obs_duration"]))
     try:
         assert sim.opt.lds_bytes(4, 2000) > 160 * 1024  # this shape is the HBM-working-set one
+        sim.keep_inputs = True
         worst, wobs, wall, fails, done, checked, worst_err = 1e9, 1e9, 1e9, 0, None, 0, 0.0
         for k in range(500):
             status, _ = sim.step()
@@ -298,3 +299,55 @@ def test_hip_graph_step_equals_eager_step(gpu_required, with_world):
             assert np.array_equal(x, y), k
     moved = np.linalg.norm(runs[1][-1][1] - start, axis=1)
     assert moved.mean() > 1.0  # the agents did fly
+
+
+@pytest.mark.parametrize("M", [2, 5, 10])
+def test_advance_kernel_equals_its_numpy_restatement(gpu_required, M):
+    """dlscqp_advance_device (fail-safe, sub-goal, state := plan(dt), next records, initial trajectory, straight-line
+    waypoint) against the same arithmetic in numpy float32: bit-exact (the waypoint to float32 rounding of a division)."""
+    import torch
+    from dlsc_gc_planner_amd.planner import BatchTrajOptimizer
+    rng = np.random.default_rng(7 + M)
+    cfg = abi.make_config(dim=3, M=M, dt=0.2)
+    n, N = cfg.n, 37
+    opt = BatchTrajOptimizer(cfg)
+    try:
+        agents = np.zeros(N, abi.AGENT_DTYPE)
+        agents["id"] = np.arange(N)
+        agents["max_vel"], agents["max_acc"], agents["radius"], agents["nominal_velocity"] = 1.0, 2.0, 0.15, 1.0
+        db = opt.make_device_batch(agents, np.zeros(N + 1, np.int64), np.zeros(0, abi.ROW_DTYPE), None, 0)
+        f = lambda *shape: rng.uniform(-3, 3, shape).astype(np.float32)  # noqa: E731
+        prev, ctrl, goal, cur, want = f(N, M, n + 1, 3), f(N, M, n + 1, 3), f(N, 3), f(N, 3), f(N, 3)
+        status = rng.choice([abi.OK, abi.INFEASIBLE], N, p=[0.7, 0.3]).astype(np.int32)
+        # desired goal nearer than one waypoint step to where the agent will be (segment 1 of the new or of the old plan)
+        want[:5] = np.where((status[:5] == abi.OK)[:, None], ctrl[:5, 1, 0], prev[:5, min(2, M - 1), 0 if M > 2 else n]) + np.float32(0.01)
+        gstat = rng.choice([abi.OK, abi.INFEASIBLE, abi.GOAL_FALLBACK], N).astype(np.int32)
+        up = lambda x: torch.from_numpy(x.copy()).cuda()  # noqa: E731
+        db.out_status.copy_(up(status)); db.out_goal_status.copy_(up(gstat)); db.out_ctrl.copy_(up(ctrl)); db.out_goal.copy_(up(goal))
+        plans, cg, init, dg = up(prev), up(cur), torch.zeros((N, M, n + 1, 3), device="cuda"), up(want)
+        opt.make_advance(db, plans, cg, init, desired_goal=dg, waypoint_step=0.5)()
+        torch.cuda.synchronize()
+        rec = db.t["agents"].cpu().numpy().view(abi.AGENT_DTYPE).reshape(-1)
+        # ---- restatement ----
+        shift = lambda p: np.concatenate([p[:, 1:], np.repeat(p[:, -1:, -1:], n + 1, axis=2)], axis=1)  # noqa: E731
+        ok = status == abi.OK
+        new = np.where(ok[:, None, None, None], ctrl, shift(prev))
+        assert np.array_equal(plans.cpu().numpy(), new)
+        assert np.array_equal(init.cpu().numpy(), shift(new))
+        cg_new = np.where((gstat != abi.INFEASIBLE)[:, None], goal, cur)
+        assert np.array_equal(cg.cpu().numpy(), cg_new) and np.array_equal(rec["current_goal_point"], cg_new)
+        s1, s2 = np.float32(n / cfg.dt), np.float32((n - 1) / cfg.dt)
+        c = new[:, 1, 0:3]
+        v0, v1 = (c[:, 1] - c[:, 0]) * s1, (c[:, 2] - c[:, 1]) * s1
+        pos = c[:, 0]
+        assert np.array_equal(rec["position"], pos)
+        assert np.array_equal(rec["velocity"], v0)
+        assert np.array_equal(rec["acceleration"], (v1 - v0) * s2)
+        d = want - pos
+        dist = np.sqrt((d * d).sum(1, dtype=np.float32).astype(np.float64))
+        wp = np.where((dist <= 0.5)[:, None], want, pos + d / np.maximum(dist, 1e-9).astype(np.float32)[:, None] * np.float32(0.5))
+        assert (dist[:5] <= 0.5).all() and (dist[5:] > 0.5).any()
+        assert np.allclose(rec["next_waypoint"], wp, rtol=0, atol=1e-6)
+        assert np.array_equal(rec["id"], np.arange(N)) and np.all(rec["max_acc"] == 2.0)  # the rest of the record is untouched
+    finally:
+        opt.close()
