@@ -230,11 +230,22 @@ def test_forest_mission_with_spinning_obstacles(gpu_required):
         assert sim.opt.lds_bytes(4, 2000) > 160 * 1024  # this shape is the HBM-working-set one
         sim.keep_inputs = True
         worst, wobs, wall, fails, done, checked, worst_err = 1e9, 1e9, 1e9, 0, None, 0, 0.0
+        sfc_oracle = oracle_lib.SfcWorld(m["boxes"], m["world_resolution"], m["world"][:3], m["world"][3:], margin=m["radius"],
+                                         grid_resolution=m["grid_resolution"], max_vel=m["max_vel"], dt=cfg.dt)
+        boxes_checked = 0
         for k in range(500):
+            sample = k % 12 == 5 and k < 320
+            if sample:  # what the corridor generator is about to read
+                before = [t.cpu().numpy().copy() for t in (sim.init_buf, sim.cur_goal, sim.sfc.sfcs)]
             status, _ = sim.step()
             fails += int((status != abi.OK).sum())
-            if k % 12 == 5 and k < 320:
+            if sample:
                 agents, ro, rows, sfc, D = sim.step_inputs()
+                # row N2 in 3-D: the step's corridor boxes against the oracle's restatement, bit for bit
+                for a in range(sim.N):
+                    _, box = sfc_oracle.construct(before[0][a], before[1][a], agents["next_waypoint"][a], before[2][a])
+                    assert np.array_equal(box, sfc[a]), (k, a)
+                    boxes_checked += cfg.M
                 got = sim.batch.results()
                 ref = oracle_lib.plan_batch(cfg, agents, ro, rows, sfc, D, True)
                 assert np.array_equal(got["goal_status"], ref["goal_status"]) and np.array_equal(got["status"], ref["status"]), k
@@ -254,10 +265,11 @@ def test_forest_mission_with_spinning_obstacles(gpu_required):
                 break
     finally:
         sim.close()
+        sfc_oracle.close()
     print("forest10_spin4_100 (3-D, M = 10): all agents at their goals after", done, "s; agent safety ratio", worst,
           "tree clearance", wall, "obstacle safety ratio", wobs, "fail-safes", fails, "| plans checked against the oracle:",
-          checked, "worst control-point difference", worst_err)
-    assert checked >= 100
+          checked, "worst control-point difference", worst_err, "| corridor boxes equal to the oracle's:", boxes_checked)
+    assert checked >= 100 and boxes_checked >= 2000
     assert worst >= 1.0 and wall >= m["radius"] - 1e-4
     assert fails <= 0.01 * 500 * sim.N
     assert done is not None and done <= 100.0
