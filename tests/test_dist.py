@@ -142,3 +142,107 @@ def test_halo_agents_are_the_ones_with_remote_neighbours():
             ids += nbr[a]
             off.append(len(ids))
         assert sharding.halo_agents(off, ids, lo, hi) == exp, (lo, hi)
+
+
+# ---- BASELINE.json configs[2]: a mission flown in closed loop with its agents sharded over two ranks -------------------
+def _closed_loop(cfg, m, steps, rank=0, world=1, pg=None):
+    """ClosedLoop's data flow (dlsc_gc_planner_amd/harness.py) on the CPU for the agents [lo, hi) of a mission: half-spaces
+    from the table of everybody's previous plans and sub-goals (lane-serial build of the device generator, local_ids),
+    goal LP + QP (lane-serial build of the kernel), fail-safe / sub-goal / state := plan(dt), then the exchange
+    (sharding.PlanExchange: control points, sub-goal, status of the local agents -> table on every rank).  Every agent
+    is every other agent's neighbour in these missions, so all agents are halo agents: the next step waits for the table."""
+    import emul_lib as E
+    from dlsc_gc_planner_amd import abi
+    start, goal = np.array(m["start"], np.float32), np.array(m["goal"], np.float32)
+    N, M, n = len(start), cfg.M, cfg.n
+    lo, hi = sharding.shard_range(N, rank, world)
+    nl = hi - lo
+    ids = np.arange(N)
+    nbr_ids = np.concatenate([np.delete(ids, a) for a in range(lo, hi)]).astype(np.int32)
+    nbr_off = (np.arange(nl + 1) * (N - 1)).astype(np.int32)
+    radius, downwash = np.full(N, m["radius"]), np.full(N, m["downwash"])
+    # tables every rank holds (all agents) and the local state
+    plans_t, goals_t = np.zeros((N, M, n + 1, 3), np.float32), start.copy()
+    pos, vel, acc = start[lo:hi].copy(), np.zeros((nl, 3), np.float32), np.zeros((nl, 3), np.float32)
+    agents = np.zeros(nl, abi.AGENT_DTYPE)
+    agents["id"], agents["n_obs"] = ids[lo:hi], N - 1
+    agents["max_vel"], agents["max_acc"], agents["radius"], agents["nominal_velocity"] = m["max_vel"], m["max_acc"], m["radius"], m["nominal_velocity"]
+    xchg = None if pg is None else sharding.PlanExchange(pg, world, nl, (M * (n + 1) * 3, 3, 1), torch.device("cpu"))
+    s1, s2 = np.float32(n / cfg.dt), np.float32((n - 1) / cfg.dt)
+    for k in range(steps):
+        d = goal[lo:hi] - pos
+        dist_ = np.sqrt((d * d).sum(1, dtype=np.float32).astype(np.float64))
+        wp = np.where((dist_ <= 0.5)[:, None], goal[lo:hi], pos + d / np.maximum(dist_, 1e-9).astype(np.float32)[:, None] * np.float32(0.5))
+        if k == 0:
+            ro, rows = E.generate_lsc(cfg, None, goals_t, radius, downwash, nbr_off, nbr_ids, local_ids=ids[lo:hi],
+                                      position=start, velocity=np.zeros_like(start))
+            init = np.repeat(np.repeat(pos[:, None, None, :], M, 1), n + 1, 2)
+        else:
+            ro, rows = E.generate_lsc(cfg, plans_t, goals_t, radius, downwash, nbr_off, nbr_ids, local_ids=ids[lo:hi])
+            p = plans_t[lo:hi]
+            init = np.concatenate([p[:, 1:], np.repeat(p[:, -1:, -1:], n + 1, axis=2)], axis=1)
+        agents["position"], agents["velocity"], agents["acceleration"] = pos, vel, acc
+        agents["current_goal_point"], agents["next_waypoint"] = goals_t[lo:hi], wp
+        got = E.plan_batch(cfg, agents, ro, rows, None, 0, True)
+        ok = got["status"] == abi.OK
+        new = np.where(ok[:, None, None, None], got["ctrl"], init).astype(np.float32)
+        cg = np.where((got["goal_status"] != abi.INFEASIBLE)[:, None], got["goal"], goals_t[lo:hi]).astype(np.float32)
+        c0, c1, c2 = new[:, 1, 0], new[:, 1, 1], new[:, 1, 2]
+        v0, v1 = (c1 - c0) * s1, (c2 - c1) * s1
+        pos, vel, acc = c0.copy(), v0, (v1 - v0) * s2
+        if xchg is None:
+            plans_t, goals_t = new, cg
+        else:
+            xchg.post(torch.from_numpy(new), torch.from_numpy(cg), torch.from_numpy(got["status"].astype(np.int32)))
+            ctrl_all, goal_all, st_all = xchg.unpack(xchg.table(), (torch.float32, torch.float32, torch.int32))
+            plans_t = ctrl_all.reshape(N, M, n + 1, 3).numpy().copy()
+            goals_t = goal_all.numpy().copy()
+            assert np.array_equal(st_all.flatten().numpy()[lo:hi], got["status"])
+    return plans_t, goals_t
+
+
+def _mission_cfg(name):
+    import json
+    from dlsc_gc_planner_amd import abi
+    here = os.path.dirname(os.path.abspath(__file__))
+    m = json.load(open(os.path.join(here, "golden", "missions_empty.json")))[name]
+    w = m["world"]
+    cfg = abi.make_config(dim=3, M=5, dt=0.2, control_input_weight=0.01, terminal_weight=1.0, communication_range=-1.0,
+                          world_use_octomap=False, world_min=tuple(w[:3]), world_max=tuple(w[3:]))
+    return cfg, m
+
+
+def _mission_worker(rank, world, port, name, steps, q):
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    sys.path.insert(0, here)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg, m = _mission_cfg(name)
+    plans, goals = _closed_loop(cfg, m, steps, rank, world, dist)
+    q.put((rank, plans, goals))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_mission_sharded_over_two_ranks_equals_one_process():
+    """empty60 (BASELINE.json configs[2]: 60 agents, 1 593 half-spaces each) flown in closed loop for three replanning
+    steps with agents 0-29 on rank 0 and 30-59 on rank 1 and one plan exchange per step: the table of plans and sub-goals
+    on either rank equals the single-process run bit for bit."""
+    name, steps = "empty60_1", 3
+    cfg, m = _mission_cfg(name)
+    ref_plans, ref_goals = _closed_loop(cfg, m, steps)
+    assert np.abs(ref_plans[:, -1, -1] - np.array(m["start"], np.float32)).max() > 0.2  # the agents are on their way
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_mission_worker, args=(r, 2, port, name, steps, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (a, b) for r, a, b in (q.get(timeout=600) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert np.array_equal(res[r][0], ref_plans) and np.array_equal(res[r][1], ref_goals), r
