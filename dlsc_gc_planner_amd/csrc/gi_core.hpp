@@ -706,9 +706,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         w.each([&](int l) {
             double bv = 0.0, bs = 0.0;  // violation and pivot score (violation / whitened row length) of the lane's best row
             int bc = -1;
-            // cached rows: per row, all LDS reads first and unconditionally (DQ_KEEP), then select-based
-            // arithmetic -- no branches, so the reads of consecutive rows issue back to back.
-            // (Staging the loads of all rows in local arrays first miscompiled on gfx950/ROCm 7.2 for SU = 7.)
+            // cached rows: ALL LDS reads of the pass first and unconditionally (DQ_KEEP), then select-based arithmetic
+            // -- no branches, and one exposed LDS round trip per pass instead of one per row.
+            double lx[KU][4], sx[SU][5];
 #pragma unroll
             for (int u = 0; u < KU; u++) {
                 const uint32_t key = ckey[u].at(l);
@@ -717,14 +717,36 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 const int p = in_model ? m * n1 + i : 0;
                 const uint32_t sl = key >> 16;
                 const bool has_slack = in_model && sl != 0xFFFFu;
-                double x0 = x[p], x1 = x[P + p], x2 = dim == 3 ? x[2 * P + p] : 0.0;
-                double x3 = x[nxc + (has_slack ? (int)sl * M + m : 0)];
-                DQ_KEEP(x0); DQ_KEEP(x1); DQ_KEEP(x2); DQ_KEEP(x3);
+                lx[u][0] = x[p];
+                lx[u][1] = x[P + p];
+                lx[u][2] = dim == 3 ? x[2 * P + p] : 0.0;
+                lx[u][3] = SLK == 0 ? 0.0 : x[nxc + (has_slack ? (int)sl * M + m : 0)];
+            }
+#pragma unroll
+            for (int u = 0; u < SU; u++) {
+                const uint32_t pi = sidx[u].at(l), pc = scb[u].at(l);
+                int i0 = pi & 0x3FF, i1 = (pi >> 10) & 0x3FF, i2 = (pi >> 20) & 0x3FF;
+                i0 = i0 == 0x3FF ? 0 : i0;  // unused entries carry coefficient 0
+                i1 = i1 == 0x3FF ? 0 : i1;
+                i2 = i2 == 0x3FF ? 0 : i2;
+                const int bsel = pc >> 24;
+                sx[u][0] = x[i0]; sx[u][1] = x[i1]; sx[u][2] = x[i2]; sx[u][3] = blo[bsel]; sx[u][4] = bhi[bsel];
+            }
+#pragma unroll
+            for (int u = 0; u < KU; u++) { DQ_KEEP(lx[u][0]); DQ_KEEP(lx[u][1]); DQ_KEEP(lx[u][2]); DQ_KEEP(lx[u][3]); }
+#pragma unroll
+            for (int u = 0; u < SU; u++) { DQ_KEEP(sx[u][0]); DQ_KEEP(sx[u][1]); DQ_KEEP(sx[u][2]); DQ_KEEP(sx[u][3]); DQ_KEEP(sx[u][4]); }
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                const uint32_t key = ckey[u].at(l);
+                const bool in_model = key != KEY_SKIP;
+                const uint32_t sl = key >> 16;
+                const bool has_slack = in_model && sl != 0xFFFFu;
                 const bool valid = in_model && !((fl_lsc.at(l) >> u) & 1);
-                double val = (double)cnx[u].at(l) * x0;
-                val = fma((double)cny[u].at(l), x1, val);
-                if (dim == 3) val = fma((double)cnz[u].at(l), x2, val);
-                val -= has_slack ? x3 : 0.0;
+                double val = (double)cnx[u].at(l) * lx[u][0];
+                val = fma((double)cny[u].at(l), lx[u][1], val);
+                if (dim == 3) val = fma((double)cnz[u].at(l), lx[u][2], val);
+                val -= has_slack ? lx[u][3] : 0.0;
                 const double v = valid ? cd[u].at(l) - val : -1.0;
                 const double sc = v > VIOL_TOL ? v * ciw[u].at(l) : -1.0;
                 bc = sc > bs ? l + 64 * u : bc;
@@ -735,18 +757,11 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             for (int u = 0; u < SU; u++) {
                 const uint32_t pi = sidx[u].at(l), pc = scb[u].at(l);
                 const bool valid = !(pi & 0x80000000u);
-                int i0 = pi & 0x3FF, i1 = (pi >> 10) & 0x3FF, i2 = (pi >> 20) & 0x3FF;
-                i0 = i0 == 0x3FF ? 0 : i0;  // unused entries carry coefficient 0
-                i1 = i1 == 0x3FF ? 0 : i1;
-                i2 = i2 == 0x3FF ? 0 : i2;
-                const int bsel = pc >> 24;
-                double x0 = x[i0], x1 = x[i1], x2 = x[i2], b0 = blo[bsel], b1 = bhi[bsel];
-                DQ_KEEP(x0); DQ_KEEP(x1); DQ_KEEP(x2); DQ_KEEP(b0); DQ_KEEP(b1);
-                double val = (double)(int8_t)(pc & 0xFF) * x0;
-                val = fma((double)(int8_t)((pc >> 8) & 0xFF), x1, val);
-                val = fma((double)(int8_t)((pc >> 16) & 0xFF), x2, val);
-                const double vlo = (valid && !((fl_slo.at(l) >> u) & 1)) ? b0 - val : -1.0;
-                const double vhi = (valid && !((fl_shi.at(l) >> u) & 1)) ? val - b1 : -1.0;
+                double val = (double)(int8_t)(pc & 0xFF) * sx[u][0];
+                val = fma((double)(int8_t)((pc >> 8) & 0xFF), sx[u][1], val);
+                val = fma((double)(int8_t)((pc >> 16) & 0xFF), sx[u][2], val);
+                const double vlo = (valid && !((fl_slo.at(l) >> u) & 1)) ? sx[u][3] - val : -1.0;
+                const double vhi = (valid && !((fl_shi.at(l) >> u) & 1)) ? val - sx[u][4] : -1.0;
                 const int s = l + 64 * u;
                 const double slo = vlo > VIOL_TOL ? vlo * siw[u].at(l) : -1.0;
                 bc = slo > bs ? K + 2 * s : bc;
