@@ -463,7 +463,55 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 
     // ---- unconstrained minimiser and bound table into LDS -------------------------------------------
     // (uniform trip counts; a lane past the end computes a clamped element and stores it to the dump slot)
+    RegD ciw[KU], siw[SU], nnr[KU];
+    constexpr int NXP = DIMS > 0 ? (DIMS * MS * 6 + 63) / 64 : 1;
+    if (DIMS > 0) {
+        // static shapes: every table read of this phase (x0 factors, slot scalings, row scalings: L2 round trips) is
+        // issued before the first use, so the phase pays one round trip instead of one per table
+        w.each([&](int l) {
+            double a0[NXP], a1[NXP], a2[NXP], ag[NXP], sv[SU], nn[KU];
+#pragma unroll
+            for (int u = 0; u < NXP; u++) {
+                const int j = 64 * u + l;
+                const int jc = j < nxc ? j : nxc - 1;
+                const int p = jc - (jc / P) * P;
+                a0[u] = tXs[p * 3 + 0]; a1[u] = tXs[p * 3 + 1]; a2[u] = tXs[p * 3 + 2]; ag[u] = tXg[p];
+            }
+#pragma unroll
+            for (int u = 0; u < SU; u++) {
+                const int s = l + 64 * u;
+                sv[u] = tSIW[s < Sc ? s : (Sc > 0 ? Sc - 1 : 0)];
+            }
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                const uint32_t key = ckey[u].at(l);
+                const bool have = key != KEY_SKIP;
+                const int mi = have ? (int)(key & 0xFF) * n1 + (int)((key >> 8) & 0xF) : 0;
+                nn[u] = tNN[mi < P ? mi : 0];
+            }
+#pragma unroll
+            for (int u = 0; u < NXP; u++) { DQ_KEEP(a0[u]); DQ_KEEP(a1[u]); DQ_KEEP(a2[u]); DQ_KEEP(ag[u]); }
+#pragma unroll
+            for (int u = 0; u < SU; u++) DQ_KEEP(sv[u]);
+#pragma unroll
+            for (int u = 0; u < KU; u++) DQ_KEEP(nn[u]);
+#pragma unroll
+            for (int u = 0; u < NXP; u++) {
+                const int j = 64 * u + l;
+                const bool in = j < nxc;
+                const int k = (in ? j : nxc - 1) / P;
+                const double v = a0[u] * (double)pick3(pos, k) + a1[u] * (double)pick3(vel, k) + a2[u] * (double)pick3(acc, k) +
+                                 ag[u] * (double)pick3(goal, k);
+                base[blend_idx(in, oX + j, odump + (l & 31))] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < SU; u++) siw[u].at(l) = (l + 64 * u < Sc) ? sv[u] : 0.0;
+#pragma unroll
+            for (int u = 0; u < KU; u++) nnr[u].at(l) = nn[u];
+        });
+    }
     w.each([&](int l) {
+        if (DIMS == 0) {
         for (int j0 = 0; j0 < nxc; j0 += 64) {
             const int j = j0 + l;
             const bool in = j < nxc;
@@ -472,6 +520,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             const double v = tXs[p * 3 + 0] * (double)pick3(pos, k) + tXs[p * 3 + 1] * (double)pick3(vel, k) +
                              tXs[p * 3 + 2] * (double)pick3(acc, k) + tXg[p] * (double)pick3(goal, k);
             base[blend_idx(in, oX + j, odump + (l & 31))] = v;
+        }
         }
         for (int s0 = 0; s0 < nslk; s0 += 64) {
             const int s2 = s0 + l;
@@ -514,16 +563,17 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         }
     });
     // finish the LSC cache: rhs = d + n.p (traj_optimizer.cpp:427-439), drop rows that are not in the model
-    RegD ciw[KU], siw[SU];
+    if (DIMS == 0) {
 #pragma unroll
-    for (int u = 0; u < SU; u++) {
-        w.each([&](int l) { siw[u].at(l) = 0.0; });
-        if (64 * u < Sc) {  // uniform
-            w.each([&](int l) {
-                const int s = l + 64 * u;
-                const double v = tSIW[s < Sc ? s : Sc - 1];
-                siw[u].at(l) = s < Sc ? v : 0.0;
-            });
+        for (int u = 0; u < SU; u++) {
+            w.each([&](int l) { siw[u].at(l) = 0.0; });
+            if (64 * u < Sc) {  // uniform
+                w.each([&](int l) {
+                    const int s = l + 64 * u;
+                    const double v = tSIW[s < Sc ? s : Sc - 1];
+                    siw[u].at(l) = s < Sc ? v : 0.0;
+                });
+            }
         }
     }
 #pragma unroll
@@ -548,7 +598,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             sl = no_such_slack ? 0xFFFFu : sl;
             // pivot scaling 1 / |N' a|  (whitened length of the row normal)
             const int mi = m * n1 + i;
-            double wsq = nsq * tNN[mi < P ? mi : 0];
+            double tnn = DIMS > 0 ? nnr[u].at(l) : tNN[mi < P ? mi : 0];
+            DQ_KEEP(tnn);
+            double wsq = nsq * tnn;
             double sg = kp.sigma[m < M ? m : 0];
             DQ_KEEP(sg);
             wsq = sl != 0xFFFFu ? wsq + sg * sg : wsq;
@@ -999,12 +1051,13 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 const bool in_ctrl = e < rc;
                 const int ec = in_ctrl ? e : 0;
                 const int k = ec / f, j = ec - k * f;
+                double nv[3];  // the three loads first (NREG: L2 round trips), then their uses
 #pragma unroll
-                for (int t = 0; t < 3; t++) {  // ep[t] is a valid row of N for unused entries too (0)
-                    double nv = NREG ? tN[ep[t] * f + j] : Nl[ep[t] * f + j];
-                    DQ_KEEP(nv);
-                    v = (in_ctrl & (ek[t] == k)) ? fma(cf[t], nv, v) : v;
-                }
+                for (int t = 0; t < 3; t++) nv[t] = NREG ? tN[ep[t] * f + j] : Nl[ep[t] * f + j];  // ep[t] is a valid row of N for unused entries too (0)
+#pragma unroll
+                for (int t = 0; t < 3; t++) DQ_KEEP(nv[t]);
+#pragma unroll
+                for (int t = 0; t < 3; t++) v = (in_ctrl & (ek[t] == k)) ? fma(cf[t], nv[t], v) : v;
                 double sgm = -kp.sigma[(sidx_row < 0 ? 0 : sidx_row) % M];
                 DQ_KEEP(sgm);
                 v = (!in_ctrl & (e - rc == sidx_row)) ? sgm : v;
