@@ -63,7 +63,7 @@ DQ_FN bool sfc_point_blocked(const SfcWorldView &w, const float sp[3], double ma
             const double dd = fabsf(cp - sp[k]);                             // LInfinityDistance, util.hpp:131-140
             linf = linf < dd ? dd : linf;
         }
-        best = (t < nt) & (linf < best) ? linf : best;
+        best = ((t < nt) & (linf < best)) ? linf : best;
     }
     const float dist = (float)(sqrt((double)(d2 < 0 ? 0 : d2)) * w.res);
     return inside & (d2 >= 0) & (dist < 1) & (best < margin + SFC_EPS_F);
