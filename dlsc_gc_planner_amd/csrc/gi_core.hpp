@@ -630,6 +630,16 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 
     int q = 0, iters = 0, n_add = 0, n_drop = 0;
     bool factors_ready = false;
+    // The Householder update of Q that an added row asks for is postponed until Q is read again: the last row an agent
+    // adds is usually followed by a pricing pass that finds nothing, and then the O(r^2) sweep is never needed.
+    bool q_pending = false;
+    int q_pend_col = 0;
+    double q_pend_alpha = 0.0, q_pend_beta = 0.0;
+    RegD q_pend_v[RC], q_pend_z[RC];
+    w.each([&](int l) {
+#pragma unroll
+        for (int c = 0; c < RC; c++) { q_pend_v[c].at(l) = 0.0; q_pend_z[c].at(l) = 0.0; }
+    });
     RegD nrow[NREG ? FB : 1];  // NREG: row (lane) of N_T, loaded with the factors
     w.each([&](int l) { for (int u = 0; u < (NREG ? FB : 1); u++) nrow[u].at(l) = 0.0; });
     const int max_iter = kp.max_iter > 0 ? kp.max_iter : 20 * (r + 8) + 200;
@@ -749,6 +759,41 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             upd(fl_slk, s & 63, s >> 6);
         }
         w.sync();
+    };
+
+    auto apply_pending_q = [&]() {
+        const int qc = q_pend_col;
+                w.each([&](int l) {
+#pragma unroll
+            for (int c = 0; c < RC; c++) {
+                const int i = l + 64 * c;
+                double *qi = Q + (i < r ? i : qdummy) * ldq;  // lanes beyond r update the spare row
+                const double gi = -q_pend_beta * (q_pend_z[c].at(l) - q_pend_alpha * qi[qc]);
+#if DQ_STAGE_H
+                for (int j0 = 0; j0 < rc; j0 += FB) {  // Q[i][:] += gi v', in blocks of FB columns
+                    if (j0 + FB <= qc) continue;  // uniform: v is zero in the first q columns
+                    const int nv = rc - j0 < FB ? rc - j0 : FB;  // uniform; == FB for static shapes
+                    double tq[FB];
+#pragma unroll
+                    for (int u = 0; u < FB; u++) tq[u] = qi[j0 + (u < nv ? u : 0)];
+#pragma unroll
+                    for (int u = 0; u < FB; u++) DQ_KEEP(tq[u]);
+#pragma unroll
+                    for (int u = 0; u < FB; u++) tq[u] = fma(gi, DQ_BC(q_pend_v, j0 + (u < nv ? u : 0)), tq[u]);
+#pragma unroll
+                    for (int u = 0; u < FB; u++)
+                        if (u < nv) qi[j0 + u] = tq[u];  // uniform condition
+                }
+#else
+#pragma unroll
+                for (int j = 0; j < rc; j++) qi[j] = fma(gi, DQ_BC(q_pend_v, j), qi[j]);  // Q[i][:] += gi v'
+#endif
+
+                for (int j = rc; j < r; j++) qi[j] = fma(gi, DQ_BC(q_pend_v, j), qi[j]);
+            }
+        });
+        w.sync();
+        q_pending = false;
     };
 
     for (;;) {
@@ -970,6 +1015,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             w.stamp(1);
         }
 
+        if (q_pending) apply_pending_q();  // uniform
         // ---- decode the row into sparse x-space entries (uniform) -------------------------------
         int ek[3] = {-1, -1, -1}, ep[3] = {0, 0, 0}, sidx_row = -1;
         double cf[3] = {0, 0, 0}, row_scale = 1.0;
@@ -1313,44 +1359,20 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 const double v0 = dq - alpha;
                 const double beta = 1.0 / (nrm * (nrm + fabs(dq)));  // 2 / v'v
                 const double inv_alpha = 1.0 / alpha;
-                // Householder vector v = (0,..,0, d_q - alpha, d_{q+1}, ..) as a register: branch-free loop below
-                RegD hv[RC];
+                // Householder vector v = (0,..,0, d_q - alpha, d_{q+1}, ..) as a register; Q <- Q H is applied by
+                // apply_pending_q() when Q is read next
                 w.each([&](int l) {
 #pragma unroll
                     for (int c = 0; c < RC; c++) {
                         const int j = l + 64 * c;
-                        hv[c].at(l) = j > q ? dv[c].at(l) : (j == q ? v0 : 0.0);
+                        q_pend_v[c].at(l) = j > q ? dv[c].at(l) : (j == q ? v0 : 0.0);
+                        q_pend_z[c].at(l) = zv[c].at(l);
                     }
                 });
-                w.each([&](int l) {
-#pragma unroll
-                    for (int c = 0; c < RC; c++) {
-                        const int i = l + 64 * c;
-                        double *qi = Q + (i < r ? i : qdummy) * ldq;  // lanes beyond r update the spare row
-                        const double gi = -beta * (zv[c].at(l) - alpha * qi[q]);
-#if DQ_STAGE_H
-                        for (int j0 = 0; j0 < rc; j0 += FB) {  // Q[i][:] += gi v', in blocks of FB columns
-                            if (j0 + FB <= q) continue;  // uniform: v is zero in the first q columns
-                            const int nv = rc - j0 < FB ? rc - j0 : FB;  // uniform; == FB for static shapes
-                            double tq[FB];
-#pragma unroll
-                            for (int u = 0; u < FB; u++) tq[u] = qi[j0 + (u < nv ? u : 0)];
-#pragma unroll
-                            for (int u = 0; u < FB; u++) DQ_KEEP(tq[u]);
-#pragma unroll
-                            for (int u = 0; u < FB; u++) tq[u] = fma(gi, DQ_BC(hv, j0 + (u < nv ? u : 0)), tq[u]);
-#pragma unroll
-                            for (int u = 0; u < FB; u++)
-                                if (u < nv) qi[j0 + u] = tq[u];  // uniform condition
-                        }
-#else
-#pragma unroll
-                        for (int j = 0; j < rc; j++) qi[j] = fma(gi, DQ_BC(hv, j), qi[j]);  // Q[i][:] += gi v'
-#endif
-
-                        for (int j = rc; j < r; j++) qi[j] = fma(gi, DQ_BC(hv, j), qi[j]);
-                    }
-                });
+                q_pending = true;
+                q_pend_col = q;
+                q_pend_alpha = alpha;
+                q_pend_beta = beta;
                 w.each([&](int l) {
 #pragma unroll
                     for (int c = 0; c < RC; c++) {
