@@ -633,6 +633,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     // The Householder update of Q that an added row asks for is postponed until Q is read again: the last row an agent
     // adds is usually followed by a pricing pass that finds nothing, and then the O(r^2) sweep is never needed.
     bool q_pending = false;
+    bool q_identity = true;  // Q has not been written yet: it is the identity (d = na, z = d2), materialised with the first update
     int q_pend_col = 0;
     double q_pend_alpha = 0.0, q_pend_beta = 0.0;
     RegD q_pend_v[RC], q_pend_z[RC];
@@ -763,6 +764,20 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 
     auto apply_pending_q = [&]() {
         const int qc = q_pend_col;
+        if (q_identity) {  // uniform: first update, Q = I first (and zeros in the spare row qdummy that lanes beyond r work on)
+            w.each([&](int l0) {
+                int l = l0;
+                DQ_KEEP(l);  // addresses computed here, not hoisted out of the iteration loop (see the factor set-up)
+                const int nq = (r_max + 1) * ldq;
+                for (int j0 = 0; j0 < nq; j0 += 64) {
+                    const int j = j0 + l;
+                    const int i = j / ldq, c = j - i * ldq;
+                    base[blend_idx(j < nq, oQ + j, odump + (l & 31))] = ((i == c) & (i < r)) ? 1.0 : 0.0;
+                }
+            });
+            w.sync();
+            q_identity = false;
+        }
                 w.each([&](int l) {
 #pragma unroll
             for (int c = 0; c < RC; c++) {
@@ -995,13 +1010,6 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                         base[blend_idx(in, oN + j, odump + (l & 31))] = v;
                     }
                 }
-                // identity, and zeros in the spare row qdummy that lanes beyond r work on
-                const int nq = (r_max + 1) * ldq;
-                for (int j0 = 0; j0 < nq; j0 += 64) {
-                    const int j = j0 + l;
-                    const int i = j / ldq, c = j - i * ldq;
-                    base[blend_idx(j < nq, oQ + j, odump + (l & 31))] = ((i == c) & (i < r)) ? 1.0 : 0.0;
-                }
             });
             if (NREG) {
                 w.each([&](int l) {
@@ -1117,6 +1125,12 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         while (!resolved) {
             if (++iters > max_iter) { status = DLSCQP_ITERATION_LIMIT; break; }
             // d = Q' na   (na is non-zero only in the touched axis blocks and one slack entry)
+            if (q_identity) {  // uniform
+                w.each([&](int l) {
+#pragma unroll
+                    for (int c = 0; c < RC; c++) dv[c].at(l) = l + 64 * c < r ? na[c].at(l) : 0.0;
+                });
+            } else
             w.each([&](int l) {
 #pragma unroll
                 for (int c = 0; c < RC; c++) {
@@ -1157,6 +1171,12 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 #pragma unroll
                 for (int c = 0; c < RC; c++) dz[c].at(l) = (l + 64 * c >= q) ? dv[c].at(l) : 0.0;
             });
+            if (q_identity) {  // uniform: Q2 = I (q = 0)
+                w.each([&](int l) {
+#pragma unroll
+                    for (int c = 0; c < RC; c++) zv[c].at(l) = dz[c].at(l);
+                });
+            } else
             w.each([&](int l) {
 #pragma unroll
                 for (int c = 0; c < RC; c++) {
