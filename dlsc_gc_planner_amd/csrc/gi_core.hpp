@@ -190,7 +190,7 @@ DQ_FN T pick3(const T *v, int k) {
 // dimension r are constants: LDS addresses become "lane part + immediate", no address arithmetic in the loops.
 template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK, class W>
 DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsigned char *mem,
-                      const dlscqp_agent *agp, const RowsView &rows, int row_begin, int K,
+                      const dlscqp_agent *agp, const RowsView &rows, int row_begin, int K_rows,
                       const float *sfc, int max_slack_obs, int do_goal, int do_traj,
                       float *out_goal, int *out_goal_status, float *out_ctrl, double *out_x,
                       double *out_cost, double *out_slack_cost, int *out_status, int *out_iters) {
@@ -200,6 +200,11 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     typedef typename W::template Reg<uint32_t> RegU;
     typedef typename W::template Reg<int> RegI;
 
+    constexpr int CB = 4;  // rows beyond the register cache are read in trips of CB blocks of 64
+    // select_instance() hands the KU = 2 instantiation only batches whose rows and slots all fit the register caches
+    // (kmax <= 128, n_slots <= 256): it is compiled without the loops over rows and slots beyond them
+    constexpr bool ALL_CACHED = KU == 2 && SU == 4;
+    const int K = ALL_CACHED && K_rows > 64 * KU ? 64 * KU : K_rows;
     const int dim = DIMS > 0 ? DIMS : kp.dim, f = FS > 0 ? FS : kp.f;
     const int M = MS > 0 ? MS : kp.M;
     constexpr int n1 = 6;  // n = 5 is the only degree the reference supports (traj_optimizer.cpp:209)
@@ -231,7 +236,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     RegF cnx[KU], cny[KU], cnz[KU], cpx[KU], cpy[KU], cpz[KU];
     RegD cd[KU];
     RegU ckey[KU];
-    const int Kc = K < 64 * KU ? K : 64 * KU;  // cached rows
+    const int Kc = ALL_CACHED ? K : (K < 64 * KU ? K : 64 * KU);  // cached rows
 #pragma unroll
     for (int u = 0; u < KU; u++) {
         w.each([&](int l) {
@@ -258,8 +263,8 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 
     // ---- structured slots into registers (issued here so that all prologue loads are in flight together)
     const Slot *slots = kp.slots;
-    const int n_slots = kp.n_slots;
-    const int Sc = n_slots < 64 * SU ? n_slots : 64 * SU;  // cached slots
+    const int n_slots = ALL_CACHED && kp.n_slots > 64 * SU ? 64 * SU : kp.n_slots;
+    const int Sc = ALL_CACHED ? n_slots : (n_slots < 64 * SU ? n_slots : 64 * SU);  // cached slots
     RegU sidx[SU], scb[SU];  // 3 x 10-bit x-space indices (0x3FF = unused) | 3 x int8 coefficients + bsel
 #pragma unroll
     for (int u = 0; u < SU; u++) {
@@ -343,12 +348,33 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 for (int u = 0; u < KU; u++)
                         lp_row(ckey[u].at(l), cnx[u].at(l), cny[u].at(l), cnz[u].at(l), cpx[u].at(l), cpy[u].at(l),
                                cpz[u].at(l), cd[u].at(l), lo, hi, bad, viol);
-                for (int j0 = 64 * KU; j0 < K; j0 += 64) {  // rows beyond the register cache (uniform trip count)
-                    const int j = j0 + l;
-                    const bool in = j < K;
-                    const int jc = in ? j : K - 1;
-                    const uint32_t kk = Rkey[jc];
-                    lp_row(in ? kk : KEY_SKIP, Rnx[jc], Rny[jc], Rnz[jc], Rpx[jc], Rpy[jc], Rpz[jc], Rd[jc], lo, hi, bad, viol);
+                // rows beyond the register cache (uniform trip count): CB blocks of 64 rows per trip, all their loads
+                // issued before the first use (one HBM round trip per CB blocks)
+                if (!ALL_CACHED)
+                for (int j0 = 64 * KU; j0 < K; j0 += 64 * CB) {
+                    uint32_t kk[CB];
+                    float g[CB][6];
+                    double gd[CB];
+#pragma unroll
+                    for (int u = 0; u < CB; u++) {
+                        const int j = j0 + 64 * u + l;
+                        const int jc = j < K ? j : K - 1;
+                        kk[u] = Rkey[jc];
+                        g[u][0] = Rnx[jc]; g[u][1] = Rny[jc]; g[u][2] = Rnz[jc];
+                        g[u][3] = Rpx[jc]; g[u][4] = Rpy[jc]; g[u][5] = Rpz[jc];
+                        gd[u] = Rd[jc];
+                    }
+#pragma unroll
+                    for (int u = 0; u < CB; u++) {  // loaded by every lane: no branch around the loads of rows past the end
+                        DQ_KEEP(kk[u]); DQ_KEEP(gd[u]);
+#pragma unroll
+                        for (int t = 0; t < 6; t++) DQ_KEEP(g[u][t]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < CB; u++) {
+                        const uint32_t kq = blend_idx(j0 + 64 * u + l < K, (int)kk[u], (int)KEY_SKIP);
+                        lp_row(kq, g[u][0], g[u][1], g[u][2], g[u][3], g[u][4], g[u][5], gd[u], lo, hi, bad, viol);
+                    }
                 }
                 llo.at(l) = lo; lhi.at(l) = hi; lbad.at(l) = bad; lviol.at(l) = viol;
             });
@@ -899,41 +925,71 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 bv = sc > bs ? v : bv;
                 bs = sc > bs ? sc : bs;
             }
-            // rows beyond the register cache: straight from HBM (rare: K > 256 or > 640 slots)
-            for (int j0 = Kc; j0 < K; j0 += 64) {
-                const int j = j0 + l;
-                const bool in = j < K;
-                const int jc = in ? j : K - 1;
-                const uint32_t key = Rkey[jc];
-                const int m = key & 0xFF, i = (key >> 8) & 0xF;
-                const float nx = Rnx[jc], ny = Rny[jc], nz = Rnz[jc];
-                int cf0 = cold_flag[jc - Kc];
-                double nrm = f32_norm3(nx, ny, nz);
-                DQ_KEEP(cf0); DQ_KEEP(nrm);
-                const bool in_model = in & (cf0 == 0) & !((m == 0) & (i < kp.phi)) & !(nrm < SP_EPSILON_FLOAT);
-                const int p = in_model ? m * n1 + i : 0;
-                double val = (double)nx * x[p] + (double)ny * x[P + p];
-                double rhs = Rd[jc] + (double)nx * (double)Rpx[jc] + (double)ny * (double)Rpy[jc];
-                const double val3 = val + (double)nz * x[(dim == 3 ? 2 : 0) * P + p], rhs3 = rhs + (double)nz * (double)Rpz[jc];
-                val = dim == 3 ? val3 : val;
-                rhs = dim == 3 ? rhs3 : rhs;
-                const uint32_t sl = key >> 16;
-                const bool has_slack = in_model & (sl != 0xFFFFu) & ((int)sl < nso);
-                double xs = x[nxc + (has_slack ? (int)sl * M + m : 0)];
-                DQ_KEEP(xs);
-                val = has_slack ? val - xs : val;
-                const double v = rhs - val;
-                double wsq = ((double)nx * (double)nx + (double)ny * (double)ny + (dim == 3 ? (double)nz * (double)nz : 0.0)) * tNN[p];
-                double sg = kp.sigma[in_model ? m : 0];
-                DQ_KEEP(sg);
-                wsq = has_slack ? wsq + sg * sg : wsq;
-                double qv = v / sqrt(wsq > 0 ? wsq : 1.0);
-                DQ_KEEP(qv);
-                const double sc = (in_model & (v > VIOL_TOL) & (wsq > 0)) ? qv : -1.0;
-                bc = sc > bs ? j : bc;
-                bv = sc > bs ? v : bv;
-                bs = sc > bs ? sc : bs;
+            // rows beyond the register cache: straight from HBM (K > 64 KU), CB blocks of 64 rows per trip: first every
+            // row's record, then the loads that depend on it (scaling, slack variable), then the arithmetic
+            if (!ALL_CACHED)
+            for (int j0 = Kc; j0 < K; j0 += 64 * CB) {
+                uint32_t key[CB];
+                float g[CB][6];
+                double gd[CB];
+                int cf0[CB];
+#pragma unroll
+                for (int u = 0; u < CB; u++) {
+                    const int j = j0 + 64 * u + l;
+                    const int jc = j < K ? j : K - 1;
+                    key[u] = Rkey[jc];
+                    g[u][0] = Rnx[jc]; g[u][1] = Rny[jc]; g[u][2] = Rnz[jc];
+                    g[u][3] = Rpx[jc]; g[u][4] = Rpy[jc]; g[u][5] = Rpz[jc];
+                    gd[u] = Rd[jc];
+                    cf0[u] = cold_flag[jc - Kc];
+                }
+#pragma unroll
+                for (int u = 0; u < CB; u++) {
+                    DQ_KEEP(key[u]); DQ_KEEP(gd[u]); DQ_KEEP(cf0[u]);
+#pragma unroll
+                    for (int t = 0; t < 6; t++) DQ_KEEP(g[u][t]);
+                }
+                double xv[CB][4], tn[CB], sg[CB];
+                bool inm[CB], hsl[CB];
+#pragma unroll
+                for (int u = 0; u < CB; u++) {
+                    const int j = j0 + 64 * u + l;
+                    const int m = key[u] & 0xFF, i = (key[u] >> 8) & 0xF;
+                    double nrm = f32_norm3(g[u][0], g[u][1], g[u][2]);
+                    DQ_KEEP(nrm);
+                    inm[u] = (j < K) & (cf0[u] == 0) & !((m == 0) & (i < kp.phi)) & !(nrm < SP_EPSILON_FLOAT);
+                    const int p = inm[u] ? m * n1 + i : 0;
+                    const uint32_t sl = key[u] >> 16;
+                    hsl[u] = inm[u] & (sl != 0xFFFFu) & ((int)sl < nso);
+                    xv[u][0] = x[p]; xv[u][1] = x[P + p]; xv[u][2] = x[(dim == 3 ? 2 : 0) * P + p];
+                    xv[u][3] = x[nxc + (hsl[u] ? (int)sl * M + m : 0)];
+                    tn[u] = tNN[p];
+                    sg[u] = kp.sigma[inm[u] ? m : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < CB; u++) { DQ_KEEP(xv[u][0]); DQ_KEEP(xv[u][1]); DQ_KEEP(xv[u][2]); DQ_KEEP(xv[u][3]); DQ_KEEP(tn[u]); DQ_KEEP(sg[u]); }
+#pragma unroll
+                for (int u = 0; u < CB; u++) {
+                    const int j = j0 + 64 * u + l;
+                    const float nx = g[u][0], ny = g[u][1], nz = g[u][2];
+                    double val = (double)nx * xv[u][0] + (double)ny * xv[u][1];
+                    double rhs = gd[u] + (double)nx * (double)g[u][3] + (double)ny * (double)g[u][4];
+                    const double val3 = val + (double)nz * xv[u][2], rhs3 = rhs + (double)nz * (double)g[u][5];
+                    val = dim == 3 ? val3 : val;
+                    rhs = dim == 3 ? rhs3 : rhs;
+                    val = hsl[u] ? val - xv[u][3] : val;
+                    const double v = rhs - val;
+                    double wsq = ((double)nx * (double)nx + (double)ny * (double)ny + (dim == 3 ? (double)nz * (double)nz : 0.0)) * tn[u];
+                    wsq = hsl[u] ? wsq + sg[u] * sg[u] : wsq;
+                    double qv = v / sqrt(wsq > 0 ? wsq : 1.0);
+                    DQ_KEEP(qv);
+                    const double sc = (inm[u] & (v > VIOL_TOL) & (wsq > 0)) ? qv : -1.0;
+                    bc = sc > bs ? j : bc;
+                    bv = sc > bs ? v : bv;
+                    bs = sc > bs ? sc : bs;
+                }
             }
+            if (!ALL_CACHED)
             for (int s0 = Sc; s0 < n_slots; s0 += 64) {
                 const int s = s0 + l;
                 const bool in = s < n_slots;
