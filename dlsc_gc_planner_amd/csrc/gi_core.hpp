@@ -775,7 +775,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             w.each([&](int) { cold_flag[code - Kc] = on ? 1 : 0; });  // every lane, same byte, same value
         } else if (code < code_slack0) {
             const int s = (code - K) >> 1, side = (code - K) & 1;
-            if (s < Sc) {
+            if (ALL_CACHED || s < Sc) {
                 if (side) upd(fl_shi, s & 63, s >> 6);
                 else upd(fl_slo, s & 63, s >> 6);
             } else {
@@ -1087,7 +1087,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         if (ip < K) {
             uint32_t key = 0;
             float nn[3] = {0, 0, 0};
-            if (ip < Kc) {
+            if (ALL_CACHED || ip < Kc) {
                 const int own = ip & 63, u = ip >> 6;
 #pragma unroll
                 for (int uq = 0; uq < KU; uq++) {  // uniform selects, no branches
@@ -1115,7 +1115,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         } else if (ip < code_slack0) {
             const int s = (ip - K) >> 1, side = (ip - K) & 1;
             int sidx3[3], scoef3[3], bs;
-            if (s < Sc) {  // from the owner lane's registers
+            if (ALL_CACHED || s < Sc) {  // from the owner lane's registers
                 const int own = s & 63, u = s >> 6;
                 uint32_t pi = 0, pc = 0;
 #pragma unroll
