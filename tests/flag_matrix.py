@@ -30,7 +30,10 @@ FLAGS = ["", "-O2", "-O1", "-fno-unroll-loops",
          "-mllvm -vgpr-regalloc=basic", "-mllvm -sgpr-regalloc=basic",
          "-mllvm -amdgpu-enable-rewrite-partial-reg-uses=false", "-mllvm -amdgpu-use-aa-in-codegen=false",
          "-mllvm -amdgpu-opt-vgpr-liverange=false", "-mllvm -split-spill-mode=size", "-mllvm -split-spill-mode=speed",
-         "-mllvm -greedy-reverse-local-assignment", "-mllvm -join-liveintervals=false"]
+         "-mllvm -greedy-reverse-local-assignment", "-mllvm -join-liveintervals=false",
+         # scheduling strategies; iterative-ilp is the one the product is built with (__graft_entry__.HIPCC_FLAGS)
+         "-mllvm -amdgpu-sched-strategy=iterative-ilp", "-mllvm -amdgpu-sched-strategy=max-ilp",
+         "-mllvm -amdgpu-sched-strategy=iterative-maxocc", "-mllvm -amdgpu-sched-strategy=iterative-minreg"]
 
 CHECK = r'''
 import sys
