@@ -570,6 +570,10 @@ extern "C" int dlscqp_get_kernel_times(dlscqp_ctx *c, float *ms_out, int32_t cap
 static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t stream) {
     if (b->n_agents <= 0) return DLSCQP_SUCCESS;
     if (b->max_slack_obs < 0 || b->max_rows_per_agent < 0) { g_last_error = "negative size"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (c->kp.use_sfc && !b->sfc_boxes) {  // same rule as the host-buffer entry points: never plan without the corridor rows
+        g_last_error = "world_use_octomap is set but sfc_boxes is NULL";
+        return DLSCQP_ERR_INVALID_ARGUMENT;
+    }
     KernelChoice kc = select_kernel(c->kp, b->max_slack_obs, b->max_rows_per_agent);
     if (!kc.fn) {
         g_last_error = "reduced dimension above 128 (dim*f + M*max_slack_obs) is not supported";
@@ -930,9 +934,11 @@ static int plan_host(dlscqp_ctx *c, int32_t n_agents, const dlscqp_agent *agents
     dlscqp_rows_to_soa(rows, nrows, (float *)(h + o_nx), (float *)(h + o_ny), (float *)(h + o_nz), (float *)(h + o_px),
                        (float *)(h + o_py), (float *)(h + o_pz), (double *)(h + o_d), (uint32_t *)(h + o_key));
     if (use_sfc) std::memcpy(h + o_sfc, sfc_boxes, sizeof(float) * 6 * M * n_agents);
-    // status defaults: agents the kernel never reaches keep a failure code
     HIP_TRY(hipMemcpyAsync(d, h, in_bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(hipMemsetAsync(d + in_bytes, 0, total - in_bytes, c->stream));
+    // verdict defaults: an agent the kernel never reaches keeps a failure code (0x03030303 is not DLSCQP_OK), not "solved"
+    HIP_TRY(hipMemsetAsync(d + o_st, DLSCQP_NUMERICAL, 4 * (size_t)n_agents, c->stream));
+    HIP_TRY(hipMemsetAsync(d + o_gst, DLSCQP_NUMERICAL, 4 * (size_t)n_agents, c->stream));
     dlscqp_device_batch b;
     std::memset(&b, 0, sizeof b);
     b.n_agents = n_agents;

@@ -59,6 +59,7 @@ struct MemLayout {
     int oQ, oRp, oN, oX, oBlo, oBhi;  // in doubles
     int oDump;                        // 32 dump slots (lane & 31) for the lanes that have nothing to store: the spare row of Q
     int oFlag;                        // byte offset of the flags of rows beyond the register cache
+    int kmax;                         // most LSC rows of one agent the layout was sized for (dlscqp_device_batch.max_rows_per_agent)
     int bytes;
 };
 
@@ -71,6 +72,7 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
     const int cold_rows = kmax > 64 * KU ? kmax - 64 * KU : 0;
     const int cold_slots = kp.n_slots > 64 * SU ? kp.n_slots - 64 * SU : 0;
     L.nflag = cold_rows + 2 * cold_slots;
+    L.kmax = kmax;
     int o = 0;
     L.oQ = o; o += (L.r_max + 1) * L.ldq;  // + one row for the lanes beyond r (see "no divergence" below)
     L.oDump = L.oQ + L.r_max * L.ldq;      // that row doubles as the dump slots: its content is never used
@@ -205,6 +207,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     // (kmax <= 128, n_slots <= 256): it is compiled without the loops over rows and slots beyond them
     constexpr bool ALL_CACHED = KU == 2 && SU == 4;
     const int K = ALL_CACHED && K_rows > 64 * KU ? 64 * KU : K_rows;
+    // The caller's max_rows_per_agent picked this instantiation and sized the flag array: an agent with more rows than
+    // declared (or, in the all-cached instantiation, more rows or slots than the register caches hold) is not planned
+    // with some of its rows dropped -- it fails with DLSCQP_NUMERICAL.
+    const bool bad_shape = K_rows < 0 || K_rows > lay.kmax || (ALL_CACHED && (K_rows > 64 * KU || kp.n_slots > 64 * SU));
     const int dim = DIMS > 0 ? DIMS : kp.dim, f = FS > 0 ? FS : kp.f;
     const int M = MS > 0 ? MS : kp.M;
     constexpr int n1 = 6;  // n = 5 is the only degree the reference supports (traj_optimizer.cpp:209)
@@ -293,7 +299,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     // min t in [0, 1+1e-5] s.t. a_r t + b_r >= 0 (goal_optimizer.cpp:138-198), closed form.
     float goal[3] = {cg[0], cg[1], cg[2]};
     int goal_status = DLSCQP_OK;
-    if (do_goal) {
+    if (do_goal && !bad_shape) {
         float dx = cg[0] - wp[0], dy = cg[1] - wp[1], dz = cg[2] - wp[2];
         if (f32_norm3(dx, dy, dz) < SP_EPSILON_FLOAT) {  // goal_optimizer.cpp:12-14
             goal[0] = wp[0]; goal[1] = wp[1]; goal[2] = wp[2];
@@ -407,7 +413,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         DQ_MARK("DQ_EXIT_STORES");
         w.each([&](int l) {
             if (do_goal) {
-                if (l < 3 && out_goal && goal_status != DLSCQP_INFEASIBLE) out_goal[l] = pick3(goal, l);
+                if (l < 3 && out_goal && goal_status != DLSCQP_INFEASIBLE && goal_status != DLSCQP_NUMERICAL) out_goal[l] = pick3(goal, l);
                 if (l == 0 && out_goal_status) *out_goal_status = goal_status;
             }
             if (l == 0 && have_traj) {
@@ -417,6 +423,11 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             }
         });
     };
+    if (bad_shape) {  // uniform
+        goal_status = DLSCQP_NUMERICAL;
+        exit_stores(DLSCQP_NUMERICAL, do_traj != 0, 0, 0, 0, 0, false, 0.0);
+        return;
+    }
     if (do_goal && goal_status == DLSCQP_INFEASIBLE) {
         // the reference throws before trajOptimization is reached (traj_planner.cpp:491-496)
         exit_stores(DLSCQP_INFEASIBLE, do_traj != 0, 0, 0, 0, 0, false, 0.0);
@@ -1032,7 +1043,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         // slow as its slowest agent, and those were the infeasible ones).  Checked every second pricing pass from the
         // eighth on.
         n_price++;
-        if (nslk == 0 && n_price >= 8 && (n_price & 1) == 0) {
+        if (kp.wd_cut && nslk == 0 && n_price >= 8 && (n_price & 1) == 0) {
             if (n_price == 8) f_max = objective_upper_bound();  // first check of this agent
             const double f_now = objective();
             DQ_TRACE(4, f_now, f_max, (double)n_price, (double)q);

@@ -139,6 +139,7 @@ bool build_tables(const dlscqp_config &cfg, int dim, int M, int n, int phi, doub
                   std::string &err) {
     if (dim < 2 || dim > 3) { err = "Invalid output dimension, output_dim > 3"; return false; }  // :248
     if (!(n == 5 && phi == 3)) { err = "Currently, only n=5, phi=3 is available"; return false; }  // :209
+    if (cfg.phi_n < 1 || cfg.phi_n > phi) { err = "phi_n must be in [1, phi]"; return false; }
     if (M < 2 || M > 32) { err = "M must be in [2, 32]"; return false; }
     if (!(dt > 0)) { err = "dt must be positive"; return false; }
     const int N = n + 1, P = M * N;
@@ -156,6 +157,10 @@ bool build_tables(const dlscqp_config &cfg, int dim, int M, int n, int phi, doub
     kp.rsfc_mode = cfg.planner_mode == DLSCQP_PLANNER_RECIPROCALRSFC ? 1 : 0;
     kp.z_2d = cfg.world_z_2d;
     for (int k = 0; k < 3; k++) { kp.world_min[k] = cfg.world_min[k]; kp.world_max[k] = cfg.world_max[k]; }
+    // objective_upper_bound() of gi_core.hpp bounds c'Q_base c by the integral of jerk^2 only: with phi_n > 1 Q_base also
+    // holds the lower-derivative Gram terms (traj_optimizer.cpp:172-187) and the bound would not hold
+    kp.wd_cut = cfg.phi_n == 1 ? 1 : 0;
+    if (std::getenv("DLSCQP_DEBUG_NO_WD")) kp.wd_cut = 0;  // debugging aid: verdicts with and without the test must agree (tests)
     kp.vel_scale = dt / n;
     kp.acc_scale = dt * dt / (n * (n - 1));
 

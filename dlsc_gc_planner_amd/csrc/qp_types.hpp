@@ -30,6 +30,7 @@ struct KParams {
     int nb;        // entries of the per-agent bound table
     int has_comm, use_sfc, stop_mode, rsfc_mode;
     int max_iter;
+    int wd_cut;    // the weak-duality infeasibility test of gi_core.hpp is valid (its objective bound assumes phi_n = 1)
     // weights and constants (param.hpp)
     double dt;
     double w_c, w_t, w_s;

@@ -114,6 +114,8 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
     std::vector<uint32_t> key(nrows);
     int kmax = 0;
     for (int a = 0; a < n_agents; a++) kmax = std::max<int>(kmax, (int)(row_offsets[a + 1] - row_offsets[a]));
+    // test hook: a caller that understates dlscqp_device_batch.max_rows_per_agent
+    if (const char *ov = std::getenv("EMUL_KMAX")) kmax = std::atoi(ov);
     for (int64_t i = 0; i < nrows; i++) {
         nx[i] = rows[i].normal[0]; ny[i] = rows[i].normal[1]; nz[i] = rows[i].normal[2];
         px[i] = rows[i].point[0]; py[i] = rows[i].point[1]; pz[i] = rows[i].point[2];
@@ -136,7 +138,7 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
 #undef DQ_CASE
     }
     MemLayout lay = make_layout(kp, max_slack_obs, kmax, KUsel, SUsel, instance_n_in_lds(ic.id));
-    std::vector<unsigned char> mem(lay.bytes + 64);
+    std::vector<unsigned char> mem(lay.bytes + 64 + 4096);
     WaveCpu w;
     const char *rev = std::getenv("EMUL_REVERSE");
     w.reverse = rev && rev[0] == '1';

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 GOLDEN = os.path.join(HERE, "golden")
 
 NAMES = ["s64", "empty3d_M5", "maze2d_M10_sfc_comm", "forest3d_M10_dyn", "forest3d_M10_dyn4", "forest3d_M5_dyn", "lsc2d_M4_nostop",
-         "rsfc3d_M5_allslack", "crowd3d_M5_400rows", "long3d_M12_comm"]
+         "rsfc3d_M5_allslack", "crowd3d_M5_400rows", "long3d_M12_comm", "empty3d_M5_phin2", "maze2d_M10_phin3"]
 
 
 def load(name):

@@ -181,6 +181,14 @@ def save(name, cfg_kwargs, cfg, batch, ans):
 
 
 def main():
+    only = sys.argv[1:]  # names of randqp configurations: (re)generate just those golden batches
+    if only:
+        for name in only:
+            ck, gk = randqp.CONFIGS[name]
+            cfg = abi.make_config(**ck)
+            batch = randqp.random_batch(cfg, 24, seed=4242, **gk)
+            save(name, ck, cfg, batch, solve_batch_highs(cfg, batch))
+        return
     make_kat()
     make_missions()
     make_worlds()

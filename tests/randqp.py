@@ -132,4 +132,9 @@ CONFIGS = {
     "crowd3d_M5_400rows": (dict(dim=3, M=5), dict(max_rows=400, n_static_max=22, keep=0.75, tight=-0.15, infeasible_frac=0.05)),
     # M = 12: runtime-shape kernel, 102 reduced dimensions (two registers per vector), > 640 structured slots
     "long3d_M12_comm": (dict(dim=3, M=12, communication_range=3.0), dict(max_rows=100, tight=0.05)),
+    # phi_n > 1: Q_base also carries the acceleration (and velocity) Gram terms (traj_optimizer.cpp:172-187); the kernel's
+    # weak-duality infeasibility test, whose objective bound covers the jerk term only, must stay off (KParams::wd_cut)
+    "empty3d_M5_phin2": (dict(dim=3, M=5, phi_n=2), dict(max_rows=80, infeasible_frac=0.3)),
+    "maze2d_M10_phin3": (dict(dim=2, M=10, phi_n=3, communication_range=3.0, world_use_octomap=True,
+                              world_min=(-2.0, -0.3, 0.0), world_max=(6.0, 4.3, 2.5)), dict(max_rows=120, infeasible_frac=0.3)),
 }

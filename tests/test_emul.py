@@ -99,3 +99,73 @@ def test_empty_and_ragged_inputs():
     # zero agents
     z = E.plan_batch(cfg, b["agents"][:0], np.array([0]), rows[:0], None, 0, True)
     assert z["status"].shape == (0,)
+
+
+def test_understated_max_rows_fails_loudly_instead_of_dropping_rows():
+    """dlscqp_device_batch.max_rows_per_agent picks the instantiation and sizes the flag array; an agent with more rows
+    than declared must come back DLSCQP_NUMERICAL, never OK with part of its half-spaces ignored."""
+    cfg, b, _ = fixtures.load("crowd3d_M5_400rows")
+    k = np.diff(b["row_offsets"])
+    os.environ["EMUL_KMAX"] = "100"  # -> the all-cached instantiation (128 rows in registers)
+    try:
+        got = E.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], None, 0, True)
+    finally:
+        del os.environ["EMUL_KMAX"]
+    ref = E.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], None, 0, True)
+    over = k > 100
+    assert over.any() and (~over).any()
+    assert (got["status"][over] == abi.NUMERICAL).all() and (got["goal_status"][over] == abi.NUMERICAL).all()
+    assert np.array_equal(got["status"][~over], ref["status"][~over])
+    ok = ~over & (ref["status"] == abi.OK)
+    assert np.array_equal(got["x"][ok], ref["x"][ok])
+
+
+def _with_and_without_weak_duality(cfg, b):
+    with_cut = E.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], b["sfc"], b["max_slack_obs"], True)
+    os.environ["DLSCQP_DEBUG_NO_WD"] = "1"
+    try:
+        without = E.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], b["sfc"], b["max_slack_obs"], True)
+    finally:
+        del os.environ["DLSCQP_DEBUG_NO_WD"]
+    assert np.array_equal(with_cut["status"], without["status"])
+    ok = with_cut["status"] == abi.OK
+    assert np.array_equal(with_cut["x"][ok], without["x"][ok])
+    return with_cut, without
+
+
+@pytest.mark.parametrize("name", ["empty3d_M5", "maze2d_M10_sfc_comm", "crowd3d_M5_400rows"])
+def test_weak_duality_test_never_changes_a_verdict(name):
+    """The kernel's early infeasibility proof (f(x) above an upper bound of the objective) compiled in and out: same
+    verdicts, same solutions, on batches with many infeasible agents."""
+    ck, gk = randqp.CONFIGS[name]
+    cfg = abi.make_config(**ck)
+    b = randqp.random_batch(cfg, 40, seed=321, **dict(gk, infeasible_frac=0.5))
+    with_cut, _ = _with_and_without_weak_duality(cfg, b)
+    assert (with_cut["status"] == abi.INFEASIBLE).sum() >= 10
+
+
+def test_weak_duality_test_cuts_iterations_of_the_bench_workload_only():
+    """3 072 agents of the bench workload (BASELINE.json configs[1]): the test fires (fewer iterations, lower maximum) and
+    every verdict and solution stays what it is without it."""
+    from dlsc_gc_planner_amd import workloads
+    cfg = workloads.s64_config()
+    wl = workloads.generate(cfg, lambda a, ro, r, s: E.plan_batch(cfg, a, ro, r, s, 0, True), n_swarms=48, swarm_size=64, seed=2000)
+    b = dict(agents=wl["agents"], row_offsets=wl["row_offsets"], rows=wl["rows"], sfc=None, max_slack_obs=0)
+    with_cut, without = _with_and_without_weak_duality(cfg, b)
+    assert with_cut["iters"][:, 0].sum() < without["iters"][:, 0].sum()
+    assert with_cut["iters"][:, 0].max() < without["iters"][:, 0].max()
+    assert (with_cut["status"] == abi.INFEASIBLE).sum() >= 100
+
+
+def test_phi_n_is_validated_and_switches_the_weak_duality_test_off():
+    with pytest.raises(ValueError):
+        E.table_info(abi.make_config(dim=3, M=5, phi_n=0))
+    with pytest.raises(ValueError):
+        E.table_info(abi.make_config(dim=3, M=5, phi_n=4))
+    # with phi_n = 2 the jerk-only objective bound is not an upper bound: the infeasible agents take the long road
+    ck, gk = randqp.CONFIGS["empty3d_M5_phin2"]
+    cfg = abi.make_config(**ck)
+    b = randqp.random_batch(cfg, 30, seed=77, **dict(gk, infeasible_frac=0.5))
+    ref = O.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], None, 0, True)
+    got = E.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], None, 0, True)
+    assert np.array_equal(got["status"], ref["status"]) and (ref["status"] == abi.INFEASIBLE).sum() >= 8

@@ -292,3 +292,99 @@ def test_full_size_batch_properties(gpu_required, s64):
     assert np.array_equal(ref["status"], r1["status"][sel])
     oks = ref["status"] == abi.OK
     assert np.abs(ref["x"][oks] - r1["x"][sel][oks]).max() < 1e-7
+
+
+# ---- contract violations and verdict edge cases (round 2) ------------------------------------------------------
+def test_understated_max_rows_fails_loudly_on_the_device(gpu_required):
+    """An agent with more rows than dlscqp_device_batch.max_rows_per_agent declares is not planned with the surplus
+    half-spaces dropped: it comes back DLSCQP_NUMERICAL; the others are untouched."""
+    cfg, b, _ = fixtures.load("crowd3d_M5_400rows")
+    opt = BatchTrajOptimizer(cfg)
+    try:
+        db = opt.make_device_batch(b["agents"], b["row_offsets"], b["rows"], None, 0, want_f64=True)
+        db.launch()
+        ref = db.results()
+        k = np.diff(b["row_offsets"])
+        for declared in (100, 200, 300):  # all-cached instantiation / register cache + HBM scan with a short flag array
+            db.c.max_rows_per_agent = declared
+            db.launch()
+            got = db.results()
+            over = k > declared
+            assert over.any()
+            assert (got["status"][over] == abi.NUMERICAL).all() and (got["goal_status"][over] == abi.NUMERICAL).all()
+            assert np.array_equal(got["status"][~over], ref["status"][~over])
+            ok = ~over & (ref["status"] == abi.OK)
+            assert np.array_equal(got["x"][ok], ref["x"][ok])
+    finally:
+        opt.close()
+
+
+def test_device_entry_rejects_missing_corridor_boxes(gpu_required):
+    """world_use_octomap = 1 and sfc_boxes = NULL: the device entry refuses like the host entry does (it used to plan
+    without the corridor rows and report OK)."""
+    from dlsc_gc_planner_amd.planner import DlscqpError
+    cfg, b, _ = fixtures.load("maze2d_M10_sfc_comm")
+    opt = BatchTrajOptimizer(cfg)
+    try:
+        db = opt.make_device_batch(b["agents"], b["row_offsets"], b["rows"], None, 0)
+        with pytest.raises(DlscqpError, match="sfc_boxes is NULL"):
+            db.launch()
+        with pytest.raises(DlscqpError, match="sfc_boxes is NULL"):
+            opt.plan(b["agents"], b["row_offsets"], b["rows"], None, 0, True, True)
+    finally:
+        opt.close()
+
+
+def test_phi_n_above_one_keeps_verdict_parity(gpu_required):
+    """phi_n = 2, 3: Q_base carries lower-derivative terms, the kernel's weak-duality test must be off; half of the agents
+    are infeasible."""
+    from dlsc_gc_planner_amd.planner import DlscqpError
+    with pytest.raises(DlscqpError, match="phi_n"):
+        BatchTrajOptimizer(abi.make_config(phi_n=0))
+    for name in ("empty3d_M5_phin2", "maze2d_M10_phin3"):
+        ck, gk = randqp.CONFIGS[name]
+        cfg = abi.make_config(**ck)
+        b = randqp.random_batch(cfg, 128, seed=4711, **dict(gk, infeasible_frac=0.5))
+        opt = BatchTrajOptimizer(cfg)
+        try:
+            got = opt.plan(b["agents"], b["row_offsets"], b["rows"], b["sfc"], 0, True, True)
+        finally:
+            opt.close()
+        ref = oracle_lib.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], b["sfc"], 0, True)
+        assert _compare(cfg, got, ref) >= 20
+        assert (ref["status"] == abi.INFEASIBLE).sum() >= 30
+
+
+def test_weak_duality_test_never_changes_a_verdict_on_the_device(gpu_required):
+    """32 768 agents of the bench workload with the early infeasibility proof on and off (DLSCQP_DEBUG_NO_WD is read when
+    the context is created): identical verdicts and solutions, fewer iterations with it."""
+    import os
+    cfg = workloads.s64_config()
+    opt = BatchTrajOptimizer(cfg)
+
+    def solver(agents, ro, rows, sfc):
+        return opt.plan(agents, ro, rows, sfc, 0, True, True)
+
+    wl = workloads.generate(cfg, solver, n_swarms=512, swarm_size=64, seed=2000)
+    try:
+        db = opt.make_device_batch(wl["agents"], wl["row_offsets"], wl["rows"], None, 0, want_f64=True, want_iters=True)
+        db.launch()
+        a = db.results()
+    finally:
+        opt.close()
+    os.environ["DLSCQP_DEBUG_NO_WD"] = "1"
+    try:
+        opt2 = BatchTrajOptimizer(cfg)
+    finally:
+        del os.environ["DLSCQP_DEBUG_NO_WD"]
+    try:
+        db2 = opt2.make_device_batch(wl["agents"], wl["row_offsets"], wl["rows"], None, 0, want_f64=True, want_iters=True)
+        db2.launch()
+        c = db2.results()
+    finally:
+        opt2.close()
+    assert np.array_equal(a["status"], c["status"])
+    ok = a["status"] == abi.OK
+    assert np.array_equal(a["x"][ok], c["x"][ok])
+    assert a["iters"][:, 0].max() < c["iters"][:, 0].max() and a["iters"][:, 0].sum() < c["iters"][:, 0].sum()
+    assert (a["status"] == abi.INFEASIBLE).sum() > 1000
