@@ -228,6 +228,21 @@ def key_of(m, i, slack, dyn):
     return (m & 0xFF) | ((i & 0xF) << 8) | ((dyn & 1) << 12) | (s << 16)
 
 
+class MapfConfig(C.Structure):  # dlscqp_mapf_config
+    _fields_ = [("world_dimension", C.c_int32), ("M", C.c_int32), ("world_use_octomap", C.c_int32), ("reserved_", C.c_int32),
+                ("dt", C.c_double), ("grid_resolution", C.c_double), ("world_resolution", C.c_double), ("world_z_2d", C.c_double),
+                ("communication_range", C.c_double), ("agent_radius", C.c_double), ("agent_downwash", C.c_double),
+                ("obs_uncertainty_horizon", C.c_double), ("world_min", C.c_double * 3), ("world_max", C.c_double * 3)]
+
+
+class MapfStepArgs(C.Structure):  # dlscqp_mapf_step_args
+    _fields_ = [("n_agents", C.c_int32), ("n1", C.c_int32), ("position", C.c_void_p), ("start_point", C.c_void_p),
+                ("desired_goal", C.c_void_p), ("current_goal", C.c_void_p), ("next_waypoint", C.c_void_p), ("plans", C.c_void_p),
+                ("n_obs", C.c_int32), ("reserved_", C.c_int32), ("obs_position", C.c_void_p), ("obs_velocity", C.c_void_p),
+                ("obs_radius", C.c_void_p), ("obs_max_acc", C.c_void_p), ("alert", C.c_void_p), ("out_desired", C.c_void_p),
+                ("out_group", C.c_void_p)]
+
+
 _LIB = None
 
 
@@ -278,6 +293,12 @@ def load_library():
     lib.dlscqp_set_timing.restype = C.c_int
     lib.dlscqp_get_kernel_times.argtypes = [vp, vp, C.c_int32, P(C.c_int32)]
     lib.dlscqp_get_kernel_times.restype = C.c_int
+    lib.dlscqp_mapf_create.argtypes = [P(MapfConfig), vp, C.c_int32, P(vp)]
+    lib.dlscqp_mapf_create.restype = C.c_int
+    lib.dlscqp_mapf_destroy.argtypes = [vp]
+    lib.dlscqp_mapf_destroy.restype = None
+    lib.dlscqp_mapf_step.argtypes = [vp, P(MapfStepArgs)]
+    lib.dlscqp_mapf_step.restype = C.c_int
     _LIB = lib
     return lib
 
@@ -287,5 +308,5 @@ EXPORTED_SYMBOLS = [
     "dlscqp_lds_bytes", "dlscqp_solve_batch", "dlscqp_goal_batch", "dlscqp_plan_batch",
     "dlscqp_plan_batch_device", "dlscqp_generate_lsc_device", "dlscqp_rows_to_soa", "dlscqp_set_timing",
     "dlscqp_get_kernel_times", "dlscqp_world_create", "dlscqp_world_destroy", "dlscqp_generate_sfc_device",
-    "dlscqp_advance_device",
+    "dlscqp_advance_device", "dlscqp_mapf_create", "dlscqp_mapf_destroy", "dlscqp_mapf_step",
 ]

@@ -331,6 +331,69 @@ class ClosedLoop:
         return float(dist.min() / (2 * self.radius))
 
 
+class MapfWaypoints:
+    """The reference's decentralised waypoint planner (MultiSyncSimulator::decentralizedMAPP: communication groups, grid
+    map, PIBT, waypoint update rules; multi_sync_simulator.cpp:308-466, grid_based_planner.cpp, src/mapf/pibt.cpp) through
+    the C ABI (dlscqp_mapf_*, csrc/grid_mapf.cpp).  Host only: numpy arrays in, next_waypoint updated in place."""
+
+    def __init__(self, cfg, boxes, world_resolution, grid_resolution, start, goal, radius, downwash, uncertainty_horizon=1.0):
+        import ctypes as C
+        self.C = C
+        self.lib = abi.load_library()
+        mc = abi.MapfConfig()
+        mc.world_dimension, mc.M, mc.world_use_octomap = cfg.world_dimension, cfg.M, int(cfg.world_use_octomap)
+        mc.dt, mc.grid_resolution, mc.world_resolution, mc.world_z_2d = cfg.dt, grid_resolution, world_resolution, cfg.world_z_2d
+        mc.communication_range, mc.agent_radius, mc.agent_downwash = cfg.communication_range, radius, downwash
+        mc.obs_uncertainty_horizon = uncertainty_horizon
+        for k in range(3):
+            mc.world_min[k], mc.world_max[k] = cfg.world_min[k], cfg.world_max[k]
+        b = np.ascontiguousarray(boxes if boxes is not None else np.zeros((0, 6)), dtype=np.float64).reshape(-1, 6)
+        self.h = C.c_void_p()
+        rc = self.lib.dlscqp_mapf_create(C.byref(mc), b.ctypes.data if len(b) else None, len(b), C.byref(self.h))
+        if rc != abi.SUCCESS:
+            raise ValueError("dlscqp_mapf_create failed (%d)" % rc)
+        self.n1 = cfg.n + 1
+        self.start = np.ascontiguousarray(start, dtype=np.float32)
+        self.goal = np.ascontiguousarray(goal, dtype=np.float32)
+        self.N = len(self.start)
+        self.desired = np.zeros((self.N, 3), np.float32)
+        self.group = np.zeros(self.N, np.int32)
+
+    def close(self):
+        if self.h:
+            self.lib.dlscqp_mapf_destroy(self.h)
+            self.h = self.C.c_void_p()
+
+    def step(self, position, current_goal, next_waypoint, plans=None, dyn=None, alert=None):
+        """position, current_goal [N,3] float32; next_waypoint [N,3] float32, updated IN PLACE; plans [N,M,n+1,3] float32
+        (the plans of the previous step) or None before the first plan; dyn: None or dict(position, velocity [D,3] float32,
+        radius, max_acc [D]).  Returns 0, or 1 if the planner failed for some group."""
+        a = abi.MapfStepArgs()
+        keep = [np.ascontiguousarray(position, dtype=np.float32), np.ascontiguousarray(current_goal, dtype=np.float32)]
+        assert next_waypoint.dtype == np.float32 and next_waypoint.flags.c_contiguous
+        a.n_agents, a.n1 = self.N, self.n1
+        a.position, a.current_goal = keep[0].ctypes.data, keep[1].ctypes.data
+        a.start_point, a.desired_goal = self.start.ctypes.data, self.goal.ctypes.data
+        a.next_waypoint = next_waypoint.ctypes.data
+        if plans is not None:
+            keep.append(np.ascontiguousarray(plans, dtype=np.float32))
+            a.plans = keep[-1].ctypes.data
+        if dyn is not None and len(dyn["radius"]):
+            dp, dv = np.ascontiguousarray(dyn["position"], np.float32), np.ascontiguousarray(dyn["velocity"], np.float32)
+            dr, da = np.ascontiguousarray(dyn["radius"], np.float64), np.ascontiguousarray(dyn["max_acc"], np.float64)
+            keep += [dp, dv, dr, da]
+            a.n_obs = len(dr)
+            a.obs_position, a.obs_velocity, a.obs_radius, a.obs_max_acc = dp.ctypes.data, dv.ctypes.data, dr.ctypes.data, da.ctypes.data
+            if alert is not None:
+                keep.append(np.ascontiguousarray(alert, np.uint8))
+                a.alert = keep[-1].ctypes.data
+        a.out_desired, a.out_group = self.desired.ctypes.data, self.group.ctypes.data
+        rc = self.lib.dlscqp_mapf_step(self.h, self.C.byref(a))
+        if rc < 0:
+            raise ValueError("dlscqp_mapf_step failed (%d)" % rc)
+        return rc
+
+
 class GridWaypoints:
     """Host-side stand-in for the reference's grid-based waypoint planner (grid_based_planner.cpp; SURVEY row N4 stays on
     the host): a 2-D grid of `grid_resolution` cells over the world, a cell is blocked if an obstacle box comes within the

@@ -316,6 +316,57 @@ typedef struct dlscqp_sfc_gen {
 } dlscqp_sfc_gen;
 int dlscqp_generate_sfc_device(dlscqp_ctx *ctx, const dlscqp_world *world, const dlscqp_sfc_gen *gen, void *stream);
 
+/* ---- the decentralised waypoint planner (host only, no device work) -----------------------------
+ * MultiSyncSimulator::decentralizedMAPP (multi_sync_simulator.cpp:308-466): communication groups, per group
+ * GridBasedPlanner::planMAPF (grid_based_planner.cpp:64-92; PIBT, src/mapf/pibt.cpp) on the grid of `grid_resolution`
+ * metres, then the rules that let an agent move its next_waypoint to the next node of its path.  Graph search on a few
+ * hundred nodes (35 us per group in the reference's log): it stays on the host, the device path reads its result from
+ * the agent records (dlscqp_agent.next_waypoint).  A context needs no GPU. */
+typedef struct dlscqp_mapf dlscqp_mapf;
+typedef struct dlscqp_mapf_config {
+    int32_t world_dimension;        /* param.world_dimension                                        */
+    int32_t M;                      /* param.M                                                      */
+    int32_t world_use_octomap;      /* param.world_use_octomap: static obstacles block grid nodes    */
+    int32_t reserved_;
+    double dt;                      /* param.dt                                                     */
+    double grid_resolution;         /* param.grid_resolution                                        */
+    double world_resolution;        /* param.world_resolution (octomap cell size)                   */
+    double world_z_2d;              /* param.world_z_2d                                             */
+    double communication_range;     /* param.communication_range (< 0: unlimited)                   */
+    double agent_radius;            /* mission.agents[0].radius (the reference uses agent 0's)       */
+    double agent_downwash;          /* mission.agents[0].downwash: vertical grid step = resolution * downwash */
+    double obs_uncertainty_horizon; /* param.obs_uncertainty_horizon                                */
+    double world_min[3], world_max[3];
+} dlscqp_mapf_config;
+
+/* boxes: the rows of the world CSV (centre x,y,z, size x,y,z), as for dlscqp_world_create; may be NULL / 0. */
+int dlscqp_mapf_create(const dlscqp_mapf_config *cfg, const double *boxes, int32_t n_boxes, dlscqp_mapf **out);
+void dlscqp_mapf_destroy(dlscqp_mapf *mapf);
+
+typedef struct dlscqp_mapf_step_args {
+    int32_t n_agents;
+    int32_t n1;                  /* n + 1 control points per segment (layout of `plans`)                         */
+    const float *position;       /* [n][3] AgentManager::getCurrentPosition                                       */
+    const float *start_point;    /* [n][3] mission start points                                                   */
+    const float *desired_goal;   /* [n][3] desired_goal_point                                                     */
+    const float *current_goal;   /* [n][3] current_goal_point (the goal LP's last result)                         */
+    float *next_waypoint;        /* [n][3] in/out                                                                 */
+    const float *plans;          /* [n][M][n1][3] the plans of the previous step (getTraj()), NULL before the first */
+    int32_t n_obs;               /* dynamic obstacles (obstacle_generator.getObstacles())                         */
+    int32_t reserved_;
+    const float *obs_position;   /* [n_obs][3] */
+    const float *obs_velocity;   /* [n_obs][3] */
+    const double *obs_radius;    /* [n_obs]    */
+    const double *obs_max_acc;   /* [n_obs]    */
+    const uint8_t *alert;        /* optional [n][n_obs]: obstacle is in the agent's collision alert (TrajOptResult) */
+    float *out_desired;          /* optional [n][3]: path[1] of every agent (before the update rules)             */
+    int32_t *out_group;          /* optional [n]: communication group index                                       */
+} dlscqp_mapf_step_args;
+
+/* One decentralizedMAPP pass: next_waypoint is updated in place.  Returns DLSCQP_SUCCESS, 1 if the planner failed for
+ * some group (its waypoints stay as they are, like the reference's "MAPF failed"), or a negative error code. */
+int dlscqp_mapf_step(dlscqp_mapf *mapf, const dlscqp_mapf_step_args *args);
+
 /* Host helper: convert n_rows AoS rows to the SoA arrays above (host memory, caller-owned). */
 void dlscqp_rows_to_soa(const dlscqp_lsc_row *rows, int64_t n_rows, float *nx, float *ny,
                         float *nz, float *px, float *py, float *pz, double *d, uint32_t *key);

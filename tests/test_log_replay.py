@@ -36,12 +36,23 @@ def test_oracle_reproduces_the_whole_logged_run():
     assert int((ok & (out["kat"]["goal_t"] > 1e-9)).sum()) >= 400  # goal LPs that stop short of the waypoint
 
 
-def test_replay_without_anchoring_stays_on_the_log_for_34_seconds():
-    """No help from the log at all after t = 0 except the waypoints: ten agents, 171 steps of closed loop through the maze.
-    The replay drifts from the reference's run only by the accumulated last-digit differences between CPLEX's and the
-    oracle's solutions -- it never leaves it (any modelling difference in the half-spaces, the corridor boxes, the LP or
-    the QP would, within a few steps)."""
-    out = R.run(anchor=False)
+def test_waypoint_planner_reproduces_every_waypoint_of_the_logged_run():
+    """Row N4 (csrc/grid_mapf.cpp: communication groups, grid map, PIBT with the reference's shuffle, waypoint update
+    rules) next to the replay: at each of the 171 steps it is handed the replay's state and must return the waypoint
+    that the log pins for each of the ten agents."""
+    out = R.run()
+    assert out["wp_diff"].shape == (171, 10) and not out["wp_diff"].any(), np.argwhere(out["wp_diff"])[:5]
+    moved = (np.abs(np.diff(out["kat"]["waypoints"], axis=0)).max(axis=2) > 1e-6).sum()
+    assert moved >= 100  # the waypoints do move: about one node per agent every two seconds
+
+
+def test_closed_loop_from_the_mission_alone_stays_on_the_log_for_34_seconds():
+    """Nothing but the mission and the world file: waypoints from the product's planner (N4), half-spaces (N1), corridor
+    boxes (N2), goal LP and QP from the oracle, state := plan(dt) -- ten agents through the maze for 171 steps.  The run
+    drifts from the reference's only by the accumulated last-digit differences between CPLEX's and the oracle's solutions
+    and never leaves it (any modelling difference in one of the stages would, within a few steps)."""
+    out = R.run(anchor=False, own_waypoints=True)
+    assert not out["wp_diff"].any()
     assert out["score"].max() < 10.0, out["score"].max()  # i.e. positions within ~3e-5 m of the log after 34 s
     assert (out["score"] <= 1.0).sum() >= 800
 
