@@ -148,11 +148,17 @@ class ClosedLoop:
                                                dyn=dyn)
         self.world = world
         self.sfc = None
+        self.comm_neighbours = False
         if world is not None:
             wmin, wmax = np.array(cfg.world_min[:], np.float32), np.array(cfg.world_max[:], np.float32)
             self.sfc = self.opt.make_sfc_generator(world["boxes"], world["resolution"], wmin, wmax, np.full(N, radius),
                                                    np.full(N, max_vel), world["grid_resolution"], device=device)
-            if world.get("pibt", False):
+            if world.get("pibt", False) == "reference":
+                # the reference's own planner (row N4, csrc/grid_mapf.cpp) and its communication-range neighbour lists
+                self.grid = MapfWaypoints(cfg, world["boxes"], world["resolution"], world["grid_resolution"], np.asarray(start, np.float32),
+                                          np.asarray(goal, np.float32), radius, downwash, world.get("uncertainty_horizon", 1.0))
+                self.comm_neighbours = cfg.communication_range > 0
+            elif world.get("pibt", False):
                 self.grid = PibtWaypoints(world["boxes"], world["grid_resolution"], wmin, wmax, np.asarray(start, np.float64),
                                           np.asarray(goal, np.float64), radius)
             else:
@@ -204,6 +210,18 @@ class ClosedLoop:
     def _waypoints_host(self):
         """Waypoints from the host-side grid planner stand-ins (worlds with static obstacles)."""
         torch, cfg = self.torch, self.cfg
+        if isinstance(self.grid, MapfWaypoints):
+            # MultiSyncSimulator::decentralizedMAPP: positions, sub-goals, previous plans in; next_waypoint updated in place
+            pos = self.pos.cpu().numpy()
+            wp = np.ascontiguousarray(self.wp.cpu().numpy())
+            gdyn = None
+            if self.D:
+                gdyn = dict(position=self.dyn_pos.cpu().numpy(), velocity=self.dyn_vel.cpu().numpy(), radius=self.dyn["radius"],
+                            max_acc=self.dyn["max_acc"])
+            self.mapf_rc = self.grid.step(pos, self.cur_goal.cpu().numpy(), wp, self.plans.cpu().numpy() if self.seq > 0 else None, dyn=gdyn)
+            if self.comm_neighbours:
+                self._set_comm_neighbours(pos)
+            return torch.from_numpy(wp)
         if isinstance(self.grid, PibtWaypoints):
             anchors = torch.cat([self.pos[:, None, :], self.plans[:, :, 0, :], self.plans[:, -1:, -1, :]], dim=1) \
                 if self.seq > 0 else self.pos[:, None, :]
@@ -214,6 +232,20 @@ class ClosedLoop:
             return torch.from_numpy(self.grid.step(self.cur_goal.cpu().numpy(), anchors.cpu().numpy(),
                                                    float(cfg.communication_range), dyn=gdyn))
         return torch.from_numpy(self.grid.next_waypoints(self.pos.cpu().numpy()))
+
+    def _set_comm_neighbours(self, pos):
+        """broadcastMsgs (multi_sync_simulator.cpp:482-503): agent qi is told about the agents within communication range
+        (L-infinity) of it, by id; the half-space generator and the QP launch get this step's lists and row counts."""
+        N, r = self.N, float(self.cfg.communication_range)
+        d = np.abs(pos[:, None, :] - pos[None, :, :]).max(axis=2)
+        keep = ~(d > np.float32(r))
+        np.fill_diagonal(keep, False)
+        offs = np.concatenate([[0], np.cumsum(keep.sum(axis=1))])
+        ids = np.concatenate([np.nonzero(keep[a])[0] for a in range(N)]) if N > 1 else np.zeros(0, np.int32)
+        ro = self.gen.set_neighbours(offs, ids)
+        self.ro32.copy_(self.torch.from_numpy(ro.astype(np.int32)))
+        self.batch.c.max_rows_per_agent = int(np.diff(ro).max())
+        self.n_neighbours = keep.sum(axis=1)
 
     def _body(self, first):
         """The device work of one step: half-spaces, corridors, goal LP + QP, then dlscqp_advance_device (fail-safe,

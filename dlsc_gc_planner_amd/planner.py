@@ -326,6 +326,22 @@ class LscGenerator:
         self.c = g
         self.n_total = n_total
 
+    def set_neighbours(self, nbr_offsets, nbr_ids):
+        """Replace the neighbour lists (broadcastMsgs hands every agent the agents within communication range, which changes
+        from step to step: multi_sync_simulator.cpp:482-503).  The total must fit the capacity the generator was made with;
+        row_offsets / n_rows follow.  Returns the new row_offsets (host)."""
+        nbr_offsets = np.ascontiguousarray(nbr_offsets, dtype=np.int32)
+        nbr_ids = np.ascontiguousarray(nbr_ids, dtype=np.int32)
+        assert len(nbr_offsets) == self.n_local + 1 and len(nbr_ids) <= len(self.t["nbr_ids"])
+        pairs = nbr_offsets.astype(np.int64) + self.n_dyn * np.arange(self.n_local + 1)
+        assert self.per * int(pairs[-1]) + 64 <= len(self.soa["d"])
+        self.t["nbr_offsets"].copy_(self.torch.from_numpy(nbr_offsets))
+        if len(nbr_ids):
+            self.t["nbr_ids"][:len(nbr_ids)].copy_(self.torch.from_numpy(nbr_ids))
+        self.n_rows = self.per * int(pairs[-1])
+        self.row_offsets = self.per * pairs
+        return self.row_offsets
+
     def generate(self, goals, plans=None, position=None, velocity=None, stream=None, dyn_position=None, dyn_velocity=None):
         """goals [n_total,3] f32 and either plans [n_total,M,n+1,3] f32 (previous plans) or position/velocity
         (first replanning step); dyn_position / dyn_velocity [n_dyn,3] f32 when the generator has dynamic obstacles:
