@@ -195,13 +195,17 @@ def _neighbours(pos, J, group):
 
 
 def generate(cfg, solver, n_swarms=1, swarm_size=64, seed=2000, steps=6, infeasible_frac=0.05,
-             waypoint_ahead=5.0):
+             waypoint_ahead=5.0, keep=1, spread=1.0):
     """Closed-loop synthetic workload: `n_swarms` independent swarms of `swarm_size` agents.
 
     solver(agents, row_offsets, rows, sfc) -> dict(goal [N,3] f32, ctrl [N,M,6,3] f32,
     status [N] i32, goal_status [N] i32) plans one batch (goal LP + trajectory QP).
     Returns the inputs of replanning step `steps` (0-based) as a dict with agents, row_offsets,
-    rows, sfc (None), K (rows per agent) and the bookkeeping needed to continue the loop."""
+    rows, sfc (None), K (rows per agent) and the bookkeeping needed to continue the loop.
+    keep > 1: out["history"] holds the inputs of the last `keep` consecutive replanning steps (oldest first, the returned
+    step last) -- the same agents 0.2 s apart, so that a launch order derived from one step's iteration counts is the hint
+    a closed loop really has for the next step.  spread < 1 packs every swarm into that fraction of the arena (denser
+    traffic: more active half-spaces per agent)."""
     rng = np.random.default_rng(seed)
     dim, M = cfg.world_dimension, cfg.M
     N = n_swarms * swarm_size
@@ -211,7 +215,7 @@ def generate(cfg, solver, n_swarms=1, swarm_size=64, seed=2000, steps=6, infeasi
     side = int(np.ceil(np.sqrt(swarm_size)))
     gx, gy = np.meshgrid(np.arange(side), np.arange(side), indexing="ij")
     cell = np.stack([gx.ravel(), gy.ravel()], 1)[:swarm_size]
-    pitch = (wmax[:2] - wmin[:2]) / side
+    pitch = (wmax[:2] - wmin[:2]) / side * spread
     pos = np.zeros((N, 3))
     goal_final = np.zeros((N, 3))
     for s in range(n_swarms):
@@ -234,6 +238,7 @@ def generate(cfg, solver, n_swarms=1, swarm_size=64, seed=2000, steps=6, infeasi
     J = 5 if swarm_size > 5 else max(swarm_size - 1, 1)
     seg_sel = [list(range(M))] * min(J, 4) + ([[M - 2, M - 1]] if J == 5 else [])
     out = None
+    history = []
     lp_failed = np.zeros(N, bool)
     for step in range(steps + 1):
         init = plan if step == 0 else _shift_plan(plan)
@@ -254,6 +259,8 @@ def generate(cfg, solver, n_swarms=1, swarm_size=64, seed=2000, steps=6, infeasi
         agents["max_vel"], agents["max_acc"], agents["radius"], agents["nominal_velocity"] = 1.0, 2.0, radius, 1.0
         out = dict(agents=agents, row_offsets=row_offsets, rows=rows, sfc=None,
                    K=int(row_offsets[1] - row_offsets[0]) if N else 0, step=step)
+        if step > steps - keep:
+            history.append(out)
         if step == steps:
             break
         res = solver(agents, row_offsets, rows, None)
@@ -274,25 +281,28 @@ def generate(cfg, solver, n_swarms=1, swarm_size=64, seed=2000, steps=6, infeasi
         v1 = (c2 - c1) * s1
         vel = v0
         acc = (v1 - v0) * s2
-    # deliberately infeasible subset: two opposing half-spaces on one control point
+    # deliberately infeasible subset: two opposing half-spaces on one control point (the same agents in every kept step)
     n_bad = int(round(infeasible_frac * N))
     bad = np.zeros(N, bool)
     if n_bad > 0 and out["K"] >= 2:
         bad_ids = rng.choice(N, n_bad, replace=False)
         bad[bad_ids] = True
         K = out["K"]
-        rows = out["rows"].reshape(N, K)
-        for a in bad_ids:
-            r0, r1 = rows[a, K - 1].copy(), rows[a, K - 2].copy()
-            nrm = np.array([0.6, 0.0, 0.8], np.float32)
-            r1["normal"], r0["normal"] = nrm, -nrm
-            r1["point"] = r0["point"] = out["agents"]["position"][a]
-            r1["d"] = r0["d"] = 0.25
-            r1["m"] = r0["m"] = M - 2
-            r1["i"] = r0["i"] = 2
-            rows[a, K - 1], rows[a, K - 2] = r0, r1
-        out["rows"] = np.ascontiguousarray(rows.reshape(-1))
-    out["infeasible_mask"] = bad
+        for o in history:
+            rows = o["rows"].reshape(N, K)
+            for a in bad_ids:
+                r0, r1 = rows[a, K - 1].copy(), rows[a, K - 2].copy()
+                nrm = np.array([0.6, 0.0, 0.8], np.float32)
+                r1["normal"], r0["normal"] = nrm, -nrm
+                r1["point"] = r0["point"] = o["agents"]["position"][a]
+                r1["d"] = r0["d"] = 0.25
+                r1["m"] = r0["m"] = M - 2
+                r1["i"] = r0["i"] = 2
+                rows[a, K - 1], rows[a, K - 2] = r0, r1
+            o["rows"] = np.ascontiguousarray(rows.reshape(-1))
+    for o in history:
+        o["infeasible_mask"] = bad
+    out["history"] = history
     return out
 
 

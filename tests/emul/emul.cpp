@@ -9,7 +9,10 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <chrono>
 #include <string>
+#include <thread>
 #include <vector>
 
 #define DQ_FN inline
@@ -29,7 +32,9 @@ struct WaveCpu {
     template <class T>
     struct Reg {
         T v[64];
+#ifndef EMUL_NO_POISON
         Reg() { std::memset(v, 0xCD, sizeof v); }  // poison: a lane value nobody wrote must not be used
+#endif
         T &at(int l) { return v[l]; }
         const T &at(int l) const { return v[l]; }
     };
@@ -91,6 +96,16 @@ struct WaveCpu {
 };
 
 }  // namespace
+
+static void dlscqp_rows_to_soa_host(const dlscqp_lsc_row *rows, int64_t n, float *nx, float *ny, float *nz, float *px, float *py,
+                                    float *pz, double *d, uint32_t *key) {
+    for (int64_t i = 0; i < n; i++) {
+        nx[i] = rows[i].normal[0]; ny[i] = rows[i].normal[1]; nz[i] = rows[i].normal[2];
+        px[i] = rows[i].point[0]; py[i] = rows[i].point[1]; pz[i] = rows[i].point[2];
+        d[i] = rows[i].d;
+        key[i] = DLSCQP_KEY(rows[i].m, rows[i].i, rows[i].slack, rows[i].flags & DLSCQP_ROW_DYNAMIC);
+    }
+}
 
 extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dlscqp_agent *agents,
                                const int64_t *row_offsets, const dlscqp_lsc_row *rows, const float *sfc,
@@ -257,5 +272,77 @@ extern "C" int emul_generate_sfc(const dlscqp_config *cfg, const double *boxes, 
                                   gen->waypoints + 3 * (size_t)a, sfcs);
         if (gen->out_code) gen->out_code[a] = code;
     }
+    return 0;
+}
+
+
+// CPU baseline of bench.py (cpu_baseline.kind = "port"): the kernel's own algorithm -- this lane-serial build of gi_core.hpp,
+// compiled -O3 -march=native without the test build's poisoning (libdlscqp_cpu.so, see Makefile) -- on `n_threads` native
+// threads, each walking its own contiguous range of the batch again and again until `seconds` have passed.  Returns the
+// number of agent-QPs (goal LP + trajectory QP) planned and the elapsed time.
+extern "C" int emul_throughput(const dlscqp_config *cfg, int n_agents, const dlscqp_agent *agents, const int64_t *row_offsets,
+                               const dlscqp_lsc_row *rows, const float *sfc, int max_slack_obs, int n_threads, double seconds,
+                               int64_t *n_done, double *elapsed_s) {
+    using namespace dlscqp;
+    HostTables tb;
+    std::string err;
+    if (!build_tables(*cfg, cfg->world_dimension, cfg->M, cfg->n, cfg->phi, cfg->dt, tb, err)) return -1;
+    KParams kp = tb.kp;
+    kp.tabN = tb.tabN.data(); kp.tabX0s = tb.tabX0s.data(); kp.tabX0g = tb.tabX0g.data();
+    kp.tabNN = tb.tabNN.data(); kp.tabSIW = tb.tabSIW.data(); kp.slots = tb.slots.data();
+    const int64_t nrows = row_offsets[n_agents];
+    std::vector<float> nx(nrows), ny(nrows), nz(nrows), px(nrows), py(nrows), pz(nrows);
+    std::vector<double> d(nrows);
+    std::vector<uint32_t> key(nrows);
+    int kmax = 0;
+    for (int a = 0; a < n_agents; a++) kmax = std::max<int>(kmax, (int)(row_offsets[a + 1] - row_offsets[a]));
+    dlscqp_rows_to_soa_host(rows, nrows, nx.data(), ny.data(), nz.data(), px.data(), py.data(), pz.data(), d.data(), key.data());
+    RowsView rv{nx.data(), ny.data(), nz.data(), px.data(), py.data(), pz.data(), d.data(), key.data()};
+    const InstanceChoice ic = select_instance(kp, max_slack_obs, kmax, false);
+    if (ic.id < 0) return -2;
+    typedef void (*fn_t)(const WaveCpu &, const KParams &, const MemLayout &, unsigned char *, const dlscqp_agent *,
+                         const RowsView &, int, int, const float *, int, int, int, float *, int *, float *, double *,
+                         double *, double *, int *, int *);
+    fn_t fn = nullptr;
+    switch (ic.id) {
+#define DQ_CASE(ID, RC, DIMS, FS, MS, KU, SU, SLK) \
+    case ID: fn = plan_agent<RC, DIMS, FS, MS, KU, SU, SLK, WaveCpu>; break;
+        DQ_INSTANCES(DQ_CASE)
+#undef DQ_CASE
+    }
+    const MemLayout lay = make_layout(kp, max_slack_obs, kmax, ic.KU, ic.SU, instance_n_in_lds(ic.id));
+    const int M = cfg->M, n1 = cfg->n + 1;
+    if (n_threads < 1) n_threads = 1;
+    std::vector<int64_t> done(n_threads, 0);
+    const auto t0 = std::chrono::steady_clock::now();
+    auto work = [&](int t) {
+        std::vector<unsigned char> mem(lay.bytes + 64 + 4096);
+        std::vector<float> ctrl((size_t)M * n1 * 3);
+        std::vector<double> slack(std::max(max_slack_obs, 1));
+        float goal[3];
+        int gst, st, it[4];
+        double cost;
+        WaveCpu w;
+        w.reverse = false;
+        const int lo = (int)((int64_t)n_agents * t / n_threads), hi = (int)((int64_t)n_agents * (t + 1) / n_threads);
+        if (hi <= lo) return;
+        int a = lo;
+        for (;;) {
+            fn(w, kp, lay, mem.data(), agents + a, rv, (int)row_offsets[a], (int)(row_offsets[a + 1] - row_offsets[a]),
+               sfc ? sfc + (size_t)a * M * 6 : nullptr, max_slack_obs, 1, 1, goal, &gst, ctrl.data(), nullptr, &cost,
+               max_slack_obs ? slack.data() : nullptr, &st, it);
+            done[t]++;
+            if (++a == hi) a = lo;
+            if ((done[t] & 15) == 0 &&
+                std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() >= seconds) break;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 0; t < n_threads; t++) th.emplace_back(work, t);
+    for (auto &x : th) x.join();
+    *elapsed_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    int64_t tot = 0;
+    for (auto v : done) tot += v;
+    *n_done = tot;
     return 0;
 }

@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _bench(*flags):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29731", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--swarms", "8", "--steps", "6", "--warmup", "2",
-                          "--no-latency", *flags], env=env, capture_output=True, text=True, timeout=600)
+                          *flags], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -23,16 +23,18 @@ def _bench(*flags):
 
 
 def test_single_gpu_line_has_the_contract_fields(gpu_required):
-    d = _bench()
+    d = _bench("--no-extras")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["unit"] == "QP/s" and d["dtype"] == "f64" and d["vs_baseline"] is None
     assert d["config"]["agents_per_gpu"] == 512 and d["value"] > 0
     r = d["roofline"]
-    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["qp_per_launch"] == 512
+    assert r["bound"] == "valu_issue" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["qp_per_launch"] == 512
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["oracle_qp_per_s_one_core"] > 0
+    assert c["value"] > 3 * c["oracle_qp_per_s_one_core"]  # the kernel's algorithm, not the dense checker
+    assert d["config"]["distinct_batches"] == 4 and d["config"]["ms_per_step_no_order_hint"] > 0
 
 
 @pytest.mark.parametrize("mode", ["pipelined", "serial"])
@@ -40,3 +42,22 @@ def test_multi_gpu_code_path_with_one_rank(gpu_required, mode):
     d = _bench("--force-dist", "--no-cpu-baseline", "--exchange", mode)
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert ("communication stream" in d["config"]["exchange"]) == (mode == "pipelined")
+    e = d["config"]["exchange_modes_ms_per_step"]
+    assert e["pipelined"] > 0 and e["serial"] > 0  # both modes are timed in every N > 1 run
+    x = d["x2048_strong"]  # BASELINE.json configs[4] through the sharded step (one rank: no halo)
+    assert x["agents_total"] == 2048 and x["halo_agents_rank0"] == 0 and x["ms_per_step_serial_exchange"] > 0 and x["solved_fraction_rank0"] > 0.9
+
+
+def test_gpus_flag_starts_the_ranks_itself(gpu_required):
+    """`bench.py --gpus 2` without RANK in the environment must not silently measure one GPU: it starts the ranks as child
+    processes (torch.distributed.run).  On a one-GPU box the second rank cannot get a device, so the run fails -- loudly."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--swarms", "2", "--steps", "4", "--warmup", "1",
+                          "--no-extras", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    import torch
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    if torch.cuda.device_count() >= 2:
+        assert out.returncode == 0 and json.loads(lines[0])["n_gpus"] == 2
+    else:
+        assert out.returncode != 0 and not lines, (out.returncode, out.stdout[-500:])
+        assert "torch.distributed" in out.stderr or "invalid device" in out.stderr.lower() or "ChildFailedError" in out.stderr
