@@ -48,6 +48,8 @@ def parse_args():
                     help="N>1, headline loop: 'pipelined' posts the all-gather of step k on a communication stream so that it "
                          "runs while step k+1 plans the agents whose neighbours are all local; 'serial' runs launch and all-gather "
                          "back to back.  The other mode is timed after the headline loop and reported beside it")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="(profiling) stop after the headline loop: the last --steps launches of the process are the timed ones")
     ap.add_argument("--force-dist", action="store_true", help="(test) create the process group even for one rank")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic_latest.json"))
     return ap.parse_args()
@@ -469,9 +471,9 @@ def main():
     res = [db.results() for db in dbs]
     # the same loop without the launch-order hint, and (N > 1) with the other exchange mode
     side_steps = max(B, min(args.steps, 200))
-    el_nohint = timed(side_steps, head_pipelined, None)
+    el_nohint = float("nan") if args.headline_only else timed(side_steps, head_pipelined, None)
     exch = None
-    if use_dist:
+    if use_dist and not args.headline_only:
         exch = {"pipelined": None, "serial": None, "steps_of_the_second_mode": side_steps}
         exch["pipelined" if head_pipelined else "serial"] = elapsed / args.steps * 1e3
         if pipelined_ok:  # the other mode, same batches, same launch order
@@ -482,7 +484,7 @@ def main():
 
     # BASELINE.json configs[4] as a strong-scaling step on the same ranks (every N, so that the scaling runs carry it)
     stress = None
-    if not args.no_extras:
+    if not args.no_extras and not args.headline_only:
         ss = StressStep(local_rank, rank, world, dist if use_dist else None)
         ms_serial = ss.time(30, False)
         ms_pipe = ss.time(30, True) if use_dist else None
@@ -520,7 +522,7 @@ def main():
         fp64 = {"flops_per_qp_model": flops_qp, "achieved_tflops": N * flops_qp / avg_kernel_s / 1e12,
                 "peak_tflops": FP64_VALU_PEAK_TFLOPS, "frac": N * flops_qp / avg_kernel_s / 1e12 / FP64_VALU_PEAK_TFLOPS}
         lat, closed, hard = None, None, None
-        if not args.no_extras and world == 1:
+        if not args.no_extras and not args.headline_only and world == 1:
             # single-swarm replanning latency through the host-buffer entry (H2D + solve + D2H)
             a1, r1 = wl["agents"][:64], wl["rows"][:wl["row_offsets"][64]]
             ro1 = wl["row_offsets"][:65]
@@ -604,7 +606,7 @@ def main():
                         "launch stream over the timed region; ~5 KB per QP can never load the HBM roof (SURVEY.md 8d)",
             },
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and not args.headline_only and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, hist[-1])
         print(json.dumps(line))
     opt.close()

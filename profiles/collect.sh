@@ -8,7 +8,7 @@ NAME=${1:-r01}
 OUT=gpurun_out/prof_$NAME
 STEPS=30
 export TMPDIR=/tmp
-B="python3 bench.py --steps $STEPS --warmup 3 --swarms 512 --no-cpu-baseline --no-latency"
+B="python3 bench.py --steps $STEPS --warmup 4 --swarms 512 --headline-only"
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $B > $OUT/fetch.log 2>&1
@@ -19,5 +19,9 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $OUT/sq4 -- $B > $OUT/sq4.log 2>&1
 python3 profiles/summarize.py $OUT $NAME --steps $STEPS --agents 32768 > $OUT/summary.txt 2>&1
 cp profiles/$NAME.md profiles/$NAME.json profiles/hbm_traffic_latest.json $OUT/ 2>/dev/null
-python3 profiles/stamps.py > $OUT/stamps.txt 2>&1
+python3 profiles/stamps.py --swarms 512 > $OUT/stamps.txt 2>&1
+cp $OUT/stamps.txt profiles/${NAME}_stamps.txt
+# every kernel of the path in one trace: the full bench (closed-loop missions: half-space, corridor and advance kernels; stress batch)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/all -- python3 bench.py --steps 40 --no-cpu-baseline > $OUT/all.log 2>&1
+python3 profiles/kernels.py $OUT/all $NAME > $OUT/kernels.txt 2>&1
 tail -5 $OUT/summary.txt

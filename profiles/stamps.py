@@ -28,7 +28,7 @@ def main():
     if not os.path.exists(LIB):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
                                "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-DDLSCQP_STAMPS", "-o", LIB, os.path.join(CSRC, "dlscqp.hip"),
-                               os.path.join(CSRC, "qp_tables.cpp"), os.path.join(CSRC, "sfc_world.cpp")])
+                               os.path.join(CSRC, "qp_tables.cpp"), os.path.join(CSRC, "sfc_world.cpp"), os.path.join(CSRC, "grid_mapf.cpp")])
     os.environ["DLSCQP_LIB"] = LIB
     import numpy as np
     import torch

@@ -88,6 +88,15 @@ def main():
             summary["pmc_" + k] = v
             out.append("| %s | %.6g |" % (k, v))
         out.append("")
+    if "pmc_SQ_INSTS_VALU" in summary and "avg_kernel_us" in summary:
+        # share of the VALU issue slots of the chip that the kernel uses: a wave64 VALU instruction occupies its SIMD's issue
+        # port for 4 cycles; 256 CUs x 4 SIMDs; 2.4 GHz peak engine clock (a lower real clock makes the true share higher)
+        frac = summary["pmc_SQ_INSTS_VALU"] * 4.0 / (1024 * summary["avg_kernel_us"] * 1e-6 * 2.4e9)
+        summary["valu_issue_frac"] = frac
+        out.append("VALU issue: SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x %.1f us x 2.4 GHz) = %.3f of the chip's VALU issue slots "
+                   "(%.0f VALU instructions per agent)\n" % (summary["avg_kernel_us"], frac, summary["pmc_SQ_INSTS_VALU"] / args.agents))
+    if "pmc_SQ_WAIT_ANY" in summary and "pmc_SQ_WAVE_CYCLES" in summary:
+        out.append("SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.3f of the wave-cycles waiting\n" % (summary["pmc_SQ_WAIT_ANY"] / summary["pmc_SQ_WAVE_CYCLES"]))
     if "pmc_FETCH_SIZE" in summary and "pmc_WRITE_SIZE" in summary:
         hbm = (2 * summary["pmc_FETCH_SIZE"] + summary["pmc_WRITE_SIZE"]) * 1024
         summary["hbm_bytes_per_launch"] = hbm
@@ -103,7 +112,7 @@ def main():
     if "hbm_bytes_per_launch" in summary:
         with open(os.path.join(here, "hbm_traffic_latest.json"), "w") as fh:
             json.dump({"agents_per_launch": args.agents, "hbm_bytes_per_launch": summary["hbm_bytes_per_launch"],
-                       "source": args.name}, fh)
+                       "valu_issue_frac": summary.get("valu_issue_frac"), "kernel": KERNEL, "source": args.name}, fh)
     print("\n".join(out))
 
 
