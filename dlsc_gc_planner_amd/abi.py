@@ -145,7 +145,13 @@ class LscGen(C.Structure):
         ("dyn_radius", C.c_void_p),
         ("dyn_max_acc", C.c_void_p),
         ("dyn_downwash", C.c_void_p),
+        ("observed_position", C.c_void_p),
+        ("reset_threshold", C.c_double),
     ]
+
+
+class WaypointTrap(C.Structure):  # dlscqp_waypoint_trap
+    _fields_ = [("agents", C.c_void_p), ("sfc_boxes", C.c_void_p), ("out_released", C.c_void_p)]
 
 
 class SfcGen(C.Structure):
@@ -285,6 +291,8 @@ def load_library():
     lib.dlscqp_plan_batch_device.restype = C.c_int
     lib.dlscqp_generate_lsc_device.argtypes = [vp, P(LscGen), vp]
     lib.dlscqp_generate_lsc_device.restype = C.c_int
+    lib.dlscqp_waypoint_trap_device.argtypes = [vp, P(LscGen), P(WaypointTrap), vp]
+    lib.dlscqp_waypoint_trap_device.restype = C.c_int
     lib.dlscqp_advance_device.argtypes = [vp, P(Advance), vp]
     lib.dlscqp_advance_device.restype = C.c_int
     lib.dlscqp_rows_to_soa.argtypes = [vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -308,5 +316,5 @@ EXPORTED_SYMBOLS = [
     "dlscqp_lds_bytes", "dlscqp_solve_batch", "dlscqp_goal_batch", "dlscqp_plan_batch",
     "dlscqp_plan_batch_device", "dlscqp_generate_lsc_device", "dlscqp_rows_to_soa", "dlscqp_set_timing",
     "dlscqp_get_kernel_times", "dlscqp_world_create", "dlscqp_world_destroy", "dlscqp_generate_sfc_device",
-    "dlscqp_advance_device", "dlscqp_mapf_create", "dlscqp_mapf_destroy", "dlscqp_mapf_step",
+    "dlscqp_advance_device", "dlscqp_waypoint_trap_device", "dlscqp_mapf_create", "dlscqp_mapf_destroy", "dlscqp_mapf_step",
 ]

@@ -302,6 +302,44 @@ __global__ __launch_bounds__(64) void dlscqp_lsc_kernel(LscGenArgs g) {
     }
 }
 
+// TrajPlanner::checkWaypointTrap: one wavefront per local agent.  The lanes test the agent's neighbour rows (ballot), the
+// verdict is wave-uniform, then the lanes empty the rows of the dynamic obstacles that can reach the waypoint.
+struct TrapArgs {
+    LscGenArgs g;
+    const dlscqp_agent *agents;
+    const float *sfc;
+    int32_t *out_released;
+    double horizon;
+};
+__global__ __launch_bounds__(64) void dlscqp_trap_kernel(TrapArgs t) {
+    const LscGenArgs &g = t.g;
+    const int k = blockIdx.x;
+    if (k >= g.n_local) return;
+    const int per = g.M * g.n1 - g.phi;
+    const int p0 = g.nbr_offsets[k], p1 = g.nbr_offsets[k + 1];
+    const size_t row0 = (size_t)per * ((size_t)p0 + (size_t)k * g.n_dyn);
+    const int n_rows = (p1 - p0) * per;
+    const dlscqp_agent *ag = t.agents + k;
+    const float *cg = ag->current_goal_point, *wp = ag->next_waypoint;
+    bool out = false;
+    for (int j = threadIdx.x; j < n_rows; j += 64) out |= trap_row_excludes(g, row0 + j, cg, wp);
+    const float *box = t.sfc ? t.sfc + ((size_t)k * g.M + (g.M - 1)) * 6 : nullptr;
+    bool trapped = __ballot(out) != 0ull;
+    trapped = trapped || !point_in_boxes(g, box, wp, cg) || !point_in_boxes(g, box, wp, wp);
+    int released = 0;
+    if (trapped) {  // uniform
+        for (int o = 0; o < g.n_dyn; o++) {
+            if (!obstacle_reaches(g.dyn_position + 3 * o, g.dyn_velocity + 3 * o, g.dyn_radius[o], g.dyn_max_acc[o], wp, ag->radius,
+                                  t.horizon, g.dyn_uncertainty_horizon))
+                continue;
+            released++;
+            const size_t r0 = row0 + (size_t)per * ((size_t)(p1 - p0) + o);
+            for (int j = threadIdx.x; j < per; j += 64) trap_empty_row(g, r0 + j);
+        }
+    }
+    if (t.out_released && threadIdx.x == 0) t.out_released[k] = released;
+}
+
 // one wavefront per agent grows / shifts its corridor boxes (sfc_core.hpp).  Control flow is
 // wave-uniform; the lanes share the lattice points of the slab under test.
 struct WaveSfc {
@@ -652,10 +690,8 @@ extern "C" int dlscqp_plan_batch_device(dlscqp_ctx *c, const dlscqp_device_batch
     return launch(c, b, (hipStream_t)stream);
 }
 
-extern "C" int dlscqp_generate_lsc_device(dlscqp_ctx *c, const dlscqp_lsc_gen *gen, void *stream) {
-    g_last_error.clear();
-    if (!c || !gen) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
-    if (gen->n_local <= 0) return DLSCQP_SUCCESS;
+// dlscqp_lsc_gen -> the argument block of the half-space and waypoint-trap kernels
+static int lsc_gen_args(dlscqp_ctx *c, const dlscqp_lsc_gen *gen, LscGenArgs *out) {
     if (!gen->goals || !gen->radius || !gen->downwash || !gen->nbr_offsets || !gen->nbr_ids || !gen->nx || !gen->d || !gen->key ||
         (gen->first_plan ? (!gen->position || !gen->velocity) : !gen->plans)) {
         g_last_error = "null buffer";
@@ -680,7 +716,39 @@ extern "C" int dlscqp_generate_lsc_device(dlscqp_ctx *c, const dlscqp_lsc_gen *g
     g.dyn_uncertainty_horizon = gen->dyn_uncertainty_horizon;
     g.dyn_position = gen->dyn_position; g.dyn_velocity = gen->dyn_velocity;
     g.dyn_radius = gen->dyn_radius; g.dyn_max_acc = gen->dyn_max_acc; g.dyn_downwash = gen->dyn_downwash;
+    g.observed_position = gen->observed_position;
+    g.reset_threshold = gen->reset_threshold;
+    g.comm_range = c->cfg.communication_range;
+    g.use_sfc = c->kp.use_sfc;
+    *out = g;
+    return DLSCQP_SUCCESS;
+}
+
+extern "C" int dlscqp_generate_lsc_device(dlscqp_ctx *c, const dlscqp_lsc_gen *gen, void *stream) {
+    g_last_error.clear();
+    if (!c || !gen) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (gen->n_local <= 0) return DLSCQP_SUCCESS;
+    LscGenArgs g;
+    const int rc = lsc_gen_args(c, gen, &g);
+    if (rc != DLSCQP_SUCCESS) return rc;
     hipLaunchKernelGGL(dlscqp_lsc_kernel, dim3(gen->n_local), dim3(64), 0, (hipStream_t)stream, g);
+    HIP_TRY(hipGetLastError());
+    return DLSCQP_SUCCESS;
+}
+
+extern "C" int dlscqp_waypoint_trap_device(dlscqp_ctx *c, const dlscqp_lsc_gen *gen, const dlscqp_waypoint_trap *trap, void *stream) {
+    g_last_error.clear();
+    if (!c || !gen || !trap) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (gen->n_local <= 0 || gen->n_dyn <= 0) return DLSCQP_SUCCESS;  // nothing to release without dynamic obstacles (:709)
+    if (!trap->agents || (c->kp.use_sfc && !trap->sfc_boxes)) { g_last_error = "null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    TrapArgs t;
+    const int rc = lsc_gen_args(c, gen, &t.g);
+    if (rc != DLSCQP_SUCCESS) return rc;
+    t.agents = trap->agents;
+    t.sfc = c->kp.use_sfc ? trap->sfc_boxes : nullptr;
+    t.out_released = trap->out_released;
+    t.horizon = c->M * c->dt;
+    hipLaunchKernelGGL(dlscqp_trap_kernel, dim3(gen->n_local), dim3(64), 0, (hipStream_t)stream, t);
     HIP_TRY(hipGetLastError());
     return DLSCQP_SUCCESS;
 }

@@ -225,6 +225,10 @@ struct LscGenArgs {  // device mirror of dlscqp_lsc_gen (include/dlscqp.h)
     double dyn_uncertainty_horizon;
     const float *dyn_position, *dyn_velocity;
     const double *dyn_radius, *dyn_max_acc, *dyn_downwash;
+    const float *observed_position;  // checkObstacleDisturbance, or null
+    double reset_threshold;
+    double comm_range;               // param.communication_range (waypoint trap)
+    int use_sfc;
 };
 
 // control point i of segment m of agent `id`'s initial trajectory (= what the others predict for it)
@@ -244,6 +248,19 @@ DQ_FN F3 initial_point(const LscGenArgs &g, int id, int m, int i) {
     return f3(c[0], c[1], c[2]);
 }
 
+// What agent `id` is PREDICTED to do (obstaclePredictionWithPrevSol + checkObstacleDisturbance, traj_planner.cpp:290-336):
+// its shifted previous plan, unless that starts farther than reset_threshold from where the agent is observed -- then it
+// is taken to stand still at the observed position (planConstVelTraj(position, 0)).
+DQ_FN F3 predicted_point(const LscGenArgs &g, int id, int m, int i) {
+    if (g.observed_position) {  // uniform
+        const float *o = g.observed_position + 3 * (size_t)id;
+        const F3 obs = f3(o[0], o[1], o[2]);
+        const F3 start = initial_point(g, id, 0, 0);
+        if (norm(start - obs) > g.reset_threshold) return obs;
+    }
+    return initial_point(g, id, m, i);
+}
+
 // One (pair, segment) item.  `row0`: index of the pair's first row in the SoA arrays.
 DQ_FN void lsc_item(const LscGenArgs &g, int self, int other, int m, size_t row0) {
     const int n = g.n1 - 1, M = g.M;
@@ -258,7 +275,7 @@ DQ_FN void lsc_item(const LscGenArgs &g, int self, int other, int m, size_t row0
         D3 pts[6];
         for (int i = 0; i < 6; i++) {
             F3 a = initial_point(g, self, m, i);
-            pred[i] = initial_point(g, other, m, i);
+            pred[i] = predicted_point(g, other, m, i);
             F3 b = pred[i];
             a.z = a.z / dwf;  // Trajectory::coordinateTransform, trajectory.cpp:206-219
             b.z = b.z / dwf;
@@ -278,7 +295,7 @@ DQ_FN void lsc_item(const LscGenArgs &g, int self, int other, int m, size_t row0
             g.key[r] = DLSCQP_KEY(m, i, -1, 0);
         }
     } else {
-        F3 l1s = initial_point(g, other, M - 1, n), l2s = initial_point(g, self, M - 1, n);
+        F3 l1s = predicted_point(g, other, M - 1, n), l2s = initial_point(g, self, M - 1, n);
         l1s.z = l1s.z / dwf;
         l2s.z = l2s.z / dwf;
         const float *go = g.goals + 3 * (size_t)other, *gs = g.goals + 3 * (size_t)self;
@@ -365,6 +382,55 @@ DQ_FN void lsc_dyn_item(const LscGenArgs &g, int self, int o, int m, size_t row0
         g.d[r] = size + r_self;  // :623
         g.key[r] = DLSCQP_KEY(m, i, o, 1);
     }
+}
+
+// ---- TrajPlanner::checkWaypointTrap (traj_planner.cpp:708-735) ---------------------------------------------------
+// LSC::isPointInLSC (collision_constraints.cpp:35-37): float32 differences and dot product, compared in double
+DQ_FN bool point_in_lsc(float nx, float ny, float nz, float px, float py, float pz, double d, const float *pt) {
+    const float e0 = pt[0] - px, e1 = pt[1] - py, e2 = pt[2] - pz;
+    const float dotv = e0 * nx + e1 * ny + e2 * nz;
+    return (double)dotv - d > -1e-9;
+}
+// Box::isPointInBox (collision_constraints.cpp:109-116)
+DQ_FN bool point_in_box(const float *bmin, const float *bmax, const float *pt) {
+    for (int k = 0; k < 3; k++)
+        if (!((double)pt[k] > (double)bmin[k] - 1e-5 && (double)pt[k] < (double)bmax[k] + 1e-5)) return false;
+    return true;
+}
+// Obstacle::isCollided (obstacle.hpp:26-36)
+DQ_FN bool obstacle_reaches(const float *pos, const float *vel, double radius, double max_acc, const float *pt, double agent_radius,
+                            double horizon, double uncertainty_horizon) {
+    const double step = 0.1 * horizon < 0.1 ? 0.1 * horizon : 0.1;
+    for (double t = 0; t <= horizon; t += step) {
+        const float tf = (float)t;
+        const F3 op = f3(pos[0] + vel[0] * tf, pos[1] + vel[1] * tf, pos[2] + vel[2] * tf);
+        const double tm = t < uncertainty_horizon ? t : uncertainty_horizon;
+        if (distance(op, f3(pt[0], pt[1], pt[2])) < agent_radius + radius + 0.5 * max_acc * tm * tm) return true;
+    }
+    return false;
+}
+// The part of isPointInFeasibleRegion(point, M-1, n) that does not depend on the rows: last corridor box and the
+// communication-range box around the waypoint (a default Box, i.e. the origin, when the range is unlimited)
+DQ_FN bool point_in_boxes(const LscGenArgs &g, const float *sfc_last, const float *wp, const float *pt) {
+    if (g.use_sfc && sfc_last && !point_in_box(sfc_last, sfc_last + 3, pt)) return false;
+    float cmin[3] = {0, 0, 0}, cmax[3] = {0, 0, 0};
+    if (g.comm_range > 0) {
+        const float dl = (float)(0.5 * g.comm_range);
+        for (int k = 0; k < 3; k++) { cmin[k] = wp[k] - dl; cmax[k] = wp[k] + dl; }
+    }
+    return point_in_box(cmin, cmax, pt);
+}
+// row r of a neighbour AGENT excludes the sub-goal or the waypoint from the feasible region of the last control point?
+DQ_FN bool trap_row_excludes(const LscGenArgs &g, size_t r, const float *cg, const float *wp) {
+    const uint32_t key = g.key[r];
+    const int m = key & 0xFF, i = (key >> 8) & 0xF, dyn = (key >> 12) & 1;
+    if (dyn || m != g.M - 1 || i != g.n1 - 1) return false;
+    return !point_in_lsc(g.nx[r], g.ny[r], g.nz[r], g.px[r], g.py[r], g.pz[r], g.d[r], cg) ||
+           !point_in_lsc(g.nx[r], g.ny[r], g.nz[r], g.px[r], g.py[r], g.pz[r], g.d[r], wp);
+}
+DQ_FN void trap_empty_row(const LscGenArgs &g, size_t r) {  // the default LSC: zero normal, zero point, d = 0 (:726-728)
+    g.nx[r] = 0; g.ny[r] = 0; g.nz[r] = 0; g.px[r] = 0; g.py[r] = 0; g.pz[r] = 0;
+    g.d[r] = 0;
 }
 
 }  // namespace dlscqp

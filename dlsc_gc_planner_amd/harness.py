@@ -198,6 +198,7 @@ class ClosedLoop:
                                              desired_goal=self.desired_goal if world is None else None,
                                              waypoint_step=waypoint_step if world is None else 0.0)
         self.records_in = torch.zeros_like(self.batch.t["agents"])
+        self.released = torch.zeros(N, dtype=torch.int32, device=dev)  # dynamic obstacles released by the waypoint trap, per agent
         self.history = []
 
     def close(self):
@@ -266,6 +267,10 @@ class ClosedLoop:
             self.gen.generate(self.cur_goal, plans=self.plans, **dkw)
         if self.sfc is not None:
             self.sfc.update(self.init_buf, self.cur_goal, self.wp)
+        if self.D and self.world is not None:
+            # TrajPlanner::checkWaypointTrap (traj_planner.cpp:708-735): a waypoint cut off by neighbours / corridor / range
+            # and within reach of a dynamic obstacle -> that obstacle's rows are dropped for this step
+            self.gen.waypoint_trap(self.batch.t["agents"], None if self.sfc is None else self.sfc.sfcs, self.released)
         if self.keep_inputs:
             self.records_in.copy_(self.batch.t["agents"])
         self.batch.launch(True, True)

@@ -342,11 +342,30 @@ class LscGenerator:
         self.row_offsets = self.per * pairs
         return self.row_offsets
 
-    def generate(self, goals, plans=None, position=None, velocity=None, stream=None, dyn_position=None, dyn_velocity=None):
+    def waypoint_trap(self, agents, sfcs=None, out_released=None, stream=None):
+        """TrajPlanner::checkWaypointTrap on the rows of the last generate(): `agents` the uint8 tensor of the local agents'
+        records (DeviceBatch.t["agents"]), `sfcs` the corridor tensor [n_local, M, 6] or None, `out_released` an optional
+        int32 tensor [n_local].  Asynchronous; a no-op without dynamic obstacles."""
+        t = abi.WaypointTrap()
+        t.agents = agents.data_ptr()
+        t.sfc_boxes = None if sfcs is None else sfcs.data_ptr()
+        t.out_released = None if out_released is None else out_released.data_ptr()
+        s = self.torch.cuda.current_stream(self.device) if stream is None else stream
+        rc = self.opt.lib.dlscqp_waypoint_trap_device(self.opt.handle, C.byref(self.c), C.byref(t), C.c_void_p(s.cuda_stream))
+        self.opt._check(rc, "dlscqp_waypoint_trap_device")
+
+    def generate(self, goals, plans=None, position=None, velocity=None, stream=None, dyn_position=None, dyn_velocity=None,
+                 observed_position=None, reset_threshold=0.0):
         """goals [n_total,3] f32 and either plans [n_total,M,n+1,3] f32 (previous plans) or position/velocity
-        (first replanning step); dyn_position / dyn_velocity [n_dyn,3] f32 when the generator has dynamic obstacles:
-        CUDA tensors.  Asynchronous."""
+        (first replanning step); dyn_position / dyn_velocity [n_dyn,3] f32 when the generator has dynamic obstacles;
+        observed_position [n_total,3] f32 + reset_threshold: TrajPlanner::checkObstacleDisturbance: CUDA tensors.  Asynchronous."""
         g = self.c
+        if observed_position is not None:
+            observed_position = observed_position.contiguous()
+            g.observed_position, g.reset_threshold = observed_position.data_ptr(), float(reset_threshold)
+            self._keep_obs = observed_position
+        else:
+            g.observed_position = None
         # raw pointers below: the layout must be the dense one
         goals = goals.contiguous()
         plans = None if plans is None else plans.contiguous()

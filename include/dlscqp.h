@@ -247,9 +247,28 @@ typedef struct dlscqp_lsc_gen {
     const double *dyn_radius;         /* [n_dyn]                                                         */
     const double *dyn_max_acc;        /* [n_dyn]                                                         */
     const double *dyn_downwash;       /* [n_dyn]                                                         */
+    /* TrajPlanner::checkObstacleDisturbance (traj_planner.cpp:329-336): a neighbour whose predicted trajectory starts
+     * farther than reset_threshold (param.reset_threshold) from where it is observed is predicted to stand still at the
+     * observed position.  NULL = no check (ideal simulation: prediction and state coincide).                      */
+    const float *observed_position;   /* [n_total][3] or NULL                                            */
+    double reset_threshold;
 } dlscqp_lsc_gen;
 
 int dlscqp_generate_lsc_device(dlscqp_ctx *ctx, const dlscqp_lsc_gen *gen, void *stream);
+
+/* TrajPlanner::checkWaypointTrap (traj_planner.cpp:708-735), after the half-spaces and the corridor boxes of a step and
+ * before the goal LP: if the agent's sub-goal or waypoint lies outside the feasible region of its last control point
+ * (CollisionConstraints::isPointInFeasibleRegion, collision_constraints.cpp:586-598: half-spaces of the neighbour AGENTS at
+ * (M-1, n), the last corridor box, the communication-range box around the waypoint), the rows of every dynamic obstacle
+ * that can reach the waypoint within the horizon (Obstacle::isCollided, obstacle.hpp:26-36) are replaced by the empty
+ * half-space (zero normal), which the LP and the QP skip (traj_optimizer.cpp:422-424).  `gen` is the structure the rows
+ * were generated with (row layout, neighbour lists, dynamic obstacles).  One wavefront per local agent.             */
+typedef struct dlscqp_waypoint_trap {
+    const dlscqp_agent *agents;   /* [gen->n_local] records of the local agents: current_goal_point, next_waypoint, radius */
+    const float *sfc_boxes;       /* [gen->n_local][M][6] or NULL (world_use_octomap == 0)                   */
+    int32_t *out_released;        /* optional [gen->n_local]: number of dynamic obstacles whose rows were emptied */
+} dlscqp_waypoint_trap;
+int dlscqp_waypoint_trap_device(dlscqp_ctx *ctx, const dlscqp_lsc_gen *gen, const dlscqp_waypoint_trap *trap, void *stream);
 
 /* ---- what happens between two launches, on the device ----------------------------------------
  * One kernel for the bookkeeping that follows dlscqp_plan_batch_device in a closed loop, so that a replanning step is

@@ -381,3 +381,76 @@ int oracle_generate_dlscgc_dynamic(const dlscqp_config *cfg, const float *init_s
     free(size);
     return nr;
 }
+
+/* ---- TrajPlanner::checkObstacleDisturbance (traj_planner.cpp:329-336) ------------------------------------------
+ * pred: a neighbour's predicted trajectory [M][n+1][3]; if it starts farther than reset_threshold from the observed
+ * position the obstacle is predicted to stand still there (planConstVelTraj(position, 0)).  Returns 1 if reset. */
+int oracle_obstacle_disturbance(float *pred, int M, int n, const float obs_position[3], double reset_threshold) {
+    float dx = pred[0] - obs_position[0], dy = pred[1] - obs_position[1], dz = pred[2] - obs_position[2];
+    float sq = dx * dx + dy * dy + dz * dz; /* octomath::Vector3::norm */
+    if (!(sqrt((double)sq) > reset_threshold)) return 0;
+    for (int p = 0; p < M * (n + 1); p++)
+        for (int k = 0; k < 3; k++) pred[3 * p + k] = obs_position[k];
+    return 1;
+}
+
+/* ---- TrajPlanner::checkWaypointTrap (traj_planner.cpp:708-735) ---------------------------------------------------
+ * rows: the agent's rows in populatebyrow order -- n_nbr neighbour agents, then n_dyn dynamic obstacles, `per` =
+ * M (n+1) - phi rows each (rows (0, i < phi) are not stored).  sfc_last: {min xyz, max xyz} of corridor box M-1 or NULL.
+ * Rows of the dynamic obstacles that can reach the waypoint are replaced by the default LSC (zero normal) if the sub-goal
+ * or the waypoint is outside the feasible region of the last control point.  Returns the number of released obstacles. */
+static int oracle_lsc_contains(const dlscqp_lsc_row *r, const float pt[3]) { /* LSC::isPointInLSC, collision_constraints.cpp:35-37 */
+    float e0 = pt[0] - r->point[0], e1 = pt[1] - r->point[1], e2 = pt[2] - r->point[2];
+    float dotv = e0 * r->normal[0] + e1 * r->normal[1] + e2 * r->normal[2];
+    return (double)dotv - r->d > -1e-9;
+}
+static int oracle_box_contains(const float bmin[3], const float bmax[3], const float pt[3]) { /* Box::isPointInBox, :109-116 */
+    for (int k = 0; k < 3; k++)
+        if (!((double)pt[k] > (double)bmin[k] - 1e-5 && (double)pt[k] < (double)bmax[k] + 1e-5)) return 0;
+    return 1;
+}
+static int oracle_feasible_last(const dlscqp_config *cfg, const dlscqp_lsc_row *rows, int n_nbr, int per, const float *sfc_last,
+                                const float wp[3], const float pt[3]) { /* isPointInFeasibleRegion(point, M-1, n), :586-598 */
+    for (int oi = 0; oi < n_nbr; oi++) {
+        const dlscqp_lsc_row *last = rows + (size_t)oi * per + (per - 1); /* (M-1, n) is the last row of an obstacle */
+        if (!oracle_lsc_contains(last, pt)) return 0;
+    }
+    if (cfg->world_use_octomap && sfc_last && !oracle_box_contains(sfc_last, sfc_last + 3, pt)) return 0;
+    float cmin[3] = {0, 0, 0}, cmax[3] = {0, 0, 0}; /* Box() until constructCommunicationRange sets it (:538-546) */
+    if (cfg->communication_range > 0) {
+        float dl = (float)(0.5 * cfg->communication_range);
+        for (int k = 0; k < 3; k++) { cmin[k] = wp[k] - dl; cmax[k] = wp[k] + dl; }
+    }
+    return oracle_box_contains(cmin, cmax, pt);
+}
+int oracle_waypoint_trap(const dlscqp_config *cfg, dlscqp_lsc_row *rows, int n_nbr, int n_dyn, const dlscqp_agent *agent,
+                         const float *sfc_last, const float *dyn_position, const float *dyn_velocity, const double *dyn_radius,
+                         const double *dyn_max_acc, double uncertainty_horizon) {
+    const int per = cfg->M * (cfg->n + 1) - cfg->phi;
+    if (n_dyn <= 0) return 0;
+    const float *cg = agent->current_goal_point, *wp = agent->next_waypoint;
+    if (oracle_feasible_last(cfg, rows, n_nbr, per, sfc_last, wp, cg) && oracle_feasible_last(cfg, rows, n_nbr, per, sfc_last, wp, wp)) return 0;
+    int released = 0;
+    const double horizon = cfg->M * cfg->dt;
+    for (int o = 0; o < n_dyn; o++) {
+        int hit = 0; /* Obstacle::isCollided, obstacle.hpp:26-36 */
+        const double step = 0.1 * horizon < 0.1 ? 0.1 * horizon : 0.1;
+        for (double t = 0; t <= horizon && !hit; t += step) {
+            float tf = (float)t;
+            float ox = dyn_position[3 * o] + dyn_velocity[3 * o] * tf, oy = dyn_position[3 * o + 1] + dyn_velocity[3 * o + 1] * tf,
+                  oz = dyn_position[3 * o + 2] + dyn_velocity[3 * o + 2] * tf;
+            double tm = t < uncertainty_horizon ? t : uncertainty_horizon;
+            float dx = ox - wp[0], dy = oy - wp[1], dz = oz - wp[2];
+            double dist = sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz); /* Vector3::distance: double squares */
+            if (dist < agent->radius + dyn_radius[o] + 0.5 * dyn_max_acc[o] * tm * tm) hit = 1;
+        }
+        if (!hit) continue;
+        released++;
+        for (int j = 0; j < per; j++) {
+            dlscqp_lsc_row *r = rows + (size_t)(n_nbr + o) * per + j;
+            for (int k = 0; k < 3; k++) { r->normal[k] = 0; r->point[k] = 0; }
+            r->d = 0;
+        }
+    }
+    return released;
+}

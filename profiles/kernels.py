@@ -19,7 +19,9 @@ def main():
         k = r["Kernel_Name"]
         if "dlscqp" not in k:
             continue
-        short = k.split("(anonymous namespace)::")[-1].split("(")[0]
+        import re
+        m = re.search(r"(dlscqp_\w+(<[^>]*>)?)", k)
+        short = m.group(1) if m else k
         by[(short, int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1))].append(r)
     out = ["# rocprofv3 --kernel-trace of the full bench.py: every kernel of the path (%s)\n" % name,
            "| kernel | workgroups | calls | avg us | min us | max us | VGPR | SGPR | LDS B/WG | scratch B/lane |", "|---|---|---|---|---|---|---|---|---|---|"]

@@ -206,7 +206,7 @@ extern "C" int emul_table_info(const dlscqp_config *cfg, int *f, int *n_slots, i
 }
 
 // Row N1: the device code of lsc_core.hpp run item by item on the host (same source as dlscqp_lsc_kernel).
-extern "C" int emul_generate_lsc(const dlscqp_config *cfg, const dlscqp_lsc_gen *gen) {
+static dlscqp::LscGenArgs emul_lsc_args(const dlscqp_config *cfg, const dlscqp_lsc_gen *gen) {
     using namespace dlscqp;
     LscGenArgs g;
     g.n_local = gen->n_local; g.first_plan = gen->first_plan;
@@ -222,6 +222,43 @@ extern "C" int emul_generate_lsc(const dlscqp_config *cfg, const dlscqp_lsc_gen 
     g.dyn_uncertainty_horizon = gen->dyn_uncertainty_horizon;
     g.dyn_position = gen->dyn_position; g.dyn_velocity = gen->dyn_velocity;
     g.dyn_radius = gen->dyn_radius; g.dyn_max_acc = gen->dyn_max_acc; g.dyn_downwash = gen->dyn_downwash;
+    g.observed_position = gen->observed_position;
+    g.reset_threshold = gen->reset_threshold;
+    g.comm_range = cfg->communication_range;
+    g.use_sfc = cfg->world_use_octomap ? 1 : 0;
+    return g;
+}
+
+// TrajPlanner::checkWaypointTrap with the device helpers of lsc_core.hpp, agents and rows one after another
+extern "C" int emul_waypoint_trap(const dlscqp_config *cfg, const dlscqp_lsc_gen *gen, const dlscqp_waypoint_trap *trap) {
+    using namespace dlscqp;
+    const LscGenArgs g = emul_lsc_args(cfg, gen);
+    const int per = g.M * g.n1 - g.phi;
+    for (int k = 0; k < g.n_local && g.n_dyn > 0; k++) {
+        const int p0 = g.nbr_offsets[k], p1 = g.nbr_offsets[k + 1];
+        const size_t row0 = (size_t)per * ((size_t)p0 + (size_t)k * g.n_dyn);
+        const dlscqp_agent *ag = trap->agents + k;
+        const float *cg = ag->current_goal_point, *wp = ag->next_waypoint;
+        bool trapped = false;
+        for (int j = 0; j < (p1 - p0) * per; j++) trapped |= trap_row_excludes(g, row0 + j, cg, wp);
+        const float *box = (g.use_sfc && trap->sfc_boxes) ? trap->sfc_boxes + ((size_t)k * g.M + (g.M - 1)) * 6 : nullptr;
+        trapped = trapped || !point_in_boxes(g, box, wp, cg) || !point_in_boxes(g, box, wp, wp);
+        int released = 0;
+        for (int o = 0; trapped && o < g.n_dyn; o++) {
+            if (!obstacle_reaches(g.dyn_position + 3 * o, g.dyn_velocity + 3 * o, g.dyn_radius[o], g.dyn_max_acc[o], wp, ag->radius,
+                                  cfg->M * cfg->dt, g.dyn_uncertainty_horizon))
+                continue;
+            released++;
+            for (int j = 0; j < per; j++) trap_empty_row(g, row0 + (size_t)per * ((size_t)(p1 - p0) + o) + j);
+        }
+        if (trap->out_released) trap->out_released[k] = released;
+    }
+    return 0;
+}
+
+extern "C" int emul_generate_lsc(const dlscqp_config *cfg, const dlscqp_lsc_gen *gen) {
+    using namespace dlscqp;
+    const LscGenArgs g = emul_lsc_args(cfg, gen);
     const int per = g.M * g.n1 - g.phi;
     for (int k = 0; k < g.n_local; k++) {  // same item -> row mapping as dlscqp_lsc_kernel
         const int self = g.local_ids ? g.local_ids[k] : k;

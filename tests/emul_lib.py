@@ -66,17 +66,33 @@ def table_info(cfg, max_slack_obs=0, kmax=0):
 
 
 def generate_lsc(cfg, plans, goals, radius, downwash, nbr_offsets, nbr_ids, local_ids=None, position=None, velocity=None,
-                 dyn=None):
+                 dyn=None, observed=None, reset_threshold=0.0, trap=None):
     """Row N1 through the host build of lsc_core.hpp.  Returns (row_offsets, rows as ROW_DTYPE).
     dyn: None or dict(position [D,3], velocity [D,3], radius [D], max_acc [D], downwash [D], size_prediction, horizon)."""
     L = lib()
     L.emul_generate_lsc.argtypes = [C.POINTER(abi.Config), C.POINTER(abi.LscGen)]
     L.emul_generate_lsc.restype = C.c_int
-    return _run_lsc_gen(cfg, lambda g: L.emul_generate_lsc(C.byref(cfg), C.byref(g)), plans, goals, radius, downwash,
-                        nbr_offsets, nbr_ids, local_ids, position, velocity, dyn)
+    L.emul_waypoint_trap.argtypes = [C.POINTER(abi.Config), C.POINTER(abi.LscGen), C.POINTER(abi.WaypointTrap)]
+    L.emul_waypoint_trap.restype = C.c_int
+
+    def call(g):
+        rc = L.emul_generate_lsc(C.byref(cfg), C.byref(g))
+        if rc == 0 and trap is not None:  # TrajPlanner::checkWaypointTrap on the rows just generated
+            t = abi.WaypointTrap()
+            ag = np.ascontiguousarray(trap["agents"], dtype=abi.AGENT_DTYPE)
+            sfc = None if trap.get("sfc") is None else np.ascontiguousarray(trap["sfc"], dtype=np.float32)
+            rel = np.zeros(len(ag), np.int32)
+            t.agents, t.sfc_boxes, t.out_released = ag.ctypes.data, None if sfc is None else sfc.ctypes.data, rel.ctypes.data
+            rc = L.emul_waypoint_trap(C.byref(cfg), C.byref(g), C.byref(t))
+            trap["released"] = rel
+        return rc
+
+    return _run_lsc_gen(cfg, call, plans, goals, radius, downwash, nbr_offsets, nbr_ids, local_ids, position, velocity, dyn,
+                        observed, reset_threshold)
 
 
-def _run_lsc_gen(cfg, call, plans, goals, radius, downwash, nbr_offsets, nbr_ids, local_ids, position, velocity, dyn=None):
+def _run_lsc_gen(cfg, call, plans, goals, radius, downwash, nbr_offsets, nbr_ids, local_ids, position, velocity, dyn=None,
+                 observed=None, reset_threshold=0.0):
     first = plans is None
     keep = []
 
@@ -97,6 +113,9 @@ def _run_lsc_gen(cfg, call, plans, goals, radius, downwash, nbr_offsets, nbr_ids
     _, g.position = arr(position, np.float32)
     _, g.velocity = arr(velocity, np.float32)
     _, g.goals = arr(goals, np.float32)
+    if observed is not None:
+        _, g.observed_position = arr(observed, np.float32)
+        g.reset_threshold = float(reset_threshold)
     _, g.radius = arr(radius, np.float64)
     _, g.downwash = arr(downwash, np.float64)
     g.nbr_offsets, g.nbr_ids = nbr_offsets.ctypes.data, nbr_ids_a.ctypes.data

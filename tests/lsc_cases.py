@@ -59,3 +59,32 @@ def random_dynamic_obstacles(n_dyn, seed, spread=2.5, first_at=None):
         pos[0], vel[0] = first_at
     return dict(position=pos, velocity=vel, radius=rng.uniform(0.1, 0.4, n_dyn), max_acc=rng.uniform(0.0, 3.0, n_dyn),
                 downwash=rng.choice([1.0, 2.0, 3.0], n_dyn), size_prediction=1, horizon=0.6)
+
+
+def trap_agents(cfg, sw, dyn, seed):
+    """Agent records for the waypoint-trap tests: sub-goals and waypoints placed so that some lie inside and some outside the
+    feasible region of the last control point, and waypoints near some dynamic obstacles' paths."""
+    from dlsc_gc_planner_amd import abi
+    rng = np.random.default_rng(seed)
+    N = len(sw["goals"])
+    ag = np.zeros(N, abi.AGENT_DTYPE)
+    last = sw["plans"][:, -1, -1]
+    ag["position"] = sw["plans"][:, 0, 0]
+    ag["current_goal_point"] = sw["goals"]
+    wp = (last + rng.uniform(-0.6, 0.6, (N, 3))).astype(np.float32)
+    # every third waypoint sits on the path of a dynamic obstacle (within its reach)
+    D = len(dyn["radius"])
+    for a in range(0, N, 3):
+        o = a % D
+        t = np.float32(rng.uniform(0.0, cfg.M * cfg.dt))
+        wp[a] = dyn["position"][o] + dyn["velocity"][o] * t + rng.normal(0, 0.05, 3).astype(np.float32)
+    ag["next_waypoint"] = wp
+    if cfg.world_dimension == 2:
+        ag["next_waypoint"][:, 2] = ag["current_goal_point"][:, 2] = np.float32(cfg.world_z_2d)
+    ag["radius"], ag["max_vel"], ag["max_acc"], ag["nominal_velocity"] = sw["radius"], 1.0, 2.0, 1.0
+    sfc = np.zeros((N, cfg.M, 6), np.float32)
+    for a in range(N):
+        c = last[a]
+        half = rng.uniform(0.3, 1.5, 3).astype(np.float32)
+        sfc[a, :, :3], sfc[a, :, 3:] = c - half, c + half
+    return ag, sfc

@@ -271,6 +271,35 @@ def generate_dlscgc(cfg, init, goals, radius, downwash, nbr_offsets, nbr_ids, lo
     return np.array(offs, np.int64), (np.concatenate(out) if out else np.zeros(0, abi.ROW_DTYPE))
 
 
+def obstacle_disturbance(pred, obs_position, reset_threshold):
+    """TrajPlanner::checkObstacleDisturbance on one predicted trajectory [M][n+1][3]: returns (pred', was_reset)."""
+    L = lib()
+    L.oracle_obstacle_disturbance.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double]
+    L.oracle_obstacle_disturbance.restype = C.c_int
+    p = np.ascontiguousarray(pred, dtype=np.float32).copy()
+    o = np.ascontiguousarray(obs_position, dtype=np.float32)
+    r = L.oracle_obstacle_disturbance(_ptr(p), p.shape[0], p.shape[1] - 1, _ptr(o), float(reset_threshold))
+    return p, bool(r)
+
+
+def waypoint_trap(cfg, rows, n_nbr, agent, sfc_last, dyn):
+    """TrajPlanner::checkWaypointTrap on one agent's rows (neighbour agents first, then the dynamic obstacles of `dyn`):
+    returns (rows', number of released obstacles)."""
+    L = lib()
+    vp = C.c_void_p
+    L.oracle_waypoint_trap.argtypes = [C.POINTER(abi.Config), vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_double]
+    L.oracle_waypoint_trap.restype = C.c_int
+    r = np.ascontiguousarray(rows, dtype=abi.ROW_DTYPE).copy()
+    ag = np.ascontiguousarray(agent, dtype=abi.AGENT_DTYPE).reshape(1)
+    box = None if sfc_last is None else np.ascontiguousarray(sfc_last, dtype=np.float32)
+    n_dyn = len(dyn["radius"])
+    dp, dv = np.ascontiguousarray(dyn["position"], np.float32), np.ascontiguousarray(dyn["velocity"], np.float32)
+    dr, da = np.ascontiguousarray(dyn["radius"], np.float64), np.ascontiguousarray(dyn["max_acc"], np.float64)
+    rel = L.oracle_waypoint_trap(C.byref(cfg), _ptr(r), int(n_nbr), n_dyn, _ptr(ag), _ptr(box), _ptr(dp), _ptr(dv), _ptr(dr), _ptr(da),
+                                 float(dyn.get("horizon", 1.0)))
+    return r, rel
+
+
 # ---- row N2: safe-flight-corridor boxes (oracle/dlsc_sfc_oracle.c, parity unpinned) ---------------------------------
 class SfcWorld:
     """Dense occupancy grid built like MapManager::updateOctreeFromCSV + the SFC routines of CollisionConstraints."""

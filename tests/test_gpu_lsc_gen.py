@@ -144,3 +144,46 @@ def test_generated_rows_with_dynamic_obstacles_feed_the_qp_kernel(gpu_required):
     assert ok.sum() > 8
     assert np.abs(got["x"][ok] - ref["x"][ok]).max() < 1e-4
     assert np.abs(got["slack_cost"][ok] - ref["slack_cost"][ok]).max() < 1e-4
+
+
+def test_waypoint_trap_and_disturbance_reset_on_the_device(gpu_required):
+    """TrajPlanner::checkObstacleDisturbance (:329-336) inside the half-space kernel and TrajPlanner::checkWaypointTrap
+    (:708-735) as its own launch, against the oracle's restatements."""
+    import lsc_cases
+    import emul_lib as E
+    cfg = abi.make_config(dim=3, M=5, communication_range=3.0, world_use_octomap=True)
+    N = 18
+    sw = lsc_cases.random_swarm(cfg, N, seed=505)
+    dyn = lsc_cases.random_dynamic_obstacles(3, seed=45)
+    ag, sfc = lsc_cases.trap_agents(cfg, sw, dyn, seed=5)
+    obs = sw["plans"][:, 1, 0].copy()
+    obs[[2, 5]] += np.float32([0.4, -0.3, 0.2])
+    opt = BatchTrajOptimizer(cfg)
+    try:
+        gen = opt.make_lsc_generator(N, sw["nbr_offsets"], sw["nbr_ids"], sw["radius"], sw["downwash"], dyn=dyn)
+        cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+        gen.generate(cu(sw["goals"]), plans=cu(sw["plans"]), dyn_position=cu(dyn["position"]), dyn_velocity=cu(dyn["velocity"]),
+                     observed_position=cu(obs), reset_threshold=0.5)
+        ro, before = gen.rows_host()
+        agents_dev = torch.from_numpy(ag.view(np.uint8).reshape(-1)).cuda()
+        released = torch.zeros(N, dtype=torch.int32, device="cuda")
+        gen.waypoint_trap(agents_dev, cu(sfc), released)
+        _, after = gen.rows_host()
+        released = released.cpu().numpy()
+    finally:
+        opt.close()
+    # the same chain through the host build of the device source (which the CPU tier pins to the oracle)
+    trap = dict(agents=ag, sfc=sfc)
+    eo, erows = E.generate_lsc(cfg, sw["plans"], sw["goals"], sw["radius"], sw["downwash"], sw["nbr_offsets"], sw["nbr_ids"], dyn=dyn,
+                               observed=obs, reset_threshold=0.5, trap=trap)
+    assert np.array_equal(ro, eo) and np.array_equal(released, trap["released"]) and (released > 0).sum() >= 2
+    for k in ("m", "i", "slack", "flags"):
+        assert np.array_equal(after[k], erows[k])
+    assert np.abs(after["normal"] - erows["normal"]).max() <= 3e-6 and np.abs(after["d"] - erows["d"]).max() <= 3e-6
+    # and directly against the oracle's trap on the device's own rows
+    for a in range(N):
+        n_nbr = int(sw["nbr_offsets"][a + 1] - sw["nbr_offsets"][a])
+        exp, rel = O.waypoint_trap(cfg, before[ro[a]:ro[a + 1]], n_nbr, ag[a], sfc[a, -1], dyn)
+        assert rel == released[a]
+        for k in ("normal", "point", "d"):
+            assert np.array_equal(after[ro[a]:ro[a + 1]][k], exp[k]), (a, k)

@@ -166,3 +166,69 @@ def test_dynamic_obstacle_size_prediction_profile():
     off = dict(dyn, size_prediction=0)
     _, rows2 = _oracle_rows(cfg, sw, dyn=off)
     assert np.allclose(rows2[:len(r0)]["d"], 0.3 + ra)
+
+
+def test_disturbed_neighbour_is_predicted_to_stand_still():
+    """TrajPlanner::checkObstacleDisturbance (traj_planner.cpp:329-336): neighbours observed farther than reset_threshold from
+    where their shifted plan starts are predicted at rest at the observed position -- device source against the oracle chain."""
+    cfg = abi.make_config(dim=3, M=5)
+    sw = lsc_cases.random_swarm(cfg, 10, seed=77)
+    obs = sw["plans"][:, 1, 0].copy()          # where the shifted plans start
+    obs[[2, 5, 6]] += np.float32([0.4, -0.3, 0.2])  # three agents were pushed away (0.54 m)
+    obs[8] += np.float32([0.05, 0, 0])          # below the threshold
+    thr = 0.5
+    init = np.stack([O.shift_plan(p) for p in sw["plans"]])
+    pred, n_reset = init.copy(), 0
+    for j in range(10):
+        pred[j], r = O.obstacle_disturbance(init[j], obs[j], thr)
+        n_reset += r
+    assert n_reset == 3 and np.array_equal(pred[8], init[8]) and (pred[5] == obs[5]).all()
+    # oracle rows: own trajectory from `init`, neighbours from `pred`
+    offs, out = [0], []
+    for a in range(10):
+        nb = sw["nbr_ids"][sw["nbr_offsets"][a]:sw["nbr_offsets"][a + 1]]
+        mixed = pred.copy()
+        mixed[a] = init[a]
+        _, r = O.generate_dlscgc(cfg, mixed, sw["goals"], sw["radius"], sw["downwash"], [0, len(nb)], nb, local_ids=[a])
+        out.append(r)
+        offs.append(offs[-1] + len(r))
+    rows = np.concatenate(out)
+    eo, erows = E.generate_lsc(cfg, sw["plans"], sw["goals"], sw["radius"], sw["downwash"], sw["nbr_offsets"], sw["nbr_ids"],
+                               observed=obs, reset_threshold=thr)
+    assert np.array_equal(eo, np.array(offs))
+    _cmp_rows(erows, rows)
+    _, plain = E.generate_lsc(cfg, sw["plans"], sw["goals"], sw["radius"], sw["downwash"], sw["nbr_offsets"], sw["nbr_ids"])
+    assert np.abs(plain["normal"] - erows["normal"]).max() > 1e-3  # the reset does change rows
+
+
+@pytest.mark.parametrize("M,dim,comm", [(5, 3, 3.0), (10, 2, 3.0), (5, 3, -1.0)])
+def test_waypoint_trap_releases_the_same_obstacles_as_the_oracle(M, dim, comm):
+    """TrajPlanner::checkWaypointTrap (traj_planner.cpp:708-735): device helpers (host build) against the oracle's
+    restatement, row for row; the cases cover trapped / free waypoints and obstacles within / out of reach."""
+    cfg = abi.make_config(dim=dim, M=M, communication_range=comm, world_use_octomap=True)
+    N = 18
+    sw = lsc_cases.random_swarm(cfg, N, seed=500 + M)
+    dyn = lsc_cases.random_dynamic_obstacles(3, seed=40 + M)
+    ag, sfc = lsc_cases.trap_agents(cfg, sw, dyn, seed=5)
+    trap = dict(agents=ag, sfc=sfc)
+    eo, erows = E.generate_lsc(cfg, sw["plans"], sw["goals"], sw["radius"], sw["downwash"], sw["nbr_offsets"], sw["nbr_ids"], dyn=dyn,
+                               trap=trap)
+    _, before = E.generate_lsc(cfg, sw["plans"], sw["goals"], sw["radius"], sw["downwash"], sw["nbr_offsets"], sw["nbr_ids"], dyn=dyn)
+    released = trap["released"]
+    per = cfg.M * (cfg.n + 1) - cfg.phi
+    exp_rel = np.zeros(N, np.int32)
+    for a in range(N):
+        n_nbr = int(sw["nbr_offsets"][a + 1] - sw["nbr_offsets"][a])
+        exp_rows, exp_rel[a] = O.waypoint_trap(cfg, before[eo[a]:eo[a + 1]], n_nbr, ag[a], sfc[a, -1], dyn)
+        got = erows[eo[a]:eo[a + 1]]
+        for k in ("normal", "point", "d", "m", "i", "slack", "flags"):
+            assert np.array_equal(got[k], exp_rows[k]), (a, k)
+        zeroed = (np.abs(got["normal"]).sum(axis=1) == 0) & (got["flags"] == abi.ROW_DYNAMIC)
+        assert zeroed.sum() == exp_rel[a] * per
+    assert np.array_equal(released, exp_rel)
+    if comm > 0:
+        assert (released > 0).sum() >= (2 if dim == 3 else 1) and (released == 0).sum() >= 2, released
+    else:
+        # unlimited range: the communication box is the default Box (the origin), every agent counts as trapped, so every
+        # obstacle within reach of the waypoint is released (harmless in the reference: such launches have no obstacles)
+        assert (released > 0).sum() >= 2
