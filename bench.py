@@ -207,7 +207,8 @@ def closed_loop_latency(device):
                           slack_collision_weight=f["slack_collision_weight"], communication_range=f["communication_range"],
                           world_use_octomap=True, world_min=tuple(f["world"][:3]), world_max=tuple(f["world"][3:]), device=device)
     spin = SpinObstacles(f["obstacles"])
-    world = dict(boxes=f["boxes"], resolution=f["world_resolution"], grid_resolution=f["grid_resolution"], pibt=True)
+    world = dict(boxes=f["boxes"], resolution=f["world_resolution"], grid_resolution=f["grid_resolution"], pibt="reference",
+                 uncertainty_horizon=f["uncertainty_horizon"])
     sim = ClosedLoop(cfg, np.array(f["start"], np.float32), np.array(f["goal"], np.float32), radius=f["radius"], downwash=f["downwash"],
                      max_vel=f["max_vel"], max_acc=f["max_acc"], nominal_velocity=1.0, waypoint_step=f["grid_resolution"],
                      world=world, dyn=spin.dyn(horizon=f["uncertainty_horizon"], duration=f["obs_duration"]), device=device)
@@ -215,7 +216,7 @@ def closed_loop_latency(device):
     out["forest10_spin4_100_1"] = {"agents": len(f["start"]), "dynamic_obstacles": len(f["obstacles"]), "steps": len(ts["eager"]),
                                    "p50_ms": float(np.percentile(ts["eager"], 50)), "p99_ms": float(np.percentile(ts["eager"], 99)),
                                    "qp_failsafes": fails,
-                                   "note": "220 variables, 124 reduced dimensions: working set in HBM (DESIGN.md 6f); includes the host-side waypoints"}
+                                   "note": "220 variables, 124 reduced dimensions: working set in HBM (DESIGN.md 6f); includes the host-side waypoint planner"}
     return out
 
 

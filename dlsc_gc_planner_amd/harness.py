@@ -149,6 +149,7 @@ class ClosedLoop:
         self.world = world
         self.sfc = None
         self.comm_neighbours = False
+        self.slack_threshold = float(world.get("slack_threshold", 0.1)) if world is not None else 0.1  # param.slack_threshold
         if world is not None:
             wmin, wmax = np.array(cfg.world_min[:], np.float32), np.array(cfg.world_max[:], np.float32)
             self.sfc = self.opt.make_sfc_generator(world["boxes"], world["resolution"], wmin, wmax, np.full(N, radius),
@@ -219,7 +220,13 @@ class ClosedLoop:
             if self.D:
                 gdyn = dict(position=self.dyn_pos.cpu().numpy(), velocity=self.dyn_vel.cpu().numpy(), radius=self.dyn["radius"],
                             max_acc=self.dyn["max_acc"])
-            self.mapf_rc = self.grid.step(pos, self.cur_goal.cpu().numpy(), wp, self.plans.cpu().numpy() if self.seq > 0 else None, dyn=gdyn)
+            alert = None
+            if self.D and self.seq > 0:
+                # TrajOptimizer::solve's collision alert (traj_optimizer.cpp:85-106): obstacles whose slack cost in the last
+                # QP exceeded param.slack_threshold; the planner treats them as obstacles of interest
+                alert = (self.batch.out_slack[:, :self.D] > self.slack_threshold).cpu().numpy().astype(np.uint8)
+            self.mapf_rc = self.grid.step(pos, self.cur_goal.cpu().numpy(), wp, self.plans.cpu().numpy() if self.seq > 0 else None, dyn=gdyn,
+                                          alert=alert)
             if self.comm_neighbours:
                 self._set_comm_neighbours(pos)
             return torch.from_numpy(wp)

@@ -246,3 +246,112 @@ def test_mission_sharded_over_two_ranks_equals_one_process():
         assert p.exitcode == 0
     for r in range(2):
         assert np.array_equal(res[r][0], ref_plans) and np.array_equal(res[r][1], ref_goals), r
+
+
+# ---- BASELINE.json configs[4] (stress batch): the interior / halo step over two gloo ranks -------------------------------
+def _stress_inputs(n_agents=192):
+    from dlsc_gc_planner_amd import workloads
+    cfg = workloads.x2048_config()
+    return cfg, workloads.x2048(cfg, n_agents=n_agents, seed=5001)
+
+
+def _stress_plan(cfg, w, ids, plans, goals, agents):
+    """Half-spaces (device source, host build) + goal LP + QP (kernel source, host build) of the agents `ids` from the table
+    (plans, goals) of everybody's previous plans and sub-goals."""
+    import emul_lib as E
+    ids = np.asarray(ids, np.int64)
+    off = w["nbr_offsets"].astype(np.int64)
+    cnt = off[ids + 1] - off[ids]
+    lo = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)
+    nb = np.concatenate([w["nbr_ids"][off[a]:off[a + 1]] for a in ids]) if len(ids) else np.zeros(0, np.int32)
+    ro, rows = E.generate_lsc(cfg, plans, goals, w["radius"], w["downwash"], lo, nb, local_ids=ids.astype(np.int32))
+    return E.plan_batch(cfg, agents[ids], ro, rows, w["sfc"][ids], 0, True)
+
+
+def _stress_advance(cfg, prev_plans, agents, res, ids):
+    """What dlscqp_advance_device does between two steps, for the agents `ids`: fail-safe, sub-goal, state := plan(dt)."""
+    ok = res["status"] == 0
+    shifted = np.concatenate([prev_plans[ids][:, 1:], np.repeat(prev_plans[ids][:, -1:, -1:], cfg.n + 1, axis=2)], axis=1)
+    plans = np.where(ok[:, None, None, None], res["ctrl"], shifted).astype(np.float32)
+    ag = agents[ids].copy()
+    gok = res["goal_status"] != 1
+    ag["current_goal_point"] = np.where(gok[:, None], res["goal"], ag["current_goal_point"])
+    s1, s2 = np.float32(cfg.n / cfg.dt), np.float32((cfg.n - 1) / cfg.dt)
+    c0, c1, c2 = plans[:, 1, 0], plans[:, 1, 1], plans[:, 1, 2]
+    v0, v1 = (c1 - c0) * s1, (c2 - c1) * s1
+    ag["position"], ag["velocity"], ag["acceleration"] = c0, v0, (v1 - v0) * s2
+    return plans, ag
+
+
+def _stress_worker(rank, world, port, q):
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    sys.path.insert(0, here)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg, w = _stress_inputs()
+    N = len(w["agents"])
+    lo, hi = sharding.shard_range(N, rank, world)
+    own = np.arange(lo, hi)
+    off = w["nbr_offsets"].astype(np.int64)
+    halo = sharding.halo_agents(off[lo:hi + 1] - off[lo], w["nbr_ids"][off[lo]:off[hi]], lo, hi)
+    interior = [a for a in range(hi - lo) if a not in set(halo)]
+    E3 = cfg.M * (cfg.n + 1) * 3
+    xchg = sharding.PlanExchange(dist, world, hi - lo, (E3, 3, 1), torch.device("cpu"))
+    # step 0: everybody holds the initial table; plan the own shard, post the plans
+    r0 = _stress_plan(cfg, w, own, w["plans"], w["goals"], w["agents"])
+    xchg.post(torch.from_numpy(r0["ctrl"].reshape(hi - lo, -1)), torch.from_numpy(r0["goal"]), torch.from_numpy(r0["status"].reshape(-1, 1)))
+    own_plans, own_agents = _stress_advance(cfg, w["plans"], w["agents"], r0, own)
+    # step 1, interior agents first: the table holds only this rank's new plans, the remote part has NOT arrived (poison)
+    plans1 = np.full_like(w["plans"], 1.0e6)
+    goals1 = np.full_like(w["goals"], -1.0e6)
+    agents1 = w["agents"].copy()
+    plans1[lo:hi], goals1[lo:hi], agents1[lo:hi] = own_plans, own_agents["current_goal_point"], own_agents
+    res_i = _stress_plan(cfg, w, lo + np.asarray(interior, np.int64), plans1, goals1, agents1)
+    # the exchange has completed: the whole table (fail-safe for agents whose QP failed: their shifted previous plan)
+    ctrl_all, goal_all, st_all = xchg.unpack(xchg.table(), (torch.float32, torch.float32, torch.int32))
+    ctrl_all = ctrl_all.numpy().reshape(N, cfg.M, cfg.n + 1, 3)
+    st_all = st_all.numpy().reshape(-1)
+    shifted = np.concatenate([w["plans"][:, 1:], np.repeat(w["plans"][:, -1:, -1:], cfg.n + 1, axis=2)], axis=1)
+    plans1 = np.where((st_all == 0)[:, None, None, None], ctrl_all, shifted).astype(np.float32)
+    # a failed goal LP keeps the previous sub-goal; the LP verdict does not travel, but the posted sub-goal of such an agent is its
+    # old one already (dlscqp_advance_device writes current_goal before the exchange packs it): emulate by the same rule
+    goals1 = goal_all.numpy().copy()
+    res_h = _stress_plan(cfg, w, lo + np.asarray(halo, np.int64), plans1, goals1, agents1)
+    out = {k: np.zeros((hi - lo,) + res_i[k].shape[1:], res_i[k].dtype) for k in ("status", "goal_status", "goal", "ctrl")}
+    for k in out:
+        out[k][interior] = res_i[k]
+        out[k][halo] = res_h[k]
+    q.put((rank, lo, hi, len(interior), len(halo), out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_stress_batch_interior_then_halo_over_two_ranks_equals_one_process():
+    """DESIGN.md section 5 on the stress workload (every shard cuts through the crowd): two gloo ranks plan step 0, exchange
+    their plans with ONE all-gather, and plan step 1 in two parts -- the interior agents before the exchange has been
+    awaited (the remote part of their plan table is poison), the halo agents after it.  Bit-identical to one process that
+    holds the complete table all along."""
+    cfg, w = _stress_inputs()
+    N = len(w["agents"])
+    allids = np.arange(N)
+    r0 = _stress_plan(cfg, w, allids, w["plans"], w["goals"], w["agents"])
+    plans1, agents1 = _stress_advance(cfg, w["plans"], w["agents"], r0, allids)
+    # the sub-goal table after step 0 as the exchange carries it: the LP's result (kept as is for the comparison)
+    ref = _stress_plan(cfg, w, allids, plans1, r0["goal"], agents1)
+    assert (ref["status"] == 0).mean() > 0.5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_stress_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, lo, hi, n_int, n_halo, out in got:
+        assert n_int > 5 and n_halo > 5, (rank, n_int, n_halo)
+        for k in ("status", "goal_status", "goal", "ctrl"):
+            assert np.array_equal(out[k], ref[k][lo:hi]), (rank, k)

@@ -207,20 +207,21 @@ def test_forest_mission_with_spinning_obstacles(gpu_required):
     """BASELINE.json configs[3]: the reference's forest10_spin4_100 mission in its own launch shape
     (testall_DLSCGC_3D.launch: 3-D, M = 10, communication range 3, octomap forest, four obstacles circling the arena at the
     agents' top speed with slack variables: 220 variables, 124 reduced dimensions, a working set beyond the LDS of a CU --
-    the kernel variant with its working set in HBM).  Corridors, half-spaces (agents + dynamic obstacles), goal LP and QP
-    on the device, waypoints from the host-side PIBT stand-in.  Checked: at sampled steps the device's plans equal the
-    CPU oracle's on the very inputs of that step (verdicts identical, control points <= 1e-4 relative); agents never
-    closer to each other than the collision distance nor to a tree cell than their radius; fail-safes stay rare; every
-    agent arrives (the obstacles disappear after obs/duration = 60 s as in the launch file).  Clearance to the spinning
-    obstacles is reported, not asserted: those rows are soft by design (slack variables) and the reference's own
-    obstacle-aware waypoint logic (grid_based_planner.cpp:196-250) is not part of the stand-in."""
+    the kernel variant with its working set in HBM).  Corridors, half-spaces (agents + dynamic obstacles), waypoint trap,
+    goal LP and QP on the device; waypoints from the reference's own planner restated on the host (row N4: warning nodes,
+    obstacles of interest from the QP's collision alerts, escape goals, PIBT).  Checked: at sampled steps the device's plans
+    equal the CPU oracle's on the very inputs of that step (verdicts identical, control points <= 1e-4 relative); agents
+    never closer to each other than the collision distance, to a tree cell than their radius, or to a spinning obstacle
+    than the sum of the radii (the obstacles move at the agents' top speed); fail-safes stay rare; every agent arrives.
+    (With round 1's simplified waypoint stand-in the same mission took 65 s and had one obstacle contact.)"""
     import oracle_lib
     from dlsc_gc_planner_amd.harness import SpinObstacles
     m = json.load(open(os.path.join(HERE, "golden", "world_forest1.json")))
     cfg = abi.make_config(dim=m["dim"], M=m["M"], dt=m["dt"], control_input_weight=0.01, terminal_weight=1.0,
                           communication_range=m["communication_range"], slack_collision_weight=m["slack_collision_weight"],
                           world_use_octomap=True, world_min=tuple(m["world"][:3]), world_max=tuple(m["world"][3:]))
-    world = dict(boxes=m["boxes"], resolution=m["world_resolution"], grid_resolution=m["grid_resolution"], pibt=True)
+    world = dict(boxes=m["boxes"], resolution=m["world_resolution"], grid_resolution=m["grid_resolution"], pibt="reference",
+                 uncertainty_horizon=m["uncertainty_horizon"])
     spin = SpinObstacles(m["obstacles"])
     sim = ClosedLoop(cfg, np.array(m["start"], np.float32), np.array(m["goal"], np.float32), radius=m["radius"],
                      downwash=m["downwash"], max_vel=m["max_vel"], max_acc=m["max_acc"], nominal_velocity=1.0,
@@ -234,13 +235,13 @@ def test_forest_mission_with_spinning_obstacles(gpu_required):
                                          grid_resolution=m["grid_resolution"], max_vel=m["max_vel"], dt=cfg.dt)
         boxes_checked = 0
         for k in range(500):
-            sample = k % 12 == 5 and k < 320
+            sample = k % 3 == 1 and k < 320
             if sample:  # what the corridor generator is about to read
                 before = [t.cpu().numpy().copy() for t in (sim.init_buf, sim.cur_goal, sim.sfc.sfcs)]
             status, _ = sim.step()
             fails += int((status != abi.OK).sum())
             if sample:
-                agents, ro, rows, sfc, D = sim.step_inputs()
+                agents, ro, rows, sfc, D = sim.step_inputs()  # rows as the LP + QP saw them, i.e. after the waypoint trap
                 # row N2 in 3-D: the step's corridor boxes against the oracle's restatement, bit for bit
                 for a in range(sim.N):
                     _, box = sfc_oracle.construct(before[0][a], before[1][a], agents["next_waypoint"][a], before[2][a])
@@ -271,8 +272,9 @@ def test_forest_mission_with_spinning_obstacles(gpu_required):
           checked, "worst control-point difference", worst_err, "| corridor boxes equal to the oracle's:", boxes_checked)
     assert checked >= 100 and boxes_checked >= 2000
     assert worst >= 1.0 and wall >= m["radius"] - 1e-4
-    assert fails <= 0.01 * 500 * sim.N
-    assert done is not None and done <= 100.0
+    assert wobs >= 1.0  # no contact with the spinning obstacles
+    assert fails <= 5
+    assert done is not None and done <= 30.0
 
 
 @pytest.mark.parametrize("with_world", [False, True])
