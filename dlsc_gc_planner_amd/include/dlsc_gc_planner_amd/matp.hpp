@@ -20,11 +20,19 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstring>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
 
+// the C ABI: -I<repo>/include (or wherever dlscqp.h is installed); the relative path is the in-tree fallback
+#if defined(__has_include) && __has_include(<dlscqp.h>)
+#include <dlscqp.h>
+#else
 #include "../../../include/dlscqp.h"
+#endif
 
 #define SP_EPSILON 1e-9        // sp_const.hpp:3
 #define SP_EPSILON_FLOAT 1e-5  // sp_const.hpp:4
@@ -264,6 +272,34 @@ inline dlscqp_config make_config(const Param &p, const Mission &m) {
 
 inline void put(float dst[3], const point3d &p) { dst[0] = p.x(); dst[1] = p.y(); dst[2] = p.z(); }
 
+// One device context per distinct configuration, shared by every optimizer object of the process.  The reference
+// constructs a TEMPORARY GoalOptimizer per agent per replanning step (traj_planner.cpp:493-495) and one TrajOptimizer per
+// agent (:29); a context (host tables, null-space QR, M Cholesky factors, device uploads, a stream) costs milliseconds to
+// build, so constructing an optimizer must not build one: it looks its configuration up here (a memcmp of 144 bytes under
+// a mutex).  Contexts live until the process ends (never destroyed: no ordering problem with the HIP runtime's own
+// teardown).  The library's entry points are synchronous on the context's stream, so sharing is safe for the reference's
+// single caller thread; concurrent callers are serialised by `use`.
+struct SharedContext {
+    dlscqp_config cfg;
+    dlscqp_ctx *ctx = nullptr;
+    std::mutex use;
+};
+inline std::shared_ptr<SharedContext> acquire_context(const dlscqp_config &c) {
+    static std::mutex mu;
+    static std::vector<std::shared_ptr<SharedContext>> *cache = new std::vector<std::shared_ptr<SharedContext>>();
+    std::lock_guard<std::mutex> lock(mu);
+    for (auto &e : *cache)
+        if (std::memcmp(&e->cfg, &c, sizeof c) == 0) return e;
+    auto e = std::make_shared<SharedContext>();
+    std::memset(&e->cfg, 0, sizeof e->cfg);
+    e->cfg = c;
+    const int rc = dlscqp_create(&c, &e->ctx);
+    if (rc == DLSCQP_ERR_INVALID_ARGUMENT) throw std::invalid_argument(dlscqp_last_error());  // traj_optimizer.cpp:209, :248
+    if (rc != DLSCQP_SUCCESS) throw std::runtime_error(std::string("[dlscqp] ") + dlscqp_last_error());
+    cache->push_back(e);
+    return e;
+}
+
 // Flatten one agent's constraints exactly in the order populatebyrow visits them
 // (traj_optimizer.cpp:413-450): obstacle, segment, control point.
 inline void marshal(const Param &param, const Agent &agent, const CollisionConstraints &cons, dlscqp_agent &ag,
@@ -315,9 +351,6 @@ public:
     template <class MatrixB>
     TrajOptimizer(const Param &_param, const Mission &_mission, const MatrixB &) : param(_param), mission(_mission) { create(); }
     TrajOptimizer(const Param &_param, const Mission &_mission) : param(_param), mission(_mission) { create(); }
-    ~TrajOptimizer() { dlscqp_destroy(ctx); }
-    TrajOptimizer(const TrajOptimizer &) = delete;
-    TrajOptimizer &operator=(const TrajOptimizer &) = delete;
 
     // traj_optimizer.cpp:18-165.  use_primal_algorithm selects a CPLEX algorithm in the reference; the
     // optimum is unique, so it has no effect here.  Throws PlanningReport::QPFAILED on failure (:152).
@@ -352,8 +385,12 @@ public:
         std::vector<float> ctrl((size_t)N * M * n1 * 3);
         std::vector<double> cost(N), slack((size_t)N * (max_slack > 0 ? max_slack : 1));
         std::vector<int32_t> st(N, DLSCQP_NUMERICAL);
-        int rc = dlscqp_solve_batch(ctx, N, ag.data(), offs.data(), rows.data(), sfc.empty() ? nullptr : sfc.data(),
+        int rc;
+        {
+            std::lock_guard<std::mutex> lock(shared->use);
+            rc = dlscqp_solve_batch(shared->ctx, N, ag.data(), offs.data(), rows.data(), sfc.empty() ? nullptr : sfc.data(),
                                     max_slack, ctrl.data(), cost.data(), max_slack > 0 ? slack.data() : nullptr, st.data());
+        }
         if (rc != DLSCQP_SUCCESS) throw std::runtime_error(std::string("[TrajOptimizer] ") + dlscqp_last_error());
         std::vector<TrajOptResult> out(N);
         status.assign(st.begin(), st.end());
@@ -386,38 +423,33 @@ public:
         return out;
     }
 
-    void updateParam(const Param &_param) {  // traj_optimizer.cpp:167-169
+    // traj_optimizer.cpp:167-169: param is replaced, the cached M, n, dt are NOT refreshed (:7-11)
+    void updateParam(const Param &_param) {
         param = _param;
         dlscqp_config c = detail::make_config(param, mission);
-        if (dlscqp_update_param(ctx, &c) != DLSCQP_SUCCESS)
-            throw std::invalid_argument(std::string("[TrajOptimizer] ") + dlscqp_last_error());
+        c.M = M_cached; c.n = n_cached; c.dt = dt_cached; c.world_dimension = dim_cached; c.phi = phi_cached;
+        shared = detail::acquire_context(c);
     }
 
 private:
     void create() {
-        dlscqp_config c = detail::make_config(param, mission);
-        int rc = dlscqp_create(&c, &ctx);
-        if (rc == DLSCQP_ERR_INVALID_ARGUMENT) throw std::invalid_argument(dlscqp_last_error());  // :209, :248
-        if (rc != DLSCQP_SUCCESS) throw std::runtime_error(std::string("[TrajOptimizer] ") + dlscqp_last_error());
+        shared = detail::acquire_context(detail::make_config(param, mission));
         M_cached = param.M; n_cached = param.n; dt_cached = param.dt;  // traj_optimizer.cpp:7-11
+        dim_cached = param.world_dimension; phi_cached = param.phi;
     }
     Param param;
     Mission mission;
-    dlscqp_ctx *ctx = nullptr;
-    int M_cached = 0, n_cached = 0;
+    std::shared_ptr<detail::SharedContext> shared;
+    int M_cached = 0, n_cached = 0, dim_cached = 0, phi_cached = 0;
     double dt_cached = 0;
 };
 
 class GoalOptimizer {
 public:
-    GoalOptimizer(const Param &_param, const Mission &_mission) : param(_param), mission(_mission) {
-        dlscqp_config c = detail::make_config(param, mission);
-        int rc = dlscqp_create(&c, &ctx);
-        if (rc != DLSCQP_SUCCESS) throw std::runtime_error(std::string("[GoalOptimizer] ") + dlscqp_last_error());
-    }
-    ~GoalOptimizer() { dlscqp_destroy(ctx); }
-    GoalOptimizer(const GoalOptimizer &) = delete;
-    GoalOptimizer &operator=(const GoalOptimizer &) = delete;
+    // cheap: the context of this configuration is shared (detail::acquire_context); the reference constructs one of these per
+    // agent per replanning step (traj_planner.cpp:493-495)
+    GoalOptimizer(const Param &_param, const Mission &_mission)
+        : param(_param), mission(_mission), shared(detail::acquire_context(detail::make_config(_param, _mission))) {}
 
     // goal_optimizer.cpp:7-136; throws PlanningReport::QPFAILED when the LP is really infeasible (:122).
     point3d solve(const Agent &agent, const CollisionConstraints &constraints, const point3d &current_goal_point,
@@ -432,7 +464,11 @@ public:
         int64_t offs[2] = {0, (int64_t)rows.size()};
         float goal[3] = {0, 0, 0};
         int32_t st = DLSCQP_NUMERICAL;
-        int rc = dlscqp_goal_batch(ctx, 1, &ag, offs, rows.data(), sfc.empty() ? nullptr : sfc.data(), goal, &st);
+        int rc;
+        {
+            std::lock_guard<std::mutex> lock(shared->use);
+            rc = dlscqp_goal_batch(shared->ctx, 1, &ag, offs, rows.data(), sfc.empty() ? nullptr : sfc.data(), goal, &st);
+        }
         if (rc != DLSCQP_SUCCESS) throw std::runtime_error(std::string("[GoalOptimizer] ") + dlscqp_last_error());
         if (st == DLSCQP_INFEASIBLE) throw PlanningReport::QPFAILED;
         return point3d(goal[0], goal[1], goal[2]);
@@ -441,7 +477,7 @@ public:
 private:
     Param param;
     Mission mission;
-    dlscqp_ctx *ctx = nullptr;
+    std::shared_ptr<detail::SharedContext> shared;
 };
 
 }  // namespace MATP

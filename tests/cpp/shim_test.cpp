@@ -3,6 +3,7 @@
 // TrajPlanner does (/root/reference/src/traj_planner.cpp:29, 491-496, 737-748).  Run on the GPU box
 // by tests/test_gpu_shim.py.  Exit code 0 = all checks passed.
 #include <cstdio>
+#include <chrono>
 #include <cmath>
 
 #include "../../dlsc_gc_planner_amd/include/dlsc_gc_planner_amd/matp.hpp"
@@ -118,6 +119,32 @@ int main() {
         std::vector<TrajOptResult> rs = opt3.solveBatch(as, cs, st);
         CHECK(st[0] == DLSCQP_INFEASIBLE && st[1] == DLSCQP_OK);
         CHECK(rs[1].total_qp_cost > 0);
+    }
+    // ---- construction cost: the reference builds a temporary GoalOptimizer per agent per step (traj_planner.cpp:493-495) and
+    // hands TrajOptimizer an Eigen matrix B (:29): both must be cheap / compile with any matrix-like argument -----------------
+    {
+        struct FakeMatrixXd { double v[36]; int rows() const { return 6; } };  // stands in for Eigen::MatrixXd (absent here)
+        FakeMatrixXd B{};
+        TrajOptimizer with_b(p3, m3, B);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < 1000; k++) {
+            GoalOptimizer g(p3, m3);
+            (void)g;
+        }
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / 1000;
+        std::printf("GoalOptimizer construction: %.2f us each (shared context)\n", us);
+        CHECK(us < 50.0);
+        // updateParam keeps the cached dimensions (traj_optimizer.cpp:167-169 vs :7-11) and changes the weights
+        Param p4 = p3;
+        p4.M = 7;                       // ignored: M stays as constructed
+        p4.control_input_weight = 0.05;
+        CollisionConstraints none(p3, m3);
+        none.initializeLSC(Obstacles());
+        TrajOptResult before = with_b.solve(a3, none, traj_t(), true);
+        with_b.updateParam(p4);
+        TrajOptResult after = with_b.solve(a3, none, traj_t(), true);
+        CHECK((int)after.desired_traj.size() == p3.M);
+        CHECK(std::fabs(after.total_qp_cost - before.total_qp_cost) > 1e-9);
     }
     // ---- unsupported degree: std::invalid_argument like traj_optimizer.cpp:209 ------------------------
     {
