@@ -388,3 +388,26 @@ def test_weak_duality_test_never_changes_a_verdict_on_the_device(gpu_required):
     assert np.array_equal(a["x"][ok], c["x"][ok])
     assert a["iters"][:, 0].max() < c["iters"][:, 0].max() and a["iters"][:, 0].sum() < c["iters"][:, 0].sum()
     assert (a["status"] == abi.INFEASIBLE).sum() > 1000
+
+
+def test_tolerance_boundaries_on_the_device(gpu_required):
+    """tests/edge_cases.py through the C ABI: QPs infeasible by 0.5x / 2x the assumed CPLEX feasibility tolerance, goal LPs
+    with an empty interval below / above it, and the reference's own 1e-5 fallback boundary -- same side as the oracle."""
+    import edge_cases as X
+    for dim, M in ((3, 5), (2, 10)):
+        cfg = abi.make_config(dim=dim, M=M)
+        opt = BatchTrajOptimizer(cfg)
+        try:
+            cases = [X.opposing_rows_qp(cfg, g) for g in (0.0, 0.5e-6, 2e-6, 1e-3)]
+            cases += [X.goal_lp_case(cfg, g, 0.0) for g in (0.5e-6, 2e-6)]
+            cases += [X.goal_lp_fallback_case(cfg, v) for v in (0.5e-5, 2e-5)]
+            agents = np.concatenate([c[0] for c in cases])
+            rows = np.concatenate([c[1] for c in cases])
+            ro = np.concatenate([[0], np.cumsum([len(c[1]) for c in cases])])
+            got = opt.plan(agents, ro, rows, None, 0, True, True)
+        finally:
+            opt.close()
+        ref = oracle_lib.plan_batch(cfg, agents, ro, rows, None, 0, True)
+        _compare(cfg, got, ref)
+        assert list(ref["status"][:4]) == [abi.OK, abi.OK, abi.INFEASIBLE, abi.INFEASIBLE]
+        assert list(ref["goal_status"][4:]) == [abi.OK, abi.INFEASIBLE, abi.GOAL_FALLBACK, abi.INFEASIBLE]
