@@ -291,14 +291,18 @@ __global__ __launch_bounds__(64) void dlscqp_lsc_kernel(LscGenArgs g) {
     const int p0 = g.nbr_offsets[k], p1 = g.nbr_offsets[k + 1];
     const int per = g.M * g.n1 - g.phi;
     const size_t pair0 = (size_t)p0 + (size_t)k * g.n_dyn;  // pairs (agent, obstacle) before this agent's
-    const int items = (p1 - p0) * g.M;
+    // items in NEIGHBOUR-major order: consecutive lanes read consecutive segments of one neighbour's plan and write one
+    // contiguous block of rows.  (Segment-major order, which would keep the lanes of a wavefront on one kind of item -- hull
+    // problem vs. the last segment's segment-segment problem -- was measured: the stress batch's step went from 0.51 to
+    // 0.74 ms; the kernel is bound by its scattered plan reads and row writes, not by the branch.)
+    const int nn = p1 - p0, items = nn * g.M;
     for (int it = threadIdx.x; it < items; it += 64) {
         const int j = it / g.M, m = it - j * g.M;
         lsc_item(g, self, g.nbr_ids[p0 + j], m, (size_t)per * (pair0 + j));
     }
     for (int it = threadIdx.x; it < g.n_dyn * g.M; it += 64) {  // dynamic obstacles after the neighbour agents
         const int o = it / g.M, m = it - o * g.M;
-        lsc_dyn_item(g, self, o, m, (size_t)per * (pair0 + (p1 - p0) + o));
+        lsc_dyn_item(g, self, o, m, (size_t)per * (pair0 + nn + o));
     }
 }
 
@@ -340,16 +344,36 @@ __global__ __launch_bounds__(64) void dlscqp_trap_kernel(TrapArgs t) {
     if (t.out_released && threadIdx.x == 0) t.out_released[k] = released;
 }
 
-// one wavefront per agent grows / shifts its corridor boxes (sfc_core.hpp).  Control flow is
-// wave-uniform; the lanes share the lattice points of the slab under test.
+// one WORKGROUP of SFC_THREADS threads per agent grows / shifts its corridor boxes (sfc_core.hpp).
+// Control flow is workgroup-uniform (every decision comes out of any_of); the threads share the lattice points of the slab
+// under test.  The routine is a chain of a few dozen trial expansions, each a table lookup per lattice point (dependent
+// L2 reads): latency, not throughput -- so the points of a slab (several hundred in the reference's 2.5 m high worlds) are
+// spread over eight wavefronts instead of being walked 64 at a time by one (10-agent maze step: 0.96 -> see profiles/).
+constexpr int SFC_THREADS = 512;
 struct WaveSfc {
     int lane;
+    int *flags;            // LDS [2][SFC_THREADS / 64]: one verdict per wavefront, double-buffered by round
+    mutable int parity = 0;
+    // workgroup-wide OR without a lane-divergent region (the library's __syncthreads_or has one): every lane of a
+    // wavefront stores the wavefront's ballot verdict to the same word, one barrier, every thread reads all words.  The
+    // buffers alternate, so a round's stores cannot meet the previous round's loads.
+    __device__ __forceinline__ bool block_or(bool v) const {
+        constexpr int NW = SFC_THREADS / 64;
+        int *fl = flags + parity * NW;
+        parity ^= 1;
+        fl[lane >> 6] = __ballot(v) != 0ull ? 1 : 0;
+        __syncthreads();
+        int r = 0;
+#pragma unroll
+        for (int k = 0; k < NW; k++) r |= fl[k];
+        return r != 0;
+    }
     template <class F>
     __device__ __forceinline__ bool any_of(int n, F f) const {
-        for (int base = 0; base < n; base += 64) {
+        for (int base = 0; base < n; base += SFC_THREADS) {
             const int idx = base + lane;
-            const bool v = f(idx < n ? idx : n - 1) & (idx < n);  // every lane evaluates a valid point
-            if (__ballot(v) != 0ull) return true;
+            const bool v = f(idx < n ? idx : n - 1) & (idx < n);  // every thread evaluates a valid point
+            if (block_or(v)) return true;
         }
         return false;
     }
@@ -370,7 +394,7 @@ struct WaveSfc {
     }
     __device__ __forceinline__ void fence() const {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
 };
@@ -385,11 +409,13 @@ struct SfcGenArgs {
     int32_t *out_code;
 };
 
-__global__ __launch_bounds__(64) void dlscqp_sfc_kernel(SfcGenArgs a) {
+__global__ __launch_bounds__(SFC_THREADS) void dlscqp_sfc_kernel(SfcGenArgs a) {
     const int ag = blockIdx.x;
     if (ag >= a.n_agents) return;
+    __shared__ int sfc_flags[2 * (SFC_THREADS / 64)];
     WaveSfc w;
     w.lane = (int)threadIdx.x;
+    w.flags = sfc_flags;
     SfcParams p;
     p.margin = a.radius[ag];
     p.grid_resolution = a.grid_resolution;
@@ -922,7 +948,7 @@ extern "C" int dlscqp_generate_sfc_device(dlscqp_ctx *c, const dlscqp_world *wor
     a.radius = gen->radius; a.max_vel = gen->max_vel;
     a.position = gen->position; a.initial_traj = gen->initial_traj; a.goals = gen->goals; a.waypoints = gen->waypoints;
     a.sfcs = gen->sfcs; a.out_code = gen->out_code;
-    hipLaunchKernelGGL(dlscqp_sfc_kernel, dim3(gen->n_agents), dim3(64), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(dlscqp_sfc_kernel, dim3(gen->n_agents), dim3(SFC_THREADS), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return DLSCQP_SUCCESS;
 }

@@ -214,13 +214,17 @@ template <class W>
 DQ_FN int sfc_construct(const W &w, const SfcWorldView &g, const SfcParams &p, const float *initial_traj, int M, int n1,
                         const float *goal, const float *waypoint, float *sfcs) {
     float cur[6], nxt[6];
+    // W::fence() orders the global accesses of all threads that work on this agent (GPU: several wavefronts): every thread has
+    // read box m + 1 before any thread overwrites it in the next iteration
     for (int m = 0; m < M - 1; m++) {  // shift, then the minor refinement reads the shifted boxes
         w.load6(sfcs + 6 * (m + 1), nxt);
+        w.fence();
         w.store6(sfcs + 6 * m, nxt);
     }
     w.fence();
     for (int m = 0; m < M - 2; m++) {
         w.load6(sfcs + 6 * (m + 1), nxt);
+        w.fence();
         if (sfc_superset_of_hull(nxt, initial_traj + (size_t)m * n1 * 3, n1)) {
             w.store6(sfcs + 6 * m, nxt);
             w.fence();
@@ -235,6 +239,7 @@ DQ_FN int sfc_construct(const W &w, const SfcWorldView &g, const SfcParams &p, c
     float upd[6];
     int code = 0;
     w.load6(sfcs + 6 * (M - 1), cur);
+    w.fence();
     if (!sfc_from_hull(w, g, p, hull, 3, (const float *)nullptr, upd)) {
         code = 1;
         if (!sfc_from_hull(w, g, p, hull, 2, cur, upd)) {
