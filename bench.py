@@ -395,7 +395,8 @@ def main():
     # replanning step earlier (for the first batch: of the last one) -- never by the batch's own counts
     iters = [db.out_iters.cpu().numpy()[:, 0].copy() for db in dbs]
     hint = [np.argsort(-iters[(j - 1) % B], kind="stable").astype(np.int32) for j in range(B)]
-    hint_corr = float(np.mean([np.corrcoef(iters[(j - 1) % B], iters[j])[0, 1] for j in range(B)])) if B > 1 else 1.0
+    with np.errstate(invalid="ignore", divide="ignore"):
+        hint_corr = float(np.nan_to_num(np.mean([np.corrcoef(iters[(j - 1) % B], iters[j])[0, 1] for j in range(B)]))) if B > 1 else 1.0
 
     pipelined_ok = False
     xchg = None
@@ -581,8 +582,8 @@ def main():
                 "exchange_modes_ms_per_step": exch,
                 "launch_order": "iteration counts of the previous replanning step (a different batch), descending; correlation of "
                                 "consecutive steps' counts %.2f" % hint_corr,
-                "ms_per_step_no_order_hint": el_nohint / side_steps * 1e3,
-                "qp_per_s_no_order_hint": world * N * side_steps / el_nohint,
+                "ms_per_step_no_order_hint": None if args.headline_only else el_nohint / side_steps * 1e3,
+                "qp_per_s_no_order_hint": None if args.headline_only else world * N * side_steps / el_nohint,
                 "solved_fraction": float(ok.mean()), "mean_active_set_iterations": float(it[:, 0].mean()),
                 "max_active_set_iterations": int(it[:, 0].max()), "zero_iteration_fraction": float((it[:, 0] == 0).mean()),
                 "seed": args.seed, "workload_generation_s": t_gen,
