@@ -72,7 +72,7 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         for i, flags in enumerate(flags_list):
             so = os.path.join(tmp, "v%d.so" % i)
-            cmd = "hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -ffp-contract=off %s %s -o %s dlscqp.hip qp_tables.cpp sfc_world.cpp" % (
+            cmd = "hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -ffp-contract=off %s %s -o %s dlscqp.hip qp_tables.cpp sfc_world.cpp grid_mapf.cpp" % (
                 "" if full else "-DDLSCQP_ONLY_G2", flags, so)
             t0 = time.time()
             p = subprocess.run(cmd, shell=True, cwd=CSRC, capture_output=True, text=True)

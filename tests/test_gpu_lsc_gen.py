@@ -187,3 +187,27 @@ def test_waypoint_trap_and_disturbance_reset_on_the_device(gpu_required):
         assert rel == released[a]
         for k in ("normal", "point", "d"):
             assert np.array_equal(after[ro[a]:ro[a + 1]][k], exp[k]), (a, k)
+
+
+def test_device_rows_against_the_oracle_running_the_references_own_gjk(gpu_required):
+    """oracle/_ref/libref_gjk.so is the reference's openGJK compiled from its own sources (oracle/Makefile); it travels to the
+    GPU box.  With it plugged into the oracle as the point-to-hull routine, the device's half-spaces (exact hull
+    enumeration instead of iterative GJK) still agree to float32 rounding."""
+    if O.ref_gjk() is None:
+        pytest.skip("oracle/_ref/libref_gjk.so not built (needs /root/reference at build time)")
+    cfg = abi.make_config(dim=3, M=10)
+    sw = lsc_cases.random_swarm(cfg, 24, seed=909)
+    O.use_reference_gjk(True)
+    try:
+        ro, rows = _oracle_rows(cfg, sw, False)
+    finally:
+        O.use_reference_gjk(False)
+    opt = BatchTrajOptimizer(cfg)
+    try:
+        gen = opt.make_lsc_generator(24, sw["nbr_offsets"], sw["nbr_ids"], sw["radius"], sw["downwash"])
+        gen.generate(torch.from_numpy(sw["goals"]).cuda(), plans=torch.from_numpy(sw["plans"]).cuda())
+        go, grows = gen.rows_host()
+    finally:
+        opt.close()
+    assert np.array_equal(ro, go) and len(rows) > 1000
+    _cmp_rows(grows, rows)
