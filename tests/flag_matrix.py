@@ -17,17 +17,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "dlsc_gc_planner_amd", "csrc")
 # Notes.  "-mllvm -disable-machine-cse" makes this compiler emit s_mov_b64 with 64-bit literals (1.5 came out as
 # s_mov_b64 s[2:3], 0x3ff8000000000000, which gfx950 cannot encode: the low half, 0, is what the hardware gets), so
-# the kernel avoids non-inline double constants on scalar paths (f + 0.5 f instead of 1.5 f).  The two -O0-style
-# allocators are not in the list: "-mllvm -sgpr-regalloc=fast" gives wrong verdicts in the generic instantiations and
-# "-mllvm -vgpr-regalloc=fast" (4 KB of scratch per lane) faults in two batches; the same source is clean under
-# address/undefined sanitizers in the lane-serial host build, neither was pursued.
+# the kernel avoids non-inline double constants on scalar paths (f + 0.5 f instead of 1.5 f).  "-mllvm -sgpr-regalloc=fast" gave
+# wrong verdicts in the generic instantiations in round 1; on the round-2 source it is clean (all twelve golden batches, default
+# and forced-generic dispatch) and is part of the list.  Under it the compiler emits ~400 whole-wave-mode save / restore
+# regions around the spills of the VGPRs that carry spilled SGPRs (tests/divergence_check.py -v -mllvm -sgpr-regalloc=fast); a scan
+# of the generated code found no SCC or EXEC value clobbered across them, and the round-1 failure could not be reproduced to
+# bisect it.  "-mllvm -vgpr-regalloc=fast" (4 KB of scratch per lane) faulted in two batches in round 1 and is not in the list.
 FLAGS = ["", "-O2", "-O1", "-fno-unroll-loops",
          "-mllvm -amdgpu-waitcnt-forcezero=1", "-mllvm -amdgpu-dpp-combine=false", "-mllvm -enable-misched=false",
          "-mllvm -enable-post-misched=false", "-mllvm -amdgpu-load-store-vectorizer=false",
          "-mllvm -amdgpu-scalarize-global-loads=false", "-mllvm -amdgpu-sdwa-peephole=false",
          "-mllvm -amdgpu-opt-exec-mask-pre-ra=false", "-mllvm -disable-machine-licm", "-mllvm -disable-machine-sink",
          "-mllvm -disable-machine-cse", "-mllvm -disable-peephole", "-mllvm -disable-branch-fold",
-         "-mllvm -vgpr-regalloc=basic", "-mllvm -sgpr-regalloc=basic",
+         "-mllvm -vgpr-regalloc=basic", "-mllvm -sgpr-regalloc=basic", "-mllvm -sgpr-regalloc=fast",
          "-mllvm -amdgpu-enable-rewrite-partial-reg-uses=false", "-mllvm -amdgpu-use-aa-in-codegen=false",
          "-mllvm -amdgpu-opt-vgpr-liverange=false", "-mllvm -split-spill-mode=size", "-mllvm -split-spill-mode=speed",
          "-mllvm -greedy-reverse-local-assignment", "-mllvm -join-liveintervals=false",
