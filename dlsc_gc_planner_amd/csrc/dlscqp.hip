@@ -282,9 +282,12 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
 #endif
 }
 
-// one wavefront per local agent, lanes over its (neighbour, segment) items; every item is
-// independent and writes its own 6 (3) rows of the SoA arrays (lsc_core.hpp).
-__global__ __launch_bounds__(64) void dlscqp_lsc_kernel(LscGenArgs g) {
+// one workgroup of LSC_THREADS threads per local agent, threads over its (neighbour, segment) items; every
+// item is independent and writes its own 6 (3) rows of the SoA arrays (lsc_core.hpp).  Four wavefronts per agent instead of
+// one: an agent of the stress batch has ~440 items of a few thousand instructions each behind scattered reads of its
+// neighbours' plans, and a grid of one wavefront per agent leaves the SIMDs with two wavefronts to hide that behind.
+constexpr int LSC_THREADS = 256;
+__global__ __launch_bounds__(LSC_THREADS) void dlscqp_lsc_kernel(LscGenArgs g) {
     const int k = blockIdx.x;
     if (k >= g.n_local) return;
     const int self = g.local_ids ? g.local_ids[k] : k;
@@ -296,11 +299,11 @@ __global__ __launch_bounds__(64) void dlscqp_lsc_kernel(LscGenArgs g) {
     // problem vs. the last segment's segment-segment problem -- was measured: the stress batch's step went from 0.51 to
     // 0.74 ms; the kernel is bound by its scattered plan reads and row writes, not by the branch.)
     const int nn = p1 - p0, items = nn * g.M;
-    for (int it = threadIdx.x; it < items; it += 64) {
+    for (int it = threadIdx.x; it < items; it += LSC_THREADS) {
         const int j = it / g.M, m = it - j * g.M;
         lsc_item(g, self, g.nbr_ids[p0 + j], m, (size_t)per * (pair0 + j));
     }
-    for (int it = threadIdx.x; it < g.n_dyn * g.M; it += 64) {  // dynamic obstacles after the neighbour agents
+    for (int it = threadIdx.x; it < g.n_dyn * g.M; it += LSC_THREADS) {  // dynamic obstacles after the neighbour agents
         const int o = it / g.M, m = it - o * g.M;
         lsc_dyn_item(g, self, o, m, (size_t)per * (pair0 + nn + o));
     }
@@ -757,7 +760,7 @@ extern "C" int dlscqp_generate_lsc_device(dlscqp_ctx *c, const dlscqp_lsc_gen *g
     LscGenArgs g;
     const int rc = lsc_gen_args(c, gen, &g);
     if (rc != DLSCQP_SUCCESS) return rc;
-    hipLaunchKernelGGL(dlscqp_lsc_kernel, dim3(gen->n_local), dim3(64), 0, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(dlscqp_lsc_kernel, dim3(gen->n_local), dim3(LSC_THREADS), 0, (hipStream_t)stream, g);
     HIP_TRY(hipGetLastError());
     return DLSCQP_SUCCESS;
 }
