@@ -883,7 +883,7 @@ extern "C" int dlscqp_advance_device(dlscqp_ctx *c, const dlscqp_advance *adv, v
 struct dlscqp_world {
     int device;
     SfcWorldView view;  // device pointers
-    void *d_near_d2, *d_near_off, *d_near_n;
+    void *d_near;
 };
 
 extern "C" int dlscqp_world_create(dlscqp_ctx *c, const double *boxes, int32_t n_boxes, double resolution,
@@ -898,7 +898,7 @@ extern "C" int dlscqp_world_create(dlscqp_ctx *c, const double *boxes, int32_t n
     build_sfc_world(boxes, n_boxes, resolution, world_min, world_max, hw);
     dlscqp_world *w = new dlscqp_world();
     w->device = c->cfg.device;
-    w->d_near_d2 = w->d_near_off = w->d_near_n = nullptr;
+    w->d_near = nullptr;
     const size_t nc = hw.cells();
     auto fail = [&](hipError_t e, const char *what) {
         g_last_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -906,20 +906,14 @@ extern "C" int dlscqp_world_create(dlscqp_ctx *c, const double *boxes, int32_t n
         return DLSCQP_ERR_HIP;
     };
     hipError_t e;
-    if ((e = hipMalloc(&w->d_near_d2, nc * sizeof(int))) != hipSuccess) return fail(e, "hipMalloc");
-    if ((e = hipMalloc(&w->d_near_off, nc * 24)) != hipSuccess) return fail(e, "hipMalloc");
-    if ((e = hipMalloc(&w->d_near_n, nc)) != hipSuccess) return fail(e, "hipMalloc");
-    if ((e = hipMemcpy(w->d_near_d2, hw.near_d2.data(), nc * sizeof(int), hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
-    if ((e = hipMemcpy(w->d_near_off, hw.near_off.data(), nc * 24, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
-    if ((e = hipMemcpy(w->d_near_n, hw.near_n.data(), nc, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
+    if ((e = hipMalloc(&w->d_near, nc * 32)) != hipSuccess) return fail(e, "hipMalloc");
+    if ((e = hipMemcpy(w->d_near, hw.near_packed.data(), nc * 32, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
     w->view.res = hw.res;
     for (int k = 0; k < 3; k++) {
         w->view.wmin[k] = hw.wmin[k]; w->view.wmax[k] = hw.wmax[k];
         w->view.lo[k] = hw.lo[k]; w->view.n[k] = hw.n[k];
     }
-    w->view.near_d2 = (const int *)w->d_near_d2;
-    w->view.near_off = (const signed char *)w->d_near_off;
-    w->view.near_n = (const unsigned char *)w->d_near_n;
+    w->view.near = (const uint32_t *)w->d_near;
     *out = w;
     return DLSCQP_SUCCESS;
 }
@@ -927,9 +921,7 @@ extern "C" int dlscqp_world_create(dlscqp_ctx *c, const double *boxes, int32_t n
 extern "C" void dlscqp_world_destroy(dlscqp_world *w) {
     if (!w) return;
     (void)hipSetDevice(w->device);
-    if (w->d_near_d2) (void)hipFree(w->d_near_d2);
-    if (w->d_near_off) (void)hipFree(w->d_near_off);
-    if (w->d_near_n) (void)hipFree(w->d_near_n);
+    if (w->d_near) (void)hipFree(w->d_near);
     delete w;
 }
 

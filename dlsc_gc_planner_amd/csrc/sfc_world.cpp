@@ -62,6 +62,13 @@ void build_sfc_world(const double *boxes, int n_boxes, double resolution, const 
                             }
                         }
             }
+    w.near_packed.assign(nc * 8, 0u);
+    for (size_t q = 0; q < nc; q++) {
+        uint32_t *rec = &w.near_packed[q * 8];
+        rec[0] = (uint32_t)w.near_d2[q];
+        rec[1] = (uint32_t)w.near_n[q];
+        for (int i = 0; i < 24; i++) rec[2 + (i >> 2)] |= (uint32_t)(uint8_t)w.near_off[q * 24 + i] << (8 * (i & 3));
+    }
 }
 
 }  // namespace dlscqp

@@ -15,6 +15,7 @@ struct SfcWorldHost {
     std::vector<int> near_d2;
     std::vector<signed char> near_off;
     std::vector<unsigned char> near_n;
+    std::vector<uint32_t> near_packed;  // the three arrays above as one 32-byte record per cell (SfcWorldView::near)
     size_t cells() const { return (size_t)n[0] * n[1] * n[2]; }
 };
 

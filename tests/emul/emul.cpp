@@ -297,7 +297,7 @@ extern "C" int emul_generate_sfc(const dlscqp_config *cfg, const double *boxes, 
     SfcWorldView v;
     v.res = hw.res;
     for (int k = 0; k < 3; k++) { v.wmin[k] = hw.wmin[k]; v.wmax[k] = hw.wmax[k]; v.lo[k] = hw.lo[k]; v.n[k] = hw.n[k]; }
-    v.near_d2 = hw.near_d2.data(); v.near_off = hw.near_off.data(); v.near_n = hw.near_n.data();
+    v.near = hw.near_packed.data();
     WaveSfcCpu w;
     const int M = cfg->M, n1 = cfg->n + 1;
     for (int a = 0; a < gen->n_agents; a++) {
