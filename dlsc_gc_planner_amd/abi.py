@@ -117,6 +117,7 @@ class DeviceBatch(C.Structure):
         ("out_iters", C.c_void_p),
         ("agent_order", C.c_void_p),
         ("debug_stamps", C.c_void_p),
+        ("row_counts", C.c_void_p),
     ]
 
 
@@ -147,6 +148,10 @@ class LscGen(C.Structure):
         ("dyn_downwash", C.c_void_p),
         ("observed_position", C.c_void_p),
         ("reset_threshold", C.c_double),
+        ("prune", C.c_int32),
+        ("reserved_", C.c_int32),
+        ("prune_sfc_boxes", C.c_void_p),
+        ("out_row_counts", C.c_void_p),
     ]
 
 

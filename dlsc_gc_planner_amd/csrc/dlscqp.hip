@@ -200,6 +200,7 @@ struct KernelArgs {
     int slot0, n_slots_launch;  // launch slots [slot0, slot0 + n_slots_launch)
     const dlscqp_agent *agents;
     const int32_t *row_offsets;
+    const int32_t *row_counts;       // optional: rows of agent a = row_counts[a] from row_offsets[a] on
     RowsView rows;
     const float *sfc;
     float *out_goal;
@@ -248,7 +249,7 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
     if (a.out_stamps) w.tr = reinterpret_cast<double *>(a.out_stamps) + (size_t)ag * 1001;
 #endif
 #endif
-    const int rb = a.row_offsets[ag], re = a.row_offsets[ag + 1];
+    const int rb = a.row_offsets[ag], re = a.row_counts ? rb + a.row_counts[ag] : a.row_offsets[ag + 1];
     const int M = kp.M, n1 = kp.n1;
     const size_t xs = (size_t)kp.dim * M * n1 + (size_t)M * a.max_slack_obs;
     plan_agent<RC, DIMS, FS, MS, KU, SU, SLK>(w, kp, lay, smem, a.agents + ag, a.rows, rb, re - rb,
@@ -299,6 +300,49 @@ __global__ __launch_bounds__(LSC_THREADS) void dlscqp_lsc_kernel(LscGenArgs g) {
     // problem vs. the last segment's segment-segment problem -- was measured: the stress batch's step went from 0.51 to
     // 0.74 ms; the kernel is bound by its scattered plan reads and row writes, not by the branch.)
     const int nn = p1 - p0, items = nn * g.M;
+    if (g.row_counts) {
+        // presolve: rows implied by the agent's own box rows are dropped, the others written contiguously in their original
+        // order -- per round of LSC_THREADS items an exclusive prefix sum of the kept-row counts over the workgroup (LDS)
+        __shared__ int scan[LSC_THREADS];
+        __shared__ int base_s;
+        if (threadIdx.x == 0) base_s = 0;
+        __syncthreads();
+        const size_t row0 = (size_t)per * pair0;
+        const int all = items + g.n_dyn * g.M;
+        for (int it0 = 0; it0 < all; it0 += LSC_THREADS) {
+            const int it = it0 + (int)threadIdx.x;
+            LscRows r;
+            r.n = 0;
+            bool keep[6] = {false, false, false, false, false, false};
+            int cnt = 0;
+            if (it < items) {
+                const int j = it / g.M, m = it - j * g.M;
+                lsc_item_rows(g, self, g.nbr_ids[p0 + j], m, r);
+                const float *box = g.prune_sfc ? g.prune_sfc + ((size_t)k * g.M + m) * 6 : nullptr;
+                for (int i = 0; i < r.n; i++) { keep[i] = !lsc_row_implied(g, box, r, i); cnt += keep[i]; }
+            } else if (it < all) {
+                const int q = it - items, o = q / g.M, m = q - o * g.M;
+                lsc_dyn_item_rows(g, self, o, m, r);
+                const float *box = g.prune_sfc ? g.prune_sfc + ((size_t)k * g.M + m) * 6 : nullptr;
+                for (int i = 0; i < r.n; i++) { keep[i] = !lsc_row_implied(g, box, r, i); cnt += keep[i]; }
+            }
+            scan[threadIdx.x] = cnt;
+            __syncthreads();
+            for (int s = 1; s < LSC_THREADS; s <<= 1) {  // Hillis-Steele inclusive scan
+                const int v = (int)threadIdx.x >= s ? scan[threadIdx.x - s] : 0;
+                __syncthreads();
+                scan[threadIdx.x] += v;
+                __syncthreads();
+            }
+            const int base = base_s;
+            if (cnt) lsc_store_rows(g, r, row0 + (size_t)(base + scan[threadIdx.x] - cnt), keep);
+            __syncthreads();
+            if (threadIdx.x == LSC_THREADS - 1) base_s = base + scan[LSC_THREADS - 1];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) g.row_counts[k] = base_s;
+        return;
+    }
     for (int it = threadIdx.x; it < items; it += LSC_THREADS) {
         const int j = it / g.M, m = it - j * g.M;
         lsc_item(g, self, g.nbr_ids[p0 + j], m, (size_t)per * (pair0 + j));
@@ -325,7 +369,9 @@ __global__ __launch_bounds__(64) void dlscqp_trap_kernel(TrapArgs t) {
     const int per = g.M * g.n1 - g.phi;
     const int p0 = g.nbr_offsets[k], p1 = g.nbr_offsets[k + 1];
     const size_t row0 = (size_t)per * ((size_t)p0 + (size_t)k * g.n_dyn);
-    const int n_rows = (p1 - p0) * per;
+    // all rows of the agent: neighbours' and dynamic obstacles' (the latter are ignored by trap_row_excludes); a generator
+    // that pruned rows says how many there are
+    const int n_rows = g.row_counts ? g.row_counts[k] : (p1 - p0 + g.n_dyn) * per;
     const dlscqp_agent *ag = t.agents + k;
     const float *cg = ag->current_goal_point, *wp = ag->next_waypoint;
     bool out = false;
@@ -340,8 +386,10 @@ __global__ __launch_bounds__(64) void dlscqp_trap_kernel(TrapArgs t) {
                                   t.horizon, g.dyn_uncertainty_horizon))
                 continue;
             released++;
-            const size_t r0 = row0 + (size_t)per * ((size_t)(p1 - p0) + o);
-            for (int j = threadIdx.x; j < per; j += 64) trap_empty_row(g, r0 + j);
+            for (int j = threadIdx.x; j < n_rows; j += 64) {  // the rows of obstacle o: dynamic flag, slack variable o
+                const uint32_t key = g.key[row0 + j];
+                if (((key >> 12) & 1) && (int)(key >> 16) == o) trap_empty_row(g, row0 + j);
+            }
         }
     }
     if (t.out_released && threadIdx.x == 0) t.out_released[k] = released;
@@ -681,6 +729,7 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
     a.do_traj = b->do_traj;
     a.agents = b->agents;
     a.row_offsets = b->row_offsets;
+    a.row_counts = b->row_counts;
     a.rows = RowsView{b->nx, b->ny, b->nz, b->px, b->py, b->pz, b->d, b->key};
     a.sfc = c->kp.use_sfc ? b->sfc_boxes : nullptr;
     a.out_goal = b->out_goal;
@@ -749,6 +798,15 @@ static int lsc_gen_args(dlscqp_ctx *c, const dlscqp_lsc_gen *gen, LscGenArgs *ou
     g.reset_threshold = gen->reset_threshold;
     g.comm_range = c->cfg.communication_range;
     g.use_sfc = c->kp.use_sfc;
+    g.prune_sfc = nullptr;
+    g.row_counts = nullptr;
+    if (gen->prune) {
+        if (!gen->out_row_counts || (c->kp.use_sfc && !gen->prune_sfc_boxes)) { g_last_error = "prune: null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+        g.prune_sfc = c->kp.use_sfc ? gen->prune_sfc_boxes : nullptr;
+        g.row_counts = gen->out_row_counts;
+    }
+    g.dim = c->dim;
+    for (int k = 0; k < 3; k++) { g.world_min[k] = c->cfg.world_min[k]; g.world_max[k] = c->cfg.world_max[k]; }
     *out = g;
     return DLSCQP_SUCCESS;
 }

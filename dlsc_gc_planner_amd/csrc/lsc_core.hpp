@@ -229,7 +229,45 @@ struct LscGenArgs {  // device mirror of dlscqp_lsc_gen (include/dlscqp.h)
     double reset_threshold;
     double comm_range;               // param.communication_range (waypoint trap)
     int use_sfc;
+    // presolve (dlscqp_lsc_gen.prune_sfc_boxes): rows implied by the agent's own box rows are not written
+    const float *prune_sfc;          // [n_local][M][6] corridor boxes of the local agents, or null
+    int32_t *row_counts;             // [n_local] rows written per agent (with prune_sfc), or null
+    double world_min[3], world_max[3];
+    int dim;
 };
+
+// One item's rows before they are written: segment m, control points i0 .. i0 + n - 1 (one normal for all of them)
+struct LscRows {
+    float nx, ny, nz;
+    float px[6], py[6], pz[6];
+    double d[6];
+    uint32_t key[6];
+    int n;
+};
+
+constexpr double PRUNE_MARGIN = 1e-4;  // metres by which a row has to be implied before it is dropped
+
+// Is row `i` of `r` implied by the rows of the model that confine control point (m, i) to a box -- the variable bounds
+// (world box, traj_optimizer.cpp:251-265) and the corridor box of segment m (:385-410)?  min over the box of n.c is
+// attained at a corner; if even that corner satisfies n.(c - p) - d >= PRUNE_MARGIN the row can never be active or
+// violated at a point that satisfies the box rows, so the QP and the goal LP have the same solutions without it (what a
+// presolve does; rows with a slack variable included: with the hard row implied, slack 0 is feasible and optimal).
+DQ_FN bool lsc_row_implied(const LscGenArgs &g, const float *box, const LscRows &r, int i) {
+    const float nv[3] = {r.nx, r.ny, r.nz};
+    const float pv[3] = {r.px[i], r.py[i], r.pz[i]};
+    double mn = 0.0, rhs = r.d[i];
+    for (int k = 0; k < 3; k++) {
+        if (k >= g.dim) continue;
+        double lo = g.world_min[k], hi = g.world_max[k];
+        if (g.use_sfc) {
+            lo = (double)box[k] > lo ? (double)box[k] : lo;
+            hi = (double)box[3 + k] < hi ? (double)box[3 + k] : hi;
+        }
+        mn += (double)nv[k] * (nv[k] >= 0 ? lo : hi);
+        rhs += (double)nv[k] * (double)pv[k];
+    }
+    return mn - rhs >= PRUNE_MARGIN;
+}
 
 // control point i of segment m of agent `id`'s initial trajectory (= what the others predict for it)
 DQ_FN F3 initial_point(const LscGenArgs &g, int id, int m, int i) {
@@ -261,15 +299,27 @@ DQ_FN F3 predicted_point(const LscGenArgs &g, int id, int m, int i) {
     return initial_point(g, id, m, i);
 }
 
-// One (pair, segment) item.  `row0`: index of the pair's first row in the SoA arrays.
-DQ_FN void lsc_item(const LscGenArgs &g, int self, int other, int m, size_t row0) {
+DQ_FN void lsc_store_rows(const LscGenArgs &g, const LscRows &r, size_t at, const bool *keep) {
+    for (int i = 0; i < r.n; i++) {
+        if (keep && !keep[i]) continue;
+        g.nx[at] = r.nx; g.ny[at] = r.ny; g.nz[at] = r.nz;
+        g.px[at] = r.px[i]; g.py[at] = r.py[i]; g.pz[at] = r.pz[i];
+        g.d[at] = r.d[i];
+        g.key[at] = r.key[i];
+        at++;
+    }
+}
+
+// One (pair, segment) item: its rows into `out` (nothing is written to memory).
+DQ_FN void lsc_item_rows(const LscGenArgs &g, int self, int other, int m, LscRows &out) {
     const int n = g.n1 - 1, M = g.M;
     const double r_self = g.radius[self], r_oth = g.radius[other];
     const double collision_dist = r_oth + r_self;                                                       // :605
     const double downwash = (g.downwash[self] * r_self + g.downwash[other] * r_oth) / (r_self + r_oth);  // :1150-1153
     const float dwf = (float)downwash;
     // rows of segment 0 start at i = phi (the others are never part of the model, traj_optimizer.cpp:417-419)
-    const size_t rbase = row0 + (m == 0 ? 0 : (size_t)(g.n1 - g.phi) + (size_t)(m - 1) * g.n1);
+    const int i0 = m == 0 ? g.phi : 0;
+    out.n = g.n1 - i0;
     if (m < M - 1) {
         F3 rel[6], pred[6];
         D3 pts[6];
@@ -287,12 +337,12 @@ DQ_FN void lsc_item(const LscGenArgs &g, int self, int other, int m, size_t row0
         cp = f3(0, 0, 0) + cp;
         const F3 nt = normalized(cp);
         const F3 nrm = f3(nt.x, nt.y, (float)((double)nt.z / downwash));  // :634-636
-        for (int i = (m == 0 ? g.phi : 0); i < g.n1; i++) {
-            const size_t r = rbase + (size_t)(i - (m == 0 ? g.phi : 0));
-            g.nx[r] = nrm.x; g.ny[r] = nrm.y; g.nz[r] = nrm.z;
-            g.px[r] = pred[i].x; g.py[r] = pred[i].y; g.pz[r] = pred[i].z;
-            g.d[r] = 0.5 * (collision_dist + dot(rel[i], nt));  // :639-640
-            g.key[r] = DLSCQP_KEY(m, i, -1, 0);
+        out.nx = nrm.x; out.ny = nrm.y; out.nz = nrm.z;
+        for (int i = i0; i < g.n1; i++) {
+            const int r = i - i0;
+            out.px[r] = pred[i].x; out.py[r] = pred[i].y; out.pz[r] = pred[i].z;
+            out.d[r] = 0.5 * (collision_dist + dot(rel[i], nt));  // :639-640
+            out.key[r] = DLSCQP_KEY(m, i, -1, 0);
         }
     } else {
         F3 l1s = predicted_point(g, other, M - 1, n), l2s = initial_point(g, self, M - 1, n);
@@ -307,14 +357,20 @@ DQ_FN void lsc_item(const LscGenArgs &g, int self, int other, int m, size_t row0
         const double dd = 0.5 * (collision_dist + c.dist);
         const F3 nrm = f3(nt.x, nt.y, (float)((double)nt.z / downwash));
         const F3 pt = f3(c.p1.x, c.p1.y, (float)((double)c.p1.z * downwash));
+        out.nx = nrm.x; out.ny = nrm.y; out.nz = nrm.z;
         for (int i = 0; i < g.n1; i++) {
-            const size_t r = rbase + (size_t)i;
-            g.nx[r] = nrm.x; g.ny[r] = nrm.y; g.nz[r] = nrm.z;
-            g.px[r] = pt.x; g.py[r] = pt.y; g.pz[r] = pt.z;
-            g.d[r] = dd;
-            g.key[r] = DLSCQP_KEY(m, i, -1, 0);
+            out.px[i] = pt.x; out.py[i] = pt.y; out.pz[i] = pt.z;
+            out.d[i] = dd;
+            out.key[i] = DLSCQP_KEY(m, i, -1, 0);
         }
     }
+}
+
+// The item's rows at their fixed place: `row0` = index of the pair's first row in the SoA arrays.
+DQ_FN void lsc_item(const LscGenArgs &g, int self, int other, int m, size_t row0) {
+    LscRows r;
+    lsc_item_rows(g, self, other, m, r);
+    lsc_store_rows(g, r, row0 + (m == 0 ? 0 : (size_t)(g.n1 - g.phi) + (size_t)(m - 1) * g.n1), nullptr);
 }
 
 // planConstVelTraj (trajectory.cpp:78-91): control point (m, i) of the constant-velocity prediction; time advances
@@ -341,8 +397,8 @@ DQ_FN Closest line_paths(F3 s1, F3 e1, F3 s2, F3 e2) {
     return c;
 }
 
-// One (agent, dynamic obstacle, segment) item: traj_planner.cpp:616-627.  `row0`: first row of the pair.
-DQ_FN void lsc_dyn_item(const LscGenArgs &g, int self, int o, int m, size_t row0) {
+// One (agent, dynamic obstacle, segment) item: traj_planner.cpp:616-627, rows into `out`.
+DQ_FN void lsc_dyn_item_rows(const LscGenArgs &g, int self, int o, int m, LscRows &out) {
     const int n = g.n1 - 1, M = g.M;
     const double r_self = g.radius[self], r_obs = g.dyn_radius[o];
     const double downwash = (r_self + g.dyn_downwash[o] * r_obs) / (r_self + r_obs);  // :1155-1157
@@ -362,8 +418,10 @@ DQ_FN void lsc_dyn_item(const LscGenArgs &g, int self, int o, int m, size_t row0
     int Mu = (int)((g.dyn_uncertainty_horizon + 1e-9) / g.dt);
     Mu = Mu < M ? Mu : M;
     const double amax = g.dyn_max_acc[o];
-    const size_t rbase = row0 + (m == 0 ? 0 : (size_t)(g.n1 - g.phi) + (size_t)(m - 1) * g.n1);
-    for (int i = (m == 0 ? g.phi : 0); i < g.n1; i++) {
+    const int i0 = m == 0 ? g.phi : 0;
+    out.n = g.n1 - i0;
+    out.nx = nrm.x; out.ny = nrm.y; out.nz = nrm.z;
+    for (int i = i0; i < g.n1; i++) {
         double size = r_obs;
         if (g.dyn_size_prediction) {
             if (m < Mu) {
@@ -376,12 +434,17 @@ DQ_FN void lsc_dyn_item(const LscGenArgs &g, int self, int o, int m, size_t row0
             }
         }
         const F3 pt = const_vel_point(op, ov, g.dt, g.n1, m, i);
-        const size_t r = rbase + (size_t)(i - (m == 0 ? g.phi : 0));
-        g.nx[r] = nrm.x; g.ny[r] = nrm.y; g.nz[r] = nrm.z;
-        g.px[r] = pt.x; g.py[r] = pt.y; g.pz[r] = pt.z;
-        g.d[r] = size + r_self;  // :623
-        g.key[r] = DLSCQP_KEY(m, i, o, 1);
+        const int r = i - i0;
+        out.px[r] = pt.x; out.py[r] = pt.y; out.pz[r] = pt.z;
+        out.d[r] = size + r_self;  // :623
+        out.key[r] = DLSCQP_KEY(m, i, o, 1);
     }
+}
+
+DQ_FN void lsc_dyn_item(const LscGenArgs &g, int self, int o, int m, size_t row0) {
+    LscRows r;
+    lsc_dyn_item_rows(g, self, o, m, r);
+    lsc_store_rows(g, r, row0 + (m == 0 ? 0 : (size_t)(g.n1 - g.phi) + (size_t)(m - 1) * g.n1), nullptr);
 }
 
 // ---- TrajPlanner::checkWaypointTrap (traj_planner.cpp:708-735) ---------------------------------------------------

@@ -198,6 +198,9 @@ class ClosedLoop:
         self.advance = self.opt.make_advance(self.batch, self.plans, self.cur_goal, self.init_buf,
                                              desired_goal=self.desired_goal if world is None else None,
                                              waypoint_step=waypoint_step if world is None else 0.0)
+        if world is not None and world.get("prune", True):
+            # presolve in the half-space generator: rows implied by this step's corridor boxes are never written
+            self.batch.use_row_counts(self.gen.enable_pruning(self.sfc.sfcs))
         self.records_in = torch.zeros_like(self.batch.t["agents"])
         self.released = torch.zeros(N, dtype=torch.int32, device=dev)  # dynamic obstacles released by the waypoint trap, per agent
         self.history = []
@@ -262,18 +265,21 @@ class ClosedLoop:
         what enable_graph() captures."""
         cfg = self.cfg
         dkw = dict(dyn_position=self.dyn_pos, dyn_velocity=self.dyn_vel) if self.D else {}
+        # the corridor boxes do not depend on the half-spaces (constructLSC and constructSFC of TrajPlanner::planImpl are
+        # independent), so they come first here: the half-space generator can then drop the rows that the step's boxes imply
         if first:
             pos = self.pos.contiguous()
-            self.gen.generate(self.cur_goal, position=pos, velocity=self.vel.contiguous(), **dkw)
             # "previous plan" of the first step: hovering at the start (zero velocity), so that its shift is itself
             self.plans.copy_(pos[:, None, None, :].expand(-1, cfg.M, cfg.n + 1, -1))
             self.init_buf.copy_(self.plans)
             if self.sfc is not None:  # TrajPlanner::constructSFC (traj_planner.cpp:517-520): initializeSFC once, then one shift per step
                 self.sfc.initialize(pos)
-        else:
-            self.gen.generate(self.cur_goal, plans=self.plans, **dkw)
         if self.sfc is not None:
             self.sfc.update(self.init_buf, self.cur_goal, self.wp)
+        if first:
+            self.gen.generate(self.cur_goal, position=self.pos.contiguous(), velocity=self.vel.contiguous(), **dkw)
+        else:
+            self.gen.generate(self.cur_goal, plans=self.plans, **dkw)
         if self.D and self.world is not None:
             # TrajPlanner::checkWaypointTrap (traj_planner.cpp:708-735): a waypoint cut off by neighbours / corridor / range
             # and within reach of a dynamic obstacle -> that obstacle's rows are dropped for this step
@@ -351,6 +357,10 @@ class ClosedLoop:
         assert self.keep_inputs, "set keep_inputs before stepping: the records are rewritten after every launch"
         agents = self.records_in.cpu().numpy().view(abi.AGENT_DTYPE).reshape(-1).copy()
         ro, rows = self.gen.rows_host()
+        if getattr(self.gen, "row_counts", None) is not None:  # pruned: only the first row_counts[k] rows of every block
+            cnt = self.gen.row_counts.cpu().numpy()
+            rows = np.concatenate([rows[ro[k]:ro[k] + cnt[k]] for k in range(len(cnt))]) if len(cnt) else rows[:0]
+            ro = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
         sfc = None if self.sfc is None else self.sfc.sfcs.cpu().numpy().copy()
         return agents, ro, rows, sfc, self.D
 

@@ -235,6 +235,11 @@ class DeviceBatch:
         self.max_rows = kmax
         self.max_slack_obs = max_slack_obs
 
+    def use_row_counts(self, counts):
+        """counts: int32 CUDA tensor [n_agents] (LscGenerator.enable_pruning) or None: rows per agent from row_offsets on."""
+        self._row_counts = counts
+        self.c.row_counts = None if counts is None else counts.data_ptr()
+
     def set_order(self, order):
         """Launch permutation (workgroup b plans agent order[b]); None restores the identity.  Meant to be the
         agents sorted by the previous replanning step's iteration count, most expensive first."""
@@ -354,6 +359,17 @@ class LscGenerator:
         rc = self.opt.lib.dlscqp_waypoint_trap_device(self.opt.handle, C.byref(self.c), C.byref(t), C.c_void_p(s.cuda_stream))
         self.opt._check(rc, "dlscqp_waypoint_trap_device")
 
+    def enable_pruning(self, sfcs=None):
+        """Presolve inside the generator (dlscqp_lsc_gen.prune): half-spaces implied by the agent's corridor / world box are not
+        written; `sfcs` [n_local, M, 6] is the corridor tensor of the local agents for the step (None without corridors).
+        Afterwards `row_counts` ([n_local] int32 CUDA tensor) holds the rows per agent: give it to DeviceBatch.use_row_counts."""
+        self.row_counts = self.torch.zeros(self.n_local, dtype=self.torch.int32, device=self.device)
+        self.c.prune = 1
+        self.c.prune_sfc_boxes = None if sfcs is None else sfcs.data_ptr()
+        self.c.out_row_counts = self.row_counts.data_ptr()
+        self._keep_prune = sfcs
+        return self.row_counts
+
     def generate(self, goals, plans=None, position=None, velocity=None, stream=None, dyn_position=None, dyn_velocity=None,
                  observed_position=None, reset_threshold=0.0):
         """goals [n_total,3] f32 and either plans [n_total,M,n+1,3] f32 (previous plans) or position/velocity
@@ -386,7 +402,8 @@ class LscGenerator:
         self.opt._check(rc, "dlscqp_generate_lsc_device")
 
     def rows_host(self):
-        """Download the rows as AoS records (tests)."""
+        """Download the rows as AoS records (tests).  With pruning on, only the first row_counts[k] rows of agent k's block are
+        meaningful (row_counts_host())."""
         self.torch.cuda.synchronize(self.device)
         R = self.n_rows
         soa = {k: v.cpu().numpy() for k, v in self.soa.items()}

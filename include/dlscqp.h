@@ -201,6 +201,9 @@ typedef struct dlscqp_device_batch {
                                        NULL = identity.  Results do not depend on it.                            */
     uint64_t *debug_stamps;         /* NULL; [n_agents][12] cycle stamps, read only by the separate
                                        -DDLSCQP_STAMPS diagnostic build (profiles/stamps.py)        */
+    const int32_t *row_counts;      /* optional [n_agents]: agent a has row_counts[a] rows starting at row_offsets[a]
+                                       (a generator that pruned rows, dlscqp_lsc_gen.prune); NULL: row_offsets[a+1] -
+                                       row_offsets[a].  max_rows_per_agent bounds both.                               */
 } dlscqp_device_batch;
 
 /* key layout: bits 0-7 m, 8-11 i, 12 dynamic flag, 16-31 slack index (0xFFFF = none). */
@@ -252,6 +255,17 @@ typedef struct dlscqp_lsc_gen {
      * observed position.  NULL = no check (ideal simulation: prediction and state coincide).                      */
     const float *observed_position;   /* [n_total][3] or NULL                                            */
     double reset_threshold;
+    /* Presolve (optional).  With prune_sfc_boxes given ([n_local][M][6], the corridor boxes of the local agents for THIS step;
+     * NULL boxes are allowed when world_use_octomap == 0: then only the world box is used), a half-space that is implied, with a
+     * margin of 0.1 mm, by the rows that confine its control point to a box -- variable bounds and corridor box,
+     * traj_optimizer.cpp:251-265, 385-410 -- is not written at all: it can be neither active nor violated, so goal LP and QP
+     * have the same solutions without it (in a crowd most neighbours within communication range are far outside an agent's
+     * corridor).  The rows that remain are written contiguously from the agent's first row on, in their original order, and
+     * out_row_counts[k] says how many: pass it as dlscqp_device_batch.row_counts.  prune != 0 switches it on.          */
+    int32_t prune;
+    int32_t reserved_;
+    const float *prune_sfc_boxes;
+    int32_t *out_row_counts;          /* [n_local], required when prune != 0                              */
 } dlscqp_lsc_gen;
 
 int dlscqp_generate_lsc_device(dlscqp_ctx *ctx, const dlscqp_lsc_gen *gen, void *stream);

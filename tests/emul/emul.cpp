@@ -226,6 +226,10 @@ static dlscqp::LscGenArgs emul_lsc_args(const dlscqp_config *cfg, const dlscqp_l
     g.reset_threshold = gen->reset_threshold;
     g.comm_range = cfg->communication_range;
     g.use_sfc = cfg->world_use_octomap ? 1 : 0;
+    g.prune_sfc = gen->prune ? (g.use_sfc ? gen->prune_sfc_boxes : nullptr) : nullptr;
+    g.row_counts = gen->prune ? gen->out_row_counts : nullptr;
+    g.dim = cfg->world_dimension;
+    for (int k = 0; k < 3; k++) { g.world_min[k] = cfg->world_min[k]; g.world_max[k] = cfg->world_max[k]; }
     return g;
 }
 
@@ -240,7 +244,8 @@ extern "C" int emul_waypoint_trap(const dlscqp_config *cfg, const dlscqp_lsc_gen
         const dlscqp_agent *ag = trap->agents + k;
         const float *cg = ag->current_goal_point, *wp = ag->next_waypoint;
         bool trapped = false;
-        for (int j = 0; j < (p1 - p0) * per; j++) trapped |= trap_row_excludes(g, row0 + j, cg, wp);
+        const int n_rows = g.row_counts ? g.row_counts[k] : (p1 - p0 + g.n_dyn) * per;
+        for (int j = 0; j < n_rows; j++) trapped |= trap_row_excludes(g, row0 + j, cg, wp);
         const float *box = (g.use_sfc && trap->sfc_boxes) ? trap->sfc_boxes + ((size_t)k * g.M + (g.M - 1)) * 6 : nullptr;
         trapped = trapped || !point_in_boxes(g, box, wp, cg) || !point_in_boxes(g, box, wp, wp);
         int released = 0;
@@ -249,7 +254,10 @@ extern "C" int emul_waypoint_trap(const dlscqp_config *cfg, const dlscqp_lsc_gen
                                   cfg->M * cfg->dt, g.dyn_uncertainty_horizon))
                 continue;
             released++;
-            for (int j = 0; j < per; j++) trap_empty_row(g, row0 + (size_t)per * ((size_t)(p1 - p0) + o) + j);
+            for (int j = 0; j < n_rows; j++) {
+                const uint32_t key = g.key[row0 + j];
+                if (((key >> 12) & 1) && (int)(key >> 16) == o) trap_empty_row(g, row0 + j);
+            }
         }
         if (trap->out_released) trap->out_released[k] = released;
     }
@@ -264,6 +272,25 @@ extern "C" int emul_generate_lsc(const dlscqp_config *cfg, const dlscqp_lsc_gen 
         const int self = g.local_ids ? g.local_ids[k] : k;
         const int p0 = g.nbr_offsets[k], p1 = g.nbr_offsets[k + 1];
         const size_t pair0 = (size_t)p0 + (size_t)k * g.n_dyn;
+        if (g.row_counts) {  // presolve: the rows that are not implied by the agent's box rows, contiguously, in order
+            size_t at = (size_t)per * pair0;
+            const size_t first = at;
+            const int items = (p1 - p0) * g.M, all = items + g.n_dyn * g.M;
+            for (int it = 0; it < all; it++) {
+                LscRows r;
+                int m;
+                if (it < items) { const int j = it / g.M; m = it - j * g.M; lsc_item_rows(g, self, g.nbr_ids[p0 + j], m, r); }
+                else { const int q = it - items, o = q / g.M; m = q - o * g.M; lsc_dyn_item_rows(g, self, o, m, r); }
+                const float *box = g.prune_sfc ? g.prune_sfc + ((size_t)k * g.M + m) * 6 : nullptr;
+                bool keep[6];
+                int cnt = 0;
+                for (int i = 0; i < r.n; i++) { keep[i] = !lsc_row_implied(g, box, r, i); cnt += keep[i]; }
+                lsc_store_rows(g, r, at, keep);
+                at += cnt;
+            }
+            g.row_counts[k] = (int)(at - first);
+            continue;
+        }
         for (int p = p0; p < p1; p++)
             for (int m = 0; m < g.M; m++) lsc_item(g, self, g.nbr_ids[p], m, (size_t)per * (pair0 + (p - p0)));
         for (int o = 0; o < g.n_dyn; o++)

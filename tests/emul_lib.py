@@ -66,7 +66,9 @@ def table_info(cfg, max_slack_obs=0, kmax=0):
 
 
 def generate_lsc(cfg, plans, goals, radius, downwash, nbr_offsets, nbr_ids, local_ids=None, position=None, velocity=None,
-                 dyn=None, observed=None, reset_threshold=0.0, trap=None):
+                 dyn=None, observed=None, reset_threshold=0.0, trap=None, prune=None):
+    """prune: None or dict(sfc=[n_local][M][6] or None): the generator's presolve; on return prune["counts"] holds the rows per
+    agent and the returned rows are the kept ones, concatenated (row_offsets accordingly)."""
     """Row N1 through the host build of lsc_core.hpp.  Returns (row_offsets, rows as ROW_DTYPE).
     dyn: None or dict(position [D,3], velocity [D,3], radius [D], max_acc [D], downwash [D], size_prediction, horizon)."""
     L = lib()
@@ -88,11 +90,11 @@ def generate_lsc(cfg, plans, goals, radius, downwash, nbr_offsets, nbr_ids, loca
         return rc
 
     return _run_lsc_gen(cfg, call, plans, goals, radius, downwash, nbr_offsets, nbr_ids, local_ids, position, velocity, dyn,
-                        observed, reset_threshold)
+                        observed, reset_threshold, prune)
 
 
 def _run_lsc_gen(cfg, call, plans, goals, radius, downwash, nbr_offsets, nbr_ids, local_ids, position, velocity, dyn=None,
-                 observed=None, reset_threshold=0.0):
+                 observed=None, reset_threshold=0.0, prune=None):
     first = plans is None
     keep = []
 
@@ -137,9 +139,20 @@ def _run_lsc_gen(cfg, call, plans, goals, radius, downwash, nbr_offsets, nbr_ids
     out["key"] = np.zeros(R + 1, np.uint32)
     for k, v in out.items():
         setattr(g, k, v.ctypes.data)
+    counts = None
+    if prune is not None:
+        counts = np.zeros(n_local, np.int32)
+        g.prune, g.out_row_counts = 1, counts.ctypes.data
+        if prune.get("sfc") is not None:
+            _, g.prune_sfc_boxes = arr(prune["sfc"], np.float32)
     rc = call(g)
     assert rc == 0
-    return per * pairs, soa_to_rows(out, R)
+    ro, rows = per * pairs, soa_to_rows(out, R)
+    if counts is not None:
+        prune["counts"] = counts
+        rows = np.concatenate([rows[ro[k]:ro[k] + counts[k]] for k in range(n_local)]) if n_local else rows[:0]
+        ro = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+    return ro, rows
 
 
 def soa_to_rows(soa, R):

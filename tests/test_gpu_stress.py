@@ -130,3 +130,49 @@ def test_x2048_rank_plans_its_interior_agents_before_the_exchange(gpu_required):
     for k in ("status", "goal_status", "goal", "ctrl"):
         assert np.array_equal(ref[k], got[k]), k
     print("x2048 rank %d of %d: %d interior agents planned before the exchange, %d halo agents after it" % (rank, world, len(interior), len(halo)))
+
+
+def test_x2048_with_the_generators_presolve(gpu_required):
+    """dlscqp_lsc_gen.prune on the full stress batch: rows implied by an agent's corridor boxes are never written; the plan
+    kernel scans what is left.  Verdicts identical, sub-goals bit-equal, solutions within 1e-7 of the run on all rows."""
+    cfg = workloads.x2048_config()
+    w = workloads.x2048(cfg)
+    N = len(w["agents"])
+    opt = BatchTrajOptimizer(cfg)
+    try:
+        plans, goals = torch.from_numpy(w["plans"]).cuda(), torch.from_numpy(w["goals"]).cuda()
+        res, ms, kept = {}, {}, None
+        for mode in ("all", "pruned"):
+            gen = opt.make_lsc_generator(N, w["nbr_offsets"], w["nbr_ids"], w["radius"], w["downwash"])
+            ro = gen.row_offsets
+            db = opt.make_device_batch(w["agents"], ro, np.zeros(0, abi.ROW_DTYPE), w["sfc"], 0, want_f64=True, want_iters=True)
+            for k in ("nx", "ny", "nz", "px", "py", "pz", "d", "key"):
+                setattr(db.c, k, gen.soa[k].data_ptr())
+            ro32 = torch.from_numpy(ro.astype(np.int32)).cuda()
+            db.c.row_offsets = ro32.data_ptr()
+            db.c.max_rows_per_agent = int(np.diff(ro).max())
+            if mode == "pruned":
+                db.use_row_counts(gen.enable_pruning(db.t["sfc"].view(torch.float32).view(N, cfg.M, 6)))
+            gen.generate(goals, plans=plans)
+            db.launch()
+            res[mode] = db.results()
+            if mode == "pruned":
+                kept = gen.row_counts.cpu().numpy()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                gen.generate(goals, plans=plans)
+                db.launch()
+            torch.cuda.synchronize()
+            ms[mode] = (time.perf_counter() - t0) / 20 * 1e3
+    finally:
+        opt.close()
+    a, b = res["all"], res["pruned"]
+    assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["goal_status"], b["goal_status"])
+    assert np.array_equal(a["goal"], b["goal"])
+    ok = a["status"] == abi.OK
+    assert ok.mean() > 0.9 and np.abs(a["x"][ok] - b["x"][ok]).max() < 1e-7
+    full = np.diff(ro)
+    print("x2048 presolve: %.0f of %.0f rows per agent kept; generation + LP + QP %.3f ms with all rows, %.3f ms pruned" % (
+        kept.mean(), full.mean(), ms["all"], ms["pruned"]))
+    assert kept.sum() < 0.5 * full.sum()

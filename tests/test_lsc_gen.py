@@ -232,3 +232,83 @@ def test_waypoint_trap_releases_the_same_obstacles_as_the_oracle(M, dim, comm):
         # unlimited range: the communication box is the default Box (the origin), every agent counts as trapped, so every
         # obstacle within reach of the waypoint is released (harmless in the reference: such launches have no obstacles)
         assert (released > 0).sum() >= 2
+
+
+@pytest.mark.parametrize("M,dim,n_dyn", [(10, 2, 0), (10, 3, 2), (5, 3, 0)])
+def test_pruned_rows_are_implied_rows_and_the_plans_do_not_change(M, dim, n_dyn):
+    """The generator's presolve (dlscqp_lsc_gen.prune): every row it drops is implied by the agent's corridor / world box with
+    a margin (checked corner by corner in numpy), the kept rows are the others in their original order, and goal LP + QP give
+    the same verdicts and solutions with and without the dropped rows."""
+    cfg = abi.make_config(dim=dim, M=M, communication_range=3.0, world_use_octomap=True, slack_collision_weight=100.0,
+                          world_min=(-6.0, -6.0, 0.0), world_max=(6.0, 6.0, 2.5))
+    N = 14
+    sw = lsc_cases.random_swarm(cfg, N, seed=700 + M + dim, spread=1.6)
+    if dim == 2:
+        sw["plans"][..., 2] = np.float32(cfg.world_z_2d)
+        sw["goals"][:, 2] = np.float32(cfg.world_z_2d)
+    dyn = lsc_cases.random_dynamic_obstacles(n_dyn, seed=3) if n_dyn else None
+    init = np.stack([O.shift_plan(p) for p in sw["plans"]])
+    rng = np.random.default_rng(1)
+    sfc = np.zeros((N, M, 6), np.float32)
+    for a in range(N):
+        for m in range(M):
+            lo, hi = init[a, m].min(axis=0), init[a, m].max(axis=0)
+            mg = rng.uniform(0.2, 0.6, 3).astype(np.float32)
+            sfc[a, m, :3], sfc[a, m, 3:] = lo - mg, hi + mg
+    full_ro, full = E.generate_lsc(cfg, sw["plans"], sw["goals"], sw["radius"], sw["downwash"], sw["nbr_offsets"], sw["nbr_ids"], dyn=dyn)
+    pr = dict(sfc=sfc)
+    ro, rows = E.generate_lsc(cfg, sw["plans"], sw["goals"], sw["radius"], sw["downwash"], sw["nbr_offsets"], sw["nbr_ids"], dyn=dyn, prune=pr)
+    assert pr["counts"].sum() == len(rows) < len(full) and (pr["counts"] > 0).any()
+    wmin, wmax = np.array(cfg.world_min[:]), np.array(cfg.world_max[:])
+    dropped = 0
+    for a in range(N):
+        f = full[full_ro[a]:full_ro[a + 1]]
+        k = rows[ro[a]:ro[a + 1]]
+        # kept rows: a subsequence of the full rows
+        kept_idx, j = [], 0
+        for i in range(len(f)):
+            if j < len(k) and f[i].tobytes() == k[j].tobytes():
+                kept_idx.append(i)
+                j += 1
+        assert j == len(k), a
+        for i in sorted(set(range(len(f))) - set(kept_idx)):
+            r = f[i]
+            lo = np.maximum(sfc[a, r["m"], :3].astype(np.float64), wmin)[:dim]
+            hi = np.minimum(sfc[a, r["m"], 3:].astype(np.float64), wmax)[:dim]
+            nv = r["normal"].astype(np.float64)[:dim]
+            mn = np.where(nv >= 0, nv * lo, nv * hi).sum()
+            assert mn - (r["d"] + (nv * r["point"].astype(np.float64)[:dim]).sum()) >= 1e-4 - 1e-12
+            dropped += 1
+    assert dropped > 50
+    ag = np.zeros(N, abi.AGENT_DTYPE)
+    ag["position"], ag["current_goal_point"], ag["next_waypoint"] = init[:, 0, 0], sw["goals"], sw["goals"]
+    ag["velocity"] = (init[:, 0, 1] - init[:, 0, 0]) * np.float32(cfg.n / cfg.dt)
+    ag["max_vel"], ag["max_acc"], ag["radius"], ag["nominal_velocity"] = 1.0, 2.0, sw["radius"], 1.0
+    ag["n_slack_obs"] = n_dyn
+    a1 = E.plan_batch(cfg, ag, full_ro, full, sfc, n_dyn, True)
+    a2 = E.plan_batch(cfg, ag, ro, rows, sfc, n_dyn, True)
+    assert np.array_equal(a1["status"], a2["status"]) and np.array_equal(a1["goal_status"], a2["goal_status"])
+    assert np.array_equal(a1["goal"], a2["goal"])
+    ok = a1["status"] == abi.OK
+    if ok.any():
+        assert np.abs(a1["x"][ok] - a2["x"][ok]).max() < 1e-8
+
+
+def test_pruning_leaves_the_plans_of_the_stress_workload_unchanged():
+    """The same on feasible problems: 96 agents of the stress workload (BASELINE.json configs[4]: 2-D, M = 10, corridor boxes,
+    every agent within 3 m a neighbour).  Most rows go; verdicts identical, sub-goals bit-equal, solutions within 1e-8."""
+    from dlsc_gc_planner_amd import workloads
+    cfg = workloads.x2048_config()
+    w = workloads.x2048(cfg, n_agents=96, seed=5002)
+    args = (cfg, w["plans"], w["goals"], w["radius"], w["downwash"], w["nbr_offsets"], w["nbr_ids"])
+    full_ro, full = E.generate_lsc(*args)
+    pr = dict(sfc=w["sfc"])
+    ro, rows = E.generate_lsc(*args, prune=pr)
+    assert len(rows) < 0.5 * len(full), (len(rows), len(full))
+    a1 = E.plan_batch(cfg, w["agents"], full_ro, full, w["sfc"], 0, True)
+    a2 = E.plan_batch(cfg, w["agents"], ro, rows, w["sfc"], 0, True)
+    assert np.array_equal(a1["status"], a2["status"]) and np.array_equal(a1["goal_status"], a2["goal_status"])
+    assert np.array_equal(a1["goal"], a2["goal"])
+    ok = a1["status"] == abi.OK
+    assert ok.mean() > 0.8 and np.abs(a1["x"][ok] - a2["x"][ok]).max() < 1e-8
+    print("stress workload: %d of %d rows kept by the presolve" % (len(rows), len(full)))
