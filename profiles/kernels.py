@@ -12,8 +12,8 @@ from collections import defaultdict
 
 def main():
     d, name = sys.argv[1], sys.argv[2]
-    tr = glob.glob(os.path.join(d, "*", "*_kernel_trace.csv"))
-    rows = list(csv.DictReader(open(tr[0])))
+    tr = sorted(glob.glob(os.path.join(d, "*", "*_kernel_trace.csv")), key=os.path.getmtime)  # the newest run of the directory
+    rows = list(csv.DictReader(open(tr[-1])))
     by = defaultdict(list)
     for r in rows:
         k = r["Kernel_Name"]

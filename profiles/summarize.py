@@ -41,9 +41,9 @@ def main():
     args = ap.parse_args()
     out = []
     summary = {"name": args.name, "agents_per_launch": args.agents}
-    tr = glob.glob(os.path.join(args.prof_dir, "trace", "*", "*_kernel_trace.csv"))
+    tr = sorted(glob.glob(os.path.join(args.prof_dir, "trace", "*", "*_kernel_trace.csv")), key=os.path.getmtime)
     if tr:
-        rows = read(tr[0])
+        rows = read(tr[-1])
         keep = last_dispatches(rows, args.steps)
         sel = [r for r in rows if KERNEL in r["Kernel_Name"] and int(r["Dispatch_Id"]) in keep]
         durs = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3 for r in sel]
@@ -63,18 +63,18 @@ def main():
         summary["achieved_GBps"] = alg / (avg * 1e-6) / 1e9
         out.append("algorithmic bytes per launch = %d agents x %d B = %d B -> %.2f GB/s achieved (%.4f of 8000 GB/s)\n" % (
             args.agents, args.bytes_per_qp, alg, summary["achieved_GBps"], summary["achieved_GBps"] / 8000))
-        st = glob.glob(os.path.join(args.prof_dir, "trace", "*", "*_kernel_stats.csv"))
+        st = sorted(glob.glob(os.path.join(args.prof_dir, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
         if st:
             out.append("rocprofv3 --stats (all dispatches of the process, including workload generation):\n")
             out.append("```")
-            out.extend(l.rstrip() for l in open(st[0]).readlines()[:6])
+            out.extend(l.rstrip() for l in open(st[-1]).readlines()[:6])
             out.append("```\n")
     counters = defaultdict(list)
     for sub in sorted(glob.glob(os.path.join(args.prof_dir, "*"))):
-        cc = glob.glob(os.path.join(sub, "*", "*_counter_collection.csv"))
+        cc = sorted(glob.glob(os.path.join(sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)
         if not cc:
             continue
-        rows = read(cc[0])
+        rows = read(cc[-1])
         keep = last_dispatches(rows, args.steps)
         for r in rows:
             if KERNEL in r["Kernel_Name"] and int(r["Dispatch_Id"]) in keep:
