@@ -288,7 +288,7 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
 // one: an agent of the stress batch has ~440 items of a few thousand instructions each behind scattered reads of its
 // neighbours' plans, and a grid of one wavefront per agent leaves the SIMDs with two wavefronts to hide that behind.
 constexpr int LSC_THREADS = 256;
-__global__ __launch_bounds__(LSC_THREADS) void dlscqp_lsc_kernel(LscGenArgs g) {
+__global__ __launch_bounds__(LSC_THREADS, 4) void dlscqp_lsc_kernel(LscGenArgs g) {
     const int k = blockIdx.x;
     if (k >= g.n_local) return;
     const int self = g.local_ids ? g.local_ids[k] : k;
@@ -300,52 +300,62 @@ __global__ __launch_bounds__(LSC_THREADS) void dlscqp_lsc_kernel(LscGenArgs g) {
     // problem vs. the last segment's segment-segment problem -- was measured: the stress batch's step went from 0.51 to
     // 0.74 ms; the kernel is bound by its scattered plan reads and row writes, not by the branch.)
     const int nn = p1 - p0, items = nn * g.M;
+    __shared__ float hull_pts[18 * LSC_THREADS];
+    const HullStore hull = {hull_pts + threadIdx.x, LSC_THREADS};
     if (g.row_counts) {
         // presolve: rows implied by the agent's own box rows are dropped, the others written contiguously in their original
         // order -- per round of LSC_THREADS items an exclusive prefix sum of the kept-row counts over the workgroup (LDS)
-        __shared__ int scan[LSC_THREADS];
-        __shared__ int base_s;
-        if (threadIdx.x == 0) base_s = 0;
-        __syncthreads();
+        __shared__ int wave_rows[2][LSC_THREADS / 64];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const size_t row0 = (size_t)per * pair0;
         const int all = items + g.n_dyn * g.M;
-        for (int it0 = 0; it0 < all; it0 += LSC_THREADS) {
+        int base = 0;  // rows the previous rounds kept (every thread carries its own copy)
+        for (int it0 = 0, round = 0; it0 < all; it0 += LSC_THREADS, round ^= 1) {
             const int it = it0 + (int)threadIdx.x;
             LscRows r;
-            r.n = 0;
+            r.i0 = 6;
             bool keep[6] = {false, false, false, false, false, false};
-            int cnt = 0;
+            int cnt = 0, m = 0;
             if (it < items) {
-                const int j = it / g.M, m = it - j * g.M;
-                lsc_item_rows(g, self, g.nbr_ids[p0 + j], m, r);
-                const float *box = g.prune_sfc ? g.prune_sfc + ((size_t)k * g.M + m) * 6 : nullptr;
-                for (int i = 0; i < r.n; i++) { keep[i] = !lsc_row_implied(g, box, r, i); cnt += keep[i]; }
+                const int j = it / g.M;
+                m = it - j * g.M;
+                lsc_item_rows(g, self, g.nbr_ids[p0 + j], m, r, hull);
             } else if (it < all) {
-                const int q = it - items, o = q / g.M, m = q - o * g.M;
+                const int q = it - items, o = q / g.M;
+                m = q - o * g.M;
                 lsc_dyn_item_rows(g, self, o, m, r);
+            }
+            if (it < all) {
                 const float *box = g.prune_sfc ? g.prune_sfc + ((size_t)k * g.M + m) * 6 : nullptr;
-                for (int i = 0; i < r.n; i++) { keep[i] = !lsc_row_implied(g, box, r, i); cnt += keep[i]; }
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    keep[i] = i >= r.i0 && !lsc_row_implied(g, box, r, i);
+                    cnt += keep[i];
+                }
             }
-            scan[threadIdx.x] = cnt;
-            __syncthreads();
-            for (int s = 1; s < LSC_THREADS; s <<= 1) {  // Hillis-Steele inclusive scan
-                const int v = (int)threadIdx.x >= s ? scan[threadIdx.x - s] : 0;
-                __syncthreads();
-                scan[threadIdx.x] += v;
-                __syncthreads();
+            int incl = cnt;  // inclusive scan over the wavefront, then the wavefronts' totals through LDS (one barrier a round)
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) {
+                const int v = __shfl_up(incl, s);
+                incl += lane >= s ? v : 0;
             }
-            const int base = base_s;
-            if (cnt) lsc_store_rows(g, r, row0 + (size_t)(base + scan[threadIdx.x] - cnt), keep);
+            if (lane == 63) wave_rows[round][wave] = incl;
             __syncthreads();
-            if (threadIdx.x == LSC_THREADS - 1) base_s = base + scan[LSC_THREADS - 1];
-            __syncthreads();
+            int before = base;
+#pragma unroll
+            for (int w = 0; w < LSC_THREADS / 64; w++) {
+                const int t = wave_rows[round][w];
+                before += w < wave ? t : 0;
+                base += t;
+            }
+            if (cnt) lsc_store_rows(g, r, row0 + (size_t)(before + incl - cnt), keep);
         }
-        if (threadIdx.x == 0) g.row_counts[k] = base_s;
+        if (threadIdx.x == 0) g.row_counts[k] = base;
         return;
     }
     for (int it = threadIdx.x; it < items; it += LSC_THREADS) {
         const int j = it / g.M, m = it - j * g.M;
-        lsc_item(g, self, g.nbr_ids[p0 + j], m, (size_t)per * (pair0 + j));
+        lsc_item(g, self, g.nbr_ids[p0 + j], m, (size_t)per * (pair0 + j), hull);
     }
     for (int it = threadIdx.x; it < g.n_dyn * g.M; it += LSC_THREADS) {  // dynamic obstacles after the neighbour agents
         const int o = it / g.M, m = it - o * g.M;

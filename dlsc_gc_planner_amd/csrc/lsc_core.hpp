@@ -58,44 +58,82 @@ DQ_FN double det3(D3 a, D3 b, D3 c) {
     return a.x * (b.y * c.z - b.z * c.y) - a.y * (b.x * c.z - b.z * c.x) + a.z * (b.x * c.y - b.y * c.x);
 }
 
-DQ_FN D3 hull6_closest_to_origin(const D3 p[6]) {
-    D3 best = p[0];
+// A lane's six hull points (float32, as the trajectories are), component c of point a at base[(3 * a + c) * stride].  On the
+// device the store is a slice of LDS (stride = workgroup size, so the lanes of a wavefront hit distinct banks): the loops
+// below index the points with their counters, and register arrays indexed like that either go to scratch memory or force the
+// compiler to unroll all 15 + 20 + 15 simplices into one 280-register body (measured: 1 wavefront per SIMD).
+struct HullStore {
+    float *base;
+    int stride;
+    DQ_FN void put(int a, F3 v) const {
+        base[(3 * a) * stride] = v.x; base[(3 * a + 1) * stride] = v.y; base[(3 * a + 2) * stride] = v.z;
+    }
+    DQ_FN F3 getf(int a) const { return f3(base[(3 * a) * stride], base[(3 * a + 1) * stride], base[(3 * a + 2) * stride]); }
+    DQ_FN D3 get(int a) const { const F3 v = getf(a); return d3(v.x, v.y, v.z); }
+};
+
+DQ_FN D3 hull6_closest_to_origin(const HullStore &p) {
+    D3 best = p.get(0);
     double bd = ddot(best, best);
-    bool inside = false;
-#pragma unroll
+    // vertices, edges and faces: the closest point of the hull's boundary
+#pragma unroll 1
     for (int a = 0; a < 6; a++) {
-        const double da = ddot(p[a], p[a]);
-        if (da < bd) { bd = da; best = p[a]; }
-#pragma unroll
+        const D3 pa = p.get(a);
+        const double da = ddot(pa, pa);
+        if (da < bd) { bd = da; best = pa; }
+#pragma unroll 1
         for (int b = a + 1; b < 6; b++) {
-            const D3 ab = p[b] - p[a];
-            const double den = ddot(ab, ab), num = -ddot(p[a], ab);
+            const D3 ab = p.get(b) - pa;
+            const double den = ddot(ab, ab), num = -ddot(pa, ab);
             if (den > 0) {
                 const double t = num / den;
                 if (t > 0 && t < 1) {
-                    const D3 c = d3(p[a].x + t * ab.x, p[a].y + t * ab.y, p[a].z + t * ab.z);
+                    const D3 c = d3(pa.x + t * ab.x, pa.y + t * ab.y, pa.z + t * ab.z);
                     const double dc = ddot(c, c);
                     if (dc < bd) { bd = dc; best = c; }
                 }
             }
-#pragma unroll
+#pragma unroll 1
             for (int ci = b + 1; ci < 6; ci++) {
-                const D3 ac = p[ci] - p[a];
+                const D3 ac = p.get(ci) - pa;
                 const double g11 = den, g12 = ddot(ab, ac), g22 = ddot(ac, ac);
-                const double r1 = num, r2 = -ddot(p[a], ac);
+                const double r1 = num, r2 = -ddot(pa, ac);
                 const double det = g11 * g22 - g12 * g12;
                 if (det > 1e-14 * g11 * g22) {
                     const double u = (r1 * g22 - r2 * g12) / det, w = (g11 * r2 - g12 * r1) / det;
                     if (u > 0 && w > 0 && u + w < 1) {
-                        const D3 c = d3(p[a].x + u * ab.x + w * ac.x, p[a].y + u * ab.y + w * ac.y, p[a].z + u * ab.z + w * ac.z);
+                        const D3 c = d3(pa.x + u * ab.x + w * ac.x, pa.y + u * ab.y + w * ac.y, pa.z + u * ab.z + w * ac.z);
                         const double dc = ddot(c, c);
                         if (dc < bd) { bd = dc; best = c; }
                     }
                 }
-#pragma unroll
+            }
+        }
+    }
+    // Is the origin inside the hull?  If the plane through the origin with normal `best` has every point strictly on its
+    // positive side, it separates the origin from the hull and the 15 tetrahedra need not be looked at (the usual case:
+    // two vehicles whose relative hull contains the origin are in collision).
+    double lo = ddot(p.get(0), best);
+#pragma unroll 1
+    for (int a = 1; a < 6; a++) {
+        const double s = ddot(p.get(a), best);
+        lo = s < lo ? s : lo;
+    }
+    if (lo > 0) return best;
+    bool inside = false;
+#pragma unroll 1
+    for (int a = 0; a < 6; a++) {
+        const D3 pa = p.get(a);
+        const D3 oa = d3(-pa.x, -pa.y, -pa.z);
+#pragma unroll 1
+        for (int b = a + 1; b < 6; b++) {
+            const D3 ab = p.get(b) - pa;
+#pragma unroll 1
+            for (int ci = b + 1; ci < 6; ci++) {
+                const D3 ac = p.get(ci) - pa;
+#pragma unroll 1
                 for (int di = ci + 1; di < 6; di++) {  // origin inside this tetrahedron => inside the hull
-                    const D3 ad = p[di] - p[a];
-                    const D3 oa = d3(-p[a].x, -p[a].y, -p[a].z);
+                    const D3 ad = p.get(di) - pa;
                     const double vol = det3(ab, ac, ad);
                     if (fabs(vol) >= 1e-300) {
                         const double l1 = det3(oa, ac, ad) / vol, l2 = det3(ab, oa, ad) / vol, l3 = det3(ab, ac, oa) / vol;
@@ -236,13 +274,14 @@ struct LscGenArgs {  // device mirror of dlscqp_lsc_gen (include/dlscqp.h)
     int dim;
 };
 
-// One item's rows before they are written: segment m, control points i0 .. i0 + n - 1 (one normal for all of them)
+// One item's rows before they are written: segment m, control points i0 .. 5 (one normal for all of them).  The arrays are
+// indexed by the control point and every loop over them is unrolled, so that they live in registers, not in scratch memory.
 struct LscRows {
     float nx, ny, nz;
     float px[6], py[6], pz[6];
     double d[6];
     uint32_t key[6];
-    int n;
+    int i0;
 };
 
 constexpr double PRUNE_MARGIN = 1e-4;  // metres by which a row has to be implied before it is dropped
@@ -300,8 +339,9 @@ DQ_FN F3 predicted_point(const LscGenArgs &g, int id, int m, int i) {
 }
 
 DQ_FN void lsc_store_rows(const LscGenArgs &g, const LscRows &r, size_t at, const bool *keep) {
-    for (int i = 0; i < r.n; i++) {
-        if (keep && !keep[i]) continue;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        if (i < r.i0 || (keep && !keep[i])) continue;
         g.nx[at] = r.nx; g.ny[at] = r.ny; g.nz[at] = r.nz;
         g.px[at] = r.px[i]; g.py[at] = r.py[i]; g.pz[at] = r.pz[i];
         g.d[at] = r.d[i];
@@ -311,38 +351,36 @@ DQ_FN void lsc_store_rows(const LscGenArgs &g, const LscRows &r, size_t at, cons
 }
 
 // One (pair, segment) item: its rows into `out` (nothing is written to memory).
-DQ_FN void lsc_item_rows(const LscGenArgs &g, int self, int other, int m, LscRows &out) {
+DQ_FN void lsc_item_rows(const LscGenArgs &g, int self, int other, int m, LscRows &out, const HullStore &hull) {
     const int n = g.n1 - 1, M = g.M;
     const double r_self = g.radius[self], r_oth = g.radius[other];
     const double collision_dist = r_oth + r_self;                                                       // :605
     const double downwash = (g.downwash[self] * r_self + g.downwash[other] * r_oth) / (r_self + r_oth);  // :1150-1153
     const float dwf = (float)downwash;
     // rows of segment 0 start at i = phi (the others are never part of the model, traj_optimizer.cpp:417-419)
-    const int i0 = m == 0 ? g.phi : 0;
-    out.n = g.n1 - i0;
+    out.i0 = m == 0 ? g.phi : 0;
     if (m < M - 1) {
-        F3 rel[6], pred[6];
-        D3 pts[6];
+        F3 pred[6];
+#pragma unroll
         for (int i = 0; i < 6; i++) {
             F3 a = initial_point(g, self, m, i);
             pred[i] = predicted_point(g, other, m, i);
             F3 b = pred[i];
             a.z = a.z / dwf;  // Trajectory::coordinateTransform, trajectory.cpp:206-219
             b.z = b.z / dwf;
-            rel[i] = a - b;
-            pts[i] = d3(rel[i].x, rel[i].y, rel[i].z);
+            hull.put(i, a - b);
         }
-        const D3 v = hull6_closest_to_origin(pts);
+        const D3 v = hull6_closest_to_origin(hull);
         F3 cp = f3((float)v.x, (float)v.y, (float)v.z);
         cp = f3(0, 0, 0) + cp;
         const F3 nt = normalized(cp);
         const F3 nrm = f3(nt.x, nt.y, (float)((double)nt.z / downwash));  // :634-636
         out.nx = nrm.x; out.ny = nrm.y; out.nz = nrm.z;
-        for (int i = i0; i < g.n1; i++) {
-            const int r = i - i0;
-            out.px[r] = pred[i].x; out.py[r] = pred[i].y; out.pz[r] = pred[i].z;
-            out.d[r] = 0.5 * (collision_dist + dot(rel[i], nt));  // :639-640
-            out.key[r] = DLSCQP_KEY(m, i, -1, 0);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {  // entries below i0 are computed too and never stored
+            out.px[i] = pred[i].x; out.py[i] = pred[i].y; out.pz[i] = pred[i].z;
+            out.d[i] = 0.5 * (collision_dist + dot(hull.getf(i), nt));  // :639-640
+            out.key[i] = DLSCQP_KEY(m, i, -1, 0);
         }
     } else {
         F3 l1s = predicted_point(g, other, M - 1, n), l2s = initial_point(g, self, M - 1, n);
@@ -358,7 +396,8 @@ DQ_FN void lsc_item_rows(const LscGenArgs &g, int self, int other, int m, LscRow
         const F3 nrm = f3(nt.x, nt.y, (float)((double)nt.z / downwash));
         const F3 pt = f3(c.p1.x, c.p1.y, (float)((double)c.p1.z * downwash));
         out.nx = nrm.x; out.ny = nrm.y; out.nz = nrm.z;
-        for (int i = 0; i < g.n1; i++) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
             out.px[i] = pt.x; out.py[i] = pt.y; out.pz[i] = pt.z;
             out.d[i] = dd;
             out.key[i] = DLSCQP_KEY(m, i, -1, 0);
@@ -367,9 +406,9 @@ DQ_FN void lsc_item_rows(const LscGenArgs &g, int self, int other, int m, LscRow
 }
 
 // The item's rows at their fixed place: `row0` = index of the pair's first row in the SoA arrays.
-DQ_FN void lsc_item(const LscGenArgs &g, int self, int other, int m, size_t row0) {
+DQ_FN void lsc_item(const LscGenArgs &g, int self, int other, int m, size_t row0, const HullStore &hull) {
     LscRows r;
-    lsc_item_rows(g, self, other, m, r);
+    lsc_item_rows(g, self, other, m, r, hull);
     lsc_store_rows(g, r, row0 + (m == 0 ? 0 : (size_t)(g.n1 - g.phi) + (size_t)(m - 1) * g.n1), nullptr);
 }
 
@@ -418,10 +457,10 @@ DQ_FN void lsc_dyn_item_rows(const LscGenArgs &g, int self, int o, int m, LscRow
     int Mu = (int)((g.dyn_uncertainty_horizon + 1e-9) / g.dt);
     Mu = Mu < M ? Mu : M;
     const double amax = g.dyn_max_acc[o];
-    const int i0 = m == 0 ? g.phi : 0;
-    out.n = g.n1 - i0;
+    out.i0 = m == 0 ? g.phi : 0;
     out.nx = nrm.x; out.ny = nrm.y; out.nz = nrm.z;
-    for (int i = i0; i < g.n1; i++) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
         double size = r_obs;
         if (g.dyn_size_prediction) {
             if (m < Mu) {
@@ -434,10 +473,9 @@ DQ_FN void lsc_dyn_item_rows(const LscGenArgs &g, int self, int o, int m, LscRow
             }
         }
         const F3 pt = const_vel_point(op, ov, g.dt, g.n1, m, i);
-        const int r = i - i0;
-        out.px[r] = pt.x; out.py[r] = pt.y; out.pz[r] = pt.z;
-        out.d[r] = size + r_self;  // :623
-        out.key[r] = DLSCQP_KEY(m, i, o, 1);
+        out.px[i] = pt.x; out.py[i] = pt.y; out.pz[i] = pt.z;
+        out.d[i] = size + r_self;  // :623
+        out.key[i] = DLSCQP_KEY(m, i, o, 1);
     }
 }
 

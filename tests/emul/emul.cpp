@@ -268,6 +268,8 @@ extern "C" int emul_generate_lsc(const dlscqp_config *cfg, const dlscqp_lsc_gen 
     using namespace dlscqp;
     const LscGenArgs g = emul_lsc_args(cfg, gen);
     const int per = g.M * g.n1 - g.phi;
+    float hull_pts[18];
+    const HullStore hull = {hull_pts, 1};
     for (int k = 0; k < g.n_local; k++) {  // same item -> row mapping as dlscqp_lsc_kernel
         const int self = g.local_ids ? g.local_ids[k] : k;
         const int p0 = g.nbr_offsets[k], p1 = g.nbr_offsets[k + 1];
@@ -279,12 +281,12 @@ extern "C" int emul_generate_lsc(const dlscqp_config *cfg, const dlscqp_lsc_gen 
             for (int it = 0; it < all; it++) {
                 LscRows r;
                 int m;
-                if (it < items) { const int j = it / g.M; m = it - j * g.M; lsc_item_rows(g, self, g.nbr_ids[p0 + j], m, r); }
+                if (it < items) { const int j = it / g.M; m = it - j * g.M; lsc_item_rows(g, self, g.nbr_ids[p0 + j], m, r, hull); }
                 else { const int q = it - items, o = q / g.M; m = q - o * g.M; lsc_dyn_item_rows(g, self, o, m, r); }
                 const float *box = g.prune_sfc ? g.prune_sfc + ((size_t)k * g.M + m) * 6 : nullptr;
                 bool keep[6];
                 int cnt = 0;
-                for (int i = 0; i < r.n; i++) { keep[i] = !lsc_row_implied(g, box, r, i); cnt += keep[i]; }
+                for (int i = 0; i < 6; i++) { keep[i] = i >= r.i0 && !lsc_row_implied(g, box, r, i); cnt += keep[i]; }
                 lsc_store_rows(g, r, at, keep);
                 at += cnt;
             }
@@ -292,7 +294,7 @@ extern "C" int emul_generate_lsc(const dlscqp_config *cfg, const dlscqp_lsc_gen 
             continue;
         }
         for (int p = p0; p < p1; p++)
-            for (int m = 0; m < g.M; m++) lsc_item(g, self, g.nbr_ids[p], m, (size_t)per * (pair0 + (p - p0)));
+            for (int m = 0; m < g.M; m++) lsc_item(g, self, g.nbr_ids[p], m, (size_t)per * (pair0 + (p - p0)), hull);
         for (int o = 0; o < g.n_dyn; o++)
             for (int m = 0; m < g.M; m++) lsc_dyn_item(g, self, o, m, (size_t)per * (pair0 + (p1 - p0) + o));
     }
