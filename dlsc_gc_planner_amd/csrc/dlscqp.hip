@@ -249,6 +249,11 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
     if (a.out_stamps) w.tr = reinterpret_cast<double *>(a.out_stamps) + (size_t)ag * 1001;
 #endif
 #endif
+#ifdef DLSCQP_TIMELINE
+    // diagnostic build only (profiles/timeline.py): when and where (CU, SIMD, wave slot) this agent's wavefront ran
+    unsigned long long tl0;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl0)::"memory");
+#endif
     const int rb = a.row_offsets[ag], re = a.row_counts ? rb + a.row_counts[ag] : a.row_offsets[ag + 1];
     const int M = kp.M, n1 = kp.n1;
     const size_t xs = (size_t)kp.dim * M * n1 + (size_t)M * a.max_slack_obs;
@@ -264,6 +269,22 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
 #ifdef DLSCQP_STAMPS
     if (a.out_stamps && threadIdx.x == 0)
         for (int p = 0; p < 12; p++) a.out_stamps[(size_t)ag * 12 + p] = w.acc[p];
+#endif
+#ifdef DLSCQP_TIMELINE
+    if (a.out_stamps) {
+        unsigned long long tl1;
+        unsigned int hw, xcc;
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl1)::"memory");
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        if (threadIdx.x == 0) {
+            a.out_stamps[(size_t)ag * 12 + 0] = tl0;
+            a.out_stamps[(size_t)ag * 12 + 1] = tl1;
+            a.out_stamps[(size_t)ag * 12 + 2] = hw;
+            a.out_stamps[(size_t)ag * 12 + 3] = xcc;
+            a.out_stamps[(size_t)ag * 12 + 4] = (unsigned long long)slot;
+        }
+    }
 #endif
 #ifdef DLSCQP_PM_LDS
     // debug build only: image of the agent's LDS working set when the solve returns (layout header + doubles)

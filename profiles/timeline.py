@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Diagnostic: when and where every wavefront of one dlscqp_plan_kernel launch ran (-DDLSCQP_TIMELINE build, never shipped).
+
+s_memrealtime (100 MHz) at the start and the end of every agent's solve plus HW_ID / XCC_ID: how full the wave slots are over
+the launch, how long a slot stays empty between two wavefronts (workgroup dispatch), how long the tail is.
+
+    python profiles/timeline.py [--swarms 512] [--grid 0]
+"""
+import argparse
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+CSRC = os.path.join(ROOT, "dlsc_gc_planner_amd", "csrc")
+LIB = os.path.join(CSRC, "libdlscqp_timeline.so")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--swarms", type=int, default=512)
+    args = ap.parse_args()
+    if not os.path.exists(LIB):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                               "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-DDLSCQP_TIMELINE", "-I" + os.path.join(ROOT, "include"), "-o", LIB]
+                              + [os.path.join(CSRC, f) for f in ("dlscqp.hip", "qp_tables.cpp", "sfc_world.cpp", "grid_mapf.cpp")])
+    os.environ["DLSCQP_LIB"] = LIB
+    import numpy as np
+    import torch
+    from dlsc_gc_planner_amd import workloads
+    from dlsc_gc_planner_amd.planner import BatchTrajOptimizer
+    cfg = workloads.s64_config()
+    opt = BatchTrajOptimizer(cfg)
+    wl = workloads.generate(cfg, lambda a, ro, r, s: opt.plan(a, ro, r, s, 0, True, True), n_swarms=args.swarms, seed=2000)
+    db = opt.make_device_batch(wl["agents"], wl["row_offsets"], wl["rows"], None, 0, want_iters=True)
+    N = len(wl["agents"])
+    stamps = torch.zeros((N, 12), dtype=torch.int64, device="cuda")
+    db.launch()
+    it = db.results()["iters"][:, 0]
+    order = torch.from_numpy(np.argsort(-it, kind="stable").astype(np.int32)).cuda()  # expensive agents first, as the bench does
+    db.c.agent_order = order.data_ptr()
+    db.c.debug_stamps = stamps.data_ptr()
+    for _ in range(3):
+        db.launch()
+    torch.cuda.synchronize()
+    st = stamps.cpu().numpy()
+    t0, t1, hw, xcc, slot = st[:, 0], st[:, 1], st[:, 2], st[:, 3] & 15, st[:, 4]
+    tick = 1e-2  # us per tick (100 MHz)
+    span = (t1.max() - t0.min()) * tick
+    dur = (t1 - t0) * tick
+    place = (xcc << 32) | (hw & 0xffff)  # XCC, SE, SH, CU, pipe, SIMD, wave slot
+    n_slots = len(np.unique(place))
+    print("agents %d, launch span %.1f us, wave slots used %d, mean solve %.2f us, sum of solves / (slots x span) = %.3f"
+          % (N, span, n_slots, dur.mean(), dur.sum() / (n_slots * span)))
+    gaps, first, last = [], [], []
+    for p in np.unique(place):
+        sel = np.where(place == p)[0]
+        o = sel[np.argsort(t0[sel])]
+        gaps.append((t0[o][1:] - t1[o][:-1]) * tick)
+        first.append((t0[o][0] - t0.min()) * tick)
+        last.append((t1.max() - t1[o][-1]) * tick)
+    gaps = np.concatenate(gaps)
+    print("gap between two wavefronts on one slot: p10 %.2f  p50 %.2f  p90 %.2f  mean %.2f us (n = %d); per agent: %.1f %% of the mean solve"
+          % (np.percentile(gaps, 10), np.percentile(gaps, 50), np.percentile(gaps, 90), gaps.mean(), len(gaps), 100 * gaps.mean() / dur.mean()))
+    print("slot first used after launch start: p50 %.2f  max %.2f us;  slot idle before launch end (tail): p50 %.2f  p90 %.2f  max %.2f us"
+          % (np.percentile(first, 50), np.max(first), np.percentile(last, 50), np.percentile(last, 90), np.max(last)))
+    # concurrency over the launch
+    ev = np.concatenate([np.stack([t0, np.ones_like(t0)], 1), np.stack([t1, -np.ones_like(t1)], 1)])
+    ev = ev[np.argsort(ev[:, 0], kind="stable")]
+    conc = np.cumsum(ev[:, 1])
+    tt = (ev[:, 0] - t0.min()) * tick
+    for frac in (0.1, 0.25, 0.5, 0.75, 0.9, 0.95, 0.99):
+        i = np.searchsorted(tt, frac * span)
+        print("  at %2.0f %% of the span: %4d wavefronts in flight" % (100 * frac, conc[min(i, len(conc) - 1)]))
+    opt.close()
+
+
+if __name__ == "__main__":
+    main()
