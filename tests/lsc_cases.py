@@ -45,6 +45,24 @@ def random_swarm(cfg, n_agents, seed, spread=2.5, first=False):
                 nbr_ids=np.array(ids, np.int32), position=pos, velocity=vel)
 
 
+def crowd(cfg, n_agents, seed, spread=0.3):
+    """random_swarm squeezed into a small volume, every agent a neighbour of every other, and odd agents flying their even
+    predecessor's plan up to 1 cm of noise: relative hulls that contain the origin (vehicles in collision), graze it, or
+    are nearly flat -- the cases in which the generator's separating-plane shortcut must not fire."""
+    sw = random_swarm(cfg, n_agents, seed, spread=spread)
+    rng = np.random.default_rng(seed + 7)
+    for a in range(1, n_agents, 2):
+        sw["plans"][a] = sw["plans"][a - 1] + rng.normal(0, 0.01, sw["plans"][a].shape).astype(np.float32)
+        if a % 4 == 1:
+            sw["plans"][a, :, :, 2] = sw["plans"][a - 1, :, :, 2]  # same height: a flat relative hull
+    if cfg.world_dimension == 2:
+        sw["plans"][..., 2] = 1.0
+    ids = [j for a in range(n_agents) for j in range(n_agents) if j != a]
+    sw["nbr_ids"] = np.array(ids, np.int32)
+    sw["nbr_offsets"] = (np.arange(n_agents + 1) * (n_agents - 1)).astype(np.int32)
+    return sw
+
+
 def random_dynamic_obstacles(n_dyn, seed, spread=2.5, first_at=None):
     """Spin-obstacle-like dynamic obstacles (position, velocity, radius, max_acc, downwash) plus the two planner
     parameters of the size prediction.  `first_at`: a (position, velocity) pair that obstacle 0 copies, to hit the

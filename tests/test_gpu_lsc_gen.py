@@ -13,10 +13,13 @@ from test_lsc_gen import _cmp_rows, _oracle_rows
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("M,dim,first", [(5, 3, False), (10, 3, False), (10, 2, False), (5, 3, True)])
-def test_device_rows_match_oracle(gpu_required, M, dim, first):
+@pytest.mark.parametrize("M,dim,first,crowd", [(5, 3, False, False), (10, 3, False, False), (10, 2, False, False), (5, 3, True, False),
+                                                (5, 3, False, True), (10, 2, False, True)])
+def test_device_rows_match_oracle(gpu_required, M, dim, first, crowd):
+    """crowd: vehicles on top of each other -- relative hulls that contain the origin (the tetrahedron search behind the
+    generator's separating-plane test), graze it, or are flat."""
     cfg = abi.make_config(dim=dim, M=M)
-    sw = lsc_cases.random_swarm(cfg, 48, seed=500 + M + dim)
+    sw = lsc_cases.crowd(cfg, 48, seed=500 + M + dim) if crowd else lsc_cases.random_swarm(cfg, 48, seed=500 + M + dim)
     ro, rows = _oracle_rows(cfg, sw, first)
     opt = BatchTrajOptimizer(cfg)
     try:

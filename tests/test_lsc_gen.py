@@ -84,6 +84,21 @@ def test_device_source_matches_oracle(M, dim, first):
     _cmp_rows(erows, rows)
 
 
+@pytest.mark.parametrize("M,dim", [(5, 3), (10, 2), (10, 3)])
+def test_device_source_matches_oracle_in_a_crowd(M, dim):
+    """Vehicles on top of each other: the relative hull contains the origin or grazes it, so the generator's
+    separating-plane shortcut does not apply and its tetrahedron search decides (lsc_core.hpp hull6_closest_to_origin);
+    the oracle always runs the full enumeration."""
+    cfg = abi.make_config(dim=dim, M=M)
+    sw = lsc_cases.crowd(cfg, 12, seed=900 + M + dim)
+    ro, rows = _oracle_rows(cfg, sw)
+    eo, erows = E.generate_lsc(cfg, sw["plans"], sw["goals"], sw["radius"], sw["downwash"], sw["nbr_offsets"], sw["nbr_ids"])
+    assert np.array_equal(ro, eo)
+    zero = (rows["normal"] == 0).all(axis=1)
+    assert zero.sum() >= 30, "the crowd holds pairs whose hull contains the origin (zero normal: the row is skipped, traj_optimizer.cpp:421)"
+    _cmp_rows(erows, rows)
+
+
 def test_shifted_plans_satisfy_their_own_half_spaces():
     """DLSC guarantee (the reason the QP stays feasible): when the previous plans keep the collision distance,
     every agent's shifted plan satisfies every generated row."""
