@@ -294,11 +294,18 @@ constexpr double PRUNE_MARGIN = 1e-4;  // metres by which a row has to be implie
 DQ_FN bool lsc_row_implied(const LscGenArgs &g, const float *box, const LscRows &r, int i) {
     const float nv[3] = {r.nx, r.ny, r.nz};
     const float pv[3] = {r.px[i], r.py[i], r.pz[i]};
+    // The last point of the last segment of an agent obstacle is also a row of the goal LP (goal_optimizer.cpp:176-195),
+    // whose variable is not a control point: the LP has the faces of the last corridor box (:158-173) but no variable
+    // bounds, so there only the corridor box may imply the row.
+    const uint32_t key = r.key[i];
+    const bool lp_row = (int)(key & 0xFF) == g.M - 1 && (int)((key >> 8) & 0xF) == g.n1 - 1 && !((key >> 12) & 1);
+    if (lp_row && !g.use_sfc) return false;
     double mn = 0.0, rhs = r.d[i];
     for (int k = 0; k < 3; k++) {
         if (k >= g.dim) continue;
         double lo = g.world_min[k], hi = g.world_max[k];
-        if (g.use_sfc) {
+        if (lp_row) { lo = (double)box[k]; hi = (double)box[3 + k]; }
+        else if (g.use_sfc) {
             lo = (double)box[k] > lo ? (double)box[k] : lo;
             hi = (double)box[3 + k] < hi ? (double)box[3 + k] : hi;
         }

@@ -290,6 +290,8 @@ def test_pruned_rows_are_implied_rows_and_the_plans_do_not_change(M, dim, n_dyn)
             r = f[i]
             lo = np.maximum(sfc[a, r["m"], :3].astype(np.float64), wmin)[:dim]
             hi = np.minimum(sfc[a, r["m"], 3:].astype(np.float64), wmax)[:dim]
+            if r["m"] == M - 1 and r["i"] == cfg.n and not (r["flags"] & 1):  # also a row of the goal LP, which has no variable bounds
+                lo, hi = sfc[a, r["m"], :3].astype(np.float64)[:dim], sfc[a, r["m"], 3:].astype(np.float64)[:dim]
             nv = r["normal"].astype(np.float64)[:dim]
             mn = np.where(nv >= 0, nv * lo, nv * hi).sum()
             assert mn - (r["d"] + (nv * r["point"].astype(np.float64)[:dim]).sum()) >= 1e-4 - 1e-12
@@ -307,6 +309,20 @@ def test_pruned_rows_are_implied_rows_and_the_plans_do_not_change(M, dim, n_dyn)
     ok = a1["status"] == abi.OK
     if ok.any():
         assert np.abs(a1["x"][ok] - a2["x"][ok]).max() < 1e-8
+
+
+def test_pruning_by_the_world_box_alone_keeps_the_goal_lp_rows():
+    """Without corridor boxes (world_use_octomap off) rows are implied by the variable bounds only -- which the goal LP does
+    not have: the rows it shares with the QP (last point of the last segment, agent obstacles) all stay."""
+    cfg = abi.make_config(dim=3, M=5, world_min=(-0.5, -0.5, 0.9), world_max=(0.5, 0.5, 1.4))  # most neighbours are far outside
+    sw = lsc_cases.random_swarm(cfg, 14, seed=41, spread=2.5)
+    args = (cfg, sw["plans"], sw["goals"], sw["radius"], sw["downwash"], sw["nbr_offsets"], sw["nbr_ids"])
+    full_ro, full = E.generate_lsc(*args)
+    pr = dict(sfc=None)
+    ro, rows = E.generate_lsc(*args, prune=pr)
+    assert 0 < len(rows) < len(full)
+    lp = lambda r: int(((r["m"] == cfg.M - 1) & (r["i"] == cfg.n)).sum())  # noqa: E731
+    assert lp(rows) == lp(full) > 20
 
 
 def test_pruning_leaves_the_plans_of_the_stress_workload_unchanged():
