@@ -228,12 +228,13 @@ class StressStep:
     after it (DESIGN.md section 5).  The batch is stationary (the generators read the workload's plan table every step);
     the payload that travels and the copies into the gathered table are the real ones."""
 
-    def __init__(self, device_index, rank, world, dist, prune=True):
+    def __init__(self, device_index, rank, world, dist, prune=True, order_hint=True):
         import numpy as np
         import torch
         from dlsc_gc_planner_amd import abi, sharding, workloads
         from dlsc_gc_planner_amd.planner import BatchTrajOptimizer
         self.torch, self.dist, self.world, self.rank = torch, dist, world, rank
+        self.order_hint = order_hint
         cfg = workloads.x2048_config(device=device_index)
         self.cfg = cfg
         w = workloads.x2048(cfg)
@@ -291,6 +292,8 @@ class StressStep:
         gen, db, _, sel = part
         gen.generate(self.goals, plans=self.plans)
         db.launch(True, True)
+        if self.order_hint:
+            db.update_order()  # the next step's launch order from this step's iteration counts, on the device
         self.own_ctrl.index_copy_(0, sel, db.out_ctrl.view(len(sel), -1))
         self.own_goal.index_copy_(0, sel, db.out_goal)
         self.own_status.index_copy_(0, sel, db.out_status.view(-1, 1))
@@ -498,6 +501,9 @@ def main():
         ss_all = StressStep(local_rank, rank, world, dist if use_dist else None, prune=False)
         ms_all_rows = ss_all.time(30, False)
         ss_all.close()
+        ss_id = StressStep(local_rank, rank, world, dist if use_dist else None, order_hint=False)
+        ms_id_order = ss_id.time(30, False)
+        ss_id.close()
         ss = StressStep(local_rank, rank, world, dist if use_dist else None)
         ms_serial = ss.time(30, False)
         ms_pipe = ss.time(30, True) if use_dist else None
@@ -506,7 +512,11 @@ def main():
                               "sharded by contiguous id range" % ss.rows_per_agent,
                   "agents_total": ss.N, "agents_this_rank": ss.n_loc, "interior_agents_rank0": ss.n_interior, "halo_agents_rank0": ss.n_halo,
                   "ms_per_step_serial_exchange": ms_serial, "ms_per_step_pipelined_exchange": ms_pipe,
-                  "ms_per_step_without_presolve": ms_all_rows, "rows_kept_per_agent_rank0": ss.rows_kept_per_agent(),
+                  "ms_per_step_without_presolve": ms_all_rows, "ms_per_step_id_launch_order": ms_id_order,
+                  "launch_order": "every step computes the next step's launch order on the device from its own iteration counts "
+                                  "(dlscqp_launch_order_device, inside the timed step); the batch is stationary, so the hint is "
+                                  "better than a moving crowd's",
+                  "rows_kept_per_agent_rank0": ss.rows_kept_per_agent(),
                   "presolve": "the half-space generator drops rows implied by the agent's corridor boxes (dlscqp_lsc_gen.prune): same "
                               "verdicts and solutions, fewer rows for the plan kernel to scan",
                   "agent_qp_per_s": ss.N / (min(ms_serial, ms_pipe) if ms_pipe else ms_serial) * 1e3,

@@ -872,6 +872,80 @@ extern "C" int dlscqp_waypoint_trap_device(dlscqp_ctx *c, const dlscqp_lsc_gen *
 }
 
 // ---------------------------------------------------------------------------------------------
+// launch order of the next step (include/dlscqp.h: dlscqp_launch_order_device)
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr int ORDER_THREADS = 1024, ORDER_BINS = 64;
+
+// One workgroup: counting sort of the agents by the iteration count of the step just planned, descending (bin 0 = 63
+// iterations or more).  A wavefront takes 64 consecutive agents per round and handles the bins present among them one
+// after the other (usually one or two): one LDS atomic per bin and wavefront instead of one per agent.
+template <class F>
+__device__ __forceinline__ void order_bins_of_wave(int bin, bool valid, F f) {
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {  // uniform
+        const int leader = __builtin_ctzll(todo);
+        const int lb = __shfl(bin, leader, 64);
+        const unsigned long long same = __ballot(valid && bin == lb);
+        f(lb, same, leader, valid && bin == lb, __popcll(same & ((1ull << lane) - 1ull)));
+        todo &= ~same;
+    }
+}
+
+__global__ __launch_bounds__(ORDER_THREADS) void dlscqp_order_kernel(const int32_t *iters, int n, int32_t *order) {
+    __shared__ int hist[ORDER_BINS], base[ORDER_BINS], cursor[ORDER_BINS];
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < ORDER_BINS) { hist[threadIdx.x] = 0; cursor[threadIdx.x] = 0; }
+    __syncthreads();
+    auto bin_of = [&](int idx) {
+        const int it = iters[(size_t)idx * 4];  // out_iters: iterations, adds, drops, active rows at exit
+        return ORDER_BINS - 1 - (it < 0 ? 0 : (it > ORDER_BINS - 1 ? ORDER_BINS - 1 : it));
+    };
+    for (int i0 = 0; i0 < n; i0 += ORDER_THREADS) {
+        const int idx = i0 + (int)threadIdx.x;
+        const bool valid = idx < n;
+        order_bins_of_wave(valid ? bin_of(idx) : -1, valid, [&](int lb, unsigned long long same, int leader, bool, int) {
+            if (lane == leader) atomicAdd(&hist[lb], __popcll(same));
+        });
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // exclusive prefix sum over the 64 bins, one wavefront
+        const int h = hist[lane];
+        int incl = h;
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) {
+            const int v = __shfl_up(incl, s, 64);
+            incl += lane >= s ? v : 0;
+        }
+        base[lane] = incl - h;
+    }
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += ORDER_THREADS) {
+        const int idx = i0 + (int)threadIdx.x;
+        const bool valid = idx < n;
+        order_bins_of_wave(valid ? bin_of(idx) : -1, valid, [&](int lb, unsigned long long same, int leader, bool mine, int rank) {
+            int start = 0;
+            if (lane == leader) start = atomicAdd(&cursor[lb], __popcll(same));
+            start = __shfl(start, leader, 64);
+            if (mine) order[base[lb] + start + rank] = idx;
+        });
+    }
+}
+}  // namespace
+
+extern "C" int dlscqp_launch_order_device(dlscqp_ctx *c, const int32_t *iters, int32_t n_agents, int32_t *order_out, void *stream) {
+    g_last_error.clear();
+    if (!c || n_agents < 0) { g_last_error = "invalid argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (n_agents == 0) return DLSCQP_SUCCESS;
+    if (!iters || !order_out) { g_last_error = "null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    hipLaunchKernelGGL(dlscqp_order_kernel, dim3(1), dim3(ORDER_THREADS), 0, (hipStream_t)stream, iters, (int)n_agents, order_out);
+    HIP_TRY(hipGetLastError());
+    return DLSCQP_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------------
 // between two launches (include/dlscqp.h: dlscqp_advance)
 // ---------------------------------------------------------------------------------------------
 namespace {

@@ -72,15 +72,36 @@ struct HullStore {
     DQ_FN D3 get(int a) const { const F3 v = getf(a); return d3(v.x, v.y, v.z); }
 };
 
+// x is THE closest point of a convex set to the origin iff p.x >= x.x for every point p of the set (for a hull: every
+// vertex).  With the tolerance below a candidate that passes is within 1.5e-7 |x| of the exact projection, i.e. the same
+// point to float32 resolution -- which is what the caller rounds it to.
+constexpr double HULL_KKT_TOL = 1e-14;
+DQ_FN bool hull6_is_projection(const HullStore &p, D3 x, double xx) {
+    double lo = ddot(p.get(0), x);
+#pragma unroll 1
+    for (int a = 1; a < 6; a++) {
+        const double s = ddot(p.get(a), x);
+        lo = s < lo ? s : lo;
+    }
+    return lo >= xx * (1.0 - HULL_KKT_TOL);
+}
+
 DQ_FN D3 hull6_closest_to_origin(const HullStore &p) {
     D3 best = p.get(0);
     double bd = ddot(best, best);
-    // vertices, edges and faces: the closest point of the hull's boundary
+    // The closest point of the hull's boundary: vertices, then edges, then faces -- each stage only if the best point so
+    // far is not already the projection (a neighbour's relative hull is a thin sliver far from the origin: its closest
+    // point is a vertex or lies on an edge, in 2-D always; the 20 faces are 60 % of the arithmetic).
 #pragma unroll 1
-    for (int a = 0; a < 6; a++) {
+    for (int a = 1; a < 6; a++) {
         const D3 pa = p.get(a);
         const double da = ddot(pa, pa);
         if (da < bd) { bd = da; best = pa; }
+    }
+    if (hull6_is_projection(p, best, bd)) return best;
+#pragma unroll 1
+    for (int a = 0; a < 6; a++) {
+        const D3 pa = p.get(a);
 #pragma unroll 1
         for (int b = a + 1; b < 6; b++) {
             const D3 ab = p.get(b) - pa;
@@ -93,6 +114,16 @@ DQ_FN D3 hull6_closest_to_origin(const HullStore &p) {
                     if (dc < bd) { bd = dc; best = c; }
                 }
             }
+        }
+    }
+    if (hull6_is_projection(p, best, bd)) return best;
+#pragma unroll 1
+    for (int a = 0; a < 6; a++) {
+        const D3 pa = p.get(a);
+#pragma unroll 1
+        for (int b = a + 1; b < 6; b++) {
+            const D3 ab = p.get(b) - pa;
+            const double den = ddot(ab, ab), num = -ddot(pa, ab);
 #pragma unroll 1
             for (int ci = b + 1; ci < 6; ci++) {
                 const D3 ac = p.get(ci) - pa;

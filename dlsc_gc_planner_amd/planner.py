@@ -252,6 +252,24 @@ class DeviceBatch:
         self.order = self.torch.from_numpy(order).to(self.device)
         self.c.agent_order = self.order.data_ptr()
 
+    def update_order(self, stream=None):
+        """Launch order of the NEXT launch from the iteration counts of the last one, on the device
+        (dlscqp_launch_order_device): the agents that needed the most iterations first.  Two order buffers alternate,
+        so the launch that is still reading its order is not disturbed."""
+        assert self.out_iters is not None, "make_device_batch(..., want_iters=True)"
+        torch = self.torch
+        if getattr(self, "_orders", None) is None:
+            self._orders = [torch.zeros(self.n_agents, dtype=torch.int32, device=self.device) for _ in range(2)]
+            self._order_i = 0
+        self._order_i ^= 1
+        o = self._orders[self._order_i]
+        s = torch.cuda.current_stream(self.device) if stream is None else stream
+        rc = self.opt.lib.dlscqp_launch_order_device(self.opt.handle, C.c_void_p(self.out_iters.data_ptr()), self.n_agents,
+                                                     C.c_void_p(o.data_ptr()), C.c_void_p(s.cuda_stream))
+        self.opt._check(rc, "dlscqp_launch_order_device")
+        self.order = o
+        self.c.agent_order = o.data_ptr()
+
     def flip_outputs(self):
         """Double-buffer the outputs another stream reads (control points, sub-goal, status): after the call `out_ctrl`,
         `out_goal` and `out_status` are the set the NEXT launch writes, and the previous set stays untouched until the

@@ -213,6 +213,14 @@ typedef struct dlscqp_device_batch {
 
 int dlscqp_plan_batch_device(dlscqp_ctx *ctx, const dlscqp_device_batch *batch, void *stream);
 
+/* Launch order for the NEXT replanning step from the iteration counts of the one just planned (out_iters of
+ * dlscqp_device_batch, 4 int32 per agent): order_out[b] = the agent workgroup b plans, agents with the most active-set
+ * iterations first, ties in no particular order -- pass it as dlscqp_device_batch.agent_order.  An agent that was hard to plan
+ * is usually hard again 0.2 s later, and a launch is as long as the agent that finishes last; the order changes when agents
+ * run, never what they compute.  Device buffers (iters [n_agents][4], order_out [n_agents]); runs on `stream` like the other
+ * *_device entry points; the reference has no counterpart (its agents are planned one after the other, multi_sync_simulator.cpp:516-524). */
+int dlscqp_launch_order_device(dlscqp_ctx *ctx, const int32_t *iters, int32_t n_agents, int32_t *order_out, void *stream);
+
 /* ---- DLSC-GC half-space generation on the device --------------------------------------
  * TrajPlanner::generateDLSCGC for neighbouring AGENTS (traj_planner.cpp:603-666) together with the shift of the
  * previous plans that precedes it (initialTrajPlanningPrevSol / obstaclePredictionWithPrevSol, :409-421,

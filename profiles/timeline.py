@@ -20,6 +20,7 @@ LIB = os.path.join(CSRC, "libdlscqp_timeline.so")
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--swarms", type=int, default=512)
+    ap.add_argument("--workload", default="s64", choices=["s64", "x2048"])
     args = ap.parse_args()
     if not os.path.exists(LIB):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
@@ -30,6 +31,8 @@ def main():
     import torch
     from dlsc_gc_planner_amd import workloads
     from dlsc_gc_planner_amd.planner import BatchTrajOptimizer
+    if args.workload == "x2048":
+        return x2048(np, torch)
     cfg = workloads.s64_config()
     opt = BatchTrajOptimizer(cfg)
     wl = workloads.generate(cfg, lambda a, ro, r, s: opt.plan(a, ro, r, s, 0, True, True), n_swarms=args.swarms, seed=2000)
@@ -74,6 +77,41 @@ def main():
         i = np.searchsorted(tt, frac * span)
         print("  at %2.0f %% of the span: %4d wavefronts in flight" % (100 * frac, conc[min(i, len(conc) - 1)]))
     opt.close()
+
+
+def x2048(np, torch):
+    """The stress batch (2 048 agents = one wavefront per wave slot): the launch is as long as its slowest agent."""
+    sys.argv = ["bench.py"]
+    import bench
+    ss = bench.StressStep(0, 0, 1, None)
+    ss.time(3, False)
+    gen, db, _, sel = ss.parts[0]
+    stamps = torch.zeros((ss.N, 12), dtype=torch.int64, device="cuda")
+    db.c.debug_stamps = stamps.data_ptr()
+    for _ in range(3):
+        db.launch(True, True)
+    torch.cuda.synchronize()
+    st = stamps.cpu().numpy()
+    it = db.results()["iters"]
+    cnt = gen.row_counts.cpu().numpy() if getattr(gen, "row_counts", None) is not None else np.diff(gen.row_offsets)
+    dur = (st[:, 1] - st[:, 0]) * 1e-2
+    span = (st[:, 1].max() - st[:, 0].min()) * 1e-2
+    print("agents %d, launch span %.1f us; solve us: mean %.1f  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f" %
+          (ss.N, span, dur.mean(), np.percentile(dur, 50), np.percentile(dur, 90), np.percentile(dur, 99), dur.max()))
+    print("rows per agent: mean %.0f max %d; iterations: mean %.2f max %d" % (cnt.mean(), cnt.max(), it[:, 0].mean(), it[:, 0].max()))
+    order = np.argsort(-dur)[:8]
+    for a in order:
+        print("  agent %4d: %6.1f us, %2d iterations (%d adds, %d drops), %4d rows -> %.1f us per pricing pass" %
+              (a, dur[a], it[a, 0], it[a, 1], it[a, 2], cnt[a], dur[a] / (it[a, 0] + 1)))
+    z = it[:, 0] == 0
+    if z.any():
+        print("agents with 0 iterations: %d, mean %.1f us (rows %.0f)" % (z.sum(), dur[z].mean(), cnt[z].mean()))
+    # us per pass against rows
+    x, y = cnt.astype(float), dur / (it[:, 0] + 1)
+    A = np.stack([np.ones_like(x), x], 1)
+    c = np.linalg.lstsq(A, y, rcond=None)[0]
+    print("least squares: us per pricing pass = %.2f + %.4f x rows" % (c[0], c[1]))
+    ss.close()
 
 
 if __name__ == "__main__":
