@@ -15,8 +15,10 @@ What is timed, and how the line avoids flattering itself:
   * the timed loop rotates through `--batches` (4) DIFFERENT batches: the same agents at consecutive replanning steps of
     the closed-loop workload generator, 0.2 s apart;
   * agents are launched most-expensive-first by the iteration counts of the PREVIOUS batch (what a closed loop knows when
-    it plans a step); the same loop in plain id order is timed right after and reported beside it
-    (`ms_per_step_no_order_hint`);
+    it plans a step), and the order is computed where a closed loop computes it: on the device, by
+    dlscqp_launch_order_device after every step, INSIDE the timed loop; the same loop in plain id order
+    (`ms_per_step_no_order_hint`) and with orders prepared on the host before the loop (`ms_per_step_host_order`) are timed
+    right after and reported beside it;
   * a "hard" batch made only of agents with at least five active rows at their solution is timed too (`hard_batch`).
 Rank 0 prints one JSON line.  `value` = agent-QPs of all ranks / max-over-ranks wall time of the K timed steps.
 """
@@ -425,10 +427,19 @@ def main():
         xchg = sharding.PlanExchange(dist, world, N, (int(np.prod(shape1)), 3, 1), dev)
 
     counter = [0]
+    device_order = [False]  # the next batch's launch order from this batch's iteration counts, computed on the device
 
     def step(pipelined):
         db = dbs[counter[0] % B]
+        nxt = dbs[(counter[0] + 1) % B]
         counter[0] += 1
+        if device_order[0]:
+            plan_step(db, pipelined)
+            nxt.update_order(iters=db.out_iters)
+        else:
+            plan_step(db, pipelined)
+
+    def plan_step(db, pipelined):
         if not use_dist:
             db.launch(True, True)
         elif pipelined:
@@ -445,8 +456,9 @@ def main():
             xchg.table()  # the next launch waits for the exchange
 
     def timed(steps, pipelined, orders, record_kernel_times=False):
+        device_order[0] = isinstance(orders, str) and orders == "device"
         for j, db in enumerate(dbs):
-            db.set_order(None if orders is None else orders[j])
+            db.set_order(None if orders is None or device_order[0] else orders[j])
         counter[0] = 0
         for _ in range(B):
             step(pipelined)
@@ -471,7 +483,7 @@ def main():
         return el
 
     head_pipelined = use_dist and pipelined_ok and args.exchange == "pipelined"
-    elapsed = timed(args.steps, head_pipelined, hint, record_kernel_times=True)
+    elapsed = timed(args.steps, head_pipelined, "device", record_kernel_times=True)
     kms = opt.kernel_times_ms(args.steps)
     if use_dist:
         # the gathered table must hold this rank's own block of the last step
@@ -485,13 +497,15 @@ def main():
     # the same loop without the launch-order hint, and (N > 1) with the other exchange mode
     side_steps = max(B, min(args.steps, 200))
     el_nohint = float("nan") if args.headline_only else timed(side_steps, head_pipelined, None)
+    el_hostorder = float("nan") if args.headline_only else timed(side_steps, head_pipelined, hint)
     exch = None
     if use_dist and not args.headline_only:
         exch = {"pipelined": None, "serial": None, "steps_of_the_second_mode": side_steps}
         exch["pipelined" if head_pipelined else "serial"] = elapsed / args.steps * 1e3
         if pipelined_ok:  # the other mode, same batches, same launch order
-            el_other = timed(side_steps, not head_pipelined, hint)
+            el_other = timed(side_steps, not head_pipelined, "device")
             exch["serial" if head_pipelined else "pipelined"] = el_other / side_steps * 1e3
+    device_order[0] = False
     for j, db in enumerate(dbs):
         db.set_order(hint[j])
 
@@ -604,8 +618,11 @@ def main():
                              "while the next step plans the agents without remote neighbours (all of them here)"
                              if head_pipelined else "one RCCL all-gather of control points, sub-goal and status per step, after the launch"),
                 "exchange_modes_ms_per_step": exch,
-                "launch_order": "iteration counts of the previous replanning step (a different batch), descending; correlation of "
-                                "consecutive steps' counts %.2f" % hint_corr,
+                "launch_order": "iteration counts of the previous replanning step (a different batch), descending, sorted on the device "
+                                "after every step inside the timed loop (dlscqp_launch_order_device); correlation of consecutive "
+                                "steps' counts %.2f" % hint_corr,
+                "ms_per_step_host_order": None if args.headline_only else el_hostorder / side_steps * 1e3,
+                "host_order": "the same hint as permutations prepared on the host before the timed loop (round 1's method)",
                 "ms_per_step_no_order_hint": None if args.headline_only else el_nohint / side_steps * 1e3,
                 "qp_per_s_no_order_hint": None if args.headline_only else world * N * side_steps / el_nohint,
                 "solved_fraction": float(ok.mean()), "mean_active_set_iterations": float(it[:, 0].mean()),

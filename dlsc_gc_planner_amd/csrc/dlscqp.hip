@@ -569,6 +569,8 @@ struct dlscqp_ctx {
     Slot *d_slots = nullptr;
     hipStream_t stream = nullptr;
     int max_dyn_lds[DQ_N_INSTANCES] = {};
+    int *d_order_scratch = nullptr;  // dlscqp_launch_order_device: two blocks of 64 counts + 64 cursors, used alternately
+    unsigned order_calls = 0;
     void *work = nullptr;  // working sets of the WS_HBM kernel
     size_t work_bytes = 0;
     // staging for the host-buffer entry points
@@ -644,6 +646,7 @@ extern "C" void dlscqp_destroy(dlscqp_ctx *c) {
     if (c->d_slots) (void)hipFree(c->d_slots);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->work) (void)hipFree(c->work);
+    if (c->d_order_scratch) (void)hipFree(c->d_order_scratch);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -877,9 +880,9 @@ extern "C" int dlscqp_waypoint_trap_device(dlscqp_ctx *c, const dlscqp_lsc_gen *
 namespace {
 constexpr int ORDER_THREADS = 1024, ORDER_BINS = 64;
 
-// One workgroup: counting sort of the agents by the iteration count of the step just planned, descending (bin 0 = 63
-// iterations or more).  A wavefront takes 64 consecutive agents per round and handles the bins present among them one
-// after the other (usually one or two): one LDS atomic per bin and wavefront instead of one per agent.
+// Counting sort of the agents by the iteration count of the step just planned, descending (bin 0 = 63 iterations or
+// more), one thread per agent in two passes.  A wavefront handles the bins present among its 64 agents one after the
+// other (usually one or two): one atomic per bin and wavefront instead of one per agent.
 template <class F>
 __device__ __forceinline__ void order_bins_of_wave(int bin, bool valid, F f) {
     const int lane = threadIdx.x & 63;
@@ -893,44 +896,62 @@ __device__ __forceinline__ void order_bins_of_wave(int bin, bool valid, F f) {
     }
 }
 
-__global__ __launch_bounds__(ORDER_THREADS) void dlscqp_order_kernel(const int32_t *iters, int n, int32_t *order) {
-    __shared__ int hist[ORDER_BINS], base[ORDER_BINS], cursor[ORDER_BINS];
+__device__ __forceinline__ int order_bin(const int32_t *iters, int idx) {
+    const int it = iters[(size_t)idx * 4];  // out_iters: iterations, adds, drops, active rows at exit
+    return ORDER_BINS - 1 - (it < 0 ? 0 : (it > ORDER_BINS - 1 ? ORDER_BINS - 1 : it));
+}
+
+// Pass 1: histogram.  Wavefronts add to the workgroup's LDS histogram, the workgroup adds its non-empty bins to the global
+// one: a few dozen global atomics on the crowded bin (agents that never iterate) instead of one per wavefront -- contended
+// device-scope atomics on one address cost ~100 ns each.  `scratch` = 64 counts + 64 cursors, zero on entry; workgroup 0
+// zeroes the OTHER scratch block, the one the next call uses.
+__global__ __launch_bounds__(ORDER_THREADS) void dlscqp_order_count_kernel(const int32_t *iters, int n, int *scratch, int *scratch_next) {
+    __shared__ int hist[ORDER_BINS];
     const int lane = threadIdx.x & 63;
-    if (threadIdx.x < ORDER_BINS) { hist[threadIdx.x] = 0; cursor[threadIdx.x] = 0; }
+    if (blockIdx.x == 0 && threadIdx.x < 2 * ORDER_BINS) scratch_next[threadIdx.x] = 0;
+    if (threadIdx.x < ORDER_BINS) hist[threadIdx.x] = 0;
     __syncthreads();
-    auto bin_of = [&](int idx) {
-        const int it = iters[(size_t)idx * 4];  // out_iters: iterations, adds, drops, active rows at exit
-        return ORDER_BINS - 1 - (it < 0 ? 0 : (it > ORDER_BINS - 1 ? ORDER_BINS - 1 : it));
-    };
-    for (int i0 = 0; i0 < n; i0 += ORDER_THREADS) {
-        const int idx = i0 + (int)threadIdx.x;
-        const bool valid = idx < n;
-        order_bins_of_wave(valid ? bin_of(idx) : -1, valid, [&](int lb, unsigned long long same, int leader, bool, int) {
-            if (lane == leader) atomicAdd(&hist[lb], __popcll(same));
-        });
-    }
+    const int idx = (int)(blockIdx.x * ORDER_THREADS + threadIdx.x);
+    const bool valid = idx < n;
+    order_bins_of_wave(valid ? order_bin(iters, idx) : -1, valid, [&](int lb, unsigned long long same, int leader, bool, int) {
+        if (lane == leader) atomicAdd(&hist[lb], __popcll(same));
+    });
     __syncthreads();
-    if (threadIdx.x < 64) {  // exclusive prefix sum over the 64 bins, one wavefront
-        const int h = hist[lane];
+    if (threadIdx.x < ORDER_BINS && hist[threadIdx.x] > 0) atomicAdd(&scratch[threadIdx.x], hist[threadIdx.x]);
+}
+
+// Pass 2: slot of an agent = first slot of its bin (exclusive prefix sum over the global histogram) + the range the
+// workgroup claims from the bin's global cursor + the range the wavefront claimed inside the workgroup + the agent's rank
+// among the wavefront's agents of that bin.
+__global__ __launch_bounds__(ORDER_THREADS) void dlscqp_order_scatter_kernel(const int32_t *iters, int n, int *scratch, int32_t *order) {
+    __shared__ int local[ORDER_BINS], first[ORDER_BINS];
+    const int lane = threadIdx.x & 63;
+    if (threadIdx.x < ORDER_BINS) local[threadIdx.x] = 0;
+    __syncthreads();
+    const int idx = (int)(blockIdx.x * ORDER_THREADS + threadIdx.x);
+    const bool valid = idx < n;
+    const int bin = valid ? order_bin(iters, idx) : 0;
+    int within = 0;  // the agent's position among the workgroup's agents of its bin
+    order_bins_of_wave(valid ? bin : -1, valid, [&](int lb, unsigned long long same, int leader, bool mine, int rank) {
+        int start = 0;
+        if (lane == leader) start = atomicAdd(&local[lb], __popcll(same));
+        start = __shfl(start, leader, 64);
+        within = mine ? start + rank : within;
+    });
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int h = scratch[lane];
         int incl = h;
 #pragma unroll
         for (int s = 1; s < 64; s <<= 1) {
             const int v = __shfl_up(incl, s, 64);
             incl += lane >= s ? v : 0;
         }
-        base[lane] = incl - h;
+        const int mine = local[lane];
+        first[lane] = incl - h + (mine > 0 ? atomicAdd(&scratch[ORDER_BINS + lane], mine) : 0);
     }
     __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += ORDER_THREADS) {
-        const int idx = i0 + (int)threadIdx.x;
-        const bool valid = idx < n;
-        order_bins_of_wave(valid ? bin_of(idx) : -1, valid, [&](int lb, unsigned long long same, int leader, bool mine, int rank) {
-            int start = 0;
-            if (lane == leader) start = atomicAdd(&cursor[lb], __popcll(same));
-            start = __shfl(start, leader, 64);
-            if (mine) order[base[lb] + start + rank] = idx;
-        });
-    }
+    if (valid) order[first[bin] + within] = idx;
 }
 }  // namespace
 
@@ -940,7 +961,15 @@ extern "C" int dlscqp_launch_order_device(dlscqp_ctx *c, const int32_t *iters, i
     if (n_agents == 0) return DLSCQP_SUCCESS;
     if (!iters || !order_out) { g_last_error = "null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
     HIP_TRY(hipSetDevice(c->cfg.device));
-    hipLaunchKernelGGL(dlscqp_order_kernel, dim3(1), dim3(ORDER_THREADS), 0, (hipStream_t)stream, iters, (int)n_agents, order_out);
+    if (!c->d_order_scratch) {
+        HIP_TRY(hipMalloc((void **)&c->d_order_scratch, 4 * ORDER_BINS * sizeof(int)));
+        HIP_TRY(hipMemset(c->d_order_scratch, 0, 4 * ORDER_BINS * sizeof(int)));
+    }
+    int *cur = c->d_order_scratch + (c->order_calls & 1) * 2 * ORDER_BINS, *nxt = c->d_order_scratch + ((c->order_calls + 1) & 1) * 2 * ORDER_BINS;
+    c->order_calls++;
+    const int grid = (n_agents + ORDER_THREADS - 1) / ORDER_THREADS;
+    hipLaunchKernelGGL(dlscqp_order_count_kernel, dim3(grid), dim3(ORDER_THREADS), 0, (hipStream_t)stream, iters, (int)n_agents, cur, nxt);
+    hipLaunchKernelGGL(dlscqp_order_scatter_kernel, dim3(grid), dim3(ORDER_THREADS), 0, (hipStream_t)stream, iters, (int)n_agents, cur, order_out);
     HIP_TRY(hipGetLastError());
     return DLSCQP_SUCCESS;
 }

@@ -252,19 +252,23 @@ class DeviceBatch:
         self.order = self.torch.from_numpy(order).to(self.device)
         self.c.agent_order = self.order.data_ptr()
 
-    def update_order(self, stream=None):
+    def update_order(self, stream=None, iters=None):
         """Launch order of the NEXT launch from the iteration counts of the last one, on the device
         (dlscqp_launch_order_device): the agents that needed the most iterations first.  Two order buffers alternate,
-        so the launch that is still reading its order is not disturbed."""
-        assert self.out_iters is not None, "make_device_batch(..., want_iters=True)"
+        so the launch that is still reading its order is not disturbed.  `iters`: the [n_agents, 4] int32 counts of
+        another batch of the same agents (the previous replanning step's) instead of this batch's own."""
         torch = self.torch
+        if iters is None:
+            assert self.out_iters is not None, "make_device_batch(..., want_iters=True)"
+            iters = self.out_iters
+        assert iters.dtype == torch.int32 and iters.numel() == 4 * self.n_agents and iters.is_contiguous()
         if getattr(self, "_orders", None) is None:
             self._orders = [torch.zeros(self.n_agents, dtype=torch.int32, device=self.device) for _ in range(2)]
             self._order_i = 0
         self._order_i ^= 1
         o = self._orders[self._order_i]
         s = torch.cuda.current_stream(self.device) if stream is None else stream
-        rc = self.opt.lib.dlscqp_launch_order_device(self.opt.handle, C.c_void_p(self.out_iters.data_ptr()), self.n_agents,
+        rc = self.opt.lib.dlscqp_launch_order_device(self.opt.handle, C.c_void_p(iters.data_ptr()), self.n_agents,
                                                      C.c_void_p(o.data_ptr()), C.c_void_p(s.cuda_stream))
         self.opt._check(rc, "dlscqp_launch_order_device")
         self.order = o

@@ -218,7 +218,8 @@ int dlscqp_plan_batch_device(dlscqp_ctx *ctx, const dlscqp_device_batch *batch, 
  * iterations first, ties in no particular order -- pass it as dlscqp_device_batch.agent_order.  An agent that was hard to plan
  * is usually hard again 0.2 s later, and a launch is as long as the agent that finishes last; the order changes when agents
  * run, never what they compute.  Device buffers (iters [n_agents][4], order_out [n_agents]); runs on `stream` like the other
- * *_device entry points; the reference has no counterpart (its agents are planned one after the other, multi_sync_simulator.cpp:516-524). */
+ * *_device entry points (calls on one context must be ordered, like its launches: they share a scratch block); the reference
+ * has no counterpart (its agents are planned one after the other, multi_sync_simulator.cpp:516-524). */
 int dlscqp_launch_order_device(dlscqp_ctx *ctx, const int32_t *iters, int32_t n_agents, int32_t *order_out, void *stream);
 
 /* ---- DLSC-GC half-space generation on the device --------------------------------------

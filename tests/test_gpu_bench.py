@@ -34,7 +34,7 @@ def test_single_gpu_line_has_the_contract_fields(gpu_required):
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["oracle_qp_per_s_one_core"] > 0
     assert c["value"] > 3 * c["oracle_qp_per_s_one_core"]  # the kernel's algorithm, not the dense checker
-    assert d["config"]["distinct_batches"] == 4 and d["config"]["ms_per_step_no_order_hint"] > 0
+    assert d["config"]["distinct_batches"] == 4 and d["config"]["ms_per_step_no_order_hint"] > 0 and d["config"]["ms_per_step_host_order"] > 0
 
 
 @pytest.mark.parametrize("mode", ["pipelined", "serial"])
