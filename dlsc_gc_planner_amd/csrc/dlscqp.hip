@@ -459,6 +459,13 @@ struct WaveSfc {
         }
         return false;
     }
+    // largest v (0..8) over the lanes of the wavefront, as a wave-uniform value: ballots and scalar selects
+    __device__ __forceinline__ int uniform_max8(int v) const {
+        int r = 0;
+#pragma unroll
+        for (int t = 1; t <= 8; t++) r = __ballot(v >= t) != 0ull ? t : r;
+        return r;
+    }
     __device__ __forceinline__ void load6(const float *src, float *dst) const {
         for (int k = 0; k < 6; k++) dst[k] = src[k];
     }

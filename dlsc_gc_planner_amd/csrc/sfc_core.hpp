@@ -44,7 +44,8 @@ struct SfcParams {
 
 // getDistanceAndClosestObstacle + collision_constraints.cpp:878-886 for one search point.  Written without
 // lane-dependent branches (clamped table index, fixed trip count, selects): the lanes of a wave test different points.
-DQ_FN bool sfc_point_blocked(const SfcWorldView &w, const float sp[3], double margin) {
+template <class W>
+DQ_FN bool sfc_point_blocked(const W &wave, const SfcWorldView &w, const float sp[3], double margin) {
     int c[3];
     for (int k = 0; k < 3; k++) c[k] = (int)floor((1.0 / w.res) * (double)sp[k]);  // OcTreeBaseImpl::coordToKey
     const int i = c[0] - w.lo[0], j = c[1] - w.lo[1], kk = c[2] - w.lo[2];
@@ -60,8 +61,13 @@ DQ_FN bool sfc_point_blocked(const SfcWorldView &w, const float sp[3], double ma
     for (int t = 0; t < 8; t++) rec[t] = w.near[q * 8 + t];
     const int d2 = (int)rec[0];
     const int nt = (int)rec[1];
+    const float dist = (float)(sqrt((double)(d2 < 0 ? 0 : d2)) * w.res);
+    const bool near_obstacle = inside & (d2 >= 0) & (dist < 1);
+    // a record lists up to 8 nearest cells, most list one or two: the loop runs to the largest count among the points the
+    // wavefront tests (wave-uniform bound; 0 when none of them has an occupied cell within 1 m)
+    const int nt_max = wave.uniform_max8(near_obstacle ? nt : 0);
     double best = 1e30;
-    for (int t = 0; t < 8; t++) {
+    for (int t = 0; t < nt_max; t++) {
         double linf = 0;
         for (int k = 0; k < 3; k++) {
             const int cell = c[k] + sfc_near_offset(rec, 3 * t + k);
@@ -74,8 +80,7 @@ DQ_FN bool sfc_point_blocked(const SfcWorldView &w, const float sp[3], double ma
         }
         best = ((t < nt) & (linf < best)) ? linf : best;
     }
-    const float dist = (float)(sqrt((double)(d2 < 0 ? 0 : d2)) * w.res);
-    return inside & (d2 >= 0) & (dist < 1) & (best < margin + SFC_EPS_F);
+    return near_obstacle & (best < margin + SFC_EPS_F);
 }
 
 // isObstacleInSFC (:859-892): the lattice points of the box, 64 at a time, one per lane.  W::any_of(n, f): true if
@@ -90,7 +95,7 @@ DQ_FN bool sfc_obstacle_in_box(const W &w, const SfcWorldView &g, const float *b
         const int it[3] = {a1, b2, c3};
         float sp[3];
         for (int k = 0; k < 3; k++) sp[k] = (float)(b[k] + it[k] * g.res);
-        return sfc_point_blocked(g, sp, margin);
+        return sfc_point_blocked(w, g, sp, margin);
     });
 }
 

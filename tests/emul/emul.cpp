@@ -315,6 +315,7 @@ struct WaveSfcCpu {
     void load6(const float *src, float *dst) const { for (int k = 0; k < 6; k++) dst[k] = src[k]; }
     void store6(float *dst, const float *src) const { for (int k = 0; k < 6; k++) dst[k] = src[k]; }
     void fence() const {}
+    int uniform_max8(int v) const { return v; }  // one point at a time on the host
 };
 }  // namespace
 
