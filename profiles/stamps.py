@@ -25,7 +25,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--swarms", type=int, default=256)
     args = ap.parse_args()
-    if not os.path.exists(LIB):
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".cpp"))]
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs):  # never a stale diagnostic build
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
                                "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-DDLSCQP_STAMPS", "-o", LIB, os.path.join(CSRC, "dlscqp.hip"),
                                os.path.join(CSRC, "qp_tables.cpp"), os.path.join(CSRC, "sfc_world.cpp"), os.path.join(CSRC, "grid_mapf.cpp")])

@@ -22,7 +22,8 @@ def main():
     ap.add_argument("--swarms", type=int, default=512)
     ap.add_argument("--workload", default="s64", choices=["s64", "x2048"])
     args = ap.parse_args()
-    if not os.path.exists(LIB):
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".cpp"))]
+    if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs):  # never a stale diagnostic build
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                                "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-DDLSCQP_TIMELINE", "-I" + os.path.join(ROOT, "include"), "-o", LIB]
                               + [os.path.join(CSRC, f) for f in ("dlscqp.hip", "qp_tables.cpp", "sfc_world.cpp", "grid_mapf.cpp")])
