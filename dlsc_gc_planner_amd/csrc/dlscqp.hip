@@ -226,14 +226,20 @@ struct KernelArgs {
 // agent stays cache-resident), so an iteration costs several times more -- a capability path for the reference's
 // ten-agent forest missions, not a throughput path.  One wavefront owns a buffer and a wavefront's memory operations
 // are performed in program order, so no fences are needed between its lanes.
-template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK, bool WS_HBM = false>
+// WS = WS_S_HBM: only S = R^-1 (the packed triangle, r (r + 1) / 2 doubles) lives in the per-slot HBM buffer; Q, N_T, x and the
+// bound table stay in LDS.  That fits every supported reduced dimension (r <= 128: 150 KB) -- the forest missions with four
+// slack obstacles (r = 124) run this way -- and WS_HBM remains for batches whose flag array of cold rows is what overflows.
+enum { WS_LDS = 0, WS_HBM = 1, WS_S_HBM = 2 };
+template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK, int WS = WS_LDS>
 __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, KernelArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];
     if ((int)blockIdx.x >= a.n_slots_launch) return;
     const int slot = a.slot0 + (int)blockIdx.x;
     unsigned char *smem;
-    if constexpr (WS_HBM) smem = a.work + (size_t)slot * a.work_stride;
+    if constexpr (WS == WS_HBM) smem = a.work + (size_t)slot * a.work_stride;
     else smem = lds;
+    double *s_ext = nullptr;
+    if constexpr (WS == WS_S_HBM) s_ext = reinterpret_cast<double *>(a.work + (size_t)slot * a.work_stride);
     const int ag = a.order ? a.order[slot] : slot;
     if (ag < 0 || ag >= a.n_agents) return;
     WaveGpu w;
@@ -257,7 +263,7 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
     const int rb = a.row_offsets[ag], re = a.row_counts ? rb + a.row_counts[ag] : a.row_offsets[ag + 1];
     const int M = kp.M, n1 = kp.n1;
     const size_t xs = (size_t)kp.dim * M * n1 + (size_t)M * a.max_slack_obs;
-    plan_agent<RC, DIMS, FS, MS, KU, SU, SLK>(w, kp, lay, smem, a.agents + ag, a.rows, rb, re - rb,
+    plan_agent<RC, DIMS, FS, MS, KU, SU, SLK, WaveGpu, WS == WS_S_HBM>(w, kp, lay, smem, a.agents + ag, a.rows, rb, re - rb,
                a.sfc ? a.sfc + (size_t)ag * M * 6 : nullptr, a.max_slack_obs, a.do_goal, a.do_traj,
                a.out_goal ? a.out_goal + (size_t)ag * 3 : nullptr,
                a.out_goal_status ? a.out_goal_status + ag : nullptr,
@@ -265,7 +271,7 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
                a.out_x ? a.out_x + ag * xs : nullptr, a.out_cost ? a.out_cost + ag : nullptr,
                a.out_slack_cost ? a.out_slack_cost + (size_t)ag * a.max_slack_obs : nullptr,
                a.out_status ? a.out_status + ag : nullptr,
-               a.out_iters ? a.out_iters + (size_t)ag * 4 : nullptr);
+               a.out_iters ? a.out_iters + (size_t)ag * 4 : nullptr, s_ext);
 #ifdef DLSCQP_STAMPS
     if (a.out_stamps && threadIdx.x == 0)
         for (int p = 0; p < 12; p++) a.out_stamps[(size_t)ag * 12 + p] = w.acc[p];
@@ -527,7 +533,9 @@ struct KernelChoice {
     int id, KU, SU;
 };
 constexpr int DQ_ID_HBM = 7;  // the runtime-shape two-register instantiation is the one that also exists as WS_HBM
-const kernel_t dlscqp_plan_kernel_hbm = dlscqp_plan_kernel<2, 0, 0, 0, 4, 10, -1, true>;
+const kernel_t dlscqp_plan_kernel_hbm = dlscqp_plan_kernel<2, 0, 0, 0, 4, 10, -1, WS_HBM>;
+const kernel_t dlscqp_plan_kernel_s_hbm = dlscqp_plan_kernel<2, 0, 0, 0, 4, 10, -1, WS_S_HBM>;
+constexpr int DQ_ID_S_HBM = DQ_N_INSTANCES;  // slot of the S-in-HBM variant in the per-kernel tables of the context
 
 // Kernel instantiation for a batch: the shared table in gi_core.hpp (DQ_INSTANCES / select_instance).
 KernelChoice select_kernel(const KParams &kp, int max_slack_obs, int kmax) {
@@ -575,7 +583,7 @@ struct dlscqp_ctx {
     double *d_tabN = nullptr, *d_tabX0s = nullptr, *d_tabX0g = nullptr, *d_tabNN = nullptr, *d_tabSIW = nullptr;
     Slot *d_slots = nullptr;
     hipStream_t stream = nullptr;
-    int max_dyn_lds[DQ_N_INSTANCES] = {};
+    int max_dyn_lds[DQ_N_INSTANCES + 1] = {};
     int *d_order_scratch = nullptr;  // dlscqp_launch_order_device: two blocks of 64 counts + 64 cursors, used alternately
     unsigned order_calls = 0;
     void *work = nullptr;  // working sets of the WS_HBM kernel
@@ -736,16 +744,27 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         return DLSCQP_ERR_UNSUPPORTED;
     }
     MemLayout lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, instance_n_in_lds(kc.id));
-    const bool ws_hbm = lay.bytes > LDS_LIMIT;
+    bool ws_hbm = lay.bytes > LDS_LIMIT, s_hbm = false;
     KernelArgs a;
     a.work = nullptr;
     a.work_stride = 0;
     if (ws_hbm) {
-        // working set beyond the LDS of a CU: the runtime-shape kernel with per-slot working sets in HBM.  The buffer
-        // belongs to the context: launches of one context that use it must not overlap.
-        kc = KernelChoice{dlscqp_plan_kernel_hbm, DQ_ID_HBM, 4, 10};
-        lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, true);
-        a.work_stride = ((size_t)lay.bytes + 255) & ~(size_t)255;
+        // Working set beyond the LDS of a CU: the runtime-shape kernel with S = R^-1 in a per-slot HBM buffer and the rest in
+        // LDS; if even that does not fit (a very long flag array), with the whole working set in HBM.  The buffer belongs to
+        // the context: launches of one context that use it must not overlap.
+        static const bool force_all = getenv("DLSCQP_DEBUG_WS") && std::string(getenv("DLSCQP_DEBUG_WS")) == "hbm";  // tests
+        const MemLayout lay_s = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, 4, 10, true, false);
+        s_hbm = !force_all && lay_s.bytes <= LDS_LIMIT;
+        if (s_hbm) {
+            ws_hbm = false;
+            kc = KernelChoice{dlscqp_plan_kernel_s_hbm, DQ_ID_S_HBM, 4, 10};
+            lay = lay_s;
+            a.work_stride = ((size_t)lay.s_ext_doubles * sizeof(double) + 255) & ~(size_t)255;
+        } else {
+            kc = KernelChoice{dlscqp_plan_kernel_hbm, DQ_ID_HBM, 4, 10};
+            lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, true);
+            a.work_stride = ((size_t)lay.bytes + 255) & ~(size_t)255;
+        }
         const size_t need = a.work_stride * (size_t)b->n_agents;
         if (need > c->work_bytes) {
             HIP_TRY(hipDeviceSynchronize());
@@ -756,7 +775,8 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
             c->work_bytes = need;
         }
         a.work = static_cast<unsigned char *>(c->work);
-    } else if (lay.bytes > c->max_dyn_lds[kc.id]) {
+    }
+    if (!ws_hbm && lay.bytes > c->max_dyn_lds[kc.id]) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kc.fn), hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
         c->max_dyn_lds[kc.id] = lay.bytes;
     }

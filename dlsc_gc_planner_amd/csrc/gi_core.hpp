@@ -61,9 +61,10 @@ struct MemLayout {
     int oFlag;                        // byte offset of the flags of rows beyond the register cache
     int kmax;                         // most LSC rows of one agent the layout was sized for (dlscqp_device_batch.max_rows_per_agent)
     int bytes;
+    int s_ext_doubles;                // > 0: S = R^-1 is not part of this block but lives in a buffer of that many doubles (dump slots included)
 };
 
-DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int KU, int SU, bool n_in_lds = true) {
+DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int KU, int SU, bool n_in_lds = true, bool s_in_block = true) {
     MemLayout L;
     const int nslk = kp.M * max_slack_obs;
     L.r_max = kp.dim * kp.f + nslk;
@@ -77,7 +78,8 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
     L.oQ = o; o += (L.r_max + 1) * L.ldq;  // + one row for the lanes beyond r (see "no divergence" below)
     L.oDump = L.oQ + L.r_max * L.ldq;      // that row doubles as the dump slots: its content is never used
     if (L.ldq < 32) o += 32 - L.ldq;
-    L.oRp = o; o += L.r_max * (L.r_max + 1) / 2;
+    L.oRp = o; o += s_in_block ? L.r_max * (L.r_max + 1) / 2 : 0;
+    L.s_ext_doubles = s_in_block ? 0 : L.r_max * (L.r_max + 1) / 2 + 32;
     L.oN = o; o += n_in_lds ? kp.P * kp.f : 0;  // instantiations that keep N_T's rows in registers need no copy
     L.oX = o; o += L.nx_max;
     L.oBlo = o; o += kp.nb;
@@ -190,12 +192,15 @@ DQ_FN T pick3(const T *v, int k) {
 // SLK: compile-time number of slack obstacles of the batch (0), or -1 = read it from the arguments.  With
 // DIMS > 0 and SLK = 0 the whole LDS layout up to the bound table (ldq, offsets of S, N, x, dump) and the whitened
 // dimension r are constants: LDS addresses become "lane part + immediate", no address arithmetic in the loops.
-template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK, class W>
+// S_EXT: the packed triangle S = R^-1 lives in `s_ext` (HBM, MemLayout::s_ext_doubles doubles of this agent's own) instead
+// of the block at `mem`: for reduced dimensions whose Q AND S do not fit the LDS of a CU together (r > 110).  The sweeps
+// over Q -- three of the four O(r^2) passes of an iteration -- stay in LDS.
+template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK, class W, bool S_EXT = false>
 DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsigned char *mem,
                       const dlscqp_agent *agp, const RowsView &rows, int row_begin, int K_rows,
                       const float *sfc, int max_slack_obs, int do_goal, int do_traj,
                       float *out_goal, int *out_goal_status, float *out_ctrl, double *out_x,
-                      double *out_cost, double *out_slack_cost, int *out_status, int *out_iters) {
+                      double *out_cost, double *out_slack_cost, int *out_status, int *out_iters, double *s_ext = nullptr) {
     static_assert(RC == 1 || RC == 2, "r <= 128");
     typedef typename W::template Reg<double> RegD;
     typedef typename W::template Reg<float> RegF;
@@ -465,7 +470,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     const int odump = ST ? R_ST * LDQ_ST : lay.oDump;  // 32 dump slots in the spare row of Q, base[odump + (lane & 31)]
     const int oBlo = ST ? (R_ST + 1) * LDQ_ST + R_ST * (R_ST + 1) / 2 + (NREG ? 0 : MS * 6 * FS) + DIMS * MS * 6 : lay.oBlo;
     const int oBhi = lay.oBhi;
-    double *Q = base + oQ, *Rp = base + oRp, *Nl = base + oN, *x = base + oX;
+    double *Q = base + oQ, *Rp = S_EXT ? s_ext : base + oRp, *Nl = base + oN, *x = base + oX;
     double *blo = base + oBlo, *bhi = base + oBhi;
     unsigned char *cold_flag = mem + lay.oFlag;
     const int rc = dim * f;      // whitened control-point dimension
@@ -473,7 +478,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     const int nxc = dim * P;     // control-point variables
     const int cold_rows = K - Kc;
     const int qdummy = r_max;  // spare row of Q for the lanes beyond r
-    const int odump_rp = odump - oRp;  // the dump slots as indices of Rp
+    const int odump_rp = S_EXT ? r_max * (r_max + 1) / 2 : odump - oRp;  // the dump slots as indices of Rp
 
     // terminal segments, traj_optimizer.cpp:543-551 (float32 point difference)
     int T;

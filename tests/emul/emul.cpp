@@ -144,7 +144,7 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
     const int KUsel = ic.KU, SUsel = ic.SU;
     typedef void (*fn_t)(const WaveCpu &, const KParams &, const MemLayout &, unsigned char *, const dlscqp_agent *,
                          const RowsView &, int, int, const float *, int, int, int, float *, int *, float *, double *,
-                         double *, double *, int *, int *);
+                         double *, double *, int *, int *, double *);
     fn_t fn = nullptr;
     switch (ic.id) {
 #define DQ_CASE(ID, RC, DIMS, FS, MS, KU, SU, SLK) \
@@ -153,6 +153,14 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
 #undef DQ_CASE
     }
     MemLayout lay = make_layout(kp, max_slack_obs, kmax, KUsel, SUsel, instance_n_in_lds(ic.id));
+    // test hook: the variant of the two-register runtime-shape instantiation that keeps S = R^-1 outside the block
+    // (the GPU's WS_S_HBM kernel, dlscqp.hip)
+    std::vector<double> s_ext;
+    if (std::getenv("EMUL_S_EXT") && ic.id == 7) {
+        fn = plan_agent<2, 0, 0, 0, 4, 10, -1, WaveCpu, true>;
+        lay = make_layout(kp, max_slack_obs, kmax, KUsel, SUsel, true, false);
+        s_ext.resize(lay.s_ext_doubles);
+    }
     std::vector<unsigned char> mem(lay.bytes + 64 + 4096);
     WaveCpu w;
     const char *rev = std::getenv("EMUL_REVERSE");
@@ -161,6 +169,7 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
     const size_t xs = (size_t)dim * M * n1 + (size_t)M * max_slack_obs;
     for (int a = 0; a < n_agents; a++) {
         std::memset(mem.data(), 0xCD, mem.size());  // poison: nothing may rely on zero-initialised LDS
+        if (!s_ext.empty()) std::memset(s_ext.data(), 0xCD, s_ext.size() * sizeof(double));
         fn(w, kp, lay, mem.data(), agents + a, rv, (int)row_offsets[a],
                    (int)(row_offsets[a + 1] - row_offsets[a]), sfc ? sfc + (size_t)a * M * 6 : nullptr,
                    max_slack_obs, do_goal, do_traj, out_goal ? out_goal + (size_t)a * 3 : nullptr,
@@ -168,7 +177,8 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
                    out_ctrl ? out_ctrl + (size_t)a * M * n1 * 3 : nullptr, out_x ? out_x + a * xs : nullptr,
                    out_cost ? out_cost + a : nullptr,
                    out_slack_cost ? out_slack_cost + (size_t)a * max_slack_obs : nullptr,
-                   out_status ? out_status + a : nullptr, out_iters ? out_iters + (size_t)a * 4 : nullptr);
+                   out_status ? out_status + a : nullptr, out_iters ? out_iters + (size_t)a * 4 : nullptr,
+                   s_ext.empty() ? nullptr : s_ext.data());
         g_last_lds = mem;
     }
     return 0;
@@ -369,7 +379,7 @@ extern "C" int emul_throughput(const dlscqp_config *cfg, int n_agents, const dls
     if (ic.id < 0) return -2;
     typedef void (*fn_t)(const WaveCpu &, const KParams &, const MemLayout &, unsigned char *, const dlscqp_agent *,
                          const RowsView &, int, int, const float *, int, int, int, float *, int *, float *, double *,
-                         double *, double *, int *, int *);
+                         double *, double *, int *, int *, double *);
     fn_t fn = nullptr;
     switch (ic.id) {
 #define DQ_CASE(ID, RC, DIMS, FS, MS, KU, SU, SLK) \
@@ -397,7 +407,7 @@ extern "C" int emul_throughput(const dlscqp_config *cfg, int n_agents, const dls
         for (;;) {
             fn(w, kp, lay, mem.data(), agents + a, rv, (int)row_offsets[a], (int)(row_offsets[a + 1] - row_offsets[a]),
                sfc ? sfc + (size_t)a * M * 6 : nullptr, max_slack_obs, 1, 1, goal, &gst, ctrl.data(), nullptr, &cost,
-               max_slack_obs ? slack.data() : nullptr, &st, it);
+               max_slack_obs ? slack.data() : nullptr, &st, it, nullptr);
             done[t]++;
             if (++a == hi) a = lo;
             if ((done[t] & 15) == 0 &&

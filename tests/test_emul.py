@@ -52,6 +52,24 @@ def test_lane_loops_have_no_cross_lane_hazard():
         assert np.array_equal(fwd[k], rev[k]), k
 
 
+@pytest.mark.parametrize("name", ["forest3d_M10_dyn4", "forest3d_M10_dyn"])
+def test_s_outside_the_block_changes_nothing(name):
+    """The variant of the two-register runtime-shape instantiation that keeps S = R^-1 in a buffer of its own (the GPU runs
+    it with Q in LDS and S in HBM when both do not fit a CU: r > 110, e.g. the forest missions' r = 124): same bits."""
+    cfg, b, ans = fixtures.load(name)
+    ref = E.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], b["sfc"], b["max_slack_obs"], True)
+    os.environ["EMUL_S_EXT"] = "1"
+    os.environ["EMUL_GENERIC"] = "1"
+    try:
+        got = E.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], b["sfc"], b["max_slack_obs"], True)
+    finally:
+        del os.environ["EMUL_S_EXT"], os.environ["EMUL_GENERIC"]
+    assert (ref["iters"][:, 0] > 3).sum() >= 3
+    for k in ("status", "goal_status", "goal", "x", "cost", "iters", "slack_cost"):
+        assert np.array_equal(ref[k], got[k]), k
+    assert fixtures.check_against_golden(cfg, b, ans, got) >= 8
+
+
 def test_goal_only_and_traj_only_entry_points_agree_with_fused():
     cfg, b, _ = fixtures.load("s64")
     fused = E.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], None, 0, True, True)
