@@ -217,19 +217,32 @@ class ClosedLoop:
         torch, cfg = self.torch, self.cfg
         if isinstance(self.grid, MapfWaypoints):
             # MultiSyncSimulator::decentralizedMAPP: positions, sub-goals, previous plans in; next_waypoint updated in place
-            pos = self.pos.cpu().numpy()
-            wp = np.ascontiguousarray(self.wp.cpu().numpy())
-            gdyn = None
-            if self.D:
-                gdyn = dict(position=self.dyn_pos.cpu().numpy(), velocity=self.dyn_vel.cpu().numpy(), radius=self.dyn["radius"],
-                            max_acc=self.dyn["max_acc"])
-            alert = None
-            if self.D and self.seq > 0:
+            # one device-to-host transfer for everything the planner reads (positions, sub-goals, waypoints, previous plans,
+            # obstacle states, slack costs): packed on the device, copied into a pinned buffer
+            N, D, E = self.N, self.D, cfg.M * (cfg.n + 1) * 3
+            parts = [self.pos.reshape(-1), self.cur_goal.reshape(-1), self.wp.reshape(-1), self.plans.reshape(-1)]
+            if D:
                 # TrajOptimizer::solve's collision alert (traj_optimizer.cpp:85-106): obstacles whose slack cost in the last
-                # QP exceeded param.slack_threshold; the planner treats them as obstacles of interest
-                alert = (self.batch.out_slack[:, :self.D] > self.slack_threshold).cpu().numpy().astype(np.uint8)
-            self.mapf_rc = self.grid.step(pos, self.cur_goal.cpu().numpy(), wp, self.plans.cpu().numpy() if self.seq > 0 else None, dyn=gdyn,
-                                          alert=alert)
+                # QP exceeded param.slack_threshold (compared on the device, in double); the planner treats them as obstacles
+                # of interest
+                parts += [self.dyn_pos.reshape(-1), self.dyn_vel.reshape(-1),
+                          (self.batch.out_slack[:, :D] > self.slack_threshold).to(torch.float32).reshape(-1)]
+            packed = torch.cat(parts)
+            if getattr(self, "_host_pack", None) is None or self._host_pack.numel() != packed.numel():
+                self._host_pack = torch.empty(packed.numel(), dtype=torch.float32).pin_memory()
+            self._host_pack.copy_(packed, non_blocking=True)
+            torch.cuda.current_stream(self.dev).synchronize()
+            h = self._host_pack.numpy()
+            o = np.cumsum([0, 3 * N, 3 * N, 3 * N, N * E] + ([3 * D, 3 * D, N * D] if D else []))
+            pos, cur_goal = h[o[0]:o[1]].reshape(N, 3).copy(), h[o[1]:o[2]].reshape(N, 3).copy()
+            wp = np.ascontiguousarray(h[o[2]:o[3]].reshape(N, 3).copy())
+            plans = h[o[3]:o[4]].reshape(N, cfg.M, cfg.n + 1, 3).copy()
+            gdyn = None
+            if D:
+                gdyn = dict(position=h[o[4]:o[5]].reshape(D, 3).copy(), velocity=h[o[5]:o[6]].reshape(D, 3).copy(), radius=self.dyn["radius"],
+                            max_acc=self.dyn["max_acc"])
+            alert = (h[o[6]:o[7]].reshape(N, D) > 0.5).astype(np.uint8) if D and self.seq > 0 else None
+            self.mapf_rc = self.grid.step(pos, cur_goal, wp, plans if self.seq > 0 else None, dyn=gdyn, alert=alert)
             if self.comm_neighbours:
                 self._set_comm_neighbours(pos)
             return torch.from_numpy(wp)
@@ -251,6 +264,9 @@ class ClosedLoop:
         d = np.abs(pos[:, None, :] - pos[None, :, :]).max(axis=2)
         keep = ~(d > np.float32(r))
         np.fill_diagonal(keep, False)
+        if getattr(self, "_comm_keep", None) is not None and np.array_equal(keep, self._comm_keep):
+            return  # the same lists as in the previous step: the generator and the launch already have them
+        self._comm_keep = keep
         offs = np.concatenate([[0], np.cumsum(keep.sum(axis=1))])
         ids = np.concatenate([np.nonzero(keep[a])[0] for a in range(N)]) if N > 1 else np.zeros(0, np.int32)
         ro = self.gen.set_neighbours(offs, ids)
