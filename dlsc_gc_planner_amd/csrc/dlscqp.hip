@@ -336,6 +336,7 @@ __global__ __launch_bounds__(LSC_THREADS, 4) void dlscqp_lsc_kernel(LscGenArgs g
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const size_t row0 = (size_t)per * pair0;
         const int all = items + g.n_dyn * g.M;
+        const LscReach reach = lsc_reach(g, k);
         int base = 0;  // rows the previous rounds kept (every thread carries its own copy)
         for (int it0 = 0, round = 0; it0 < all; it0 += LSC_THREADS, round ^= 1) {
             const int it = it0 + (int)threadIdx.x;
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(LSC_THREADS, 4) void dlscqp_lsc_kernel(LscGenArgs g
                 const float *box = g.prune_sfc ? g.prune_sfc + ((size_t)k * g.M + m) * 6 : nullptr;
 #pragma unroll
                 for (int i = 0; i < 6; i++) {
-                    keep[i] = i >= r.i0 && !lsc_row_implied(g, box, r, i);
+                    keep[i] = i >= r.i0 && !lsc_row_implied(g, box, r, i, reach);
                     cnt += keep[i];
                 }
             }
@@ -860,6 +861,7 @@ static int lsc_gen_args(dlscqp_ctx *c, const dlscqp_lsc_gen *gen, LscGenArgs *ou
     g.comm_range = c->cfg.communication_range;
     g.use_sfc = c->kp.use_sfc;
     g.prune_sfc = nullptr;
+    g.prune_agents = gen->prune ? gen->prune_agents : nullptr;
     g.row_counts = nullptr;
     if (gen->prune) {
         if (!gen->out_row_counts || (c->kp.use_sfc && !gen->prune_sfc_boxes)) { g_last_error = "prune: null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
