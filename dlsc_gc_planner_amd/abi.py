@@ -152,7 +152,6 @@ class LscGen(C.Structure):
         ("reserved_", C.c_int32),
         ("prune_sfc_boxes", C.c_void_p),
         ("out_row_counts", C.c_void_p),
-        ("prune_agents", C.c_void_p),
     ]
 
 

@@ -312,8 +312,10 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
 
 // one workgroup of LSC_THREADS threads per local agent, threads over its (neighbour, segment) items; every
 // item is independent and writes its own 6 (3) rows of the SoA arrays (lsc_core.hpp).  Four wavefronts per agent instead of
-// one: an agent of the stress batch has ~440 items of a few thousand instructions each behind scattered reads of its
-// neighbours' plans, and a grid of one wavefront per agent leaves the SIMDs with two wavefronts to hide that behind.
+// one: an agent of the stress batch has ~440 items of one to two thousand instructions each behind scattered reads of its
+// neighbours' plans, and a grid of one wavefront per agent leaves the SIMDs with two wavefronts to hide that behind.  With
+// 128 VGPRs (the hull points of a lane live in LDS, lsc_core.hpp: HullStore) four workgroups share a CU; by the counters
+// the kernel then issues VALU instructions in ~0.8 of the slots (round 2).
 constexpr int LSC_THREADS = 256;
 __global__ __launch_bounds__(LSC_THREADS, 4) void dlscqp_lsc_kernel(LscGenArgs g) {
     const int k = blockIdx.x;
@@ -324,8 +326,10 @@ __global__ __launch_bounds__(LSC_THREADS, 4) void dlscqp_lsc_kernel(LscGenArgs g
     const size_t pair0 = (size_t)p0 + (size_t)k * g.n_dyn;  // pairs (agent, obstacle) before this agent's
     // items in NEIGHBOUR-major order: consecutive lanes read consecutive segments of one neighbour's plan and write one
     // contiguous block of rows.  (Segment-major order, which would keep the lanes of a wavefront on one kind of item -- hull
-    // problem vs. the last segment's segment-segment problem -- was measured: the stress batch's step went from 0.51 to
-    // 0.74 ms; the kernel is bound by its scattered plan reads and row writes, not by the branch.)
+    // problem vs. the last segment's segment-segment problem -- was measured with the round-1 kernel: the stress batch's
+    // step went from 0.51 to 0.74 ms: the scattered plan reads and row writes cost more than the branch saves.  Round 2:
+    // computing the last segments of all pairs in a pass of their own, one pair per thread, and handing them to the items
+    // through LDS: generator 0.095 -> 0.102 ms -- the extra pass and its registers cost more than the branch.)
     const int nn = p1 - p0, items = nn * g.M;
     __shared__ float hull_pts[18 * LSC_THREADS];
     const HullStore hull = {hull_pts + threadIdx.x, LSC_THREADS};
@@ -336,7 +340,6 @@ __global__ __launch_bounds__(LSC_THREADS, 4) void dlscqp_lsc_kernel(LscGenArgs g
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const size_t row0 = (size_t)per * pair0;
         const int all = items + g.n_dyn * g.M;
-        const LscReach reach = lsc_reach(g, k);
         int base = 0;  // rows the previous rounds kept (every thread carries its own copy)
         for (int it0 = 0, round = 0; it0 < all; it0 += LSC_THREADS, round ^= 1) {
             const int it = it0 + (int)threadIdx.x;
@@ -357,7 +360,7 @@ __global__ __launch_bounds__(LSC_THREADS, 4) void dlscqp_lsc_kernel(LscGenArgs g
                 const float *box = g.prune_sfc ? g.prune_sfc + ((size_t)k * g.M + m) * 6 : nullptr;
 #pragma unroll
                 for (int i = 0; i < 6; i++) {
-                    keep[i] = i >= r.i0 && !lsc_row_implied(g, box, r, i, reach);
+                    keep[i] = i >= r.i0 && !lsc_row_implied(g, box, r, i);
                     cnt += keep[i];
                 }
             }
@@ -861,7 +864,6 @@ static int lsc_gen_args(dlscqp_ctx *c, const dlscqp_lsc_gen *gen, LscGenArgs *ou
     g.comm_range = c->cfg.communication_range;
     g.use_sfc = c->kp.use_sfc;
     g.prune_sfc = nullptr;
-    g.prune_agents = gen->prune ? gen->prune_agents : nullptr;
     g.row_counts = nullptr;
     if (gen->prune) {
         if (!gen->out_row_counts || (c->kp.use_sfc && !gen->prune_sfc_boxes)) { g_last_error = "prune: null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }

@@ -301,7 +301,6 @@ struct LscGenArgs {  // device mirror of dlscqp_lsc_gen (include/dlscqp.h)
     // presolve (dlscqp_lsc_gen.prune_sfc_boxes): rows implied by the agent's own box rows are not written
     const float *prune_sfc;          // [n_local][M][6] corridor boxes of the local agents, or null
     int32_t *row_counts;             // [n_local] rows written per agent (with prune_sfc), or null
-    const dlscqp_agent *prune_agents;  // [n_local] records of the local agents (reachability part of the presolve), or null
     double world_min[3], world_max[3];
     int dim;
 };
@@ -323,28 +322,7 @@ constexpr double PRUNE_MARGIN = 1e-4;  // metres by which a row has to be implie
 // attained at a corner; if even that corner satisfies n.(c - p) - d >= PRUNE_MARGIN the row can never be active or
 // violated at a point that satisfies the box rows, so the QP and the goal LP have the same solutions without it (what a
 // presolve does; rows with a slack variable included: with the hard row implied, slack 0 is feasible and optimal).
-// What the velocity rows let the control points of one agent reach (dlscqp_lsc_gen.prune_agents): c_{0,2} from the
-// initial-state rows, and the largest difference of two neighbouring control points per axis.
-struct LscReach {
-    bool on;
-    double c02[3], step;
-};
-DQ_FN LscReach lsc_reach(const LscGenArgs &g, int k) {
-    LscReach rc;
-    rc.on = g.prune_agents != nullptr;
-    rc.step = 0;
-    for (int a = 0; a < 3; a++) rc.c02[a] = 0;
-    if (rc.on) {
-        const dlscqp_agent &ag = g.prune_agents[k];
-        const int n = g.n1 - 1;
-        for (int a = 0; a < 3; a++)  // traj_optimizer.cpp:334-367: c01 = c00 + v dt / n, c02 - 2 c01 + c00 = acc dt^2 / (n (n - 1))
-            rc.c02[a] = (double)ag.position[a] + 2.0 * (double)ag.velocity[a] * g.dt / n + (double)ag.acceleration[a] * g.dt * g.dt / (n * (n - 1));
-        rc.step = ag.max_vel * g.dt / n;  // :453-470
-    }
-    return rc;
-}
-
-DQ_FN bool lsc_row_implied(const LscGenArgs &g, const float *box, const LscRows &r, int i, const LscReach &reach) {
+DQ_FN bool lsc_row_implied(const LscGenArgs &g, const float *box, const LscRows &r, int i) {
     const float nv[3] = {r.nx, r.ny, r.nz};
     const float pv[3] = {r.px[i], r.py[i], r.pz[i]};
     // The last point of the last segment of an agent obstacle is also a row of the goal LP (goal_optimizer.cpp:176-195),
@@ -354,7 +332,6 @@ DQ_FN bool lsc_row_implied(const LscGenArgs &g, const float *box, const LscRows 
     const bool lp_row = (int)(key & 0xFF) == g.M - 1 && (int)((key >> 8) & 0xF) == g.n1 - 1 && !((key >> 12) & 1);
     if (lp_row && !g.use_sfc) return false;
     double mn = 0.0, rhs = r.d[i];
-    const int steps = (int)(key & 0xFF) * (g.n1 - 1) + (int)((key >> 8) & 0xF) - 2;  // control points between c_{0,2} and (m, i)
     for (int k = 0; k < 3; k++) {
         if (k >= g.dim) continue;
         double lo = g.world_min[k], hi = g.world_max[k];
@@ -362,11 +339,6 @@ DQ_FN bool lsc_row_implied(const LscGenArgs &g, const float *box, const LscRows 
         else if (g.use_sfc) {
             lo = (double)box[k] > lo ? (double)box[k] : lo;
             hi = (double)box[3 + k] < hi ? (double)box[3 + k] : hi;
-        }
-        if (reach.on && !lp_row && steps >= 0) {
-            const double rl = reach.c02[k] - reach.step * steps, rh = reach.c02[k] + reach.step * steps;
-            lo = rl > lo ? rl : lo;
-            hi = rh < hi ? rh : hi;
         }
         mn += (double)nv[k] * (nv[k] >= 0 ? lo : hi);
         rhs += (double)nv[k] * (double)pv[k];

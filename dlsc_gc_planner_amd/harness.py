@@ -200,8 +200,7 @@ class ClosedLoop:
                                              waypoint_step=waypoint_step if world is None else 0.0)
         if world is not None and world.get("prune", True):
             # presolve in the half-space generator: rows implied by this step's corridor boxes are never written
-            # (world["prune_reach"]: also the rows that the velocity rows' reach implies -- measured neutral, off by default)
-            self.batch.use_row_counts(self.gen.enable_pruning(self.sfc.sfcs, agents=self.batch.t["agents"] if world.get("prune_reach") else None))
+            self.batch.use_row_counts(self.gen.enable_pruning(self.sfc.sfcs))
         self.records_in = torch.zeros_like(self.batch.t["agents"])
         self.released = torch.zeros(N, dtype=torch.int32, device=dev)  # dynamic obstacles released by the waypoint trap, per agent
         self.history = []

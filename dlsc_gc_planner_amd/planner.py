@@ -381,18 +381,15 @@ class LscGenerator:
         rc = self.opt.lib.dlscqp_waypoint_trap_device(self.opt.handle, C.byref(self.c), C.byref(t), C.c_void_p(s.cuda_stream))
         self.opt._check(rc, "dlscqp_waypoint_trap_device")
 
-    def enable_pruning(self, sfcs=None, agents=None):
+    def enable_pruning(self, sfcs=None):
         """Presolve inside the generator (dlscqp_lsc_gen.prune): half-spaces implied by the agent's corridor / world box are not
-        written; `sfcs` [n_local, M, 6] is the corridor tensor of the local agents for the step (None without corridors);
-        `agents`: the device tensor of the local agents' records that the plan launch reads (DeviceBatch.t["agents"]) -- with it
-        the box is intersected with what the velocity rows let a control point reach.
+        written; `sfcs` [n_local, M, 6] is the corridor tensor of the local agents for the step (None without corridors).
         Afterwards `row_counts` ([n_local] int32 CUDA tensor) holds the rows per agent: give it to DeviceBatch.use_row_counts."""
         self.row_counts = self.torch.zeros(self.n_local, dtype=self.torch.int32, device=self.device)
         self.c.prune = 1
         self.c.prune_sfc_boxes = None if sfcs is None else sfcs.data_ptr()
         self.c.out_row_counts = self.row_counts.data_ptr()
-        self.c.prune_agents = None if agents is None else agents.data_ptr()
-        self._keep_prune = (sfcs, agents)
+        self._keep_prune = sfcs
         return self.row_counts
 
     def generate(self, goals, plans=None, position=None, velocity=None, stream=None, dyn_position=None, dyn_velocity=None,

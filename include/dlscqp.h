@@ -270,17 +270,11 @@ typedef struct dlscqp_lsc_gen {
      * traj_optimizer.cpp:251-265, 385-410 -- is not written at all: it can be neither active nor violated, so goal LP and QP
      * have the same solutions without it (in a crowd most neighbours within communication range are far outside an agent's
      * corridor).  The rows that remain are written contiguously from the agent's first row on, in their original order, and
-     * out_row_counts[k] says how many: pass it as dlscqp_device_batch.row_counts.  prune != 0 switches it on.
-     * prune_agents (optional, [n_local] records of the local agents as the plan launch of THIS step will read them): the box is
-     * intersected with what the model's velocity rows let control point (m, i) reach -- the initial-state rows fix c_{0,0..2}
-     * (traj_optimizer.cpp:334-367), the velocity rows bound every further difference of neighbouring control points by
-     * max_vel dt / n per axis (:453-470), the segments are C0-continuous, so  |c_{m,i} - c_{0,2}| <= max_vel dt (m n + i - 2) / n
-     * per axis: early segments cannot come near most neighbours.  Not applied to the row a pair shares with the goal LP.   */
+     * out_row_counts[k] says how many: pass it as dlscqp_device_batch.row_counts.  prune != 0 switches it on.          */
     int32_t prune;
     int32_t reserved_;
     const float *prune_sfc_boxes;
     int32_t *out_row_counts;          /* [n_local], required when prune != 0                              */
-    const dlscqp_agent *prune_agents; /* [n_local] or NULL                                                */
 } dlscqp_lsc_gen;
 
 int dlscqp_generate_lsc_device(dlscqp_ctx *ctx, const dlscqp_lsc_gen *gen, void *stream);

@@ -238,7 +238,6 @@ static dlscqp::LscGenArgs emul_lsc_args(const dlscqp_config *cfg, const dlscqp_l
     g.use_sfc = cfg->world_use_octomap ? 1 : 0;
     g.prune_sfc = gen->prune ? (g.use_sfc ? gen->prune_sfc_boxes : nullptr) : nullptr;
     g.row_counts = gen->prune ? gen->out_row_counts : nullptr;
-    g.prune_agents = gen->prune ? gen->prune_agents : nullptr;
     g.dim = cfg->world_dimension;
     for (int k = 0; k < 3; k++) { g.world_min[k] = cfg->world_min[k]; g.world_max[k] = cfg->world_max[k]; }
     return g;
@@ -289,7 +288,6 @@ extern "C" int emul_generate_lsc(const dlscqp_config *cfg, const dlscqp_lsc_gen 
             size_t at = (size_t)per * pair0;
             const size_t first = at;
             const int items = (p1 - p0) * g.M, all = items + g.n_dyn * g.M;
-            const LscReach reach = lsc_reach(g, k);
             for (int it = 0; it < all; it++) {
                 LscRows r;
                 int m;
@@ -298,7 +296,7 @@ extern "C" int emul_generate_lsc(const dlscqp_config *cfg, const dlscqp_lsc_gen 
                 const float *box = g.prune_sfc ? g.prune_sfc + ((size_t)k * g.M + m) * 6 : nullptr;
                 bool keep[6];
                 int cnt = 0;
-                for (int i = 0; i < 6; i++) { keep[i] = i >= r.i0 && !lsc_row_implied(g, box, r, i, reach); cnt += keep[i]; }
+                for (int i = 0; i < 6; i++) { keep[i] = i >= r.i0 && !lsc_row_implied(g, box, r, i); cnt += keep[i]; }
                 lsc_store_rows(g, r, at, keep);
                 at += cnt;
             }

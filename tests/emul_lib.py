@@ -145,8 +145,6 @@ def _run_lsc_gen(cfg, call, plans, goals, radius, downwash, nbr_offsets, nbr_ids
         g.prune, g.out_row_counts = 1, counts.ctypes.data
         if prune.get("sfc") is not None:
             _, g.prune_sfc_boxes = arr(prune["sfc"], np.float32)
-        if prune.get("agents") is not None:
-            _, g.prune_agents = arr(prune["agents"], abi.AGENT_DTYPE)
     rc = call(g)
     assert rc == 0
     ro, rows = per * pairs, soa_to_rows(out, R)

@@ -325,85 +325,6 @@ def test_pruning_by_the_world_box_alone_keeps_the_goal_lp_rows():
     assert lp(rows) == lp(full) > 20
 
 
-@pytest.mark.parametrize("M,dim", [(10, 2), (5, 3)])
-def test_reachability_pruning_drops_only_rows_the_velocity_rows_imply(M, dim):
-    """dlscqp_lsc_gen.prune_agents: the corridor / world box is intersected with the box the velocity rows confine control
-    point (m, i) to -- c_{0,2} +- max_vel dt (m n + i - 2) / n per axis.  Every additionally dropped row is re-checked in
-    numpy against that box; LP + QP give the same verdicts and solutions; the rows shared with the goal LP all stay."""
-    from dlsc_gc_planner_amd import workloads
-    if dim == 2:
-        cfg = workloads.x2048_config()
-        w = workloads.x2048(cfg, n_agents=64, seed=77)
-        sw = dict(plans=w["plans"], goals=w["goals"], radius=w["radius"], downwash=w["downwash"], nbr_offsets=w["nbr_offsets"], nbr_ids=w["nbr_ids"])
-        ag, sfc = w["agents"], w["sfc"]
-    else:
-        cfg = abi.make_config(dim=3, M=M, communication_range=3.0, world_use_octomap=True, world_min=(-6.0, -6.0, 0.0), world_max=(6.0, 6.0, 2.5))
-        N = 14
-        sw = lsc_cases.random_swarm(cfg, N, seed=31, spread=1.6)
-        init = np.stack([O.shift_plan(p) for p in sw["plans"]])
-        sfc = np.zeros((N, M, 6), np.float32)
-        for a in range(N):
-            for m in range(M):
-                sfc[a, m, :3], sfc[a, m, 3:] = init[a, m].min(axis=0) - np.float32(0.8), init[a, m].max(axis=0) + np.float32(0.8)
-        ag = np.zeros(N, abi.AGENT_DTYPE)
-        ag["position"], ag["current_goal_point"], ag["next_waypoint"] = init[:, 0, 0], sw["goals"], sw["goals"]
-        ag["velocity"] = (init[:, 0, 1] - init[:, 0, 0]) * np.float32(cfg.n / cfg.dt)
-        ag["acceleration"] = (init[:, 0, 2] - 2 * init[:, 0, 1] + init[:, 0, 0]) * np.float32(cfg.n * (cfg.n - 1) / cfg.dt ** 2)
-        ag["max_vel"], ag["max_acc"], ag["radius"], ag["nominal_velocity"] = 1.0, 2.0, sw["radius"], 1.0
-    args = (cfg, sw["plans"], sw["goals"], sw["radius"], sw["downwash"], sw["nbr_offsets"], sw["nbr_ids"])
-    pb = dict(sfc=sfc)
-    bo, box_rows = E.generate_lsc(*args, prune=pb)
-    pr = dict(sfc=sfc, agents=ag)
-    ro, rows = E.generate_lsc(*args, prune=pr)
-    assert len(rows) < len(box_rows), (len(rows), len(box_rows))
-    n, dt = cfg.n, cfg.dt
-    wmin, wmax = np.array(cfg.world_min[:]), np.array(cfg.world_max[:])
-    dropped = 0
-    for a in range(len(ag)):
-        f, k = box_rows[bo[a]:bo[a + 1]], rows[ro[a]:ro[a + 1]]
-        keep, j = [], 0
-        for i in range(len(f)):
-            if j < len(k) and f[i].tobytes() == k[j].tobytes():
-                keep.append(i)
-                j += 1
-        assert j == len(k), a  # a subsequence, in order
-        c02 = ag["position"][a].astype(np.float64) + 2 * ag["velocity"][a].astype(np.float64) * dt / n + \
-            ag["acceleration"][a].astype(np.float64) * dt * dt / (n * (n - 1))
-        for i in sorted(set(range(len(f))) - set(keep)):
-            r = f[i]
-            m, ii = int(r["m"]), int(r["i"])
-            assert not (m == cfg.M - 1 and ii == n and not (r["flags"] & 1)), "a row of the goal LP was dropped"
-            hw = ag["max_vel"][a] * dt / n * (m * n + ii - 2)
-            lo = np.maximum.reduce([c02 - hw, sfc[a, m, :3].astype(np.float64), wmin])[:dim]
-            hi = np.minimum.reduce([c02 + hw, sfc[a, m, 3:].astype(np.float64), wmax])[:dim]
-            nv = r["normal"].astype(np.float64)[:dim]
-            mn = np.where(nv >= 0, nv * lo, nv * hi).sum()
-            assert mn - (r["d"] + (nv * r["point"].astype(np.float64)[:dim]).sum()) >= 1e-4 - 1e-12
-            dropped += 1
-    assert dropped > 30
-    a1 = E.plan_batch(cfg, ag, bo, box_rows, sfc, 0, True)
-    a2 = E.plan_batch(cfg, ag, ro, rows, sfc, 0, True)
-    assert np.array_equal(a1["status"], a2["status"]) and np.array_equal(a1["goal_status"], a2["goal_status"])
-    assert np.array_equal(a1["goal"], a2["goal"])
-    ok = a1["status"] == abi.OK
-    if dim == 2:
-        assert ok.mean() > 0.8
-    if ok.any():
-        assert np.abs(a1["x"][ok] - a2["x"][ok]).max() < 1e-8
-    # and every solution really lies in its reach boxes (the premise): control point (m, i) within hw of c_{0,2}
-    P = cfg.M * (n + 1)
-    for a in np.nonzero(ok)[0]:
-        c02 = ag["position"][a].astype(np.float64) + 2 * ag["velocity"][a].astype(np.float64) * dt / n + \
-            ag["acceleration"][a].astype(np.float64) * dt * dt / (n * (n - 1))
-        for kx in range(dim):
-            c = a1["x"][a][kx * P:(kx + 1) * P].reshape(cfg.M, n + 1)
-            for m in range(cfg.M):
-                for ii in range(n + 1):
-                    st = m * n + ii - 2
-                    if st >= 0:
-                        assert abs(c[m, ii] - c02[kx]) <= ag["max_vel"][a] * dt / n * st + 1e-6, (a, kx, m, ii)
-
-
 def test_pruning_leaves_the_plans_of_the_stress_workload_unchanged():
     """The same on feasible problems: 96 agents of the stress workload (BASELINE.json configs[4]: 2-D, M = 10, corridor boxes,
     every agent within 3 m a neighbour).  Most rows go; verdicts identical, sub-goals bit-equal, solutions within 1e-8."""
