@@ -327,12 +327,17 @@ __global__ __launch_bounds__(LSC_THREADS, 4) void dlscqp_lsc_kernel(LscGenArgs g
     // items in NEIGHBOUR-major order: consecutive lanes read consecutive segments of one neighbour's plan and write one
     // contiguous block of rows.  (Segment-major order, which would keep the lanes of a wavefront on one kind of item -- hull
     // problem vs. the last segment's segment-segment problem -- was measured with the round-1 kernel: the stress batch's
-    // step went from 0.51 to 0.74 ms: the scattered plan reads and row writes cost more than the branch saves.  Round 2:
-    // computing the last segments of all pairs in a pass of their own, one pair per thread, and handing them to the items
-    // through LDS: generator 0.095 -> 0.102 ms -- the extra pass and its registers cost more than the branch.)
+    // step went from 0.51 to 0.74 ms: the scattered plan reads and row writes cost more than the branch saves.  What does
+    // pay is the pass below that computes the last segments of all pairs first, one pair per thread: 0.0955 -> 0.0877 ms.)
     const int nn = p1 - p0, items = nn * g.M;
     __shared__ float hull_pts[18 * LSC_THREADS];
     const HullStore hull = {hull_pts + threadIdx.x, LSC_THREADS};
+    // the last-segment geometry of every pair first, one pair per thread (lsc_item_rows says why); pairs beyond the block's
+    // capacity are computed in place
+    constexpr int LAST_CAP = 160;
+    __shared__ LscLast last_geo[LAST_CAP];
+    for (int j = threadIdx.x; j < nn && j < LAST_CAP; j += LSC_THREADS) last_geo[j] = lsc_last_geometry(g, self, g.nbr_ids[p0 + j]);
+    __syncthreads();
     if (g.row_counts) {
         // presolve: rows implied by the agent's own box rows are dropped, the others written contiguously in their original
         // order -- per round of LSC_THREADS items an exclusive prefix sum of the kept-row counts over the workgroup (LDS)
@@ -350,7 +355,7 @@ __global__ __launch_bounds__(LSC_THREADS, 4) void dlscqp_lsc_kernel(LscGenArgs g
             if (it < items) {
                 const int j = it / g.M;
                 m = it - j * g.M;
-                lsc_item_rows(g, self, g.nbr_ids[p0 + j], m, r, hull);
+                lsc_item_rows(g, self, g.nbr_ids[p0 + j], m, r, hull, j < LAST_CAP ? &last_geo[j] : nullptr);
             } else if (it < all) {
                 const int q = it - items, o = q / g.M;
                 m = q - o * g.M;
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(LSC_THREADS, 4) void dlscqp_lsc_kernel(LscGenArgs g
     }
     for (int it = threadIdx.x; it < items; it += LSC_THREADS) {
         const int j = it / g.M, m = it - j * g.M;
-        lsc_item(g, self, g.nbr_ids[p0 + j], m, (size_t)per * (pair0 + j), hull);
+        lsc_item(g, self, g.nbr_ids[p0 + j], m, (size_t)per * (pair0 + j), hull, j < LAST_CAP ? &last_geo[j] : nullptr);
     }
     for (int it = threadIdx.x; it < g.n_dyn * g.M; it += LSC_THREADS) {  // dynamic obstacles after the neighbour agents
         const int o = it / g.M, m = it - o * g.M;

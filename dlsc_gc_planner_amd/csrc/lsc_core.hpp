@@ -388,9 +388,40 @@ DQ_FN void lsc_store_rows(const LscGenArgs &g, const LscRows &r, size_t at, cons
     }
 }
 
-// One (pair, segment) item: its rows into `out` (nothing is written to memory).
-DQ_FN void lsc_item_rows(const LscGenArgs &g, int self, int other, int m, LscRows &out, const HullStore &hull) {
+// The last segment of a pair (m = M - 1): one half-space between the two straight paths "end of the plan -> sub-goal"
+// (traj_planner.cpp:642-660), the same normal, point and distance for all n + 1 rows.
+struct LscLast {
+    float nx, ny, nz, px, py, pz;
+    double dd;
+};
+DQ_FN LscLast lsc_last_geometry(const LscGenArgs &g, int self, int other) {
     const int n = g.n1 - 1, M = g.M;
+    const double r_self = g.radius[self], r_oth = g.radius[other];
+    const double collision_dist = r_oth + r_self;
+    const double downwash = (g.downwash[self] * r_self + g.downwash[other] * r_oth) / (r_self + r_oth);
+    const float dwf = (float)downwash;
+    F3 l1s = predicted_point(g, other, M - 1, n), l2s = initial_point(g, self, M - 1, n);
+    l1s.z = l1s.z / dwf;
+    l2s.z = l2s.z / dwf;
+    const float *go = g.goals + 3 * (size_t)other, *gs = g.goals + 3 * (size_t)self;
+    // TrajPlanner::coordinateTransform of a point: double division, :1183-1187
+    const F3 obs_goal = f3(go[0], go[1], (float)((double)go[2] / downwash));
+    const F3 agent_goal = f3(gs[0], gs[1], (float)((double)gs[2] / downwash));
+    const Closest c = segments(l1s, obs_goal, l2s, agent_goal);
+    const F3 nt = normalized(c.p2 - c.p1);
+    LscLast L;
+    L.dd = 0.5 * (collision_dist + c.dist);
+    L.nx = nt.x; L.ny = nt.y; L.nz = (float)((double)nt.z / downwash);
+    L.px = c.p1.x; L.py = c.p1.y; L.pz = (float)((double)c.p1.z * downwash);
+    return L;
+}
+
+// One (pair, segment) item: its rows into `out` (nothing is written to memory).  `last`: the pair's last-segment geometry
+// if the caller has computed it beforehand (the GPU kernel does, for all pairs of an agent at once: among the items of a
+// wavefront one in M is a last segment, and computed in place it sends the whole wavefront through the segment-to-segment
+// code), else null.
+DQ_FN void lsc_item_rows(const LscGenArgs &g, int self, int other, int m, LscRows &out, const HullStore &hull, const LscLast *last = nullptr) {
+    const int M = g.M;
     const double r_self = g.radius[self], r_oth = g.radius[other];
     const double collision_dist = r_oth + r_self;                                                       // :605
     const double downwash = (g.downwash[self] * r_self + g.downwash[other] * r_oth) / (r_self + r_oth);  // :1150-1153
@@ -421,32 +452,23 @@ DQ_FN void lsc_item_rows(const LscGenArgs &g, int self, int other, int m, LscRow
             out.key[i] = DLSCQP_KEY(m, i, -1, 0);
         }
     } else {
-        F3 l1s = predicted_point(g, other, M - 1, n), l2s = initial_point(g, self, M - 1, n);
-        l1s.z = l1s.z / dwf;
-        l2s.z = l2s.z / dwf;
-        const float *go = g.goals + 3 * (size_t)other, *gs = g.goals + 3 * (size_t)self;
-        // TrajPlanner::coordinateTransform of a point: double division, :1183-1187
-        const F3 obs_goal = f3(go[0], go[1], (float)((double)go[2] / downwash));
-        const F3 agent_goal = f3(gs[0], gs[1], (float)((double)gs[2] / downwash));
-        const Closest c = segments(l1s, obs_goal, l2s, agent_goal);
-        const F3 nt = normalized(c.p2 - c.p1);
-        const double dd = 0.5 * (collision_dist + c.dist);
-        const F3 nrm = f3(nt.x, nt.y, (float)((double)nt.z / downwash));
-        const F3 pt = f3(c.p1.x, c.p1.y, (float)((double)c.p1.z * downwash));
-        out.nx = nrm.x; out.ny = nrm.y; out.nz = nrm.z;
+        LscLast L;
+        if (last) L = *last;
+        else L = lsc_last_geometry(g, self, other);
+        out.nx = L.nx; out.ny = L.ny; out.nz = L.nz;
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            out.px[i] = pt.x; out.py[i] = pt.y; out.pz[i] = pt.z;
-            out.d[i] = dd;
+            out.px[i] = L.px; out.py[i] = L.py; out.pz[i] = L.pz;
+            out.d[i] = L.dd;
             out.key[i] = DLSCQP_KEY(m, i, -1, 0);
         }
     }
 }
 
 // The item's rows at their fixed place: `row0` = index of the pair's first row in the SoA arrays.
-DQ_FN void lsc_item(const LscGenArgs &g, int self, int other, int m, size_t row0, const HullStore &hull) {
+DQ_FN void lsc_item(const LscGenArgs &g, int self, int other, int m, size_t row0, const HullStore &hull, const LscLast *last = nullptr) {
     LscRows r;
-    lsc_item_rows(g, self, other, m, r, hull);
+    lsc_item_rows(g, self, other, m, r, hull, last);
     lsc_store_rows(g, r, row0 + (m == 0 ? 0 : (size_t)(g.n1 - g.phi) + (size_t)(m - 1) * g.n1), nullptr);
 }
 
