@@ -363,11 +363,7 @@ __global__ __launch_bounds__(LSC_THREADS, 4) void dlscqp_lsc_kernel(LscGenArgs g
             }
             if (it < all) {
                 const float *box = g.prune_sfc ? g.prune_sfc + ((size_t)k * g.M + m) * 6 : nullptr;
-#pragma unroll
-                for (int i = 0; i < 6; i++) {
-                    keep[i] = i >= r.i0 && !lsc_row_implied(g, box, r, i);
-                    cnt += keep[i];
-                }
+                cnt = lsc_rows_kept(g, box, r, keep);
             }
             int incl = cnt;  // inclusive scan over the wavefront, then the wavefronts' totals through LDS (one barrier a round)
 #pragma unroll

@@ -322,28 +322,41 @@ constexpr double PRUNE_MARGIN = 1e-4;  // metres by which a row has to be implie
 // attained at a corner; if even that corner satisfies n.(c - p) - d >= PRUNE_MARGIN the row can never be active or
 // violated at a point that satisfies the box rows, so the QP and the goal LP have the same solutions without it (what a
 // presolve does; rows with a slack variable included: with the hard row implied, slack 0 is feasible and optimal).
-DQ_FN bool lsc_row_implied(const LscGenArgs &g, const float *box, const LscRows &r, int i) {
+// keep[i] for the (up to) six rows of an item, returns how many are kept.  The rows share normal and box, so the box part
+// -- the smallest n.c over the box -- is computed once per item and only  d_i + n.p_i  per row.
+DQ_FN int lsc_rows_kept(const LscGenArgs &g, const float *box, const LscRows &r, bool keep[6]) {
     const float nv[3] = {r.nx, r.ny, r.nz};
-    const float pv[3] = {r.px[i], r.py[i], r.pz[i]};
     // The last point of the last segment of an agent obstacle is also a row of the goal LP (goal_optimizer.cpp:176-195),
     // whose variable is not a control point: the LP has the faces of the last corridor box (:158-173) but no variable
     // bounds, so there only the corridor box may imply the row.
-    const uint32_t key = r.key[i];
-    const bool lp_row = (int)(key & 0xFF) == g.M - 1 && (int)((key >> 8) & 0xF) == g.n1 - 1 && !((key >> 12) & 1);
-    if (lp_row && !g.use_sfc) return false;
-    double mn = 0.0, rhs = r.d[i];
+    const uint32_t key5 = r.key[5];  // all rows of an item: same segment, same kind of obstacle
+    const bool last_agent_item = (int)(key5 & 0xFF) == g.M - 1 && !((key5 >> 12) & 1);
+    double mn = 0.0, mn_lp = 0.0;
     for (int k = 0; k < 3; k++) {
         if (k >= g.dim) continue;
         double lo = g.world_min[k], hi = g.world_max[k];
-        if (lp_row) { lo = (double)box[k]; hi = (double)box[3 + k]; }
-        else if (g.use_sfc) {
+        if (g.use_sfc) {
             lo = (double)box[k] > lo ? (double)box[k] : lo;
             hi = (double)box[3 + k] < hi ? (double)box[3 + k] : hi;
+            mn_lp += (double)nv[k] * (nv[k] >= 0 ? (double)box[k] : (double)box[3 + k]);
         }
         mn += (double)nv[k] * (nv[k] >= 0 ? lo : hi);
-        rhs += (double)nv[k] * (double)pv[k];
     }
-    return mn - rhs >= PRUNE_MARGIN;
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const float pv[3] = {r.px[i], r.py[i], r.pz[i]};
+        double rhs = r.d[i];
+        for (int k = 0; k < 3; k++) {
+            if (k >= g.dim) continue;
+            rhs += (double)nv[k] * (double)pv[k];
+        }
+        const bool lp_row = last_agent_item && i == g.n1 - 1;
+        const bool implied = lp_row ? (g.use_sfc && mn_lp - rhs >= PRUNE_MARGIN) : (mn - rhs >= PRUNE_MARGIN);
+        keep[i] = i >= r.i0 && !implied;
+        cnt += keep[i];
+    }
+    return cnt;
 }
 
 // control point i of segment m of agent `id`'s initial trajectory (= what the others predict for it)

@@ -295,8 +295,7 @@ extern "C" int emul_generate_lsc(const dlscqp_config *cfg, const dlscqp_lsc_gen 
                 else { const int q = it - items, o = q / g.M; m = q - o * g.M; lsc_dyn_item_rows(g, self, o, m, r); }
                 const float *box = g.prune_sfc ? g.prune_sfc + ((size_t)k * g.M + m) * 6 : nullptr;
                 bool keep[6];
-                int cnt = 0;
-                for (int i = 0; i < 6; i++) { keep[i] = i >= r.i0 && !lsc_row_implied(g, box, r, i); cnt += keep[i]; }
+                const int cnt = lsc_rows_kept(g, box, r, keep);
                 lsc_store_rows(g, r, at, keep);
                 at += cnt;
             }
