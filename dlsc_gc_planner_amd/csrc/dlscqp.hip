@@ -15,6 +15,9 @@
 #include <vector>
 
 #define DQ_FN __host__ __device__ __forceinline__
+#if defined(__HIP_DEVICE_COMPILE__)
+#define DQ_WAVE_ALL(c) (__ballot(!(c)) == 0ull)
+#endif
 #define DQ_KEEP(v) asm volatile("" : "+v"(v))
 #define DQ_MARK(text) asm volatile("; " text)
 #ifdef DLSCQP_TRACE_LDS

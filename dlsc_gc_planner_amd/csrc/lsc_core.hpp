@@ -17,11 +17,16 @@
 #pragma once
 #include <math.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/dlscqp.h"
 
 #ifndef DQ_FN
 #define DQ_FN inline
+#endif
+// DQ_WAVE_ALL(c): c holds for every lane of the wavefront (a wave-uniform value a real branch can test); host: c itself
+#ifndef DQ_WAVE_ALL
+#define DQ_WAVE_ALL(c) (c)
 #endif
 
 namespace dlscqp {
@@ -439,6 +444,10 @@ DQ_FN void lsc_item_rows(const LscGenArgs &g, int self, int other, int m, LscRow
     const double collision_dist = r_oth + r_self;                                                       // :605
     const double downwash = (g.downwash[self] * r_self + g.downwash[other] * r_oth) / (r_self + r_oth);  // :1150-1153
     const float dwf = (float)downwash;
+    const float dw_inv = 1.0f / dwf;
+    uint32_t dw_bits;
+    memcpy(&dw_bits, &dwf, 4);
+    const bool dw_pow2 = (dw_bits & 0x7FFFFFu) == 0 && dwf > 1e-30f && dwf < 1e30f;  // zero mantissa: +-2^e, reciprocal exact
     // rows of segment 0 start at i = phi (the others are never part of the model, traj_optimizer.cpp:417-419)
     out.i0 = m == 0 ? g.phi : 0;
     if (m < M - 1) {
@@ -448,8 +457,16 @@ DQ_FN void lsc_item_rows(const LscGenArgs &g, int self, int other, int m, LscRow
             F3 a = initial_point(g, self, m, i);
             pred[i] = predicted_point(g, other, m, i);
             F3 b = pred[i];
-            a.z = a.z / dwf;  // Trajectory::coordinateTransform, trajectory.cpp:206-219
-            b.z = b.z / dwf;
+            // Trajectory::coordinateTransform, trajectory.cpp:206-219.  The downwash factor is 1, 2 or another power of two in
+            // every mission of the reference: dividing by it is then the same as multiplying by its reciprocal, bit for
+            // bit, and a float32 division is a dozen instructions -- twelve of them per item.
+            if (DQ_WAVE_ALL(dw_pow2)) {
+                a.z = a.z * dw_inv;
+                b.z = b.z * dw_inv;
+            } else {
+                a.z = a.z / dwf;
+                b.z = b.z / dwf;
+            }
             hull.put(i, a - b);
         }
         const D3 v = hull6_closest_to_origin(hull);
