@@ -145,6 +145,18 @@ DQ_FN double f32_norm3(float a, float b, float c) {
     return sqrt((double)sq);
 }
 
+// f32_norm3(a, b, c) < SP_EPSILON_FLOAT without the square root: the float32 sum of squares is below the smallest float32
+// whose double square root reaches 1e-5 (0x2EDBE6FF = 1.0000000e-10; the square root is monotone and correctly rounded, so
+// the two tests agree on every input -- tests/test_norm_threshold.py walks the floats around the threshold).  A double
+// square root is ~40 instructions and the zero-normal test runs for every cached row of every agent, twice.
+DQ_FN bool f32_norm3_below_eps(float a, float b, float c) {
+    const float sq = a * a + b * b + c * c;
+    uint32_t lim_bits = 0x2EDBE6FFu;
+    float lim;
+    memcpy(&lim, &lim_bits, 4);
+    return sq < lim;
+}
+
 constexpr uint32_t KEY_SKIP = 0xFFFFFFFFu;  // cached LSC row that is not part of the model
 
 // cond ? a : b on indices with mask arithmetic: the index of a store that a lane may have to send to the dump slot
@@ -333,9 +345,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                               double &lo, double &hi, int &bad, int &viol) {
                 // select form (no lane-dependent branch): rows that are not part of the LP leave lo/hi/bad/viol as they are
                 const int m = key & 0xFF, i = (key >> 8) & 0xF, dyn = (key >> 12) & 1;
-                double nrm = f32_norm3(nx, ny, nz);
-                DQ_KEEP(nrm);  // computed by every lane: no short-circuit branch around the sqrt
-                const bool in_lp = (key != KEY_SKIP) & (dyn == 0) & (m == M - 1) & (i == n) & !(nrm < SP_EPSILON_FLOAT);
+                const bool in_lp = (key != KEY_SKIP) & (dyn == 0) & (m == M - 1) & (i == n) & !f32_norm3_below_eps(nx, ny, nz);
                 const float ox = wp[0] - qx, oy = wp[1] - qy, oz = wp[2] - qz;
                 double a = (double)nx * (double)diff[0] + (double)ny * (double)diff[1];
                 double b = -dd + (double)nx * (double)ox + (double)ny * (double)oy;
@@ -626,9 +636,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             const int m = have ? (int)(key & 0xFF) : 0, i = have ? (int)((key >> 8) & 0xF) : 0;
             const float nx = cnx[u].at(l), ny = cny[u].at(l), nz = cnz[u].at(l);
             // rows the reference leaves out of the model (:417-424)
-            double nrm = f32_norm3(nx, ny, nz);
-            DQ_KEEP(nrm);
-            const bool in_model = have & !(((m == 0) & (i < kp.phi)) | (nrm < SP_EPSILON_FLOAT));
+            const bool in_model = have & !(((m == 0) & (i < kp.phi)) | f32_norm3_below_eps(nx, ny, nz));
             double rhs = cd[u].at(l) + (double)nx * (double)cpx[u].at(l) + (double)ny * (double)cpy[u].at(l);
             double nsq = (double)nx * (double)nx + (double)ny * (double)ny;
             const double rhs3 = rhs + (double)nz * (double)cpz[u].at(l), nsq3 = nsq + (double)nz * (double)nz;
@@ -646,12 +654,12 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             double sg = kp.sigma[m < M ? m : 0];
             DQ_KEEP(sg);
             wsq = sl != 0xFFFFu ? wsq + sg * sg : wsq;
-            double iw = 1.0 / sqrt(wsq > 0 ? wsq : 1.0);
-            DQ_KEEP(iw);
             DQ_KEEP(rhs);
             cd[u].at(l) = in_model ? rhs : cd[u].at(l);
             ckey[u].at(l) = in_model ? key2 : KEY_SKIP;
-            ciw[u].at(l) = (in_model & (wsq > 0)) ? iw : 0.0;
+            // the SQUARED whitened length for now: 1 / sqrt of it (a square root and a division, ~70 instructions a row) is
+            // taken when the first pricing pass finds a violated cached row -- for most agents never
+            ciw[u].at(l) = (in_model & (wsq > 0)) ? wsq : 0.0;
         });
     }
     w.sync();
@@ -672,6 +680,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 
     int q = 0, iters = 0, n_add = 0, n_drop = 0;
     bool factors_ready = false;
+    bool ciw_ready = false;  // ciw holds 1 / whitened length (true) or still the squared length (false)
     // The Householder update of Q that an added row asks for is postponed until Q is read again: the last row an agent
     // adds is usually followed by a pricing pass that finds nothing, and then the O(r^2) sweep is never needed.
     bool q_pending = false;
@@ -857,12 +866,11 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         // ---- most violated inactive row ---------------------------------------------------------
         RegD bestv, bests;
         RegI bestc;
+        // cached rows: ALL LDS reads of the pass first and unconditionally (DQ_KEEP), then select-based arithmetic -- no
+        // branches, and one exposed LDS round trip per pass instead of one per row.
+        RegD lxr[KU][4], sxr[SU][5], lvr[KU];
+        RegI lsc_viol;
         w.each([&](int l) {
-            double bv = 0.0, bs = 0.0;  // violation and pivot score (violation / whitened row length) of the lane's best row
-            int bc = -1;
-            // cached rows: ALL LDS reads of the pass first and unconditionally (DQ_KEEP), then select-based arithmetic
-            // -- no branches, and one exposed LDS round trip per pass instead of one per row.
-            double lx[KU][4], sx[SU][5];
 #pragma unroll
             for (int u = 0; u < KU; u++) {
                 const uint32_t key = ckey[u].at(l);
@@ -871,10 +879,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 const int p = in_model ? m * n1 + i : 0;
                 const uint32_t sl = key >> 16;
                 const bool has_slack = in_model && sl != 0xFFFFu;
-                lx[u][0] = x[p];
-                lx[u][1] = x[P + p];
-                lx[u][2] = dim == 3 ? x[2 * P + p] : 0.0;
-                lx[u][3] = SLK == 0 ? 0.0 : x[nxc + (has_slack ? (int)sl * M + m : 0)];
+                lxr[u][0].at(l) = x[p];
+                lxr[u][1].at(l) = x[P + p];
+                lxr[u][2].at(l) = dim == 3 ? x[2 * P + p] : 0.0;
+                lxr[u][3].at(l) = SLK == 0 ? 0.0 : x[nxc + (has_slack ? (int)sl * M + m : 0)];
             }
 #pragma unroll
             for (int u = 0; u < SU; u++) {
@@ -884,12 +892,16 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 i1 = i1 == 0x3FF ? 0 : i1;
                 i2 = i2 == 0x3FF ? 0 : i2;
                 const int bsel = pc >> 24;
-                sx[u][0] = x[i0]; sx[u][1] = x[i1]; sx[u][2] = x[i2]; sx[u][3] = blo[bsel]; sx[u][4] = bhi[bsel];
+                sxr[u][0].at(l) = x[i0]; sxr[u][1].at(l) = x[i1]; sxr[u][2].at(l) = x[i2];
+                sxr[u][3].at(l) = blo[bsel]; sxr[u][4].at(l) = bhi[bsel];
             }
 #pragma unroll
-            for (int u = 0; u < KU; u++) { DQ_KEEP(lx[u][0]); DQ_KEEP(lx[u][1]); DQ_KEEP(lx[u][2]); DQ_KEEP(lx[u][3]); }
+            for (int u = 0; u < KU; u++) { DQ_KEEP(lxr[u][0].at(l)); DQ_KEEP(lxr[u][1].at(l)); DQ_KEEP(lxr[u][2].at(l)); DQ_KEEP(lxr[u][3].at(l)); }
 #pragma unroll
-            for (int u = 0; u < SU; u++) { DQ_KEEP(sx[u][0]); DQ_KEEP(sx[u][1]); DQ_KEEP(sx[u][2]); DQ_KEEP(sx[u][3]); DQ_KEEP(sx[u][4]); }
+            for (int u = 0; u < SU; u++) {
+                DQ_KEEP(sxr[u][0].at(l)); DQ_KEEP(sxr[u][1].at(l)); DQ_KEEP(sxr[u][2].at(l)); DQ_KEEP(sxr[u][3].at(l)); DQ_KEEP(sxr[u][4].at(l));
+            }
+            bool violated = false;
 #pragma unroll
             for (int u = 0; u < KU; u++) {
                 const uint32_t key = ckey[u].at(l);
@@ -897,12 +909,41 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 const uint32_t sl = key >> 16;
                 const bool has_slack = in_model && sl != 0xFFFFu;
                 const bool valid = in_model && !((fl_lsc.at(l) >> u) & 1);
-                double val = (double)cnx[u].at(l) * lx[u][0];
-                val = fma((double)cny[u].at(l), lx[u][1], val);
-                if (dim == 3) val = fma((double)cnz[u].at(l), lx[u][2], val);
-                val -= has_slack ? lx[u][3] : 0.0;
+                double val = (double)cnx[u].at(l) * lxr[u][0].at(l);
+                val = fma((double)cny[u].at(l), lxr[u][1].at(l), val);
+                if (dim == 3) val = fma((double)cnz[u].at(l), lxr[u][2].at(l), val);
+                val -= has_slack ? lxr[u][3].at(l) : 0.0;
                 const double v = valid ? cd[u].at(l) - val : -1.0;
-                const double sc = v > VIOL_TOL ? v * ciw[u].at(l) : -1.0;
+                lvr[u].at(l) = v;
+                violated |= v > VIOL_TOL;
+            }
+            lsc_viol.at(l) = violated ? 1 : 0;
+        });
+        // pivot scaling of the cached rows: 1 / sqrt(squared whitened length), taken when a pass first finds one of them
+        // violated (wave-uniform branch, at most once per agent; most agents never get here)
+        if (!ciw_ready && w.any(lsc_viol)) {
+            w.each([&](int l) {
+#pragma unroll
+                for (int u = 0; u < KU; u++) {
+                    const double wsq = ciw[u].at(l);
+                    double iw = 1.0 / sqrt(wsq > 0 ? wsq : 1.0);
+                    DQ_KEEP(iw);
+                    ciw[u].at(l) = wsq > 0 ? iw : 0.0;
+                }
+            });
+            ciw_ready = true;
+        }
+        w.each([&](int l) {
+            double bv = 0.0, bs = 0.0;  // violation and pivot score (violation / whitened row length) of the lane's best row
+            int bc = -1;
+            double sx[SU][5];
+#pragma unroll
+            for (int u = 0; u < SU; u++)
+                for (int t = 0; t < 5; t++) sx[u][t] = sxr[u][t].at(l);
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                const double v = lvr[u].at(l);
+                const double sc = v > VIOL_TOL ? v * ciw[u].at(l) : -1.0;  // scaling not taken yet: no lane has v > VIOL_TOL
                 bc = sc > bs ? l + 64 * u : bc;
                 bv = sc > bs ? v : bv;
                 bs = sc > bs ? sc : bs;
@@ -971,9 +1012,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 for (int u = 0; u < CB; u++) {
                     const int j = j0 + 64 * u + l;
                     const int m = key[u] & 0xFF, i = (key[u] >> 8) & 0xF;
-                    double nrm = f32_norm3(g[u][0], g[u][1], g[u][2]);
-                    DQ_KEEP(nrm);
-                    inm[u] = (j < K) & (cf0[u] == 0) & !((m == 0) & (i < kp.phi)) & !(nrm < SP_EPSILON_FLOAT);
+                    inm[u] = (j < K) & (cf0[u] == 0) & !((m == 0) & (i < kp.phi)) & !f32_norm3_below_eps(g[u][0], g[u][1], g[u][2]);
                     const int p = inm[u] ? m * n1 + i : 0;
                     const uint32_t sl = key[u] >> 16;
                     hsl[u] = inm[u] & (sl != 0xFFFFu) & ((int)sl < nso);
