@@ -97,7 +97,7 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
     X(0, 1, 3, 13, 5, 2, 4, 0)   \
     X(1, 1, 3, 13, 5, 4, 5, 0)   \
     X(2, 1, 3, 13, 5, 4, 5, -1)  \
-    X(3, 1, 2, 28, 10, 4, 7, 0)  \
+    X(3, 1, 2, 28, 10, 3, 5, 0)  \
     X(4, 2, 3, 28, 10, 4, 10, 0) \
     X(5, 2, 3, 28, 10, 4, 10, -1) \
     X(6, 1, 0, 0, 0, 4, 10, -1)  \
@@ -123,19 +123,31 @@ inline bool instance_n_in_lds(int id) {
 }
 
 // Which instantiation plans a batch (r_max = dim f + M max_slack_obs, kmax = most LSC rows of one agent).
+// register-cache sizes of an instantiation, from the table above (the one place they are written down)
+inline InstanceChoice instance_choice(int id) {
+    switch (id) {
+#define DQ_CASE(ID, RC, DIMS, FS, MS, KU, SU, SLK) \
+    case ID: return {ID, KU, SU};
+        DQ_INSTANCES(DQ_CASE)
+#undef DQ_CASE
+    default: return {-1, 0, 0};
+    }
+}
+
 inline InstanceChoice select_instance(const KParams &kp, int max_slack_obs, int kmax, bool force_generic) {
     const int r_max = kp.dim * kp.f + kp.M * max_slack_obs;
     const bool ns = max_slack_obs == 0;
     if (!force_generic) {
         if (kp.dim == 3 && kp.f == 13 && kp.M == 5 && r_max <= 64) {
-            if (ns && kmax <= 128 && kp.n_slots <= 256) return {0, 2, 4};
-            return {ns ? 1 : 2, 4, 5};
+            const InstanceChoice all_cached = instance_choice(0);  // compiled without the loops over rows / slots beyond its caches
+            if (ns && kmax <= 64 * all_cached.KU && kp.n_slots <= 64 * all_cached.SU) return all_cached;
+            return instance_choice(ns ? 1 : 2);
         }
-        if (kp.dim == 2 && kp.f == 28 && kp.M == 10 && ns) return {3, 4, 7};
-        if (kp.dim == 3 && kp.f == 28 && kp.M == 10 && r_max <= 128) return {ns ? 4 : 5, 4, 10};
+        if (kp.dim == 2 && kp.f == 28 && kp.M == 10 && ns) return instance_choice(3);
+        if (kp.dim == 3 && kp.f == 28 && kp.M == 10 && r_max <= 128) return instance_choice(ns ? 4 : 5);
     }
-    if (r_max <= 64) return {6, 4, 10};
-    if (r_max <= 128) return {7, 4, 10};
+    if (r_max <= 64) return instance_choice(6);
+    if (r_max <= 128) return instance_choice(7);
     return {-1, 0, 0};
 }
 
