@@ -541,8 +541,8 @@ struct KernelChoice {
     int id, KU, SU;
 };
 constexpr int DQ_ID_HBM = 7;  // the runtime-shape two-register instantiation is the one that also exists as WS_HBM
-const kernel_t dlscqp_plan_kernel_hbm = dlscqp_plan_kernel<2, 0, 0, 0, 4, 10, -1, WS_HBM>;
-const kernel_t dlscqp_plan_kernel_s_hbm = dlscqp_plan_kernel<2, 0, 0, 0, 4, 10, -1, WS_S_HBM>;
+const kernel_t dlscqp_plan_kernel_hbm = dlscqp_plan_kernel<2, 0, 0, 0, DQ_G2_KU, DQ_G2_SU, -1, WS_HBM>;
+const kernel_t dlscqp_plan_kernel_s_hbm = dlscqp_plan_kernel<2, 0, 0, 0, DQ_G2_KU, DQ_G2_SU, -1, WS_S_HBM>;
 constexpr int DQ_ID_S_HBM = DQ_N_INSTANCES;  // slot of the S-in-HBM variant in the per-kernel tables of the context
 
 // Kernel instantiation for a batch: the shared table in gi_core.hpp (DQ_INSTANCES / select_instance).
@@ -550,7 +550,7 @@ KernelChoice select_kernel(const KParams &kp, int max_slack_obs, int kmax) {
     static const bool force_generic = std::getenv("DLSCQP_FORCE_GENERIC") != nullptr;  // debugging aid
 #ifdef DLSCQP_ONLY_G2  // debugging aid: compile only the generic two-register instantiation
     (void)force_generic;
-    return {dlscqp_plan_kernel<2, 0, 0, 0, 4, 10, -1>, 7, 4, 10};
+    return {dlscqp_plan_kernel<2, 0, 0, 0, DQ_G2_KU, DQ_G2_SU, -1>, 7, DQ_G2_KU, DQ_G2_SU};
 #else
     const InstanceChoice ic = select_instance(kp, max_slack_obs, kmax, force_generic);
     switch (ic.id) {
@@ -761,15 +761,15 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         // LDS; if even that does not fit (a very long flag array), with the whole working set in HBM.  The buffer belongs to
         // the context: launches of one context that use it must not overlap.
         static const bool force_all = getenv("DLSCQP_DEBUG_WS") && std::string(getenv("DLSCQP_DEBUG_WS")) == "hbm";  // tests
-        const MemLayout lay_s = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, 4, 10, true, false);
+        const MemLayout lay_s = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, DQ_G2_KU, DQ_G2_SU, true, false);
         s_hbm = !force_all && lay_s.bytes <= LDS_LIMIT;
         if (s_hbm) {
             ws_hbm = false;
-            kc = KernelChoice{dlscqp_plan_kernel_s_hbm, DQ_ID_S_HBM, 4, 10};
+            kc = KernelChoice{dlscqp_plan_kernel_s_hbm, DQ_ID_S_HBM, DQ_G2_KU, DQ_G2_SU};
             lay = lay_s;
             a.work_stride = ((size_t)lay.s_ext_doubles * sizeof(double) + 255) & ~(size_t)255;
         } else {
-            kc = KernelChoice{dlscqp_plan_kernel_hbm, DQ_ID_HBM, 4, 10};
+            kc = KernelChoice{dlscqp_plan_kernel_hbm, DQ_ID_HBM, DQ_G2_KU, DQ_G2_SU};
             lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, true);
             a.work_stride = ((size_t)lay.bytes + 255) & ~(size_t)255;
         }

@@ -93,6 +93,10 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
 // files (3-D M=5: f=13; 2-D / 3-D M=10: f=28) with register caches sized to the row counts, with and without
 // slack (dynamic) obstacles; runtime-shape instantiations for everything else.  One list for the HIP launcher
 // and for the lane-serial test build.
+#ifndef DQ_G2_KU  // register caches of the two-register runtime-shape instantiation (also the one with HBM working-set variants)
+#define DQ_G2_KU 2
+#define DQ_G2_SU 6
+#endif
 #define DQ_INSTANCES(X)          \
     X(0, 1, 3, 13, 5, 2, 4, 0)   \
     X(1, 1, 3, 13, 5, 4, 5, 0)   \
@@ -101,7 +105,7 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
     X(4, 2, 3, 28, 10, 4, 10, 0) \
     X(5, 2, 3, 28, 10, 4, 10, -1) \
     X(6, 1, 0, 0, 0, 4, 10, -1)  \
-    X(7, 2, 0, 0, 0, 4, 10, -1)
+    X(7, 2, 0, 0, 0, DQ_G2_KU, DQ_G2_SU, -1)
 constexpr int DQ_N_INSTANCES = 8;
 
 struct InstanceChoice {

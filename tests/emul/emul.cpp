@@ -157,7 +157,7 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
     // (the GPU's WS_S_HBM kernel, dlscqp.hip)
     std::vector<double> s_ext;
     if (std::getenv("EMUL_S_EXT") && ic.id == 7) {
-        fn = plan_agent<2, 0, 0, 0, 4, 10, -1, WaveCpu, true>;
+        fn = plan_agent<2, 0, 0, 0, DQ_G2_KU, DQ_G2_SU, -1, WaveCpu, true>;
         lay = make_layout(kp, max_slack_obs, kmax, KUsel, SUsel, true, false);
         s_ext.resize(lay.s_ext_doubles);
     }
