@@ -102,9 +102,9 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
     X(1, 1, 3, 13, 5, 4, 5, 0)   \
     X(2, 1, 3, 13, 5, 4, 5, -1)  \
     X(3, 1, 2, 28, 10, 3, 5, 0)  \
-    X(4, 2, 3, 28, 10, 4, 10, 0) \
-    X(5, 2, 3, 28, 10, 4, 10, -1) \
-    X(6, 1, 0, 0, 0, 4, 10, -1)  \
+    X(4, 2, 3, 28, 10, 2, 6, 0)  \
+    X(5, 2, 3, 28, 10, 2, 6, -1) \
+    X(6, 1, 0, 0, 0, 2, 6, -1)   \
     X(7, 2, 0, 0, 0, DQ_G2_KU, DQ_G2_SU, -1)
 constexpr int DQ_N_INSTANCES = 8;
 
