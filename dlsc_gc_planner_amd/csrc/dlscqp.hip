@@ -220,8 +220,11 @@ struct KernelArgs {
     size_t work_stride;
 };
 
+// Two wavefronts per SIMD (256 VGPRs each) where eight agents fit the LDS of a CU; where the working set allows two or three
+// agents per CU anyway (reduced dimension above 64, and the 2-D M = 10 shape with its 54 KB) one wavefront per SIMD is all
+// that can run: those instantiations get the whole register file, and what spilled to scratch memory lives in AGPRs.
 #ifndef DQ_KERNEL_ATTR
-#define DQ_KERNEL_ATTR __launch_bounds__(64, 2)
+#define DQ_KERNEL_ATTR __launch_bounds__(64, (RC == 2 || (DIMS == 2 && FS == 28)) ? 1 : 2)
 #endif
 // WS_HBM: the agent's working set (Q, S, x, bound table: MemLayout) lives in a per-slot HBM buffer instead of LDS -- for
 // the shapes whose working set exceeds the 160 KiB of a CU (3-D, M = 10 with four or more slack obstacles: r > 110,
