@@ -223,8 +223,10 @@ struct KernelArgs {
 // Two wavefronts per SIMD (256 VGPRs each) where eight agents fit the LDS of a CU; where the working set allows two or three
 // agents per CU anyway (reduced dimension above 64, and the 2-D M = 10 shape with its 54 KB) one wavefront per SIMD is all
 // that can run: those instantiations get the whole register file, and what spilled to scratch memory lives in AGPRs.
+// The instantiations that keep two wavefronts per SIMD exist a second time, WIDE, for launches too small to put a second
+// wavefront on a SIMD at all (at most one agent per SIMD of the chip: every mission of the reference).
 #ifndef DQ_KERNEL_ATTR
-#define DQ_KERNEL_ATTR __launch_bounds__(64, (RC == 2 || (DIMS == 2 && FS == 28)) ? 1 : 2)
+#define DQ_KERNEL_ATTR __launch_bounds__(64, (WIDE || RC == 2 || (DIMS == 2 && FS == 28)) ? 1 : 2)
 #endif
 // WS_HBM: the agent's working set (Q, S, x, bound table: MemLayout) lives in a per-slot HBM buffer instead of LDS -- for
 // the shapes whose working set exceeds the 160 KiB of a CU (3-D, M = 10 with four or more slack obstacles: r > 110,
@@ -236,7 +238,7 @@ struct KernelArgs {
 // bound table stay in LDS.  That fits every supported reduced dimension (r <= 128: 150 KB) -- the forest missions with four
 // slack obstacles (r = 124) run this way -- and WS_HBM remains for batches whose flag array of cold rows is what overflows.
 enum { WS_LDS = 0, WS_HBM = 1, WS_S_HBM = 2 };
-template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK, int WS = WS_LDS>
+template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK, int WS = WS_LDS, bool WIDE = false>
 __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, KernelArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];
     if ((int)blockIdx.x >= a.n_slots_launch) return;
@@ -542,11 +544,23 @@ typedef void (*kernel_t)(KParams, MemLayout, KernelArgs);
 struct KernelChoice {
     kernel_t fn;
     int id, KU, SU;
+    kernel_t fn_wide = nullptr;  // the one-wavefront-per-SIMD build of the same instantiation, where there is one
 };
+constexpr int DQ_WIDE_MAX_SLOTS = 1024;  // launches of at most this many agents use it: one agent per SIMD of the chip
 constexpr int DQ_ID_HBM = 7;  // the runtime-shape two-register instantiation is the one that also exists as WS_HBM
 const kernel_t dlscqp_plan_kernel_hbm = dlscqp_plan_kernel<2, 0, 0, 0, DQ_G2_KU, DQ_G2_SU, -1, WS_HBM>;
 const kernel_t dlscqp_plan_kernel_s_hbm = dlscqp_plan_kernel<2, 0, 0, 0, DQ_G2_KU, DQ_G2_SU, -1, WS_S_HBM>;
 constexpr int DQ_ID_S_HBM = DQ_N_INSTANCES;  // slot of the S-in-HBM variant in the per-kernel tables of the context
+
+// The WIDE build of an instantiation, for those that have one: two wavefronts per SIMD normally, and register caches
+// beyond the all-in-registers instantiation (which does not spill).
+template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK>
+kernel_t wide_kernel() {
+    if constexpr (RC == 1 && !(DIMS == 2 && FS == 28) && !(KU == 2 && SU == 4))
+        return dlscqp_plan_kernel<RC, DIMS, FS, MS, KU, SU, SLK, WS_LDS, true>;
+    else
+        return nullptr;
+}
 
 // Kernel instantiation for a batch: the shared table in gi_core.hpp (DQ_INSTANCES / select_instance).
 KernelChoice select_kernel(const KParams &kp, int max_slack_obs, int kmax) {
@@ -558,7 +572,7 @@ KernelChoice select_kernel(const KParams &kp, int max_slack_obs, int kmax) {
     const InstanceChoice ic = select_instance(kp, max_slack_obs, kmax, force_generic);
     switch (ic.id) {
 #define DQ_CASE(ID, RC, DIMS, FS, MS, KU, SU, SLK) \
-    case ID: return {dlscqp_plan_kernel<RC, DIMS, FS, MS, KU, SU, SLK>, ID, KU, SU};
+    case ID: return {dlscqp_plan_kernel<RC, DIMS, FS, MS, KU, SU, SLK>, ID, KU, SU, wide_kernel<RC, DIMS, FS, MS, KU, SU, SLK>()};
         DQ_INSTANCES(DQ_CASE)
 #undef DQ_CASE
     default: return {nullptr, -1, 0, 0};
@@ -594,7 +608,7 @@ struct dlscqp_ctx {
     double *d_tabN = nullptr, *d_tabX0s = nullptr, *d_tabX0g = nullptr, *d_tabNN = nullptr, *d_tabSIW = nullptr;
     Slot *d_slots = nullptr;
     hipStream_t stream = nullptr;
-    int max_dyn_lds[DQ_N_INSTANCES + 1] = {};
+    int max_dyn_lds[2 * (DQ_N_INSTANCES + 1)] = {};  // second half: the WIDE builds
     int *d_order_scratch = nullptr;  // dlscqp_launch_order_device: two blocks of 64 counts + 64 cursors, used alternately
     unsigned order_calls = 0;
     void *work = nullptr;  // working sets of the WS_HBM kernel
@@ -787,14 +801,16 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         }
         a.work = static_cast<unsigned char *>(c->work);
     }
-    if (!ws_hbm && lay.bytes > c->max_dyn_lds[kc.id]) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kc.fn), hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
-        c->max_dyn_lds[kc.id] = lay.bytes;
-    }
-    kernel_t kfn = kc.fn;
     a.n_agents = b->n_agents;
     a.slot0 = b->launch_count > 0 ? b->launch_offset : 0;
     a.n_slots_launch = b->launch_count > 0 ? b->launch_count : b->n_agents;
+    const bool wide = kc.fn_wide && a.n_slots_launch <= DQ_WIDE_MAX_SLOTS;
+    kernel_t kfn = wide ? kc.fn_wide : kc.fn;
+    const int attr_slot = kc.id + (wide ? DQ_N_INSTANCES + 1 : 0);
+    if (!ws_hbm && lay.bytes > c->max_dyn_lds[attr_slot]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
+        c->max_dyn_lds[attr_slot] = lay.bytes;
+    }
     if (a.slot0 < 0 || a.slot0 + a.n_slots_launch > b->n_agents) { g_last_error = "launch slots out of range"; return DLSCQP_ERR_INVALID_ARGUMENT; }
     a.max_slack_obs = b->max_slack_obs;
     a.do_goal = b->do_goal;
