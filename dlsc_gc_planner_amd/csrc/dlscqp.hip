@@ -221,12 +221,14 @@ struct KernelArgs {
 };
 
 // Two wavefronts per SIMD (256 VGPRs each) where eight agents fit the LDS of a CU; where the working set allows two or three
-// agents per CU anyway (reduced dimension above 64, and the 2-D M = 10 shape with its 54 KB) one wavefront per SIMD is all
-// that can run: those instantiations get the whole register file, and what spilled to scratch memory lives in AGPRs.
+// agents per CU anyway (the static shapes with reduced dimension above 64, and the 2-D M = 10 shape with its 54 KB) one
+// wavefront per SIMD is all that can run: those instantiations get the whole register file, and what spilled to scratch
+// memory lives in AGPRs.  (Not the runtime-shape two-register instantiation and its HBM variants: they gained 3 %, and one
+// developer-only compiler configuration of tests/flag_matrix.py, -sgpr-regalloc=fast, produced a wrong forest batch with it.)
 // The instantiations that keep two wavefronts per SIMD exist a second time, WIDE, for launches too small to put a second
 // wavefront on a SIMD at all (at most one agent per SIMD of the chip: every mission of the reference).
 #ifndef DQ_KERNEL_ATTR
-#define DQ_KERNEL_ATTR __launch_bounds__(64, (WIDE || RC == 2 || (DIMS == 2 && FS == 28)) ? 1 : 2)
+#define DQ_KERNEL_ATTR __launch_bounds__(64, (WIDE || (DIMS > 0 && (RC == 2 || (DIMS == 2 && FS == 28)))) ? 1 : 2)
 #endif
 // WS_HBM: the agent's working set (Q, S, x, bound table: MemLayout) lives in a per-slot HBM buffer instead of LDS -- for
 // the shapes whose working set exceeds the 160 KiB of a CU (3-D, M = 10 with four or more slack obstacles: r > 110,
