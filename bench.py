@@ -435,7 +435,10 @@ def main():
         counter[0] += 1
         if device_order[0]:
             plan_step(db, pipelined)
-            nxt.update_order(iters=db.out_iters)
+            # the next batch's order from this batch's counts and the two batches' before it -- never from its own
+            j = (counter[0] - 1) % B
+            older = [dbs[(j - k) % B].out_iters for k in (1, 2) if (j - k) % B != (j + 1) % B]
+            nxt.update_order(iters=db.out_iters, history=older)
         else:
             plan_step(db, pipelined)
 
@@ -618,9 +621,10 @@ def main():
                              "while the next step plans the agents without remote neighbours (all of them here)"
                              if head_pipelined else "one RCCL all-gather of control points, sub-goal and status per step, after the launch"),
                 "exchange_modes_ms_per_step": exch,
-                "launch_order": "iteration counts of the previous replanning step (a different batch), descending, sorted on the device "
-                                "after every step inside the timed loop (dlscqp_launch_order_device); correlation of consecutive "
-                                "steps' counts %.2f" % hint_corr,
+                "launch_order": "iteration counts of the three previous replanning steps (the other batches of the rotation, never the "
+                                "batch's own), maximum with decay 3/4 per step, descending, sorted on the device after every step "
+                                "inside the timed loop (dlscqp_launch_order_history_device); correlation of consecutive steps' "
+                                "counts %.2f" % hint_corr,
                 "ms_per_step_host_order": None if args.headline_only else el_hostorder / side_steps * 1e3,
                 "host_order": "the same hint as permutations prepared on the host before the timed loop (round 1's method)",
                 "ms_per_step_no_order_hint": None if args.headline_only else el_nohint / side_steps * 1e3,

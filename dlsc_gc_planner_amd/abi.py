@@ -314,6 +314,8 @@ def load_library():
     lib.dlscqp_mapf_step.restype = C.c_int
     lib.dlscqp_launch_order_device.argtypes = [vp, vp, C.c_int32, vp, vp]
     lib.dlscqp_launch_order_device.restype = C.c_int
+    lib.dlscqp_launch_order_history_device.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp]
+    lib.dlscqp_launch_order_history_device.restype = C.c_int
     _LIB = lib
     return lib
 
@@ -324,5 +326,5 @@ EXPORTED_SYMBOLS = [
     "dlscqp_plan_batch_device", "dlscqp_generate_lsc_device", "dlscqp_rows_to_soa", "dlscqp_set_timing",
     "dlscqp_get_kernel_times", "dlscqp_world_create", "dlscqp_world_destroy", "dlscqp_generate_sfc_device",
     "dlscqp_advance_device", "dlscqp_waypoint_trap_device", "dlscqp_mapf_create", "dlscqp_mapf_destroy", "dlscqp_mapf_step",
-    "dlscqp_launch_order_device",
+    "dlscqp_launch_order_device", "dlscqp_launch_order_history_device",
 ]

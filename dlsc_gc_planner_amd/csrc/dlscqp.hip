@@ -952,8 +952,17 @@ __device__ __forceinline__ void order_bins_of_wave(int bin, bool valid, F f) {
     }
 }
 
-__device__ __forceinline__ int order_bin(const int32_t *iters, int idx) {
-    const int it = iters[(size_t)idx * 4];  // out_iters: iterations, adds, drops, active rows at exit
+// The key of an agent: the iteration count of the step just planned (out_iters: iterations, adds, drops, active rows at
+// exit) -- or, with the counts of up to three earlier steps as well, their maximum with decay, max_k (3/4)^k iterations_k: an
+// agent that was hard two or three steps ago is likely to be hard again, and one long agent that starts late is what a
+// launch waits for.
+struct OrderHist {
+    const int32_t *it[3];  // newest first; null = not given
+};
+__device__ __forceinline__ int order_bin(const OrderHist &h, int idx) {
+    int it = h.it[0][(size_t)idx * 4];
+    if (h.it[1]) { const int v = (3 * h.it[1][(size_t)idx * 4]) / 4; it = v > it ? v : it; }
+    if (h.it[2]) { const int v = (9 * h.it[2][(size_t)idx * 4]) / 16; it = v > it ? v : it; }
     return ORDER_BINS - 1 - (it < 0 ? 0 : (it > ORDER_BINS - 1 ? ORDER_BINS - 1 : it));
 }
 
@@ -961,7 +970,7 @@ __device__ __forceinline__ int order_bin(const int32_t *iters, int idx) {
 // one: a few dozen global atomics on the crowded bin (agents that never iterate) instead of one per wavefront -- contended
 // device-scope atomics on one address cost ~100 ns each.  `scratch` = 64 counts + 64 cursors, zero on entry; workgroup 0
 // zeroes the OTHER scratch block, the one the next call uses.
-__global__ __launch_bounds__(ORDER_THREADS) void dlscqp_order_count_kernel(const int32_t *iters, int n, int *scratch, int *scratch_next) {
+__global__ __launch_bounds__(ORDER_THREADS) void dlscqp_order_count_kernel(OrderHist iters, int n, int *scratch, int *scratch_next) {
     __shared__ int hist[ORDER_BINS];
     const int lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x < 2 * ORDER_BINS) scratch_next[threadIdx.x] = 0;
@@ -979,7 +988,7 @@ __global__ __launch_bounds__(ORDER_THREADS) void dlscqp_order_count_kernel(const
 // Pass 2: slot of an agent = first slot of its bin (exclusive prefix sum over the global histogram) + the range the
 // workgroup claims from the bin's global cursor + the range the wavefront claimed inside the workgroup + the agent's rank
 // among the wavefront's agents of that bin.
-__global__ __launch_bounds__(ORDER_THREADS) void dlscqp_order_scatter_kernel(const int32_t *iters, int n, int *scratch, int32_t *order) {
+__global__ __launch_bounds__(ORDER_THREADS) void dlscqp_order_scatter_kernel(OrderHist iters, int n, int *scratch, int32_t *order) {
     __shared__ int local[ORDER_BINS], first[ORDER_BINS];
     const int lane = threadIdx.x & 63;
     if (threadIdx.x < ORDER_BINS) local[threadIdx.x] = 0;
@@ -1011,11 +1020,26 @@ __global__ __launch_bounds__(ORDER_THREADS) void dlscqp_order_scatter_kernel(con
 }
 }  // namespace
 
+static int order_launch(dlscqp_ctx *c, const OrderHist &h, int32_t n_agents, int32_t *order_out, void *stream);
+
 extern "C" int dlscqp_launch_order_device(dlscqp_ctx *c, const int32_t *iters, int32_t n_agents, int32_t *order_out, void *stream) {
+    return order_launch(c, OrderHist{{iters, nullptr, nullptr}}, n_agents, order_out, stream);
+}
+
+extern "C" int dlscqp_launch_order_history_device(dlscqp_ctx *c, const int32_t *const *iters, int32_t n_steps, int32_t n_agents,
+                                                  int32_t *order_out, void *stream) {
+    if (!iters || n_steps < 1 || n_steps > 3) { g_last_error = "one to three steps of iteration counts"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    OrderHist h{{iters[0], n_steps > 1 ? iters[1] : nullptr, n_steps > 2 ? iters[2] : nullptr}};
+    for (int k = 0; k < n_steps; k++)
+        if (!iters[k] && n_agents > 0) { g_last_error = "null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    return order_launch(c, h, n_agents, order_out, stream);
+}
+
+static int order_launch(dlscqp_ctx *c, const OrderHist &iters, int32_t n_agents, int32_t *order_out, void *stream) {
     g_last_error.clear();
     if (!c || n_agents < 0) { g_last_error = "invalid argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
     if (n_agents == 0) return DLSCQP_SUCCESS;
-    if (!iters || !order_out) { g_last_error = "null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (!iters.it[0] || !order_out) { g_last_error = "null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
     HIP_TRY(hipSetDevice(c->cfg.device));
     if (!c->d_order_scratch) {
         HIP_TRY(hipMalloc((void **)&c->d_order_scratch, 4 * ORDER_BINS * sizeof(int)));

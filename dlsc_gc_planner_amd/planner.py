@@ -252,7 +252,7 @@ class DeviceBatch:
         self.order = self.torch.from_numpy(order).to(self.device)
         self.c.agent_order = self.order.data_ptr()
 
-    def update_order(self, stream=None, iters=None):
+    def update_order(self, stream=None, iters=None, history=()):
         """Launch order of the NEXT launch from the iteration counts of the last one, on the device
         (dlscqp_launch_order_device): the agents that needed the most iterations first.  Two order buffers alternate,
         so the launch that is still reading its order is not disturbed.  `iters`: the [n_agents, 4] int32 counts of
@@ -268,8 +268,16 @@ class DeviceBatch:
         self._order_i ^= 1
         o = self._orders[self._order_i]
         s = torch.cuda.current_stream(self.device) if stream is None else stream
-        rc = self.opt.lib.dlscqp_launch_order_device(self.opt.handle, C.c_void_p(iters.data_ptr()), self.n_agents,
-                                                     C.c_void_p(o.data_ptr()), C.c_void_p(s.cuda_stream))
+        if history:  # the counts of one or two steps before `iters` ([n_agents, 4] int32 CUDA tensors, newest first)
+            hs = [iters] + list(history)[:2]
+            for h in hs:
+                assert h.dtype == torch.int32 and h.numel() == 4 * self.n_agents and h.is_contiguous()
+            ptrs = (C.c_void_p * len(hs))(*[h.data_ptr() for h in hs])
+            rc = self.opt.lib.dlscqp_launch_order_history_device(self.opt.handle, ptrs, len(hs), self.n_agents, C.c_void_p(o.data_ptr()),
+                                                                 C.c_void_p(s.cuda_stream))
+        else:
+            rc = self.opt.lib.dlscqp_launch_order_device(self.opt.handle, C.c_void_p(iters.data_ptr()), self.n_agents,
+                                                         C.c_void_p(o.data_ptr()), C.c_void_p(s.cuda_stream))
         self.opt._check(rc, "dlscqp_launch_order_device")
         self.order = o
         self.c.agent_order = o.data_ptr()

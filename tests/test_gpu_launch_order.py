@@ -40,6 +40,32 @@ def test_order_is_a_permutation_sorted_by_iterations(gpu_required, n_swarms):
         opt.close()
 
 
+def test_order_from_the_counts_of_three_steps(gpu_required):
+    """dlscqp_launch_order_history_device: key = max(it_0, 3/4 it_1, 9/16 it_2) per agent."""
+    cfg = workloads.s64_config()
+    opt = BatchTrajOptimizer(cfg)
+    try:
+        wl = workloads.generate(cfg, lambda a, ro, r, s: opt.plan(a, ro, r, s, 0, True, True), n_swarms=6, seed=78)
+        db = opt.make_device_batch(wl["agents"], wl["row_offsets"], wl["rows"], None, 0, want_iters=True)
+        db.launch()
+        it0 = db.results()["iters"][:, 0].astype(np.int64)
+        N = len(it0)
+        rng = np.random.default_rng(0)
+        older = [np.zeros((N, 4), np.int32) for _ in range(2)]
+        for o in older:
+            o[:, 0] = rng.integers(0, 80, N)
+        td = [torch.from_numpy(o).cuda() for o in older]
+        db.update_order(history=td)
+        torch.cuda.synchronize()
+        want = np.maximum.reduce([it0, (3 * older[0][:, 0].astype(np.int64)) // 4, (9 * older[1][:, 0].astype(np.int64)) // 16])
+        order = db.order.cpu().numpy()
+        assert np.array_equal(np.sort(order), np.arange(N))
+        key = np.minimum(want[order], 63)
+        assert (np.diff(key) <= 0).all() and key[0] == min(want.max(), 63)
+    finally:
+        opt.close()
+
+
 def test_order_rejects_null_buffers(gpu_required):
     import ctypes as C
     from dlsc_gc_planner_amd import abi
