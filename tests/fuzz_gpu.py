@@ -6,12 +6,13 @@ from dlsc_gc_planner_amd import abi, workloads
 from dlsc_gc_planner_amd.planner import BatchTrajOptimizer
 import oracle_lib as O, randqp
 tot=0; bad=0
+S0 = int(__import__('os').environ.get('FUZZ_SEED0', '0'))  # shifts every seed: other random batches
 for name,(ck,gk) in randqp.CONFIGS.items():
     cfg = abi.make_config(**ck)
     opt = BatchTrajOptimizer(cfg)
     for seed in range(3):
         n = 600 if 'M10' not in name and 'M12' not in name else 250
-        b = randqp.random_batch(cfg, n, seed=1000+seed, **gk)
+        b = randqp.random_batch(cfg, n, seed=1000+seed+S0, **gk)
         t0=time.time()
         ref = O.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], b["sfc"], b["max_slack_obs"], True)
         t1=time.time()
@@ -26,7 +27,7 @@ for name,(ck,gk) in randqp.CONFIGS.items():
     opt.close()
 # S64 closed-loop workloads, several seeds
 cfg = workloads.s64_config(); opt = BatchTrajOptimizer(cfg)
-for seed in (11,12,13):
+for seed in (11+S0,12+S0,13+S0):
     wl = workloads.generate(cfg, lambda a,ro,r,s: opt.plan(a,ro,r,s,0,True,True), n_swarms=16, seed=seed)
     ref = O.plan_batch(cfg, wl['agents'], wl['row_offsets'], wl['rows'], None, 0, True)
     got = opt.plan(wl['agents'], wl['row_offsets'], wl['rows'], None, 0, True, True)
