@@ -1,0 +1,49 @@
+"""-m gpu: the instantiations that exist twice -- two wavefronts per SIMD for large launches, one wavefront per SIMD (whole
+register file) for launches of at most 1 024 agents (dlscqp.hip: WIDE) -- give the same bits.  A golden batch is tiled to
+1 500 agents and planned once as a whole (large-launch build) and once in two halves (small-launch build)."""
+import numpy as np
+import pytest
+
+from dlsc_gc_planner_amd import abi
+from dlsc_gc_planner_amd.planner import BatchTrajOptimizer
+import fixtures
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["crowd3d_M5_400rows", "forest3d_M5_dyn", "lsc2d_M4_nostop"])
+def test_small_and_large_launch_builds_agree(gpu_required, name):
+    cfg, b, ans = fixtures.load(name)
+    n0 = len(b["agents"])
+    reps = -(-1500 // n0)
+    ro = b["row_offsets"].astype(np.int64)
+    agents = np.tile(b["agents"], reps)
+    rows = np.concatenate([b["rows"]] * reps)
+    offs = np.concatenate([[0], np.cumsum(np.tile(np.diff(ro), reps))]).astype(np.int64)
+    sfc = None if b["sfc"] is None else np.concatenate([b["sfc"]] * reps)
+    N = len(agents)
+    assert N > 1024
+    opt = BatchTrajOptimizer(cfg)
+    try:
+        db = opt.make_device_batch(agents, offs, rows, sfc, b["max_slack_obs"], want_f64=True, want_iters=True)
+        db.launch()
+        whole = db.results()
+        for k in ("out_status", "out_ctrl", "out_cost", "out_iters"):  # poison what the halves must rewrite
+            getattr(db, k).fill_(-7)
+        db.out_x.zero_()  # (an agent writes only its own slack columns of x: the rest stays as allocated)
+        half = N // 2
+        db.launch(offset=0, count=half)
+        db.launch(offset=half, count=N - half)
+        halves = db.results()
+    finally:
+        opt.close()
+    for k in ("status", "goal_status", "goal", "iters"):
+        assert np.array_equal(whole[k], halves[k]), k
+    ok = whole["status"] == abi.OK  # a failed agent's plan is not written at all
+    assert ok.sum() > N // 4
+    for k in ("ctrl", "x", "cost", "slack_cost"):
+        assert np.array_equal(whole[k][ok], halves[k][ok]), k
+    # and both are the golden answers
+    first = {k: v[:n0] for k, v in whole.items()}
+    assert fixtures.check_against_golden(cfg, b, ans, first) >= 5
+    assert (whole["status"][:n0] == whole["status"][n0:2 * n0]).all()
