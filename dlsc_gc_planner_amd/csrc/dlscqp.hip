@@ -321,12 +321,13 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
 }
 
 // one workgroup of LSC_THREADS threads per local agent, threads over its (neighbour, segment) items; every
-// item is independent and writes its own 6 (3) rows of the SoA arrays (lsc_core.hpp).  Four wavefronts per agent instead of
-// one: an agent of the stress batch has ~440 items of one to two thousand instructions each behind scattered reads of its
+// item is independent and writes its own 6 (3) rows of the SoA arrays (lsc_core.hpp).  Several wavefronts per agent instead
+// of one: an agent of the stress batch has ~440 items of about a thousand instructions each behind scattered reads of its
 // neighbours' plans, and a grid of one wavefront per agent leaves the SIMDs with two wavefronts to hide that behind.  With
-// 128 VGPRs (the hull points of a lane live in LDS, lsc_core.hpp: HullStore) four workgroups share a CU; by the counters
-// the kernel then issues VALU instructions in ~0.8 of the slots (round 2).
-constexpr int LSC_THREADS = 256;
+// 128 VGPRs (the hull points of a lane live in LDS, lsc_core.hpp: HullStore) four wavefronts share a SIMD.  Two wavefronts
+// per agent: measured on the stress batch at the end of round 2 -- 64 / 128 / 192 / 256 / 512 threads: 0.072 / 0.062 / 0.072 /
+// 0.067 / 0.085 ms (440 items fill 3.4 rounds of 128 to 86 %, and eight workgroups share a CU).
+constexpr int LSC_THREADS = 128;
 __global__ __launch_bounds__(LSC_THREADS, 4) void dlscqp_lsc_kernel(LscGenArgs g) {
     const int k = blockIdx.x;
     if (k >= g.n_local) return;
