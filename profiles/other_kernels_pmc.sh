@@ -12,9 +12,12 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ
 python3 - <<PY
 import csv, glob, collections
 out = ["# PMC counters of the other kernels (average per launch; rocprofv3, one run per counter group)", ""]
-for tag, kern, grid in (("lsc", "lsc_kernel", "524288"), ("sfc", "sfc_kernel", None)):
+for tag, kern, grid in (("lsc", "lsc_kernel", "max"), ("sfc", "sfc_kernel", None)):
     acc = collections.defaultdict(list)
     dur = []
+    if grid == "max":  # the launches with the most threads: the stress batch
+        f = sorted(glob.glob("$O/%s1/*/*kernel_trace.csv" % tag))[-1]
+        grid = str(max(int(r["Grid_Size_X"]) for r in csv.DictReader(open(f)) if kern in r["Kernel_Name"]))
     for d in (tag + "1", tag + "2"):
         f = sorted(glob.glob("$O/%s/*/*counter_collection.csv" % d))[-1]
         for r in csv.DictReader(open(f)):
@@ -25,7 +28,7 @@ for tag, kern, grid in (("lsc", "lsc_kernel", "524288"), ("sfc", "sfc_kernel", N
             if kern in r["Kernel_Name"] and (grid is None or r["Grid_Size_X"] == grid):
                 dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     us = sum(dur) / max(len(dur), 1)
-    out.append("## dlscqp_%s (%s), %.1f us per launch under the profiler" % (kern, "2 048 workgroups of 256 threads, stress batch" if tag == "lsc" else "10 workgroups of 512 threads, maze mission", us))
+    out.append("## dlscqp_%s (%s), %.1f us per launch under the profiler" % (kern, "2 048 workgroups, %s threads in all, stress batch" % grid if tag == "lsc" else "10 workgroups of 512 threads, maze mission", us))
     out.append("")
     out.append("| counter | per launch |")
     out.append("|---|---|")
