@@ -1,7 +1,7 @@
 // dlscqp.hip -- gfx950 kernel + C ABI (include/dlscqp.h) of the batched DLSC-GC trajectory optimizer.
 //
 // One agent per wavefront (64 lanes), one wavefront per workgroup; the agent's working set
-// (orthogonal factor Q, packed R, whitening map N_T, control points, bound table, row flags) is in
+// (Gram table G_T, packed S = R^-1 of the active rows, control points, step direction, bound table, row flags) is in
 // LDS, the stacked LSC rows are read from HBM in structure-of-arrays form (64 consecutive rows per
 // load instruction), reductions are DPP/shuffle butterflies.  The algorithm itself is in
 // gi_core.hpp; this file supplies the wave primitives, the launch and the host marshalling.
@@ -20,6 +20,19 @@
 #endif
 #define DQ_KEEP(v) asm volatile("" : "+v"(v))
 #define DQ_MARK(text) asm volatile("; " text)
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __forceinline__ double dq_score_max(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+static __device__ __forceinline__ double dq_rsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);  // v_rsq_f64: ~2^-26 relative
+    return y * fma(-0.5 * x, y * y, 1.5);
+}
+#define DQ_SCORE_MAX(a, b) dq_score_max((a), (b))
+#define DQ_RSQRT(x) dq_rsqrt(x)
+#endif
 #ifdef DLSCQP_TRACE_LDS
 #define DLSCQP_TRACE
 #endif
@@ -137,6 +150,24 @@ struct WaveGpu {
         s = fmax(s, dpp_f64<0x143, 0xc>(id, s));
         return readlane_f64(s, 63);
     }
+    // Maximum of values that are all >= +0 (tagged pivot scores): their bit patterns order like unsigned integers, so
+    // two 32-bit reductions -- the high words, then the low words of the lanes that hold the largest high word -- with
+    // the DPP step folded into v_max_u32 replace six steps of two DPP moves and a v_max_f64 each.
+    static __device__ __forceinline__ uint32_t max_u32_wave(uint32_t v) {
+        v = ::max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true));
+        v = ::max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true));
+        v = ::max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true));
+        v = ::max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true));
+        v = ::max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+        v = ::max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+        return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+    }
+    __device__ __forceinline__ double max_pos(const Reg<double> &r) const {
+        const uint32_t hi = (uint32_t)__double2hiint(r.v), lo = (uint32_t)__double2loint(r.v);
+        const uint32_t hmax = max_u32_wave(hi);
+        const uint32_t lmax = max_u32_wave(hi == hmax ? lo : 0u);
+        return __hiloint2double((int)hmax, (int)lmax);
+    }
     __device__ __forceinline__ double min(const Reg<double> &r) const {
         const double id = 1.7976931348623157e308;
         double s = r.v;
@@ -182,6 +213,20 @@ struct WaveGpu {
         const T tail = c > 0 ? __shfl(arr[c - 1].v, 63, 64) : T(0);
         out.v = lane == 0 ? tail : prv;
     }
+    __device__ __forceinline__ double sum(const Reg<double> &a) const {
+        double x = a.v;
+        x += dpp_f64<0x111, 0xf>(0.0, x);
+        x += dpp_f64<0x112, 0xf>(0.0, x);
+        x += dpp_f64<0x114, 0xf>(0.0, x);
+        x += dpp_f64<0x118, 0xf>(0.0, x);
+        x += dpp_f64<0x142, 0xa>(0.0, x);
+        x += dpp_f64<0x143, 0xc>(0.0, x);
+        return readlane_f64(x, 63);
+    }
+    // a value that every lane computed identically (e.g. from LDS reads at a uniform address): into SGPRs, so that the
+    // control flow that depends on it is scalar
+    __device__ __forceinline__ double uni(double v) const { return uniform_f64(v); }
+    __device__ __forceinline__ uint64_t ballot(const Reg<int> &r) const { return __ballot(r.v != 0); }
     __device__ __forceinline__ bool any(const Reg<int> &r) const { return __ballot(r.v != 0) != 0ull; }
     __device__ __forceinline__ int first_lane(const Reg<int> &r) const {
         unsigned long long m = __ballot(r.v != 0);
@@ -230,16 +275,14 @@ struct KernelArgs {
 #ifndef DQ_KERNEL_ATTR
 #define DQ_KERNEL_ATTR __launch_bounds__(64, (WIDE || (DIMS > 0 && (RC == 2 || (DIMS == 2 && FS == 28)))) ? 1 : 2)
 #endif
-// WS_HBM: the agent's working set (Q, S, x, bound table: MemLayout) lives in a per-slot HBM buffer instead of LDS -- for
-// the shapes whose working set exceeds the 160 KiB of a CU (3-D, M = 10 with four or more slack obstacles: r > 110,
-// > 200 KB).  Same code, same layout; what was an LDS round trip becomes an L1/L2 round trip (the buffer of a running
-// agent stays cache-resident), so an iteration costs several times more -- a capability path for the reference's
-// ten-agent forest missions, not a throughput path.  One wavefront owns a buffer and a wavefront's memory operations
-// are performed in program order, so no fences are needed between its lanes.
-// WS = WS_S_HBM: only S = R^-1 (the packed triangle, r (r + 1) / 2 doubles) lives in the per-slot HBM buffer; Q, N_T, x and the
-// bound table stay in LDS.  That fits every supported reduced dimension (r <= 128: 150 KB) -- the forest missions with four
-// slack obstacles (r = 124) run this way -- and WS_HBM remains for batches whose flag array of cold rows is what overflows.
-enum { WS_LDS = 0, WS_HBM = 1, WS_S_HBM = 2 };
+// WS_HBM: the agent's working set (MemLayout) lives in a per-slot HBM buffer instead of LDS -- for batches whose working
+// set exceeds the 160 KiB of a CU.  Since the solver keeps no orthogonal factor (gi_core.hpp) that is only a batch with
+// a very long flag array of rows beyond the register cache (> 60 000 rows per agent); the reference's largest shape
+// (3-D, M = 10, four slack obstacles: 124 active rows at most) needs 95 KB.  Same code, same layout; what was an LDS
+// round trip becomes an L1/L2 round trip (the buffer of a running agent stays cache-resident) -- a capability path.
+// One wavefront owns a buffer and a wavefront's memory operations are performed in program order, so no fences are
+// needed between its lanes.
+enum { WS_LDS = 0, WS_HBM = 1 };
 template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK, int WS = WS_LDS, bool WIDE = false>
 __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, KernelArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];
@@ -248,8 +291,6 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
     unsigned char *smem;
     if constexpr (WS == WS_HBM) smem = a.work + (size_t)slot * a.work_stride;
     else smem = lds;
-    double *s_ext = nullptr;
-    if constexpr (WS == WS_S_HBM) s_ext = reinterpret_cast<double *>(a.work + (size_t)slot * a.work_stride);
     const int ag = a.order ? a.order[slot] : slot;
     if (ag < 0 || ag >= a.n_agents) return;
     WaveGpu w;
@@ -273,7 +314,7 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
     const int rb = a.row_offsets[ag], re = a.row_counts ? rb + a.row_counts[ag] : a.row_offsets[ag + 1];
     const int M = kp.M, n1 = kp.n1;
     const size_t xs = (size_t)kp.dim * M * n1 + (size_t)M * a.max_slack_obs;
-    plan_agent<RC, DIMS, FS, MS, KU, SU, SLK, WaveGpu, WS == WS_S_HBM>(w, kp, lay, smem, a.agents + ag, a.rows, rb, re - rb,
+    plan_agent<RC, DIMS, FS, MS, KU, SU, SLK, WaveGpu>(w, kp, lay, smem, a.agents + ag, a.rows, rb, re - rb,
                a.sfc ? a.sfc + (size_t)ag * M * 6 : nullptr, a.max_slack_obs, a.do_goal, a.do_traj,
                a.out_goal ? a.out_goal + (size_t)ag * 3 : nullptr,
                a.out_goal_status ? a.out_goal_status + ag : nullptr,
@@ -281,7 +322,7 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
                a.out_x ? a.out_x + ag * xs : nullptr, a.out_cost ? a.out_cost + ag : nullptr,
                a.out_slack_cost ? a.out_slack_cost + (size_t)ag * a.max_slack_obs : nullptr,
                a.out_status ? a.out_status + ag : nullptr,
-               a.out_iters ? a.out_iters + (size_t)ag * 4 : nullptr, s_ext);
+               a.out_iters ? a.out_iters + (size_t)ag * 4 : nullptr);
 #ifdef DLSCQP_STAMPS
     if (a.out_stamps && threadIdx.x == 0)
         for (int p = 0; p < 12; p++) a.out_stamps[(size_t)ag * 12 + p] = w.acc[p];
@@ -308,8 +349,8 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
         unsigned long long *o = a.out_stamps + (size_t)ag * 20992;
         const unsigned long long *src = reinterpret_cast<const unsigned long long *>(smem);
         if (threadIdx.x == 0) {
-            o[0] = lay.bytes; o[1] = lay.oQ; o[2] = lay.oRp; o[3] = lay.oN; o[4] = lay.oX; o[5] = lay.oBlo; o[6] = lay.oBhi;
-            o[7] = lay.oFlag; o[8] = lay.ldq; o[9] = lay.r_max;
+            o[0] = lay.bytes; o[1] = lay.oG; o[2] = lay.oRp; o[3] = lay.oDx; o[4] = lay.oX; o[5] = lay.oBlo; o[6] = lay.oBhi;
+            o[7] = lay.oFlag; o[8] = lay.ldg; o[9] = lay.r_max;
         }
         int nd = lay.bytes / 8;
 #ifdef DLSCQP_TRACE_LDS
@@ -547,19 +588,18 @@ typedef void (*kernel_t)(KParams, MemLayout, KernelArgs);
 struct KernelChoice {
     kernel_t fn;
     int id, KU, SU;
+    bool by_kind = false;
     kernel_t fn_wide = nullptr;  // the one-wavefront-per-SIMD build of the same instantiation, where there is one
 };
 constexpr int DQ_WIDE_MAX_SLOTS = 1024;  // launches of at most this many agents use it: one agent per SIMD of the chip
 constexpr int DQ_ID_HBM = 7;  // the runtime-shape two-register instantiation is the one that also exists as WS_HBM
 const kernel_t dlscqp_plan_kernel_hbm = dlscqp_plan_kernel<2, 0, 0, 0, DQ_G2_KU, DQ_G2_SU, -1, WS_HBM>;
-const kernel_t dlscqp_plan_kernel_s_hbm = dlscqp_plan_kernel<2, 0, 0, 0, DQ_G2_KU, DQ_G2_SU, -1, WS_S_HBM>;
-constexpr int DQ_ID_S_HBM = DQ_N_INSTANCES;  // slot of the S-in-HBM variant in the per-kernel tables of the context
 
 // The WIDE build of an instantiation, for those that have one: two wavefronts per SIMD normally, and register caches
 // beyond the all-in-registers instantiation (which does not spill).
 template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK>
 kernel_t wide_kernel() {
-    if constexpr (RC == 1 && !(DIMS == 2 && FS == 28) && !(KU == 2 && SU == 4))
+    if constexpr (RC == 1 && !(DIMS == 2 && FS == 28) && !(KU == 2 && SU == 0))
         return dlscqp_plan_kernel<RC, DIMS, FS, MS, KU, SU, SLK, WS_LDS, true>;
     else
         return nullptr;
@@ -570,15 +610,15 @@ KernelChoice select_kernel(const KParams &kp, int max_slack_obs, int kmax) {
     static const bool force_generic = std::getenv("DLSCQP_FORCE_GENERIC") != nullptr;  // debugging aid
 #ifdef DLSCQP_ONLY_G2  // debugging aid: compile only the generic two-register instantiation
     (void)force_generic;
-    return {dlscqp_plan_kernel<2, 0, 0, 0, DQ_G2_KU, DQ_G2_SU, -1>, 7, DQ_G2_KU, DQ_G2_SU};
+    return {dlscqp_plan_kernel<2, 0, 0, 0, DQ_G2_KU, DQ_G2_SU, -1>, 7, DQ_G2_KU, DQ_G2_SU, false};
 #else
     const InstanceChoice ic = select_instance(kp, max_slack_obs, kmax, force_generic);
     switch (ic.id) {
 #define DQ_CASE(ID, RC, DIMS, FS, MS, KU, SU, SLK) \
-    case ID: return {dlscqp_plan_kernel<RC, DIMS, FS, MS, KU, SU, SLK>, ID, KU, SU, wide_kernel<RC, DIMS, FS, MS, KU, SU, SLK>()};
+    case ID: return {dlscqp_plan_kernel<RC, DIMS, FS, MS, KU, SU, SLK>, ID, KU, SU, (DIMS) > 0, wide_kernel<RC, DIMS, FS, MS, KU, SU, SLK>()};
         DQ_INSTANCES(DQ_CASE)
 #undef DQ_CASE
-    default: return {nullptr, -1, 0, 0};
+    default: return {nullptr, -1, 0, 0, false};
     }
 #endif
 }
@@ -608,7 +648,7 @@ struct dlscqp_ctx {
     double dt;
     HostTables tb;
     KParams kp;  // with device table pointers
-    double *d_tabN = nullptr, *d_tabX0s = nullptr, *d_tabX0g = nullptr, *d_tabNN = nullptr, *d_tabSIW = nullptr;
+    double *d_tabKIW = nullptr, *d_tabG = nullptr, *d_tabX0s = nullptr, *d_tabX0g = nullptr, *d_tabNN = nullptr, *d_tabSIW = nullptr;
     Slot *d_slots = nullptr;
     hipStream_t stream = nullptr;
     int max_dyn_lds[2 * (DQ_N_INSTANCES + 1)] = {};  // second half: the WIDE builds
@@ -630,18 +670,20 @@ static int upload_tables(dlscqp_ctx *c) {
         if (!hip_ok(hipMalloc(dptr, std::max<size_t>(bytes, 16)), "hipMalloc(tables)")) return false;
         return hip_ok(hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice), "hipMemcpy(tables)");
     };
-    if (!up((void **)&c->d_tabN, c->tb.tabN.data(), c->tb.tabN.size() * 8)) return DLSCQP_ERR_HIP;
+    if (!up((void **)&c->d_tabG, c->tb.tabG.data(), c->tb.tabG.size() * 8)) return DLSCQP_ERR_HIP;
     if (!up((void **)&c->d_tabX0s, c->tb.tabX0s.data(), c->tb.tabX0s.size() * 8)) return DLSCQP_ERR_HIP;
     if (!up((void **)&c->d_tabX0g, c->tb.tabX0g.data(), c->tb.tabX0g.size() * 8)) return DLSCQP_ERR_HIP;
     if (!up((void **)&c->d_tabNN, c->tb.tabNN.data(), c->tb.tabNN.size() * 8)) return DLSCQP_ERR_HIP;
     if (!up((void **)&c->d_tabSIW, c->tb.tabSIW.data(), c->tb.tabSIW.size() * 8)) return DLSCQP_ERR_HIP;
+    if (!up((void **)&c->d_tabKIW, c->tb.tabKIW.data(), c->tb.tabKIW.size() * 8)) return DLSCQP_ERR_HIP;
     if (!up((void **)&c->d_slots, c->tb.slots.data(), c->tb.slots.size() * sizeof(Slot))) return DLSCQP_ERR_HIP;
     c->kp = c->tb.kp;
-    c->kp.tabN = c->d_tabN;
+    c->kp.tabG = c->d_tabG;
     c->kp.tabX0s = c->d_tabX0s;
     c->kp.tabX0g = c->d_tabX0g;
     c->kp.tabNN = c->d_tabNN;
     c->kp.tabSIW = c->d_tabSIW;
+    c->kp.tabKIW = c->d_tabKIW;
     c->kp.slots = c->d_slots;
     return DLSCQP_SUCCESS;
 }
@@ -681,11 +723,12 @@ extern "C" void dlscqp_destroy(dlscqp_ctx *c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto e : c->ev0) (void)hipEventDestroy(e);
     for (auto e : c->ev1) (void)hipEventDestroy(e);
-    if (c->d_tabN) (void)hipFree(c->d_tabN);
+    if (c->d_tabG) (void)hipFree(c->d_tabG);
     if (c->d_tabX0s) (void)hipFree(c->d_tabX0s);
     if (c->d_tabX0g) (void)hipFree(c->d_tabX0g);
     if (c->d_tabNN) (void)hipFree(c->d_tabNN);
     if (c->d_tabSIW) (void)hipFree(c->d_tabSIW);
+    if (c->d_tabKIW) (void)hipFree(c->d_tabKIW);
     if (c->d_slots) (void)hipFree(c->d_slots);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->work) (void)hipFree(c->work);
@@ -719,7 +762,7 @@ extern "C" int64_t dlscqp_lds_bytes(const dlscqp_ctx *c, int32_t max_slack_obs, 
     if (!c) return -1;
     KernelChoice kc = select_kernel(c->tb.kp, max_slack_obs, max_rows_per_agent);
     if (!kc.fn) return -1;
-    return make_layout(c->tb.kp, max_slack_obs, max_rows_per_agent, kc.KU, kc.SU, instance_n_in_lds(kc.id)).bytes;
+    return make_layout(c->tb.kp, max_slack_obs, max_rows_per_agent, kc.KU, kc.SU, kc.by_kind).bytes;
 }
 
 extern "C" int dlscqp_set_timing(dlscqp_ctx *c, int32_t capacity) {
@@ -771,28 +814,18 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         g_last_error = "reduced dimension above 128 (dim*f + M*max_slack_obs) is not supported";
         return DLSCQP_ERR_UNSUPPORTED;
     }
-    MemLayout lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, instance_n_in_lds(kc.id));
-    bool ws_hbm = lay.bytes > LDS_LIMIT, s_hbm = false;
+    MemLayout lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, kc.by_kind);
+    static const bool force_hbm = getenv("DLSCQP_DEBUG_WS") && std::string(getenv("DLSCQP_DEBUG_WS")) == "hbm";  // tests
+    const bool ws_hbm = lay.bytes > LDS_LIMIT || force_hbm;
     KernelArgs a;
     a.work = nullptr;
     a.work_stride = 0;
     if (ws_hbm) {
-        // Working set beyond the LDS of a CU: the runtime-shape kernel with S = R^-1 in a per-slot HBM buffer and the rest in
-        // LDS; if even that does not fit (a very long flag array), with the whole working set in HBM.  The buffer belongs to
-        // the context: launches of one context that use it must not overlap.
-        static const bool force_all = getenv("DLSCQP_DEBUG_WS") && std::string(getenv("DLSCQP_DEBUG_WS")) == "hbm";  // tests
-        const MemLayout lay_s = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, DQ_G2_KU, DQ_G2_SU, true, false);
-        s_hbm = !force_all && lay_s.bytes <= LDS_LIMIT;
-        if (s_hbm) {
-            ws_hbm = false;
-            kc = KernelChoice{dlscqp_plan_kernel_s_hbm, DQ_ID_S_HBM, DQ_G2_KU, DQ_G2_SU};
-            lay = lay_s;
-            a.work_stride = ((size_t)lay.s_ext_doubles * sizeof(double) + 255) & ~(size_t)255;
-        } else {
-            kc = KernelChoice{dlscqp_plan_kernel_hbm, DQ_ID_HBM, DQ_G2_KU, DQ_G2_SU};
-            lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, true);
-            a.work_stride = ((size_t)lay.bytes + 255) & ~(size_t)255;
-        }
+        // Working set beyond the LDS of a CU: the runtime-shape kernel with its working set in a per-slot HBM buffer.  The
+        // buffer belongs to the context: launches of one context that use it must not overlap.
+        kc = KernelChoice{dlscqp_plan_kernel_hbm, DQ_ID_HBM, DQ_G2_KU, DQ_G2_SU, false};
+        lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, false);
+        a.work_stride = ((size_t)lay.bytes + 255) & ~(size_t)255;
         const size_t need = a.work_stride * (size_t)b->n_agents;
         if (need > c->work_bytes) {
             HIP_TRY(hipDeviceSynchronize());

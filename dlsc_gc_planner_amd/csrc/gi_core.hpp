@@ -3,19 +3,22 @@
 // Replaces GoalOptimizer::solve (goal_optimizer.cpp:7-198) and TrajOptimizer::solve
 // (traj_optimizer.cpp:18-165, model at :225-527) of the reference.  The equalities are eliminated
 // and the Hessian whitened on the host (qp_tables.cpp), which leaves, per agent, a projection
-// problem  min 1/2 |w|^2  s.t. sparse half-spaces in control-point space, solved here with a
-// Goldfarb-Idnani dual active-set method:
+// problem  min 1/2 |w|^2  s.t. sparse half-spaces in control-point space (x = x0 + N_T w), solved here
+// with a Goldfarb-Idnani dual active-set method in RANGE-SPACE form -- the kernel never sees w or N_T:
 //   * every constraint row the wave will ever look at is decoded ONCE into registers: lane l owns
 //     LSC rows l, l+64, ... (coalesced SoA loads) and structured slots l, l+64, ...; a scan is then
 //     pure LDS reads of control points + FMAs, followed by one arg-max butterfly;
-//   * the small vectors of the method (whitened normal, d = Q'a, step direction z, R^-1 d, duals,
-//     active list) are one register per lane, broadcast with readlane -- no LDS round trips;
-//   * Q (r x r orthogonal) and S = R^-1 (packed upper triangle; R = triangular factor of the active
-//     normals) live in LDS and are set up lazily: the ~60 % of agents whose unconstrained optimum is
-//     feasible never touch them.  Keeping the INVERSE turns the O(q)-deep back substitution R^-1 d into
-//     one lane-parallel product, appending a row into writing one column (-S d1 / alpha, 1 / alpha), and
-//     deleting a row into a column-rotation sweep whose angles come from one prefix sum of row l of S;
-//   * a row is added with ONE Householder reflection (rank-1 update of the trailing block of Q).
+//   * a row touches at most three control-point coordinates (and one slack variable), so everything the
+//     method needs from the whitened space is an entry of the Gram table G_T = N_T N_T' (P x P per axis,
+//     one table per number of terminal segments, built on the host, copied to LDS when an agent first
+//     iterates): a_i' G a_j is at most nine table entries, the step direction dx = G (a - A' r) is one
+//     table row per touched control point.  There is no orthogonal factor: work per iteration is
+//     O(active rows), not O(r^2);
+//   * lane i keeps active row i (its sparse entries, its dual) in registers; S = R^-1 (packed upper
+//     triangle; R'R = A G A' is the Gram matrix of the active rows) lives in LDS.  Keeping the INVERSE
+//     turns both triangular solves into lane-parallel products, appending a row into writing one column
+//     (-r / alpha, 1 / alpha), and deleting a row into a column-rotation sweep whose angles come from one
+//     prefix sum of row l of S.  ~60 % of the agents never get that far: their unconstrained optimum is feasible.
 //
 // Compiled with -ffp-contract=off: the float32 expressions mirror octomap::point3d arithmetic of
 // the reference and must not be fused; the hot FP64 loops call fma() explicitly.
@@ -43,6 +46,15 @@
 #ifndef DQ_KEEP
 #define DQ_KEEP(v) ((void)0)
 #endif
+// DQ_SCORE_MAX(a, b): the larger of two tagged pivot scores (never NaN) -- on the GPU one v_max_f64, without the
+// canonicalisation of its operands that DQ_SCORE_MAX() asks for
+#ifndef DQ_SCORE_MAX
+#define DQ_SCORE_MAX(a, b) ((a) > (b) ? (a) : (b))
+#endif
+// DQ_RSQRT(x): 1 / sqrt(x) for a pivot scaling (ranks rows, never enters a result): v_rsq_f64 and one Newton step on the GPU
+#ifndef DQ_RSQRT
+#define DQ_RSQRT(x) (1.0 / sqrt(x))
+#endif
 // DQ_MARK(text): a comment in the generated assembly (tests/divergence_check.py recognises the exit stores by it)
 #ifndef DQ_MARK
 #define DQ_MARK(text) ((void)0)
@@ -55,33 +67,32 @@ namespace dlscqp {
 // plan_agent: the register budget of the wave (256 VGPRs at 2 waves/SIMD) is shared with the unrolled loops.
 
 struct MemLayout {
-    int r_max, nx_max, ldq, nflag;
-    int oQ, oRp, oN, oX, oBlo, oBhi;  // in doubles
-    int oDump;                        // 32 dump slots (lane & 31) for the lanes that have nothing to store: the spare row of Q
-    int oFlag;                        // byte offset of the flags of rows beyond the register cache
-    int kmax;                         // most LSC rows of one agent the layout was sized for (dlscqp_device_batch.max_rows_per_agent)
+    int r_max, nx_max, ldg, nflag;
+    int oG, oRp, oX, oDx, oBlo, oBhi;  // in doubles
+    int oDump;                         // 32 dump slots (lane & 31) for the lanes that have nothing to store, right behind S;
+                                       // then two doubles that stay 0.0 (what a masked read of S is sent to)
+    int oFlag;                         // byte offset of the flags of rows beyond the register cache
+    int kmax;                          // most LSC rows of one agent the layout was sized for (dlscqp_device_batch.max_rows_per_agent)
     int bytes;
-    int s_ext_doubles;                // > 0: S = R^-1 is not part of this block but lives in a buffer of that many doubles (dump slots included)
 };
 
-DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int KU, int SU, bool n_in_lds = true, bool s_in_block = true) {
+DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int KU, int SU, bool by_kind) {
     MemLayout L;
     const int nslk = kp.M * max_slack_obs;
-    L.r_max = kp.dim * kp.f + nslk;
+    L.r_max = kp.dim * kp.f + nslk;  // the active rows are independent in the whitened space: never more than its dimension
     L.nx_max = kp.dim * kp.P + nslk;
-    L.ldq = L.r_max | 1;  // odd leading dimension: conflict-free column and row sweeps
+    L.ldg = kp.P | 1;  // odd leading dimension of the Gram table: conflict-free row reads and gathers along a column
     const int cold_rows = kmax > 64 * KU ? kmax - 64 * KU : 0;
-    const int cold_slots = kp.n_slots > 64 * SU ? kp.n_slots - 64 * SU : 0;
+    const int gen_slots = by_kind ? kp.n_slots - kp.n_struct : kp.n_slots;  // the slots the generic code scans
+    const int cold_slots = gen_slots > 64 * SU ? gen_slots - 64 * SU : 0;
     L.nflag = cold_rows + 2 * cold_slots;
     L.kmax = kmax;
     int o = 0;
-    L.oQ = o; o += (L.r_max + 1) * L.ldq;  // + one row for the lanes beyond r (see "no divergence" below)
-    L.oDump = L.oQ + L.r_max * L.ldq;      // that row doubles as the dump slots: its content is never used
-    if (L.ldq < 32) o += 32 - L.ldq;
-    L.oRp = o; o += s_in_block ? L.r_max * (L.r_max + 1) / 2 : 0;
-    L.s_ext_doubles = s_in_block ? 0 : L.r_max * (L.r_max + 1) / 2 + 32;
-    L.oN = o; o += n_in_lds ? kp.P * kp.f : 0;  // instantiations that keep N_T's rows in registers need no copy
+    L.oG = o; o += kp.P * L.ldg;
+    L.oRp = o; o += L.r_max * (L.r_max + 1) / 2;
+    L.oDump = o; o += 32 + 2;
     L.oX = o; o += L.nx_max;
+    L.oDx = o; o += L.nx_max;
     L.oBlo = o; o += kp.nb;
     L.oBhi = o; o += kp.nb;
     L.oFlag = o * 8;
@@ -98,43 +109,30 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
 #define DQ_G2_SU 6
 #endif
 #define DQ_INSTANCES(X)          \
-    X(0, 1, 3, 13, 5, 2, 4, 0)   \
-    X(1, 1, 3, 13, 5, 4, 5, 0)   \
-    X(2, 1, 3, 13, 5, 4, 5, -1)  \
-    X(3, 1, 2, 28, 10, 3, 5, 0)  \
-    X(4, 2, 3, 28, 10, 2, 6, 0)  \
-    X(5, 2, 3, 28, 10, 2, 6, -1) \
+    X(0, 1, 3, 13, 5, 2, 0, 0)   \
+    X(1, 1, 3, 13, 5, 4, 4, 0)   \
+    X(2, 1, 3, 13, 5, 4, 4, -1)  \
+    X(3, 1, 2, 28, 10, 3, 3, 0)  \
+    X(4, 2, 3, 28, 10, 2, 4, 0)  \
+    X(5, 2, 3, 28, 10, 2, 4, -1) \
     X(6, 1, 0, 0, 0, 2, 6, -1)   \
     X(7, 2, 0, 0, 0, DQ_G2_KU, DQ_G2_SU, -1)
 constexpr int DQ_N_INSTANCES = 8;
 
 struct InstanceChoice {
     int id, KU, SU;  // id < 0: unsupported (reduced dimension above 128)
+    bool by_kind;    // static shapes: bound / velocity / acceleration rows by coordinate, not from the slot table
 };
-
-// Instantiations with f <= 16 and at most 64 control points per axis (the 3-D M = 5 ones) keep lane p's row of N_T
-// in registers and read the three rows of a constraint normal straight from the (L2-resident) table: no copy of N_T
-// in LDS, which is what fits an eighth agent on a CU.
-constexpr bool n_in_registers(int FS, int MS) { return FS > 0 && FS <= 16 && MS * 6 <= 64; }
-inline bool instance_n_in_lds(int id) {
-    switch (id) {
-#define DQ_CASE(ID, RC, DIMS, FS, MS, KU, SU, SLK) \
-    case ID: return !n_in_registers(FS, MS);
-        DQ_INSTANCES(DQ_CASE)
-#undef DQ_CASE
-    default: return true;
-    }
-}
 
 // Which instantiation plans a batch (r_max = dim f + M max_slack_obs, kmax = most LSC rows of one agent).
 // register-cache sizes of an instantiation, from the table above (the one place they are written down)
 inline InstanceChoice instance_choice(int id) {
     switch (id) {
 #define DQ_CASE(ID, RC, DIMS, FS, MS, KU, SU, SLK) \
-    case ID: return {ID, KU, SU};
+    case ID: return {ID, KU, SU, (DIMS) > 0};
         DQ_INSTANCES(DQ_CASE)
 #undef DQ_CASE
-    default: return {-1, 0, 0};
+    default: return {-1, 0, 0, false};
     }
 }
 
@@ -144,7 +142,7 @@ inline InstanceChoice select_instance(const KParams &kp, int max_slack_obs, int 
     if (!force_generic) {
         if (kp.dim == 3 && kp.f == 13 && kp.M == 5 && r_max <= 64) {
             const InstanceChoice all_cached = instance_choice(0);  // compiled without the loops over rows / slots beyond its caches
-            if (ns && kmax <= 64 * all_cached.KU && kp.n_slots <= 64 * all_cached.SU) return all_cached;
+            if (ns && kmax <= 64 * all_cached.KU && kp.n_slots - kp.n_struct <= 64 * all_cached.SU) return all_cached;
             return instance_choice(ns ? 1 : 2);
         }
         if (kp.dim == 2 && kp.f == 28 && kp.M == 10 && ns) return instance_choice(3);
@@ -152,7 +150,7 @@ inline InstanceChoice select_instance(const KParams &kp, int max_slack_obs, int 
     }
     if (r_max <= 64) return instance_choice(6);
     if (r_max <= 128) return instance_choice(7);
-    return {-1, 0, 0};
+    return {-1, 0, 0, false};
 }
 
 // octomath::Vector3 semantics: float32 products and sum, sqrt in double
@@ -182,6 +180,30 @@ DQ_FN int blend_idx(bool cond, int a, int b) {
     return b ^ ((a ^ b) & m);
 }
 
+DQ_FN int ctz64(uint64_t m) { return __builtin_ctzll(m); }
+
+// Pivot scores carry the code of their row in the TAG_BITS low bits of the mantissa (a relative perturbation of 2^-32):
+// the arg-max over all rows of an agent is then a plain maximum -- one v_max_f64 per candidate row, one wave reduction,
+// and the winner's code is read off the result.  code = unit * 8 + c: `unit` numbers the things a lane owns (a coordinate
+// of the control polygon, an LSC row, a structured slot, a slack variable), c the candidate row of that unit.
+constexpr int TAG_BITS = 20;
+DQ_FN double tag_score(double sc, uint32_t code) {
+    uint64_t b;
+    memcpy(&b, &sc, 8);
+    b = (b & ~(uint64_t)((1u << TAG_BITS) - 1u)) | (uint64_t)code;
+    memcpy(&sc, &b, 8);
+    return sc;
+}
+DQ_FN uint32_t score_code(double sc) {
+    uint64_t b;
+    memcpy(&b, &sc, 8);
+    return (uint32_t)(b & (uint64_t)((1u << TAG_BITS) - 1u));
+}
+// a tagged score is "violated" when it is a positive NORMAL number: a score of exactly +0 becomes a denormal by its tag
+constexpr double SCORE_MIN = 2.2250738585072014e-308;
+constexpr double NEVER = 1e200;  // limit of a row that is not in the model (or is active): never violated (times a pivot scaling it stays finite:
+                                 // an infinite score would turn into a NaN under its tag)
+
 // v[k] for a per-lane k without dynamic indexing of a register array (which would go through scratch memory)
 template <class T>
 DQ_FN T pick3(const T *v, int k) {
@@ -195,22 +217,35 @@ DQ_FN T pick3(const T *v, int k) {
 #define DQ_RP(i, j) Rp[(j) * ((j) + 1) / 2 + (i)]
 // element e of a per-lane vector spread over RC registers
 #define DQ_BC(arr, e) (RC == 1 ? w.bcast((arr)[0], (e)) : ((e) < 64 ? w.bcast((arr)[0], (e)) : w.bcast((arr)[RC - 1], (e) - 64)))
+#define DQ_BCI(arr, e) DQ_BC(arr, e)
+// element e of column t of a [RC][3] array of per-lane vectors
+#define DQ_BC2(arr, t, e) (RC == 1 ? w.bcast((arr)[0][t], (e)) : ((e) < 64 ? w.bcast((arr)[0][t], (e)) : w.bcast((arr)[RC - 1][t], (e) - 64)))
 
-// RC: registers per per-lane vector (r <= 64 RC).  DIMS/FS/MS: compile-time world dimension, free
-// degrees of freedom per axis and segment count (0 = read them from KParams).  With static shapes every O(r) / O(f) loop
-// below has a constant trip count, is fully unrolled, and its LDS reads are issued back to back instead
-// of one dependent round trip per iteration -- the difference between ~35k and a few thousand cycles per
-// active-set iteration for a single wavefront.
+// RC: registers per per-lane vector over the active rows (at most 64 RC of them; the whitened dimension r bounds their number).
+// DIMS/FS/MS: compile-time world dimension, free degrees of freedom per axis and segment count (0 = read them from KParams).
+// With static shapes the loops over control points and bound-table entries have constant trip counts and are fully unrolled.
 //
 // NO DIVERGENCE.  Every lane executes every instruction of plan_agent: there is no branch and no loop bound that
 // depends on the lane.  Lanes that have no element to work on use a clamped (valid) index for their loads,
-// mask the result with a select, and send their stores to a dump slot (MemLayout::oDump, the extra row of Q).
+// mask the result with a select, and send their stores to a dump slot (MemLayout::oDump).
 // This is a correctness rule, not a style: the solver keeps ~100 VGPRs of per-lane state and wave-uniform
 // values (LDS addresses, cached rows) alive across the whole iteration, and when the register allocator
 // splits or spills such a live range INSIDE a lane-divergent region, the copy runs under the region's EXEC
 // mask and the inactive lanes come back as garbage after the region (seen on gfx950 / ROCm 7.2: lanes
 // >= r - 64 of the two-register generic instantiation, depending on unrelated source changes).  Branches on
 // wave-uniform conditions do not touch EXEC and are fine.
+// profiling builds only (-DDQ_PHASE_PROFILE, tests/tools/phase_cost.py): DLSCQP_DEBUG_EXIT_PHASE=k in the environment ends every
+// agent's solve after phase k, so that the difference of two launches' times is what a phase costs in throughput (not in
+// one wavefront's latency)
+#ifdef DQ_PHASE_PROFILE
+#define DQ_PHASE_EXIT(k)                                          \
+    if (kp.dbg_exit_phase == (k)) {                               \
+        exit_stores(DLSCQP_OK, true, 0, 0, 0, 0, false, 0.0);     \
+        return;                                                   \
+    }
+#else
+#define DQ_PHASE_EXIT(k)
+#endif
 #ifdef DLSCQP_TRACE
 #define DQ_TRACE(tag, a, b, c, d) w.trace(tag, a, b, c, d)  // debug builds only (tests/trace_gpu.py)
 #else
@@ -218,17 +253,14 @@ DQ_FN T pick3(const T *v, int k) {
 #endif
 
 // SLK: compile-time number of slack obstacles of the batch (0), or -1 = read it from the arguments.  With
-// DIMS > 0 and SLK = 0 the whole LDS layout up to the bound table (ldq, offsets of S, N, x, dump) and the whitened
-// dimension r are constants: LDS addresses become "lane part + immediate", no address arithmetic in the loops.
-// S_EXT: the packed triangle S = R^-1 lives in `s_ext` (HBM, MemLayout::s_ext_doubles doubles of this agent's own) instead
-// of the block at `mem`: for reduced dimensions whose Q AND S do not fit the LDS of a CU together (r > 110).  The sweeps
-// over Q -- three of the four O(r^2) passes of an iteration -- stay in LDS.
-template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK, class W, bool S_EXT = false>
+// DIMS > 0 and SLK = 0 the whole LDS layout up to the bound table (offsets of G, S, x, dx, dump) is made of
+// constants: LDS addresses become "lane part + immediate", no address arithmetic in the loops.
+template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK, class W>
 DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsigned char *mem,
                       const dlscqp_agent *agp, const RowsView &rows, int row_begin, int K_rows,
                       const float *sfc, int max_slack_obs, int do_goal, int do_traj,
                       float *out_goal, int *out_goal_status, float *out_ctrl, double *out_x,
-                      double *out_cost, double *out_slack_cost, int *out_status, int *out_iters, double *s_ext = nullptr) {
+                      double *out_cost, double *out_slack_cost, int *out_status, int *out_iters) {
     static_assert(RC == 1 || RC == 2, "r <= 128");
     typedef typename W::template Reg<double> RegD;
     typedef typename W::template Reg<float> RegF;
@@ -238,17 +270,29 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     constexpr int CB = 4;  // rows beyond the register cache are read in trips of CB blocks of 64
     // select_instance() hands the KU = 2 instantiation only batches whose rows and slots all fit the register caches
     // (kmax <= 128, n_slots <= 256): it is compiled without the loops over rows and slots beyond them
-    constexpr bool ALL_CACHED = KU == 2 && SU == 4;
-    const int K = ALL_CACHED && K_rows > 64 * KU ? 64 * KU : K_rows;
-    // The caller's max_rows_per_agent picked this instantiation and sized the flag array: an agent with more rows than
-    // declared (or, in the all-cached instantiation, more rows or slots than the register caches hold) is not planned
-    // with some of its rows dropped -- it fails with DLSCQP_NUMERICAL.
-    const bool bad_shape = K_rows < 0 || K_rows > lay.kmax || (ALL_CACHED && (K_rows > 64 * KU || kp.n_slots > 64 * SU));
+    constexpr bool ALL_CACHED = KU == 2 && SU == 0;
+    constexpr int SUA = SU > 0 ? SU : 1;  // register arrays of the slot cache (never empty)
+    // BYK (static shapes): the rows of one KIND that every agent has -- variable bounds / box faces, velocity and
+    // acceleration limits (traj_optimizer.cpp:237-270, 385-410, 453-487) -- are not decoded from the slot table: lane l owns
+    // COORDINATES l, l + 64 of the control polygon (axis k, control point p: index k P + p) with their six rows
+    //   lo <= x_j <= hi,   |x_{j+1} - x_j| <= hv,   |x_{j+2} - 2 x_{j+1} + x_j| <= ha,
+    // the limits in registers (NEVER where the model has no such row, or while the row is active).  Only the rows of the
+    // communication range (kinds COMM, WAYPOINT), where there are any, go through the generic slot code.
+    constexpr bool BYK = DIMS > 0;
     const int dim = DIMS > 0 ? DIMS : kp.dim, f = FS > 0 ? FS : kp.f;
     const int M = MS > 0 ? MS : kp.M;
     constexpr int n1 = 6;  // n = 5 is the only degree the reference supports (traj_optimizer.cpp:209)
     const int P = M * n1;
     const int n = n1 - 1;
+    const int nxc = dim * P;  // control-point variables ("coordinates")
+    const int slot0 = BYK ? kp.n_struct : 0;  // the slots the generic code handles
+    const int n_slots_all = kp.n_slots - slot0;
+    const int K = ALL_CACHED && K_rows > 64 * KU ? 64 * KU : K_rows;
+    // The caller's max_rows_per_agent picked this instantiation and sized the flag array: an agent with more rows than
+    // declared (or, in the all-cached instantiation, more rows or slots than the register caches hold) is not planned
+    // with some of its rows dropped -- it fails with DLSCQP_NUMERICAL.
+    const bool bad_shape = K_rows < 0 || K_rows > lay.kmax || (ALL_CACHED && (K_rows > 64 * KU || n_slots_all > 64 * SU)) ||
+                           (nxc + K_rows + n_slots_all + M * max_slack_obs) >= (1 << (TAG_BITS - 3));
     // ---- agent record (uniform) ---------------------------------------------------------------
     float pos[3], vel[3], acc[3], cg[3], wp[3];
     for (int k = 0; k < 3; k++) {
@@ -301,10 +345,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     }
 
     // ---- structured slots into registers (issued here so that all prologue loads are in flight together)
-    const Slot *slots = kp.slots;
-    const int n_slots = ALL_CACHED && kp.n_slots > 64 * SU ? 64 * SU : kp.n_slots;
+    const Slot *slots = kp.slots + slot0;
+    const int n_slots = ALL_CACHED && n_slots_all > 64 * SU ? 64 * SU : n_slots_all;
     const int Sc = ALL_CACHED ? n_slots : (n_slots < 64 * SU ? n_slots : 64 * SU);  // cached slots
-    RegU sidx[SU], scb[SU];  // 3 x 10-bit x-space indices (0x3FF = unused) | 3 x int8 coefficients + bsel
+    RegU sidx[SUA], scb[SUA];  // 3 x 10-bit x-space indices (0x3FF = unused) | 3 x int8 coefficients + bsel
 #pragma unroll
     for (int u = 0; u < SU; u++) {
         {
@@ -465,6 +509,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         return;
     }
     w.stamp(0);  // agent record, row cache, goal LP
+    DQ_PHASE_EXIT(0);
     if (!do_traj) {
         exit_stores(0, false, 0, 0, 0, 0, false, 0.0);
         return;
@@ -473,38 +518,26 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     // ================================ trajectory QP =============================================
     double *base = reinterpret_cast<double *>(mem);
     // layout (make_layout): compile-time for static shapes without slack obstacles, else from the arguments
-#ifndef DQ_STAGE_Z
-#define DQ_STAGE_Z 1
-#endif
-#ifndef DQ_STAGE_S
-#define DQ_STAGE_S 1
-#endif
-#ifndef DQ_STAGE_H
-#define DQ_STAGE_H 1
-#endif
-    constexpr int FB = FS > 0 ? FS : 8;  // block of LDS reads issued together in the O(r) loops
-    constexpr bool NREG = n_in_registers(FS, MS);  // lane p holds row p of N_T in registers, no LDS copy
     constexpr bool ST = DIMS > 0 && SLK == 0;
-    constexpr int R_ST = DIMS * FS, LDQ_ST = (DIMS * FS) | 1;
-    static_assert(!ST || LDQ_ST >= 32, "the spare row of Q holds the 32 dump slots");
+    constexpr int P_ST = MS * 6, LDG_ST = (MS * 6) | 1, R_ST = DIMS * FS, NX_ST = DIMS * MS * 6;
+    constexpr int ORP_ST = P_ST * LDG_ST, ODUMP_ST = ORP_ST + R_ST * (R_ST + 1) / 2, OX_ST = ODUMP_ST + 32 + 2;
     const int r_max = ST ? R_ST : lay.r_max;
-    const int ldq = ST ? LDQ_ST : lay.ldq;
-    const int oQ = 0;
-    const int oRp = ST ? (R_ST + 1) * LDQ_ST : lay.oRp;
-    const int oN = ST ? (R_ST + 1) * LDQ_ST + R_ST * (R_ST + 1) / 2 : lay.oN;
-    const int oX = ST ? (R_ST + 1) * LDQ_ST + R_ST * (R_ST + 1) / 2 + (NREG ? 0 : MS * 6 * FS) : lay.oX;
-    const int odump = ST ? R_ST * LDQ_ST : lay.oDump;  // 32 dump slots in the spare row of Q, base[odump + (lane & 31)]
-    const int oBlo = ST ? (R_ST + 1) * LDQ_ST + R_ST * (R_ST + 1) / 2 + (NREG ? 0 : MS * 6 * FS) + DIMS * MS * 6 : lay.oBlo;
+    const int ldg = DIMS > 0 ? LDG_ST : lay.ldg;
+    const int oG = 0;
+    const int oRp = DIMS > 0 ? ORP_ST : lay.oRp;
+    const int odump = ST ? ODUMP_ST : lay.oDump;  // 32 dump slots, base[odump + (lane & 31)]
+    const int oX = ST ? OX_ST : lay.oX;
+    const int oDx = ST ? OX_ST + NX_ST : lay.oDx;
+    const int oBlo = ST ? OX_ST + 2 * NX_ST : lay.oBlo;
     const int oBhi = lay.oBhi;
-    double *Q = base + oQ, *Rp = S_EXT ? s_ext : base + oRp, *Nl = base + oN, *x = base + oX;
+    double *G = base + oG, *Rp = base + oRp, *x = base + oX, *dxl = base + oDx;
     double *blo = base + oBlo, *bhi = base + oBhi;
     unsigned char *cold_flag = mem + lay.oFlag;
     const int rc = dim * f;      // whitened control-point dimension
-    const int r = rc + nslk;     // whitened dimension
-    const int nxc = dim * P;     // control-point variables
+    const int r = rc + nslk;     // whitened dimension: the active rows are independent, there are never more than r
     const int cold_rows = K - Kc;
-    const int qdummy = r_max;  // spare row of Q for the lanes beyond r
-    const int odump_rp = S_EXT ? r_max * (r_max + 1) / 2 : odump - oRp;  // the dump slots as indices of Rp
+    const int odump_rp = odump - oRp;  // the dump slots as indices of Rp
+    const int ozero_rp = odump_rp + 32;  // a zero: where the reads of S below its diagonal go
 
     // terminal segments, traj_optimizer.cpp:543-551 (float32 point difference)
     int T;
@@ -517,33 +550,36 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     int status = DLSCQP_OK;
     if (!kp.t_valid[T - 1]) status = DLSCQP_NUMERICAL;
     if (nslk > 0 && !(kp.w_s > 0)) status = DLSCQP_NUMERICAL;
-    if (r > 64 * RC || dim != kp.dim || f != kp.f || M != kp.M || n1 != kp.n1) status = DLSCQP_NUMERICAL;  // the launcher picks the instantiation; defensive
+    if (r > 64 * RC || r > r_max || P > 255 || dim != kp.dim || f != kp.f || M != kp.M || n1 != kp.n1) status = DLSCQP_NUMERICAL;  // the launcher picks the instantiation; defensive
     if (status != DLSCQP_OK) {
         exit_stores(status, true, 0, 0, 0, 0, false, 0.0);
         return;
     }
 
-    const double *tN = kp.tabN + (size_t)(T - 1) * P * f;
+    const double *tG = kp.tabG + (size_t)(T - 1) * P * ldg;
     const double *tXs = kp.tabX0s + (size_t)(T - 1) * P * 3;
     const double *tXg = kp.tabX0g + (size_t)(T - 1) * P;
     const double *tNN = kp.tabNN + (size_t)(T - 1) * P;
-    const double *tSIW = kp.tabSIW + (size_t)(T - 1) * kp.n_slots;
+    const double *tSIW = kp.tabSIW + (size_t)(T - 1) * kp.n_slots + slot0;
+    const double *tKIW = kp.tabKIW + (size_t)(T - 1) * 3 * P;  // [kind][p]: pivot scaling of the bound / velocity / acceleration row at control point p
 
     // ---- unconstrained minimiser and bound table into LDS -------------------------------------------
     // (uniform trip counts; a lane past the end computes a clamped element and stores it to the dump slot)
-    RegD ciw[KU], siw[SU], nnr[KU];
+    RegD ciw[KU], siw[SUA], nnr[KU];
     constexpr int NXP = DIMS > 0 ? (DIMS * MS * 6 + 63) / 64 : 1;
+    RegD kiw[NXP][3];  // BYK: pivot scalings of the bound / velocity / acceleration rows of the lane's coordinates
     if (DIMS > 0) {
         // static shapes: every table read of this phase (x0 factors, slot scalings, row scalings: L2 round trips) is
         // issued before the first use, so the phase pays one round trip instead of one per table
         w.each([&](int l) {
-            double a0[NXP], a1[NXP], a2[NXP], ag[NXP], sv[SU], nn[KU];
+            double a0[NXP], a1[NXP], a2[NXP], ag[NXP], sv[SUA], nn[KU], kw[NXP][3];
 #pragma unroll
             for (int u = 0; u < NXP; u++) {
                 const int j = 64 * u + l;
                 const int jc = j < nxc ? j : nxc - 1;
                 const int p = jc - (jc / P) * P;
                 a0[u] = tXs[p * 3 + 0]; a1[u] = tXs[p * 3 + 1]; a2[u] = tXs[p * 3 + 2]; ag[u] = tXg[p];
+                kw[u][0] = tKIW[p]; kw[u][1] = tKIW[P + p]; kw[u][2] = tKIW[2 * P + p];
             }
 #pragma unroll
             for (int u = 0; u < SU; u++) {
@@ -558,7 +594,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 nn[u] = tNN[mi < P ? mi : 0];
             }
 #pragma unroll
-            for (int u = 0; u < NXP; u++) { DQ_KEEP(a0[u]); DQ_KEEP(a1[u]); DQ_KEEP(a2[u]); DQ_KEEP(ag[u]); }
+            for (int u = 0; u < NXP; u++) {
+                DQ_KEEP(a0[u]); DQ_KEEP(a1[u]); DQ_KEEP(a2[u]); DQ_KEEP(ag[u]);
+                DQ_KEEP(kw[u][0]); DQ_KEEP(kw[u][1]); DQ_KEEP(kw[u][2]);
+            }
 #pragma unroll
             for (int u = 0; u < SU; u++) DQ_KEEP(sv[u]);
 #pragma unroll
@@ -571,6 +610,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 const double v = a0[u] * (double)pick3(pos, k) + a1[u] * (double)pick3(vel, k) + a2[u] * (double)pick3(acc, k) +
                                  ag[u] * (double)pick3(goal, k);
                 base[blend_idx(in, oX + j, odump + (l & 31))] = v;
+                kiw[u][0].at(l) = kw[u][0]; kiw[u][1].at(l) = kw[u][1]; kiw[u][2].at(l) = kw[u][2];
             }
 #pragma unroll
             for (int u = 0; u < SU; u++) siw[u].at(l) = (l + 64 * u < Sc) ? sv[u] : 0.0;
@@ -578,6 +618,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             for (int u = 0; u < KU; u++) nnr[u].at(l) = nn[u];
         });
     }
+    const double hv_lim = max_vel * kp.vel_scale, ha_lim = max_acc * kp.acc_scale;  // dynamic limits in metres (T3g)
     w.each([&](int l) {
         if (DIMS == 0) {
         for (int j0 = 0; j0 < nxc; j0 += 64) {
@@ -594,6 +635,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             const int s2 = s0 + l;
             base[blend_idx(s2 < nslk, oX + nxc + s2, odump + (l & 31))] = 0.0;
         }
+        base[odump + 32 + (l & 1)] = 0.0;  // every lane, the same two zeros
         for (int j0 = 0; j0 < lay.nflag; j0 += 64) {
             const int j = j0 + l;
             cold_flag[j < lay.nflag ? j : lay.nflag] = 0;  // [nflag] is the dump byte
@@ -616,21 +658,19 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 blo_box = smin > blo_box ? smin : blo_box;
                 bhi_box = smax < bhi_box ? smax : bhi_box;
             }
-            const double hv = max_vel * kp.vel_scale, ha = max_acc * kp.acc_scale;
             const double hc = 0.5 * kp.comm_range - radius;  // traj_optimizer.cpp:495-500
             const int kw = bc - (dim * M + 3);
             const double cw = 0.5 * kp.comm_range - SP_EPSILON_FLOAT;  // traj_optimizer.cpp:507-510
             const double wpk = (double)pick3(wp, kw < 0 ? 0 : kw);
             double lo = wpk - cw, hi = wpk + cw;
             lo = bc == dim * M + 2 ? -hc : lo; hi = bc == dim * M + 2 ? hc : hi;
-            lo = bc == dim * M + 1 ? -ha : lo; hi = bc == dim * M + 1 ? ha : hi;
-            lo = bc == dim * M ? -hv : lo;     hi = bc == dim * M ? hv : hi;
+            lo = bc == dim * M + 1 ? -ha_lim : lo; hi = bc == dim * M + 1 ? ha_lim : hi;
+            lo = bc == dim * M ? -hv_lim : lo;     hi = bc == dim * M ? hv_lim : hi;
             lo = is_box ? blo_box : lo;        hi = is_box ? bhi_box : hi;
             base[blend_idx(in, oBlo + b, odump + (l & 31))] = lo;
             base[blend_idx(in, oBhi + b, odump + (l & 31))] = hi;
         }
     });
-    // finish the LSC cache: rhs = d + n.p (traj_optimizer.cpp:427-439), drop rows that are not in the model
     if (DIMS == 0) {
 #pragma unroll
         for (int u = 0; u < SU; u++) {
@@ -644,6 +684,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             }
         }
     }
+    // finish the LSC cache: rhs = d + n.p (traj_optimizer.cpp:427-439); a row that is not part of the model keeps a zero
+    // normal and the right-hand side -NEVER: it is never violated, and the pricing pass needs no test for it
+    RegI cpo[KU];   // control point of the row
+    RegU ltag[KU];  // the row's code (tag of its pivot score)
 #pragma unroll
     for (int u = 0; u < KU; u++) {
         w.each([&](int l) {
@@ -671,48 +715,77 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             DQ_KEEP(sg);
             wsq = sl != 0xFFFFu ? wsq + sg * sg : wsq;
             DQ_KEEP(rhs);
-            cd[u].at(l) = in_model ? rhs : cd[u].at(l);
-            ckey[u].at(l) = in_model ? key2 : KEY_SKIP;
-            // the SQUARED whitened length for now: 1 / sqrt of it (a square root and a division, ~70 instructions a row) is
-            // taken when the first pricing pass finds a violated cached row -- for most agents never
-            ciw[u].at(l) = (in_model & (wsq > 0)) ? wsq : 0.0;
+            const bool live = in_model & (wsq > 0);
+            cd[u].at(l) = live ? rhs : -NEVER;
+            cnx[u].at(l) = live ? nx : 0.0f; cny[u].at(l) = live ? ny : 0.0f; cnz[u].at(l) = live ? nz : 0.0f;
+            ckey[u].at(l) = live ? key2 : KEY_SKIP;
+            cpo[u].at(l) = live && mi < P ? mi : 0;
+            ltag[u].at(l) = (uint32_t)((BYK ? nxc : 0) + l + 64 * u) << 3;
+            double iw = DQ_RSQRT(live ? wsq : 1.0);
+            DQ_KEEP(iw);
+            ciw[u].at(l) = iw;
         });
     }
     w.sync();
+    // BYK: the limits of the lane's coordinates (after the sync: the box faces come from the bound table in LDS)
+    RegD blo_r[NXP], bhi_r[NXP], hv_r[NXP], ha_r[NXP];
+    RegU jtag[NXP];
+    if (BYK) {
+        w.each([&](int l) {
+#pragma unroll
+            for (int u = 0; u < NXP; u++) {
+                const int j = 64 * u + l;
+                const bool in = j < nxc;
+                const int jc = in ? j : nxc - 1;
+                const int k = jc / P, p = jc - k * P, m = p / n1, i = p - m * n1;
+                double lo = blo[k * M + m], hi = bhi[k * M + m];
+                DQ_KEEP(lo); DQ_KEEP(hi);
+                const bool has_b = in & !((m == 0) & (i < 3));              // traj_optimizer.cpp:260-262, 390-392
+                const bool has_v = in & (i < n) & !((m == 0) & (i < 2));    // :457-459
+                const bool has_a = in & (i < n - 1) & !((m == 0) & (i == 0));  // :471-473
+                blo_r[u].at(l) = has_b ? lo : -NEVER;
+                bhi_r[u].at(l) = has_b ? hi : NEVER;
+                hv_r[u].at(l) = has_v ? hv_lim : NEVER;
+                ha_r[u].at(l) = has_a ? ha_lim : NEVER;
+                jtag[u].at(l) = (uint32_t)jc << 3;
+            }
+        });
+    }
     w.stamp(1);  // slot cache, x0, bounds
+    DQ_PHASE_EXIT(1);
 
-    // per-lane state of the method
-    RegU fl_lsc, fl_slo, fl_shi, fl_slk;  // "skip" bits of the cached rows: active or accepted-infeasible
-    RegD na[RC], dv[RC], zv[RC], rv[RC], uu[RC];
+    // per-lane state of the method: lane i (+ 64 c) keeps active row i -- its dual, its row code and its sparse entries
+    RegU fl_slo, fl_shi, fl_slk;  // "skip" bits of the cached slots and slack bounds: active or accepted-infeasible
+    RegD uu[RC], rv[RC];
     RegI act[RC];
+    RegU a_pk[RC];     // three control-point indices of 8 bits | axis << 24 | LINE << 26 (see the decode step)
+    RegF a_cf[RC][3];  // POINT row: coefficient per axis, LINE row: per point (float32 normals and small integers: exact)
+    RegI a_sl[RC];     // slack variable of the row (coefficient -1), or -1
+    RegD a_rhs[RC];    // right-hand side of an active cached LSC row (its register in the row cache holds -NEVER meanwhile)
+    constexpr uint32_t PK_NONE = 0;  // a POINT row at control point 0 with zero coefficients
     w.each([&](int l) {
-        fl_lsc.at(l) = 0; fl_slo.at(l) = 0; fl_shi.at(l) = 0; fl_slk.at(l) = 0;
+        fl_slo.at(l) = 0; fl_shi.at(l) = 0; fl_slk.at(l) = 0;
 #pragma unroll
         for (int c = 0; c < RC; c++) {
-            uu[c].at(l) = 0; act[c].at(l) = -1; rv[c].at(l) = 0;
-            na[c].at(l) = 0; dv[c].at(l) = 0; zv[c].at(l) = 0;
+            uu[c].at(l) = 0; act[c].at(l) = -1; rv[c].at(l) = 0; a_rhs[c].at(l) = 0;
+            a_pk[c].at(l) = PK_NONE; a_sl[c].at(l) = -1;
+            a_cf[c][0].at(l) = 0; a_cf[c][1].at(l) = 0; a_cf[c][2].at(l) = 0;
         }
     });
 
+    constexpr int QB = 8;  // block of the two triangular products over the active rows
+    constexpr int DB = 4;  // block of the step direction's loop over them
+    constexpr bool DXREG = DIMS > 0 && SLK == 0 && MS * 6 <= 64;  // the step direction stays in registers (see there)
+    static_assert((64 % QB) == 0 && (64 % DB) == 0, "a block never runs past the last lane");
     int q = 0, iters = 0, n_add = 0, n_drop = 0;
     bool factors_ready = false;
-    bool ciw_ready = false;  // ciw holds 1 / whitened length (true) or still the squared length (false)
-    // The Householder update of Q that an added row asks for is postponed until Q is read again: the last row an agent
-    // adds is usually followed by a pricing pass that finds nothing, and then the O(r^2) sweep is never needed.
-    bool q_pending = false;
-    bool q_identity = true;  // Q has not been written yet: it is the identity (d = na, z = d2), materialised with the first update
-    int q_pend_col = 0;
-    double q_pend_alpha = 0.0, q_pend_beta = 0.0;
-    RegD q_pend_v[RC], q_pend_z[RC];
-    w.each([&](int l) {
-#pragma unroll
-        for (int c = 0; c < RC; c++) { q_pend_v[c].at(l) = 0.0; q_pend_z[c].at(l) = 0.0; }
-    });
-    RegD nrow[NREG ? FB : 1];  // NREG: row (lane) of N_T, loaded with the factors
-    w.each([&](int l) { for (int u = 0; u < (NREG ? FB : 1); u++) nrow[u].at(l) = 0.0; });
     const int max_iter = kp.max_iter > 0 ? kp.max_iter : 20 * (r + 8) + 200;
-    // unified row codes: [0,K) LSC rows, K + 2 s + side structured slots, K + 2 n_slots + s slack bounds
-    const int code_slack0 = K + 2 * n_slots;
+    // Row codes, code = unit * 8 + c (tag_score):
+    //   units [0, UL0)   BYK: coordinate j of the control polygon; c = 2 kind + side, kind 0 bound / 1 velocity / 2 acceleration
+    //   units [UL0, UX0) LSC row (c = 0)
+    //   units [UX0, US0) structured slot of the generic code (c = side)
+    //   units [US0, ...) slack variable: its bound eps <= 0 (c = 0)
+    const int UL0 = BYK ? nxc : 0, UX0 = UL0 + K, US0 = UX0 + n_slots;
 
     // objective value of the current iterate x (cplex.getObjValue(), traj_optimizer.cpp:109, objective at :286-331)
     auto objective = [&]() -> double {
@@ -802,7 +875,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     int n_price = 0;
     double f_max = -1.0;  // computed when first needed
 
-    auto set_skip = [&](int code, bool on) {  // code and on are uniform; the owner lane is picked by a select
+    // Takes a row out of the pricing passes (on: it became active, or was accepted within CPLEX's tolerance) or puts it back
+    // (off: it left the active set; `rhs` = its right-hand side if it is a cached LSC row).  code and on are uniform, the
+    // owner lane is picked by a select.
+    auto set_skip = [&](int code, bool on, double rhs) {
         auto upd = [&](RegU &fr, int owner, int u) {
             w.each([&](int l) {
                 const uint32_t cur = fr.at(l), bit = 1u << u;
@@ -810,12 +886,37 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 fr.at(l) = l == owner ? nv : cur;
             });
         };
-        if (code < Kc) {
-            upd(fl_lsc, code & 63, code >> 6);
-        } else if (code < K) {
-            w.each([&](int) { cold_flag[code - Kc] = on ? 1 : 0; });  // every lane, same byte, same value
-        } else if (code < code_slack0) {
-            const int s = (code - K) >> 1, side = (code - K) & 1;
+        const int unit = code >> 3, cc = code & 7;
+        if (unit < UL0) {  // BYK: the limit register of the coordinate's row
+            const int own = unit & 63, uo = unit >> 6, kind = cc >> 1, side = cc & 1;
+            const int k = unit / P, m = (unit - k * P) / n1;
+            double lim;  // what the register goes back to
+            if (kind == 0) lim = side ? bhi[k * M + m] : blo[k * M + m];
+            else lim = kind == 1 ? hv_lim : ha_lim;
+            lim = w.uni(lim);
+            const double off = (kind == 0 && side == 0) ? -NEVER : NEVER;
+            const double nv = on ? off : lim;
+            w.each([&](int l) {
+#pragma unroll
+                for (int u = 0; u < NXP; u++) {
+                    const bool me = (l == own) & (u == uo);
+                    blo_r[u].at(l) = (me & (kind == 0) & (side == 0)) ? nv : blo_r[u].at(l);
+                    bhi_r[u].at(l) = (me & (kind == 0) & (side == 1)) ? nv : bhi_r[u].at(l);
+                    hv_r[u].at(l) = (me & (kind == 1)) ? nv : hv_r[u].at(l);
+                    ha_r[u].at(l) = (me & (kind == 2)) ? nv : ha_r[u].at(l);
+                }
+            });
+        } else if (unit < UL0 + Kc) {
+            const int row = unit - UL0, own = row & 63, uo = row >> 6;
+            const double nv = on ? -NEVER : rhs;
+            w.each([&](int l) {
+#pragma unroll
+                for (int u = 0; u < KU; u++) cd[u].at(l) = ((l == own) & (u == uo)) ? nv : cd[u].at(l);
+            });
+        } else if (unit < UX0) {
+            w.each([&](int) { cold_flag[unit - UL0 - Kc] = on ? 1 : 0; });  // every lane, same byte, same value
+        } else if (unit < US0) {
+            const int s = unit - UX0, side = cc & 1;
             if (ALL_CACHED || s < Sc) {
                 if (side) upd(fl_shi, s & 63, s >> 6);
                 else upd(fl_slo, s & 63, s >> 6);
@@ -823,165 +924,116 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 w.each([&](int) { cold_flag[cold_rows + 2 * (s - Sc) + side] = on ? 1 : 0; });
             }
         } else {
-            const int s = code - code_slack0;
+            const int s = unit - US0;
             upd(fl_slk, s & 63, s >> 6);
         }
         w.sync();
     };
 
-    auto apply_pending_q = [&]() {
-        const int qc = q_pend_col;
-        if (q_identity) {  // uniform: first update, Q = I first (and zeros in the spare row qdummy that lanes beyond r work on)
-            w.each([&](int l0) {
-                int l = l0;
-                DQ_KEEP(l);  // addresses computed here, not hoisted out of the iteration loop (see the factor set-up)
-                const int nq = (r_max + 1) * ldq;
-                for (int j0 = 0; j0 < nq; j0 += 64) {
-                    const int j = j0 + l;
-                    const int i = j / ldq, c = j - i * ldq;
-                    base[blend_idx(j < nq, oQ + j, odump + (l & 31))] = ((i == c) & (i < r)) ? 1.0 : 0.0;
-                }
-            });
-            w.sync();
-            q_identity = false;
-        }
-                w.each([&](int l) {
-#pragma unroll
-            for (int c = 0; c < RC; c++) {
-                const int i = l + 64 * c;
-                double *qi = Q + (i < r ? i : qdummy) * ldq;  // lanes beyond r update the spare row
-                const double gi = -q_pend_beta * (q_pend_z[c].at(l) - q_pend_alpha * qi[qc]);
-#if DQ_STAGE_H
-                for (int j0 = 0; j0 < rc; j0 += FB) {  // Q[i][:] += gi v', in blocks of FB columns
-                    if (j0 + FB <= qc) continue;  // uniform: v is zero in the first q columns
-                    const int nv = rc - j0 < FB ? rc - j0 : FB;  // uniform; == FB for static shapes
-                    double tq[FB];
-#pragma unroll
-                    for (int u = 0; u < FB; u++) tq[u] = qi[j0 + (u < nv ? u : 0)];
-#pragma unroll
-                    for (int u = 0; u < FB; u++) DQ_KEEP(tq[u]);
-#pragma unroll
-                    for (int u = 0; u < FB; u++) tq[u] = fma(gi, DQ_BC(q_pend_v, j0 + (u < nv ? u : 0)), tq[u]);
-#pragma unroll
-                    for (int u = 0; u < FB; u++)
-                        if (u < nv) qi[j0 + u] = tq[u];  // uniform condition
-                }
-#else
-#pragma unroll
-                for (int j = 0; j < rc; j++) qi[j] = fma(gi, DQ_BC(q_pend_v, j), qi[j]);  // Q[i][:] += gi v'
-#endif
-
-                for (int j = rc; j < r; j++) qi[j] = fma(gi, DQ_BC(q_pend_v, j), qi[j]);
-            }
-        });
-        w.sync();
-        q_pending = false;
-    };
-
     for (;;) {
         // ---- most violated inactive row ---------------------------------------------------------
-        RegD bestv, bests;
-        RegI bestc;
-        // cached rows: ALL LDS reads of the pass first and unconditionally (DQ_KEEP), then select-based arithmetic -- no
-        // branches, and one exposed LDS round trip per pass instead of one per row.
-        RegD lxr[KU][4], sxr[SU][5], lvr[KU];
-        RegI lsc_viol;
+        // Every candidate row: violation v = limit - value (or value - limit), pivot score (v - VIOL_TOL) / |N'a| tagged with
+        // the row's code, running maximum.  Rows that are not in the model, or are active, have a limit that is never
+        // violated; all LDS reads of a part come first and unconditionally (one exposed round trip per part).
+        RegD best;
         w.each([&](int l) {
+            double xr[KU][4];
 #pragma unroll
             for (int u = 0; u < KU; u++) {
-                const uint32_t key = ckey[u].at(l);
-                const bool in_model = key != KEY_SKIP;
-                const int m = key & 0xFF, i = (key >> 8) & 0xF;
-                const int p = in_model ? m * n1 + i : 0;
-                const uint32_t sl = key >> 16;
-                const bool has_slack = in_model && sl != 0xFFFFu;
-                lxr[u][0].at(l) = x[p];
-                lxr[u][1].at(l) = x[P + p];
-                lxr[u][2].at(l) = dim == 3 ? x[2 * P + p] : 0.0;
-                lxr[u][3].at(l) = SLK == 0 ? 0.0 : x[nxc + (has_slack ? (int)sl * M + m : 0)];
-            }
-#pragma unroll
-            for (int u = 0; u < SU; u++) {
-                const uint32_t pi = sidx[u].at(l), pc = scb[u].at(l);
-                int i0 = pi & 0x3FF, i1 = (pi >> 10) & 0x3FF, i2 = (pi >> 20) & 0x3FF;
-                i0 = i0 == 0x3FF ? 0 : i0;  // unused entries carry coefficient 0
-                i1 = i1 == 0x3FF ? 0 : i1;
-                i2 = i2 == 0x3FF ? 0 : i2;
-                const int bsel = pc >> 24;
-                sxr[u][0].at(l) = x[i0]; sxr[u][1].at(l) = x[i1]; sxr[u][2].at(l) = x[i2];
-                sxr[u][3].at(l) = blo[bsel]; sxr[u][4].at(l) = bhi[bsel];
-            }
-#pragma unroll
-            for (int u = 0; u < KU; u++) { DQ_KEEP(lxr[u][0].at(l)); DQ_KEEP(lxr[u][1].at(l)); DQ_KEEP(lxr[u][2].at(l)); DQ_KEEP(lxr[u][3].at(l)); }
-#pragma unroll
-            for (int u = 0; u < SU; u++) {
-                DQ_KEEP(sxr[u][0].at(l)); DQ_KEEP(sxr[u][1].at(l)); DQ_KEEP(sxr[u][2].at(l)); DQ_KEEP(sxr[u][3].at(l)); DQ_KEEP(sxr[u][4].at(l));
-            }
-            bool violated = false;
-#pragma unroll
-            for (int u = 0; u < KU; u++) {
-                const uint32_t key = ckey[u].at(l);
-                const bool in_model = key != KEY_SKIP;
-                const uint32_t sl = key >> 16;
-                const bool has_slack = in_model && sl != 0xFFFFu;
-                const bool valid = in_model && !((fl_lsc.at(l) >> u) & 1);
-                double val = (double)cnx[u].at(l) * lxr[u][0].at(l);
-                val = fma((double)cny[u].at(l), lxr[u][1].at(l), val);
-                if (dim == 3) val = fma((double)cnz[u].at(l), lxr[u][2].at(l), val);
-                val -= has_slack ? lxr[u][3].at(l) : 0.0;
-                const double v = valid ? cd[u].at(l) - val : -1.0;
-                lvr[u].at(l) = v;
-                violated |= v > VIOL_TOL;
-            }
-            lsc_viol.at(l) = violated ? 1 : 0;
-        });
-        // pivot scaling of the cached rows: 1 / sqrt(squared whitened length), taken when a pass first finds one of them
-        // violated (wave-uniform branch, at most once per agent; most agents never get here)
-        if (!ciw_ready && w.any(lsc_viol)) {
-            w.each([&](int l) {
-#pragma unroll
-                for (int u = 0; u < KU; u++) {
-                    const double wsq = ciw[u].at(l);
-                    double iw = 1.0 / sqrt(wsq > 0 ? wsq : 1.0);
-                    DQ_KEEP(iw);
-                    ciw[u].at(l) = wsq > 0 ? iw : 0.0;
+                const int p = cpo[u].at(l);
+                xr[u][0] = x[p];
+                xr[u][1] = x[P + p];
+                xr[u][2] = dim == 3 ? x[2 * P + p] : 0.0;
+                if (SLK != 0) {
+                    const uint32_t key = ckey[u].at(l);
+                    const uint32_t sl = key >> 16;
+                    const bool has_slack = key != KEY_SKIP && sl != 0xFFFFu;
+                    const double xs = x[nxc + (has_slack ? (int)sl * M + (int)(key & 0xFF) : 0)];
+                    xr[u][3] = has_slack ? xs : 0.0;
+                } else {
+                    xr[u][3] = 0.0;
                 }
-            });
-            ciw_ready = true;
-        }
-        w.each([&](int l) {
-            double bv = 0.0, bs = 0.0;  // violation and pivot score (violation / whitened row length) of the lane's best row
-            int bc = -1;
-            double sx[SU][5];
+            }
+            // BYK: x_j, x_{j+1}, x_{j+2} of the lane's coordinates (the neighbours that do not exist meet a limit that is never
+            // violated)
+            double c0[NXP], c1[NXP], c2[NXP];
+            if (BYK) {
 #pragma unroll
-            for (int u = 0; u < SU; u++)
-                for (int t = 0; t < 5; t++) sx[u][t] = sxr[u][t].at(l);
-#pragma unroll
-            for (int u = 0; u < KU; u++) {
-                const double v = lvr[u].at(l);
-                const double sc = v > VIOL_TOL ? v * ciw[u].at(l) : -1.0;  // scaling not taken yet: no lane has v > VIOL_TOL
-                bc = sc > bs ? l + 64 * u : bc;
-                bv = sc > bs ? v : bv;
-                bs = sc > bs ? sc : bs;
+                for (int u = 0; u < NXP; u++) {
+                    const int j = 64 * u + l;
+                    const int j0 = j < nxc ? j : nxc - 1, j1 = j + 1 < nxc ? j + 1 : nxc - 1, j2 = j + 2 < nxc ? j + 2 : nxc - 1;
+                    c0[u] = x[j0]; c1[u] = x[j1]; c2[u] = x[j2];
+                }
             }
 #pragma unroll
-            for (int u = 0; u < SU; u++) {
-                const uint32_t pi = sidx[u].at(l), pc = scb[u].at(l);
-                const bool valid = !(pi & 0x80000000u);
-                double val = (double)(int8_t)(pc & 0xFF) * sx[u][0];
-                val = fma((double)(int8_t)((pc >> 8) & 0xFF), sx[u][1], val);
-                val = fma((double)(int8_t)((pc >> 16) & 0xFF), sx[u][2], val);
-                const double vlo = (valid && !((fl_slo.at(l) >> u) & 1)) ? sx[u][3] - val : -1.0;
-                const double vhi = (valid && !((fl_shi.at(l) >> u) & 1)) ? val - sx[u][4] : -1.0;
-                const int s = l + 64 * u;
-                const double slo = vlo > VIOL_TOL ? vlo * siw[u].at(l) : -1.0;
-                bc = slo > bs ? K + 2 * s : bc;
-                bv = slo > bs ? vlo : bv;
-                bs = slo > bs ? slo : bs;
-                const double shi = vhi > VIOL_TOL ? vhi * siw[u].at(l) : -1.0;
-                bc = shi > bs ? K + 2 * s + 1 : bc;
-                bv = shi > bs ? vhi : bv;
-                bs = shi > bs ? shi : bs;
+            for (int u = 0; u < KU; u++) { DQ_KEEP(xr[u][0]); DQ_KEEP(xr[u][1]); DQ_KEEP(xr[u][2]); DQ_KEEP(xr[u][3]); }
+            if (BYK) {
+#pragma unroll
+                for (int u = 0; u < NXP; u++) { DQ_KEEP(c0[u]); DQ_KEEP(c1[u]); DQ_KEEP(c2[u]); }
+            }
+            double bs = 0.0;
+#pragma unroll
+            for (int u = 0; u < KU; u++) {  // cached LSC rows
+                double val = (double)cnx[u].at(l) * xr[u][0];
+                val = fma((double)cny[u].at(l), xr[u][1], val);
+                if (dim == 3) val = fma((double)cnz[u].at(l), xr[u][2], val);
+                if (SLK != 0) val -= xr[u][3];
+                const double v = (cd[u].at(l) - VIOL_TOL) - val;
+                bs = DQ_SCORE_MAX(bs, tag_score(v * ciw[u].at(l), ltag[u].at(l)));
+            }
+            if (BYK) {
+                // the six rows of each of the lane's coordinates
+#pragma unroll
+                for (int u = 0; u < NXP; u++) {
+                    const double dv = c1[u] - c0[u], da = (c2[u] - c1[u]) - dv;
+                    const double wb = kiw[u][0].at(l), wv = kiw[u][1].at(l), wa = kiw[u][2].at(l);
+                    const double hv = hv_r[u].at(l) + VIOL_TOL, ha = ha_r[u].at(l) + VIOL_TOL;
+                    double sb = DQ_SCORE_MAX(tag_score(((blo_r[u].at(l) - VIOL_TOL) - c0[u]) * wb, 0u),
+                                     tag_score((c0[u] - (bhi_r[u].at(l) + VIOL_TOL)) * wb, 1u));
+                    sb = DQ_SCORE_MAX(sb, tag_score((-hv - dv) * wv, 2u));
+                    sb = DQ_SCORE_MAX(sb, tag_score((dv - hv) * wv, 3u));
+                    sb = DQ_SCORE_MAX(sb, tag_score((-ha - da) * wa, 4u));
+                    sb = DQ_SCORE_MAX(sb, tag_score((da - ha) * wa, 5u));
+                    // the coordinate's number above the row's (tag_score keeps the three low bits of the lane's winner)
+                    uint64_t b;
+                    memcpy(&b, &sb, 8);
+                    b |= (uint64_t)jtag[u].at(l);
+                    memcpy(&sb, &b, 8);
+                    bs = DQ_SCORE_MAX(bs, sb);
+#ifdef DLSCQP_DEBUG_SCAN
+                    if (64 * u + l == 76 || 64 * u + l == 77) printf("coord %d c0 %.6f lo %.6g hi %.6g wb %.6g hv %.4g ha %.4g sb %.6g code %u\n", 64 * u + l, c0[u], blo_r[u].at(l), bhi_r[u].at(l), wb, hv_r[u].at(l), ha_r[u].at(l), sb, score_code(sb)), printf("   dv %g da %g wv %g wa %g c1 %g c2 %g\n", dv, da, wv, wa, c1[u], c2[u]);
+#endif
+                }
+            }
+            // structured slots of the generic code (BYK: the rows of the communication range only)
+            {
+                double sx[SUA][5];
+#pragma unroll
+                for (int u = 0; u < SU; u++) {
+                    const uint32_t pi = sidx[u].at(l), pc = scb[u].at(l);
+                    int i0 = pi & 0x3FF, i1 = (pi >> 10) & 0x3FF, i2 = (pi >> 20) & 0x3FF;
+                    i0 = i0 == 0x3FF ? 0 : i0;  // unused entries carry coefficient 0
+                    i1 = i1 == 0x3FF ? 0 : i1;
+                    i2 = i2 == 0x3FF ? 0 : i2;
+                    const int bsel = pc >> 24;
+                    sx[u][0] = x[i0]; sx[u][1] = x[i1]; sx[u][2] = x[i2];
+                    sx[u][3] = blo[bsel]; sx[u][4] = bhi[bsel];
+                }
+#pragma unroll
+                for (int u = 0; u < SU; u++) { DQ_KEEP(sx[u][0]); DQ_KEEP(sx[u][1]); DQ_KEEP(sx[u][2]); DQ_KEEP(sx[u][3]); DQ_KEEP(sx[u][4]); }
+#pragma unroll
+                for (int u = 0; u < SU; u++) {
+                    const uint32_t pi = sidx[u].at(l), pc = scb[u].at(l);
+                    const bool valid = !(pi & 0x80000000u);
+                    double val = (double)(int8_t)(pc & 0xFF) * sx[u][0];
+                    val = fma((double)(int8_t)((pc >> 8) & 0xFF), sx[u][1], val);
+                    val = fma((double)(int8_t)((pc >> 16) & 0xFF), sx[u][2], val);
+                    const double vlo = (valid && !((fl_slo.at(l) >> u) & 1)) ? (sx[u][3] - VIOL_TOL) - val : -1.0;
+                    const double vhi = (valid && !((fl_shi.at(l) >> u) & 1)) ? val - (sx[u][4] + VIOL_TOL) : -1.0;
+                    const uint32_t code = (uint32_t)(UX0 + l + 64 * u) << 3;
+                    bs = DQ_SCORE_MAX(bs, tag_score(vlo * siw[u].at(l), code));
+                    bs = DQ_SCORE_MAX(bs, tag_score(vhi * siw[u].at(l), code | 1u));
+                }
             }
             for (int s0 = 0; s0 < nslk; s0 += 64) {  // eps <= 0 (traj_optimizer.cpp:276); uniform trip count
                 const int s = s0 + l;
@@ -990,13 +1042,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 double v = x[nxc + sc2];
                 double sg = kp.sigma[sc2 % M];
                 DQ_KEEP(v); DQ_KEEP(sg);
-                const bool cand = in & (v > VIOL_TOL) & (sg > 0) & !((fl_slk.at(l) >> (s0 >> 6)) & 1);
-                double qv = v / (sg > 0 ? sg : 1.0);
+                const bool cand = in & (sg > 0) & !((fl_slk.at(l) >> (s0 >> 6)) & 1);
+                double qv = (v - VIOL_TOL) / (sg > 0 ? sg : 1.0);
                 DQ_KEEP(qv);
-                const double sc = cand ? qv : -1.0;
-                bc = sc > bs ? code_slack0 + s : bc;
-                bv = sc > bs ? v : bv;
-                bs = sc > bs ? sc : bs;
+                bs = DQ_SCORE_MAX(bs, tag_score(cand ? qv : -1.0, (uint32_t)(US0 + sc2) << 3));
             }
             // rows beyond the register cache: straight from HBM (K > 64 KU), CB blocks of 64 rows per trip: first every
             // row's record, then the loads that depend on it (scaling, slack variable), then the arithmetic
@@ -1049,15 +1098,13 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     val = dim == 3 ? val3 : val;
                     rhs = dim == 3 ? rhs3 : rhs;
                     val = hsl[u] ? val - xv[u][3] : val;
-                    const double v = rhs - val;
+                    const double v = (rhs - VIOL_TOL) - val;
                     double wsq = ((double)nx * (double)nx + (double)ny * (double)ny + (dim == 3 ? (double)nz * (double)nz : 0.0)) * tn[u];
                     wsq = hsl[u] ? wsq + sg[u] * sg[u] : wsq;
                     double qv = v / sqrt(wsq > 0 ? wsq : 1.0);
                     DQ_KEEP(qv);
-                    const double sc = (inm[u] & (v > VIOL_TOL) & (wsq > 0)) ? qv : -1.0;
-                    bc = sc > bs ? j : bc;
-                    bv = sc > bs ? v : bv;
-                    bs = sc > bs ? sc : bs;
+                    const double sc = (inm[u] & (wsq > 0)) ? qv : -1.0;
+                    bs = DQ_SCORE_MAX(bs, tag_score(sc, (uint32_t)(UL0 + (j < K ? j : K - 1)) << 3));
                 }
             }
             if (!ALL_CACHED)
@@ -1074,27 +1121,21 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     DQ_KEEP(xv);
                     val = used ? val + (double)sl.coef[t] * xv : val;
                 }
-                const double vlo = blo[sl.bsel] - val, vhi = val - bhi[sl.bsel];
+                const double vlo = (blo[sl.bsel] - VIOL_TOL) - val, vhi = val - (bhi[sl.bsel] + VIOL_TOL);
                 const double iw = tSIW[sc2];
                 const int fo = cold_rows + 2 * (sc2 - Sc);
                 int f_lo = cold_flag[fo], f_hi = cold_flag[fo + 1];
                 DQ_KEEP(f_lo); DQ_KEEP(f_hi);
-                const double slo = (in & (vlo > VIOL_TOL) & (f_lo == 0)) ? vlo * iw : -1.0;
-                bc = slo > bs ? K + 2 * s : bc;
-                bv = slo > bs ? vlo : bv;
-                bs = slo > bs ? slo : bs;
-                const double shi = (in & (vhi > VIOL_TOL) & (f_hi == 0)) ? vhi * iw : -1.0;
-                bc = shi > bs ? K + 2 * s + 1 : bc;
-                bv = shi > bs ? vhi : bv;
-                bs = shi > bs ? shi : bs;
+                const uint32_t code = (uint32_t)(UX0 + sc2) << 3;
+                bs = DQ_SCORE_MAX(bs, tag_score((in & (f_lo == 0)) ? vlo * iw : -1.0, code));
+                bs = DQ_SCORE_MAX(bs, tag_score((in & (f_hi == 0)) ? vhi * iw : -1.0, code | 1u));
             }
-            bestv.at(l) = bv;
-            bests.at(l) = bs;
-            bestc.at(l) = bc;
+            best.at(l) = bs;
         });
-        const double top = w.max(bests);  // best pivot score over all violated rows
+        const double top = w.max_pos(best);  // best pivot score over all violated rows, with the row's code
         w.stamp(2);                       // row scan + arg-max
-        if (!(top > 0.0)) break;          // no row violated by more than VIOL_TOL: optimal
+        DQ_PHASE_EXIT(2);
+        if (!(top >= SCORE_MIN)) break;   // no row violated by more than VIOL_TOL: optimal
         // ---- infeasibility by weak duality ------------------------------------------------------
         // x minimises the objective over the active rows with non-negative multipliers, so f(x) is a lower bound
         // of the optimum.  Every feasible point obeys the box and acceleration rows, which bound the objective
@@ -1112,79 +1153,104 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 break;
             }
         }
-        RegI is_top;
-        w.each([&](int l) { is_top.at(l) = (bests.at(l) == top && bestc.at(l) >= 0) ? 1 : 0; });
-        const int owner_lane = w.first_lane(is_top);
-        const int ip = w.bcast(bestc, owner_lane);
-        double viol = w.bcast(bestv, owner_lane);  // = -(a.x - b) of the chosen row
-        DQ_TRACE(1, (double)ip, viol, top, (double)q);
+        const int ip = (int)score_code(top);
 #ifdef DLSCQP_TRACE
         DQ_TRACE(3, objective(), 0.0, 0.0, 0.0);
 #endif
 
         if (!factors_ready) {
-            // first violated row: set up the factors (agents that never get here skip all of this)
+            // first violated row: the Gram table G_T of this agent's number of terminal segments into LDS (agents that
+            // never get here skip all of this)
             w.each([&](int l0) {
                 // the lane index through an opaque copy: the addresses below must be computed here, not hoisted
-                // out of the iteration loop (where ~25 loop-invariant address registers were kept alive in scratch)
+                // out of the iteration loop (where loop-invariant address registers were kept alive in scratch)
                 int l = l0;
                 DQ_KEEP(l);
-                if (!NREG) {
-                    for (int j0 = 0; j0 < P * f; j0 += 64) {
-                        const int j = j0 + l;
-                        const bool in = j < P * f;
-                        const double v = tN[in ? j : P * f - 1];
-                        base[blend_idx(in, oN + j, odump + (l & 31))] = v;
-                    }
+                const int ng = P * ldg;
+                for (int j0 = 0; j0 < ng; j0 += 64) {
+                    const int j = j0 + l;
+                    const bool in = j < ng;
+                    const double v = tG[in ? j : ng - 1];
+                    base[blend_idx(in, oG + j, odump + (l & 31))] = v;
                 }
             });
-            if (NREG) {
-                w.each([&](int l) {
-                    const int pc = l < P ? l : P - 1;
-#pragma unroll
-                    for (int u = 0; u < (NREG ? FB : 1); u++) nrow[u].at(l) = tN[pc * f + u];
-                });
-            }
             w.sync();
             factors_ready = true;
             w.stamp(1);
         }
 
-        if (q_pending) apply_pending_q();  // uniform
-        // ---- decode the row into sparse x-space entries (uniform) -------------------------------
-        int ek[3] = {-1, -1, -1}, ep[3] = {0, 0, 0}, sidx_row = -1;
-        double cf[3] = {0, 0, 0}, row_scale = 1.0;
-        int axes_mask = 0;
-        if (ip < K) {
+        // ---- decode the row into sparse x-space entries and evaluate its violation (uniform) ----------------------
+        // Two shapes of rows.  POINT rows touch one control point on up to three axes (LSC rows, box faces, waypoint range, and
+        // the rows of a slack variable alone): point p, one coefficient per axis.  LINE rows touch up to three control points of
+        // one axis (velocity, acceleration, communication range): axis k, one coefficient per point.  Packed (also the form lane i
+        // keeps active row i in): three point indices of 8 bits | axis << 24 | LINE << 26.
+        int sidx_row = -1;
+        double row_scale = 1.0, row_rhs = 0.0;
+        bool new_line = false;
+        int new_axis = 0, np0 = 0, np1 = 0, np2 = 0;
+        double ncf[3] = {0.0, 0.0, 0.0};  // POINT: coefficient of axis k; LINE: coefficient of point t
+        double viol;                      // limit - value of the row (> VIOL_TOL)
+        const int unit = ip >> 3, icand = ip & 7;
+        if (unit < UL0) {
+            // BYK: row `icand` of coordinate `unit`
+            const int kind = icand >> 1, side = icand & 1;
+            const int k = unit / P, p = unit - k * P, m = p / n1;
+            const int j1 = unit + 1 < nxc ? unit + 1 : nxc - 1, j2 = unit + 2 < nxc ? unit + 2 : nxc - 1;
+            const double c0 = x[unit], c1 = x[j1], c2 = x[j2], lo = blo[k * M + m], hi = bhi[k * M + m];
+            const double sg = side == 0 ? 1.0 : -1.0;  // val >= lo   |   -val >= -hi
+            np0 = p;
+            double val, lim_lo, lim_hi;
+            if (kind == 0) {
+                np1 = p; np2 = p;
+                ncf[0] = k == 0 ? sg : 0.0; ncf[1] = k == 1 ? sg : 0.0; ncf[2] = k == 2 ? sg : 0.0;
+                val = c0; lim_lo = lo; lim_hi = hi;
+            } else if (kind == 1) {
+                new_line = true; new_axis = k; np1 = p + 1; np2 = p;
+                ncf[0] = -sg; ncf[1] = sg;
+                val = c1 - c0; lim_lo = -hv_lim; lim_hi = hv_lim;
+                row_scale = 1.0 / kp.vel_scale;  // back to the reference's row scaling: n/dt
+            } else {
+                new_line = true; new_axis = k; np1 = p + 1; np2 = p + 2;
+                ncf[0] = sg; ncf[1] = -2.0 * sg; ncf[2] = sg;
+                val = (c2 - c1) - (c1 - c0); lim_lo = -ha_lim; lim_hi = ha_lim;
+                row_scale = 1.0 / kp.acc_scale;  // n(n-1)/dt^2
+            }
+            viol = w.uni(side == 0 ? lim_lo - val : val - lim_hi);
+        } else if (unit < UX0) {
+            const int row = unit - UL0;
             uint32_t key = 0;
             float nn[3] = {0, 0, 0};
-            if (ALL_CACHED || ip < Kc) {
-                const int own = ip & 63, u = ip >> 6;
+            if (ALL_CACHED || row < Kc) {
+                const int own = row & 63, u = row >> 6;
+                double rh = 0.0;
 #pragma unroll
                 for (int uq = 0; uq < KU; uq++) {  // uniform selects, no branches
                     const uint32_t kq = w.bcast(ckey[uq], own);
                     const float a0 = w.bcast(cnx[uq], own), a1 = w.bcast(cny[uq], own), a2 = w.bcast(cnz[uq], own);
+                    const double rq = w.bcast(cd[uq], own);
                     key = uq == u ? kq : key;
                     nn[0] = uq == u ? a0 : nn[0]; nn[1] = uq == u ? a1 : nn[1]; nn[2] = uq == u ? a2 : nn[2];
+                    rh = uq == u ? rq : rh;
                 }
+                row_rhs = rh;
             } else {
-                key = Rkey[ip];
-                nn[0] = Rnx[ip]; nn[1] = Rny[ip]; nn[2] = Rnz[ip];
+                key = Rkey[row];
+                nn[0] = Rnx[row]; nn[1] = Rny[row]; nn[2] = Rnz[row];
                 uint32_t sl = key >> 16;
                 if (sl != 0xFFFFu && (int)sl >= nso) key |= 0xFFFF0000u;
+                row_rhs = Rd[row] + (double)nn[0] * (double)Rpx[row] + (double)nn[1] * (double)Rpy[row] +
+                          (dim == 3 ? (double)nn[2] * (double)Rpz[row] : 0.0);
             }
             const int m = key & 0xFF, i = (key >> 8) & 0xF;
-#pragma unroll
-            for (int k = 0; k < 3; k++) {
-                if (k < dim) {
-                    ek[k] = k; ep[k] = m * n1 + i; cf[k] = (double)nn[k];
-                    axes_mask |= 1 << k;
-                }
-            }
+            np0 = np1 = np2 = m * n1 + i;
+            ncf[0] = (double)nn[0]; ncf[1] = (double)nn[1]; ncf[2] = dim == 3 ? (double)nn[2] : 0.0;
             const uint32_t sl = key >> 16;
             if (sl != 0xFFFFu) sidx_row = (int)sl * M + m;
-        } else if (ip < code_slack0) {
-            const int s = (ip - K) >> 1, side = (ip - K) & 1;
+            double val = ncf[0] * x[np0] + ncf[1] * x[P + np0] + (dim == 3 ? ncf[2] * x[2 * P + np0] : 0.0);
+            val -= sidx_row >= 0 ? x[nxc + sidx_row] : 0.0;
+            viol = w.uni(row_rhs - val);
+        } else if (unit < US0) {
+            const int s = unit - UX0, side = icand & 1;
             int sidx3[3], scoef3[3], bs;
             if (ALL_CACHED || s < Sc) {  // from the owner lane's registers
                 const int own = s & 63, u = s >> 6;
@@ -1209,6 +1275,8 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 bs = sl.bsel;
             }
             const double sg = side == 0 ? 1.0 : -1.0;  // val >= lo   |   -val >= -hi
+            int ek[3], ep[3];
+            double cf[3], val = 0.0;
 #pragma unroll
             for (int t = 0; t < 3; t++) {  // fixed positions, unused entries keep ek = -1 / cf = 0
                 const bool used = sidx3[t] >= 0;
@@ -1216,174 +1284,336 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 ek[t] = k;
                 ep[t] = used ? sidx3[t] - k * P : 0;
                 cf[t] = used ? sg * (double)scoef3[t] : 0.0;
-                axes_mask |= used ? (1 << k) : 0;
+                val += used ? (double)scoef3[t] * x[sidx3[t]] : 0.0;
             }
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                new_line = new_line || (ek[t] >= 0 && ep[t] != ep[0]);
+                new_axis = ek[t] >= 0 ? ek[t] : new_axis;  // LINE rows: all used entries share it (qp_tables.cpp)
+            }
+            if (new_line) {
+                ncf[0] = cf[0]; ncf[1] = cf[1]; ncf[2] = cf[2];
+                np0 = ep[0]; np1 = ep[1]; np2 = ep[2];
+            } else {
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    ncf[0] = ek[t] == 0 ? cf[t] : ncf[0];
+                    ncf[1] = ek[t] == 1 ? cf[t] : ncf[1];
+                    ncf[2] = ek[t] == 2 ? cf[t] : ncf[2];
+                }
+                np0 = np1 = np2 = ep[0];
+            }
+            viol = w.uni(side == 0 ? blo[bs] - val : val - bhi[bs]);
             // back to the reference's row scaling: n/dt for velocity rows, n(n-1)/dt^2 for acceleration rows
             row_scale = bs == dim * M ? 1.0 / kp.vel_scale : (bs == dim * M + 1 ? 1.0 / kp.acc_scale : 1.0);
         } else {
-            sidx_row = ip - code_slack0;
+            sidx_row = unit - US0;
+            viol = w.uni(x[nxc + sidx_row]);
         }
-        // whitened normal na = N' a  (slack part: -sigma), one element per lane
-        w.each([&](int l) {
-#pragma unroll
-            for (int c = 0; c < RC; c++) {
-                const int e = l + 64 * c;
-                double v = 0;
-                const bool in_ctrl = e < rc;
-                const int ec = in_ctrl ? e : 0;
-                const int k = ec / f, j = ec - k * f;
-                double nv[3];  // the three loads first (NREG: L2 round trips), then their uses
-#pragma unroll
-                for (int t = 0; t < 3; t++) nv[t] = NREG ? tN[ep[t] * f + j] : Nl[ep[t] * f + j];  // ep[t] is a valid row of N for unused entries too (0)
-#pragma unroll
-                for (int t = 0; t < 3; t++) DQ_KEEP(nv[t]);
-#pragma unroll
-                for (int t = 0; t < 3; t++) v = (in_ctrl & (ek[t] == k)) ? fma(cf[t], nv[t], v) : v;
-                double sgm = -kp.sigma[(sidx_row < 0 ? 0 : sidx_row) % M];
-                DQ_KEEP(sgm);
-                v = (!in_ctrl & (e - rc == sidx_row)) ? sgm : v;
-                na[c].at(l) = v;
-            }
-        });
-        w.stamp(3);  // decode + whitened normal
+        const uint32_t pk_new = new_line ? ((uint32_t)np0 | ((uint32_t)np1 << 8) | ((uint32_t)np2 << 16) | ((uint32_t)new_axis << 24) | (1u << 26))
+                                         : (uint32_t)np0 * 0x010101u;
+        DQ_TRACE(1, (double)ip, viol, top, (double)q);
+        const double sig_row = kp.sigma[(sidx_row < 0 ? 0 : sidx_row) % M];
+        const double sig2_row = sidx_row >= 0 ? sig_row * sig_row : 0.0;
+        // squared whitened length of the row, a' G a (every lane reads the same entries of G)
+        double dall;
+        if (new_line) {  // uniform
+            const double g00 = G[np0 * ldg + np0], g01 = G[np0 * ldg + np1], g02 = G[np0 * ldg + np2];
+            const double g11 = G[np1 * ldg + np1], g12 = G[np1 * ldg + np2], g22 = G[np2 * ldg + np2];
+            const double line = ncf[0] * (ncf[0] * g00 + 2.0 * (ncf[1] * g01 + ncf[2] * g02)) +
+                                ncf[1] * (ncf[1] * g11 + 2.0 * ncf[2] * g12) + ncf[2] * ncf[2] * g22;
+            dall = w.uni(line + sig2_row);
+        } else {
+            dall = w.uni((ncf[0] * ncf[0] + ncf[1] * ncf[1] + ncf[2] * ncf[2]) * G[np0 * ldg + np0] + sig2_row);
+        }
+        w.stamp(3);  // decode
 
         double uq = 0.0;
         bool resolved = false;
         while (!resolved) {
             if (++iters > max_iter) { status = DLSCQP_ITERATION_LIMIT; break; }
-            // d = Q' na   (na is non-zero only in the touched axis blocks and one slack entry)
-            if (q_identity) {  // uniform
-                w.each([&](int l) {
-#pragma unroll
-                    for (int c = 0; c < RC; c++) dv[c].at(l) = l + 64 * c < r ? na[c].at(l) : 0.0;
-                });
-            } else
-            w.each([&](int l) {
-#pragma unroll
-                for (int c = 0; c < RC; c++) {
-                    const int j = l + 64 * c;
-                    double a0 = 0.0, a1 = 0.0;
-                    const int jc = j < r ? j : 0;  // lanes beyond r read column 0 and drop the sum
-#pragma unroll
-                    for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++) {
-                        if (k < dim && (axes_mask & (1 << k))) {  // uniform
-                            // blocks of FB rows: all LDS reads of a block are issued before the first use
-                            for (int i0 = 0; i0 < f; i0 += FB) {
-                                const int nv = f - i0 < FB ? f - i0 : FB;  // uniform; == FB for static shapes
-                                double tq[FB];
-#pragma unroll
-                                for (int u = 0; u < FB; u++) tq[u] = Q[(k * f + i0 + (u < nv ? u : 0)) * ldq + jc];
-#pragma unroll
-                                for (int u = 0; u < FB; u++) DQ_KEEP(tq[u]);
-#pragma unroll
-                                for (int u = 0; u < FB; u += 2) {
-                                    if (u < nv) a0 = fma(tq[u], DQ_BC(na, k * f + i0 + u), a0);
-                                    if (u + 1 < FB && u + 1 < nv) a1 = fma(tq[u + 1], DQ_BC(na, k * f + i0 + u + 1), a1);
-                                }
-                            }
-                        }
-                    }
-                    if (sidx_row >= 0) {  // uniform
-                        const int i = rc + sidx_row;
-                        a0 = fma(Q[i * ldq + jc], DQ_BC(na, i), a0);
-                    }
-                    dv[c].at(l) = j < r ? a0 + a1 : 0.0;
-                }
-            });
-            w.stamp(4);  // d = Q' na
-            // z = Q2 d2, |d2|^2, |d|^2.  d2 = d with the first q entries zeroed, as a register of its own, so
-            // that the unrolled loop below is select- and branch-free (its LDS reads then issue back to back)
-            RegD dz[RC];
-            w.each([&](int l) {
-#pragma unroll
-                for (int c = 0; c < RC; c++) dz[c].at(l) = (l + 64 * c >= q) ? dv[c].at(l) : 0.0;
-            });
-            if (q_identity) {  // uniform: Q2 = I (q = 0)
-                w.each([&](int l) {
-#pragma unroll
-                    for (int c = 0; c < RC; c++) zv[c].at(l) = dz[c].at(l);
-                });
-            } else
-            w.each([&](int l) {
-#pragma unroll
-                for (int c = 0; c < RC; c++) {
-                    const int i = l + 64 * c;
-                    double a0 = 0.0, a1 = 0.0;
-                    const double *qi = Q + (i < r ? i : qdummy) * ldq;  // lanes beyond r: the spare row
-#if DQ_STAGE_Z
-                    for (int j0 = 0; j0 < rc; j0 += FB) {
-                        if (j0 + FB <= q) continue;  // uniform: d2 is zero in the first q columns
-                        const int nv = rc - j0 < FB ? rc - j0 : FB;  // uniform; == FB for static shapes
-                        double tq[FB];
-#pragma unroll
-                        for (int u = 0; u < FB; u++) tq[u] = qi[j0 + (u < nv ? u : 0)];
-#pragma unroll
-                        for (int u = 0; u < FB; u++) DQ_KEEP(tq[u]);
-#pragma unroll
-                        for (int u = 0; u < FB; u += 2) {
-                            if (u < nv) a0 = fma(tq[u], DQ_BC(dz, j0 + u), a0);
-                            if (u + 1 < FB && u + 1 < nv) a1 = fma(tq[u + 1], DQ_BC(dz, j0 + u + 1), a1);
-                        }
-                    }
-#else
-#pragma unroll
-                    for (int j = 0; j < rc; j += 2) {
-                        a0 = fma(qi[j], DQ_BC(dz, j), a0);
-                        if (j + 1 < rc) a1 = fma(qi[j + 1], DQ_BC(dz, j + 1), a1);
-                    }
-#endif
-
-                    for (int j = rc; j < r; j++) a0 = fma(qi[j], DQ_BC(dz, j), a0);  // slack columns
-                    zv[c].at(l) = i < r ? a0 + a1 : 0.0;
-                }
-            });
-            RegD s_d2, s_all;
-            w.each([&](int l) {
-                double a2 = 0, aa = 0;
-#pragma unroll
-                for (int c = 0; c < RC; c++) {
-                    const int j = l + 64 * c;
-                    const double t = dv[c].at(l) * dv[c].at(l);  // dv is zero beyond r
-                    aa += t;
-                    a2 += j >= q ? t : 0.0;
-                }
-                s_d2.at(l) = a2;
-                s_all.at(l) = aa;
-            });
-            double dd2, dall;
-            w.sum2(s_d2, s_all, dd2, dall);
-            w.stamp(5);  // z, |d2|^2, |d|^2
-            // rv = R^{-1} d1 = S d1: lane i accumulates row i of S; no dependence between lanes
-            {
-                RegD dm[RC];
-                w.each([&](int l) {
-#pragma unroll
-                    for (int c = 0; c < RC; c++) dm[c].at(l) = (l + 64 * c < q) ? dv[c].at(l) : 0.0;
-                });
+            // ---- g = A G a (lane i: a_i' G a, nine table entries at most), d1 = S' g, rv = S d1 = (A G A')^-1 g --------
+            // (nothing to do while no row is active: rv keeps its zeros)
+            if (q > 0) {  // uniform
+                RegD gv[RC], d1[RC];
                 w.each([&](int l) {
 #pragma unroll
                     for (int c = 0; c < RC; c++) {
                         const int i = l + 64 * c;
-                        double a0 = 0.0, a1 = 0.0;
-                        int k = 0;
-                        for (; k + 1 < q; k += 2) {  // S(i,k) = 0 below the diagonal (packed storage: mask it)
-                            const double s0 = DQ_RP(i <= k ? i : 0, k), s1 = DQ_RP(i <= k + 1 ? i : 0, k + 1);
-                            a0 = fma(i <= k ? s0 : 0.0, DQ_BC(dm, k), a0);
-                            a1 = fma(i <= k + 1 ? s1 : 0.0, DQ_BC(dm, k + 1), a1);
+                        const uint32_t pk = a_pk[c].at(l);
+                        const int p0 = pk & 0xFF, p1 = (pk >> 8) & 0xFF, p2 = (pk >> 16) & 0xFF;
+                        const int ka = (pk >> 24) & 3;
+                        const bool line = (pk >> 26) & 1;
+                        const double c0 = (double)a_cf[c][0].at(l), c1 = (double)a_cf[c][1].at(l), c2 = (double)a_cf[c][2].at(l);
+                        double s;
+                        if (!new_line) {  // uniform
+                            // the new row touches one control point: one table entry per point of this lane's row
+                            double g0 = G[p0 * ldg + np0], g1 = G[p1 * ldg + np0], g2 = G[p2 * ldg + np0];
+                            DQ_KEEP(g0); DQ_KEEP(g1); DQ_KEEP(g2);
+                            const double s_point = (c0 * ncf[0] + c1 * ncf[1] + c2 * ncf[2]) * g0;
+                            const double s_line = pick3(ncf, ka) * (c0 * g0 + c1 * g1 + c2 * g2);
+                            s = line ? s_line : s_point;
+                        } else {
+                            double ga[3][3];
+                            ga[0][0] = G[p0 * ldg + np0]; ga[0][1] = G[p0 * ldg + np1]; ga[0][2] = G[p0 * ldg + np2];
+                            ga[1][0] = G[p1 * ldg + np0]; ga[1][1] = G[p1 * ldg + np1]; ga[1][2] = G[p1 * ldg + np2];
+                            ga[2][0] = G[p2 * ldg + np0]; ga[2][1] = G[p2 * ldg + np1]; ga[2][2] = G[p2 * ldg + np2];
+#pragma unroll
+                            for (int t = 0; t < 3; t++) { DQ_KEEP(ga[t][0]); DQ_KEEP(ga[t][1]); DQ_KEEP(ga[t][2]); }
+                            const double r0 = ncf[0] * ga[0][0] + ncf[1] * ga[0][1] + ncf[2] * ga[0][2];
+                            const double r1 = ncf[0] * ga[1][0] + ncf[1] * ga[1][1] + ncf[2] * ga[1][2];
+                            const double r2 = ncf[0] * ga[2][0] + ncf[1] * ga[2][1] + ncf[2] * ga[2][2];
+                            const double cax[3] = {c0, c1, c2};
+                            const double s_point = pick3(cax, new_axis) * r0;
+                            double s_all = c0 * r0 + c1 * r1 + c2 * r2;
+                            DQ_KEEP(s_all);  // a select, not a branch around the arithmetic
+                            const double s_line = ka == new_axis ? s_all : 0.0;
+                            s = line ? s_line : s_point;
                         }
-                        if (k < q) {
-                            const double s0 = DQ_RP(i <= k ? i : 0, k);
-                            a0 = fma(i <= k ? s0 : 0.0, DQ_BC(dm, k), a0);
+                        s += (sidx_row >= 0 && a_sl[c].at(l) == sidx_row) ? sig2_row : 0.0;
+                        gv[c].at(l) = i < q ? s : 0.0;
+                    }
+                });
+                w.stamp(4);  // g
+                // Both products walk the active rows in blocks of QB with every LDS read of a block issued before its first
+                // use: a trip costs one LDS round trip, not QB of them.  Entries beyond the active rows meet a zero of gv / d1.
+                w.each([&](int l) {  // d1 = S' g: lane k walks column k of the packed triangle
+#pragma unroll
+                    for (int c = 0; c < RC; c++) {
+                        const int k = l + 64 * c;
+                        const int kc = k < q ? k : 0;
+                        const int col = kc * (kc + 1) / 2;
+                        double a0 = 0.0, a1 = 0.0;
+                        for (int i0 = 0; i0 < q; i0 += QB) {  // S(i,k) = 0 below the diagonal: those reads go to the zero slot
+                            double sv[QB];
+#pragma unroll
+                            for (int u = 0; u < QB; u++) sv[u] = Rp[blend_idx(i0 + u <= kc, col + i0 + u, ozero_rp)];
+#pragma unroll
+                            for (int u = 0; u < QB; u++) DQ_KEEP(sv[u]);
+#pragma unroll
+                            for (int u = 0; u < QB; u += 2) {
+                                a0 = fma(sv[u], DQ_BC(gv, i0 + u), a0);
+                                a1 = fma(sv[u + 1], DQ_BC(gv, i0 + u + 1), a1);
+                            }
+                        }
+                        d1[c].at(l) = k < q ? a0 + a1 : 0.0;
+                    }
+                });
+                w.each([&](int l) {  // rv = S d1: lane i accumulates row i of S; no dependence between lanes
+#pragma unroll
+                    for (int c = 0; c < RC; c++) {
+                        const int i = l + 64 * c;
+                        double a0 = 0.0, a1 = 0.0;
+                        for (int k0 = 0; k0 < q; k0 += QB) {
+                            double sv[QB];
+#pragma unroll
+                            for (int u = 0; u < QB; u++) {
+                                const int k = k0 + u < q ? k0 + u : q - 1;  // uniform: a column that exists
+                                sv[u] = Rp[blend_idx(i <= k, k * (k + 1) / 2 + i, ozero_rp)];
+                            }
+#pragma unroll
+                            for (int u = 0; u < QB; u++) DQ_KEEP(sv[u]);
+#pragma unroll
+                            for (int u = 0; u < QB; u += 2) {
+                                a0 = fma(sv[u], DQ_BC(d1, k0 + u), a0);
+                                a1 = fma(sv[u + 1], DQ_BC(d1, k0 + u + 1), a1);
+                            }
                         }
                         rv[c].at(l) = a0 + a1;
                     }
                 });
+                w.stamp(5);  // two triangular products
             }
-            w.stamp(6);  // back substitution
-            // step lengths: t1 = min u_k / r_k over r_k > 0 (dual), t2 = viol / |d2|^2 (primal)
+            // ---- step direction in control-point space: dx = G (a - A' rv) ------------------------------------------
+            // lane p: row p of G against the sparse vector a - A' rv -- one table entry per POINT row, three per LINE row
+            RegD wc[RC][3], wcp[RC][3];  // -rv_i x coefficient; wcp: the same with zeros for LINE rows
+            RegI is_line[RC];
+            w.each([&](int l) {
+#pragma unroll
+                for (int c = 0; c < RC; c++) {
+                    const bool on = l + 64 * c < q;
+                    const bool line = (a_pk[c].at(l) >> 26) & 1;
+                    const double mr = on ? -rv[c].at(l) : 0.0;
+#pragma unroll
+                    for (int t = 0; t < 3; t++) {
+                        const double v = mr * (double)a_cf[c][t].at(l);
+                        wc[c][t].at(l) = v;
+                        wcp[c][t].at(l) = line ? 0.0 : v;
+                    }
+                    is_line[c].at(l) = (on & line) ? 1 : 0;
+                }
+            });
+            uint64_t line_rows[RC];
+#pragma unroll
+            for (int c = 0; c < RC; c++) line_rows[c] = w.ballot(is_line[c]);
+            // DXREG (static shapes without slack variables, P <= 64): lane p keeps dx of control point p in registers; the
+            // step is taken from there and dx goes to LDS only when |z|^2 has to be evaluated as a quadratic form (below)
+            RegD dkr[3];
+            w.each([&](int l) {
+                for (int pb = 0; pb < P; pb += 64) {  // uniform trip count
+                    const int p = pb + l;
+                    const bool in = p < P;
+                    const int pc = in ? p : P - 1;
+                    double dk[3];
+                    {
+                        double g0 = G[np0 * ldg + pc], g1 = G[np1 * ldg + pc], g2 = G[np2 * ldg + pc];
+                        DQ_KEEP(g0); DQ_KEEP(g1); DQ_KEEP(g2);
+                        const double sl = ncf[0] * g0 + ncf[1] * g1 + ncf[2] * g2;
+                        dk[0] = new_line ? (new_axis == 0 ? sl : 0.0) : ncf[0] * g0;
+                        dk[1] = new_line ? (new_axis == 1 ? sl : 0.0) : ncf[1] * g0;
+                        dk[2] = new_line ? (new_axis == 2 ? sl : 0.0) : ncf[2] * g0;
+                    }
+                    // POINT rows, in blocks of DB (its weights are wave-uniform: a block must fit the scalar registers) with the table reads of a block issued together (a LINE row, and what the last
+                    // block holds beyond the active rows, multiplies a valid table entry by zero)
+                    for (int i0 = 0; i0 < q; i0 += DB) {
+                        double gq[DB];
+#pragma unroll
+                        for (int u = 0; u < DB; u++) {
+                            const int i = i0 + u;
+                            const uint32_t pk = RC == 1 ? w.bcast(a_pk[0], i) : (i < 64 ? w.bcast(a_pk[0], i) : w.bcast(a_pk[RC - 1], i - 64));
+                            gq[u] = G[(int)(pk & 0xFF) * ldg + pc];
+                        }
+#pragma unroll
+                        for (int u = 0; u < DB; u++) DQ_KEEP(gq[u]);
+#pragma unroll
+                        for (int u = 0; u < DB; u++) {
+                            dk[0] = fma(DQ_BC2(wcp, 0, i0 + u), gq[u], dk[0]);
+                            dk[1] = fma(DQ_BC2(wcp, 1, i0 + u), gq[u], dk[1]);
+                            if (DIMS != 2) dk[2] = fma(DQ_BC2(wcp, 2, i0 + u), gq[u], dk[2]);
+                        }
+                    }
+                    // LINE rows: three table entries each, LB rows per trip with every read of the trip issued together (rows that
+                    // the last trip does not have get weight zero)
+#pragma unroll
+                    for (int c = 0; c < RC; c++) {
+                        constexpr int LB = 2;
+                        uint64_t todo = line_rows[c];
+                        while (todo) {  // uniform
+                            double gl[LB][3], wl[LB][3], ax[LB][3];
+#pragma unroll
+                            for (int u = 0; u < LB; u++) {
+                                const bool have = todo != 0;
+                                const int il = have ? ctz64(todo) : 0;
+                                todo &= todo - (have ? 1 : 0);
+                                const uint32_t pk = w.bcast(a_pk[c], il);
+                                const int ka = (pk >> 24) & 3;
+                                gl[u][0] = G[(int)(pk & 0xFF) * ldg + pc];
+                                gl[u][1] = G[(int)((pk >> 8) & 0xFF) * ldg + pc];
+                                gl[u][2] = G[(int)((pk >> 16) & 0xFF) * ldg + pc];
+#pragma unroll
+                                for (int t = 0; t < 3; t++) {
+                                    const double wv = w.bcast(wc[c][t], il);
+                                    wl[u][t] = have ? wv : 0.0;
+                                    ax[u][t] = ka == t ? 1.0 : 0.0;
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < LB; u++) { DQ_KEEP(gl[u][0]); DQ_KEEP(gl[u][1]); DQ_KEEP(gl[u][2]); }
+#pragma unroll
+                            for (int u = 0; u < LB; u++) {
+                                const double sl = wl[u][0] * gl[u][0] + wl[u][1] * gl[u][1] + wl[u][2] * gl[u][2];
+                                dk[0] = fma(ax[u][0], sl, dk[0]);
+                                dk[1] = fma(ax[u][1], sl, dk[1]);
+                                if (DIMS != 2) dk[2] = fma(ax[u][2], sl, dk[2]);
+                            }
+                        }
+                    }
+                    if (DXREG) {
+                        dkr[0].at(l) = in ? dk[0] : 0.0; dkr[1].at(l) = in ? dk[1] : 0.0; dkr[2].at(l) = (in && dim > 2) ? dk[2] : 0.0;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++)
+                            if (k < dim) base[blend_idx(in, oDx + k * P + p, odump + (l & 31))] = dk[k];  // uniform condition
+                    }
+                }
+                // slack variables: dx_s = sigma_s^2 (a_s - sum_i rv_i a_is), every slack coefficient is -1
+                for (int s0 = 0; s0 < nslk; s0 += 64) {  // uniform trip count
+                    const int s = s0 + l;
+                    double v = s == sidx_row ? -1.0 : 0.0;
+                    for (int i = 0; i < q; i++) {
+                        const int si = RC == 1 ? w.bcast(a_sl[0], i) : (i < 64 ? w.bcast(a_sl[0], i) : w.bcast(a_sl[RC - 1], i - 64));
+                        const double rvi = DQ_BC(rv, i);
+                        v += si == s ? rvi : 0.0;
+                    }
+                    const double sg = kp.sigma[(s < nslk ? s : 0) % M];
+                    base[blend_idx(s < nslk, oDx + nxc + s, odump + (l & 31))] = sg * sg * v;
+                }
+            });
+            w.sync();
+            // ---- |z|^2 = (a - A' rv)' G (a - A' rv) = a.dx - sum_i rv_i (a_i.dx): the squared length of the step in the whitened
+            // space, as a quadratic form (its error is quadratic in the error of rv: a dependent row gives ~1e-30, not ~1e-15)
+            auto z_squared = [&]() -> double {  // reads dx from LDS
+                double adx;
+                {
+                    const double x0 = dxl[(new_line ? new_axis : 0) * P + np0];
+                    const double x1 = dxl[(new_line ? new_axis : (dim > 1 ? 1 : 0)) * P + np1];
+                    const double x2 = dxl[(new_line ? new_axis : (dim > 2 ? 2 : 0)) * P + np2];
+                    const double xs = dxl[nxc + (sidx_row >= 0 ? sidx_row : 0)];
+                    double s = ncf[0] * x0 + ncf[1] * x1 + (new_line || dim > 2 ? ncf[2] * x2 : 0.0);
+                    s -= (SLK != 0 && sidx_row >= 0) ? xs : 0.0;
+                    adx = w.uni(s);
+                }
+                if (q == 0) return adx;  // uniform
+                RegD tr;
+                w.each([&](int l) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int c = 0; c < RC; c++) {
+                        const uint32_t pk = a_pk[c].at(l);
+                        const int ka = (pk >> 24) & 3;
+                        const bool line = (pk >> 26) & 1;
+                        const int sl = a_sl[c].at(l);
+                        double x0 = dxl[(line ? ka : 0) * P + (int)(pk & 0xFF)];
+                        double x1 = dxl[(line ? ka : (dim > 1 ? 1 : 0)) * P + (int)((pk >> 8) & 0xFF)];
+                        double x2 = dxl[(line ? ka : (dim > 2 ? 2 : 0)) * P + (int)((pk >> 16) & 0xFF)];
+                        double xs = SLK != 0 ? dxl[nxc + (sl >= 0 ? sl : 0)] : 0.0;
+                        DQ_KEEP(x0); DQ_KEEP(x1); DQ_KEEP(x2); DQ_KEEP(xs);
+                        // wc = -rv c (zero beyond the active rows); POINT rows in 2-D carry a zero third coefficient
+                        double s = wc[c][0].at(l) * x0 + wc[c][1].at(l) * x1 + wc[c][2].at(l) * x2;
+                        s += (SLK != 0 && sl >= 0 && l + 64 * c < q) ? rv[c].at(l) * xs : 0.0;
+                        acc += s;
+                    }
+                    tr.at(l) = acc;
+                });
+                return adx + w.sum(tr);
+            };
+            double dd2;
+            if (DXREG) {
+                // a.dx from the registers: the rate at which the step moves the row it is taken for.  Equal to |z|^2 up to the
+                // rounding of rv (~1e-16 x the conditioning of the active rows, relative to |N'a|^2); only a row that looks
+                // nearly dependent that way is measured again as the quadratic form
+                const int ax0 = new_line ? new_axis : 0, ax1 = new_line ? new_axis : 1, ax2 = new_line ? new_axis : 2;
+                const double e00 = w.bcast(dkr[0], np0), e01 = w.bcast(dkr[1], np0), e02 = w.bcast(dkr[2], np0);
+                const double e10 = w.bcast(dkr[0], np1), e11 = w.bcast(dkr[1], np1), e12 = w.bcast(dkr[2], np1);
+                const double e20 = w.bcast(dkr[0], np2), e21 = w.bcast(dkr[1], np2), e22 = w.bcast(dkr[2], np2);
+                const double y0 = ax0 == 0 ? e00 : (ax0 == 1 ? e01 : e02);
+                const double y1 = ax1 == 0 ? e10 : (ax1 == 1 ? e11 : e12);
+                const double y2 = ax2 == 0 ? e20 : (ax2 == 1 ? e21 : e22);
+                dd2 = ncf[0] * y0 + ncf[1] * y1 + ncf[2] * y2;
+                if (q > 0 && !(dd2 > 1e-6 * dall)) {  // uniform, rare
+                    w.each([&](int l) {
+#pragma unroll
+                        for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++)
+                            base[blend_idx(l < P, oDx + k * P + l, odump + (l & 31))] = dkr[k].at(l);
+                    });
+                    w.sync();
+                    dd2 = z_squared();
+                }
+            } else {
+                dd2 = z_squared();
+            }
+            w.stamp(6);  // step direction, its whitened length
+            // step lengths: t1 = min u_k / r_k over r_k > 0 (dual), t2 = viol / |z|^2 (primal)
             double t1 = 1e300;
             int ldrop = -1;
-            if (q > 0) {
+            RegI rpos;
+            w.each([&](int l) {
+                bool any_pos = false;
+#pragma unroll
+                for (int c = 0; c < RC; c++) any_pos |= (l + 64 * c < q) & (rv[c].at(l) > 0);
+                rpos.at(l) = any_pos ? 1 : 0;
+            });
+            if (q > 0 && w.any(rpos)) {  // uniform: without a positive entry of rv no dual step is blocked
                 RegD lt1;
                 RegI lk;
                 w.each([&](int l) {
@@ -1409,14 +1639,15 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     ldrop = w.bcast(lk, w.first_lane(is_min));
                 }
             }
-            const bool dependent = !(dd2 > DEP_TOL * dall) || !(dd2 > 0);
+            // q == r: the active rows span the whitened space, every further row depends on them
+            const bool dependent = !(dd2 > DEP_TOL * dall) || !(dd2 > 0) || q >= r;
             const double t2 = dependent ? 1e300 : viol / dd2;
             DQ_TRACE(2, dd2, dall, t1, (double)ldrop);
             w.stamp(7);  // ratio test
             if (t1 >= 1e300 && t2 >= 1e300) {
                 // no step possible: infeasible, unless within CPLEX's feasibility tolerance
                 if (viol * row_scale <= CPLEX_FEAS_TOL) {
-                    set_skip(ip, true);
+                    set_skip(ip, true, 0.0);
                     resolved = true;
                     break;
                 }
@@ -1425,67 +1656,44 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             }
             const double t = t1 < t2 ? t1 : t2;
             if (!dependent) {
-                // primal step  x += t N z  (a row of N is read once and used for every axis)
+                // primal step  x += t dx
                 w.each([&](int l) {
-                    for (int p0 = 0; p0 < P; p0 += 64) {  // uniform trip count
-                        const int p = p0 + l;
-                        const bool in = p < P;
-                        const int pc = in ? p : P - 1;
-                        double sk[3] = {0.0, 0.0, 0.0};
-#if DQ_STAGE_S
-                        if (NREG) {  // row p of N_T is in this lane's registers (p = lane: P <= 64)
+                    constexpr int NXC = DIMS > 0 && SLK == 0 ? (DIMS * MS * 6 + 63) / 64 : 1;
+                    const int nx = nxc + nslk;
+                    if (DXREG) {
+                        const int pc = l < P ? l : P - 1;
+                        double xo[3];
 #pragma unroll
-                            for (int u = 0; u < (NREG ? FB : 1); u++)
+                        for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++) xo[k] = x[k * P + pc];
 #pragma unroll
-                                for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++)
-                                    if (k < dim) sk[k] = fma(nrow[NREG ? u : 0].at(l), DQ_BC(zv, k * f + u), sk[k]);
-                        } else
-                        for (int c0 = 0; c0 < f; c0 += FB) {
-                            const int nvb = f - c0 < FB ? f - c0 : FB;  // uniform; == FB for static shapes
-                            double tn[FB];
-#pragma unroll
-                            for (int u = 0; u < FB; u++) tn[u] = Nl[pc * f + c0 + (u < nvb ? u : 0)];
-#pragma unroll
-                            for (int u = 0; u < FB; u++) DQ_KEEP(tn[u]);
-#pragma unroll
-                            for (int u = 0; u < FB; u++) {
-                                if (u < nvb) {  // uniform
-#pragma unroll
-                                    for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++)
-                                        if (k < dim) sk[k] = fma(tn[u], DQ_BC(zv, k * f + c0 + u), sk[k]);
-                                }
-                            }
-                        }
-#else
-#pragma unroll
-                        for (int c = 0; c < f; c++) {
-                            const double nv = Nl[pc * f + c];
-#pragma unroll
-                            for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++)
-                                if (k < dim) sk[k] = fma(nv, DQ_BC(zv, k * f + c), sk[k]);
-                        }
-#endif
-
+                        for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++) DQ_KEEP(xo[k]);
 #pragma unroll
                         for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++)
-                            if (k < dim) {  // uniform
-                                const double xn = fma(t, sk[k], x[k * P + pc]);
-                                base[blend_idx(in, oX + k * P + p, odump + (l & 31))] = xn;
-                            }
+                            base[blend_idx(l < P, oX + k * P + l, odump + (l & 31))] = fma(t, dkr[k].at(l), xo[k]);
+                    } else if (DIMS > 0 && SLK == 0) {
+                        double xo[NXC], dv[NXC];
+#pragma unroll
+                        for (int u = 0; u < NXC; u++) {
+                            const int j = 64 * u + l;
+                            const int jc = j < nx ? j : nx - 1;
+                            xo[u] = x[jc]; dv[u] = dxl[jc];
+                        }
+#pragma unroll
+                        for (int u = 0; u < NXC; u++) { DQ_KEEP(xo[u]); DQ_KEEP(dv[u]); }
+#pragma unroll
+                        for (int u = 0; u < NXC; u++) {
+                            const int j = 64 * u + l;
+                            base[blend_idx(j < nx, oX + j, odump + (l & 31))] = fma(t, dv[u], xo[u]);
+                        }
+                    } else {
+                        for (int j0 = 0; j0 < nx; j0 += 64) {  // uniform trip count
+                            const int j = j0 + l;
+                            const int jc = j < nx ? j : nx - 1;
+                            const double xn = fma(t, dxl[jc], x[jc]);
+                            base[blend_idx(j < nx, oX + j, odump + (l & 31))] = xn;
+                        }
                     }
                 });
-                if (nslk > 0) {  // uniform
-                    w.each([&](int l) {
-#pragma unroll
-                        for (int c = 0; c < RC; c++) {
-                            const int e = l + 64 * c;
-                            const bool in = e >= rc && e < r;
-                            const int s = in ? e - rc : 0;
-                            const double xn = fma(t * kp.sigma[s % M], zv[c].at(l), x[nxc + s]);
-                            base[blend_idx(in, oX + nxc + s, odump + (l & 31))] = xn;
-                        }
-                    });
-                }
                 viol -= t * dd2;
             }
             w.each([&](int l) {
@@ -1499,50 +1707,36 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             w.sync();
             w.stamp(8);  // primal / dual step
             if (!dependent && t2 <= t1) {
-                // ---- add row ip: Householder reflection of d2 onto e_1 ---------------------------
-                const double dq = DQ_BC(dv, q);
-                const double nrm = sqrt(dd2);
-                const double alpha = dq > 0 ? -nrm : nrm;
-                const double v0 = dq - alpha;
-                const double beta = 1.0 / (nrm * (nrm + fabs(dq)));  // 2 / v'v
-                const double inv_alpha = 1.0 / alpha;
-                // Householder vector v = (0,..,0, d_q - alpha, d_{q+1}, ..) as a register; Q <- Q H is applied by
-                // apply_pending_q() when Q is read next
-                w.each([&](int l) {
-#pragma unroll
-                    for (int c = 0; c < RC; c++) {
-                        const int j = l + 64 * c;
-                        q_pend_v[c].at(l) = j > q ? dv[c].at(l) : (j == q ? v0 : 0.0);
-                        q_pend_z[c].at(l) = zv[c].at(l);
-                    }
-                });
-                q_pending = true;
-                q_pend_col = q;
-                q_pend_alpha = alpha;
-                q_pend_beta = beta;
+                // ---- add row ip: R gains the column (d1; alpha), alpha = |z|  <=>  S = R^-1 gains (-S d1 / alpha; 1 / alpha) ----
+                const double inv_alpha = 1.0 / sqrt(dd2);
                 w.each([&](int l) {
 #pragma unroll
                     for (int c = 0; c < RC; c++) {
                         const int i = l + 64 * c;
-                        // R gains the column (d1; alpha)  <=>  S = R^-1 gains the column (-S d1 / alpha; 1 / alpha)
                         const double sv = i < q ? -rv[c].at(l) * inv_alpha : inv_alpha;
                         Rp[blend_idx(i <= q, q * (q + 1) / 2 + i, odump_rp + (l & 31))] = sv;
-                        uu[c].at(l) = i == q ? uq : uu[c].at(l);
-                        act[c].at(l) = i == q ? ip : act[c].at(l);
+                        const bool me = i == q;
+                        uu[c].at(l) = me ? uq : uu[c].at(l);
+                        act[c].at(l) = me ? ip : act[c].at(l);
+                        a_pk[c].at(l) = me ? pk_new : a_pk[c].at(l);
+                        a_sl[c].at(l) = me ? sidx_row : a_sl[c].at(l);
+                        a_rhs[c].at(l) = me ? row_rhs : a_rhs[c].at(l);
+#pragma unroll
+                        for (int t = 0; t < 3; t++) a_cf[c][t].at(l) = me ? (float)ncf[t] : a_cf[c][t].at(l);
                     }
                 });
-                set_skip(ip, true);
+                set_skip(ip, true, 0.0);
                 q++;
                 n_add++;
                 resolved = true;
-                w.stamp(9);  // Householder add
+                w.stamp(9);  // add
             } else {
                 // ---- drop active row ldrop: delete column l of R, restore the triangle with Givens ----
                 const int lcol = ldrop;
-                set_skip(DQ_BC(act, lcol), false);
+                set_skip(DQ_BCI(act, lcol), false, DQ_BC(a_rhs, lcol));
                 // Deleting column lcol of R: the rotations G of columns (t, t+1), t = lcol..q-2, that restore the
                 // triangle are those that sweep row lcol of S into its last entry; S' = (S without row lcol) G'
-                // without its last column, Q' = Q G'.  All angles come from one prefix sum of squares.
+                // without its last column.  All angles come from one prefix sum of squares.
                 RegD srow[RC], pre[RC], gc[RC], gs[RC];
                 w.each([&](int l) {
 #pragma unroll
@@ -1577,14 +1771,13 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                         }
                     });
                 }
-                RegD yS[RC], yQ[RC];
+                RegD yS[RC];
                 w.each([&](int l) {
 #pragma unroll
                     for (int c = 0; c < RC; c++) {
                         const int i = l + 64 * c;
-                        const double s0 = DQ_RP(i <= lcol ? i : 0, lcol), q0 = Q[(i < r ? i : qdummy) * ldq + lcol];
+                        const double s0 = DQ_RP(i <= lcol ? i : 0, lcol);
                         yS[c].at(l) = i <= lcol ? s0 : 0.0;
-                        yQ[c].at(l) = q0;
                     }
                 });
                 for (int t = lcol; t < q - 1; t++) {
@@ -1600,30 +1793,33 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                             yS[c].at(l) = sn * yS[c].at(l) + cs * cS;
                             const int inew = i < lcol ? i : i - 1;
                             Rp[blend_idx((i != lcol) & (inew <= t), t * (t + 1) / 2 + inew, odump_rp + (l & 31))] = oS;
-                            double *qi = Q + (i < r ? i : qdummy) * ldq;
-                            const double cQ = qi[t + 1];
-                            qi[t] = cs * yQ[c].at(l) - sn * cQ;
-                            yQ[c].at(l) = sn * yQ[c].at(l) + cs * cQ;
                         }
                     });
                     w.sync();
                 }
-                w.each([&](int l) {
-#pragma unroll
-                    for (int c = 0; c < RC; c++) {
-                        const int i = l + 64 * c;
-                        Q[(i < r ? i : qdummy) * ldq + q - 1] = yQ[c].at(l);
-                    }
-                });
-                w.sync();
-                // compact the per-lane duals and the active list: element k takes element k+1, k >= lcol
+                // compact the per-lane state of the active rows: element k takes element k+1, k >= lcol
                 {
-                    RegD nu[RC];
-                    RegI nact[RC];
+                    RegD nu[RC], nrh[RC];
+                    RegI nact[RC], nsl[RC];
+                    RegU npk[RC];
+                    RegF ncfr[RC][3];
 #pragma unroll
                     for (int c = 0; c < RC; c++) {
                         w.shift_down(uu, c, RC, nu[c]);
+                        w.shift_down(a_rhs, c, RC, nrh[c]);
                         w.shift_down(act, c, RC, nact[c]);
+                        w.shift_down(a_sl, c, RC, nsl[c]);
+                        w.shift_down(a_pk, c, RC, npk[c]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 3; t++) {
+                        RegF col[RC];
+                        w.each([&](int l) {
+#pragma unroll
+                            for (int c = 0; c < RC; c++) col[c].at(l) = a_cf[c][t].at(l);
+                        });
+#pragma unroll
+                        for (int c = 0; c < RC; c++) w.shift_down(col, c, RC, ncfr[c][t]);
                     }
                     w.each([&](int l) {
 #pragma unroll
@@ -1631,7 +1827,12 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                             const int k = l + 64 * c;
                             const bool mv = k >= lcol && k < q - 1;
                             uu[c].at(l) = mv ? nu[c].at(l) : uu[c].at(l);
+                            a_rhs[c].at(l) = mv ? nrh[c].at(l) : a_rhs[c].at(l);
                             act[c].at(l) = mv ? nact[c].at(l) : act[c].at(l);
+                            a_sl[c].at(l) = mv ? nsl[c].at(l) : a_sl[c].at(l);
+                            a_pk[c].at(l) = mv ? npk[c].at(l) : a_pk[c].at(l);
+#pragma unroll
+                            for (int t = 0; t < 3; t++) a_cf[c][t].at(l) = mv ? ncfr[c][t].at(l) : a_cf[c][t].at(l);
                         }
                     });
                 }
@@ -1688,5 +1889,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 
 #undef DQ_RP
 #undef DQ_BC
+#undef DQ_BCI
+#undef DQ_BC2
 
 }  // namespace dlscqp

@@ -7,8 +7,9 @@
 //   * per-axis equality block E c = S [pos vel acc]'  (traj_optimizer.cpp:333-381, 515-524)
 //     -> orthonormal null-space basis Z and minimum-norm particular-solution map Xp (Householder QR)
 //   * for every possible number of terminal segments T = 1..M (traj_optimizer.cpp:301-315, 543-551):
-//     reduced Hessian Z'HZ = L L', whitening map N_T = Z L^{-T}, and the unconstrained minimiser
-//     as a linear map of (pos, vel, acc, goal): x0 = X0s_T s + X0g_T goal
+//     reduced Hessian Z'HZ = L L', whitening map N_T = Z L^{-T}, its Gram table G_T = N_T N_T'
+//     (= Z (Z'HZ)^-1 Z', the inverse Hessian on the null space of the equalities: what the kernel reads),
+//     and the unconstrained minimiser as a linear map of (pos, vel, acc, goal): x0 = X0s_T s + X0g_T goal
 //   * the table of structured two-sided rows shared by all agents (bounds/SFC faces, dynamic
 //     limits, communication range).
 #include "qp_tables.hpp"
@@ -329,6 +330,7 @@ bool build_tables(const dlscqp_config &cfg, int dim, int M, int n, int phi, doub
                     k * P + m * N + i + 1, -2, k * P + m * N + i, 1);
             }
         }
+    kp.n_struct = (int)out.slots.size();
     if (kp.has_comm) {  // :490-513
         for (int k = 0; k < dim; k++)
             for (int mi = 0; mi < M; mi++)
@@ -341,13 +343,44 @@ bool build_tables(const dlscqp_config &cfg, int dim, int M, int n, int phi, doub
     // (steepest dual ascent); this roughly halves the active-set iterations of the hard agents
     out.tabNN.assign((size_t)M * P, 0.0);
     out.tabSIW.assign((size_t)M * kp.n_slots, 0.0);
+    // Gram tables G_T = N_T N_T' (P x P, row stride P | 1): all the kernel needs of the whitened space -- a row of the model
+    // touches at most three control points, so a_i' G a_j is a handful of entries and G (a - A' r) a handful of rows
+    const int ldg = P | 1;
+    out.tabG.assign((size_t)M * P * ldg, 0.0);
+    out.tabKIW.assign((size_t)M * 3 * P, 0.0);
     for (int T = 1; T <= M; T++) {
         if (!kp.t_valid[T - 1]) continue;
         const double *oN = &out.tabN[(size_t)(T - 1) * P * f];
+        double *oG = &out.tabG[(size_t)(T - 1) * P * ldg];
+        for (int p = 0; p < P; p++)
+            for (int p2 = 0; p2 <= p; p2++) {
+                double t = 0;
+                for (int a = 0; a < f; a++) t += oN[(size_t)p * f + a] * oN[(size_t)p2 * f + a];
+                oG[(size_t)p * ldg + p2] = oG[(size_t)p2 * ldg + p] = t;  // exactly symmetric
+            }
         for (int p = 0; p < P; p++) {
             double t = 0;
             for (int a = 0; a < f; a++) t += oN[(size_t)p * f + a] * oN[(size_t)p * f + a];
             out.tabNN[(size_t)(T - 1) * P + p] = t;
+        }
+        // the same scalings by kind and first control point (they do not depend on the axis): what the static-shape kernels
+        // read instead of the slot table
+        double *oK = &out.tabKIW[(size_t)(T - 1) * 3 * P];
+        for (int p = 0; p < P; p++) {
+            const double *g = oG;
+            auto at = [&](int a, int b) { return (a < P && b < P) ? g[(size_t)a * ldg + b] : 0.0; };
+            const double wb = at(p, p);
+            const double wv = at(p + 1, p + 1) - 2.0 * at(p + 1, p) + at(p, p);
+            const double c[3] = {1.0, -2.0, 1.0};
+            double wa = 0;
+            for (int a = 0; a < 3; a++)
+                for (int b = 0; b < 3; b++) wa += c[a] * c[b] * at(p + a, p + b);
+            oK[p] = wb > 0 ? 1.0 / std::sqrt(wb) : 0.0;
+            // rows that do not exist (they would reach into the next segment) get scaling 0: across a joint the difference
+            // of two control points is pinned by the continuity rows, its whitened length is ~0 and 1 / it would overflow
+            const int i = p % N;
+            oK[P + p] = (i < n && wv > 0) ? 1.0 / std::sqrt(wv) : 0.0;
+            oK[2 * P + p] = (i < n - 1 && wa > 0) ? 1.0 / std::sqrt(wa) : 0.0;
         }
         for (int si = 0; si < kp.n_slots; si++) {
             const Slot &sl = out.slots[si];
@@ -362,6 +395,8 @@ bool build_tables(const dlscqp_config &cfg, int dim, int M, int n, int phi, doub
         }
     }
     kp.max_iter = 0;  // 0: 20 (r + 8) + 200, chosen per agent in plan_agent
+    kp.dbg_exit_phase = -1;
+    if (const char *dbg = std::getenv("DLSCQP_DEBUG_EXIT_PHASE")) kp.dbg_exit_phase = std::atoi(dbg);  // read by -DDQ_PHASE_PROFILE builds only
     if (const char *dbg = std::getenv("DLSCQP_DEBUG_MAX_ITER")) kp.max_iter = std::atoi(dbg);  // debugging aid
     return true;
 }

@@ -10,11 +10,13 @@ namespace dlscqp {
 
 struct HostTables {
     KParams kp;                  // table pointers left null; the owner fills them in
-    std::vector<double> tabN;    // [M][P][f]
+    std::vector<double> tabN;    // [M][P][f]     whitening maps (host only: the kernel reads their Gram tables)
+    std::vector<double> tabG;    // [M][P][P|1]   G_T = N_T N_T'
     std::vector<double> tabX0s;  // [M][P][3]
     std::vector<double> tabX0g;  // [M][P]
     std::vector<double> tabNN;   // [M][P]
     std::vector<double> tabSIW;  // [M][n_slots]
+    std::vector<double> tabKIW;  // [M][3][P]
     std::vector<Slot> slots;
 };
 

@@ -27,9 +27,11 @@ struct KParams {
     // dimensions
     int dim, M, n1, P, f, phi;
     int n_slots;   // two-sided structured rows
+    int n_struct;  // the first n_struct of them are bounds, velocity and acceleration rows (static-shape kernels do not read those from the table)
     int nb;        // entries of the per-agent bound table
     int has_comm, use_sfc, stop_mode, rsfc_mode;
     int max_iter;
+    int dbg_exit_phase;  // profiling builds only (gi_core.hpp: DQ_PHASE_EXIT), else -1
     int wd_cut;    // the weak-duality infeasibility test of gi_core.hpp is valid (its objective bound assumes phi_n = 1)
     // weights and constants (param.hpp)
     double dt;
@@ -42,11 +44,12 @@ struct KParams {
     double sigma[32];             // slack whitening 1/sqrt(2 w_s (M-m)/M), m < M <= 32
     int t_valid[32];              // reduced Hessian positive definite for T = idx+1
     // device (or host, in the emulation build) tables
-    const double *tabN;           // [M][P][f]
+    const double *tabG;           // [M][P][P|1]   Gram table N_T N_T' of the whitening map (row stride odd, as it is copied to LDS)
     const double *tabX0s;         // [M][P][3]
     const double *tabX0g;         // [M][P]
     const double *tabNN;          // [M][P]        |N_T[p,:]|^2  (pivot scaling of LSC rows)
     const double *tabSIW;         // [M][n_slots]  1 / |N_T' a_slot|  (pivot scaling of structured rows)
+    const double *tabKIW;         // [M][3][P]     the same by kind and first control point: bound / velocity / acceleration row at p
     const Slot *slots;            // [n_slots]
 };
 
@@ -55,7 +58,7 @@ struct KParams {
 // a row that cannot be satisfied but is violated by no more than this is accepted, as CPLEX would.
 constexpr double VIOL_TOL = 1e-9;
 constexpr double CPLEX_FEAS_TOL = 1e-6;
-constexpr double DEP_TOL = 1e-20;  // ||d2||^2 <= DEP_TOL ||d||^2  -> normal depends on the active set
+constexpr double DEP_TOL = 1e-20;  // |z|^2 <= DEP_TOL |N'a|^2  -> the row's normal depends on the active rows'
 constexpr double SP_EPSILON = 1e-9;        // sp_const.hpp:3
 constexpr double SP_EPSILON_FLOAT = 1e-5;  // sp_const.hpp:4
 

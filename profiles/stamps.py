@@ -17,8 +17,8 @@ sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "dlsc_gc_planner_amd", "csrc")
 LIB = os.environ.get("DLSCQP_STAMPS_LIB", os.path.join(CSRC, "libdlscqp_stamps.so"))
 
-PHASES = ["agent+goalLP", "init(LDS tables,Q=I)", "scan+argmax", "decode+normal", "d=Q'na", "z,|d2|,|d|",
-          "backsub", "ratio test", "primal/dual step", "householder add", "givens drop", "readout"]
+PHASES = ["agent+goalLP", "init(x0,bounds,G->LDS)", "scan+argmax", "decode,|N'a|^2", "g=AGa", "d1=S'g,rv=S d1",
+          "dx=G(a-A'rv),|z|^2", "ratio test", "primal/dual step", "add row", "givens drop", "readout"]
 
 
 def main():

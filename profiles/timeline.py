@@ -57,6 +57,14 @@ def main():
     n_slots = len(np.unique(place))
     print("agents %d, launch span %.1f us, wave slots used %d, mean solve %.2f us, sum of solves / (slots x span) = %.3f"
           % (N, span, n_slots, dur.mean(), dur.sum() / (n_slots * span)))
+    res = db.results()["iters"]
+    for a in np.argsort(-dur)[:6]:
+        print("  agent %6d: %6.1f us from %6.1f us after launch start, %2d iterations (%d adds, %d drops, %d active at exit)" %
+              (a, dur[a], (t0[a] - t0.min()) * tick, res[a, 0], res[a, 1], res[a, 2], res[a, 3]))
+    for lo, hi in ((0, 0), (1, 3), (4, 9), (10, 19), (20, 99)):
+        m = (res[:, 0] >= lo) & (res[:, 0] <= hi)
+        if m.any():
+            print("  %2d-%2d iterations: %5d agents, mean solve %6.1f us, %4.1f %% of the slot time" % (lo, hi, m.sum(), dur[m].mean(), 100 * dur[m].sum() / dur.sum()))
     gaps, first, last = [], [], []
     for p in np.unique(place):
         sel = np.where(place == p)[0]

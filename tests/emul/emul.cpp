@@ -57,6 +57,7 @@ struct WaveCpu {
         for (int l = 1; l < 64; l++) s = r.v[l] > s ? r.v[l] : s;
         return s;
     }
+    double max_pos(const Reg<double> &r) const { return max(r); }  // the GPU's shortcut for values >= +0
     double min(const Reg<double> &r) const {
         double s = r.v[0];
         for (int l = 1; l < 64; l++) s = r.v[l] < s ? r.v[l] : s;
@@ -65,6 +66,17 @@ struct WaveCpu {
     void sum2(const Reg<double> &a, const Reg<double> &b, double &sa, double &sb) const {
         sa = 0; sb = 0;
         for (int l = 0; l < 64; l++) { sa += a.v[l]; sb += b.v[l]; }
+    }
+    double sum(const Reg<double> &a) const {
+        double sa = 0;
+        for (int l = 0; l < 64; l++) sa += a.v[l];
+        return sa;
+    }
+    double uni(double v) const { return v; }  // a value every lane computed identically
+    uint64_t ballot(const Reg<int> &r) const {
+        uint64_t m = 0;
+        for (int l = 0; l < 64; l++) if (r.v[l]) m |= 1ull << l;
+        return m;
     }
     bool any(const Reg<int> &r) const {
         for (int l = 0; l < 64; l++) if (r.v[l]) return true;
@@ -117,11 +129,12 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
     std::string err;
     if (!build_tables(*cfg, cfg->world_dimension, cfg->M, cfg->n, cfg->phi, cfg->dt, tb, err)) return -1;
     KParams kp = tb.kp;
-    kp.tabN = tb.tabN.data();
+    kp.tabG = tb.tabG.data();
     kp.tabX0s = tb.tabX0s.data();
     kp.tabX0g = tb.tabX0g.data();
     kp.tabNN = tb.tabNN.data();
     kp.tabSIW = tb.tabSIW.data();
+    kp.tabKIW = tb.tabKIW.data();
     kp.slots = tb.slots.data();
     const int64_t nrows = row_offsets[n_agents];
     std::vector<float> nx(nrows), ny(nrows), nz(nrows), px(nrows), py(nrows), pz(nrows);
@@ -144,7 +157,7 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
     const int KUsel = ic.KU, SUsel = ic.SU;
     typedef void (*fn_t)(const WaveCpu &, const KParams &, const MemLayout &, unsigned char *, const dlscqp_agent *,
                          const RowsView &, int, int, const float *, int, int, int, float *, int *, float *, double *,
-                         double *, double *, int *, int *, double *);
+                         double *, double *, int *, int *);
     fn_t fn = nullptr;
     switch (ic.id) {
 #define DQ_CASE(ID, RC, DIMS, FS, MS, KU, SU, SLK) \
@@ -152,15 +165,7 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
         DQ_INSTANCES(DQ_CASE)
 #undef DQ_CASE
     }
-    MemLayout lay = make_layout(kp, max_slack_obs, kmax, KUsel, SUsel, instance_n_in_lds(ic.id));
-    // test hook: the variant of the two-register runtime-shape instantiation that keeps S = R^-1 outside the block
-    // (the GPU's WS_S_HBM kernel, dlscqp.hip)
-    std::vector<double> s_ext;
-    if (std::getenv("EMUL_S_EXT") && ic.id == 7) {
-        fn = plan_agent<2, 0, 0, 0, DQ_G2_KU, DQ_G2_SU, -1, WaveCpu, true>;
-        lay = make_layout(kp, max_slack_obs, kmax, KUsel, SUsel, true, false);
-        s_ext.resize(lay.s_ext_doubles);
-    }
+    MemLayout lay = make_layout(kp, max_slack_obs, kmax, KUsel, SUsel, ic.by_kind);
     std::vector<unsigned char> mem(lay.bytes + 64 + 4096);
     WaveCpu w;
     const char *rev = std::getenv("EMUL_REVERSE");
@@ -169,7 +174,6 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
     const size_t xs = (size_t)dim * M * n1 + (size_t)M * max_slack_obs;
     for (int a = 0; a < n_agents; a++) {
         std::memset(mem.data(), 0xCD, mem.size());  // poison: nothing may rely on zero-initialised LDS
-        if (!s_ext.empty()) std::memset(s_ext.data(), 0xCD, s_ext.size() * sizeof(double));
         fn(w, kp, lay, mem.data(), agents + a, rv, (int)row_offsets[a],
                    (int)(row_offsets[a + 1] - row_offsets[a]), sfc ? sfc + (size_t)a * M * 6 : nullptr,
                    max_slack_obs, do_goal, do_traj, out_goal ? out_goal + (size_t)a * 3 : nullptr,
@@ -177,8 +181,7 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
                    out_ctrl ? out_ctrl + (size_t)a * M * n1 * 3 : nullptr, out_x ? out_x + a * xs : nullptr,
                    out_cost ? out_cost + a : nullptr,
                    out_slack_cost ? out_slack_cost + (size_t)a * max_slack_obs : nullptr,
-                   out_status ? out_status + a : nullptr, out_iters ? out_iters + (size_t)a * 4 : nullptr,
-                   s_ext.empty() ? nullptr : s_ext.data());
+                   out_status ? out_status + a : nullptr, out_iters ? out_iters + (size_t)a * 4 : nullptr);
         g_last_lds = mem;
     }
     return 0;
@@ -211,7 +214,7 @@ extern "C" int emul_table_info(const dlscqp_config *cfg, int *f, int *n_slots, i
     *n_slots = tb.kp.n_slots;
     *nb = tb.kp.nb;
     const InstanceChoice ic = select_instance(tb.kp, max_slack_obs, kmax, false);
-    *lds_bytes = ic.id < 0 ? -1 : make_layout(tb.kp, max_slack_obs, kmax, ic.KU, ic.SU, instance_n_in_lds(ic.id)).bytes;
+    *lds_bytes = ic.id < 0 ? -1 : make_layout(tb.kp, max_slack_obs, kmax, ic.KU, ic.SU, ic.by_kind).bytes;
     return 0;
 }
 
@@ -364,8 +367,8 @@ extern "C" int emul_throughput(const dlscqp_config *cfg, int n_agents, const dls
     std::string err;
     if (!build_tables(*cfg, cfg->world_dimension, cfg->M, cfg->n, cfg->phi, cfg->dt, tb, err)) return -1;
     KParams kp = tb.kp;
-    kp.tabN = tb.tabN.data(); kp.tabX0s = tb.tabX0s.data(); kp.tabX0g = tb.tabX0g.data();
-    kp.tabNN = tb.tabNN.data(); kp.tabSIW = tb.tabSIW.data(); kp.slots = tb.slots.data();
+    kp.tabG = tb.tabG.data(); kp.tabX0s = tb.tabX0s.data(); kp.tabX0g = tb.tabX0g.data();
+    kp.tabNN = tb.tabNN.data(); kp.tabSIW = tb.tabSIW.data(); kp.tabKIW = tb.tabKIW.data(); kp.slots = tb.slots.data();
     const int64_t nrows = row_offsets[n_agents];
     std::vector<float> nx(nrows), ny(nrows), nz(nrows), px(nrows), py(nrows), pz(nrows);
     std::vector<double> d(nrows);
@@ -378,7 +381,7 @@ extern "C" int emul_throughput(const dlscqp_config *cfg, int n_agents, const dls
     if (ic.id < 0) return -2;
     typedef void (*fn_t)(const WaveCpu &, const KParams &, const MemLayout &, unsigned char *, const dlscqp_agent *,
                          const RowsView &, int, int, const float *, int, int, int, float *, int *, float *, double *,
-                         double *, double *, int *, int *, double *);
+                         double *, double *, int *, int *);
     fn_t fn = nullptr;
     switch (ic.id) {
 #define DQ_CASE(ID, RC, DIMS, FS, MS, KU, SU, SLK) \
@@ -386,7 +389,7 @@ extern "C" int emul_throughput(const dlscqp_config *cfg, int n_agents, const dls
         DQ_INSTANCES(DQ_CASE)
 #undef DQ_CASE
     }
-    const MemLayout lay = make_layout(kp, max_slack_obs, kmax, ic.KU, ic.SU, instance_n_in_lds(ic.id));
+    const MemLayout lay = make_layout(kp, max_slack_obs, kmax, ic.KU, ic.SU, ic.by_kind);
     const int M = cfg->M, n1 = cfg->n + 1;
     if (n_threads < 1) n_threads = 1;
     std::vector<int64_t> done(n_threads, 0);
@@ -406,7 +409,7 @@ extern "C" int emul_throughput(const dlscqp_config *cfg, int n_agents, const dls
         for (;;) {
             fn(w, kp, lay, mem.data(), agents + a, rv, (int)row_offsets[a], (int)(row_offsets[a + 1] - row_offsets[a]),
                sfc ? sfc + (size_t)a * M * 6 : nullptr, max_slack_obs, 1, 1, goal, &gst, ctrl.data(), nullptr, &cost,
-               max_slack_obs ? slack.data() : nullptr, &st, it, nullptr);
+               max_slack_obs ? slack.data() : nullptr, &st, it);
             done[t]++;
             if (++a == hi) a = lo;
             if ((done[t] & 15) == 0 &&

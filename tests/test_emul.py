@@ -53,20 +53,24 @@ def test_lane_loops_have_no_cross_lane_hazard():
 
 
 @pytest.mark.parametrize("name", ["forest3d_M10_dyn4", "forest3d_M10_dyn"])
-def test_s_outside_the_block_changes_nothing(name):
-    """The variant of the two-register runtime-shape instantiation that keeps S = R^-1 in a buffer of its own (the GPU runs
-    it with Q in LDS and S in HBM when both do not fit a CU: r > 110, e.g. the forest missions' r = 124): same bits."""
+def test_runtime_shape_instantiation_equals_the_static_one(name):
+    """The runtime-shape instantiation (layout and loop bounds from the arguments, every structured row from the slot table)
+    against the static-shape one that select_instance picks for the forest missions (bound / velocity / acceleration rows by
+    coordinate): same verdicts, the same optimum to rounding (the pivot scores carry different row codes in their low bits, so
+    the two may add the rows of a tie in another order)."""
     cfg, b, ans = fixtures.load(name)
     ref = E.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], b["sfc"], b["max_slack_obs"], True)
-    os.environ["EMUL_S_EXT"] = "1"
     os.environ["EMUL_GENERIC"] = "1"
     try:
         got = E.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], b["sfc"], b["max_slack_obs"], True)
     finally:
-        del os.environ["EMUL_S_EXT"], os.environ["EMUL_GENERIC"]
+        del os.environ["EMUL_GENERIC"]
     assert (ref["iters"][:, 0] > 3).sum() >= 3
-    for k in ("status", "goal_status", "goal", "x", "cost", "iters", "slack_cost"):
+    for k in ("status", "goal_status", "goal"):
         assert np.array_equal(ref[k], got[k]), k
+    ok = ref["status"] == 0
+    assert np.abs(ref["x"][ok] - got["x"][ok]).max() <= 1e-9
+    assert np.allclose(ref["cost"][ok], got["cost"][ok], rtol=1e-9, atol=1e-12)
     assert fixtures.check_against_golden(cfg, b, ans, got) >= 8
 
 

@@ -228,7 +228,7 @@ def test_forest_mission_with_spinning_obstacles(gpu_required):
                      waypoint_step=m["grid_resolution"], world=world,
                      dyn=spin.dyn(size_prediction=1, horizon=m["uncertainty_horizon"], duration=m["obs_duration"]))
     try:
-        assert sim.opt.lds_bytes(4, 2000) > 160 * 1024  # this shape is the HBM-working-set one
+        assert sim.opt.lds_bytes(4, 2000) <= 160 * 1024  # 124 active rows at most: S (62 KB) + Gram table (29 KB) fit the LDS of a CU
         sim.keep_inputs = True
         worst, wobs, wall, fails, done, checked, worst_err = 1e9, 1e9, 1e9, 0, None, 0, 0.0
         sfc_oracle = oracle_lib.SfcWorld(m["boxes"], m["world_resolution"], m["world"][:3], m["world"][3:], margin=m["radius"],
