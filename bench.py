@@ -145,6 +145,32 @@ def cpu_baseline(cfg, wl, seconds=12.0):
             "ref_published_note": "reference log: 11.18 ms/QP mean, CPLEX 22.1.1 Threads=6, 2-D M=10, unknown CPU"}
 
 
+def cpu_port_step_ms(cfg, inputs, seconds=1.0):
+    """The same replanning step on the host: the kernel's own algorithm (lane-serial -O3 build of csrc/gi_core.hpp,
+    tests/emul/libdlscqp_cpu.so) on the inputs the GPU step read (read back from HBM), one native thread per granted core
+    (never more threads than agents), each walking its own range of the agents.  Returns (ms for all agents once, threads)."""
+    import ctypes as C
+    import numpy as np
+    from dlsc_gc_planner_amd import abi
+    agents, ro, rows, sfc, D = inputs
+    agents = np.ascontiguousarray(agents)
+    ro = np.ascontiguousarray(ro, dtype=np.int64)
+    rows = np.ascontiguousarray(rows)
+    sfc = None if sfc is None else np.ascontiguousarray(sfc, dtype=np.float32)
+    N = len(agents)
+    nt = max(1, min(host_cores(), N))
+    L = C.CDLL(os.path.join(ROOT, "tests", "emul", "libdlscqp_cpu.so"))
+    vp = C.c_void_p
+    L.emul_throughput.argtypes = [C.POINTER(abi.Config), C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int64),
+                                  C.POINTER(C.c_double)]
+    n, el = C.c_int64(), C.c_double()
+    rc = L.emul_throughput(C.byref(cfg), N, agents.ctypes.data, ro.ctypes.data, rows.ctypes.data, None if sfc is None else sfc.ctypes.data,
+                           int(D), nt, float(seconds), C.byref(n), C.byref(el))
+    if rc != 0:
+        raise RuntimeError("emul_throughput failed (%d)" % rc)
+    return el.value / n.value * N * 1e3, nt
+
+
 def closed_loop_latency(device):
     """Wall time of one replanning step of four of the reference's missions flown by the device-resident closed loop
     (dlsc_gc_planner_amd/harness.py), synchronised after every step:
@@ -162,9 +188,17 @@ def closed_loop_latency(device):
     missions = json.load(open(os.path.join(g, "missions_empty.json")))
 
     def fly(sim, steps, graph_at=None, skip=5):
+        """Wall time per step (synchronised), then -- for the eager steps -- the stages in the reference's columns (HIP
+        events; host time of the waypoint planner) and the same step on the host (the kernel's algorithm, all granted cores,
+        the inputs of one mid-flight step read back from HBM)."""
         ts, fails = {"eager": [], "graph": []}, 0
+        sim.keep_inputs = True
+        sim.enable_stage_timers()
+        inputs = None
         for k in range(steps):
             if graph_at is not None and k == graph_at:
+                stages = sim.stage_times()
+                sim.enable_stage_timers(False)
                 sim.enable_graph()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -174,8 +208,23 @@ def closed_loop_latency(device):
             if (k - (graph_at or 0) if phase == "graph" else k) >= skip:
                 ts[phase].append((time.perf_counter() - t0) * 1e3)
             fails += int((status != abi.OK).sum())
+            if k == min(steps - 1, 30):
+                inputs = sim.step_inputs()
+        if graph_at is None:
+            stages = sim.stage_times()
+        extra = {"stage_p50_ms": {k2: float(np.percentile(v[skip:], 50)) for k2, v in stages.items() if len(v) > skip},
+                 "stage_names": "the reference's timers (sp_const.hpp:81-122, summary columns multi_sync_simulator.cpp:863-871): "
+                                "traj_optimization_time = goal LP + QP in one launch; mapf_time = host waypoint planner with its transfers"}
+        try:
+            ms, nt = cpu_port_step_ms(sim.cfg, inputs)
+            extra["cpu_port_ms"] = ms
+            extra["cpu_port_threads"] = nt
+            extra["cpu_port_note"] = "goal LP + QP of one mid-flight step on the host (lane-serial -O3 build of the kernel source), inputs read back from HBM"
+        except Exception as e:  # the checker library is optional for the bench line
+            extra["cpu_port_ms"] = None
+            extra["cpu_port_note"] = "unavailable: %s" % e
         sim.close()
-        return ts, fails
+        return ts, fails, extra
 
     for name in ("empty10_1", "empty60_1"):
         m = missions[name]
@@ -185,10 +234,11 @@ def closed_loop_latency(device):
         sim = ClosedLoop(cfg, np.array(m["start"], np.float32), np.array(m["goal"], np.float32), radius=m["radius"],
                          downwash=m["downwash"], max_vel=m["max_vel"], max_acc=m["max_acc"],
                          nominal_velocity=m["nominal_velocity"], device=device)
-        ts, fails = fly(sim, 110, graph_at=55)
+        ts, fails, extra = fly(sim, 110, graph_at=55)
         out[name] = {"agents": len(m["start"]), "lsc_rows_per_agent": (len(m["start"]) - 1) * 27, "steps": len(ts["eager"]),
                      "p50_ms": float(np.percentile(ts["eager"], 50)), "p99_ms": float(np.percentile(ts["eager"], 99)),
                      "p50_ms_as_one_hip_graph": float(np.percentile(ts["graph"], 50)), "qp_failsafes": fails}
+        out[name].update(extra)
     # the mission of the reference's log: 2-D, M = 10, corridors, communication range 3, the reference's waypoint planner
     w = json.load(open(os.path.join(g, "world_maze1.json")))
     cfg = abi.make_config(dim=2, M=10, dt=0.2, control_input_weight=0.01, terminal_weight=1.0, communication_range=3.0,
@@ -198,11 +248,16 @@ def closed_loop_latency(device):
     sim = ClosedLoop(cfg, np.array(w["start"], np.float32), np.array(w["goal"], np.float32), radius=w["radius"], downwash=2.0,
                      max_vel=w["max_vel"], max_acc=w["max_acc"], nominal_velocity=1.0, waypoint_step=w["grid_resolution"],
                      world=world, device=device)
-    ts, fails = fly(sim, 171)
+    ts, fails, extra = fly(sim, 171)
     out["maze10_dense_1"] = {"agents": 10, "steps": len(ts["eager"]), "p50_ms": float(np.percentile(ts["eager"], 50)),
                              "p99_ms": float(np.percentile(ts["eager"], 99)), "qp_failsafes": fails,
                              "includes": "host-side waypoint planner (PIBT) and the per-step neighbour lists",
-                             "reference_log_planning_time_ms_per_agent": 12.17}
+                             "reference_log_planning_time_ms_per_agent": 12.17,
+                             "reference_log_stage_ms_per_agent": {"lsc_generation_time": 0.145, "sfc_generation_time": 0.542,
+                                                                  "traj_optimization_time": 11.18,
+                                                                  "note": "log/summary_DLSCGC_10agents.csv: per agent and step, CPLEX 22.1.1, unknown CPU; the "
+                                                                          "figures above are per STEP of all ten agents"}}
+    out["maze10_dense_1"].update(extra)
     # BASELINE.json configs[3]
     f = json.load(open(os.path.join(g, "world_forest1.json")))
     cfg = abi.make_config(dim=f["dim"], M=f["M"], dt=f["dt"], control_input_weight=0.01, terminal_weight=1.0,
@@ -214,11 +269,68 @@ def closed_loop_latency(device):
     sim = ClosedLoop(cfg, np.array(f["start"], np.float32), np.array(f["goal"], np.float32), radius=f["radius"], downwash=f["downwash"],
                      max_vel=f["max_vel"], max_acc=f["max_acc"], nominal_velocity=1.0, waypoint_step=f["grid_resolution"],
                      world=world, dyn=spin.dyn(horizon=f["uncertainty_horizon"], duration=f["obs_duration"]), device=device)
-    ts, fails = fly(sim, 80)
+    ts, fails, extra = fly(sim, 80)
     out["forest10_spin4_100_1"] = {"agents": len(f["start"]), "dynamic_obstacles": len(f["obstacles"]), "steps": len(ts["eager"]),
                                    "p50_ms": float(np.percentile(ts["eager"], 50)), "p99_ms": float(np.percentile(ts["eager"], 99)),
                                    "qp_failsafes": fails,
-                                   "note": "220 variables, 124 reduced dimensions: working set in HBM (DESIGN.md 6f); includes the host-side waypoint planner"}
+                                   "note": "220 variables, up to 124 active rows: the working set (96 KB) fits the LDS of a CU since the solver "
+                                           "keeps no orthogonal factor (DESIGN.md 6f); includes the host-side waypoint planner"}
+    out["forest10_spin4_100_1"].update(extra)
+    out["x2048_moving_crowd"] = moving_crowd(device)
+    return out
+
+
+def moving_crowd(device, steps=60, warm=20):
+    """BASELINE.json configs[4] FLOWN: 2 048 agents in one 2-D arena, every agent swapping places with a partner 3.4 m away
+    (workloads.swapping_pairs); every step, all in HBM: communication-range neighbour search (dlscqp_neighbours_device),
+    corridor boxes, DLSC-GC half-spaces with the generator's presolve, goal LP + QP in the order of the previous step's
+    iteration counts, state update.  No host work and no synchronisation inside a step."""
+    import numpy as np
+    import torch
+    from dlsc_gc_planner_amd import abi, workloads
+    from dlsc_gc_planner_amd.harness import ClosedLoop
+    cfg = workloads.x2048_config(device=device)
+    N = 2048
+    start, goal = workloads.swapping_pairs(cfg, N)
+    sim = ClosedLoop(cfg, start, goal, radius=0.15, downwash=2.0, max_vel=1.0, max_acc=2.0, waypoint_step=0.5, device=device,
+                     neighbours="device", nbr_pitch=256, corridor_margin=0.5, prune=True, order_hint=True)
+    sim.keep_inputs = True
+    for _ in range(warm):
+        sim.step()
+    torch.cuda.synchronize()
+    # un-synchronised: the steps queue up on the stream like a real loop's
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sim.step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    sim.enable_stage_timers()
+    its, act, fails, rows = [], [], 0, []
+    for _ in range(20):
+        sim.step()
+        r = sim.batch.results()
+        its.append(r["iters"][:, 0].copy())
+        act.append(r["iters"][:, 3].mean())
+        fails += int((r["status"] != abi.OK).sum())
+        rows.append(float(sim.row_counts.float().mean()))
+    stages = sim.stage_times()
+    inputs = sim.step_inputs()
+    its = np.stack(its)
+    out = {"agents": N, "steps_timed": steps, "ms_per_step": ms, "agent_qp_per_s": N / ms * 1e3,
+           "mean_active_set_iterations": float(its.mean()), "max_active_set_iterations": int(its.max()),
+           "zero_iteration_fraction": float((its == 0).mean()), "mean_active_rows": float(np.mean(act)),
+           "rows_kept_per_agent": float(np.mean(rows)), "neighbours_per_agent": float(sim.nbr.counts.float().mean()),
+           "neighbour_list_overflow": int(sim.nbr.overflow.cpu()[0]), "qp_failsafes_in_20_steps": fails,
+           "min_separation_ratio": sim.min_separation(),
+           "stage_p50_ms": {k: float(np.percentile(v, 50)) for k, v in stages.items()},
+           "includes": "neighbour search + corridor boxes + half-space generation (presolve) + goal LP + QP + launch order + state update"}
+    try:
+        cms, nt = cpu_port_step_ms(cfg, inputs, seconds=2.0)
+        out["cpu_port_ms"], out["cpu_port_threads"] = cms, nt
+        out["cpu_port_note"] = "goal LP + QP only (no neighbour search, no half-space generation) on the host, inputs read back from HBM"
+    except Exception as e:
+        out["cpu_port_ms"], out["cpu_port_note"] = None, "unavailable: %s" % e
+    sim.close()
     return out
 
 

@@ -152,6 +152,24 @@ class LscGen(C.Structure):
         ("reserved_", C.c_int32),
         ("prune_sfc_boxes", C.c_void_p),
         ("out_row_counts", C.c_void_p),
+        ("nbr_counts", C.c_void_p),
+    ]
+
+
+class NeighbourSearch(C.Structure):  # dlscqp_neighbour_search
+    _fields_ = [
+        ("n_total", C.c_int32),
+        ("n_local", C.c_int32),
+        ("local_ids", C.c_void_p),
+        ("position", C.c_void_p),
+        ("position_stride", C.c_int32),
+        ("pitch", C.c_int32),
+        ("out_nbr_ids", C.c_void_p),
+        ("out_nbr_counts", C.c_void_p),
+        ("out_row_counts", C.c_void_p),
+        ("n_dyn", C.c_int32),
+        ("reserved_", C.c_int32),
+        ("out_overflow", C.c_void_p),
     ]
 
 
@@ -296,6 +314,8 @@ def load_library():
     lib.dlscqp_plan_batch_device.restype = C.c_int
     lib.dlscqp_generate_lsc_device.argtypes = [vp, P(LscGen), vp]
     lib.dlscqp_generate_lsc_device.restype = C.c_int
+    lib.dlscqp_neighbours_device.argtypes = [vp, P(NeighbourSearch), vp]
+    lib.dlscqp_neighbours_device.restype = C.c_int
     lib.dlscqp_waypoint_trap_device.argtypes = [vp, P(LscGen), P(WaypointTrap), vp]
     lib.dlscqp_waypoint_trap_device.restype = C.c_int
     lib.dlscqp_advance_device.argtypes = [vp, P(Advance), vp]
@@ -326,5 +346,5 @@ EXPORTED_SYMBOLS = [
     "dlscqp_plan_batch_device", "dlscqp_generate_lsc_device", "dlscqp_rows_to_soa", "dlscqp_set_timing",
     "dlscqp_get_kernel_times", "dlscqp_world_create", "dlscqp_world_destroy", "dlscqp_generate_sfc_device",
     "dlscqp_advance_device", "dlscqp_waypoint_trap_device", "dlscqp_mapf_create", "dlscqp_mapf_destroy", "dlscqp_mapf_step",
-    "dlscqp_launch_order_device", "dlscqp_launch_order_history_device",
+    "dlscqp_launch_order_device", "dlscqp_launch_order_history_device", "dlscqp_neighbours_device",
 ]

@@ -373,7 +373,7 @@ __global__ __launch_bounds__(LSC_THREADS, 4) void dlscqp_lsc_kernel(LscGenArgs g
     const int k = blockIdx.x;
     if (k >= g.n_local) return;
     const int self = g.local_ids ? g.local_ids[k] : k;
-    const int p0 = g.nbr_offsets[k], p1 = g.nbr_offsets[k + 1];
+    const int p0 = g.nbr_offsets[k], p1 = g.nbr_counts ? p0 + g.nbr_counts[k] : g.nbr_offsets[k + 1];
     const int per = g.M * g.n1 - g.phi;
     const size_t pair0 = (size_t)p0 + (size_t)k * g.n_dyn;  // pairs (agent, obstacle) before this agent's
     // items in NEIGHBOUR-major order: consecutive lanes read consecutive segments of one neighbour's plan and write one
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64) void dlscqp_trap_kernel(TrapArgs t) {
     const int k = blockIdx.x;
     if (k >= g.n_local) return;
     const int per = g.M * g.n1 - g.phi;
-    const int p0 = g.nbr_offsets[k], p1 = g.nbr_offsets[k + 1];
+    const int p0 = g.nbr_offsets[k], p1 = g.nbr_counts ? p0 + g.nbr_counts[k] : g.nbr_offsets[k + 1];
     const size_t row0 = (size_t)per * ((size_t)p0 + (size_t)k * g.n_dyn);
     // all rows of the agent: neighbours' and dynamic obstacles' (the latter are ignored by trap_row_excludes); a generator
     // that pruned rows says how many there are
@@ -655,6 +655,8 @@ struct dlscqp_ctx {
     int *d_order_scratch = nullptr;  // dlscqp_launch_order_device: two blocks of 64 counts + 64 cursors, used alternately
     unsigned order_calls = 0;
     void *work = nullptr;  // working sets of the WS_HBM kernel
+    int32_t *nbr_scratch = nullptr;  // dlscqp_neighbours_device: cell counts / starts, agents' cells and slots, agents by cell
+    size_t nbr_scratch_ints = 0;
     size_t work_bytes = 0;
     // staging for the host-buffer entry points
     unsigned char *h_stage = nullptr, *d_stage = nullptr;
@@ -733,6 +735,7 @@ extern "C" void dlscqp_destroy(dlscqp_ctx *c) {
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->work) (void)hipFree(c->work);
     if (c->d_order_scratch) (void)hipFree(c->d_order_scratch);
+    if (c->nbr_scratch) (void)hipFree(c->nbr_scratch);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -906,7 +909,7 @@ static int lsc_gen_args(dlscqp_ctx *c, const dlscqp_lsc_gen *gen, LscGenArgs *ou
     g.local_ids = gen->local_ids;
     g.plans = gen->plans; g.position = gen->position; g.velocity = gen->velocity; g.goals = gen->goals;
     g.radius = gen->radius; g.downwash = gen->downwash;
-    g.nbr_offsets = gen->nbr_offsets; g.nbr_ids = gen->nbr_ids;
+    g.nbr_offsets = gen->nbr_offsets; g.nbr_ids = gen->nbr_ids; g.nbr_counts = gen->nbr_counts;
     g.nx = gen->nx; g.ny = gen->ny; g.nz = gen->nz; g.px = gen->px; g.py = gen->py; g.pz = gen->pz;
     g.d = gen->d; g.key = gen->key;
     g.n_dyn = gen->n_dyn > 0 ? gen->n_dyn : 0;
@@ -960,6 +963,189 @@ extern "C" int dlscqp_waypoint_trap_device(dlscqp_ctx *c, const dlscqp_lsc_gen *
     t.out_released = trap->out_released;
     t.horizon = c->M * c->dt;
     hipLaunchKernelGGL(dlscqp_trap_kernel, dim3(gen->n_local), dim3(64), 0, (hipStream_t)stream, t);
+    HIP_TRY(hipGetLastError());
+    return DLSCQP_SUCCESS;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// communication-range neighbour lists (include/dlscqp.h: dlscqp_neighbours_device)
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct NbrGrid {
+    float lo[3], inv_cell[3];
+    int n[3];
+};
+struct NbrArgs {
+    NbrGrid grid;
+    dlscqp_neighbour_search ns;
+    double range;
+    int per;
+    int32_t *cell_count, *cell_start, *agent_cell, *agent_slot, *by_cell;
+    int n_cells;
+};
+
+__device__ __forceinline__ int nbr_cell_of(const NbrGrid &g, const float *p, int *c3) {
+    int id = 0;
+#pragma unroll
+    for (int k = 2; k >= 0; k--) {
+        int c = (int)floorf((p[k] - g.lo[k]) * g.inv_cell[k]);
+        c = c < 0 ? 0 : (c >= g.n[k] ? g.n[k] - 1 : c);  // monotone clamp: agents within range stay in adjacent cells
+        c3[k] = c;
+        id = id * g.n[k] + c;
+    }
+    return id;
+}
+
+// 1: every agent takes a slot in its cell
+__global__ __launch_bounds__(256) void dlscqp_nbr_bin_kernel(NbrArgs a) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= a.ns.n_total) return;
+    int c3[3];
+    const int cell = nbr_cell_of(a.grid, a.ns.position + (size_t)i * a.ns.position_stride, c3);
+    a.agent_cell[i] = cell;
+    a.agent_slot[i] = atomicAdd(&a.cell_count[cell], 1);
+}
+
+// 2: exclusive prefix sum of the cell counts (one workgroup; a few hundred to a few thousand cells)
+__global__ __launch_bounds__(1024) void dlscqp_nbr_scan_kernel(NbrArgs a) {
+    __shared__ int part[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < a.n_cells; base += 1024) {
+        const int i = base + (int)threadIdx.x;
+        const int v = i < a.n_cells ? a.cell_count[i] : 0;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int s = 1; s < 1024; s <<= 1) {
+            const int t = threadIdx.x >= (unsigned)s ? part[threadIdx.x - s] : 0;
+            __syncthreads();
+            part[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < a.n_cells) a.cell_start[i] = carry + part[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) a.cell_start[a.n_cells] = carry;
+}
+
+// 3: agents ordered by cell (order within a cell: as the slots were drawn -- the lists are sorted afterwards)
+__global__ __launch_bounds__(256) void dlscqp_nbr_scatter_kernel(NbrArgs a) {
+    const int i = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (i >= a.ns.n_total) return;
+    a.by_cell[a.cell_start[a.agent_cell[i]] + a.agent_slot[i]] = i;
+}
+
+// 4: one wavefront per local agent: the members of the 27 cells around its own (nine runs of up to three cells that are
+// contiguous in by_cell), LInfinityDistance test, compaction into LDS, rank sort by id, the first `pitch` ids out
+constexpr int NBR_LIST_CAP = 4096;
+__global__ __launch_bounds__(64) void dlscqp_nbr_gather_kernel(NbrArgs a) {
+    __shared__ int list[NBR_LIST_CAP];
+    const int k = (int)blockIdx.x, lane = (int)threadIdx.x;
+    if (k >= a.ns.n_local) return;
+    const int self = a.ns.local_ids ? a.ns.local_ids[k] : k;
+    const float *ps = a.ns.position + (size_t)self * a.ns.position_stride;
+    const float sx = ps[0], sy = ps[1], sz = ps[2];
+    int count = 0;
+    auto consider = [&](int lo, int hi) {  // candidates by_cell[lo .. hi), uniform bounds
+        for (int b = lo; b < hi; b += 64) {
+            const int j = b + lane;
+            const int id = j < hi ? a.by_cell[j] : self;
+            const float *pq = a.ns.position + (size_t)id * a.ns.position_stride;
+            // util.hpp:131-140: float32 differences, the largest of their absolute values, compared in double
+            float d = fabsf(sx - pq[0]);
+            d = fmaxf(d, fabsf(sy - pq[1]));
+            d = fmaxf(d, fabsf(sz - pq[2]));
+            const bool in = id != self && !(a.range > 0 && (double)d > a.range);
+            const unsigned long long m = __ballot(in);
+            const int at = count + __popcll(m & ((1ull << lane) - 1ull));
+            if (in && at < NBR_LIST_CAP) list[at] = id;
+            count += __popcll(m);
+        }
+    };
+    if (a.range > 0) {
+        int c3[3];
+        nbr_cell_of(a.grid, ps, c3);
+        for (int dz = -1; dz <= 1; dz++) {
+            const int z = c3[2] + dz;
+            if (z < 0 || z >= a.grid.n[2]) continue;
+            for (int dy = -1; dy <= 1; dy++) {
+                const int y = c3[1] + dy;
+                if (y < 0 || y >= a.grid.n[1]) continue;
+                const int x0 = c3[0] > 0 ? c3[0] - 1 : 0, x1 = c3[0] + 1 < a.grid.n[0] ? c3[0] + 1 : a.grid.n[0] - 1;
+                const int row = (z * a.grid.n[1] + y) * a.grid.n[0];
+                consider(a.cell_start[row + x0], a.cell_start[row + x1 + 1]);
+            }
+        }
+    } else {
+        consider(0, a.ns.n_total);  // no communication limit: by_cell holds every agent
+    }
+    __syncthreads();
+    const int kept = count < NBR_LIST_CAP ? count : NBR_LIST_CAP;
+    for (int e = lane; e < kept; e += 64) {
+        const int id = list[e];
+        int rank = 0;
+        for (int j = 0; j < kept; j++) rank += list[j] < id ? 1 : 0;
+        if (rank < a.ns.pitch) a.ns.out_nbr_ids[(size_t)k * a.ns.pitch + rank] = id;
+    }
+    if (lane == 0) {
+        const int n = kept < a.ns.pitch ? kept : a.ns.pitch;
+        a.ns.out_nbr_counts[k] = n;
+        if (a.ns.out_row_counts) a.ns.out_row_counts[k] = (n + a.ns.n_dyn) * a.per;
+        if (a.ns.out_overflow && (count > a.ns.pitch || count > NBR_LIST_CAP)) *a.ns.out_overflow = 1;
+    }
+}
+}  // namespace
+
+extern "C" int dlscqp_neighbours_device(dlscqp_ctx *c, const dlscqp_neighbour_search *ns, void *stream) {
+    g_last_error.clear();
+    if (!c || !ns) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (ns->n_local <= 0 || ns->n_total <= 0) return DLSCQP_SUCCESS;
+    if (!ns->position || !ns->out_nbr_ids || !ns->out_nbr_counts || ns->pitch <= 0 || ns->position_stride < 3 || ns->n_dyn < 0) {
+        g_last_error = "null buffer or invalid size";
+        return DLSCQP_ERR_INVALID_ARGUMENT;
+    }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    NbrArgs a;
+    a.ns = *ns;
+    a.range = c->cfg.communication_range;
+    a.per = c->M * (c->n + 1) - c->phi;
+    // cells of one communication range (never more than 64 per axis: larger cells keep the 27-cell search valid)
+    a.n_cells = 1;
+    for (int k = 0; k < 3; k++) {
+        const double ext = std::max(0.0, c->cfg.world_max[k] - c->cfg.world_min[k]);
+        double cell = a.range > 0 ? a.range : std::max(ext, 1.0);
+        if (ext / cell > 64.0) cell = ext / 64.0;
+        a.grid.lo[k] = (float)c->cfg.world_min[k];
+        a.grid.inv_cell[k] = (float)(1.0 / (cell * (1.0 + 1e-6)));  // a hair larger than the range: float rounding of the cell
+                                                                      // index can then never separate two agents within range by two cells
+        a.grid.n[k] = a.range > 0 ? std::max(1, (int)std::floor(ext / cell) + 1) : 1;
+        a.n_cells *= a.grid.n[k];
+    }
+    const size_t need = (size_t)2 * (a.n_cells + 1) + (size_t)3 * ns->n_total + 16;
+    if (need > c->nbr_scratch_ints) {
+        HIP_TRY(hipDeviceSynchronize());
+        if (c->nbr_scratch) (void)hipFree(c->nbr_scratch);
+        c->nbr_scratch = nullptr;
+        c->nbr_scratch_ints = 0;
+        HIP_TRY(hipMalloc((void **)&c->nbr_scratch, need * sizeof(int32_t)));
+        c->nbr_scratch_ints = need;
+    }
+    a.cell_count = c->nbr_scratch;
+    a.cell_start = a.cell_count + a.n_cells + 1;
+    a.agent_cell = a.cell_start + a.n_cells + 1;
+    a.agent_slot = a.agent_cell + ns->n_total;
+    a.by_cell = a.agent_slot + ns->n_total;
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(a.cell_count, 0, (size_t)(a.n_cells + 1) * sizeof(int32_t), st));
+    const int nb = (ns->n_total + 255) / 256;
+    hipLaunchKernelGGL(dlscqp_nbr_bin_kernel, dim3(nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(dlscqp_nbr_scan_kernel, dim3(1), dim3(1024), 0, st, a);
+    hipLaunchKernelGGL(dlscqp_nbr_scatter_kernel, dim3(nb), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(dlscqp_nbr_gather_kernel, dim3(ns->n_local), dim3(64), 0, st, a);
     HIP_TRY(hipGetLastError());
     return DLSCQP_SUCCESS;
 }

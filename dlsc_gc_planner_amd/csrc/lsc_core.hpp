@@ -292,6 +292,7 @@ struct LscGenArgs {  // device mirror of dlscqp_lsc_gen (include/dlscqp.h)
     const float *plans, *position, *velocity, *goals;
     const double *radius, *downwash;
     const int32_t *nbr_offsets, *nbr_ids;
+    const int32_t *nbr_counts;       // lists of fixed pitch: neighbours of local agent k (else nbr_offsets[k+1] - nbr_offsets[k])
     float *nx, *ny, *nz, *px, *py, *pz;
     double *d;
     uint32_t *key;

@@ -111,11 +111,18 @@ class SpinObstacles:
 
 class ClosedLoop:
     def __init__(self, cfg, start, goal, radius=0.15, downwash=2.0, max_vel=1.0, max_acc=2.0, nominal_velocity=1.0,
-                 waypoint_step=0.5, device=0, dyn=None, result_csv=None, world=None):
+                 waypoint_step=0.5, device=0, dyn=None, result_csv=None, world=None, neighbours=None, nbr_pitch=96,
+                 corridor_margin=None, prune=False, order_hint=False):
         """dyn: None or dict(position [D,3], velocity [D,3], radius, max_acc, downwash [D], size_prediction, horizon) --
         obstacles that keep their velocity (obstacle.hpp: straight-line dynamic obstacles).  result_csv: path of a
         result file in the reference's layout.  world: None or dict(boxes [K,6] centre+size, resolution, grid_resolution)
-        -- static obstacles: corridor boxes from the device generator (row N2) and waypoints from GridWaypoints."""
+        -- static obstacles: corridor boxes from the device generator (row N2) and waypoints from GridWaypoints.
+        neighbours="device": the communication-range neighbour lists (broadcastMsgs, multi_sync_simulator.cpp:482-503) are
+        rebuilt in HBM every step by dlscqp_neighbours_device, at most nbr_pitch per agent -- what a crowd of thousands needs
+        (all-to-all lists grow with N^2).  corridor_margin (obstacle-free worlds with world_use_octomap set): one corridor
+        box per segment, the bounding box of the segment's control points of the initial trajectory grown by that many metres
+        (a stand-in for the boxes the octomap corridor generator would grow in a crowded maze).  prune: the generator's
+        presolve.  order_hint: every launch in the order of the previous step's iteration counts, sorted on the device."""
         import torch
         self.torch = torch
         self.cfg = cfg
@@ -137,8 +144,14 @@ class ClosedLoop:
         self.seq = 0
         # every agent is every other agent's obstacle (communication range -1 in testall_DLSCGC_empty.launch)
         ids = np.arange(N)
-        nbr_ids = np.concatenate([np.delete(ids, a) for a in range(N)]) if N > 1 else np.zeros(0, np.int32)
-        nbr_offsets = np.arange(N + 1) * (N - 1)
+        self.nbr = None
+        if neighbours == "device":
+            assert cfg.communication_range > 0 and not (world is not None and world.get("pibt", False) == "reference")
+            nbr_pitch = min(int(nbr_pitch), max(N - 1, 1))
+            nbr_ids, nbr_offsets = np.zeros(N * nbr_pitch, np.int32), np.arange(N + 1) * nbr_pitch
+        else:
+            nbr_ids = np.concatenate([np.delete(ids, a) for a in range(N)]) if N > 1 else np.zeros(0, np.int32)
+            nbr_offsets = np.arange(N + 1) * (N - 1)
         self.dyn = dyn
         self.D = 0 if dyn is None else len(dyn["radius"])
         self.dyn_model = None if dyn is None else dyn.get("model")
@@ -146,8 +159,12 @@ class ClosedLoop:
             self.dyn_pos, self.dyn_vel = f32(dyn["position"]), f32(dyn["velocity"])
         self.gen = self.opt.make_lsc_generator(N, nbr_offsets, nbr_ids, np.full(N, radius), np.full(N, downwash), device=device,
                                                dyn=dyn)
+        if neighbours == "device":
+            self.nbr = self.opt.make_neighbour_search(self.gen, nbr_pitch)
         self.world = world
         self.sfc = None
+        self.box_margin = None
+        self.order_hint = bool(order_hint)
         self.comm_neighbours = False
         self.slack_threshold = float(world.get("slack_threshold", 0.1)) if world is not None else 0.1  # param.slack_threshold
         if world is not None:
@@ -181,7 +198,24 @@ class ClosedLoop:
             setattr(self.batch.c, k, self.gen.soa[k].data_ptr())
         self.ro32 = torch.from_numpy(ro.astype(np.int32)).to(dev)
         self.batch.c.row_offsets = self.ro32.data_ptr()
+        # sized once to the generator's capacity and never shrunk: the launch's kernel choice, LDS layout and flag array
+        # follow it, and a captured graph freezes them
         self.batch.c.max_rows_per_agent = int(np.diff(ro).max()) if N else 0
+        if corridor_margin is not None:
+            assert world is None and cfg.world_use_octomap, "synthetic corridor boxes stand in for the octomap generator"
+            self.box_margin = float(corridor_margin)
+            self.box_t = torch.zeros((N, M, 6), dtype=torch.float32, device=dev)
+            self.batch.sfc_t = self.box_t  # keep alive
+            self.batch.c.sfc_boxes = self.box_t.data_ptr()
+            self.box_lo = f32(np.array(cfg.world_min[:], np.float32))
+            self.box_hi = f32(np.array(cfg.world_max[:], np.float32))
+        self.row_counts = None
+        if prune:
+            self.row_counts = self.gen.enable_pruning(self.sfc.sfcs if self.sfc is not None else (self.box_t if self.box_margin is not None else None))
+        elif self.nbr is not None:
+            self.row_counts = self.nbr.row_counts
+        if self.row_counts is not None:
+            self.batch.use_row_counts(self.row_counts)
         self.agent_f32 = self.batch.t["agents"].view(torch.float32).view(N, abi.AGENT_DTYPE.itemsize // 4)
         # position, velocity, acceleration and next_waypoint live in the agent records (views); dlscqp_advance_device
         # rewrites them after every launch
@@ -198,9 +232,10 @@ class ClosedLoop:
         self.advance = self.opt.make_advance(self.batch, self.plans, self.cur_goal, self.init_buf,
                                              desired_goal=self.desired_goal if world is None else None,
                                              waypoint_step=waypoint_step if world is None else 0.0)
-        if world is not None and world.get("prune", True):
+        if world is not None and world.get("prune", True) and not prune:
             # presolve in the half-space generator: rows implied by this step's corridor boxes are never written
-            self.batch.use_row_counts(self.gen.enable_pruning(self.sfc.sfcs))
+            self.row_counts = self.gen.enable_pruning(self.sfc.sfcs)
+            self.batch.use_row_counts(self.row_counts)
         self.records_in = torch.zeros_like(self.batch.t["agents"])
         self.released = torch.zeros(N, dtype=torch.int32, device=dev)  # dynamic obstacles released by the waypoint trap, per agent
         self.history = []
@@ -271,8 +306,47 @@ class ClosedLoop:
         ids = np.concatenate([np.nonzero(keep[a])[0] for a in range(N)]) if N > 1 else np.zeros(0, np.int32)
         ro = self.gen.set_neighbours(offs, ids)
         self.ro32.copy_(self.torch.from_numpy(ro.astype(np.int32)))
-        self.batch.c.max_rows_per_agent = int(np.diff(ro).max())
+        # max_rows_per_agent stays at the generator's capacity (set once in the constructor): see there
         self.n_neighbours = keep.sum(axis=1)
+
+    # ---- per-stage timing in the reference's vocabulary (timer.hpp, sp_const.hpp:81-122; the columns of its summary file,
+    # multi_sync_simulator.cpp:852-900): HIP events around the launches of a stage, host time for the waypoint planner
+    STAGES = ("sfc_generation_time", "lsc_generation_time", "traj_optimization_time", "state_update_time")
+
+    def enable_stage_timers(self, on=True):
+        """Record a pair of events around every stage of the following steps (not with a captured graph); stage_times()
+        returns what they measured.  traj_optimization_time = goal LP + QP (one fused launch here; the reference times
+        goal_planning_time and traj_optimization_time apart); lsc_generation_time includes the neighbour search and the
+        waypoint trap; mapf_time is host time of the reference's waypoint planner incl. its transfers."""
+        self._stage_ev = [] if on else None
+        self._mapf_ms = []
+
+    def _stage(self, name):
+        if getattr(self, "_stage_ev", None) is None:
+            return
+        ev = self.torch.cuda.Event(enable_timing=True)
+        ev.record(self.torch.cuda.current_stream(self.dev))
+        self._stage_ev.append((name, ev))
+
+    def stage_times(self):
+        """dict stage -> array of ms per step (steps since enable_stage_timers)."""
+        self.torch.cuda.synchronize(self.dev)
+        out = {k: [] for k in self.STAGES}
+        ev = self._stage_ev
+        cur = {}
+        for i in range(len(ev) - 1):
+            name, e0 = ev[i]
+            if name == "end":
+                continue
+            cur[name] = cur.get(name, 0.0) + e0.elapsed_time(ev[i + 1][1])
+            if ev[i + 1][0] == "end":
+                for k in self.STAGES:
+                    out[k].append(cur.get(k, 0.0))
+                cur = {}
+        res = {k: np.array(v) for k, v in out.items()}
+        if self._mapf_ms:
+            res["mapf_time"] = np.array(self._mapf_ms)
+        return res
 
     def _body(self, first):
         """The device work of one step: half-spaces, corridors, goal LP + QP, then dlscqp_advance_device (fail-safe,
@@ -290,8 +364,19 @@ class ClosedLoop:
             self.init_buf.copy_(self.plans)
             if self.sfc is not None:  # TrajPlanner::constructSFC (traj_planner.cpp:517-520): initializeSFC once, then one shift per step
                 self.sfc.initialize(pos)
+        self._stage("sfc_generation_time")
         if self.sfc is not None:
             self.sfc.update(self.init_buf, self.cur_goal, self.wp)
+        if self.box_margin is not None:
+            # one box per segment around the initial trajectory (the shifted previous plan), inside the world box
+            torch = self.torch
+            lo = torch.maximum(self.init_buf.amin(dim=2) - self.box_margin, self.box_lo)
+            hi = torch.minimum(self.init_buf.amax(dim=2) + self.box_margin, self.box_hi)
+            self.box_t[:, :, 0:3].copy_(lo)
+            self.box_t[:, :, 3:6].copy_(hi)
+        self._stage("lsc_generation_time")
+        if self.nbr is not None:
+            self.nbr.search(self.pos)
         if first:
             self.gen.generate(self.cur_goal, position=self.pos.contiguous(), velocity=self.vel.contiguous(), **dkw)
         else:
@@ -302,10 +387,15 @@ class ClosedLoop:
             self.gen.waypoint_trap(self.batch.t["agents"], None if self.sfc is None else self.sfc.sfcs, self.released)
         if self.keep_inputs:
             self.records_in.copy_(self.batch.t["agents"])
+        self._stage("traj_optimization_time")
         self.batch.launch(True, True)
+        self._stage("state_update_time")
+        if self.order_hint:
+            self.batch.update_order()  # the next step's launch order from this step's iteration counts
         # fail-safe: keep the shifted previous plan (traj_planner.cpp:776); sub-goal from the LP (traj_planner.cpp:494);
         # doStep of the next iteration: state = desired_traj.getStateAt(dt) = start of segment 1, float32 differences
         self.advance()
+        self._stage("end")
 
     def enable_graph(self):
         """Capture the steady-state step in a HIP graph (torch.cuda.CUDAGraph): a ten-agent step is three or four small
@@ -338,7 +428,10 @@ class ClosedLoop:
         first = self.seq < 1  # planner_seq < 2 in the reference counts from 1
         t_wall = time.perf_counter() if self.csv else 0.0
         if self.world is not None:
+            t_mapf = time.perf_counter()
             self.wp.copy_(self._waypoints_host())
+            if getattr(self, "_stage_ev", None) is not None:
+                self._mapf_ms.append((time.perf_counter() - t_mapf) * 1e3)
         if self.graph is not None and not first:
             self.graph.replay()
         else:
@@ -373,11 +466,13 @@ class ClosedLoop:
         assert self.keep_inputs, "set keep_inputs before stepping: the records are rewritten after every launch"
         agents = self.records_in.cpu().numpy().view(abi.AGENT_DTYPE).reshape(-1).copy()
         ro, rows = self.gen.rows_host()
-        if getattr(self.gen, "row_counts", None) is not None:  # pruned: only the first row_counts[k] rows of every block
-            cnt = self.gen.row_counts.cpu().numpy()
+        if self.row_counts is not None:  # presolve or lists of fixed pitch: only the first row_counts[k] rows of every block
+            cnt = self.row_counts.cpu().numpy()
             rows = np.concatenate([rows[ro[k]:ro[k] + cnt[k]] for k in range(len(cnt))]) if len(cnt) else rows[:0]
             ro = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
         sfc = None if self.sfc is None else self.sfc.sfcs.cpu().numpy().copy()
+        if self.box_margin is not None:
+            sfc = self.box_t.cpu().numpy().copy()
         return agents, ro, rows, sfc, self.D
 
     def min_obstacle_separation(self):

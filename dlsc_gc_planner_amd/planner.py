@@ -129,6 +129,11 @@ class BatchTrajOptimizer:
         describes the dynamic obstacles every agent sees (radius, max_acc, downwash, size_prediction, horizon)."""
         return LscGenerator(self, n_total, nbr_offsets, nbr_ids, radius, downwash, local_ids, device, dyn)
 
+    def make_neighbour_search(self, gen, pitch, device=None):
+        """Communication-range neighbour lists of `gen`'s local agents, rebuilt on the device every step
+        (dlscqp_neighbours_device; `gen` must have been made with nbr_offsets = arange(n_local + 1) * pitch)."""
+        return NeighbourSearch(self, gen, pitch, device)
+
     def make_sfc_generator(self, boxes, resolution, world_min, world_max, radius, max_vel, grid_resolution, device=None):
         """Device-resident safe-flight-corridor generator for a world given as axis-aligned boxes."""
         return SfcGenerator(self, boxes, resolution, world_min, world_max, radius, max_vel, grid_resolution, device)
@@ -448,6 +453,54 @@ class LscGenerator:
         sl = (key >> 16).astype(np.int64)
         rows["slack"] = np.where(sl == 0xFFFF, -1, sl)
         return self.row_offsets, rows
+
+
+class NeighbourSearch:
+    """broadcastMsgs' communication-range filter (multi_sync_simulator.cpp:482-503) on the device: every step the lists of
+    a LscGenerator whose lists have a fixed pitch are rebuilt from the agents' positions, in HBM, with nothing sized or
+    scanned on the host.  `counts` [n_local] int32 and `overflow` [1] int32 are CUDA tensors; with `row_counts=True` the
+    rows per agent that the generator writes WITHOUT its presolve go to `row_counts` (with the presolve the generator
+    writes its own)."""
+
+    def __init__(self, opt, gen, pitch, device):
+        import torch
+        self.torch, self.opt, self.gen = torch, opt, gen
+        dev = gen.device if device is None else torch.device("cuda", device)
+        self.device = dev
+        n = gen.n_local
+        self.pitch = int(pitch)
+        assert gen.t["nbr_ids"].numel() >= n * self.pitch
+        off = gen.t["nbr_offsets"].cpu().numpy()
+        assert np.array_equal(off, np.arange(n + 1) * self.pitch), "the generator's lists must have this pitch"
+        self.counts = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.row_counts = torch.zeros(n, dtype=torch.int32, device=dev)
+        gen.c.nbr_counts = self.counts.data_ptr()
+        c = abi.NeighbourSearch()
+        c.n_total, c.n_local = gen.n_total, n
+        c.local_ids = None if gen.t["local_ids"] is None else gen.t["local_ids"].data_ptr()
+        c.pitch = self.pitch
+        c.out_nbr_ids, c.out_nbr_counts = gen.t["nbr_ids"].data_ptr(), self.counts.data_ptr()
+        c.out_row_counts = self.row_counts.data_ptr()
+        c.n_dyn = gen.n_dyn
+        c.out_overflow = self.overflow.data_ptr()
+        self.c = c
+
+    def search(self, position, stream=None):
+        """position: CUDA float32 tensor [n_total, >= 3] whose rows are `position.stride(0)` floats apart (a dense table or a
+        view into the agent records).  Asynchronous."""
+        assert position.dtype == self.torch.float32 and position.stride(1) == 1
+        self.c.position, self.c.position_stride = position.data_ptr(), int(position.stride(0))
+        self._keep = position
+        s = self.torch.cuda.current_stream(self.device) if stream is None else stream
+        rc = self.opt.lib.dlscqp_neighbours_device(self.opt.handle, C.byref(self.c), C.c_void_p(s.cuda_stream))
+        self.opt._check(rc, "dlscqp_neighbours_device")
+
+    def lists_host(self):
+        """(counts, ids [n_local, pitch]) on the host (tests)."""
+        self.torch.cuda.synchronize(self.device)
+        n = self.gen.n_local
+        return self.counts.cpu().numpy(), self.gen.t["nbr_ids"][:n * self.pitch].cpu().numpy().reshape(n, self.pitch)
 
 
 class SfcGenerator:

@@ -389,3 +389,23 @@ def x2048(cfg, n_agents=2048, seed=5000, spacing=0.85, jitter=0.15, sense=3.0):
     return dict(plans=plans, init=init, goals=goals.astype(np.float32), radius=np.full(n_agents, 0.15),
                 downwash=np.full(n_agents, DOWNWASH), nbr_offsets=np.array(offs, np.int32), nbr_ids=nbr_ids,
                 agents=agents, sfc=np.ascontiguousarray(sfc))
+
+
+def swapping_pairs(cfg, n_agents, seed=5000, spacing=0.85, jitter=0.15, hop=4):
+    """BASELINE.json configs[4] as a MOVING crowd: the start points of x2048 (jittered grid); every agent swaps places with the agent `hop` grid cells further
+    along x (3.4 m): counter-flowing pairs everywhere, and the density of the crowd stays what it is."""
+    rng = np.random.default_rng(seed)
+    side = int(np.ceil(np.sqrt(n_agents)))
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side), indexing="ij")
+    cell = np.stack([gx.ravel(), gy.ravel()], 1)[:n_agents]
+    origin = -0.5 * spacing * (side - 1)
+    start = np.zeros((n_agents, 3), np.float32)
+    start[:, :2] = origin + cell * spacing + rng.uniform(-jitter, jitter, (n_agents, 2))
+    start[:, 2] = cfg.world_z_2d
+    index = {(int(a), int(b)): k for k, (a, b) in enumerate(cell)}
+    partner = np.arange(n_agents)
+    for k, (a, b) in enumerate(cell):
+        q = (int(a) + hop, int(b)) if (int(a) // hop) % 2 == 0 else (int(a) - hop, int(b))
+        partner[k] = index.get(q, k)
+    partner = np.where(partner[partner] == np.arange(n_agents), partner, np.arange(n_agents))  # pairs only
+    return start, start[partner].copy()

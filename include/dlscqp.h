@@ -280,9 +280,38 @@ typedef struct dlscqp_lsc_gen {
     int32_t reserved_;
     const float *prune_sfc_boxes;
     int32_t *out_row_counts;          /* [n_local], required when prune != 0                              */
+    /* Neighbour lists of fixed pitch (dlscqp_neighbours_device): when nbr_counts is given, local agent k has nbr_counts[k]
+     * neighbours from nbr_ids[nbr_offsets[k]] on (nbr_offsets[k] = k * pitch), not nbr_offsets[k+1] - nbr_offsets[k].   */
+    const int32_t *nbr_counts;        /* [n_local] or NULL                                                */
 } dlscqp_lsc_gen;
 
 int dlscqp_generate_lsc_device(dlscqp_ctx *ctx, const dlscqp_lsc_gen *gen, void *stream);
+
+/* The communication-range filter of MultiSyncSimulator::broadcastMsgs (multi_sync_simulator.cpp:482-503) on the device:
+ * local agent k is told about every other agent qj with LInfinityDistance(position_k, position_qj) <= communication_range
+ * (util.hpp:131-140: float32 differences, compared in double), in ascending id order -- the obstacle order the
+ * half-space generator and populatebyrow walk.  A uniform grid with cells of one communication range (over the world box of
+ * the configuration) bins the agents; every local agent then searches the 27 cells around its own.  Lists have a fixed
+ * pitch, so nothing is scanned or sized on the host: out_nbr_ids[k * pitch ...] holds out_nbr_counts[k] ids; a list longer
+ * than `pitch` is cut to its `pitch` smallest ids and *out_overflow is set.  communication_range <= 0 (no limit): every
+ * other agent.  Asynchronous on `stream`; scratch memory belongs to the context (calls of one context must not overlap). */
+typedef struct dlscqp_neighbour_search {
+    int32_t n_total;            /* agents in the position table                                         */
+    int32_t n_local;            /* agents to build lists for                                            */
+    const int32_t *local_ids;   /* [n_local] ids into the table, NULL = 0..n_local-1                    */
+    const float *position;      /* position of agent a: position[a * position_stride + 0..2]            */
+    int32_t position_stride;    /* in floats: 3 for a dense [n_total][3] table, 26 for the dlscqp_agent records */
+    int32_t pitch;              /* capacity of one list                                                 */
+    int32_t *out_nbr_ids;       /* [n_local][pitch]                                                     */
+    int32_t *out_nbr_counts;    /* [n_local]                                                            */
+    int32_t *out_row_counts;    /* optional [n_local]: rows the half-space generator writes without its presolve,
+                                 * (count + n_dyn) * (M (n+1) - phi)                                     */
+    int32_t n_dyn;
+    int32_t reserved_;
+    int32_t *out_overflow;      /* optional: set to 1 when a list was cut (never cleared here)          */
+} dlscqp_neighbour_search;
+
+int dlscqp_neighbours_device(dlscqp_ctx *ctx, const dlscqp_neighbour_search *ns, void *stream);
 
 /* TrajPlanner::checkWaypointTrap (traj_planner.cpp:708-735), after the half-spaces and the corridor boxes of a step and
  * before the goal LP: if the agent's sub-goal or waypoint lies outside the feasible region of its last control point

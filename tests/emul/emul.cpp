@@ -227,7 +227,7 @@ static dlscqp::LscGenArgs emul_lsc_args(const dlscqp_config *cfg, const dlscqp_l
     g.local_ids = gen->local_ids;
     g.plans = gen->plans; g.position = gen->position; g.velocity = gen->velocity; g.goals = gen->goals;
     g.radius = gen->radius; g.downwash = gen->downwash;
-    g.nbr_offsets = gen->nbr_offsets; g.nbr_ids = gen->nbr_ids;
+    g.nbr_offsets = gen->nbr_offsets; g.nbr_ids = gen->nbr_ids; g.nbr_counts = gen->nbr_counts;
     g.nx = gen->nx; g.ny = gen->ny; g.nz = gen->nz; g.px = gen->px; g.py = gen->py; g.pz = gen->pz;
     g.d = gen->d; g.key = gen->key;
     g.n_dyn = gen->n_dyn > 0 ? gen->n_dyn : 0;
@@ -252,7 +252,7 @@ extern "C" int emul_waypoint_trap(const dlscqp_config *cfg, const dlscqp_lsc_gen
     const LscGenArgs g = emul_lsc_args(cfg, gen);
     const int per = g.M * g.n1 - g.phi;
     for (int k = 0; k < g.n_local && g.n_dyn > 0; k++) {
-        const int p0 = g.nbr_offsets[k], p1 = g.nbr_offsets[k + 1];
+        const int p0 = g.nbr_offsets[k], p1 = g.nbr_counts ? p0 + g.nbr_counts[k] : g.nbr_offsets[k + 1];
         const size_t row0 = (size_t)per * ((size_t)p0 + (size_t)k * g.n_dyn);
         const dlscqp_agent *ag = trap->agents + k;
         const float *cg = ag->current_goal_point, *wp = ag->next_waypoint;
@@ -285,7 +285,7 @@ extern "C" int emul_generate_lsc(const dlscqp_config *cfg, const dlscqp_lsc_gen 
     const HullStore hull = {hull_pts, 1};
     for (int k = 0; k < g.n_local; k++) {  // same item -> row mapping as dlscqp_lsc_kernel
         const int self = g.local_ids ? g.local_ids[k] : k;
-        const int p0 = g.nbr_offsets[k], p1 = g.nbr_offsets[k + 1];
+        const int p0 = g.nbr_offsets[k], p1 = g.nbr_counts ? p0 + g.nbr_counts[k] : g.nbr_offsets[k + 1];
         const size_t pair0 = (size_t)p0 + (size_t)k * g.n_dyn;
         if (g.row_counts) {  // presolve: the rows that are not implied by the agent's box rows, contiguously, in order
             size_t at = (size_t)per * pair0;
