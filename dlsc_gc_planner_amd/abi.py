@@ -16,6 +16,7 @@ ERR_INVALID_ARGUMENT = -1
 ERR_HIP = -2
 ERR_NO_DEVICE = -3
 ERR_UNSUPPORTED = -4
+ERR_SELFTEST = -5
 
 # per-agent verdicts
 OK = 0
@@ -314,6 +315,8 @@ def load_library():
     lib.dlscqp_plan_batch_device.restype = C.c_int
     lib.dlscqp_generate_lsc_device.argtypes = [vp, P(LscGen), vp]
     lib.dlscqp_generate_lsc_device.restype = C.c_int
+    lib.dlscqp_selftest.argtypes = [vp]
+    lib.dlscqp_selftest.restype = C.c_int
     lib.dlscqp_neighbours_device.argtypes = [vp, P(NeighbourSearch), vp]
     lib.dlscqp_neighbours_device.restype = C.c_int
     lib.dlscqp_waypoint_trap_device.argtypes = [vp, P(LscGen), P(WaypointTrap), vp]
@@ -346,5 +349,5 @@ EXPORTED_SYMBOLS = [
     "dlscqp_plan_batch_device", "dlscqp_generate_lsc_device", "dlscqp_rows_to_soa", "dlscqp_set_timing",
     "dlscqp_get_kernel_times", "dlscqp_world_create", "dlscqp_world_destroy", "dlscqp_generate_sfc_device",
     "dlscqp_advance_device", "dlscqp_waypoint_trap_device", "dlscqp_mapf_create", "dlscqp_mapf_destroy", "dlscqp_mapf_step",
-    "dlscqp_launch_order_device", "dlscqp_launch_order_history_device", "dlscqp_neighbours_device",
+    "dlscqp_launch_order_device", "dlscqp_launch_order_history_device", "dlscqp_neighbours_device", "dlscqp_selftest",
 ]

@@ -606,8 +606,9 @@ kernel_t wide_kernel() {
 }
 
 // Kernel instantiation for a batch: the shared table in gi_core.hpp (DQ_INSTANCES / select_instance).
-KernelChoice select_kernel(const KParams &kp, int max_slack_obs, int kmax) {
-    static const bool force_generic = std::getenv("DLSCQP_FORCE_GENERIC") != nullptr;  // debugging aid
+KernelChoice select_kernel(const KParams &kp, int max_slack_obs, int kmax, bool force_runtime_shape = false) {
+    static const bool force_env = std::getenv("DLSCQP_FORCE_GENERIC") != nullptr;  // debugging aid
+    const bool force_generic = force_env || force_runtime_shape;
 #ifdef DLSCQP_ONLY_G2  // debugging aid: compile only the generic two-register instantiation
     (void)force_generic;
     return {dlscqp_plan_kernel<2, 0, 0, 0, DQ_G2_KU, DQ_G2_SU, -1>, 7, DQ_G2_KU, DQ_G2_SU, false};
@@ -652,9 +653,9 @@ struct dlscqp_ctx {
     Slot *d_slots = nullptr;
     hipStream_t stream = nullptr;
     int max_dyn_lds[2 * (DQ_N_INSTANCES + 1)] = {};  // second half: the WIDE builds
-    int *d_order_scratch = nullptr;  // dlscqp_launch_order_device: two blocks of 64 counts + 64 cursors, used alternately
-    unsigned order_calls = 0;
+    int *d_order_scratch = nullptr;  // dlscqp_launch_order_device: 64 counts + 64 cursors
     void *work = nullptr;  // working sets of the WS_HBM kernel
+    int force_instance = 0;  // dlscqp_selftest: 1 = the runtime-shape instantiation, 2 = its variant with the working set in HBM
     int32_t *nbr_scratch = nullptr;  // dlscqp_neighbours_device: cell counts / starts, agents' cells and slots, agents by cell
     size_t nbr_scratch_ints = 0;
     size_t work_bytes = 0;
@@ -715,6 +716,15 @@ extern "C" int dlscqp_create(const dlscqp_config *cfg, dlscqp_ctx **out_ctx) {
     if (!hip_ok(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return DLSCQP_ERR_HIP; }
     int rc = upload_tables(c);
     if (rc != DLSCQP_SUCCESS) { dlscqp_destroy(c); return rc; }
+    if (!std::getenv("DLSCQP_NO_SELFTEST")) {
+        rc = dlscqp_selftest(c);
+        if (rc != DLSCQP_SUCCESS) {
+            const std::string why = g_last_error;
+            dlscqp_destroy(c);
+            g_last_error = why;
+            return rc;
+        }
+    }
     *out_ctx = c;
     return DLSCQP_SUCCESS;
 }
@@ -812,14 +822,14 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         g_last_error = "world_use_octomap is set but sfc_boxes is NULL";
         return DLSCQP_ERR_INVALID_ARGUMENT;
     }
-    KernelChoice kc = select_kernel(c->kp, b->max_slack_obs, b->max_rows_per_agent);
+    KernelChoice kc = select_kernel(c->kp, b->max_slack_obs, b->max_rows_per_agent, c->force_instance != 0);
     if (!kc.fn) {
         g_last_error = "reduced dimension above 128 (dim*f + M*max_slack_obs) is not supported";
         return DLSCQP_ERR_UNSUPPORTED;
     }
     MemLayout lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, kc.by_kind);
     static const bool force_hbm = getenv("DLSCQP_DEBUG_WS") && std::string(getenv("DLSCQP_DEBUG_WS")) == "hbm";  // tests
-    const bool ws_hbm = lay.bytes > LDS_LIMIT || force_hbm;
+    const bool ws_hbm = lay.bytes > LDS_LIMIT || force_hbm || c->force_instance == 2;
     KernelArgs a;
     a.work = nullptr;
     a.work_stride = 0;
@@ -929,6 +939,12 @@ static int lsc_gen_args(dlscqp_ctx *c, const dlscqp_lsc_gen *gen, LscGenArgs *ou
     g.row_counts = nullptr;
     if (gen->prune) {
         if (!gen->out_row_counts || (c->kp.use_sfc && !gen->prune_sfc_boxes)) { g_last_error = "prune: null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+        if (c->kp.rsfc_mode) {
+            // RECIPROCALRSFC bounds the first segment's z by +-100, not by the world box (traj_optimizer.cpp:254-258): the
+            // presolve's box is not the model's there
+            g_last_error = "prune is not available in RECIPROCALRSFC mode";
+            return DLSCQP_ERR_UNSUPPORTED;
+        }
         g.prune_sfc = c->kp.use_sfc ? gen->prune_sfc_boxes : nullptr;
         g.row_counts = gen->out_row_counts;
     }
@@ -1188,12 +1204,11 @@ __device__ __forceinline__ int order_bin(const OrderHist &h, int idx) {
 
 // Pass 1: histogram.  Wavefronts add to the workgroup's LDS histogram, the workgroup adds its non-empty bins to the global
 // one: a few dozen global atomics on the crowded bin (agents that never iterate) instead of one per wavefront -- contended
-// device-scope atomics on one address cost ~100 ns each.  `scratch` = 64 counts + 64 cursors, zero on entry; workgroup 0
-// zeroes the OTHER scratch block, the one the next call uses.
-__global__ __launch_bounds__(ORDER_THREADS) void dlscqp_order_count_kernel(OrderHist iters, int n, int *scratch, int *scratch_next) {
+// device-scope atomics on one address cost ~100 ns each.  `scratch` = 64 counts + 64 cursors, zeroed on the stream right
+// before this kernel (so that a captured graph, or calls on different streams, start from zero every time).
+__global__ __launch_bounds__(ORDER_THREADS) void dlscqp_order_count_kernel(OrderHist iters, int n, int *scratch) {
     __shared__ int hist[ORDER_BINS];
     const int lane = threadIdx.x & 63;
-    if (blockIdx.x == 0 && threadIdx.x < 2 * ORDER_BINS) scratch_next[threadIdx.x] = 0;
     if (threadIdx.x < ORDER_BINS) hist[threadIdx.x] = 0;
     __syncthreads();
     const int idx = (int)(blockIdx.x * ORDER_THREADS + threadIdx.x);
@@ -1236,7 +1251,8 @@ __global__ __launch_bounds__(ORDER_THREADS) void dlscqp_order_scatter_kernel(Ord
         first[lane] = incl - h + (mine > 0 ? atomicAdd(&scratch[ORDER_BINS + lane], mine) : 0);
     }
     __syncthreads();
-    if (valid) order[first[bin] + within] = idx;
+    const int at = first[bin] + within;
+    if (valid && at >= 0 && at < n) order[at] = idx;  // in range by construction; a corrupted scratch block must not write elsewhere
 }
 }  // namespace
 
@@ -1261,14 +1277,11 @@ static int order_launch(dlscqp_ctx *c, const OrderHist &iters, int32_t n_agents,
     if (n_agents == 0) return DLSCQP_SUCCESS;
     if (!iters.it[0] || !order_out) { g_last_error = "null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
     HIP_TRY(hipSetDevice(c->cfg.device));
-    if (!c->d_order_scratch) {
-        HIP_TRY(hipMalloc((void **)&c->d_order_scratch, 4 * ORDER_BINS * sizeof(int)));
-        HIP_TRY(hipMemset(c->d_order_scratch, 0, 4 * ORDER_BINS * sizeof(int)));
-    }
-    int *cur = c->d_order_scratch + (c->order_calls & 1) * 2 * ORDER_BINS, *nxt = c->d_order_scratch + ((c->order_calls + 1) & 1) * 2 * ORDER_BINS;
-    c->order_calls++;
+    if (!c->d_order_scratch) HIP_TRY(hipMalloc((void **)&c->d_order_scratch, 2 * ORDER_BINS * sizeof(int)));
+    int *cur = c->d_order_scratch;  // one block, used by the calls of a context in stream order (they must not overlap)
     const int grid = (n_agents + ORDER_THREADS - 1) / ORDER_THREADS;
-    hipLaunchKernelGGL(dlscqp_order_count_kernel, dim3(grid), dim3(ORDER_THREADS), 0, (hipStream_t)stream, iters, (int)n_agents, cur, nxt);
+    HIP_TRY(hipMemsetAsync(cur, 0, 2 * ORDER_BINS * sizeof(int), (hipStream_t)stream));
+    hipLaunchKernelGGL(dlscqp_order_count_kernel, dim3(grid), dim3(ORDER_THREADS), 0, (hipStream_t)stream, iters, (int)n_agents, cur);
     hipLaunchKernelGGL(dlscqp_order_scatter_kernel, dim3(grid), dim3(ORDER_THREADS), 0, (hipStream_t)stream, iters, (int)n_agents, cur, order_out);
     HIP_TRY(hipGetLastError());
     return DLSCQP_SUCCESS;
@@ -1460,7 +1473,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static int plan_host(dlscqp_ctx *c, int32_t n_agents, const dlscqp_agent *agents, const int64_t *row_offsets,
                      const dlscqp_lsc_row *rows, const float *sfc_boxes, int32_t max_slack_obs, int do_goal,
                      int do_traj, float *out_goal, int32_t *out_goal_status, float *out_ctrl, double *out_cost,
-                     double *out_slack_cost, int32_t *out_status) {
+                     double *out_slack_cost, int32_t *out_status, int declared_rows_per_agent = 0) {
     g_last_error.clear();
     if (!c) { g_last_error = "null context"; return DLSCQP_ERR_INVALID_ARGUMENT; }
     if (n_agents < 0) { g_last_error = "negative n_agents"; return DLSCQP_ERR_INVALID_ARGUMENT; }
@@ -1526,7 +1539,7 @@ static int plan_host(dlscqp_ctx *c, int32_t n_agents, const dlscqp_agent *agents
     b.max_slack_obs = max_slack_obs;
     b.do_goal = do_goal;
     b.do_traj = do_traj;
-    b.max_rows_per_agent = kmax;
+    b.max_rows_per_agent = std::max(kmax, declared_rows_per_agent);
     b.agents = (const dlscqp_agent *)(d + o_agents);
     b.row_offsets = (const int32_t *)(d + o_off);
     b.nx = (const float *)(d + o_nx); b.ny = (const float *)(d + o_ny); b.nz = (const float *)(d + o_nz);
@@ -1562,6 +1575,117 @@ static int plan_host(dlscqp_ctx *c, int32_t n_agents, const dlscqp_agent *agents
             } else {
                 if (out_cost) out_cost[a] = 0;
             }
+        }
+    }
+    return DLSCQP_SUCCESS;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// self-test (include/dlscqp.h: dlscqp_selftest)
+// ---------------------------------------------------------------------------------------------
+extern "C" int dlscqp_selftest(dlscqp_ctx *c) {
+    g_last_error.clear();
+    if (!c) { g_last_error = "null context"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    const int M = c->M, n = c->n, n1 = n + 1, dim = c->dim;
+    const double dt = c->dt;
+    const float z = dim == 2 ? (float)c->cfg.world_z_2d : (float)(0.5 * (c->cfg.world_min[2] + c->cfg.world_max[2]));
+    const float x0 = (float)(0.5 * (c->cfg.world_min[0] + c->cfg.world_max[0])), y0 = (float)(0.5 * (c->cfg.world_min[1] + c->cfg.world_max[1]));
+    const double horizon = M * dt;
+    // how far agent 0 may go along x: less than it coasts when it brakes as gently as it can (v T / 2 = 0.1 horizon), eight
+    // times its stopping distance at full deceleration -- the wall is active whatever the weights are, and can be met
+    const float wall = (float)(0.08 * horizon);
+    dlscqp_agent ag[2];
+    std::memset(ag, 0, sizeof ag);
+    for (int a = 0; a < 2; a++) {
+        ag[a].position[0] = x0; ag[a].position[1] = y0 + (a ? 0.5f : 0.0f); ag[a].position[2] = z;
+        ag[a].velocity[0] = 0.2f;
+        const float reach = (float)(0.45 * horizon);
+        ag[a].current_goal_point[0] = x0 + reach; ag[a].current_goal_point[1] = ag[a].position[1]; ag[a].current_goal_point[2] = z;
+        ag[a].next_waypoint[0] = x0 + 0.5f * reach; ag[a].next_waypoint[1] = ag[a].position[1]; ag[a].next_waypoint[2] = z;
+        ag[a].id = a; ag[a].n_obs = a == 0 ? 1 : 0; ag[a].n_slack_obs = 0;
+        ag[a].max_vel = 1.0; ag[a].max_acc = 2.0; ag[a].radius = 0.15; ag[a].nominal_velocity = 1.0;
+    }
+    // agent 0: one "neighbour" whose half-spaces are the wall x <= x0 + wall at every control point of the model
+    std::vector<dlscqp_lsc_row> rows;
+    for (int m = 0; m < M; m++)
+        for (int i = 0; i < n1; i++) {
+            if (m == 0 && i < c->phi) continue;
+            dlscqp_lsc_row r;
+            std::memset(&r, 0, sizeof r);
+            r.normal[0] = -1.0f;
+            r.point[0] = x0 + wall; r.point[1] = y0; r.point[2] = z;
+            r.d = 0.0; r.m = (int16_t)m; r.i = (int8_t)i; r.flags = 0; r.obs = 0; r.slack = -1;
+            rows.push_back(r);
+        }
+    const int64_t ro[3] = {0, (int64_t)rows.size(), (int64_t)rows.size()};
+    std::vector<float> sfc;
+    if (c->kp.use_sfc) {
+        sfc.resize((size_t)2 * M * 6);
+        for (int a = 0; a < 2; a++)
+            for (int m = 0; m < M; m++)
+                for (int k = 0; k < 3; k++) {
+                    sfc[((size_t)a * M + m) * 6 + k] = (float)c->cfg.world_min[k];
+                    sfc[((size_t)a * M + m) * 6 + 3 + k] = (float)c->cfg.world_max[k];
+                }
+    }
+    struct Variant { const char *name; int slack_obs, declared_rows, force; };
+    const Variant variants[] = {{"register-cache instantiation", 0, 0, 0}, {"instantiation for long row lists", 0, 1000, 0},
+                                {"instantiation with slack obstacles", 1, 0, 0}, {"runtime-shape instantiation", 1, 1000, 1},
+                                {"working set in HBM", 1, 1000, 2}};
+    const size_t cs = (size_t)3 * M * n1;
+    std::vector<float> ref;
+    for (const Variant &v : variants) {
+        std::vector<float> ctrl(2 * cs, 0.0f);
+        std::vector<double> cost(2, 0.0), slack(2, 0.0);
+        int32_t st[2] = {-99, -99};
+        c->force_instance = v.force;
+        const int rc = plan_host(c, 2, ag, ro, rows.data(), sfc.empty() ? nullptr : sfc.data(), v.slack_obs, 0, 1, nullptr, nullptr, ctrl.data(),
+                                 cost.data(), slack.data(), st, v.declared_rows);
+        c->force_instance = 0;
+        if (rc == DLSCQP_ERR_UNSUPPORTED) continue;  // a shape this build has no such instantiation for
+        if (rc != DLSCQP_SUCCESS) { g_last_error = std::string("selftest (") + v.name + "): " + g_last_error; return rc; }
+        auto fail = [&](const char *what, int a, double val) {
+            char buf[256];
+            std::snprintf(buf, sizeof buf, "selftest failed (%s): %s (agent %d, %.3g) -- this build of libdlscqp does not plan correctly on this "
+                          "machine; rebuild with the flags of __graft_entry__.py", v.name, what, a, val);
+            g_last_error = buf;
+            return DLSCQP_ERR_SELFTEST;
+        };
+        for (int a = 0; a < 2; a++) {
+            if (st[a] != DLSCQP_OK) return fail("verdict is not DLSCQP_OK", a, st[a]);
+            const float *p = ctrl.data() + a * cs;
+            auto at = [&](int m, int i, int k) { return (double)p[((size_t)m * n1 + i) * 3 + k]; };
+            for (int k = 0; k < dim; k++) {
+                const double s1 = n / dt, s2 = n * (n - 1) / (dt * dt);
+                if (std::fabs(at(0, 0, k) - ag[a].position[k]) > 1e-6) return fail("initial position", a, at(0, 0, k));
+                if (std::fabs((at(0, 1, k) - at(0, 0, k)) * s1 - ag[a].velocity[k]) > 1e-3) return fail("initial velocity", a, (at(0, 1, k) - at(0, 0, k)) * s1);
+                if (std::fabs((at(0, 2, k) - 2 * at(0, 1, k) + at(0, 0, k)) * s2) > 5e-2) return fail("initial acceleration", a, 0);
+                for (int m = 1; m < M; m++) {
+                    if (std::fabs(at(m, 0, k) - at(m - 1, n, k)) > 1e-6) return fail("position continuity", a, m);
+                    if (std::fabs((at(m, 1, k) - at(m, 0, k)) - (at(m - 1, n, k) - at(m - 1, n - 1, k))) > 2e-6) return fail("velocity continuity", a, m);
+                }
+                if (c->kp.stop_mode && std::fabs(at(M - 1, n, k) - at(M - 1, n - 1, k)) > 2e-6) return fail("terminal stop", a, k);
+                for (int m = 0; m < M; m++)
+                    for (int i = 0; i < n; i++)
+                        if (std::fabs((at(m, i + 1, k) - at(m, i, k)) * s1) > ag[a].max_vel + 1e-3) return fail("velocity limit", a, m);
+            }
+            double far = -1e30;
+            for (int m = 0; m < M; m++)
+                for (int i = 0; i < n1; i++) {
+                    if (a == 0 && !(m == 0 && i < c->phi) && at(m, i, 0) > (double)x0 + (double)wall + 2e-6) return fail("the wall is crossed", a, at(m, i, 0));
+                    if (std::fabs(at(m, i, 1) - ag[a].position[1]) > 1e-5) return fail("lateral drift", a, at(m, i, 1));
+                    far = std::max(far, at(m, i, 0));
+                }
+            // the wall matters: without it the agent goes past it (agent 1 does), with it the plan touches it
+            if (a == 0 && std::fabs(far - ((double)x0 + (double)wall)) > 1e-5) return fail("the plan does not touch the wall", a, far);
+            if (a == 1 && !(far > (double)x0 + (double)wall + 1e-4)) return fail("the free agent stops short of where the wall would be", a, far);
+        }
+        if (ref.empty()) {
+            ref = ctrl;
+        } else {
+            for (size_t j = 0; j < ctrl.size(); j++)
+                if (std::fabs((double)ctrl[j] - (double)ref[j]) > 1e-6) return fail("differs from the first instantiation's plan", (int)(j / cs), (double)ctrl[j] - (double)ref[j]);
         }
     }
     return DLSCQP_SUCCESS;

@@ -590,6 +590,9 @@ struct GridMapf {
         for (const auto &a : agents)
             if (is_occupied(a.waypoint) || is_occupied(a.goal)) { valid = false; break; }
         if (!valid) update_grid_map(agent_radius, {});
+        bool any_node = false;
+        for (int id = 0; id < n_nodes() && !any_node; id++) any_node = exist[id];
+        if (!any_node) return false;  // every node is occupied: point_to_closest_node has nothing to return (the planner "fails")
         obs_tables.clear();
         for (const auto &o : obstacles) obs_tables.push_back(bfs_table(point_to_closest_node(o.position)));
         update_doi(agents, obstacles, agent_radius);
@@ -643,7 +646,10 @@ extern "C" int dlscqp_mapf_step(dlscqp_mapf *m, const dlscqp_mapf_step_args *s) 
     if (!m || !s || s->n_agents < 0) return DLSCQP_ERR_INVALID_ARGUMENT;
     if (s->n_agents == 0) return DLSCQP_SUCCESS;
     if (!s->position || !s->start_point || !s->desired_goal || !s->current_goal || !s->next_waypoint) return DLSCQP_ERR_INVALID_ARGUMENT;
+    if (s->n_obs < 0 || (s->n_obs > 0 && (!s->obs_position || !s->obs_velocity || !s->obs_radius || !s->obs_max_acc))) return DLSCQP_ERR_INVALID_ARGUMENT;
+    if (s->plans && s->n1 <= 0) return DLSCQP_ERR_INVALID_ARGUMENT;
     GridMapf &g = m->g;
+    if (g.n_nodes() <= 0) return DLSCQP_ERR_INVALID_ARGUMENT;  // a world without a grid: there is nothing to plan on
     const dlscqp_mapf_config &cfg = g.cfg;
     const int N = s->n_agents;
     auto p3 = [](const float *a, int i) { return P3{a[3 * i], a[3 * i + 1], a[3 * i + 2]}; };

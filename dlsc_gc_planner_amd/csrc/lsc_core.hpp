@@ -602,11 +602,13 @@ DQ_FN bool obstacle_reaches(const float *pos, const float *vel, double radius, d
     return false;
 }
 // The part of isPointInFeasibleRegion(point, M-1, n) that does not depend on the rows: last corridor box and the
-// communication-range box around the waypoint (a default Box, i.e. the origin, when the range is unlimited)
+// communication-range box around the waypoint.  The reference sets that box in constructCommunicationRange, which only
+// generateSFC's non-initialising branch calls (traj_planner.cpp:692-705, collision_constraints.cpp:538-546): it is still the
+// default Box -- the origin -- on the first plan, without octomap corridors, and when the range is unlimited.
 DQ_FN bool point_in_boxes(const LscGenArgs &g, const float *sfc_last, const float *wp, const float *pt) {
     if (g.use_sfc && sfc_last && !point_in_box(sfc_last, sfc_last + 3, pt)) return false;
     float cmin[3] = {0, 0, 0}, cmax[3] = {0, 0, 0};
-    if (g.comm_range > 0) {
+    if (g.comm_range > 0 && g.use_sfc && !g.first_plan) {
         const float dl = (float)(0.5 * g.comm_range);
         for (int k = 0; k < 3; k++) { cmin[k] = wp[k] - dl; cmax[k] = wp[k] + dl; }
     }

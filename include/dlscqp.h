@@ -38,7 +38,8 @@ enum {
     DLSCQP_ERR_INVALID_ARGUMENT = -1, /* std::invalid_argument in the reference (traj_optimizer.cpp:209,248) */
     DLSCQP_ERR_HIP = -2,              /* a HIP runtime call failed; see dlscqp_last_error() */
     DLSCQP_ERR_NO_DEVICE = -3,
-    DLSCQP_ERR_UNSUPPORTED = -4
+    DLSCQP_ERR_UNSUPPORTED = -4,
+    DLSCQP_ERR_SELFTEST = -5          /* dlscqp_selftest: the kernels of this build do not solve a known problem; see dlscqp_last_error() */
 };
 
 /* Per-agent verdicts written to out_status[]. */
@@ -286,6 +287,20 @@ typedef struct dlscqp_lsc_gen {
 } dlscqp_lsc_gen;
 
 int dlscqp_generate_lsc_device(dlscqp_ctx *ctx, const dlscqp_lsc_gen *gen, void *stream);
+
+/* Self-test of the plan kernels, run by dlscqp_create (DLSCQP_NO_SELFTEST=1 in the environment skips it there).  The
+ * kernels keep ~100 registers of per-lane state across a data-dependent loop and read other lanes' registers; twice a
+ * developer-only compiler configuration has produced an instantiation that returned wrong plans ("NO
+ * DIVERGENCE").  So that a miscompiling toolchain fails loudly on the user's machine and not silently in flight: a wall
+ * problem of the context's own shape (an agent drifting at a half-space that it reaches even when it brakes as gently as
+ * it can, plus an agent that is free to go) is planned by every kernel instantiation a batch of this context can be handed -- the one
+ * select_instance picks with all rows in the register cache, the one for longer row lists, the one for batches with slack
+ * obstacles, the runtime-shape one, the variant with its working set in HBM -- and every answer must (1) report DLSCQP_OK,
+ * (2) keep the initial state, continuity to the second derivative and the terminal stop, (3) satisfy the wall, the box and
+ * the velocity limit, touch the wall (agent 0) or pass where it would be (agent 1), (4) agree with the other
+ * instantiations' to 1e-6 m.  Returns DLSCQP_SUCCESS or DLSCQP_ERR_SELFTEST.
+ * A few launches of two agents: well under a millisecond after the first launch of the process.                        */
+int dlscqp_selftest(dlscqp_ctx *ctx);
 
 /* The communication-range filter of MultiSyncSimulator::broadcastMsgs (multi_sync_simulator.cpp:482-503) on the device:
  * local agent k is told about every other agent qj with LInfinityDistance(position_k, position_qj) <= communication_range

@@ -410,14 +410,15 @@ static int oracle_box_contains(const float bmin[3], const float bmax[3], const f
     return 1;
 }
 static int oracle_feasible_last(const dlscqp_config *cfg, const dlscqp_lsc_row *rows, int n_nbr, int per, const float *sfc_last,
-                                const float wp[3], const float pt[3]) { /* isPointInFeasibleRegion(point, M-1, n), :586-598 */
+                                const float wp[3], const float pt[3], int first_plan) { /* isPointInFeasibleRegion(point, M-1, n), :586-598 */
     for (int oi = 0; oi < n_nbr; oi++) {
         const dlscqp_lsc_row *last = rows + (size_t)oi * per + (per - 1); /* (M-1, n) is the last row of an obstacle */
         if (!oracle_lsc_contains(last, pt)) return 0;
     }
     if (cfg->world_use_octomap && sfc_last && !oracle_box_contains(sfc_last, sfc_last + 3, pt)) return 0;
-    float cmin[3] = {0, 0, 0}, cmax[3] = {0, 0, 0}; /* Box() until constructCommunicationRange sets it (:538-546) */
-    if (cfg->communication_range > 0) {
+    float cmin[3] = {0, 0, 0}, cmax[3] = {0, 0, 0}; /* Box() until constructCommunicationRange sets it (:538-546), which only the
+                                                      * non-initialising branch of generateSFC calls (traj_planner.cpp:692-705) */
+    if (cfg->communication_range > 0 && cfg->world_use_octomap && !first_plan) {
         float dl = (float)(0.5 * cfg->communication_range);
         for (int k = 0; k < 3; k++) { cmin[k] = wp[k] - dl; cmax[k] = wp[k] + dl; }
     }
@@ -425,11 +426,11 @@ static int oracle_feasible_last(const dlscqp_config *cfg, const dlscqp_lsc_row *
 }
 int oracle_waypoint_trap(const dlscqp_config *cfg, dlscqp_lsc_row *rows, int n_nbr, int n_dyn, const dlscqp_agent *agent,
                          const float *sfc_last, const float *dyn_position, const float *dyn_velocity, const double *dyn_radius,
-                         const double *dyn_max_acc, double uncertainty_horizon) {
+                         const double *dyn_max_acc, double uncertainty_horizon, int first_plan) {
     const int per = cfg->M * (cfg->n + 1) - cfg->phi;
     if (n_dyn <= 0) return 0;
     const float *cg = agent->current_goal_point, *wp = agent->next_waypoint;
-    if (oracle_feasible_last(cfg, rows, n_nbr, per, sfc_last, wp, cg) && oracle_feasible_last(cfg, rows, n_nbr, per, sfc_last, wp, wp)) return 0;
+    if (oracle_feasible_last(cfg, rows, n_nbr, per, sfc_last, wp, cg, first_plan) && oracle_feasible_last(cfg, rows, n_nbr, per, sfc_last, wp, wp, first_plan)) return 0;
     int released = 0;
     const double horizon = cfg->M * cfg->dt;
     for (int o = 0; o < n_dyn; o++) {

@@ -282,12 +282,13 @@ def obstacle_disturbance(pred, obs_position, reset_threshold):
     return p, bool(r)
 
 
-def waypoint_trap(cfg, rows, n_nbr, agent, sfc_last, dyn):
+def waypoint_trap(cfg, rows, n_nbr, agent, sfc_last, dyn, first_plan=False):
     """TrajPlanner::checkWaypointTrap on one agent's rows (neighbour agents first, then the dynamic obstacles of `dyn`):
-    returns (rows', number of released obstacles)."""
+    returns (rows', number of released obstacles).  first_plan: the step on which generateSFC only initialises the corridor
+    (the communication-range box is then still the default Box)."""
     L = lib()
     vp = C.c_void_p
-    L.oracle_waypoint_trap.argtypes = [C.POINTER(abi.Config), vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_double]
+    L.oracle_waypoint_trap.argtypes = [C.POINTER(abi.Config), vp, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, C.c_double, C.c_int]
     L.oracle_waypoint_trap.restype = C.c_int
     r = np.ascontiguousarray(rows, dtype=abi.ROW_DTYPE).copy()
     ag = np.ascontiguousarray(agent, dtype=abi.AGENT_DTYPE).reshape(1)
@@ -296,7 +297,7 @@ def waypoint_trap(cfg, rows, n_nbr, agent, sfc_last, dyn):
     dp, dv = np.ascontiguousarray(dyn["position"], np.float32), np.ascontiguousarray(dyn["velocity"], np.float32)
     dr, da = np.ascontiguousarray(dyn["radius"], np.float64), np.ascontiguousarray(dyn["max_acc"], np.float64)
     rel = L.oracle_waypoint_trap(C.byref(cfg), _ptr(r), int(n_nbr), n_dyn, _ptr(ag), _ptr(box), _ptr(dp), _ptr(dv), _ptr(dr), _ptr(da),
-                                 float(dyn.get("horizon", 1.0)))
+                                 float(dyn.get("horizon", 1.0)), int(bool(first_plan)))
     return r, rel
 
 

@@ -29,6 +29,8 @@ def test_hip_path_reproduces_the_logged_cplex_run(gpu_required):
     ok = sc <= 1.0
     print("HIP vs the reference's log: %d of %d (agent, step) pairs within the log's precision, worst %.2f" % (ok.sum(), ok.size, sc.max()))
     assert ok.sum() >= 1680 and sc.max() <= 2.0
+    from test_log_replay import assert_the_known_misses
+    assert_the_known_misses(sc)  # the same 27 answers as the oracle and the kernel source, by name
     act = out["kat"]["active"]
     assert int((ok & (act[:, :, 0] > 0)).sum()) >= 40      # velocity limit active
     assert int((ok & (act[:, :, 1] > 0)).sum()) >= 10      # acceleration limit active

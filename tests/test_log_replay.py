@@ -16,6 +16,18 @@ import log_replay as R
 # the file was mined; the other 27 are within twice that (position: 3e-6 m + 3 print units)
 MIN_KNOWN_ANSWERS = 1680
 WORST_SCORE = 2.0
+# The 27 (step, agent) answers outside the printed precision, by name: all of them are POSITION misses of at most 1.94
+# tolerances (velocity and acceleration are inside), spread over all agents and steps 8-141 with no row family
+# over-represented (9 with a corridor row active, 2 DLSC-GC, 1 velocity) -- CPLEX's own ~1e-6 m noise (the log's
+# mirror-symmetric agents differ from each other by that much).  The oracle, the kernel source and the HIP kernel miss the
+# SAME 27: a change that moved one answer in or out of the set is a change of the solution, not of the noise.
+MISSES = [(8, 3), (16, 1), (21, 0), (26, 4), (30, 3), (40, 3), (44, 0), (53, 1), (58, 5), (60, 9), (63, 6), (70, 4), (70, 8), (76, 8),
+          (77, 2), (78, 9), (81, 9), (90, 5), (108, 6), (113, 5), (115, 8), (117, 5), (121, 6), (124, 1), (131, 5), (134, 6), (141, 8)]
+
+
+def assert_the_known_misses(sc):
+    got = sorted((int(a), int(b)) for a, b in np.argwhere(sc > 1.0))
+    assert got == MISSES, (sorted(set(got) - set(MISSES)), sorted(set(MISSES) - set(got)))
 
 
 def test_oracle_reproduces_the_whole_logged_run():
@@ -25,6 +37,12 @@ def test_oracle_reproduces_the_whole_logged_run():
     ok = sc <= 1.0
     assert ok.sum() >= MIN_KNOWN_ANSWERS, ok.sum()
     assert sc.max() <= WORST_SCORE, sc.max()
+    assert_the_known_misses(sc)
+    # every miss is a position miss: velocity and acceleration of those plans are inside their tolerances
+    for k, i in MISSES:
+        e1, e2 = R.log_states(out["log"], k, i)
+        e = R.errors(out["sols"][k * 10 + i]["ctrl"], out["cfg"].dt, e1, e2)
+        assert e[0] > 1.0 and e[1] <= 1.0 and e[2] <= 1.0, (k, i, e)
     assert np.allclose(sc, out["kat"]["score"], atol=1e-6)  # what the mining run saw
     st = np.array([s["status"] for s in out["sols"]])
     assert (st == abi.OK).all()  # the reference's run never hit QPFAILED either (it would have stopped, multi_sync_simulator.cpp:521)
@@ -66,6 +84,7 @@ def test_kernel_source_reproduces_the_logged_run():
     assert (got["status"] == abi.OK).all()
     sc = R.score_batch(out, got["ctrl"], got["status"])
     assert (sc <= 1.0).sum() >= MIN_KNOWN_ANSWERS and sc.max() <= WORST_SCORE
+    assert_the_known_misses(sc)
     ref_goal = np.stack([s["goal"] for s in out["sols"]])
     assert np.array_equal(got["goal"], ref_goal)  # sub-goals bit-exact
     ref_x = np.stack([s["x"] for s in out["sols"]])

@@ -249,6 +249,33 @@ def test_waypoint_trap_releases_the_same_obstacles_as_the_oracle(M, dim, comm):
         assert (released > 0).sum() >= 2
 
 
+def test_waypoint_trap_on_the_first_plan_uses_the_default_communication_box():
+    """On the first plan generateSFC only initialises the corridor (traj_planner.cpp:692-705): constructCommunicationRange
+    has not run yet, the communication box is the default Box at the origin, every agent counts as trapped and every
+    dynamic obstacle within reach of its waypoint is released -- device helpers and oracle agree, and differ from a later
+    step's answer on the same geometry."""
+    cfg = abi.make_config(dim=3, M=5, communication_range=3.0, world_use_octomap=True)
+    N = 18
+    sw = lsc_cases.random_swarm(cfg, N, seed=505)
+    dyn = lsc_cases.random_dynamic_obstacles(3, seed=45)
+    ag, sfc = lsc_cases.trap_agents(cfg, sw, dyn, seed=5)
+    pos, vel = sw["plans"][:, 0, 0].copy(), np.zeros((N, 3), np.float32)
+    trap = dict(agents=ag, sfc=sfc)
+    eo, erows = E.generate_lsc(cfg, None, sw["goals"], sw["radius"], sw["downwash"], sw["nbr_offsets"], sw["nbr_ids"], position=pos,
+                               velocity=vel, dyn=dyn, trap=trap)
+    _, before = E.generate_lsc(cfg, None, sw["goals"], sw["radius"], sw["downwash"], sw["nbr_offsets"], sw["nbr_ids"], position=pos,
+                               velocity=vel, dyn=dyn)
+    first, later = np.zeros(N, np.int32), np.zeros(N, np.int32)
+    for a in range(N):
+        n_nbr = int(sw["nbr_offsets"][a + 1] - sw["nbr_offsets"][a])
+        exp_rows, first[a] = O.waypoint_trap(cfg, before[eo[a]:eo[a + 1]], n_nbr, ag[a], sfc[a, -1], dyn, first_plan=True)
+        _, later[a] = O.waypoint_trap(cfg, before[eo[a]:eo[a + 1]], n_nbr, ag[a], sfc[a, -1], dyn, first_plan=False)
+        for k in ("normal", "point", "d"):
+            assert np.array_equal(erows[eo[a]:eo[a + 1]][k], exp_rows[k]), (a, k)
+    assert np.array_equal(trap["released"], first)
+    assert (first >= later).all() and first.sum() > 0  # the default box traps everybody: never fewer releases than later
+
+
 @pytest.mark.parametrize("M,dim,n_dyn", [(10, 2, 0), (10, 3, 2), (5, 3, 0)])
 def test_pruned_rows_are_implied_rows_and_the_plans_do_not_change(M, dim, n_dyn):
     """The generator's presolve (dlscqp_lsc_gen.prune): every row it drops is implied by the agent's corridor / world box with
