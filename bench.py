@@ -220,6 +220,12 @@ def closed_loop_latency(device):
             extra["cpu_port_ms"] = ms
             extra["cpu_port_threads"] = nt
             extra["cpu_port_note"] = "goal LP + QP of one mid-flight step on the host (lane-serial -O3 build of the kernel source), inputs read back from HBM"
+            gpu_ms = extra["stage_p50_ms"].get("traj_optimization_time")
+            if gpu_ms:
+                extra["lp_qp_gpu_ms_over_cpu_port_ms"] = gpu_ms / ms
+                extra["verdict"] = ("%d host threads plan this step's %d LP + QPs %.1fx faster than the GPU launch does (one wavefront per "
+                                    "agent leaves the chip empty at this size; the launch alone is ~10 us)" % (nt, len(inputs[0]), gpu_ms / ms)
+                                    if ms < gpu_ms else "the GPU launch plans this step's LP + QPs %.1fx faster than %d host threads" % (ms / gpu_ms, nt))
         except Exception as e:  # the checker library is optional for the bench line
             extra["cpu_port_ms"] = None
             extra["cpu_port_note"] = "unavailable: %s" % e
@@ -470,6 +476,83 @@ class StressStep:
         self.opt.close()
 
 
+def over_ranks(dist, dev, values):
+    """{name: {"min", "max", "mean"} over the ranks} of one float per rank and name (one small all-gather)."""
+    import torch
+    names = sorted(values)
+    t = torch.tensor([float(values[k]) for k in names], dtype=torch.float64, device=dev)
+    if dist is not None:
+        world = dist.get_world_size()
+        out = torch.empty(world * len(names), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(out, t)
+        m = out.view(world, len(names)).cpu().numpy()
+    else:
+        m = t.cpu().numpy()[None, :]
+    return {k: {"min": float(m[:, i].min()), "max": float(m[:, i].max()), "mean": float(m[:, i].mean())} for i, k in enumerate(names)}
+
+
+def exchange_breakdown(xchg, skip=0):
+    """Mean ms per exchange of a PlanExchange that was timed (sharding.PlanExchange.enable_timing)."""
+    import numpy as np
+    t = xchg.times()
+    return {"pack_ms": float(np.mean(t["pack"][skip:])) if len(t.get("pack", [])) > skip else float("nan"),
+            "all_gather_ms": float(np.mean(t["all_gather"][skip:])) if len(t.get("all_gather", [])) > skip else float("nan"),
+            "output_ready_to_gathered_ms": float(np.mean(t["lag"][skip:])) if len(t.get("lag", [])) > skip else float("nan"),
+            "wait_for_table_ms": float(np.mean(t["wait"][skip:])) if len(t.get("wait", [])) > skip else 0.0}
+
+
+def sharded_mission(dist, rank, world, device, steps=50, warm=10):
+    """BASELINE.json configs[2]: the empty60 mission flown in closed loop with its 60 agents sharded over the ranks and the
+    RCCL all-gather of plans, sub-goals and verdicts on the critical path of every step (every agent neighbours every other
+    one: harness.ShardedLoop).  ms per step = max over the ranks of (wall time of `steps` steps) / steps, steps queued
+    without synchronising; the breakdown is per rank (HIP events on the compute and the communication stream)."""
+    import numpy as np
+    import torch
+    from dlsc_gc_planner_amd import abi
+    from dlsc_gc_planner_amd.harness import ShardedLoop
+    m = json.load(open(os.path.join(ROOT, "tests", "golden", "missions_empty.json")))["empty60_1"]
+    w = m["world"]
+    cfg = abi.make_config(dim=3, M=5, dt=0.2, control_input_weight=0.01, terminal_weight=1.0, communication_range=-1.0,
+                          world_use_octomap=False, world_min=tuple(w[:3]), world_max=tuple(w[3:]), device=device)
+    dev = torch.device("cuda", device)
+    sim = ShardedLoop(cfg, np.array(m["start"], np.float32), np.array(m["goal"], np.float32), dist, rank, world, radius=m["radius"],
+                      downwash=m["downwash"], max_vel=m["max_vel"], max_acc=m["max_acc"], nominal_velocity=m["nominal_velocity"], device=device)
+    for _ in range(warm):
+        sim.step()
+    torch.cuda.synchronize(dev)
+    sim.xchg.enable_timing()
+    sim.opt.set_timing(steps)
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sim.step()
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    el = time.perf_counter() - t0
+    tt = torch.tensor([el], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    kms = sim.opt.kernel_times_ms(steps)
+    per_rank = exchange_breakdown(sim.xchg)
+    per_rank["plan_kernel_ms"] = float(np.mean(kms)) if len(kms) else float("nan")
+    st = sim.batch.results()["status"]
+    fails = torch.tensor([int((st != abi.OK).sum())], dtype=torch.int64, device=dev)
+    dist.all_reduce(fails)
+    moved = float((sim.plans_all[:, 0, 0] - torch.from_numpy(np.array(m["start"], np.float32)).to(dev)).norm(dim=1).mean())
+    out = {"mission": "empty60_1", "agents": 60, "agents_this_rank": sim.hi - sim.lo, "ranks": world, "steps_timed": steps,
+           "ms_per_step": float(tt.item()) / steps * 1e3, "qp_failsafes_last_step_all_ranks": int(fails.item()),
+           "mean_distance_flown_m": moved,
+           "per_rank_ms": over_ranks(dist, dev, per_rank),
+           "per_rank_note": "plan_kernel_ms: HIP events around the LP + QP launch; pack / all_gather / output_ready_to_gathered: events "
+                            "on the compute and communication streams of sharding.PlanExchange; wait_for_table: how long the compute "
+                            "stream stood still for the gathered table; min / max / mean over the ranks",
+           "exchange": "one all-gather of [agents, 94] float32 (plans, sub-goal, verdict) per step, on the critical path: every agent "
+                       "reads every other agent's previous plan"}
+    sim.close()
+    return out
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -485,6 +568,11 @@ def main():
     dev = torch.device("cuda", local_rank)
     dist = None
     use_dist = world > 1 or args.force_dist
+    # stdout carries ONE line, the JSON: libraries that write to file descriptor 1 themselves (RCCL prints its version
+    # there) are sent to stderr for the life of the process
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -494,6 +582,10 @@ def main():
         opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=opts)
         world = dist.get_world_size()  # n_gpus in the line = the ranks RCCL really has
+        if world != args.gpus and not args.force_dist:
+            raise SystemExit("bench.py --gpus %d, but the process group has %d ranks: the line would report the wrong N" % (args.gpus, world))
+        if torch.cuda.device_count() < (1 if args.force_dist else args.gpus):
+            raise SystemExit("bench.py --gpus %d, but only %d devices are visible" % (args.gpus, torch.cuda.device_count()))
 
     from dlsc_gc_planner_amd import abi, workloads
     from dlsc_gc_planner_amd.planner import BatchTrajOptimizer
@@ -598,8 +690,16 @@ def main():
         return el
 
     head_pipelined = use_dist and pipelined_ok and args.exchange == "pipelined"
+    if use_dist:
+        xchg.enable_timing()
     elapsed = timed(args.steps, head_pipelined, "device", record_kernel_times=True)
     kms = opt.kernel_times_ms(args.steps)
+    rank_breakdown = None
+    if use_dist:
+        br = exchange_breakdown(xchg, skip=B)  # the first B exchanges are the untimed warm-up steps of timed()
+        xchg.enable_timing(False)
+        br["plan_kernel_ms"] = float(np.mean(kms)) if len(kms) else float("nan")
+        rank_breakdown = over_ranks(dist, dev, br)
     if use_dist:
         # the gathered table must hold this rank's own block of the last step
         last = dbs[(args.steps - 1) % B]
@@ -634,13 +734,23 @@ def main():
         ms_id_order = ss_id.time(30, False)
         ss_id.close()
         ss = StressStep(local_rank, rank, world, dist if use_dist else None)
+        stress_br = None
+        if use_dist:
+            ss.xchg.enable_timing()
         ms_serial = ss.time(30, False)
+        if use_dist:
+            stress_br = {"serial": over_ranks(dist, dev, exchange_breakdown(ss.xchg, skip=3))}
+            ss.xchg.enable_timing()
         ms_pipe = ss.time(30, True) if use_dist else None
+        if use_dist:
+            stress_br["pipelined"] = over_ranks(dist, dev, exchange_breakdown(ss.xchg, skip=3))
+            ss.xchg.enable_timing(False)
         stress = {"workload": "X2048 (BASELINE.json configs[4]): 2 048 agents in one 2-D maze-density crowd, M = 10, corridor boxes, "
                               "communication range 3, %.0f DLSC-GC rows per agent generated on the device; STRONG scaling, agents "
                               "sharded by contiguous id range" % ss.rows_per_agent,
                   "agents_total": ss.N, "agents_this_rank": ss.n_loc, "interior_agents_rank0": ss.n_interior, "halo_agents_rank0": ss.n_halo,
                   "ms_per_step_serial_exchange": ms_serial, "ms_per_step_pipelined_exchange": ms_pipe,
+                  "exchange_per_rank_ms": stress_br,
                   "ms_per_step_without_presolve": ms_all_rows, "ms_per_step_id_launch_order": ms_id_order,
                   "launch_order": "every step computes the next step's launch order on the device from its own iteration counts "
                                   "(dlscqp_launch_order_device, inside the timed step); the batch is stationary, so the hint is "
@@ -652,6 +762,10 @@ def main():
                   "includes": "half-space generation + goal LP + QP" + (" + all-gather of the plans + copy into the plan table" if use_dist else ""),
                   "solved_fraction_rank0": ss.solved_fraction()}
         ss.close()
+    # BASELINE.json configs[2]: empty60 sharded over the ranks, the exchange on the critical path
+    sharded = None
+    if use_dist and not args.no_extras and not args.headline_only:
+        sharded = sharded_mission(dist, rank, world, local_rank)
 
     if rank == 0:
         ok = np.concatenate([r["status"] for r in res]) == abi.OK
@@ -687,26 +801,36 @@ def main():
                 opt.plan(a1, ro1, r1, None, 0, True, True)
                 lat.append((time.perf_counter() - t1) * 1e3)
             lat = np.array(lat[10:])
-            # "hard" batch: only agents that end with at least five active rows, taken from the timed batches and tiled to
-            # the same launch size; launch order from a permutation-free hint is not available here: id order
+            # "hard" batch: only agents that end with at least five active rows, taken from the timed batches and tiled to the
+            # same launch size.  Launch order: like the headline's, from what a closed loop knows -- the iteration count the SAME
+            # agent had one replanning step earlier (the previous batch of the rotation) -- sorted on the device
             sel = [(j, a) for j in range(B) for a in np.nonzero((res[j]["iters"][:, 3] >= 5) & (res[j]["status"] == abi.OK))[0]]
             if len(sel) >= 64:
                 pick = [sel[i % len(sel)] for i in range(N)]
                 ha = np.concatenate([hist[j]["agents"][a:a + 1] for j, a in pick])
                 hr = np.concatenate([hist[j]["rows"][a * K:(a + 1) * K] for j, a in pick])
                 hdb = opt.make_device_batch(ha, np.arange(N + 1) * K, hr, None, 0, want_iters=True)
-                for _ in range(5):
-                    hdb.launch(True, True)
-                torch.cuda.synchronize(dev)
-                t1 = time.perf_counter()
-                for _ in range(100):
-                    hdb.launch(True, True)
-                torch.cuda.synchronize(dev)
-                hms = (time.perf_counter() - t1) / 100 * 1e3
+                prev = np.zeros((N, 4), np.int32)
+                prev[:, 0] = [res[(j - 1) % B]["iters"][a, 0] for j, a in pick]
+                prev_t = torch.from_numpy(prev).to(dev)
+                hms = {}
+                for tag in ("id_order", "hinted"):
+                    if tag == "hinted":
+                        hdb.update_order(iters=prev_t)
+                    for _ in range(5):
+                        hdb.launch(True, True)
+                    torch.cuda.synchronize(dev)
+                    t1 = time.perf_counter()
+                    for _ in range(100):
+                        hdb.launch(True, True)
+                    torch.cuda.synchronize(dev)
+                    hms[tag] = (time.perf_counter() - t1) / 100 * 1e3
                 hit = hdb.results()["iters"]
-                hard = {"agents_per_launch": N, "distinct_agents": len(sel), "ms_per_step": hms, "qp_per_s": N / hms * 1e3,
+                hard = {"agents_per_launch": N, "distinct_agents": len(sel), "ms_per_step": hms["hinted"], "qp_per_s": N / hms["hinted"] * 1e3,
+                        "ms_per_step_id_order": hms["id_order"],
                         "mean_active_set_iterations": float(hit[:, 0].mean()), "mean_active_rows": float(hit[:, 3].mean()),
-                        "note": "every agent has >= 5 active rows at its solution; id launch order"}
+                        "note": "every agent has >= 5 active rows at its solution; launched in the order of the iteration counts the same "
+                                "agents had one replanning step earlier (dlscqp_launch_order_device), like the headline"}
                 del hdb
             closed = closed_loop_latency(local_rank)
         line = {
@@ -745,6 +869,9 @@ def main():
                 "max_active_set_iterations": int(it[:, 0].max()), "zero_iteration_fraction": float((it[:, 0] == 0).mean()),
                 "seed": args.seed, "workload_generation_s": t_gen,
             },
+            "n_gpus_requested": args.gpus, "n_gpus_visible": int(torch.cuda.device_count()),
+            "per_rank_ms": rank_breakdown,
+            "empty60_sharded": sharded,
             "hard_batch": hard,
             "x2048_strong": stress,
             "p50_replan_ms_one_swarm_host_to_host": None if lat is None else float(np.percentile(lat, 50)),
@@ -767,7 +894,8 @@ def main():
         }
         if not args.no_cpu_baseline and not args.headline_only and world == 1:
             line["cpu_baseline"] = cpu_baseline(cfg, hist[-1])
-        print(json.dumps(line))
+        json_out.write(json.dumps(line) + "\n")
+        json_out.flush()
     opt.close()
     if use_dist:
         dist.barrier()

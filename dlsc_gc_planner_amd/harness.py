@@ -496,6 +496,102 @@ class ClosedLoop:
         return float(dist.min() / (2 * self.radius))
 
 
+class ShardedLoop:
+    """BASELINE.json configs[2]: an obstacle-free mission flown in closed loop with its agents sharded over the ranks of a
+    torch.distributed group by contiguous id range (sharding.shard_range).  Every rank holds the table of everybody's
+    previous plans and sub-goals; per replanning step it generates the half-spaces of ITS agents from that table, plans them
+    (goal LP + QP), updates their states, and ONE all-gather (sharding.PlanExchange: RCCL over xGMI) of plans, sub-goals and
+    verdicts rebuilds the table -- the reference's broadcastMsgs (multi_sync_simulator.cpp:468-514) ahead of its plan loop
+    (:516-524).  In these missions every agent neighbours every other (communication range -1): every agent is a halo
+    agent and the exchange is on the critical path by necessity.  With world size 1 (one-rank group) the same code runs
+    with a one-rank all-gather."""
+
+    def __init__(self, cfg, start, goal, dist, rank, world, radius=0.15, downwash=2.0, max_vel=1.0, max_acc=2.0,
+                 nominal_velocity=1.0, waypoint_step=0.5, device=0):
+        import torch
+        from . import sharding
+        self.torch, self.dist, self.rank, self.world, self.cfg = torch, dist, rank, world, cfg
+        self.opt = BatchTrajOptimizer(cfg)
+        dev = torch.device("cuda", device)
+        self.dev = dev
+        N = len(start)
+        self.N = N
+        M, n = cfg.M, cfg.n
+        lo, hi = sharding.shard_range(N, rank, world)
+        self.lo, self.hi = lo, hi
+        nl = hi - lo
+        self.pad = max(sharding.shard_sizes(N, world))
+        f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)  # noqa: E731
+        start, goal = np.asarray(start, np.float32), np.asarray(goal, np.float32)
+        # the table every rank holds
+        self.plans_all = f32(np.broadcast_to(start[:, None, None, :], (N, M, n + 1, 3)).copy())  # hovering at the start
+        self.goals_all = f32(start)
+        self.pos_all, self.vel_all = f32(start), torch.zeros((N, 3), dtype=torch.float32, device=dev)
+        ids = np.arange(N)
+        own = np.arange(lo, hi)
+        nbr_ids = np.concatenate([np.delete(ids, a) for a in own]) if N > 1 else np.zeros(0, np.int32)
+        self.gen = self.opt.make_lsc_generator(N, np.arange(nl + 1) * (N - 1), nbr_ids, np.full(N, radius), np.full(N, downwash),
+                                               local_ids=own.astype(np.int32), device=device)
+        agents = np.zeros(nl, abi.AGENT_DTYPE)
+        agents["id"] = own
+        agents["n_obs"] = N - 1
+        agents["max_vel"], agents["max_acc"], agents["radius"], agents["nominal_velocity"] = max_vel, max_acc, radius, nominal_velocity
+        for k in ("position", "current_goal_point", "next_waypoint"):
+            agents[k] = start[lo:hi]
+        ro = self.gen.row_offsets
+        self.batch = self.opt.make_device_batch(agents, ro, np.zeros(0, abi.ROW_DTYPE), None, 0, want_iters=True, device=device)
+        for k in ("nx", "ny", "nz", "px", "py", "pz", "d", "key"):
+            setattr(self.batch.c, k, self.gen.soa[k].data_ptr())
+        self.ro32 = torch.from_numpy(ro.astype(np.int32)).to(dev)
+        self.batch.c.row_offsets = self.ro32.data_ptr()
+        self.batch.c.max_rows_per_agent = int(np.diff(ro).max()) if nl else 0
+        self.plans = self.plans_all[lo:hi].clone()
+        self.init_buf = self.plans.clone()
+        self.cur_goal = f32(start[lo:hi])
+        self.desired_goal = f32(goal[lo:hi])
+        a = self.batch.t["agents"].view(torch.float32).view(nl, abi.AGENT_DTYPE.itemsize // 4)
+        self.pos, self.wp = a[:, 0:3], a[:, 12:15]
+        to_goal = self.desired_goal - self.pos
+        dist_ = to_goal.norm(dim=1, keepdim=True)
+        self.wp.copy_(torch.where(dist_ <= waypoint_step, self.desired_goal, self.pos + to_goal / dist_.clamp_min(1e-9) * waypoint_step))
+        self.advance = self.opt.make_advance(self.batch, self.plans, self.cur_goal, self.init_buf, desired_goal=self.desired_goal,
+                                             waypoint_step=waypoint_step)
+        E = M * (n + 1) * 3
+        self.E = E
+        self.xchg = sharding.PlanExchange(dist, world, self.pad, (E, 3, 1), dev)
+        self.send_plans = torch.zeros((self.pad, E), dtype=torch.float32, device=dev)
+        self.send_goal = torch.zeros((self.pad, 3), dtype=torch.float32, device=dev)
+        self.send_status = torch.zeros((self.pad, 1), dtype=torch.int32, device=dev)
+        rows = np.concatenate([r * self.pad + np.arange(sharding.shard_range(N, r, world)[1] - sharding.shard_range(N, r, world)[0])
+                               for r in range(world)])
+        self.valid_rows = torch.from_numpy(rows.astype(np.int64)).to(dev)
+        self.seq = 0
+
+    def step(self):
+        """One replanning step of this rank's agents and the exchange that follows it; asynchronous."""
+        torch = self.torch
+        nl = self.hi - self.lo
+        if self.seq == 0:
+            self.gen.generate(self.goals_all, position=self.pos_all, velocity=self.vel_all)
+        else:
+            self.gen.generate(self.goals_all, plans=self.plans_all)
+        self.batch.launch(True, True)
+        self.advance()
+        self.send_plans[:nl].copy_(self.plans.view(nl, -1))
+        self.send_goal[:nl].copy_(self.cur_goal)
+        self.send_status[:nl].copy_(self.batch.out_status.view(nl, 1))
+        self.xchg.post(self.send_plans, self.send_goal, self.send_status)
+        table = self.xchg.table()  # every agent of the next step reads other ranks' plans: wait here
+        if self.world > 1 or self.pad * self.world != self.N:
+            table = table.index_select(0, self.valid_rows)
+        self.plans_all.view(self.N, -1).copy_(table[:, :self.E])
+        self.goals_all.copy_(table[:, self.E:self.E + 3])
+        self.seq += 1
+
+    def close(self):
+        self.opt.close()
+
+
 class MapfWaypoints:
     """The reference's decentralised waypoint planner (MultiSyncSimulator::decentralizedMAPP: communication groups, grid
     map, PIBT, waypoint update rules; multi_sync_simulator.cpp:308-466, grid_based_planner.cpp, src/mapf/pibt.cpp) through

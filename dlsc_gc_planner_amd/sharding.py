@@ -84,6 +84,28 @@ class PlanExchange:
         self.comm = torch.cuda.Stream(device) if self.cuda else None
         self.k = 0
         self.last = None
+        self._ev = None  # enable_timing(): per exchange (ready, packed, gathered) events; per table(): (before, after) the wait
+
+    def enable_timing(self, on=True):
+        """CUDA: record events around the pack, the all-gather and the consumer's wait of every following exchange;
+        times() returns what they measured (a diagnosis of where a multi-GPU step's time goes, not a product path)."""
+        self._ev = {"post": [], "wait": []} if (on and self.cuda) else None
+
+    def times(self):
+        """dict of float arrays in ms, one entry per exchange: 'pack' (packing the rank's output), 'all_gather' (the
+        collective on the communication stream, from the end of the pack), 'lag' (from the compute stream's 'output ready'
+        event to the end of the collective: what an un-overlapped exchange costs), 'wait' (how long the consumer's stream
+        really stood still in table())."""
+        import numpy as np
+        if not self._ev:
+            return {}
+        self.torch.cuda.synchronize(self.device)
+        post, wait = self._ev["post"], self._ev["wait"]
+        out = {"pack": np.array([a.elapsed_time(b) for a, b, c in post]),
+               "all_gather": np.array([b.elapsed_time(c) for a, b, c in post]),
+               "lag": np.array([a.elapsed_time(c) for a, b, c in post]),
+               "wait": np.array([a.elapsed_time(b) for a, b in wait])}
+        return out
 
     def _pack(self, b, parts):
         torch = self.torch
@@ -106,24 +128,39 @@ class PlanExchange:
         torch = self.torch
         b = self.k & 1
         self.k += 1
+        timed = self._ev is not None
+        ev = (lambda: torch.cuda.Event(enable_timing=True)) if timed else (lambda: torch.cuda.Event())
         if self.cuda and pack_on_comm:
-            ready = torch.cuda.current_stream(self.device).record_event()
+            ready = ev()
+            ready.record(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self.comm):  # in order behind exchange k-2, which used the same buffers
                 self.comm.wait_event(ready)
+                t0 = ev()
+                t0.record(self.comm)
                 self._pack(b, parts)
-                self.packed[b] = self.comm.record_event()
+                self.packed[b] = ev()
+                self.packed[b].record(self.comm)
                 self.dist.all_gather_into_tensor(self.recv[b], self.send[b])
-                self.done[b] = self.comm.record_event()
+                self.done[b] = ev()
+                self.done[b].record(self.comm)
+            if timed:
+                self._ev["post"].append((t0, self.packed[b], self.done[b]))
         elif self.cuda:
             cur = torch.cuda.current_stream(self.device)
             if self.done[b] is not None:
                 cur.wait_event(self.done[b])  # exchange k-2 has read send[b] and filled recv[b]
+            t0 = ev()
+            t0.record(cur)
             self._pack(b, parts)
-            ready = cur.record_event()
+            ready = ev()
+            ready.record(cur)
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(ready)
                 self.dist.all_gather_into_tensor(self.recv[b], self.send[b])
-                self.done[b] = self.comm.record_event()
+                self.done[b] = ev()
+                self.done[b].record(self.comm)
+            if timed:
+                self._ev["post"].append((t0, ready, self.done[b]))
         else:
             if self.done[b] is not None:
                 self.done[b].wait()
@@ -134,7 +171,15 @@ class PlanExchange:
     def table(self):
         b = self.last
         if self.cuda:
-            self.torch.cuda.current_stream(self.device).wait_event(self.done[b])
+            cur = self.torch.cuda.current_stream(self.device)
+            if self._ev is not None:
+                w0 = self.torch.cuda.Event(enable_timing=True)
+                w0.record(cur)
+            cur.wait_event(self.done[b])
+            if self._ev is not None:
+                w1 = self.torch.cuda.Event(enable_timing=True)
+                w1.record(cur)
+                self._ev["wait"].append((w0, w1))
         else:
             self.done[b].wait()
         return self.recv[b]

@@ -19,6 +19,7 @@ def _bench(*flags):
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
+    assert out.stdout.strip() == lines[0], "stdout carries the JSON line and nothing else"
     return json.loads(lines[0])
 
 
@@ -46,6 +47,22 @@ def test_multi_gpu_code_path_with_one_rank(gpu_required, mode):
     assert e["pipelined"] > 0 and e["serial"] > 0  # both modes are timed in every N > 1 run
     x = d["x2048_strong"]  # BASELINE.json configs[4] through the sharded step (one rank: no halo)
     assert x["agents_total"] == 2048 and x["halo_agents_rank0"] == 0 and x["ms_per_step_serial_exchange"] > 0 and x["solved_fraction_rank0"] > 0.9
+    assert x["ms_per_step_pipelined_exchange"] > 0
+    # every field a real multi-GPU run will be read by is there, non-null, with a one-rank group already
+    assert d["n_gpus_requested"] == 1 and d["n_gpus_visible"] >= 1
+    stages = ("plan_kernel_ms", "pack_ms", "all_gather_ms", "output_ready_to_gathered_ms", "wait_for_table_ms")
+    for k in stages:
+        v = d["per_rank_ms"][k]
+        assert v["min"] is not None and v["min"] == v["min"] and v["min"] <= v["mean"] <= v["max"], (k, v)
+    assert d["per_rank_ms"]["plan_kernel_ms"]["mean"] > 0 and d["per_rank_ms"]["all_gather_ms"]["mean"] > 0
+    for m2 in ("serial", "pipelined"):
+        for k in stages[1:]:
+            assert x["exchange_per_rank_ms"][m2][k]["mean"] >= 0, (m2, k)
+    e60 = d["empty60_sharded"]  # BASELINE.json configs[2]: the mission sharded over the ranks, exchange on the critical path
+    assert e60["agents"] == 60 and e60["ranks"] == 1 and e60["ms_per_step"] > 0 and e60["mean_distance_flown_m"] > 0.3
+    assert e60["qp_failsafes_last_step_all_ranks"] == 0
+    for k in stages:
+        assert e60["per_rank_ms"][k]["mean"] > 0, k  # the wait for the table is real here: every agent is a halo agent
 
 
 def test_gpus_flag_starts_the_ranks_itself(gpu_required):
