@@ -330,6 +330,16 @@ def moving_crowd(device, steps=60, warm=20):
            "min_separation_ratio": sim.min_separation(),
            "stage_p50_ms": {k: float(np.percentile(v, 50)) for k, v in stages.items()},
            "includes": "neighbour search + corridor boxes + half-space generation (presolve) + goal LP + QP + launch order + state update"}
+    # roofline line of the half-space generator (dlscqp_lsc_kernel, with the neighbour search in front of it): it reads one
+    # 736-byte record per neighbour (its previous plan and sub-goal) and writes 36 bytes per row that survives the presolve
+    nb, kept = float(sim.nbr.counts.float().sum()), float(sim.row_counts.float().sum())
+    lsc_ms = float(np.percentile(stages["lsc_generation_time"], 50))
+    lsc_bytes = 736.0 * nb + 36.0 * kept
+    out["lsc_generation_roofline"] = {"bound": "valu_issue", "algorithmic_bytes_per_step": lsc_bytes, "ms": lsc_ms,
+                                      "achieved": lsc_bytes / (lsc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": lsc_bytes / (lsc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "note": "736 B x neighbours read + 36 B x rows written; the kernel is arithmetic (hull search per "
+                                              "neighbour and segment), not HBM bound: profiles/r02_other_kernels_pmc.md"}
     try:
         cms, nt = cpu_port_step_ms(cfg, inputs, seconds=2.0)
         out["cpu_port_ms"], out["cpu_port_threads"] = cms, nt
@@ -778,15 +788,23 @@ def main():
         try:
             with open(args.traffic_json) as fh:
                 prof = json.load(fh)
-            if prof.get("agents_per_launch") == N:
+            sys.path.insert(0, os.path.join(ROOT, "profiles"))
+            import summarize
+            if prof.get("agents_per_launch") == N and prof.get("csrc_sha1") == summarize.csrc_sha1():
                 traffic = prof.get("hbm_bytes_per_launch")
                 valu_frac = prof.get("valu_issue_frac")
-                traffic_src = "%s: rocprofv3 --pmc passes of this command (%s)" % (os.path.relpath(args.traffic_json, ROOT), prof.get("source", ""))
+                traffic_src = "%s: rocprofv3 --pmc passes of this command (%s), taken on these kernel sources" % (
+                    os.path.relpath(args.traffic_json, ROOT), prof.get("source", ""))
+            elif prof.get("agents_per_launch") == N:
+                traffic_src = "%s was measured on other kernel sources (csrc hash differs): not reported" % os.path.relpath(args.traffic_json, ROOT)
         except Exception:
             pass
-        R_rows, r_dim = K + 2 * 207, dim * (M * (n + 1) - 17)
-        # n_W grows from 0 to `active` over the adds: sum over iterations ~ iterations * active / 2
-        flops_qp = float((it[:, 0] * (6.0 * R_rows + 2.0 * r_dim * r_dim) + 6.0 * r_dim * it[:, 0] * it[:, 3] / 2.0).mean()
+        R_rows, P_pts = K + 2 * 207, M * (n + 1)
+        # per active-set iteration: one pricing pass over the R rows (6 flops a row), two triangular products with the q x q factor
+        # (2 q^2), the step direction G (a - A'r) (one table row of P entries per active row and axis: 2 dim P q); the working
+        # set grows from 0 to `active` over the adds, q ~ active / 2 on average
+        q_avg = it[:, 3] / 2.0
+        flops_qp = float((it[:, 0] * (6.0 * R_rows + 2.0 * q_avg * q_avg + 2.0 * dim * P_pts * (q_avg + 1.0))).mean()
                          + 6.0 * R_rows)  # + the scan that finds no violated row
         fp64 = {"flops_per_qp_model": flops_qp, "achieved_tflops": N * flops_qp / avg_kernel_s / 1e12,
                 "peak_tflops": FP64_VALU_PEAK_TFLOPS, "frac": N * flops_qp / avg_kernel_s / 1e12 / FP64_VALU_PEAK_TFLOPS}
@@ -796,11 +814,11 @@ def main():
             a1, r1 = wl["agents"][:64], wl["rows"][:wl["row_offsets"][64]]
             ro1 = wl["row_offsets"][:65]
             lat = []
-            for _ in range(60):
+            for _ in range(1020):  # 1 000 samples: a p99 from fifty of them is the slowest call, not a percentile (profiles/r03_latency_tail.md)
                 t1 = time.perf_counter()
                 opt.plan(a1, ro1, r1, None, 0, True, True)
                 lat.append((time.perf_counter() - t1) * 1e3)
-            lat = np.array(lat[10:])
+            lat = np.array(lat[20:])
             # "hard" batch: only agents that end with at least five active rows, taken from the timed batches and tiled to the
             # same launch size.  Launch order: like the headline's, from what a closed loop knows -- the iteration count the SAME
             # agent had one replanning step earlier (the previous batch of the rotation) -- sorted on the device
@@ -876,9 +894,11 @@ def main():
             "x2048_strong": stress,
             "p50_replan_ms_one_swarm_host_to_host": None if lat is None else float(np.percentile(lat, 50)),
             "p99_replan_ms_one_swarm_host_to_host": None if lat is None else float(np.percentile(lat, 99)),
+            "max_replan_ms_one_swarm_host_to_host": None if lat is None else float(lat.max()),
+            "replan_ms_one_swarm_samples": None if lat is None else int(len(lat)),
             "closed_loop_replan_ms": closed,
-            # SURVEY.md 8(d) flop model: per active-set iteration 6 R (row residuals) + 2 r^2 (two r x r sweeps) + 6 r n_W
-            # (factor update at working-set size n_W), R = inequality rows, r = reduced dimension
+            # flop model of the range-space iteration (see where flops_qp is computed): SURVEY.md 8(d)'s dense model (2 r^2 sweeps
+            # of an orthogonal factor) no longer describes what the kernel does -- its arithmetic per iteration is O(active rows)
             "fp64_valu": fp64,
             "roofline": {
                 # what binds the kernel according to the counters (profiles/): the VALU issue rate of the SIMDs -- neither of

@@ -19,6 +19,8 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $OUT/sq4 -- $B > $OUT/sq4.log 2>&1
 python3 profiles/summarize.py $OUT $NAME --steps $STEPS --agents 32768 > $OUT/summary.txt 2>&1
 cp profiles/$NAME.md profiles/$NAME.json profiles/hbm_traffic_latest.json $OUT/ 2>/dev/null
+python3 tests/tools/phase_cost.py > $OUT/phase_cost.txt 2>&1
+python3 profiles/timeline.py > $OUT/timeline.txt 2>&1
 python3 profiles/stamps.py --swarms 512 > $OUT/stamps.txt 2>&1
 cp $OUT/stamps.txt profiles/${NAME}_stamps.txt
 # every kernel of the path in one trace: the full bench (closed-loop missions: half-space, corridor and advance kernels; stress batch)

@@ -19,6 +19,34 @@ import sys
 from collections import defaultdict
 
 KERNEL = "dlscqp_plan_kernel"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def csrc_sha1():
+    """Hash of the kernel sources a profile was measured on (bench.py compares it with the tree it runs from)."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(os.path.dirname(HERE), "dlsc_gc_planner_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp", ".cpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
+
+
+def dynamic_lds_bytes():
+    """The plan kernel takes its LDS as DYNAMIC shared memory: the trace's LDS column shows the static part (0).  Ask the
+    library what the S64 launch of bench.py asks for (needs the GPU: this runs on the box the profile was taken on)."""
+    try:
+        sys.path.insert(0, os.path.dirname(HERE))
+        from dlsc_gc_planner_amd import workloads
+        from dlsc_gc_planner_amd.planner import BatchTrajOptimizer
+        opt = BatchTrajOptimizer(workloads.s64_config())
+        b = int(opt.lds_bytes(0, 120))
+        opt.close()
+        return b
+    except Exception:
+        return None
 
 
 def read(path):
@@ -58,6 +86,13 @@ def main():
         out.append("| %.1f | %.1f | %.1f | %d | %d | %d | %d | %d | %d |\n" % (
             avg, min(durs), max(durs), summary["grid"], summary["wg"], summary["vgpr"], summary["sgpr"],
             summary["lds_bytes"], summary["scratch"]))
+        dyn = dynamic_lds_bytes()
+        if dyn:
+            by_lds = (160 * 1024) // (dyn + summary["lds_bytes"])
+            by_vgpr = 4 * max(1, 512 // max(2 * summary["vgpr"], 1))  # the trace's VGPR column counts register pairs
+            summary.update(dynamic_lds_bytes=dyn, waves_per_cu=min(by_lds, by_vgpr, 32))
+            out.append("dynamic LDS per workgroup (= per agent, one wavefront): %d B -> %d agents fit the 160 KiB of a CU; the registers allow "
+                       "%d wavefronts per CU; resident: %d wavefronts per CU\n" % (dyn, by_lds, by_vgpr, summary["waves_per_cu"]))
         alg = args.agents * args.bytes_per_qp
         summary["algorithmic_bytes_per_launch"] = alg
         summary["achieved_GBps"] = alg / (avg * 1e-6) / 1e9
@@ -103,7 +138,7 @@ def main():
         out.append("HBM traffic per launch = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 = %.4g B (algorithmic %.4g B, ratio %.2f)\n" % (
             hbm, summary.get("algorithmic_bytes_per_launch", float("nan")),
             hbm / summary.get("algorithmic_bytes_per_launch", float("nan"))))
-    here = os.path.dirname(os.path.abspath(__file__))
+    here = HERE
     with open(os.path.join(here, args.name + ".md"), "w") as fh:
         fh.write("# rocprofv3 summary %s\n\n" % args.name)
         fh.write("\n".join(out) + "\n")
@@ -112,7 +147,9 @@ def main():
     if "hbm_bytes_per_launch" in summary:
         with open(os.path.join(here, "hbm_traffic_latest.json"), "w") as fh:
             json.dump({"agents_per_launch": args.agents, "hbm_bytes_per_launch": summary["hbm_bytes_per_launch"],
-                       "valu_issue_frac": summary.get("valu_issue_frac"), "kernel": KERNEL, "source": args.name}, fh)
+                       "valu_issue_frac": summary.get("valu_issue_frac"), "kernel": KERNEL, "source": args.name,
+                       "valu_insts_per_agent": summary.get("pmc_SQ_INSTS_VALU", 0.0) / args.agents if "pmc_SQ_INSTS_VALU" in summary else None,
+                       "csrc_sha1": csrc_sha1()}, fh)
     print("\n".join(out))
 
 
