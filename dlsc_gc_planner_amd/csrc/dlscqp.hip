@@ -70,6 +70,23 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // v_readlane (broadcasts), ds_bpermute butterflies (reductions) and ballots.
 struct WaveGpu {
     int lane;
+    // Helper wavefronts (WPA > 1): the workgroup of an agent has nw wavefronts; wavefront 0 plans, the others price their
+    // share of the rows beyond the register cache in every pricing pass.  mail (LDS, 8 doubles): [0] = 1.0 when the planning
+    // wavefront is done, [1] = the agent's number of terminal segments T, [1 + v] = best tagged score of wavefront v >= 1.
+    int nw = 1;
+    double *mail = nullptr;
+    __device__ __forceinline__ void pass_begin(int T) const {
+        mail[lane & 1] = (lane & 1) ? (double)T : 0.0;  // every lane, two words, the same values (no lane-guarded store)
+        __syncthreads();                                 // the control points in LDS are current: helpers may read
+    }
+    __device__ __forceinline__ double pass_end(double top) const {
+        __syncthreads();  // every helper has written its score
+        for (int v = 1; v < nw; v++) {
+            const double r = uniform_f64(mail[1 + v]);
+            top = r > top ? r : top;
+        }
+        return top;
+    }
     template <class T>
     struct Reg {
         T v;
@@ -273,7 +290,10 @@ struct KernelArgs {
 // The instantiations that keep two wavefronts per SIMD exist a second time, WIDE, for launches too small to put a second
 // wavefront on a SIMD at all (at most one agent per SIMD of the chip: every mission of the reference).
 #ifndef DQ_KERNEL_ATTR
-#define DQ_KERNEL_ATTR __launch_bounds__(64, (WIDE || (DIMS > 0 && (RC == 2 || (DIMS == 2 && FS == 28)))) ? 1 : 2)
+#ifndef DQ_WPA_OCC
+#define DQ_WPA_OCC 1  // wavefronts per SIMD the builds with helper wavefronts are compiled for
+#endif
+#define DQ_KERNEL_ATTR __launch_bounds__(64 * WPA, WPA > 1 ? DQ_WPA_OCC : ((WIDE || (DIMS > 0 && (RC == 2 || (DIMS == 2 && FS == 28)))) ? 1 : 2))
 #endif
 // WS_HBM: the agent's working set (MemLayout) lives in a per-slot HBM buffer instead of LDS -- for batches whose working
 // set exceeds the 160 KiB of a CU.  Since the solver keeps no orthogonal factor (gi_core.hpp) that is only a batch with
@@ -283,7 +303,12 @@ struct KernelArgs {
 // One wavefront owns a buffer and a wavefront's memory operations are performed in program order, so no fences are
 // needed between its lanes.
 enum { WS_LDS = 0, WS_HBM = 1 };
-template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK, int WS = WS_LDS, bool WIDE = false>
+// WPA (wavefronts per agent) > 1: a workgroup of WPA wavefronts per agent for launches that leave most of the chip empty
+// (few agents) or whose agents have long row lists (a crowd): wavefront 0 plans as always; wavefronts 1 .. WPA-1 are HELPERS
+// that price their share of the rows beyond the planning wavefront's register cache, once per pricing pass, between two
+// workgroup barriers (WaveGpu::pass_begin / pass_end).  Same arithmetic per row, same maximum: the answers do not depend on
+// WPA (tests/test_gpu_wide_builds.py).
+template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK, int WS = WS_LDS, bool WIDE = false, int WPA = 1>
 __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, KernelArgs a) {
     extern __shared__ __align__(16) unsigned char lds[];
     if ((int)blockIdx.x >= a.n_slots_launch) return;
@@ -292,9 +317,47 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
     if constexpr (WS == WS_HBM) smem = a.work + (size_t)slot * a.work_stride;
     else smem = lds;
     const int ag = a.order ? a.order[slot] : slot;
-    if (ag < 0 || ag >= a.n_agents) return;
+    if (ag < 0 || ag >= a.n_agents) return;  // the whole workgroup
     WaveGpu w;
-    w.lane = (int)threadIdx.x;
+    w.lane = (int)threadIdx.x & 63;
+    if constexpr (WPA > 1) {
+        static_assert(WS == WS_LDS, "the helpers' mailbox is in LDS");
+        w.nw = WPA;
+        w.mail = reinterpret_cast<double *>(smem) + lay.oMail;
+        const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);  // wave-uniform, and known to be
+        if (wave > 0) {
+            // ---- helper wavefront: price a share of the cold rows whenever the planning wavefront opens a pass -------------
+            const int rb = a.row_offsets[ag], K = (a.row_counts ? a.row_counts[ag] : a.row_offsets[ag + 1] - rb);
+            const int Kc = K < 64 * KU ? K : 64 * KU;
+            const dlscqp_agent *agp = a.agents + ag;
+            ColdRows c;
+            c.nx = a.rows.nx + rb; c.ny = a.rows.ny + rb; c.nz = a.rows.nz + rb;
+            c.px = a.rows.px + rb; c.py = a.rows.py + rb; c.pz = a.rows.pz + rb;
+            c.d = a.rows.d + rb; c.key = a.rows.key + rb;
+            c.flag = smem + lay.oFlag;
+            c.x = reinterpret_cast<const double *>(smem) + lay.oX;
+            c.sigma = kp.sigma;
+            c.K = K; c.Kc = Kc; c.M = kp.M; c.P = kp.M * kp.n1; c.dim = kp.dim; c.nxc = kp.dim * c.P;
+            int nso = agp->n_slack_obs;
+            nso = nso > a.max_slack_obs ? a.max_slack_obs : (nso < 0 ? 0 : nso);
+            c.nso = SLK == 0 ? 0 : nso;
+            c.phi = kp.phi;
+            c.unit0 = DIMS > 0 ? c.nxc : 0;
+            int jb, je;
+            cold_rows_share(Kc, K, wave, WPA, jb, je);
+            for (;;) {
+                __syncthreads();  // pass_begin (or the end of the solve)
+                if (uniform_f64(w.mail[0]) != 0.0) break;  // every lane reads the same word
+                c.tNN = kp.tabNN + (size_t)((int)uniform_f64(w.mail[1]) - 1) * c.P;
+                WaveGpu::Reg<double> best;
+                best.v = cold_rows_lane_best<4>(c, w.lane, jb, je, 0.0);
+                const double top = w.max_pos(best);
+                w.mail[1 + wave] = top;  // every lane, the same word, the same value
+                __syncthreads();  // pass_end
+            }
+            return;
+        }
+    }
 #ifdef DLSCQP_STAMPS
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(w.last)::"memory");
 #endif
@@ -323,6 +386,10 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
                a.out_slack_cost ? a.out_slack_cost + (size_t)ag * a.max_slack_obs : nullptr,
                a.out_status ? a.out_status + ag : nullptr,
                a.out_iters ? a.out_iters + (size_t)ag * 4 : nullptr);
+    if constexpr (WPA > 1) {  // release the helpers: the solve is over
+        w.mail[0] = 1.0;
+        __syncthreads();
+    }
 #ifdef DLSCQP_STAMPS
     if (a.out_stamps && threadIdx.x == 0)
         for (int p = 0; p < 12; p++) a.out_stamps[(size_t)ag * 12 + p] = w.acc[p];
@@ -590,7 +657,10 @@ struct KernelChoice {
     int id, KU, SU;
     bool by_kind = false;
     kernel_t fn_wide = nullptr;  // the one-wavefront-per-SIMD build of the same instantiation, where there is one
+    kernel_t fn_wpa = nullptr;   // the build with helper wavefronts (DQ_WPA per agent), for instantiations that price rows beyond their cache
 };
+constexpr int DQ_WPA = 4;
+constexpr int DQ_WPA_MAX_SLOTS = 512;  // launches of at most this many agents use the builds with helper wavefronts
 constexpr int DQ_WIDE_MAX_SLOTS = 1024;  // launches of at most this many agents use it: one agent per SIMD of the chip
 constexpr int DQ_ID_HBM = 7;  // the runtime-shape two-register instantiation is the one that also exists as WS_HBM
 const kernel_t dlscqp_plan_kernel_hbm = dlscqp_plan_kernel<2, 0, 0, 0, DQ_G2_KU, DQ_G2_SU, -1, WS_HBM>;
@@ -601,6 +671,14 @@ template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK>
 kernel_t wide_kernel() {
     if constexpr (RC == 1 && !(DIMS == 2 && FS == 28) && !(KU == 2 && SU == 0))
         return dlscqp_plan_kernel<RC, DIMS, FS, MS, KU, SU, SLK, WS_LDS, true>;
+    else
+        return nullptr;
+}
+
+template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK>
+kernel_t wpa_kernel() {
+    if constexpr (!(KU == 2 && SU == 0))
+        return dlscqp_plan_kernel<RC, DIMS, FS, MS, KU, SU, SLK, WS_LDS, false, DQ_WPA>;
     else
         return nullptr;
 }
@@ -616,7 +694,8 @@ KernelChoice select_kernel(const KParams &kp, int max_slack_obs, int kmax, bool 
     const InstanceChoice ic = select_instance(kp, max_slack_obs, kmax, force_generic);
     switch (ic.id) {
 #define DQ_CASE(ID, RC, DIMS, FS, MS, KU, SU, SLK) \
-    case ID: return {dlscqp_plan_kernel<RC, DIMS, FS, MS, KU, SU, SLK>, ID, KU, SU, (DIMS) > 0, wide_kernel<RC, DIMS, FS, MS, KU, SU, SLK>()};
+    case ID: return {dlscqp_plan_kernel<RC, DIMS, FS, MS, KU, SU, SLK>, ID, KU, SU, (DIMS) > 0, wide_kernel<RC, DIMS, FS, MS, KU, SU, SLK>(), \
+                     wpa_kernel<RC, DIMS, FS, MS, KU, SU, SLK>()};
         DQ_INSTANCES(DQ_CASE)
 #undef DQ_CASE
     default: return {nullptr, -1, 0, 0, false};
@@ -652,7 +731,7 @@ struct dlscqp_ctx {
     double *d_tabKIW = nullptr, *d_tabG = nullptr, *d_tabX0s = nullptr, *d_tabX0g = nullptr, *d_tabNN = nullptr, *d_tabSIW = nullptr;
     Slot *d_slots = nullptr;
     hipStream_t stream = nullptr;
-    int max_dyn_lds[2 * (DQ_N_INSTANCES + 1)] = {};  // second half: the WIDE builds
+    int max_dyn_lds[3 * (DQ_N_INSTANCES + 1)] = {};  // second third: the WIDE builds, last third: the builds with helper wavefronts
     int *d_order_scratch = nullptr;  // dlscqp_launch_order_device: 64 counts + 64 cursors
     void *work = nullptr;  // working sets of the WS_HBM kernel
     int force_instance = 0;  // dlscqp_selftest: 1 = the runtime-shape instantiation, 2 = its variant with the working set in HBM
@@ -853,9 +932,16 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
     a.n_agents = b->n_agents;
     a.slot0 = b->launch_count > 0 ? b->launch_offset : 0;
     a.n_slots_launch = b->launch_count > 0 ? b->launch_count : b->n_agents;
-    const bool wide = kc.fn_wide && a.n_slots_launch <= DQ_WIDE_MAX_SLOTS;
-    kernel_t kfn = wide ? kc.fn_wide : kc.fn;
-    const int attr_slot = kc.id + (wide ? DQ_N_INSTANCES + 1 : 0);
+    // Helper wavefronts where an agent has rows beyond the planning wavefront's register cache AND the launch is so small that
+    // one wavefront per agent leaves most SIMDs of the chip without work (at most two agents per CU): measured on one MI355X,
+    // LP + QP launch of the empty60 mission (60 agents x 1 593 rows) 0.053 -> 0.038 ms; a 2 048-agent crowd, whose agents
+    // already fill the CUs their LDS lets them share, loses (0.138 -> 0.19 ms: the builds with helpers run one workgroup per CU)
+    static const char *wpa_env = getenv("DLSCQP_WPA");  // tests: "1" = never, "4" = whenever the instantiation has the build
+    bool wpa = !ws_hbm && kc.fn_wpa && b->max_rows_per_agent > 64 * kc.KU && a.n_slots_launch <= DQ_WPA_MAX_SLOTS;
+    if (wpa_env) wpa = !ws_hbm && kc.fn_wpa && wpa_env[0] != '1';
+    const bool wide = !wpa && kc.fn_wide && a.n_slots_launch <= DQ_WIDE_MAX_SLOTS;
+    kernel_t kfn = wpa ? kc.fn_wpa : (wide ? kc.fn_wide : kc.fn);
+    const int attr_slot = kc.id + (wpa ? 2 * (DQ_N_INSTANCES + 1) : (wide ? DQ_N_INSTANCES + 1 : 0));
     if (!ws_hbm && lay.bytes > c->max_dyn_lds[attr_slot]) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
         c->max_dyn_lds[attr_slot] = lay.bytes;
@@ -883,9 +969,9 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
     if (timed) HIP_TRY(hipEventRecord(c->ev0[c->ev_used], stream));
 #ifdef DLSCQP_TRACE_LDS
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kc.fn), hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes + 8016));
-    hipLaunchKernelGGL(kfn, dim3(a.n_slots_launch), dim3(64), lay.bytes + 8016, stream, c->kp, lay, a);
+    hipLaunchKernelGGL(kfn, dim3(a.n_slots_launch), dim3(wpa ? 64 * DQ_WPA : 64), lay.bytes + 8016, stream, c->kp, lay, a);
 #else
-    hipLaunchKernelGGL(kfn, dim3(a.n_slots_launch), dim3(64), ws_hbm ? 0 : lay.bytes, stream, c->kp, lay, a);
+    hipLaunchKernelGGL(kfn, dim3(a.n_slots_launch), dim3(wpa ? 64 * DQ_WPA : 64), ws_hbm ? 0 : lay.bytes, stream, c->kp, lay, a);
 #endif
     HIP_TRY(hipGetLastError());
     if (timed) {

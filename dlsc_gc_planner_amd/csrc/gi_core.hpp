@@ -69,6 +69,7 @@ namespace dlscqp {
 struct MemLayout {
     int r_max, nx_max, ldg, nflag;
     int oG, oRp, oX, oDx, oBlo, oBhi;  // in doubles
+    int oMail;                         // 8 doubles: what the planning wavefront and its helper wavefronts tell each other (dlscqp.hip)
     int oDump;                         // 32 dump slots (lane & 31) for the lanes that have nothing to store, right behind S;
                                        // then two doubles that stay 0.0 (what a masked read of S is sent to)
     int oFlag;                         // byte offset of the flags of rows beyond the register cache
@@ -95,6 +96,7 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
     L.oDx = o; o += L.nx_max;
     L.oBlo = o; o += kp.nb;
     L.oBhi = o; o += kp.nb;
+    L.oMail = o; o += 8;
     L.oFlag = o * 8;
     L.bytes = (L.oFlag + L.nflag + 1 + 15) & ~15;  // + one flag byte as the dump of the flag array
     return L;
@@ -220,6 +222,91 @@ DQ_FN T pick3(const T *v, int k) {
 #define DQ_BCI(arr, e) DQ_BC(arr, e)
 // element e of column t of a [RC][3] array of per-lane vectors
 #define DQ_BC2(arr, t, e) (RC == 1 ? w.bcast((arr)[0][t], (e)) : ((e) < 64 ? w.bcast((arr)[0][t], (e)) : w.bcast((arr)[RC - 1][t], (e) - 64)))
+
+// The rows of an agent that do not fit the register cache of the wavefront that plans it ("cold" rows): priced straight from
+// HBM, CB blocks of 64 rows per trip -- first every row's record, then the loads that depend on it (control points, scaling,
+// slack variable), then the arithmetic.  One lane's share of rows [jb, je) of the agent's K rows; returns the lane's best
+// tagged pivot score (tag_score).  Shared by the planning wavefront and the HELPER wavefronts of a workgroup that only
+// price cold rows (dlscqp.hip: WPA > 1).
+struct ColdRows {
+    const float *nx, *ny, *nz, *px, *py, *pz;  // the agent's rows (RowsView + row_begin)
+    const double *d;
+    const uint32_t *key;
+    const unsigned char *flag;  // [K - Kc] skip flags in the working set
+    const double *x;            // control points and slack variables
+    const double *tNN, *sigma;
+    int K, Kc, P, M, dim, nxc, nso, phi, unit0;
+};
+template <int CB>
+DQ_FN double cold_rows_lane_best(const ColdRows &c, int l, int jb, int je, double bs) {
+    constexpr int n1 = 6;
+    for (int j0 = jb; j0 < je; j0 += 64 * CB) {  // uniform trip count
+        uint32_t key[CB];
+        float g[CB][6];
+        double gd[CB];
+        int cf0[CB];
+#pragma unroll
+        for (int u = 0; u < CB; u++) {
+            const int j = j0 + 64 * u + l;
+            const int jc = j < je ? j : je - 1;
+            key[u] = c.key[jc];
+            g[u][0] = c.nx[jc]; g[u][1] = c.ny[jc]; g[u][2] = c.nz[jc];
+            g[u][3] = c.px[jc]; g[u][4] = c.py[jc]; g[u][5] = c.pz[jc];
+            gd[u] = c.d[jc];
+            cf0[u] = c.flag[jc - c.Kc];
+        }
+#pragma unroll
+        for (int u = 0; u < CB; u++) {
+            DQ_KEEP(key[u]); DQ_KEEP(gd[u]); DQ_KEEP(cf0[u]);
+#pragma unroll
+            for (int t = 0; t < 6; t++) DQ_KEEP(g[u][t]);
+        }
+        double xv[CB][4], tn[CB], sg[CB];
+        bool inm[CB], hsl[CB];
+#pragma unroll
+        for (int u = 0; u < CB; u++) {
+            const int j = j0 + 64 * u + l;
+            const int m = key[u] & 0xFF, i = (key[u] >> 8) & 0xF;
+            inm[u] = (j < je) & (cf0[u] == 0) & !((m == 0) & (i < c.phi)) & !f32_norm3_below_eps(g[u][0], g[u][1], g[u][2]);
+            const int p = inm[u] ? m * n1 + i : 0;
+            const uint32_t sl = key[u] >> 16;
+            hsl[u] = inm[u] & (sl != 0xFFFFu) & ((int)sl < c.nso);
+            xv[u][0] = c.x[p]; xv[u][1] = c.x[c.P + p]; xv[u][2] = c.x[(c.dim == 3 ? 2 : 0) * c.P + p];
+            xv[u][3] = c.x[c.nxc + (hsl[u] ? (int)sl * c.M + m : 0)];
+            tn[u] = c.tNN[p];
+            sg[u] = c.sigma[inm[u] ? m : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < CB; u++) { DQ_KEEP(xv[u][0]); DQ_KEEP(xv[u][1]); DQ_KEEP(xv[u][2]); DQ_KEEP(xv[u][3]); DQ_KEEP(tn[u]); DQ_KEEP(sg[u]); }
+#pragma unroll
+        for (int u = 0; u < CB; u++) {
+            const int j = j0 + 64 * u + l;
+            const float nx = g[u][0], ny = g[u][1], nz = g[u][2];
+            double val = (double)nx * xv[u][0] + (double)ny * xv[u][1];
+            double rhs = gd[u] + (double)nx * (double)g[u][3] + (double)ny * (double)g[u][4];
+            const double val3 = val + (double)nz * xv[u][2], rhs3 = rhs + (double)nz * (double)g[u][5];
+            val = c.dim == 3 ? val3 : val;
+            rhs = c.dim == 3 ? rhs3 : rhs;
+            val = hsl[u] ? val - xv[u][3] : val;
+            const double v = (rhs - VIOL_TOL) - val;
+            double wsq = ((double)nx * (double)nx + (double)ny * (double)ny + (c.dim == 3 ? (double)nz * (double)nz : 0.0)) * tn[u];
+            wsq = hsl[u] ? wsq + sg[u] * sg[u] : wsq;
+            double qv = v * DQ_RSQRT(wsq > 0 ? wsq : 1.0);
+            DQ_KEEP(qv);
+            const double sc = (inm[u] & (wsq > 0)) ? qv : -1.0;
+            bs = DQ_SCORE_MAX(bs, tag_score(sc, (uint32_t)(c.unit0 + (j < je ? j : je - 1)) << 3));
+        }
+    }
+    return bs;
+}
+// rows [jb, je) of the cold rows [Kc, K) that wavefront `wave` of `nw` prices: contiguous shares of whole blocks of 64
+DQ_FN void cold_rows_share(int Kc, int K, int wave, int nw, int &jb, int &je) {
+    const int blocks = (K - Kc + 63) / 64, per = (blocks + nw - 1) / nw;
+    jb = Kc + 64 * per * wave;
+    je = Kc + 64 * per * (wave + 1);
+    jb = jb < K ? jb : K;
+    je = je < K ? je : K;
+}
 
 // RC: registers per per-lane vector over the active rows (at most 64 RC of them; the whitened dimension r bounds their number).
 // DIMS/FS/MS: compile-time world dimension, free degrees of freedom per axis and segment count (0 = read them from KParams).
@@ -930,12 +1017,20 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         w.sync();
     };
 
+    ColdRows cold;
+    cold.nx = Rnx; cold.ny = Rny; cold.nz = Rnz; cold.px = Rpx; cold.py = Rpy; cold.pz = Rpz; cold.d = Rd; cold.key = Rkey;
+    cold.flag = cold_flag; cold.x = x; cold.tNN = tNN; cold.sigma = kp.sigma;
+    cold.K = K; cold.Kc = Kc; cold.P = P; cold.M = M; cold.dim = dim; cold.nxc = nxc; cold.nso = nso; cold.phi = kp.phi; cold.unit0 = UL0;
+    int cold_jb, cold_je;
+    cold_rows_share(Kc, K, 0, w.nw, cold_jb, cold_je);
+
     for (;;) {
         // ---- most violated inactive row ---------------------------------------------------------
         // Every candidate row: violation v = limit - value (or value - limit), pivot score (v - VIOL_TOL) / |N'a| tagged with
         // the row's code, running maximum.  Rows that are not in the model, or are active, have a limit that is never
         // violated; all LDS reads of a part come first and unconditionally (one exposed round trip per part).
         RegD best;
+        if (!ALL_CACHED && w.nw > 1) w.pass_begin(T);  // the helper wavefronts start on their shares of the cold rows
         w.each([&](int l) {
             double xr[KU][4];
 #pragma unroll
@@ -1047,66 +1142,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 DQ_KEEP(qv);
                 bs = DQ_SCORE_MAX(bs, tag_score(cand ? qv : -1.0, (uint32_t)(US0 + sc2) << 3));
             }
-            // rows beyond the register cache: straight from HBM (K > 64 KU), CB blocks of 64 rows per trip: first every
-            // row's record, then the loads that depend on it (scaling, slack variable), then the arithmetic
-            if (!ALL_CACHED)
-            for (int j0 = Kc; j0 < K; j0 += 64 * CB) {
-                uint32_t key[CB];
-                float g[CB][6];
-                double gd[CB];
-                int cf0[CB];
-#pragma unroll
-                for (int u = 0; u < CB; u++) {
-                    const int j = j0 + 64 * u + l;
-                    const int jc = j < K ? j : K - 1;
-                    key[u] = Rkey[jc];
-                    g[u][0] = Rnx[jc]; g[u][1] = Rny[jc]; g[u][2] = Rnz[jc];
-                    g[u][3] = Rpx[jc]; g[u][4] = Rpy[jc]; g[u][5] = Rpz[jc];
-                    gd[u] = Rd[jc];
-                    cf0[u] = cold_flag[jc - Kc];
-                }
-#pragma unroll
-                for (int u = 0; u < CB; u++) {
-                    DQ_KEEP(key[u]); DQ_KEEP(gd[u]); DQ_KEEP(cf0[u]);
-#pragma unroll
-                    for (int t = 0; t < 6; t++) DQ_KEEP(g[u][t]);
-                }
-                double xv[CB][4], tn[CB], sg[CB];
-                bool inm[CB], hsl[CB];
-#pragma unroll
-                for (int u = 0; u < CB; u++) {
-                    const int j = j0 + 64 * u + l;
-                    const int m = key[u] & 0xFF, i = (key[u] >> 8) & 0xF;
-                    inm[u] = (j < K) & (cf0[u] == 0) & !((m == 0) & (i < kp.phi)) & !f32_norm3_below_eps(g[u][0], g[u][1], g[u][2]);
-                    const int p = inm[u] ? m * n1 + i : 0;
-                    const uint32_t sl = key[u] >> 16;
-                    hsl[u] = inm[u] & (sl != 0xFFFFu) & ((int)sl < nso);
-                    xv[u][0] = x[p]; xv[u][1] = x[P + p]; xv[u][2] = x[(dim == 3 ? 2 : 0) * P + p];
-                    xv[u][3] = x[nxc + (hsl[u] ? (int)sl * M + m : 0)];
-                    tn[u] = tNN[p];
-                    sg[u] = kp.sigma[inm[u] ? m : 0];
-                }
-#pragma unroll
-                for (int u = 0; u < CB; u++) { DQ_KEEP(xv[u][0]); DQ_KEEP(xv[u][1]); DQ_KEEP(xv[u][2]); DQ_KEEP(xv[u][3]); DQ_KEEP(tn[u]); DQ_KEEP(sg[u]); }
-#pragma unroll
-                for (int u = 0; u < CB; u++) {
-                    const int j = j0 + 64 * u + l;
-                    const float nx = g[u][0], ny = g[u][1], nz = g[u][2];
-                    double val = (double)nx * xv[u][0] + (double)ny * xv[u][1];
-                    double rhs = gd[u] + (double)nx * (double)g[u][3] + (double)ny * (double)g[u][4];
-                    const double val3 = val + (double)nz * xv[u][2], rhs3 = rhs + (double)nz * (double)g[u][5];
-                    val = dim == 3 ? val3 : val;
-                    rhs = dim == 3 ? rhs3 : rhs;
-                    val = hsl[u] ? val - xv[u][3] : val;
-                    const double v = (rhs - VIOL_TOL) - val;
-                    double wsq = ((double)nx * (double)nx + (double)ny * (double)ny + (dim == 3 ? (double)nz * (double)nz : 0.0)) * tn[u];
-                    wsq = hsl[u] ? wsq + sg[u] * sg[u] : wsq;
-                    double qv = v / sqrt(wsq > 0 ? wsq : 1.0);
-                    DQ_KEEP(qv);
-                    const double sc = (inm[u] & (wsq > 0)) ? qv : -1.0;
-                    bs = DQ_SCORE_MAX(bs, tag_score(sc, (uint32_t)(UL0 + (j < K ? j : K - 1)) << 3));
-                }
-            }
+            // rows beyond the register cache: this wavefront's share of them (all of them unless helper wavefronts price
+            // the rest: W::nw > 1)
+            if (!ALL_CACHED) bs = cold_rows_lane_best<CB>(cold, l, cold_jb, cold_je, bs);
             if (!ALL_CACHED)
             for (int s0 = Sc; s0 < n_slots; s0 += 64) {
                 const int s = s0 + l;
@@ -1132,7 +1170,8 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             }
             best.at(l) = bs;
         });
-        const double top = w.max_pos(best);  // best pivot score over all violated rows, with the row's code
+        double top = w.max_pos(best);  // best pivot score over all violated rows, with the row's code
+        if (!ALL_CACHED && w.nw > 1) top = w.pass_end(top);  // ... the helpers' included
         w.stamp(2);                       // row scan + arg-max
         DQ_PHASE_EXIT(2);
         if (!(top >= SCORE_MIN)) break;   // no row violated by more than VIOL_TOL: optimal

@@ -29,6 +29,9 @@ std::vector<unsigned char> g_last_lds;  // debug: LDS image of the last agent so
 
 struct WaveCpu {
     bool reverse;
+    static constexpr int nw = 1;  // no helper wavefronts on the host
+    void pass_begin(int) const {}
+    double pass_end(double top) const { return top; }
     template <class T>
     struct Reg {
         T v[64];
@@ -273,6 +276,35 @@ extern "C" int emul_waypoint_trap(const dlscqp_config *cfg, const dlscqp_lsc_gen
             }
         }
         if (trap->out_released) trap->out_released[k] = released;
+    }
+    return 0;
+}
+
+// broadcastMsgs' communication-range filter (multi_sync_simulator.cpp:482-503) with the output layout of
+// dlscqp_neighbours_device (lists of fixed pitch, ascending ids, cut to the pitch smallest): the CPU tier's stand-in for the
+// device search -- a plain loop over all pairs, no grid.
+extern "C" int emul_neighbours(const dlscqp_config *cfg, const dlscqp_neighbour_search *ns) {
+    const double range = cfg->communication_range;
+    const int per = cfg->M * (cfg->n + 1) - cfg->phi;
+    for (int k = 0; k < ns->n_local; k++) {
+        const int self = ns->local_ids ? ns->local_ids[k] : k;
+        const float *ps = ns->position + (size_t)self * ns->position_stride;
+        int count = 0, total = 0;
+        for (int q = 0; q < ns->n_total; q++) {
+            if (q == self) continue;
+            const float *pq = ns->position + (size_t)q * ns->position_stride;
+            double dist = 0;  // util.hpp:131-140
+            for (int c = 0; c < 3; c++) {
+                const double dc = std::abs(ps[c] - pq[c]);
+                if (dist < dc) dist = dc;
+            }
+            if (range > 0 && dist > range) continue;
+            total++;
+            if (count < ns->pitch) ns->out_nbr_ids[(size_t)k * ns->pitch + count++] = q;
+        }
+        ns->out_nbr_counts[k] = count;
+        if (ns->out_row_counts) ns->out_row_counts[k] = (count + ns->n_dyn) * per;
+        if (ns->out_overflow && total > ns->pitch) *ns->out_overflow = 1;
     }
     return 0;
 }

@@ -56,6 +56,26 @@ def plan_batch(cfg, agents, row_offsets, rows, sfc=None, max_slack_obs=0, do_goa
     return out
 
 
+def neighbours(cfg, position, pitch, local_ids=None, n_dyn=0):
+    """The CPU tier's stand-in for dlscqp_neighbours_device: (counts [n_local], ids [n_local, pitch], row_counts, overflow)."""
+    L = lib()
+    L.emul_neighbours.argtypes = [C.POINTER(abi.Config), C.POINTER(abi.NeighbourSearch)]
+    L.emul_neighbours.restype = C.c_int
+    pos = np.ascontiguousarray(position, dtype=np.float32)
+    loc = None if local_ids is None else np.ascontiguousarray(local_ids, dtype=np.int32)
+    n_local = len(pos) if loc is None else len(loc)
+    ids = np.zeros((n_local, pitch), np.int32)
+    counts, rows, over = np.zeros(n_local, np.int32), np.zeros(n_local, np.int32), np.zeros(1, np.int32)
+    ns = abi.NeighbourSearch()
+    ns.n_total, ns.n_local = len(pos), n_local
+    ns.local_ids = None if loc is None else loc.ctypes.data
+    ns.position, ns.position_stride, ns.pitch = pos.ctypes.data, pos.shape[1], pitch
+    ns.out_nbr_ids, ns.out_nbr_counts, ns.out_row_counts = ids.ctypes.data, counts.ctypes.data, rows.ctypes.data
+    ns.n_dyn, ns.out_overflow = n_dyn, over.ctypes.data
+    assert L.emul_neighbours(C.byref(cfg), C.byref(ns)) == 0
+    return counts, ids, rows, int(over[0])
+
+
 def table_info(cfg, max_slack_obs=0, kmax=0):
     L = lib()
     v = [C.c_int() for _ in range(4)]
@@ -66,7 +86,7 @@ def table_info(cfg, max_slack_obs=0, kmax=0):
 
 
 def generate_lsc(cfg, plans, goals, radius, downwash, nbr_offsets, nbr_ids, local_ids=None, position=None, velocity=None,
-                 dyn=None, observed=None, reset_threshold=0.0, trap=None, prune=None):
+                 dyn=None, observed=None, reset_threshold=0.0, trap=None, prune=None, nbr_counts=None):
     """prune: None or dict(sfc=[n_local][M][6] or None): the generator's presolve; on return prune["counts"] holds the rows per
     agent and the returned rows are the kept ones, concatenated (row_offsets accordingly)."""
     """Row N1 through the host build of lsc_core.hpp.  Returns (row_offsets, rows as ROW_DTYPE).
@@ -90,11 +110,11 @@ def generate_lsc(cfg, plans, goals, radius, downwash, nbr_offsets, nbr_ids, loca
         return rc
 
     return _run_lsc_gen(cfg, call, plans, goals, radius, downwash, nbr_offsets, nbr_ids, local_ids, position, velocity, dyn,
-                        observed, reset_threshold, prune)
+                        observed, reset_threshold, prune, nbr_counts)
 
 
 def _run_lsc_gen(cfg, call, plans, goals, radius, downwash, nbr_offsets, nbr_ids, local_ids, position, velocity, dyn=None,
-                 observed=None, reset_threshold=0.0, prune=None):
+                 observed=None, reset_threshold=0.0, prune=None, nbr_counts=None):
     first = plans is None
     keep = []
 
@@ -121,6 +141,8 @@ def _run_lsc_gen(cfg, call, plans, goals, radius, downwash, nbr_offsets, nbr_ids
     _, g.radius = arr(radius, np.float64)
     _, g.downwash = arr(downwash, np.float64)
     g.nbr_offsets, g.nbr_ids = nbr_offsets.ctypes.data, nbr_ids_a.ctypes.data
+    if nbr_counts is not None:  # lists of fixed pitch (dlscqp_neighbours_device)
+        _, g.nbr_counts = arr(nbr_counts, np.int32)
     per = cfg.M * (cfg.n + 1) - cfg.phi
     n_dyn = 0 if dyn is None else len(dyn["radius"])
     if n_dyn:

@@ -355,3 +355,88 @@ def test_stress_batch_interior_then_halo_over_two_ranks_equals_one_process():
         assert n_int > 5 and n_halo > 5, (rank, n_int, n_halo)
         for k in ("status", "goal_status", "goal", "ctrl"):
             assert np.array_equal(out[k], ref[k][lo:hi]), (rank, k)
+
+
+# ---- the moving crowd over two gloo ranks: rank-local neighbour lists of fixed pitch -------------------------------------
+PITCH = 64
+
+
+def _crowd_inputs(n_agents=96):
+    from dlsc_gc_planner_amd import workloads
+    cfg = workloads.x2048_config()
+    w = workloads.x2048(cfg, n_agents=n_agents, seed=5002)
+    return cfg, w
+
+
+def _crowd_plan(cfg, w, ids, plans, goals, agents):
+    """One step of the agents `ids` as the device loop does it: communication-range neighbour lists of fixed pitch from the
+    positions of EVERYBODY's previous plans (the stand-in of dlscqp_neighbours_device), half-spaces, goal LP + QP."""
+    import emul_lib as E
+    ids = np.asarray(ids, np.int32)
+    pos = plans[:, 1, 0]  # where every agent is at the start of this step: its previous plan at dt
+    counts, nb, _, over = E.neighbours(cfg, pos, PITCH, local_ids=ids)
+    assert over == 0
+    per = cfg.M * (cfg.n + 1) - cfg.phi
+    ro, rows = E.generate_lsc(cfg, plans, goals, w["radius"], w["downwash"], np.arange(len(ids) + 1) * PITCH, nb.ravel(), local_ids=ids,
+                              nbr_counts=counts)
+    kept = np.concatenate([rows[ro[k]:ro[k] + counts[k] * per] for k in range(len(ids))])
+    ro2 = np.concatenate([[0], np.cumsum(counts.astype(np.int64) * per)])
+    return E.plan_batch(cfg, agents[ids], ro2, kept, w["sfc"][ids], 0, True), counts
+
+
+def _crowd_worker(rank, world, port, steps, q):
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    sys.path.insert(0, here)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg, w = _crowd_inputs()
+    N = len(w["agents"])
+    lo, hi = sharding.shard_range(N, rank, world)
+    own = np.arange(lo, hi)
+    E3 = cfg.M * (cfg.n + 1) * 3
+    xchg = sharding.PlanExchange(dist, world, hi - lo, (E3, 3, 1), torch.device("cpu"))
+    plans, goals, agents = w["plans"].copy(), w["goals"].copy(), w["agents"].copy()
+    n_remote = 0
+    for _ in range(steps):
+        res, counts = _crowd_plan(cfg, w, own, plans, goals, agents)
+        new_plans, new_agents = _stress_advance(cfg, plans, agents, res, own)
+        xchg.post(torch.from_numpy(new_plans.reshape(hi - lo, -1)), torch.from_numpy(new_agents["current_goal_point"].copy()),
+                  torch.from_numpy(res["status"].reshape(-1, 1)))
+        ctrl_all, goal_all, _ = xchg.unpack(xchg.table(), (torch.float32, torch.float32, torch.int32))
+        plans = ctrl_all.numpy().reshape(N, cfg.M, cfg.n + 1, 3).copy()
+        goals = goal_all.numpy().copy()
+        agents[lo:hi] = new_agents
+    q.put((rank, plans, goals))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_moving_crowd_with_rank_local_neighbour_lists_over_two_ranks_equals_one_process():
+    """BASELINE.json configs[4] as the device loop flies it (neighbour lists rebuilt every step from everybody's positions,
+    fixed pitch, ascending ids), three steps, agents sharded over two gloo ranks with one plan exchange per step: the table
+    of plans and sub-goals on either rank equals the single-process run bit for bit -- the lists of a shard are the rows of
+    the global lists."""
+    steps = 3
+    cfg, w = _crowd_inputs()
+    N = len(w["agents"])
+    allids = np.arange(N)
+    plans, goals, agents = w["plans"].copy(), w["goals"].copy(), w["agents"].copy()
+    for _ in range(steps):
+        res, counts = _crowd_plan(cfg, w, allids, plans, goals, agents)
+        plans, agents = _stress_advance(cfg, plans, agents, res, allids)
+        goals = agents["current_goal_point"].copy()
+    assert counts.min() >= 3 and counts.max() < PITCH
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + (os.getpid() % 90)
+    procs = [ctx.Process(target=_crowd_worker, args=(r, 2, port, steps, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res2 = {r: (a, b) for r, a, b in (q.get(timeout=600) for _ in range(2))}
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        assert np.array_equal(res2[r][0], plans) and np.array_equal(res2[r][1], goals), r

@@ -47,3 +47,42 @@ def test_small_and_large_launch_builds_agree(gpu_required, name):
     first = {k: v[:n0] for k, v in whole.items()}
     assert fixtures.check_against_golden(cfg, b, ans, first) >= 5
     assert (whole["status"][:n0] == whole["status"][n0:2 * n0]).all()
+
+
+SCRIPT = r"""
+import sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(here)r)
+import numpy as np
+import fixtures
+from dlsc_gc_planner_amd.planner import BatchTrajOptimizer
+cfg, b, ans = fixtures.load(%(name)r)
+opt = BatchTrajOptimizer(cfg)
+db = opt.make_device_batch(b["agents"], b["row_offsets"], b["rows"], b["sfc"], b["max_slack_obs"], want_f64=True, want_iters=True)
+db.launch()
+got = db.results()
+assert fixtures.check_against_golden(cfg, b, ans, got) >= 5
+np.savez(sys.argv[1], **{k: got[k] for k in ("status", "goal_status", "goal", "ctrl", "x", "cost", "iters")})
+opt.close()
+"""
+
+
+@pytest.mark.parametrize("name", ["crowd3d_M5_400rows", "maze2d_M10_sfc_comm", "forest3d_M10_dyn4", "long3d_M12_comm"])
+def test_helper_wavefronts_change_nothing(gpu_required, tmp_path, name):
+    """Small launches of agents with rows beyond the register cache run with four wavefronts per agent (dlscqp.hip: WPA): three
+    helpers price their share of those rows in every pricing pass.  Same rows, same arithmetic, same maximum: forced on
+    (DLSCQP_WPA=4) and off (=1), the answers are the same bits -- and the golden ones."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for wpa in ("1", "4"):
+        out = str(tmp_path / ("wpa%s.npz" % wpa))
+        env = dict(os.environ, DLSCQP_WPA=wpa)
+        r = subprocess.run([sys.executable, "-c", SCRIPT % dict(root=os.path.dirname(here), here=here, name=name), out], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[wpa] = np.load(out)
+    assert res["1"]["iters"][:, 0].max() >= 2
+    for k in ("status", "goal_status", "goal", "ctrl", "x", "cost", "iters"):
+        assert np.array_equal(res["1"][k], res["4"][k]), k
