@@ -17,6 +17,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <unordered_map>
 #include <cstring>
 #include <functional>
 #include <queue>
@@ -140,10 +141,38 @@ struct GridMapf {
     bool have_world = false;
     double gmin[3], gmax[3];
     int dim[3];
-    // current grid map
+    // current grid map.  Two of them are kept per replanning step -- with the step's dynamic obstacles and without any (the
+    // fallback of planMAPF, and all there is in a world without obstacles) -- and every communication group of the step
+    // reuses them: the map depends on the world, the agents' radius and the obstacles, not on the group (the reference
+    // rebuilds it per agent; the result is the same).  `exist`, `warning`, `nbr` are the active one.
     std::vector<char> exist, warning;
     std::vector<std::vector<int>> nbr;
-    std::vector<std::vector<int>> obs_tables;
+    struct GridState {
+        std::vector<char> exist, warning;
+        std::vector<std::vector<int>> nbr;
+        bool valid = false;
+        double radius = -1.0;
+    } stored[2];
+    int active = -1;
+    std::vector<char> static_free;  // node is clear of the static world (depends on the agents' radius only)
+    double static_radius = -1.0;
+    void use_state(int which) {
+        if (active == which) return;
+        auto swap_with = [&](GridState &g) { exist.swap(g.exist); warning.swap(g.warning); nbr.swap(g.nbr); };
+        if (active >= 0) swap_with(stored[active]);
+        swap_with(stored[which]);
+        active = which;
+    }
+    void new_step() {  // the obstacles have moved; the map without them stays
+        stored[1].valid = false;
+        tables_valid[0] = tables_valid[1] = false;
+        goal_tables[1].clear();
+    }
+    // breadth-first distance tables from the obstacles' nodes, per grid state and step (every group of a step reads the same)
+    std::vector<std::vector<int>> tables[2];
+    bool tables_valid[2] = {false, false};
+    const std::vector<std::vector<int>> *obs_tables_p = nullptr;
+    std::unordered_map<int, std::vector<int>> goal_tables[2];  // PIBT's distance tables by goal node, per grid state
     PlanResult plan_result;
     int n_agents = 0;
 
@@ -250,24 +279,62 @@ struct GridMapf {
 
     // updateGridMap, :94-171
     void update_grid_map(double agent_radius, const std::vector<MapfObstacle> &obstacles) {
+        const int which = obstacles.empty() ? 0 : 1;
+        use_state(which);
+        GridState &st = stored[which];
+        if (st.valid && st.radius == agent_radius) return;  // this step's map (or the static one) is there already
+        st.valid = true;
+        st.radius = agent_radius;
+        goal_tables[which].clear();  // a new map: its distance tables go with the old one
         const int nn = n_nodes();
+        if (static_radius != agent_radius) {  // clearance of the static world: once
+            static_free.assign(nn, 1);
+            if (have_world)
+                for (int x = 0; x < dim[0]; x++)
+                    for (int y = 0; y < dim[1]; y++)
+                        for (int z = 0; z < dim[2]; z++)
+                            if (static_clearance(pos_to_point(x, y, z)) < agent_radius - EPS_F) static_free[node_id(x, y, z)] = 0;
+            static_radius = agent_radius;
+        }
         exist.assign(nn, 0);
         warning.assign(nn, 0);
+        const double horizon = cfg.M * cfg.dt;
+        // a node farther from an obstacle's straight path than the obstacle can ever reach needs no walk along the path
+        // (Obstacle::isCollided samples it: obstacle.hpp:26-36); margin 1 mm against the float32 arithmetic of the samples
+        std::vector<double> reach(obstacles.size());
+        for (size_t oi = 0; oi < obstacles.size(); oi++) {
+            const double tu = std::min(horizon, cfg.obs_uncertainty_horizon);
+            reach[oi] = agent_radius + obstacles[oi].radius + 0.5 * obstacles[oi].max_acc * tu * tu + 1e-3;
+        }
+        auto dist_to_path = [&](const MapfObstacle &o, const P3 &sp) {
+            const double ax = o.position.x, ay = o.position.y, az = o.position.z;
+            const double dx = o.velocity.x * horizon, dy = o.velocity.y * horizon, dz = o.velocity.z * horizon;
+            const double px = sp.x - ax, py = sp.y - ay, pz = sp.z - az;
+            const double dd = dx * dx + dy * dy + dz * dz;
+            double t = dd > 0 ? (px * dx + py * dy + pz * dz) / dd : 0.0;
+            t = t < 0 ? 0 : (t > 1 ? 1 : t);
+            const double qx = px - t * dx, qy = py - t * dy, qz = pz - t * dz;
+            return std::sqrt(qx * qx + qy * qy + qz * qz);
+        };
         for (int x = 0; x < dim[0]; x++)
             for (int y = 0; y < dim[1]; y++)
                 for (int z = 0; z < dim[2]; z++) {
                     const int id = node_id(x, y, z);
+                    if (!static_free[id]) continue;
                     const P3 sp = pos_to_point(x, y, z);
-                    if (have_world && static_clearance(sp) < agent_radius - EPS_F) continue;
                     bool warn = false;
-                    for (const auto &o : obstacles)
-                        if (o.is_collided(sp, agent_radius, cfg.M * cfg.dt, cfg.obs_uncertainty_horizon)) warn = true;
+                    for (size_t oi = 0; oi < obstacles.size() && !warn; oi++) {
+                        const auto &o = obstacles[oi];
+                        if (dist_to_path(o, sp) > reach[oi]) continue;
+                        if (o.is_collided(sp, agent_radius, horizon, cfg.obs_uncertainty_horizon)) warn = true;
+                    }
                     exist[id] = 1;
                     warning[id] = warn ? 1 : 0;
                 }
         // Grid::Grid (graph.cpp:371-431): neighbours in the order left, right, up, down, top, bottom; an edge v -> w
         // exists unless it leads from a safe node into a warning node
-        nbr.assign(nn, {});
+        nbr.resize(nn);
+        for (auto &v : nbr) v.clear();  // keeps the capacity: no allocation after the first step
         const int d6[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
         for (int z = 0; z < dim[2]; z++)
             for (int y = 0; y < dim[1]; y++)
@@ -302,7 +369,7 @@ struct GridMapf {
     double obs_cost(const std::set<int> &obs_ids, int node) const {  // :686-698
         double cost = 0;
         for (int oid : obs_ids) {
-            const int d = obs_tables[oid][node];
+            const int d = (*obs_tables_p)[oid][node];
             cost += d == 0 ? INF : 1.0 / ((double)d * d);
         }
         return cost;
@@ -387,11 +454,19 @@ struct GridMapf {
                                            const std::vector<int> &obs, const std::vector<float> &obs_dist) {
         const int n = (int)cur.size();
         std::mt19937 mt(0);  // DEFAULT_SEED, a fresh generator for every Problem (problem.cpp:84)
-        std::vector<std::vector<int>> table(n);  // Solver::createDistanceTable: BFS from every goal
+        // Solver::createDistanceTable: BFS from every goal.  A table depends on the grid map and the goal node only: kept per
+        // grid state (the map without dynamic obstacles never changes; the one with them is new every step)
+        std::vector<const std::vector<int> *> table(n);
         for (int i = 0; i < n; i++) {
-            table[i] = bfs_table(goal[i]);
-            for (auto &d : table[i])
-                if (d >= (int)INF) d = MAX_TIMESTEP;
+            auto &cache = goal_tables[active];
+            auto it = cache.find(goal[i]);
+            if (it == cache.end()) {
+                std::vector<int> t = bfs_table(goal[i]);
+                for (auto &d : t)
+                    if (d >= (int)INF) d = MAX_TIMESTEP;
+                it = cache.emplace(goal[i], std::move(t)).first;
+            }
+            table[i] = &it->second;
         }
         std::vector<PAgent> A(n);
         std::vector<int> occupied_now(n_nodes(), -1), occupied_next(n_nodes(), -1);
@@ -405,7 +480,7 @@ struct GridMapf {
         std::priority_queue<int, std::vector<int>, decltype(compare)> undecided(compare);
         std::vector<int> decided;
         for (int i = 0; i < n; i++) {
-            A[i] = PAgent{i, cur[i], -1, goal[i], obs_dist[i] > 1000 ? -1 : obs[i], 0, table[i][start[i]], (float)i / (float)n, obs_dist[i]};
+            A[i] = PAgent{i, cur[i], -1, goal[i], obs_dist[i] > 1000 ? -1 : obs[i], 0, (*table[i])[start[i]], (float)i / (float)n, obs_dist[i]};
             undecided.push(i);
             occupied_now[cur[i]] = i;
         }
@@ -441,7 +516,7 @@ struct GridMapf {
                 if (v == -1) {
                     v = u;
                 } else {
-                    const int c_v = table[a.id][v], c_u = table[a.id][u];
+                    const int c_v = (*table[a.id])[v], c_u = (*table[a.id])[u];
                     const float o_v = obs_dist_to(a, v), o_u = obs_dist_to(a, u);
                     const float d_v = goal_dist(a, v), d_u = goal_dist(a, u);
                     if ((c_u < c_v) || (c_u == c_v && occupied_now[v] != -1 && occupied_now[u] == -1) || (c_u == c_v && o_u > o_v) ||
@@ -593,8 +668,12 @@ struct GridMapf {
         bool any_node = false;
         for (int id = 0; id < n_nodes() && !any_node; id++) any_node = exist[id];
         if (!any_node) return false;  // every node is occupied: point_to_closest_node has nothing to return (the planner "fails")
-        obs_tables.clear();
-        for (const auto &o : obstacles) obs_tables.push_back(bfs_table(point_to_closest_node(o.position)));
+        if (!tables_valid[active]) {
+            tables[active].clear();
+            for (const auto &o : obstacles) tables[active].push_back(bfs_table(point_to_closest_node(o.position)));
+            tables_valid[active] = true;
+        }
+        obs_tables_p = &tables[active];
         update_doi(agents, obstacles, agent_radius);
         update_goal(agents);
         bool ok = run_mapf(agents);
@@ -650,6 +729,7 @@ extern "C" int dlscqp_mapf_step(dlscqp_mapf *m, const dlscqp_mapf_step_args *s) 
     if (s->plans && s->n1 <= 0) return DLSCQP_ERR_INVALID_ARGUMENT;
     GridMapf &g = m->g;
     if (g.n_nodes() <= 0) return DLSCQP_ERR_INVALID_ARGUMENT;  // a world without a grid: there is nothing to plan on
+    g.new_step();
     const dlscqp_mapf_config &cfg = g.cfg;
     const int N = s->n_agents;
     auto p3 = [](const float *a, int i) { return P3{a[3 * i], a[3 * i + 1], a[3 * i + 2]}; };
