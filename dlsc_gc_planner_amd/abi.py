@@ -315,10 +315,11 @@ def load_library():
     lib.dlscqp_plan_batch_device.restype = C.c_int
     lib.dlscqp_generate_lsc_device.argtypes = [vp, P(LscGen), vp]
     lib.dlscqp_generate_lsc_device.restype = C.c_int
-    lib.dlscqp_selftest.argtypes = [vp]
-    lib.dlscqp_selftest.restype = C.c_int
-    lib.dlscqp_neighbours_device.argtypes = [vp, P(NeighbourSearch), vp]
-    lib.dlscqp_neighbours_device.restype = C.c_int
+    if hasattr(lib, "dlscqp_selftest"):  # (tests/tools/kbench.py also loads builds of earlier rounds for A/B timing)
+        lib.dlscqp_selftest.argtypes = [vp]
+        lib.dlscqp_selftest.restype = C.c_int
+        lib.dlscqp_neighbours_device.argtypes = [vp, P(NeighbourSearch), vp]
+        lib.dlscqp_neighbours_device.restype = C.c_int
     lib.dlscqp_waypoint_trap_device.argtypes = [vp, P(LscGen), P(WaypointTrap), vp]
     lib.dlscqp_waypoint_trap_device.restype = C.c_int
     lib.dlscqp_advance_device.argtypes = [vp, P(Advance), vp]

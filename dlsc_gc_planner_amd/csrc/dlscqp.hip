@@ -728,7 +728,7 @@ struct dlscqp_ctx {
     double dt;
     HostTables tb;
     KParams kp;  // with device table pointers
-    double *d_tabKIW = nullptr, *d_tabG = nullptr, *d_tabX0s = nullptr, *d_tabX0g = nullptr, *d_tabNN = nullptr, *d_tabSIW = nullptr;
+    double *d_tabPhi = nullptr, *d_tabKIW = nullptr, *d_tabG = nullptr, *d_tabX0s = nullptr, *d_tabX0g = nullptr, *d_tabNN = nullptr, *d_tabSIW = nullptr;
     Slot *d_slots = nullptr;
     hipStream_t stream = nullptr;
     int max_dyn_lds[3 * (DQ_N_INSTANCES + 1)] = {};  // second third: the WIDE builds, last third: the builds with helper wavefronts
@@ -758,6 +758,7 @@ static int upload_tables(dlscqp_ctx *c) {
     if (!up((void **)&c->d_tabNN, c->tb.tabNN.data(), c->tb.tabNN.size() * 8)) return DLSCQP_ERR_HIP;
     if (!up((void **)&c->d_tabSIW, c->tb.tabSIW.data(), c->tb.tabSIW.size() * 8)) return DLSCQP_ERR_HIP;
     if (!up((void **)&c->d_tabKIW, c->tb.tabKIW.data(), c->tb.tabKIW.size() * 8)) return DLSCQP_ERR_HIP;
+    if (!up((void **)&c->d_tabPhi, c->tb.tabPhi.data(), c->tb.tabPhi.size() * 8)) return DLSCQP_ERR_HIP;
     if (!up((void **)&c->d_slots, c->tb.slots.data(), c->tb.slots.size() * sizeof(Slot))) return DLSCQP_ERR_HIP;
     c->kp = c->tb.kp;
     c->kp.tabG = c->d_tabG;
@@ -766,6 +767,7 @@ static int upload_tables(dlscqp_ctx *c) {
     c->kp.tabNN = c->d_tabNN;
     c->kp.tabSIW = c->d_tabSIW;
     c->kp.tabKIW = c->d_tabKIW;
+    c->kp.tabPhi = c->d_tabPhi;
     c->kp.slots = c->d_slots;
     return DLSCQP_SUCCESS;
 }
@@ -820,6 +822,7 @@ extern "C" void dlscqp_destroy(dlscqp_ctx *c) {
     if (c->d_tabNN) (void)hipFree(c->d_tabNN);
     if (c->d_tabSIW) (void)hipFree(c->d_tabSIW);
     if (c->d_tabKIW) (void)hipFree(c->d_tabKIW);
+    if (c->d_tabPhi) (void)hipFree(c->d_tabPhi);
     if (c->d_slots) (void)hipFree(c->d_slots);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->work) (void)hipFree(c->work);

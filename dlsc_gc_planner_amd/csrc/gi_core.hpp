@@ -1889,8 +1889,24 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         exit_stores(status, true, iters, n_add, n_drop, q, false, 0.0);
         return;
     }
-    // objective before the guarded stores below, so that nothing computed later is live across them
-    const double fval = out_cost ? objective() : 0.0;
+    // objective before the guarded stores below, so that nothing computed later is live across them.  An agent that never
+    // iterated sits at its unconstrained minimiser: its objective is a 4 x 4 quadratic form per axis (qp_tables.cpp: tabPhi)
+    double fval = 0.0;
+    if (out_cost) {
+        if (iters == 0 && kp.phi_ok) {  // uniform
+            const double *ph = kp.tabPhi + (size_t)(T - 1) * 10;
+            double pq[10];
+#pragma unroll
+            for (int j = 0; j < 10; j++) pq[j] = ph[j];
+            for (int k = 0; k < dim; k++) {
+                const double s0 = (double)pos[k], s1 = (double)vel[k], s2 = (double)acc[k], s3 = (double)goal[k];
+                fval += s0 * (pq[0] * s0 + 2.0 * (pq[1] * s1 + pq[2] * s2 + pq[3] * s3)) + s1 * (pq[4] * s1 + 2.0 * (pq[5] * s2 + pq[6] * s3)) +
+                        s2 * (pq[7] * s2 + 2.0 * pq[8] * s3) + pq[9] * s3 * s3;
+            }
+        } else {
+            fval = objective();
+        }
+    }
     // Per-lane results: the only lane-guarded instructions of the kernel are these final global stores.
     w.each([&](int l) {
         // traj_optimizer.cpp:69-83: point3d(float) control points, z = world_z_2d in 2-D

@@ -237,6 +237,8 @@ bool build_tables(const dlscqp_config &cfg, int dim, int M, int n, int phi, doub
     out.tabN.assign((size_t)M * P * f, 0.0);
     out.tabX0s.assign((size_t)M * P * 3, 0.0);
     out.tabX0g.assign((size_t)M * P, 0.0);
+    out.tabPhi.assign((size_t)M * 10, 0.0);
+    kp.phi_ok = 1;
     Mat H((size_t)P * P), HZ((size_t)P * f), Hr((size_t)f * f), Nt((size_t)P * f), HXp((size_t)P * 3), G((size_t)f * 3), tv(f);
     for (int T = 1; T <= M; T++) {
         std::fill(H.begin(), H.end(), 0.0);
@@ -298,6 +300,28 @@ bool build_tables(const dlscqp_config &cfg, int dim, int M, int n, int phi, doub
             double t = 0;
             for (int a = 0; a < f; a++) t += Nt[(size_t)p * f + a] * tv[a];
             oXg[p] = t;
+        }
+        // The objective at the unconstrained minimiser, per axis, as a quadratic form s' Psi_T s of s = (pos, vel, acc, goal):
+        // x0 = [X0s X0g] s, so c' Qb c and the terminal terms (c_{m,n} - goal)^2 are quadratic in s with the very tables the
+        // kernel builds x0 from.  What an agent that never iterates reports as its cost (cplex.getObjValue(),
+        // traj_optimizer.cpp:109) without a pass over its control points.  (A 3 x 3 form in (goal - pos, vel, acc) would do
+        // in exact arithmetic -- the model is translation-invariant -- but the tables are so only to ~1e-10, which shows in
+        // costs of 1e-2.)
+        {
+            double *oPhi = &out.tabPhi[(size_t)(T - 1) * 10];
+            auto Bcol = [&](int p, int c) { return c == 3 ? oXg[p] : oXs[p * 3 + c]; };
+            for (int a = 0, q = 0; a < 4; a++)
+                for (int b = a; b < 4; b++, q++) {
+                    double t = 0;
+                    for (int m = 0; m < M; m++)
+                        for (int i = 0; i < N; i++)
+                            for (int j = 0; j < N; j++) t += Bcol(m * N + i, a) * kp.Qb[i * N + j] * Bcol(m * N + j, b);
+                    for (int m = M - T; m < M; m++) {
+                        const int pe = m * N + n;
+                        t += cfg.terminal_weight * (Bcol(pe, a) - (a == 3 ? 1.0 : 0.0)) * (Bcol(pe, b) - (b == 3 ? 1.0 : 0.0));
+                    }
+                    oPhi[q] = t;
+                }
         }
     }
 

@@ -17,6 +17,7 @@ struct HostTables {
     std::vector<double> tabNN;   // [M][P]
     std::vector<double> tabSIW;  // [M][n_slots]
     std::vector<double> tabKIW;  // [M][3][P]
+    std::vector<double> tabPhi;  // [M][10]
     std::vector<Slot> slots;
 };
 

@@ -31,6 +31,7 @@ struct KParams {
     int nb;        // entries of the per-agent bound table
     int has_comm, use_sfc, stop_mode, rsfc_mode;
     int max_iter;
+    int phi_ok;    // tabPhi is valid
     int dbg_exit_phase;  // profiling builds only (gi_core.hpp: DQ_PHASE_EXIT), else -1
     int wd_cut;    // the weak-duality infeasibility test of gi_core.hpp is valid (its objective bound assumes phi_n = 1)
     // weights and constants (param.hpp)
@@ -49,6 +50,7 @@ struct KParams {
     const double *tabX0g;         // [M][P]
     const double *tabNN;          // [M][P]        |N_T[p,:]|^2  (pivot scaling of LSC rows)
     const double *tabSIW;         // [M][n_slots]  1 / |N_T' a_slot|  (pivot scaling of structured rows)
+    const double *tabPhi;         // [M][10]       objective of the unconstrained minimiser as a quadratic form of (pos, vel, acc, goal) per axis
     const double *tabKIW;         // [M][3][P]     the same by kind and first control point: bound / velocity / acceleration row at p
     const Slot *slots;            // [n_slots]
 };

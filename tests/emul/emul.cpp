@@ -138,6 +138,7 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
     kp.tabNN = tb.tabNN.data();
     kp.tabSIW = tb.tabSIW.data();
     kp.tabKIW = tb.tabKIW.data();
+    kp.tabPhi = tb.tabPhi.data();
     kp.slots = tb.slots.data();
     const int64_t nrows = row_offsets[n_agents];
     std::vector<float> nx(nrows), ny(nrows), nz(nrows), px(nrows), py(nrows), pz(nrows);
@@ -400,7 +401,7 @@ extern "C" int emul_throughput(const dlscqp_config *cfg, int n_agents, const dls
     if (!build_tables(*cfg, cfg->world_dimension, cfg->M, cfg->n, cfg->phi, cfg->dt, tb, err)) return -1;
     KParams kp = tb.kp;
     kp.tabG = tb.tabG.data(); kp.tabX0s = tb.tabX0s.data(); kp.tabX0g = tb.tabX0g.data();
-    kp.tabNN = tb.tabNN.data(); kp.tabSIW = tb.tabSIW.data(); kp.tabKIW = tb.tabKIW.data(); kp.slots = tb.slots.data();
+    kp.tabNN = tb.tabNN.data(); kp.tabSIW = tb.tabSIW.data(); kp.tabKIW = tb.tabKIW.data(); kp.tabPhi = tb.tabPhi.data(); kp.slots = tb.slots.data();
     const int64_t nrows = row_offsets[n_agents];
     std::vector<float> nx(nrows), ny(nrows), nz(nrows), px(nrows), py(nrows), pz(nrows);
     std::vector<double> d(nrows);

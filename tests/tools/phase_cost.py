@@ -50,6 +50,7 @@ def main():
     opt0.close()
     abi._LIB = None
     os.environ["DLSCQP_LIB"] = lib
+    os.environ["DLSCQP_NO_SELFTEST"] = "1"  # a kernel that stops after a phase does not pass the self-test of dlscqp_create, by design
     print("launch time of %d agents [ms]; 'rotation' = bench.py's four batches in id order, 'zero' = only agents that never iterate" % N)
     prev = {}
     for ph, name in ((0, "agent record, row/slot cache, goal LP"), (1, "+ x0, bound table, scalings"), (2, "+ first pricing pass"),
