@@ -69,6 +69,8 @@ namespace dlscqp {
 struct MemLayout {
     int r_max, nx_max, ldg, nflag;
     int oG, oRp, oX, oDx, oBlo, oBhi;  // in doubles
+    int oLam;                          // by-kind shapes: two tables of nx_max + 2 doubles, the weights of the active velocity and acceleration
+                                       // rows by coordinate (plan_agent: dense step direction)
     int oMail;                         // 8 doubles: what the planning wavefront and its helper wavefronts tell each other (dlscqp.hip)
     int oDump;                         // 32 dump slots (lane & 31) for the lanes that have nothing to store, right behind S;
                                        // then two doubles that stay 0.0 (what a masked read of S is sent to)
@@ -97,6 +99,7 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
     L.oBlo = o; o += kp.nb;
     L.oBhi = o; o += kp.nb;
     L.oMail = o; o += 8;
+    L.oLam = o; o += by_kind ? 2 * (L.nx_max + 2) : 0;
     L.oFlag = o * 8;
     L.bytes = (L.oFlag + L.nflag + 1 + 15) & ~15;  // + one flag byte as the dump of the flag array
     return L;
@@ -109,6 +112,9 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
 #ifndef DQ_G2_KU  // register caches of the two-register runtime-shape instantiation (also the one with HBM working-set variants)
 #define DQ_G2_KU 2
 #define DQ_G2_SU 6
+#endif
+#ifndef DQ_QDENSE  // plan_agent: from this many active velocity / acceleration rows on, their part of the step direction is a dense product
+#define DQ_QDENSE 8
 #endif
 #define DQ_INSTANCES(X)          \
     X(0, 1, 3, 13, 5, 2, 0, 0)   \
@@ -183,6 +189,7 @@ DQ_FN int blend_idx(bool cond, int a, int b) {
 }
 
 DQ_FN int ctz64(uint64_t m) { return __builtin_ctzll(m); }
+DQ_FN int popc64(uint64_t m) { return __builtin_popcountll(m); }
 
 // Pivot scores carry the code of their row in the TAG_BITS low bits of the mantissa (a relative perturbation of 2^-32):
 // the arg-max over all rows of an agent is then a plain maximum -- one v_max_f64 per candidate row, one wave reduction,
@@ -1212,6 +1219,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     const double v = tG[in ? j : ng - 1];
                     base[blend_idx(in, oG + j, odump + (l & 31))] = v;
                 }
+                if (BYK && DXREG)  // the weight tables of the dense step direction: zero wherever no such row is active
+                    for (int j0 = 0; j0 < 2 * (nxc + 2); j0 += 64)
+                        base[blend_idx(j0 + l < 2 * (nxc + 2), lay.oLam + j0 + l, odump + (l & 31))] = 0.0;
             });
             w.sync();
             factors_ready = true;
@@ -1466,12 +1476,15 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             // ---- step direction in control-point space: dx = G (a - A' rv) ------------------------------------------
             // lane p: row p of G against the sparse vector a - A' rv -- one table entry per POINT row, three per LINE row
             RegD wc[RC][3], wcp[RC][3];  // -rv_i x coefficient; wcp: the same with zeros for LINE rows
-            RegI is_line[RC];
+            RegI is_line[RC], is_point[RC], is_kline[RC];
             w.each([&](int l) {
 #pragma unroll
                 for (int c = 0; c < RC; c++) {
                     const bool on = l + 64 * c < q;
                     const bool line = (a_pk[c].at(l) >> 26) & 1;
+                    const int cd = act[c].at(l);
+                    is_kline[c].at(l) = (BYK && DXREG && on && (cd >> 3) < UL0 && (cd & 7) >= 2) ? 1 : 0;  // velocity / acceleration row of a coordinate
+                    is_point[c].at(l) = (on & !line) ? 1 : 0;
                     const double mr = on ? -rv[c].at(l) : 0.0;
 #pragma unroll
                     for (int t = 0; t < 3; t++) {
@@ -1482,9 +1495,57 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     is_line[c].at(l) = (on & line) ? 1 : 0;
                 }
             });
-            uint64_t line_rows[RC];
+            uint64_t line_rows[RC], point_rows[RC];
+            // Many active velocity / acceleration rows (static shapes): the loops over the active rows below cost ~250 cycles per
+            // such row and the agents that set the length of a launch have thirty of them (infeasible agents: acceleration rows
+            // all along the horizon).  Such a row is (coordinate j, kind) and nothing else -- its entries are (-1, 1) or (1, -2, 1)
+            // times one weight at j, j+1, j+2 -- so every row's lane stores that weight at [kind][j] of a table in LDS (no two
+            // active rows share a slot; a slot is zeroed when its row is dropped), lane p gathers
+            // u_j = v_j - v_(j-1) + a_j - 2 a_(j-1) + a_(j-2) for its control point (a velocity row never starts on the last point of
+            // a segment, an acceleration row not on the last two: the entries read across a segment or axis boundary are zeros)
+            // and dx gets G u as a dense product: P table reads and dim P FMAs per lane whatever the number of rows (~2 800 cycles
+            // for P = 30 against ~7 000 for 25 such rows; measured: the slowest agent of the S64 batch 238 -> 214 us, the launch
+            // 0.359 -> 0.325 ms).  Bound rows in a third table were tried and lost 1 % (more LDS, a longer gather).
+            bool dense_dx = false;
+            RegD ureg[3];  // dense_dx: lane p holds u of control point p
+            if (BYK && DXREG) {
+                int n_kline = 0;
 #pragma unroll
-            for (int c = 0; c < RC; c++) line_rows[c] = w.ballot(is_line[c]);
+                for (int c = 0; c < RC; c++) n_kline += popc64(w.ballot(is_kline[c]));
+                dense_dx = n_kline >= (P > 5 * DQ_QDENSE ? P / 5 : DQ_QDENSE);  // uniform; the dense product costs ~40 cycles per control point
+            }
+#pragma unroll
+            for (int c = 0; c < RC; c++) {
+                line_rows[c] = w.ballot(is_line[c]);
+                point_rows[c] = w.ballot(is_point[c]);
+                if (dense_dx) line_rows[c] &= ~w.ballot(is_kline[c]);
+            }
+            if (dense_dx) {  // uniform
+                double *lam = base + lay.oLam;
+                const int LS = nxc + 2;
+                w.each([&](int l) {
+#pragma unroll
+                    for (int c = 0; c < RC; c++) {
+                        const int cd = act[c].at(l);
+                        const bool kl = is_kline[c].at(l) != 0;
+                        const int slot = ((cd & 7) >= 4 ? LS : 0) + 2 + (kl ? cd >> 3 : 0);
+                        base[blend_idx(kl, lay.oLam + slot, odump + (l & 31))] = wc[c][0].at(l);  // the weight of the row's first point
+                    }
+                });
+                w.sync();
+                w.each([&](int l) {
+                    const bool in = l < P;
+                    const int pc = in ? l : P - 1;
+#pragma unroll
+                    for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++) {
+                        const int j = k * P + pc;
+                        double v0 = lam[j + 2], v1 = lam[j + 1], a0 = lam[LS + j + 2], a1 = lam[LS + j + 1], a2 = lam[LS + j];
+                        DQ_KEEP(v0); DQ_KEEP(v1); DQ_KEEP(a0); DQ_KEEP(a1); DQ_KEEP(a2);
+                        ureg[k].at(l) = in ? (v0 - v1) + ((a0 - 2.0 * a1) + a2) : 0.0;
+                    }
+                    if ((DIMS > 0 ? DIMS : 3) < 3) ureg[2].at(l) = 0.0;
+                });
+            }
             // DXREG (static shapes without slack variables, P <= 64): lane p keeps dx of control point p in registers; the
             // step is taken from there and dx goes to LDS only when |z|^2 has to be evaluated as a quadratic form (below)
             RegD dkr[3];
@@ -1502,6 +1563,53 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                         dk[1] = new_line ? (new_axis == 1 ? sl : 0.0) : ncf[1] * g0;
                         dk[2] = new_line ? (new_axis == 2 ? sl : 0.0) : ncf[2] * g0;
                     }
+                    if (BYK && DXREG && dense_dx) {  // uniform
+                        const double *gr = G + pc * ldg;
+                        // (u through v_readlane: wave-uniform operands in scalar registers, like the weights of the loops below;
+                        // the kernel has no vector registers left for a block of u read from LDS)
+                        constexpr int UB = 6;  // P = 6 M: no remainder
+                        for (int pp = 0; pp < P; pp += UB) {
+                            double gq[UB];
+#pragma unroll
+                            for (int u = 0; u < UB; u++) gq[u] = gr[pp + u];
+#pragma unroll
+                            for (int u = 0; u < UB; u++) DQ_KEEP(gq[u]);
+#pragma unroll
+                            for (int u = 0; u < UB; u++) {
+#pragma unroll
+                                for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++) dk[k] = fma(gq[u], w.bcast(ureg[k], pp + u), dk[k]);
+                            }
+                        }
+                        // the POINT rows by their mask: the loop over all active rows below would spend most of its trips on
+                        // the rows the dense product has dealt with
+#pragma unroll
+                        for (int c = 0; c < RC; c++) {
+                            uint64_t todo = point_rows[c];
+                            while (todo) {  // uniform
+                                double gq[DB], wq[DB][3];
+#pragma unroll
+                                for (int u = 0; u < DB; u++) {
+                                    const bool have = todo != 0;
+                                    const int il = have ? ctz64(todo) : 0;
+                                    todo &= todo - (have ? 1 : 0);
+                                    gq[u] = G[(int)(w.bcast(a_pk[c], il) & 0xFF) * ldg + pc];
+#pragma unroll
+                                    for (int t = 0; t < 3; t++) {
+                                        const double wv = w.bcast(wcp[c][t], il);
+                                        wq[u][t] = have ? wv : 0.0;
+                                    }
+                                }
+#pragma unroll
+                                for (int u = 0; u < DB; u++) DQ_KEEP(gq[u]);
+#pragma unroll
+                                for (int u = 0; u < DB; u++) {
+                                    dk[0] = fma(wq[u][0], gq[u], dk[0]);
+                                    dk[1] = fma(wq[u][1], gq[u], dk[1]);
+                                    if (DIMS != 2) dk[2] = fma(wq[u][2], gq[u], dk[2]);
+                                }
+                            }
+                        }
+                    } else
                     // POINT rows, in blocks of DB (its weights are wave-uniform: a block must fit the scalar registers) with the table reads of a block issued together (a LINE row, and what the last
                     // block holds beyond the active rows, multiplies a valid table entry by zero)
                     for (int i0 = 0; i0 < q; i0 += DB) {
@@ -1773,6 +1881,12 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 // ---- drop active row ldrop: delete column l of R, restore the triangle with Givens ----
                 const int lcol = ldrop;
                 set_skip(DQ_BCI(act, lcol), false, DQ_BC(a_rhs, lcol));
+                if (BYK && DXREG) {  // its entry of the weight tables (dense step direction) back to zero
+                    const int cd = DQ_BCI(act, lcol);
+                    const bool sl = (cd >> 3) < UL0 && (cd & 7) >= 2;
+                    const int slot = ((cd & 7) >= 4 ? nxc + 2 : 0) + 2 + (sl ? cd >> 3 : 0);
+                    w.each([&](int l) { base[blend_idx(sl, lay.oLam + slot, odump + (l & 31))] = 0.0; });
+                }
                 // Deleting column lcol of R: the rotations G of columns (t, t+1), t = lcol..q-2, that restore the
                 // triangle are those that sweep row lcol of S into its last entry; S' = (S without row lcol) G'
                 // without its last column.  All angles come from one prefix sum of squares.
