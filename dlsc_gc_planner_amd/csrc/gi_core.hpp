@@ -79,6 +79,12 @@ struct MemLayout {
     int bytes;
 };
 
+// The Gram table of the 2-D, M = 10 shape (P = 60: 29 KB) stays in HBM / L2: with it in LDS three agents fit a CU, without it
+// the registers' eight (DQ_G_IN_LDS=1 puts it back).
+#ifndef DQ_G_IN_LDS
+#define DQ_G_IN_LDS 0
+#endif
+DQ_FN bool gram_table_in_lds(int dim, int M, bool by_kind) { return DQ_G_IN_LDS || !(by_kind && dim == 2 && M == 10); }
 DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int KU, int SU, bool by_kind) {
     MemLayout L;
     const int nslk = kp.M * max_slack_obs;
@@ -91,7 +97,7 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
     L.nflag = cold_rows + 2 * cold_slots;
     L.kmax = kmax;
     int o = 0;
-    L.oG = o; o += kp.P * L.ldg;
+    L.oG = o; o += gram_table_in_lds(kp.dim, kp.M, by_kind) ? kp.P * L.ldg : 0;
     L.oRp = o; o += L.r_max * (L.r_max + 1) / 2;
     L.oDump = o; o += 32 + 2;
     L.oX = o; o += L.nx_max;
@@ -614,7 +620,8 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     // layout (make_layout): compile-time for static shapes without slack obstacles, else from the arguments
     constexpr bool ST = DIMS > 0 && SLK == 0;
     constexpr int P_ST = MS * 6, LDG_ST = (MS * 6) | 1, R_ST = DIMS * FS, NX_ST = DIMS * MS * 6;
-    constexpr int ORP_ST = P_ST * LDG_ST, ODUMP_ST = ORP_ST + R_ST * (R_ST + 1) / 2, OX_ST = ODUMP_ST + 32 + 2;
+    constexpr bool GLDS = DQ_G_IN_LDS || !(DIMS == 2 && MS == 10);  // gram_table_in_lds
+    constexpr int ORP_ST = GLDS ? P_ST * LDG_ST : 0, ODUMP_ST = ORP_ST + R_ST * (R_ST + 1) / 2, OX_ST = ODUMP_ST + 32 + 2;
     const int r_max = ST ? R_ST : lay.r_max;
     const int ldg = DIMS > 0 ? LDG_ST : lay.ldg;
     const int oG = 0;
@@ -624,7 +631,8 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     const int oDx = ST ? OX_ST + NX_ST : lay.oDx;
     const int oBlo = ST ? OX_ST + 2 * NX_ST : lay.oBlo;
     const int oBhi = lay.oBhi;
-    double *G = base + oG, *Rp = base + oRp, *x = base + oX, *dxl = base + oDx;
+    const double *G = base + oG;  // (or the table itself where it is, below)
+    double *Rp = base + oRp, *x = base + oX, *dxl = base + oDx;
     double *blo = base + oBlo, *bhi = base + oBhi;
     unsigned char *cold_flag = mem + lay.oFlag;
     const int rc = dim * f;      // whitened control-point dimension
@@ -651,6 +659,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     }
 
     const double *tG = kp.tabG + (size_t)(T - 1) * P * ldg;
+    if (!GLDS) G = tG;
     const double *tXs = kp.tabX0s + (size_t)(T - 1) * P * 3;
     const double *tXg = kp.tabX0g + (size_t)(T - 1) * P;
     const double *tNN = kp.tabNN + (size_t)(T - 1) * P;
@@ -1212,7 +1221,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 // out of the iteration loop (where loop-invariant address registers were kept alive in scratch)
                 int l = l0;
                 DQ_KEEP(l);
-                const int ng = P * ldg;
+                const int ng = GLDS ? P * ldg : 0;
                 for (int j0 = 0; j0 < ng; j0 += 64) {
                     const int j = j0 + l;
                     const bool in = j < ng;
