@@ -16,6 +16,9 @@
 #include "grid_mapf.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <unordered_map>
 #include <cstring>
@@ -66,8 +69,7 @@ unsigned long uniform_gcc9(std::mt19937 &g, unsigned long b) {
 
 // libstdc++ (GCC 7-10) std::shuffle with a 32-bit generator: two swap positions per draw
 template <class T>
-void shuffle_gcc9(std::vector<T> &v, std::mt19937 &g) {
-    const size_t n = v.size();
+void shuffle_gcc9(T *v, size_t n, std::mt19937 &g) {
     if (n == 0) return;
     size_t i = 1;
     if (n % 2 == 0) {
@@ -135,7 +137,26 @@ struct PlanResult {
     }
 };
 
+// DLSCQP_MAPF_PROFILE=1 in the environment: where a step's time goes, printed when the planner is destroyed
+struct MapfProfile {
+    bool on = std::getenv("DLSCQP_MAPF_PROFILE") != nullptr;
+    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long steps = 0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    struct Scope {
+        MapfProfile &p; int k; double t0;
+        Scope(MapfProfile &pp, int kk) : p(pp), k(kk), t0(pp.on ? now() : 0.0) {}
+        ~Scope() { if (p.on) p.t[k] += now() - t0; }
+    };
+    ~MapfProfile() {
+        if (!on || !steps) return;
+        const char *names[8] = {"grid map", "obstacle tables", "obstacles of interest", "escape goals", "PIBT", "goal tables (inside PIBT)", "waypoint rules", "whole step"};
+        for (int k = 0; k < 8; k++) std::fprintf(stderr, "[mapf profile] %-28s %8.1f us per step\n", names[k], 1e6 * t[k] / steps);
+    }
+};
+
 struct GridMapf {
+    MapfProfile prof;
     dlscqp_mapf_config cfg;
     SfcWorldHost world;
     bool have_world = false;
@@ -146,19 +167,61 @@ struct GridMapf {
     // reuses them: the map depends on the world, the agents' radius and the obstacles, not on the group (the reference
     // rebuilds it per agent; the result is the same).  `exist`, `warning`, `nbr` are the active one.
     std::vector<char> exist, warning;
-    std::vector<std::vector<int>> nbr;
+    // adjacency, flat: node v has nbr_n[v] neighbours at nbr_flat[6 v ...], in the order of Grid::Grid (graph.cpp:371-431)
+    std::vector<int> nbr_flat;
+    std::vector<unsigned char> nbr_n;
+    struct NbrRange {
+        const int *b, *e;
+        const int *begin() const { return b; }
+        const int *end() const { return e; }
+    };
+    NbrRange nbr_of(int v) const { return {nbr_flat.data() + 6 * (size_t)v, nbr_flat.data() + 6 * (size_t)v + nbr_n[v]}; }
+    // A breadth-first distance table that is filled as far as it is asked: at(v) expands the search until v has its distance
+    // (or the component of the source is exhausted: unreachable).  The values are those of the full search -- a node's first
+    // visit is its distance -- so a planner that only asks about the nodes between its agents and their goals never pays
+    // for the rest of the map.
+    struct LazyBfs {
+        std::vector<int> t, q;
+        int head = 0, tail = 0;
+        void start(int n_nodes, int src) {
+            t.assign(n_nodes, (int)INF);
+            q.resize(n_nodes + 1);  // (+1: lazy_at writes a candidate before it knows whether it is new)
+            head = tail = 0;
+            q[tail++] = src;
+            t[src] = 0;
+        }
+    };
+    int lazy_at(LazyBfs &b, int v) const {
+        const int inf = (int)INF;
+        while (b.t[v] == inf && b.head < b.tail) {
+            const int n = b.q[b.head++];
+            const int d = b.t[n] + 1;
+            for (int m : nbr_of(n)) {  // without a branch on "seen before": it is taken half the time, in no pattern
+                const int tm = b.t[m];
+                const bool fresh = tm == inf;
+                b.t[m] = fresh ? d : tm;
+                b.q[b.tail] = m;
+                b.tail += fresh ? 1 : 0;
+            }
+        }
+        return b.t[v];
+    }
     struct GridState {
         std::vector<char> exist, warning;
-        std::vector<std::vector<int>> nbr;
+        std::vector<int> nbr_flat;
+        std::vector<unsigned char> nbr_n;
         bool valid = false;
         double radius = -1.0;
     } stored[2];
     int active = -1;
     std::vector<char> static_free;  // node is clear of the static world (depends on the agents' radius only)
     double static_radius = -1.0;
+    std::vector<int> static_adj;    // adjacency of the map without dynamic obstacles (update_grid_map)
+    std::vector<unsigned char> static_adj_n;
+    double static_adj_radius = -1.0;
     void use_state(int which) {
         if (active == which) return;
-        auto swap_with = [&](GridState &g) { exist.swap(g.exist); warning.swap(g.warning); nbr.swap(g.nbr); };
+        auto swap_with = [&](GridState &g) { exist.swap(g.exist); warning.swap(g.warning); nbr_flat.swap(g.nbr_flat); nbr_n.swap(g.nbr_n); };
         if (active >= 0) swap_with(stored[active]);
         swap_with(stored[which]);
         active = which;
@@ -169,10 +232,10 @@ struct GridMapf {
         goal_tables[1].clear();
     }
     // breadth-first distance tables from the obstacles' nodes, per grid state and step (every group of a step reads the same)
-    std::vector<std::vector<int>> tables[2];
+    mutable std::vector<LazyBfs> tables[2];  // by obstacle, started when the step's first group is planned, filled as far as asked
     bool tables_valid[2] = {false, false};
-    const std::vector<std::vector<int>> *obs_tables_p = nullptr;
-    std::unordered_map<int, std::vector<int>> goal_tables[2];  // PIBT's distance tables by goal node, per grid state
+    std::vector<LazyBfs> *obs_tables_p = nullptr;
+    mutable std::unordered_map<int, LazyBfs> goal_tables[2];  // PIBT's distance tables by goal node, per grid state
     PlanResult plan_result;
     int n_agents = 0;
 
@@ -296,80 +359,85 @@ struct GridMapf {
                             if (static_clearance(pos_to_point(x, y, z)) < agent_radius - EPS_F) static_free[node_id(x, y, z)] = 0;
             static_radius = agent_radius;
         }
-        exist.assign(nn, 0);
+        // The map without dynamic obstacles -- nodes clear of the static world, six-neighbour adjacency in the order of Grid::Grid
+        // (graph.cpp:371-431: left, right, up, down, top, bottom) -- is built once per radius; a step's map is that one with the
+        // warning nodes marked and the edges from safe nodes into warning nodes taken out.
+        if (static_adj_radius != agent_radius) {
+            static_adj.assign((size_t)6 * nn, -1);
+            static_adj_n.assign(nn, 0);
+            const int d6[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+            for (int z = 0; z < dim[2]; z++)
+                for (int y = 0; y < dim[1]; y++)
+                    for (int x = 0; x < dim[0]; x++) {
+                        const int v = node_id(x, y, z);
+                        if (!static_free[v]) continue;
+                        for (const auto &d : d6) {
+                            const int x1 = x + d[0], y1 = y + d[1], z1 = z + d[2];
+                            if (x1 < 0 || y1 < 0 || z1 < 0 || x1 >= dim[0] || y1 >= dim[1] || z1 >= dim[2]) continue;
+                            const int w = node_id(x1, y1, z1);
+                            if (static_free[w]) static_adj[6 * (size_t)v + static_adj_n[v]++] = w;
+                        }
+                    }
+            static_adj_radius = agent_radius;
+        }
+        exist = static_free;
         warning.assign(nn, 0);
+        nbr_flat = static_adj;
+        nbr_n = static_adj_n;
+        if (obstacles.empty()) return;
         const double horizon = cfg.M * cfg.dt;
-        // a node farther from an obstacle's straight path than the obstacle can ever reach needs no walk along the path
-        // (Obstacle::isCollided samples it: obstacle.hpp:26-36); margin 1 mm against the float32 arithmetic of the samples
-        std::vector<double> reach(obstacles.size());
-        for (size_t oi = 0; oi < obstacles.size(); oi++) {
+        // warning nodes, updateGridMap :125-160: a node the obstacle can reach within the horizon (Obstacle::isCollided samples
+        // its straight path, obstacle.hpp:26-36).  Only the nodes of the box around that path, grown by what the obstacle can
+        // ever reach (+ 1 mm against the float32 arithmetic of the samples), are looked at, and of those only the ones within
+        // that distance of the path.
+        std::vector<int> warned;
+        for (const auto &o : obstacles) {
             const double tu = std::min(horizon, cfg.obs_uncertainty_horizon);
-            reach[oi] = agent_radius + obstacles[oi].radius + 0.5 * obstacles[oi].max_acc * tu * tu + 1e-3;
-        }
-        auto dist_to_path = [&](const MapfObstacle &o, const P3 &sp) {
-            const double ax = o.position.x, ay = o.position.y, az = o.position.z;
-            const double dx = o.velocity.x * horizon, dy = o.velocity.y * horizon, dz = o.velocity.z * horizon;
-            const double px = sp.x - ax, py = sp.y - ay, pz = sp.z - az;
-            const double dd = dx * dx + dy * dy + dz * dz;
-            double t = dd > 0 ? (px * dx + py * dy + pz * dz) / dd : 0.0;
-            t = t < 0 ? 0 : (t > 1 ? 1 : t);
-            const double qx = px - t * dx, qy = py - t * dy, qz = pz - t * dz;
-            return std::sqrt(qx * qx + qy * qy + qz * qz);
-        };
-        for (int x = 0; x < dim[0]; x++)
-            for (int y = 0; y < dim[1]; y++)
-                for (int z = 0; z < dim[2]; z++) {
-                    const int id = node_id(x, y, z);
-                    if (!static_free[id]) continue;
-                    const P3 sp = pos_to_point(x, y, z);
-                    bool warn = false;
-                    for (size_t oi = 0; oi < obstacles.size() && !warn; oi++) {
-                        const auto &o = obstacles[oi];
-                        if (dist_to_path(o, sp) > reach[oi]) continue;
-                        if (o.is_collided(sp, agent_radius, horizon, cfg.obs_uncertainty_horizon)) warn = true;
-                    }
-                    exist[id] = 1;
-                    warning[id] = warn ? 1 : 0;
-                }
-        // Grid::Grid (graph.cpp:371-431): neighbours in the order left, right, up, down, top, bottom; an edge v -> w
-        // exists unless it leads from a safe node into a warning node
-        nbr.resize(nn);
-        for (auto &v : nbr) v.clear();  // keeps the capacity: no allocation after the first step
-        const int d6[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
-        for (int z = 0; z < dim[2]; z++)
-            for (int y = 0; y < dim[1]; y++)
-                for (int x = 0; x < dim[0]; x++) {
-                    if (!exist_at(x, y, z)) continue;
-                    const int v = node_id(x, y, z);
-                    for (const auto &d : d6) {
-                        if (!exist_at(x + d[0], y + d[1], z + d[2])) continue;
-                        const int w = node_id(x + d[0], y + d[1], z + d[2]);
-                        if (warning[v] || !warning[w]) nbr[v].push_back(w);
-                    }
-                }
-    }
-
-    std::vector<int> bfs_table(int src) const {
-        std::vector<int> t(n_nodes(), (int)INF);
-        std::queue<int> open;
-        open.push(src);
-        t[src] = 0;
-        while (!open.empty()) {
-            const int n = open.front();
-            open.pop();
-            for (int m : nbr[n]) {
-                if (t[n] + 1 >= t[m]) continue;
-                t[m] = t[n] + 1;
-                open.push(m);
+            const double reach = agent_radius + o.radius + 0.5 * o.max_acc * tu * tu + 1e-3;
+            const double a3[3] = {o.position.x, o.position.y, o.position.z};
+            const double d3[3] = {o.velocity.x * horizon, o.velocity.y * horizon, o.velocity.z * horizon};
+            int lo[3], hi[3];
+            for (int k = 0; k < 3; k++) {
+                if (k == 2 && cfg.world_dimension == 2) { lo[k] = hi[k] = 0; continue; }
+                const double p0 = std::min(a3[k], a3[k] + d3[k]) - reach, p1 = std::max(a3[k], a3[k] + d3[k]) + reach;
+                lo[k] = std::max(0, (int)std::floor((p0 - gmin[k]) / gres(k)) - 1);
+                hi[k] = std::min(dim[k] - 1, (int)std::ceil((p1 - gmin[k]) / gres(k)) + 1);
             }
+            const double dd = d3[0] * d3[0] + d3[1] * d3[1] + d3[2] * d3[2];
+            for (int x = lo[0]; x <= hi[0]; x++)
+                for (int y = lo[1]; y <= hi[1]; y++)
+                    for (int z = lo[2]; z <= hi[2]; z++) {
+                        const int id = node_id(x, y, z);
+                        if (!static_free[id] || warning[id]) continue;
+                        const P3 sp = pos_to_point(x, y, z);
+                        const double px = sp.x - a3[0], py = sp.y - a3[1], pz = sp.z - a3[2];
+                        double t = dd > 0 ? (px * d3[0] + py * d3[1] + pz * d3[2]) / dd : 0.0;
+                        t = t < 0 ? 0 : (t > 1 ? 1 : t);
+                        const double qx = px - t * d3[0], qy = py - t * d3[1], qz = pz - t * d3[2];
+                        if (std::sqrt(qx * qx + qy * qy + qz * qz) > reach) continue;
+                        if (o.is_collided(sp, agent_radius, horizon, cfg.obs_uncertainty_horizon)) {
+                            warning[id] = 1;
+                            warned.push_back(id);
+                        }
+                    }
         }
-        return t;
+        // an edge v -> w exists unless it leads from a safe node into a warning node: take w out of its safe neighbours' lists
+        // (the grid is symmetric: w's own list names them), keeping the order of the others
+        for (int w : warned)
+            for (int u : NbrRange{static_adj.data() + 6 * (size_t)w, static_adj.data() + 6 * (size_t)w + static_adj_n[w]}) {
+                if (warning[u]) continue;
+                int *lu = nbr_flat.data() + 6 * (size_t)u;
+                int n = nbr_n[u], k = 0;
+                for (int j = 0; j < n; j++)
+                    if (lu[j] != w) lu[k++] = lu[j];
+                nbr_n[u] = (unsigned char)k;
+            }
     }
 
     double obs_cost(const std::set<int> &obs_ids, int node) const {  // :686-698
         double cost = 0;
         for (int oid : obs_ids) {
-            const int d = (*obs_tables_p)[oid][node];
+            const int d = lazy_at((*obs_tables_p)[oid], node);
             cost += d == 0 ? INF : 1.0 / ((double)d * d);
         }
         return cost;
@@ -427,7 +495,7 @@ struct GridMapf {
                     continue;
                 }
                 const double c_n = obs_cost(a.doi.cand_ids, n);
-                for (int m : nbr[n]) {
+                for (int m : nbr_of(n)) {
                     const double c_m = obs_cost(a.doi.cand_ids, m);
                     if (c_n < c_m + EPS_F) continue;
                     if (c_m < min_cost) {
@@ -456,18 +524,21 @@ struct GridMapf {
         std::mt19937 mt(0);  // DEFAULT_SEED, a fresh generator for every Problem (problem.cpp:84)
         // Solver::createDistanceTable: BFS from every goal.  A table depends on the grid map and the goal node only: kept per
         // grid state (the map without dynamic obstacles never changes; the one with them is new every step)
-        std::vector<const std::vector<int> *> table(n);
+        std::vector<LazyBfs *> table(n);
         for (int i = 0; i < n; i++) {
             auto &cache = goal_tables[active];
             auto it = cache.find(goal[i]);
             if (it == cache.end()) {
-                std::vector<int> t = bfs_table(goal[i]);
-                for (auto &d : t)
-                    if (d >= (int)INF) d = MAX_TIMESTEP;
-                it = cache.emplace(goal[i], std::move(t)).first;
+                it = cache.emplace(goal[i], LazyBfs()).first;
+                it->second.start(n_nodes(), goal[i]);
             }
             table[i] = &it->second;
         }
+        auto goal_steps = [&](int i, int v) {  // Solver::pathDist: the table's entry, MAX_TIMESTEP where the goal cannot be reached
+            MapfProfile::Scope sc(prof, 5);
+            const int d = lazy_at(*table[i], v);
+            return d >= (int)INF ? MAX_TIMESTEP : d;
+        };
         std::vector<PAgent> A(n);
         std::vector<int> occupied_now(n_nodes(), -1), occupied_next(n_nodes(), -1);
         auto compare = [&](int ia, int ib) {  // pibt.cpp:15-21
@@ -480,7 +551,7 @@ struct GridMapf {
         std::priority_queue<int, std::vector<int>, decltype(compare)> undecided(compare);
         std::vector<int> decided;
         for (int i = 0; i < n; i++) {
-            A[i] = PAgent{i, cur[i], -1, goal[i], obs_dist[i] > 1000 ? -1 : obs[i], 0, (*table[i])[start[i]], (float)i / (float)n, obs_dist[i]};
+            A[i] = PAgent{i, cur[i], -1, goal[i], obs_dist[i] > 1000 ? -1 : obs[i], 0, goal_steps(i, start[i]), (float)i / (float)n, obs_dist[i]};
             undecided.push(i);
             occupied_now[cur[i]] = i;
         }
@@ -504,11 +575,13 @@ struct GridMapf {
             return std::sqrt(dx * dx + dy * dy + dz * dz);
         };
         auto choose_node = [&](PAgent &a) -> int {  // pibt.cpp:149-203
-            std::vector<int> C = nbr[a.v_now];
-            C.push_back(a.v_now);
-            shuffle_gcc9(C, mt);
+            int C[7], nc = 0;  // at most six neighbours and the node itself
+            for (int u : nbr_of(a.v_now)) C[nc++] = u;
+            C[nc++] = a.v_now;
+            shuffle_gcc9(C, (size_t)nc, mt);
             int v = -1;
-            for (int u : C) {
+            for (int ci = 0; ci < nc; ci++) {
+                const int u = C[ci];
                 if (occupied_next[u] != -1) continue;
                 const int aj = occupied_now[u];
                 if (aj != -1 && A[aj].v_next == a.v_now) continue;
@@ -516,7 +589,7 @@ struct GridMapf {
                 if (v == -1) {
                     v = u;
                 } else {
-                    const int c_v = (*table[a.id])[v], c_u = (*table[a.id])[u];
+                    const int c_v = goal_steps(a.id, v), c_u = goal_steps(a.id, u);
                     const float o_v = obs_dist_to(a, v), o_u = obs_dist_to(a, u);
                     const float d_v = goal_dist(a, v), d_u = goal_dist(a, u);
                     if ((c_u < c_v) || (c_u == c_v && occupied_now[v] != -1 && occupied_now[u] == -1) || (c_u == c_v && o_u > o_v) ||
@@ -660,7 +733,7 @@ struct GridMapf {
     // planMAPF, :64-92
     bool plan_mapf(std::vector<MapfAgent> agents, double agent_radius, const std::vector<MapfObstacle> &obstacles) {
         n_agents = (int)agents.size();
-        update_grid_map(agent_radius, obstacles);
+        { MapfProfile::Scope sc(prof, 0); update_grid_map(agent_radius, obstacles); }
         bool valid = true;
         for (const auto &a : agents)
             if (is_occupied(a.waypoint) || is_occupied(a.goal)) { valid = false; break; }
@@ -669,14 +742,16 @@ struct GridMapf {
         for (int id = 0; id < n_nodes() && !any_node; id++) any_node = exist[id];
         if (!any_node) return false;  // every node is occupied: point_to_closest_node has nothing to return (the planner "fails")
         if (!tables_valid[active]) {
-            tables[active].clear();
-            for (const auto &o : obstacles) tables[active].push_back(bfs_table(point_to_closest_node(o.position)));
+            MapfProfile::Scope sc(prof, 1);
+            tables[active].resize(obstacles.size());
+            for (size_t oi = 0; oi < obstacles.size(); oi++) tables[active][oi].start(n_nodes(), point_to_closest_node(obstacles[oi].position));
             tables_valid[active] = true;
         }
         obs_tables_p = &tables[active];
-        update_doi(agents, obstacles, agent_radius);
-        update_goal(agents);
-        bool ok = run_mapf(agents);
+        { MapfProfile::Scope sc(prof, 2); update_doi(agents, obstacles, agent_radius); }
+        { MapfProfile::Scope sc(prof, 3); update_goal(agents); }
+        bool ok;
+        { MapfProfile::Scope sc(prof, 4); ok = run_mapf(agents); }
         if (!ok && !obstacles.empty()) {
             update_grid_map(agent_radius, {});
             ok = run_mapf(agents);
@@ -728,6 +803,8 @@ extern "C" int dlscqp_mapf_step(dlscqp_mapf *m, const dlscqp_mapf_step_args *s) 
     if (s->n_obs < 0 || (s->n_obs > 0 && (!s->obs_position || !s->obs_velocity || !s->obs_radius || !s->obs_max_acc))) return DLSCQP_ERR_INVALID_ARGUMENT;
     if (s->plans && s->n1 <= 0) return DLSCQP_ERR_INVALID_ARGUMENT;
     GridMapf &g = m->g;
+    MapfProfile::Scope whole(g.prof, 7);
+    g.prof.steps++;
     if (g.n_nodes() <= 0) return DLSCQP_ERR_INVALID_ARGUMENT;  // a world without a grid: there is nothing to plan on
     g.new_step();
     const dlscqp_mapf_config &cfg = g.cfg;

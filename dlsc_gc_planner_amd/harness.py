@@ -93,9 +93,13 @@ class SpinObstacles:
         self.downwash = np.array([ob["downwash"] if ob["downwash"] != 0 else 1.0 for ob in o], np.float64)
 
     @staticmethod
-    def _rotate(v, n, theta):  # Rodrigues; the reference conjugates with the unit quaternion of the same rotation
+    def _cross(a, b):  # (np.cross spends 20 us per call on axis bookkeeping: this runs every replanning step)
+        return np.stack([a[:, 1] * b[:, 2] - a[:, 2] * b[:, 1], a[:, 2] * b[:, 0] - a[:, 0] * b[:, 2], a[:, 0] * b[:, 1] - a[:, 1] * b[:, 0]], 1)
+
+    @classmethod
+    def _rotate(cls, v, n, theta):  # Rodrigues; the reference conjugates with the unit quaternion of the same rotation
         c, s = np.cos(theta)[:, None], np.sin(theta)[:, None]
-        return v * c + np.cross(n, v) * s + n * (n * v).sum(1, keepdims=True) * (1 - c)
+        return v * c + cls._cross(n, v) * s + n * (n * v).sum(1, keepdims=True) * (1 - c)
 
     def state(self, t):
         p = self._rotate(self.a, self.n, self.w * t)
@@ -145,8 +149,12 @@ class ClosedLoop:
         # every agent is every other agent's obstacle (communication range -1 in testall_DLSCGC_empty.launch)
         ids = np.arange(N)
         self.nbr = None
+        if neighbours is None and world is not None and world.get("pibt", False) == "reference" and cfg.communication_range > 0 and N > 1:
+            # the reference's missions: broadcastMsgs' communication-range lists, rebuilt in HBM every step (a list per agent of
+            # everybody else at most: the pitch never overflows) instead of on the host
+            neighbours, nbr_pitch = "device", N - 1
         if neighbours == "device":
-            assert cfg.communication_range > 0 and not (world is not None and world.get("pibt", False) == "reference")
+            assert cfg.communication_range > 0
             nbr_pitch = min(int(nbr_pitch), max(N - 1, 1))
             nbr_ids, nbr_offsets = np.zeros(N * nbr_pitch, np.int32), np.arange(N + 1) * nbr_pitch
         else:
@@ -156,7 +164,11 @@ class ClosedLoop:
         self.D = 0 if dyn is None else len(dyn["radius"])
         self.dyn_model = None if dyn is None else dyn.get("model")
         if self.D:
-            self.dyn_pos, self.dyn_vel = f32(dyn["position"]), f32(dyn["velocity"])
+            # position and velocity of the obstacles: two views of one buffer, refreshed by ONE transfer per step from pinned
+            # memory that does not make the host wait for the step's kernels (step())
+            self._dyn_dev = torch.stack([f32(dyn["position"]), f32(dyn["velocity"])])
+            self.dyn_pos, self.dyn_vel = self._dyn_dev[0], self._dyn_dev[1]
+            self._dyn_pin = torch.empty((2, self.D, 3), dtype=torch.float32).pin_memory()
         self.gen = self.opt.make_lsc_generator(N, nbr_offsets, nbr_ids, np.full(N, radius), np.full(N, downwash), device=device,
                                                dyn=dyn)
         if neighbours == "device":
@@ -175,7 +187,7 @@ class ClosedLoop:
                 # the reference's own planner (row N4, csrc/grid_mapf.cpp) and its communication-range neighbour lists
                 self.grid = MapfWaypoints(cfg, world["boxes"], world["resolution"], world["grid_resolution"], np.asarray(start, np.float32),
                                           np.asarray(goal, np.float32), radius, downwash, world.get("uncertainty_horizon", 1.0))
-                self.comm_neighbours = cfg.communication_range > 0
+                self.comm_neighbours = cfg.communication_range > 0 and self.nbr is None  # host-side lists only without the device search
             elif world.get("pibt", False):
                 self.grid = PibtWaypoints(world["boxes"], world["grid_resolution"], wmin, wmax, np.asarray(start, np.float64),
                                           np.asarray(goal, np.float64), radius)
@@ -270,7 +282,10 @@ class ClosedLoop:
             h = self._host_pack.numpy()
             o = np.cumsum([0, 3 * N, 3 * N, 3 * N, N * E] + ([3 * D, 3 * D, N * D] if D else []))
             pos, cur_goal = h[o[0]:o[1]].reshape(N, 3).copy(), h[o[1]:o[2]].reshape(N, 3).copy()
-            wp = np.ascontiguousarray(h[o[2]:o[3]].reshape(N, 3).copy())
+            if getattr(self, "_wp_pin", None) is None:
+                self._wp_pin = torch.empty((N, 3), dtype=torch.float32).pin_memory()
+            wp = self._wp_pin.numpy()  # the planner updates the waypoints in place, in the buffer they are uploaded from
+            wp[:] = h[o[2]:o[3]].reshape(N, 3)
             plans = h[o[3]:o[4]].reshape(N, cfg.M, cfg.n + 1, 3).copy()
             gdyn = None
             if D:
@@ -280,7 +295,7 @@ class ClosedLoop:
             self.mapf_rc = self.grid.step(pos, cur_goal, wp, plans if self.seq > 0 else None, dyn=gdyn, alert=alert)
             if self.comm_neighbours:
                 self._set_comm_neighbours(pos)
-            return torch.from_numpy(wp)
+            return self._wp_pin
         if isinstance(self.grid, PibtWaypoints):
             anchors = torch.cat([self.pos[:, None, :], self.plans[:, :, 0, :], self.plans[:, -1:, -1, :]], dim=1) \
                 if self.seq > 0 else self.pos[:, None, :]
@@ -429,7 +444,7 @@ class ClosedLoop:
         t_wall = time.perf_counter() if self.csv else 0.0
         if self.world is not None:
             t_mapf = time.perf_counter()
-            self.wp.copy_(self._waypoints_host())
+            self.wp.copy_(self._waypoints_host(), non_blocking=True)
             if getattr(self, "_stage_ev", None) is not None:
                 self._mapf_ms.append((time.perf_counter() - t_mapf) * 1e3)
         if self.graph is not None and not first:
@@ -451,9 +466,11 @@ class ClosedLoop:
             self.dyn_pos.fill_(1000.0)
             self.dyn_vel.zero_()
         elif self.dyn_model is not None:
+            # (computed while the step's kernels run: nothing here waits for them)
             p, v = self.dyn_model.state(self.sim_time)
-            self.dyn_pos.copy_(torch.from_numpy(p))
-            self.dyn_vel.copy_(torch.from_numpy(v))
+            pin = self._dyn_pin.numpy()
+            pin[0], pin[1] = p, v
+            self._dyn_dev.copy_(self._dyn_pin, non_blocking=True)
         elif self.D:
             self.dyn_pos.add_(self.dyn_vel * np.float32(dt))
         self.seq += 1
