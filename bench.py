@@ -42,6 +42,11 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--swarms", type=int, default=512, help="64-agent swarms per GPU per step")
     ap.add_argument("--batches", type=int, default=4, help="distinct consecutive replanning steps rotated through the timed loop")
+    ap.add_argument("--groups", type=int, default=0,
+                    help="independent groups the swarms of a GPU are planned in, each on its own stream with its own sequence of replanning steps "
+                         "(1 = one launch of all agents per step; default: 4 on one GPU, 2 with the plan exchange of N > 1 -- measured with a "
+                         "one-rank process group: 0.31 ms per step with 2 groups, 0.37 with 1, 0.41-0.52 with 4, where the host's calls "
+                         "for four groups and the exchange no longer fit the step)")
     ap.add_argument("--seed", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", "--no-latency", dest="no_extras", action="store_true",
@@ -612,21 +617,139 @@ def main():
     t_gen = time.perf_counter() - t_gen
     hist = wl["history"]
     N, K = len(wl["agents"]), wl["K"]
-    dbs = [opt.make_device_batch(h["agents"], h["row_offsets"], h["rows"], None, 0, want_iters=True) for h in hist]
-    shape1 = tuple(dbs[0].out_ctrl.shape[1:])
 
-    for i in range(max(args.warmup, B)):
-        dbs[i % B].launch(True, True)
-    torch.cuda.synchronize(dev)
-    # launch order of batch j: most expensive first by the iteration counts of batch j-1, i.e. of the same agents one
-    # replanning step earlier (for the first batch: of the last one) -- never by the batch's own counts
-    iters = [db.out_iters.cpu().numpy()[:, 0].copy() for db in dbs]
-    hint = [np.argsort(-iters[(j - 1) % B], kind="stable").astype(np.int32) for j in range(B)]
+    class SwarmLoop:
+        """The timed loop.  The swarms of this rank in `G` groups; every group is its own sequence of replanning steps on its own
+        stream -- launch, launch order of the group's next step from its own iteration counts, exchange of its plans -- and
+        no group waits for another: swarms are independent (an agent's neighbours are the other 63 agents of its swarm), so
+        nothing requires them to replan in lockstep, and the tail of one group's launch (its few 30-iteration agents) runs
+        beside the other groups' launches instead of holding an empty GPU.  G = 1 is one launch of all agents per step."""
+
+        def __init__(self, G):
+            assert (N // 64) % G == 0, "whole swarms per group"
+            self.G, self.per = G, N // G
+            per = self.per
+            self.opts = [opt] + [BatchTrajOptimizer(cfg) for _ in range(G - 1)]  # a context per group: launch-order scratch, event pairs
+            self.streams = [torch.cuda.Stream(dev) for _ in range(G)]
+            self.dbs = [[self.opts[g].make_device_batch(h["agents"][g * per:(g + 1) * per], np.arange(per + 1) * K,
+                                                         h["rows"][g * per * K:(g + 1) * per * K], None, 0, want_iters=True) for h in hist]
+                        for g in range(G)]
+            self.counter = 0
+            self.device_order = False
+            self.xchg = None
+            self.older = [[[self.dbs[g][(j - k) % B].out_iters for k in (1, 2) if (j - k) % B != (j + 1) % B] for j in range(B)] for g in range(G)]
+            self.planned = [[torch.cuda.Event() for _ in range(B)] for _ in range(G)]
+            for i in range(max(args.warmup, B)):
+                for g in range(G):
+                    self.dbs[g][i % B].launch(True, True)
+            torch.cuda.synchronize(dev)
+            # launch order of batch j: most expensive first by the iteration counts of batch j-1, i.e. of the same agents one
+            # replanning step earlier (for the first batch: of the last one) -- never by the batch's own counts
+            self.iters = [np.concatenate([self.dbs[g][j].out_iters.cpu().numpy()[:, 0] for g in range(G)]) for j in range(B)]
+            self.hint = [[np.argsort(-self.iters[(j - 1) % B][g * per:(g + 1) * per], kind="stable").astype(np.int32) for j in range(B)]
+                         for g in range(G)]
+
+        def make_exchange(self):
+            # per agent: control points, sub-goal, status (376 B at S64) -- the broadcast payload of the reference.  ONE exchange
+            # per step for all groups: the groups' batches of a step write slices of one output table, a stream of its own
+            # (`join`) waits for the groups' launches of the step and posts the table; no group's stream waits for another
+            # group (four exchanges per step, one per group, were measured first: the step became bound by the host's calls)
+            from dlsc_gc_planner_amd import sharding
+            shape1 = tuple(self.dbs[0][0].out_ctrl.shape[1:])
+            self.xchg = sharding.PlanExchange(dist, world, N, (int(np.prod(shape1)), 3, 1), dev)
+            self.join = torch.cuda.Stream(dev)
+            self.table_ready = None  # serial mode: the gathered table of the previous step (an event on `join`)
+            per = self.per
+            self.out = [(torch.zeros((N,) + shape1, dtype=torch.float32, device=dev), torch.zeros((N, 3), dtype=torch.float32, device=dev),
+                         torch.full((N,), -1, dtype=torch.int32, device=dev)) for _ in range(B)]
+            for g in range(self.G):
+                for j in range(B):
+                    c_, g_, s_ = self.out[j]
+                    self.dbs[g][j].use_outputs(c_[g * per:(g + 1) * per], g_[g * per:(g + 1) * per], s_[g * per:(g + 1) * per])
+
+        def step(self, pipelined):
+            j = self.counter % B
+            self.counter += 1
+            for g in range(self.G):
+                st = self.streams[g]  # (explicit streams and events made once: a stream context or an event object per call costs
+                db, nxt = self.dbs[g][j], self.dbs[g][(j + 1) % B]  # the host ~10 us, and this loop makes dozens of calls per step)
+                if use_dist and pipelined:
+                    # the exchange of step k (packing included) runs on the communication stream while step k+1 writes another
+                    # batch's outputs (B >= 3 batches rotate: the table a launch writes was posted B steps ago)
+                    self.xchg.before_overwrite(st)
+                elif use_dist and self.table_ready is not None:
+                    st.wait_event(self.table_ready)  # serial mode: the next launch waits for the exchange
+                db.launch(True, True, stream=st)
+                if use_dist:
+                    self.planned[g][j].record(st)
+                if self.device_order:
+                    # the next batch's order from this batch's counts and the two batches' before it -- never from its own
+                    nxt.update_order(stream=st, iters=db.out_iters, history=self.older[g][j])
+            if use_dist:
+                for g in range(self.G):
+                    self.join.wait_event(self.planned[g][j])
+                self.xchg.post(*self.out[j], pack_on_comm=pipelined, stream=self.join)
+                if not pipelined:
+                    self.xchg.table(self.join)
+                    if self.table_ready is None:
+                        self.table_ready = torch.cuda.Event()
+                    self.table_ready.record(self.join)
+
+        def sync(self):
+            torch.cuda.synchronize(dev)
+
+        def timed(self, steps, pipelined, orders, record_kernel_times=False):
+            self.device_order = isinstance(orders, str) and orders == "device"
+            for g in range(self.G):
+                for j, db in enumerate(self.dbs[g]):
+                    db.set_order(None if orders is None or self.device_order else self.hint[g][j])
+            self.counter = 0
+            for _ in range(B):
+                self.step(pipelined)
+            self.sync()
+            self.counter = 0
+            for o in self.opts:
+                o.set_timing(steps if record_kernel_times else 0)
+            if use_dist:
+                dist.barrier()
+            self.sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                self.step(pipelined)
+            self.host_ms_per_step = (time.perf_counter() - t0) / steps * 1e3  # what the host needs to queue a step
+            self.sync()
+            if use_dist:
+                dist.barrier()
+            self.sync()
+            el = time.perf_counter() - t0
+            if use_dist:
+                tt = torch.tensor([el], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                el = float(tt.item())
+            return el
+
+        def kernel_times_ms(self, steps):
+            return np.concatenate([np.asarray(o.kernel_times_ms(steps), dtype=np.float64) for o in self.opts])
+
+        def results(self):
+            """per batch of the rotation: the groups' outputs, concatenated in agent order"""
+            per_group = [[db.results() for db in self.dbs[g]] for g in range(self.G)]
+            return [{k: np.concatenate([per_group[g][j][k] for g in range(self.G)]) for k in per_group[0][j]} for j in range(B)]
+
+        def close(self):
+            self.dbs = None
+            for o in self.opts[1:]:
+                o.close()
+
+    G = args.groups if args.groups > 0 else (2 if use_dist else 4)
+    while (N // 64) % G:
+        G -= 1
+    loop = SwarmLoop(G)
+    iters = loop.iters
     with np.errstate(invalid="ignore", divide="ignore"):
         hint_corr = float(np.nan_to_num(np.mean([np.corrcoef(iters[(j - 1) % B], iters[j])[0, 1] for j in range(B)]))) if B > 1 else 1.0
 
     pipelined_ok = False
-    xchg = None
     if use_dist:
         from dlsc_gc_planner_amd import sharding
         # Which agents of step k+1 need the gathered table of step k?  Those with a neighbour on another rank.  Every
@@ -637,102 +760,55 @@ def main():
         nbr_ids = members[members != (lo + np.arange(N))[:, None]]                 # ... without the agent itself
         halo = sharding.halo_agents(np.arange(N + 1) * 63, nbr_ids, lo, lo + N)
         pipelined_ok = len(halo) == 0
-        # per agent: control points, sub-goal, status (376 B at S64) -- the broadcast payload of the reference
-        xchg = sharding.PlanExchange(dist, world, N, (int(np.prod(shape1)), 3, 1), dev)
-
-    counter = [0]
-    device_order = [False]  # the next batch's launch order from this batch's iteration counts, computed on the device
-
-    def step(pipelined):
-        db = dbs[counter[0] % B]
-        nxt = dbs[(counter[0] + 1) % B]
-        counter[0] += 1
-        if device_order[0]:
-            plan_step(db, pipelined)
-            # the next batch's order from this batch's counts and the two batches' before it -- never from its own
-            j = (counter[0] - 1) % B
-            older = [dbs[(j - k) % B].out_iters for k in (1, 2) if (j - k) % B != (j + 1) % B]
-            nxt.update_order(iters=db.out_iters, history=older)
-        else:
-            plan_step(db, pipelined)
-
-    def plan_step(db, pipelined):
-        if not use_dist:
-            db.launch(True, True)
-        elif pipelined:
-            # the exchange of step k (packing included) runs on the communication stream while step k+1 writes another
-            # batch's outputs; with fewer than three batches the outputs are double-buffered instead
-            if B < 3:
-                db.flip_outputs()
-            xchg.before_overwrite()
-            db.launch(True, True)
-            xchg.post(db.out_ctrl, db.out_goal, db.out_status, pack_on_comm=True)
-        else:
-            db.launch(True, True)
-            xchg.post(db.out_ctrl, db.out_goal, db.out_status)
-            xchg.table()  # the next launch waits for the exchange
-
-    def timed(steps, pipelined, orders, record_kernel_times=False):
-        device_order[0] = isinstance(orders, str) and orders == "device"
-        for j, db in enumerate(dbs):
-            db.set_order(None if orders is None or device_order[0] else orders[j])
-        counter[0] = 0
-        for _ in range(B):
-            step(pipelined)
-        torch.cuda.synchronize(dev)
-        counter[0] = 0
-        opt.set_timing(steps if record_kernel_times else 0)
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step(pipelined)
-        torch.cuda.synchronize(dev)
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-        el = time.perf_counter() - t0
-        if use_dist:
-            tt = torch.tensor([el], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            el = float(tt.item())
-        return el
+        loop.make_exchange()
 
     head_pipelined = use_dist and pipelined_ok and args.exchange == "pipelined"
     if use_dist:
-        xchg.enable_timing()
-    elapsed = timed(args.steps, head_pipelined, "device", record_kernel_times=True)
-    kms = opt.kernel_times_ms(args.steps)
+        assert B >= 3, "the pipelined exchange reads a step's output table while the next steps write other tables"
+    elapsed = loop.timed(args.steps, head_pipelined, "device", record_kernel_times=True)
+    kms = loop.kernel_times_ms(args.steps)
+    host_queue_ms = loop.host_ms_per_step
     rank_breakdown = None
     if use_dist:
-        br = exchange_breakdown(xchg, skip=B)  # the first B exchanges are the untimed warm-up steps of timed()
-        xchg.enable_timing(False)
+        # the stages of the exchange from a second, shorter pass of the same loop with events around them (the events cost
+        # the host ~0.1 ms per step: not in the headline's pass)
+        loop.xchg.enable_timing()
+        loop.timed(max(B, min(args.steps, 100)), head_pipelined, "device")
+        br = exchange_breakdown(loop.xchg, skip=B)  # the first B exchanges are the untimed warm-up steps of timed()
+        loop.xchg.enable_timing(False)
         br["plan_kernel_ms"] = float(np.mean(kms)) if len(kms) else float("nan")
         rank_breakdown = over_ranks(dist, dev, br)
     if use_dist:
         # the gathered table must hold this rank's own block of the last step
-        last = dbs[(args.steps - 1) % B]
-        ctrl_all, goal_all, status_all = xchg.unpack(xchg.table(), (torch.float32, torch.float32, torch.int32))
+        last = loop.out[(args.steps - 1) % B]
+        ctrl_all, goal_all, status_all = loop.xchg.unpack(loop.xchg.table(), (torch.float32, torch.float32, torch.int32))
         torch.cuda.synchronize(dev)
         own = slice(rank * N, (rank + 1) * N)
-        assert torch.equal(ctrl_all[own], last.out_ctrl.view(N, -1)) and torch.equal(goal_all[own], last.out_goal)
-        assert torch.equal(status_all[own].flatten(), last.out_status)
-    res = [db.results() for db in dbs]
+        assert torch.equal(ctrl_all[own], last[0].view(N, -1)) and torch.equal(goal_all[own], last[1])
+        assert torch.equal(status_all[own].flatten(), last[2])
+        assert int((last[2] >= 0).sum()) == N  # every group wrote its slice
+    res = loop.results()
     # the same loop without the launch-order hint, and (N > 1) with the other exchange mode
     side_steps = max(B, min(args.steps, 200))
-    el_nohint = float("nan") if args.headline_only else timed(side_steps, head_pipelined, None)
-    el_hostorder = float("nan") if args.headline_only else timed(side_steps, head_pipelined, hint)
+    el_nohint = float("nan") if args.headline_only else loop.timed(side_steps, head_pipelined, None)
+    el_hostorder = float("nan") if args.headline_only else loop.timed(side_steps, head_pipelined, "host")
     exch = None
     if use_dist and not args.headline_only:
         exch = {"pipelined": None, "serial": None, "steps_of_the_second_mode": side_steps}
         exch["pipelined" if head_pipelined else "serial"] = elapsed / args.steps * 1e3
         if pipelined_ok:  # the other mode, same batches, same launch order
-            el_other = timed(side_steps, not head_pipelined, "device")
+            el_other = loop.timed(side_steps, not head_pipelined, "device")
             exch["serial" if head_pipelined else "pipelined"] = el_other / side_steps * 1e3
-    device_order[0] = False
-    for j, db in enumerate(dbs):
-        db.set_order(hint[j])
+    G_used, per_launch = loop.G, loop.per
+    loop.close()
+    del loop
+    # ... and as ONE launch of all agents per step (rounds 1-2's loop): what the groups buy
+    one_launch = None
+    if G_used > 1 and not args.headline_only and not use_dist:
+        l1 = SwarmLoop(1)
+        one_launch = {"device_order": l1.timed(side_steps, False, "device") / side_steps * 1e3, "id_order": l1.timed(side_steps, False, None) / side_steps * 1e3}
+        l1.close()
+        del l1
 
     # BASELINE.json configs[4] as a strong-scaling step on the same ranks (every N, so that the scaling runs carry it)
     stress = None
@@ -783,19 +859,21 @@ def main():
         dim, M, n = cfg.world_dimension, cfg.M, cfg.n
         bytes_qp = algorithmic_bytes_per_qp(dim, M, n, K, False, 0)
         avg_kernel_s = float(np.mean(kms)) * 1e-3 if len(kms) else float("nan")
-        achieved = N * bytes_qp / avg_kernel_s / 1e9
+        # G_used launches run side by side (one per group, each on its stream) and last avg_kernel_s on average: the device
+        # moves the bytes of all of them in that time
+        achieved = G_used * per_launch * bytes_qp / avg_kernel_s / 1e9
         traffic, traffic_src, valu_frac, prof = None, None, None, {}
         try:
             with open(args.traffic_json) as fh:
                 prof = json.load(fh)
             sys.path.insert(0, os.path.join(ROOT, "profiles"))
             import summarize
-            if prof.get("agents_per_launch") == N and prof.get("csrc_sha1") == summarize.csrc_sha1():
+            if prof.get("agents_per_launch") == per_launch and prof.get("csrc_sha1") == summarize.csrc_sha1():
                 traffic = prof.get("hbm_bytes_per_launch")
                 valu_frac = prof.get("valu_issue_frac")
                 traffic_src = "%s: rocprofv3 --pmc passes of this command (%s), taken on these kernel sources" % (
                     os.path.relpath(args.traffic_json, ROOT), prof.get("source", ""))
-            elif prof.get("agents_per_launch") == N:
+            elif prof.get("agents_per_launch") == per_launch:
                 traffic_src = "%s was measured on other kernel sources (csrc hash differs): not reported" % os.path.relpath(args.traffic_json, ROOT)
         except Exception:
             pass
@@ -827,29 +905,45 @@ def main():
                 pick = [sel[i % len(sel)] for i in range(N)]
                 ha = np.concatenate([hist[j]["agents"][a:a + 1] for j, a in pick])
                 hr = np.concatenate([hist[j]["rows"][a * K:(a + 1) * K] for j, a in pick])
-                hdb = opt.make_device_batch(ha, np.arange(N + 1) * K, hr, None, 0, want_iters=True)
                 prev = np.zeros((N, 4), np.int32)
                 prev[:, 0] = [res[(j - 1) % B]["iters"][a, 0] for j, a in pick]
                 prev_t = torch.from_numpy(prev).to(dev)
                 hms = {}
-                for tag in ("id_order", "hinted"):
-                    if tag == "hinted":
-                        hdb.update_order(iters=prev_t)
-                    for _ in range(5):
-                        hdb.launch(True, True)
-                    torch.cuda.synchronize(dev)
-                    t1 = time.perf_counter()
-                    for _ in range(100):
-                        hdb.launch(True, True)
-                    torch.cuda.synchronize(dev)
-                    hms[tag] = (time.perf_counter() - t1) / 100 * 1e3
-                hit = hdb.results()["iters"]
-                hard = {"agents_per_launch": N, "distinct_agents": len(sel), "ms_per_step": hms["hinted"], "qp_per_s": N / hms["hinted"] * 1e3,
-                        "ms_per_step_id_order": hms["id_order"],
+                hit = None
+                # as one launch of all agents per step, and in the headline's groups (each group on its own stream)
+                for gname, Gh in (("one_launch", 1), ("groups", G_used)):
+                    ph = N // Gh
+                    hopts = [opt] + [BatchTrajOptimizer(cfg) for _ in range(Gh - 1)]
+                    hstreams = [torch.cuda.Stream(dev) for _ in range(Gh)]
+                    hdbs = [hopts[g].make_device_batch(ha[g * ph:(g + 1) * ph], np.arange(ph + 1) * K, hr[g * ph * K:(g + 1) * ph * K], None, 0,
+                                                       want_iters=True) for g in range(Gh)]
+                    for tag in ("id_order", "hinted"):
+                        if tag == "hinted":
+                            for g in range(Gh):
+                                hdbs[g].update_order(iters=prev_t[g * ph:(g + 1) * ph])
+                        torch.cuda.synchronize(dev)
+                        for rep_ in range(105):
+                            if rep_ == 5:
+                                torch.cuda.synchronize(dev)
+                                t1 = time.perf_counter()
+                            for g in range(Gh):
+                                with torch.cuda.stream(hstreams[g]):
+                                    hdbs[g].launch(True, True)
+                        torch.cuda.synchronize(dev)
+                        hms[gname, tag] = (time.perf_counter() - t1) / 100 * 1e3
+                    if hit is None:
+                        hit = hdbs[0].results()["iters"]
+                    del hdbs
+                    for o in hopts[1:]:
+                        o.close()
+                hard = {"agents_per_step": N, "groups": G_used, "distinct_agents": len(sel), "ms_per_step": hms["groups", "hinted"],
+                        "qp_per_s": N / hms["groups", "hinted"] * 1e3, "ms_per_step_id_order": hms["groups", "id_order"],
+                        "ms_per_step_one_launch": hms["one_launch", "hinted"], "ms_per_step_one_launch_id_order": hms["one_launch", "id_order"],
+                        "qp_per_s_one_launch": N / hms["one_launch", "hinted"] * 1e3,
                         "mean_active_set_iterations": float(hit[:, 0].mean()), "mean_active_rows": float(hit[:, 3].mean()),
                         "note": "every agent has >= 5 active rows at its solution; launched in the order of the iteration counts the same "
-                                "agents had one replanning step earlier (dlscqp_launch_order_device), like the headline"}
-                del hdb
+                                "agents had one replanning step earlier (dlscqp_launch_order_device), in the headline's groups; the "
+                                "one_launch figures are rounds 1-2's shape (one launch of all agents per step)"}
             closed = closed_loop_latency(local_rank)
         line = {
             "metric": "agent-QP solves/sec (goal LP + trajectory QP per agent per replanning step)",
@@ -868,7 +962,15 @@ def main():
                 "workload": "S64: %d independent 64-agent swarms per GPU per step (BASELINE.json configs[1]: 3-D, 5 segments x degree 5, "
                             "%d DLSC rows per agent); the timed loop rotates through %d consecutive replanning steps of the closed-loop "
                             "generator" % (args.swarms, K, B),
-                "agents_per_gpu": N, "segments": M, "degree": n, "lsc_rows_per_agent": K,
+                "agents_per_gpu": N, "swarm_groups": G_used, "agents_per_launch": per_launch,
+                "swarm_groups_note": "the %d swarms of a GPU are planned in %d independent groups, each on its own stream with its own sequence "
+                                     "of replanning steps (launch, next launch order from its own iteration counts%s); swarms have no neighbours "
+                                     "outside themselves, so no group waits for another, and a step is every group advanced by one replanning "
+                                     "step%s" % (args.swarms, G_used, "", "; one all-gather of all groups' plans per step, posted from a stream that waits for "
+                                                                        "the groups' launches of that step" if use_dist else ""),
+                "ms_per_step_one_launch_per_step": one_launch,
+                "host_ms_to_queue_a_step": host_queue_ms,
+                "segments": M, "degree": n, "lsc_rows_per_agent": K,
                 "vars_per_agent": dim * M * (n + 1), "ineq_rows_per_agent": K + 2 * 207, "distinct_batches": B,
                 "exchange": ("none (1 GPU)" if not use_dist else
                              "one RCCL all-gather of control points, sub-goal and status per step, posted on a communication stream: runs "
@@ -904,12 +1006,14 @@ def main():
                 # what binds the kernel according to the counters (profiles/): the VALU issue rate of the SIMDs -- neither of
                 # the two classical roofs.  achieved / peak / frac are the HBM figures the contract asks for.
                 "bound": "valu_issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None if traffic is None else traffic * G_used, "traffic_source": traffic_src,
                 "valu_issue_frac": valu_frac,
                 "kernel": prof.get("kernel", "dlscqp_plan_kernel"), "avg_kernel_ms": avg_kernel_s * 1e3,
-                "algorithmic_bytes_per_qp": bytes_qp, "qp_per_launch": N,
-                "note": "achieved = algorithmic bytes (SURVEY.md 8d) x agents per launch / average launch duration by HIP events on the "
-                        "launch stream over the timed region; ~5 KB per QP can never load the HBM roof (SURVEY.md 8d)",
+                "algorithmic_bytes_per_qp": bytes_qp, "qp_per_launch": per_launch, "concurrent_launches": G_used,
+                "achieved_one_launch": per_launch * bytes_qp / avg_kernel_s / 1e9,
+                "note": "achieved = algorithmic bytes (SURVEY.md 8d) x agents per launch x launches running side by side (one per swarm "
+                        "group, each on its stream) / average launch duration by HIP events on the launch streams over the timed region; "
+                        "traffic likewise (per launch x concurrent launches); ~5 KB per QP can never load the HBM roof (SURVEY.md 8d)",
             },
         }
         if not args.no_cpu_baseline and not args.headline_only and world == 1:

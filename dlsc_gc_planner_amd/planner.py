@@ -299,6 +299,15 @@ class DeviceBatch:
         self._alt = cur
         self.c.out_ctrl, self.c.out_goal, self.c.out_status = self.out_ctrl.data_ptr(), self.out_goal.data_ptr(), self.out_status.data_ptr()
 
+    def use_outputs(self, ctrl, goal, status):
+        """Write control points, sub-goal and status into the caller's tensors (e.g. slices of one table that several batches
+        fill and one plan exchange reads): [N, M, n+1, 3] float32, [N, 3] float32, [N] int32, contiguous."""
+        assert ctrl.shape == self.out_ctrl.shape and goal.shape == self.out_goal.shape and status.shape == self.out_status.shape
+        assert ctrl.is_contiguous() and goal.is_contiguous() and status.is_contiguous()
+        assert ctrl.dtype == self.out_ctrl.dtype and goal.dtype == self.out_goal.dtype and status.dtype == self.out_status.dtype
+        self.out_ctrl, self.out_goal, self.out_status = ctrl, goal, status
+        self.c.out_ctrl, self.c.out_goal, self.c.out_status = ctrl.data_ptr(), goal.data_ptr(), status.data_ptr()
+
     def launch(self, do_goal=True, do_traj=True, stream=None, offset=0, count=0):
         """Asynchronous launch on `stream` (default: torch's current stream); `offset`/`count` restrict it to a
         range of launch slots (count = 0: the whole batch)."""

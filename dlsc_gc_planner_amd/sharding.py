@@ -81,6 +81,7 @@ class PlanExchange:
         self.recv = [torch.empty((world * n_local, width), dtype=torch.float32, device=device) for _ in range(2)]
         self.done = [None, None]  # CUDA: event on the communication stream; CPU: Work handle
         self.packed = [None, None]  # CUDA, pack_on_comm: the inputs of post k have been read
+        self._reuse = [None, None]
         self.comm = torch.cuda.Stream(device) if self.cuda else None
         self.k = 0
         self.last = None
@@ -118,40 +119,46 @@ class PlanExchange:
             flat.append(p)
         torch.cat(flat, dim=1, out=self.send[b])
 
-    def before_overwrite(self):
-        """pack_on_comm: make the current stream wait until the tensors of the post before last have been read."""
+    def before_overwrite(self, stream=None):
+        """pack_on_comm: make `stream` (default: the current one) wait until the tensors of the post before last have been read."""
         e = self.packed[self.k & 1]
         if e is not None:
-            self.torch.cuda.current_stream(self.device).wait_event(e)
+            (self.torch.cuda.current_stream(self.device) if stream is None else stream).wait_event(e)
 
-    def post(self, *parts, pack_on_comm=False):
+    def post(self, *parts, pack_on_comm=False, stream=None):
+        """stream: the stream the parts are ready on (default: the current one)."""
         torch = self.torch
         b = self.k & 1
         self.k += 1
         timed = self._ev is not None
         ev = (lambda: torch.cuda.Event(enable_timing=True)) if timed else (lambda: torch.cuda.Event())
         if self.cuda and pack_on_comm:
-            ready = ev()
-            ready.record(torch.cuda.current_stream(self.device))
+            if timed:
+                ready, t0, self.packed[b], self.done[b] = ev(), ev(), ev(), ev()
+            else:  # untimed: the events of exchange k-2 are recorded again (an event object per exchange costs the host ~10 us)
+                if self._reuse[b] is None:
+                    self._reuse[b] = (ev(), ev(), ev())
+                ready, self.packed[b], self.done[b] = self._reuse[b]
+                t0 = None
+            ready.record(torch.cuda.current_stream(self.device) if stream is None else stream)
             with torch.cuda.stream(self.comm):  # in order behind exchange k-2, which used the same buffers
                 self.comm.wait_event(ready)
-                t0 = ev()
-                t0.record(self.comm)
+                if timed:
+                    t0.record(self.comm)
                 self._pack(b, parts)
-                self.packed[b] = ev()
                 self.packed[b].record(self.comm)
                 self.dist.all_gather_into_tensor(self.recv[b], self.send[b])
-                self.done[b] = ev()
                 self.done[b].record(self.comm)
             if timed:
                 self._ev["post"].append((t0, self.packed[b], self.done[b]))
         elif self.cuda:
-            cur = torch.cuda.current_stream(self.device)
+            cur = torch.cuda.current_stream(self.device) if stream is None else stream
             if self.done[b] is not None:
                 cur.wait_event(self.done[b])  # exchange k-2 has read send[b] and filled recv[b]
             t0 = ev()
             t0.record(cur)
-            self._pack(b, parts)
+            with torch.cuda.stream(cur):  # (the packing kernel goes where torch's current stream is)
+                self._pack(b, parts)
             ready = ev()
             ready.record(cur)
             with torch.cuda.stream(self.comm):
@@ -168,10 +175,10 @@ class PlanExchange:
             self.done[b] = self.dist.all_gather_into_tensor(self.recv[b], self.send[b], async_op=True)
         self.last = b
 
-    def table(self):
+    def table(self, stream=None):
         b = self.last
         if self.cuda:
-            cur = self.torch.cuda.current_stream(self.device)
+            cur = self.torch.cuda.current_stream(self.device) if stream is None else stream
             if self._ev is not None:
                 w0 = self.torch.cuda.Event(enable_timing=True)
                 w0.record(cur)

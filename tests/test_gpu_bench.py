@@ -31,7 +31,10 @@ def test_single_gpu_line_has_the_contract_fields(gpu_required):
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["unit"] == "QP/s" and d["dtype"] == "f64" and d["vs_baseline"] is None
     assert d["config"]["agents_per_gpu"] == 512 and d["value"] > 0
     r = d["roofline"]
-    assert r["bound"] == "valu_issue" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["qp_per_launch"] == 512
+    assert r["bound"] == "valu_issue" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # the eight swarms in four groups, each group on its own stream: four launches of 128 agents side by side
+    assert r["qp_per_launch"] == 128 and r["concurrent_launches"] == 4 and d["config"]["swarm_groups"] == 4
+    assert abs(r["achieved"] - 4 * r["achieved_one_launch"]) < 1e-9 * r["achieved"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["oracle_qp_per_s_one_core"] > 0
     assert c["value"] > 3 * c["oracle_qp_per_s_one_core"]  # the kernel's algorithm, not the dense checker
@@ -43,6 +46,9 @@ def test_multi_gpu_code_path_with_one_rank(gpu_required, mode):
     d = _bench("--force-dist", "--no-cpu-baseline", "--exchange", mode)
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert ("communication stream" in d["config"]["exchange"]) == (mode == "pipelined")
+    # with the exchange the swarms are planned in two groups; ONE all-gather per step carries both groups' plans
+    assert d["config"]["swarm_groups"] == 2 and d["roofline"]["concurrent_launches"] == 2 and d["roofline"]["qp_per_launch"] == 256
+    assert d["config"]["host_ms_to_queue_a_step"] > 0
     e = d["config"]["exchange_modes_ms_per_step"]
     assert e["pipelined"] > 0 and e["serial"] > 0  # both modes are timed in every N > 1 run
     x = d["x2048_strong"]  # BASELINE.json configs[4] through the sharded step (one rank: no halo)

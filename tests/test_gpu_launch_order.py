@@ -9,7 +9,7 @@ from dlsc_gc_planner_amd.planner import BatchTrajOptimizer
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n_swarms", [1, 5, 40])
+@pytest.mark.parametrize("n_swarms", [1, 5, 40, 300])  # 300 swarms: beyond the single-workgroup kernel (two-pass sort)
 def test_order_is_a_permutation_sorted_by_iterations(gpu_required, n_swarms):
     cfg = workloads.s64_config()
     opt = BatchTrajOptimizer(cfg)
