@@ -7,8 +7,9 @@ set -u
 NAME=${1:-r01}
 OUT=gpurun_out/prof_$NAME
 STEPS=30
+GROUPS_=4   # bench.py's default on one GPU: four swarm groups, four launches of 8 192 agents side by side per step
 export TMPDIR=/tmp
-B="python3 bench.py --steps $STEPS --warmup 4 --swarms 512 --headline-only"
+B="python3 bench.py --steps $STEPS --warmup 4 --swarms 512 --groups $GROUPS_ --headline-only"
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $B > $OUT/fetch.log 2>&1
@@ -17,7 +18,7 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_AN
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM --output-format csv -d $OUT/sq2 -- $B > $OUT/sq2.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $OUT/sq3 -- $B > $OUT/sq3.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $OUT/sq4 -- $B > $OUT/sq4.log 2>&1
-python3 profiles/summarize.py $OUT $NAME --steps $STEPS --agents 32768 > $OUT/summary.txt 2>&1
+python3 profiles/summarize.py $OUT $NAME --steps $((STEPS * GROUPS_)) --agents $((32768 / GROUPS_)) --concurrent $GROUPS_ > $OUT/summary.txt 2>&1
 cp profiles/$NAME.md profiles/$NAME.json profiles/hbm_traffic_latest.json $OUT/ 2>/dev/null
 python3 tests/tools/phase_cost.py > $OUT/phase_cost.txt 2>&1
 python3 profiles/timeline.py > $OUT/timeline.txt 2>&1

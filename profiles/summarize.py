@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--agents", type=int, default=16384)
     ap.add_argument("--bytes-per-qp", type=int, default=4900)
+    ap.add_argument("--concurrent", type=int, default=1,
+                    help="launches of the kernel that run side by side in the timed loop (bench.py's swarm groups, one stream each): device-level "
+                         "rates are per-launch figures x this; the PMC passes serialise the kernels, their counters are per launch either way")
     args = ap.parse_args()
     out = []
     summary = {"name": args.name, "agents_per_launch": args.agents}
@@ -95,9 +98,11 @@ def main():
                        "%d wavefronts per CU; resident: %d wavefronts per CU\n" % (dyn, by_lds, by_vgpr, summary["waves_per_cu"]))
         alg = args.agents * args.bytes_per_qp
         summary["algorithmic_bytes_per_launch"] = alg
-        summary["achieved_GBps"] = alg / (avg * 1e-6) / 1e9
-        out.append("algorithmic bytes per launch = %d agents x %d B = %d B -> %.2f GB/s achieved (%.4f of 8000 GB/s)\n" % (
-            args.agents, args.bytes_per_qp, alg, summary["achieved_GBps"], summary["achieved_GBps"] / 8000))
+        summary["concurrent_launches"] = args.concurrent
+        summary["achieved_GBps"] = args.concurrent * alg / (avg * 1e-6) / 1e9
+        out.append("algorithmic bytes per launch = %d agents x %d B = %d B; %d launch(es) side by side, %.1f us each on average -> %.2f GB/s "
+                   "achieved (%.4f of 8000 GB/s)\n" % (args.agents, args.bytes_per_qp, alg, args.concurrent, avg, summary["achieved_GBps"],
+                                                       summary["achieved_GBps"] / 8000))
         st = sorted(glob.glob(os.path.join(args.prof_dir, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
         if st:
             out.append("rocprofv3 --stats (all dispatches of the process, including workload generation):\n")
@@ -126,10 +131,11 @@ def main():
     if "pmc_SQ_INSTS_VALU" in summary and "avg_kernel_us" in summary:
         # share of the VALU issue slots of the chip that the kernel uses: a wave64 VALU instruction occupies its SIMD's issue
         # port for 4 cycles; 256 CUs x 4 SIMDs; 2.4 GHz peak engine clock (a lower real clock makes the true share higher)
-        frac = summary["pmc_SQ_INSTS_VALU"] * 4.0 / (1024 * summary["avg_kernel_us"] * 1e-6 * 2.4e9)
+        frac = args.concurrent * summary["pmc_SQ_INSTS_VALU"] * 4.0 / (1024 * summary["avg_kernel_us"] * 1e-6 * 2.4e9)
         summary["valu_issue_frac"] = frac
-        out.append("VALU issue: SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x %.1f us x 2.4 GHz) = %.3f of the chip's VALU issue slots "
-                   "(%.0f VALU instructions per agent)\n" % (summary["avg_kernel_us"], frac, summary["pmc_SQ_INSTS_VALU"] / args.agents))
+        out.append("VALU issue: %d launch(es) x SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x %.1f us x 2.4 GHz) = %.3f of the chip's VALU issue slots "
+                   "(%.0f VALU instructions per agent; the launch duration is the kernel trace's, where the launches overlap; the counter is "
+                   "per launch)\n" % (args.concurrent, summary["avg_kernel_us"], frac, summary["pmc_SQ_INSTS_VALU"] / args.agents))
     if "pmc_SQ_WAIT_ANY" in summary and "pmc_SQ_WAVE_CYCLES" in summary:
         out.append("SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.3f of the wave-cycles waiting\n" % (summary["pmc_SQ_WAIT_ANY"] / summary["pmc_SQ_WAVE_CYCLES"]))
     if "pmc_FETCH_SIZE" in summary and "pmc_WRITE_SIZE" in summary:
