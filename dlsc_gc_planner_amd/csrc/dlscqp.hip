@@ -1293,8 +1293,8 @@ __device__ __forceinline__ int order_bin(const OrderHist &h, int idx) {
 
 // Pass 1: histogram.  Wavefronts add to the workgroup's LDS histogram, the workgroup adds its non-empty bins to the global
 // one: a few dozen global atomics on the crowded bin (agents that never iterate) instead of one per wavefront -- contended
-// device-scope atomics on one address cost ~100 ns each.  `scratch` = 64 counts + 64 cursors, zeroed on the stream right
-// before this kernel (so that a captured graph, or calls on different streams, start from zero every time).
+// device-scope atomics on one address cost ~100 ns each.  `scratch` = 64 counts + 64 cursors + a ticket, zero when a
+// call starts: the scatter kernel's last workgroup zeroes them again (a replayed graph finds them as the capture did).
 __global__ __launch_bounds__(ORDER_THREADS) void dlscqp_order_count_kernel(OrderHist iters, int n, int *scratch) {
     __shared__ int hist[ORDER_BINS];
     const int lane = threadIdx.x & 63;
@@ -1342,6 +1342,16 @@ __global__ __launch_bounds__(ORDER_THREADS) void dlscqp_order_scatter_kernel(Ord
     __syncthreads();
     const int at = first[bin] + within;
     if (valid && at >= 0 && at < n) order[at] = idx;  // in range by construction; a corrupted scratch block must not write elsewhere
+    // the last workgroup to get here leaves the scratch block zeroed for the next call (a memset on the stream before every
+    // call was a third stream operation: with several groups of swarms sorting side by side each one waits for wave slots)
+    __shared__ int last;
+    __syncthreads();  // this workgroup has read the histogram and claimed its ranges
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(&scratch[2 * ORDER_BINS], 1) == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x <= 2 * ORDER_BINS) scratch[threadIdx.x] = 0;
 }
 }  // namespace
 
@@ -1366,10 +1376,12 @@ static int order_launch(dlscqp_ctx *c, const OrderHist &iters, int32_t n_agents,
     if (n_agents == 0) return DLSCQP_SUCCESS;
     if (!iters.it[0] || !order_out) { g_last_error = "null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
     HIP_TRY(hipSetDevice(c->cfg.device));
-    if (!c->d_order_scratch) HIP_TRY(hipMalloc((void **)&c->d_order_scratch, 2 * ORDER_BINS * sizeof(int)));
+    if (!c->d_order_scratch) {  // 64 counts, 64 cursors, a ticket: zero now, and every call leaves them zero (dlscqp_order_scatter_kernel)
+        HIP_TRY(hipMalloc((void **)&c->d_order_scratch, (2 * ORDER_BINS + 1) * sizeof(int)));
+        HIP_TRY(hipMemset(c->d_order_scratch, 0, (2 * ORDER_BINS + 1) * sizeof(int)));
+    }
     int *cur = c->d_order_scratch;  // one block, used by the calls of a context in stream order (they must not overlap)
     const int grid = (n_agents + ORDER_THREADS - 1) / ORDER_THREADS;
-    HIP_TRY(hipMemsetAsync(cur, 0, 2 * ORDER_BINS * sizeof(int), (hipStream_t)stream));
     hipLaunchKernelGGL(dlscqp_order_count_kernel, dim3(grid), dim3(ORDER_THREADS), 0, (hipStream_t)stream, iters, (int)n_agents, cur);
     hipLaunchKernelGGL(dlscqp_order_scatter_kernel, dim3(grid), dim3(ORDER_THREADS), 0, (hipStream_t)stream, iters, (int)n_agents, cur, order_out);
     HIP_TRY(hipGetLastError());

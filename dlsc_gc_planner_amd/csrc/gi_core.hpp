@@ -119,9 +119,6 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
 #define DQ_G2_KU 2
 #define DQ_G2_SU 6
 #endif
-#ifndef DQ_QDENSE  // plan_agent: from this many active velocity / acceleration rows on, their part of the step direction is a dense product
-#define DQ_QDENSE 8
-#endif
 #define DQ_INSTANCES(X)          \
     X(0, 1, 3, 13, 5, 2, 0, 0)   \
     X(1, 1, 3, 13, 5, 4, 4, 0)   \
@@ -1521,7 +1518,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 int n_kline = 0;
 #pragma unroll
                 for (int c = 0; c < RC; c++) n_kline += popc64(w.ballot(is_kline[c]));
-                dense_dx = n_kline >= (P > 5 * DQ_QDENSE ? P / 5 : DQ_QDENSE);  // uniform; the dense product costs ~40 cycles per control point
+                dense_dx = n_kline >= kp.dense_min;  // uniform
             }
 #pragma unroll
             for (int c = 0; c < RC; c++) {

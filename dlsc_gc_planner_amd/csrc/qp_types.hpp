@@ -23,6 +23,9 @@ struct Slot {
 };
 static_assert(sizeof(Slot) == 16, "Slot layout");
 
+#ifndef DQ_QDENSE  // plan_agent: from this many active velocity / acceleration rows on, their part of the step direction is a dense product
+#define DQ_QDENSE 8
+#endif
 struct KParams {
     // dimensions
     int dim, M, n1, P, f, phi;
@@ -33,6 +36,8 @@ struct KParams {
     int max_iter;
     int phi_ok;    // tabPhi is valid
     int dbg_exit_phase;  // profiling builds only (gi_core.hpp: DQ_PHASE_EXIT), else -1
+    int dense_min;       // plan_agent: from this many active velocity / acceleration rows on the step direction is a dense product
+                         // (DQ_QDENSE, or P / 5 for long horizons; DLSCQP_DENSE_MIN in the environment: tests force the path)
     int wd_cut;    // the weak-duality infeasibility test of gi_core.hpp is valid (its objective bound assumes phi_n = 1)
     // weights and constants (param.hpp)
     double dt;

@@ -69,6 +69,25 @@ def main():
                             nxt.update_order(iters=dbs[g][(j - 1) % B].out_iters, history=[dbs[g][(j - 2) % B].out_iters])
                             sorted_ev[g][(j + 1) % B] = torch.cuda.Event()
                             sorted_ev[g][(j + 1) % B].record(side[g])
+        if os.environ.get("PRIO_SORT"):
+            # the three stream operations of the launch order on a high-priority stream per group: same dependencies, but their
+            # workgroups do not queue behind the other groups' plan kernels
+            side = [torch.cuda.Stream(dev, priority=-1) for _ in range(G)]
+            e_plan = [torch.cuda.Event() for _ in range(G)]
+            e_sort = [torch.cuda.Event() for _ in range(G)]
+
+            def step(c):  # noqa: F811
+                j = c % B
+                for g in range(G):
+                    db, nxt = dbs[g][j], dbs[g][(j + 1) % B]
+                    if c:
+                        streams[g].wait_event(e_sort[g])
+                    db.launch(True, True, stream=streams[g])
+                    e_plan[g].record(streams[g])
+                    side[g].wait_event(e_plan[g])
+                    older = [dbs[g][(j - k) % B].out_iters for k in (1, 2) if (j - k) % B != (j + 1) % B]
+                    nxt.update_order(stream=side[g], iters=db.out_iters, history=older)
+                    e_sort[g].record(side[g])
         for c in range(2 * B):
             step(c)
         torch.cuda.synchronize(dev)
