@@ -1259,7 +1259,11 @@ extern "C" int dlscqp_neighbours_device(dlscqp_ctx *c, const dlscqp_neighbour_se
 // launch order of the next step (include/dlscqp.h: dlscqp_launch_order_device)
 // ---------------------------------------------------------------------------------------------
 namespace {
-constexpr int ORDER_THREADS = 1024, ORDER_BINS = 64;
+#ifndef DQ_ORDER_THREADS
+#define DQ_ORDER_THREADS 1024
+#endif
+constexpr int ORDER_THREADS = DQ_ORDER_THREADS, ORDER_BINS = 64;
+static_assert(ORDER_THREADS > 2 * ORDER_BINS, "the scatter kernel's last workgroup zeroes the scratch block with one thread per word");
 
 // Counting sort of the agents by the iteration count of the step just planned, descending (bin 0 = 63 iterations or
 // more), one thread per agent in two passes.  A wavefront handles the bins present among its 64 agents one after the
