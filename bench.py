@@ -575,6 +575,12 @@ def main():
     import numpy as np
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # TEST HOOK (tests/test_gpu_bench.py): DLSCQP_BENCH_GLOO_ONE_DEVICE=1 runs the ranks of an N > 1 launch on ONE device over gloo
+    # (which moves device tensors through the host) -- the multi-rank logic of this file (shards, halo agents, the exchange, the
+    # checks of the gathered tables) on a one-GPU box; RCCL refuses two ranks on one device.  Not a measurement.
+    one_device = os.environ.get("DLSCQP_BENCH_GLOO_ONE_DEVICE") == "1"
+    if one_device:
+        local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     if not torch.cuda.is_available():
@@ -594,12 +600,15 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29500")
         # RCCL's kernels on a high-priority stream: with the pipelined exchange they share the GPU with the plan kernel of
         # the next step and should get the first free workgroup slots
-        opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=opts)
+        if one_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, pg_options=opts)
         world = dist.get_world_size()  # n_gpus in the line = the ranks RCCL really has
         if world != args.gpus and not args.force_dist:
             raise SystemExit("bench.py --gpus %d, but the process group has %d ranks: the line would report the wrong N" % (args.gpus, world))
-        if torch.cuda.device_count() < (1 if args.force_dist else args.gpus):
+        if torch.cuda.device_count() < (1 if args.force_dist or one_device else args.gpus):
             raise SystemExit("bench.py --gpus %d, but only %d devices are visible" % (args.gpus, torch.cuda.device_count()))
 
     from dlsc_gc_planner_amd import abi, workloads
@@ -957,7 +966,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
-            "data": "synthetic",
+            "data": "synthetic" if not one_device else "synthetic; TEST HOOK: all ranks on one device over gloo -- not a measurement",
             "config": {
                 "workload": "S64: %d independent 64-agent swarms per GPU per step (BASELINE.json configs[1]: 3-D, 5 segments x degree 5, "
                             "%d DLSC rows per agent); the timed loop rotates through %d consecutive replanning steps of the closed-loop "

@@ -84,3 +84,29 @@ def test_gpus_flag_starts_the_ranks_itself(gpu_required):
     else:
         assert out.returncode != 0 and not lines, (out.returncode, out.stdout[-500:])
         assert "torch.distributed" in out.stderr or "invalid device" in out.stderr.lower() or "ChildFailedError" in out.stderr
+
+
+def test_two_ranks_end_to_end_on_one_gpu_over_gloo(gpu_required):
+    """The multi-rank logic of bench.py with TWO real ranks: RCCL refuses two ranks on one device, gloo moves device tensors
+    through the host, so `DLSCQP_BENCH_GLOO_ONE_DEVICE=1` (a test hook of bench.py) runs both ranks on cuda:0 -- shards of the S64
+    swarms in two groups per rank with one exchange per step, the check that every gathered table holds the rank's own
+    block, X2048 with real halo agents on both ranks (interior launch, exchange, halo launch), empty60 sharded 30 + 30 with the
+    exchange on the critical path, the per-rank breakdown gathered over both ranks.  Logic, not timing."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(DLSCQP_BENCH_GLOO_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29737",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--swarms", "8", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["n_gpus_requested"] == 2 and "TEST HOOK" in d["data"]
+    assert d["value"] > 0 and d["config"]["swarm_groups"] == 2 and d["config"]["agents_per_gpu"] == 512
+    for k, v in d["per_rank_ms"].items():
+        assert v["min"] <= v["mean"] <= v["max"], k
+    x = d["x2048_strong"]
+    assert x["agents_total"] == 2048 and x["agents_this_rank"] == 1024 and x["halo_agents_rank0"] > 0 and x["interior_agents_rank0"] > 0
+    assert x["ms_per_step_serial_exchange"] > 0 and x["ms_per_step_pipelined_exchange"] > 0 and x["solved_fraction_rank0"] > 0.9
+    e60 = d["empty60_sharded"]
+    assert e60["ranks"] == 2 and e60["agents"] == 60 and e60["qp_failsafes_last_step_all_ranks"] == 0 and e60["mean_distance_flown_m"] > 0.3
