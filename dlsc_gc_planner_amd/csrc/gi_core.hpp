@@ -690,7 +690,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             for (int u = 0; u < KU; u++) {
                 const uint32_t key = ckey[u].at(l);
                 const bool have = key != KEY_SKIP;
-                const int mi = have ? (int)(key & 0xFF) * n1 + (int)((key >> 8) & 0xF) : 0;
+                int mi = (int)(key & 0xFF) * n1 + (int)((key >> 8) & 0xF);
+                DQ_KEEP(mi);  // computed for every lane, then selected: as one ?: expression this came out as an EXEC-masked region
+                mi = have ? mi : 0;
                 nn[u] = tNN[mi < P ? mi : 0];
             }
 #pragma unroll
