@@ -123,6 +123,9 @@ struct WaveGpu {
 #endif
     template <class F>
     __device__ __forceinline__ void each(F f) const { f(lane); }
+    // wave-uniform work on the working set: every lane reads, computes and writes the same (lock step: all lanes read before any writes)
+    template <class F>
+    __device__ __forceinline__ void once(F f) const { f(); }
     __device__ __forceinline__ void sync() const {
 #ifdef DLSCQP_SAFE_SYNC
         __syncthreads();
@@ -728,7 +731,7 @@ struct dlscqp_ctx {
     double dt;
     HostTables tb;
     KParams kp;  // with device table pointers
-    double *d_tabPhi = nullptr, *d_tabKIW = nullptr, *d_tabG = nullptr, *d_tabX0s = nullptr, *d_tabX0g = nullptr, *d_tabNN = nullptr, *d_tabSIW = nullptr;
+    double *d_tabPhi = nullptr, *d_tabKIW = nullptr, *d_tabG = nullptr, *d_tabN = nullptr, *d_tabX0s = nullptr, *d_tabX0g = nullptr, *d_tabNN = nullptr, *d_tabSIW = nullptr;
     Slot *d_slots = nullptr;
     hipStream_t stream = nullptr;
     int max_dyn_lds[3 * (DQ_N_INSTANCES + 1)] = {};  // second third: the WIDE builds, last third: the builds with helper wavefronts
@@ -753,6 +756,7 @@ static int upload_tables(dlscqp_ctx *c) {
         return hip_ok(hipMemcpy(*dptr, src, bytes, hipMemcpyHostToDevice), "hipMemcpy(tables)");
     };
     if (!up((void **)&c->d_tabG, c->tb.tabG.data(), c->tb.tabG.size() * 8)) return DLSCQP_ERR_HIP;
+    if (!up((void **)&c->d_tabN, c->tb.tabN.data(), c->tb.tabN.size() * 8)) return DLSCQP_ERR_HIP;
     if (!up((void **)&c->d_tabX0s, c->tb.tabX0s.data(), c->tb.tabX0s.size() * 8)) return DLSCQP_ERR_HIP;
     if (!up((void **)&c->d_tabX0g, c->tb.tabX0g.data(), c->tb.tabX0g.size() * 8)) return DLSCQP_ERR_HIP;
     if (!up((void **)&c->d_tabNN, c->tb.tabNN.data(), c->tb.tabNN.size() * 8)) return DLSCQP_ERR_HIP;
@@ -762,6 +766,7 @@ static int upload_tables(dlscqp_ctx *c) {
     if (!up((void **)&c->d_slots, c->tb.slots.data(), c->tb.slots.size() * sizeof(Slot))) return DLSCQP_ERR_HIP;
     c->kp = c->tb.kp;
     c->kp.tabG = c->d_tabG;
+    c->kp.tabN = c->d_tabN;
     c->kp.tabX0s = c->d_tabX0s;
     c->kp.tabX0g = c->d_tabX0g;
     c->kp.tabNN = c->d_tabNN;
@@ -817,6 +822,7 @@ extern "C" void dlscqp_destroy(dlscqp_ctx *c) {
     for (auto e : c->ev0) (void)hipEventDestroy(e);
     for (auto e : c->ev1) (void)hipEventDestroy(e);
     if (c->d_tabG) (void)hipFree(c->d_tabG);
+    if (c->d_tabN) (void)hipFree(c->d_tabN);
     if (c->d_tabX0s) (void)hipFree(c->d_tabX0s);
     if (c->d_tabX0g) (void)hipFree(c->d_tabX0g);
     if (c->d_tabNN) (void)hipFree(c->d_tabNN);

@@ -71,6 +71,7 @@ struct MemLayout {
     int oG, oRp, oX, oDx, oBlo, oBhi;  // in doubles
     int oLam;                          // by-kind shapes: two tables of nx_max + 2 doubles, the weights of the active velocity and acceleration
                                        // rows by coordinate (plan_agent: dense step direction)
+    int oU;                            // nx_max doubles: a - A' r in the variables' own space (plan_agent: whitened_length)
     int oMail;                         // 8 doubles: what the planning wavefront and its helper wavefronts tell each other (dlscqp.hip)
     int oDump;                         // 32 dump slots (lane & 31) for the lanes that have nothing to store, right behind S;
                                        // then two doubles that stay 0.0 (what a masked read of S is sent to)
@@ -105,6 +106,7 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
     L.oBlo = o; o += kp.nb;
     L.oBhi = o; o += kp.nb;
     L.oMail = o; o += 8;
+    L.oU = o; o += L.nx_max;
     L.oLam = o; o += by_kind ? 2 * (L.nx_max + 2) : 0;
     L.oFlag = o * 8;
     L.bytes = (L.oFlag + L.nflag + 1 + 15) & ~15;  // + one flag byte as the dump of the flag array
@@ -1732,6 +1734,71 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 });
                 return adx + w.sum(tr);
             };
+            // Whether the row DEPENDS on the active rows is decided in the whitened space itself.  dx = G (a - A' rv) of a row
+            // that depends on them modulo the equality constraints is G u with u in the range of the equalities' transpose:
+            // zero in exact arithmetic, eps |G| |u| in floating point -- and both forms of |z|^2 above inherit that: the
+            // quotient |z|^2 / |N'a|^2 of a dependent row comes out between 1e-16 and 1e-7 (the reduced Hessian's condition
+            // number is 2e5 .. 3.5e6), no threshold separates it from a row that is merely close to the active ones, and a
+            // dependent row taken for an independent one gets a step of 1e13 times noise (found by tests/fuzz_gpu.py: 6 of
+            // 17 622 random QPs accepted although infeasible).  So a row that looks nearly dependent is measured again the way
+            // the dense method measures every row: u = a - A' rv in the variables' own space (every lane the same
+            // read-modify-write, one active row after the other), z = N_T' u with the whitening map itself (read from HBM / L2,
+            // here only), |z|^2 = sum z_j^2 -- the error is (eps |N| |u|)^2, a dependent row gives ~1e-28.
+            auto whitened_length = [&]() -> double {
+                double *u = base + lay.oU;
+                const double *tN = kp.tabN + (size_t)(T - 1) * P * f;
+                const int nx = nxc + nslk;
+                w.each([&](int l) {
+                    for (int j0 = 0; j0 < nx; j0 += 64) base[blend_idx(j0 + l < nx, lay.oU + j0 + l, odump + (l & 31))] = 0.0;  // uniform trip count
+                });
+                w.sync();
+                for (int i = 0; i <= q; i++) {  // uniform; i == q: the new row itself
+                    const bool act = i < q;
+                    const int ic = act ? i : 0;
+                    const uint32_t pk = act ? (uint32_t)DQ_BC(a_pk, ic) : pk_new;
+                    const double c0 = act ? DQ_BC2(wc, 0, ic) : ncf[0], c1 = act ? DQ_BC2(wc, 1, ic) : ncf[1], c2 = act ? DQ_BC2(wc, 2, ic) : ncf[2];
+                    const int sl = act ? DQ_BCI(a_sl, ic) : sidx_row;
+                    const double cs = act ? DQ_BC(rv, ic) : -1.0;  // the slack variable's coefficient is -1: -rv x -1
+                    const int ka = (pk >> 24) & 3;
+                    const bool line = (pk >> 26) & 1;
+                    const int p0 = pk & 0xFF, p1 = (pk >> 8) & 0xFF, p2 = (pk >> 16) & 0xFF;
+                    // a POINT row in 2-D has a zero third coefficient and no third axis: it is added to the first axis' entry
+                    const int j0 = (line ? ka : 0) * P + p0, j1 = (line ? ka : (dim > 1 ? 1 : 0)) * P + (line ? p1 : p0);
+                    const int j2 = (line ? ka : (dim > 2 ? 2 : 0)) * P + (line ? p2 : p0);
+                    const double c2u = (line || dim > 2) ? c2 : 0.0;
+                    w.once([&]() {
+                        u[j0] += c0;
+                        u[j1] += c1;
+                        u[j2] += c2u;
+                        if (SLK != 0 && sl >= 0) u[nxc + sl] += cs;  // uniform
+                    });
+                    w.sync();
+                }
+                RegD acc;
+                w.each([&](int l) {
+                    double s = 0.0;
+                    for (int jb = 0; jb < f; jb += 64) {  // uniform trip count
+                        const int j = jb + l;
+                        const int jc = j < f ? j : f - 1;
+                        // (rolled loops, one accumulator: this path is rare, and the kernel has no registers to lend it)
+#pragma nounroll
+                        for (int k = 0; k < dim; k++) {
+                            double z = 0.0;
+#pragma nounroll
+                            for (int p = 0; p < P; p++) z = fma(tN[(size_t)p * f + jc], u[k * P + p], z);
+                            s += j < f ? z * z : 0.0;
+                        }
+                    }
+                    for (int s0 = 0; s0 < nslk; s0 += 64) {  // uniform trip count
+                        const int sidx = s0 + l;
+                        const int sc = sidx < nslk ? sidx : 0;
+                        const double v = kp.sigma[sc % M] * u[nxc + sc];
+                        s += sidx < nslk ? v * v : 0.0;
+                    }
+                    acc.at(l) = s;
+                });
+                return w.sum(acc);
+            };
             double dd2;
             if (DXREG) {
                 // a.dx from the registers: the rate at which the step moves the row it is taken for.  Equal to |z|^2 up to the
@@ -1745,18 +1812,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 const double y1 = ax1 == 0 ? e10 : (ax1 == 1 ? e11 : e12);
                 const double y2 = ax2 == 0 ? e20 : (ax2 == 1 ? e21 : e22);
                 dd2 = ncf[0] * y0 + ncf[1] * y1 + ncf[2] * y2;
-                if (q > 0 && !(dd2 > 1e-6 * dall)) {  // uniform, rare
-                    w.each([&](int l) {
-#pragma unroll
-                        for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++)
-                            base[blend_idx(l < P, oDx + k * P + l, odump + (l & 31))] = dkr[k].at(l);
-                    });
-                    w.sync();
-                    dd2 = z_squared();
-                }
             } else {
                 dd2 = z_squared();
             }
+            if (q > 0 && !(dd2 > 1e-6 * dall)) dd2 = whitened_length();  // uniform, a few per cent of the iterations
             w.stamp(6);  // step direction, its whitened length
             // step lengths: t1 = min u_k / r_k over r_k > 0 (dual), t2 = viol / |z|^2 (primal)
             double t1 = 1e300;

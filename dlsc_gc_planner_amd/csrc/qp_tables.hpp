@@ -10,7 +10,7 @@ namespace dlscqp {
 
 struct HostTables {
     KParams kp;                  // table pointers left null; the owner fills them in
-    std::vector<double> tabN;    // [M][P][f]     whitening maps (host only: the kernel reads their Gram tables)
+    std::vector<double> tabN;    // [M][P][f]     whitening maps (the kernel reads their Gram tables, and these where a row looks dependent)
     std::vector<double> tabG;    // [M][P][P|1]   G_T = N_T N_T'
     std::vector<double> tabX0s;  // [M][P][3]
     std::vector<double> tabX0g;  // [M][P]

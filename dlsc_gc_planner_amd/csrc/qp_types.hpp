@@ -50,6 +50,7 @@ struct KParams {
     double sigma[32];             // slack whitening 1/sqrt(2 w_s (M-m)/M), m < M <= 32
     int t_valid[32];              // reduced Hessian positive definite for T = idx+1
     // device (or host, in the emulation build) tables
+    const double *tabN;           // [M][P][f]     whitening maps N_T: read only where a row looks dependent on the active rows (plan_agent: whitened_length)
     const double *tabG;           // [M][P][P|1]   Gram table N_T N_T' of the whitening map (row stride odd, as it is copied to LDS)
     const double *tabX0s;         // [M][P][3]
     const double *tabX0g;         // [M][P]

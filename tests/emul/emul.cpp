@@ -49,6 +49,8 @@ struct WaveCpu {
             for (int l = 63; l >= 0; l--) f(l);
     }
     void sync() const {}
+    template <class F>
+    void once(F f) const { f(); }  // wave-uniform work on the working set: here it runs once, on the device every lane does the same
     void stamp(int) const {}
     void trace(int tag, double a, double b, double c, double d) const {
         if (g_trace) { g_trace->push_back(tag); g_trace->push_back(a); g_trace->push_back(b); g_trace->push_back(c); g_trace->push_back(d); }
@@ -133,6 +135,7 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
     if (!build_tables(*cfg, cfg->world_dimension, cfg->M, cfg->n, cfg->phi, cfg->dt, tb, err)) return -1;
     KParams kp = tb.kp;
     kp.tabG = tb.tabG.data();
+    kp.tabN = tb.tabN.data();
     kp.tabX0s = tb.tabX0s.data();
     kp.tabX0g = tb.tabX0g.data();
     kp.tabNN = tb.tabNN.data();
@@ -400,6 +403,7 @@ extern "C" int emul_throughput(const dlscqp_config *cfg, int n_agents, const dls
     std::string err;
     if (!build_tables(*cfg, cfg->world_dimension, cfg->M, cfg->n, cfg->phi, cfg->dt, tb, err)) return -1;
     KParams kp = tb.kp;
+    kp.tabN = tb.tabN.data();
     kp.tabG = tb.tabG.data(); kp.tabX0s = tb.tabX0s.data(); kp.tabX0g = tb.tabX0g.data();
     kp.tabNN = tb.tabNN.data(); kp.tabSIW = tb.tabSIW.data(); kp.tabKIW = tb.tabKIW.data(); kp.tabPhi = tb.tabPhi.data(); kp.slots = tb.slots.data();
     const int64_t nrows = row_offsets[n_agents];
