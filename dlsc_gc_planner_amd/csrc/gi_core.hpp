@@ -1744,6 +1744,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             // the dense method measures every row: u = a - A' rv in the variables' own space (every lane the same
             // read-modify-write, one active row after the other), z = N_T' u with the whitening map itself (read from HBM / L2,
             // here only), |z|^2 = sum z_j^2 -- the error is (eps |N| |u|)^2, a dependent row gives ~1e-28.
+            double noise2 = 0.0;  // (set by whitened_length) sum_j (sum_p |N_pj| |u_p|)^2: eps^2 times it is the rounding noise of |z|^2
             auto whitened_length = [&]() -> double {
                 double *u = base + lay.oU;
                 const double *tN = kp.tabN + (size_t)(T - 1) * P * f;
@@ -1774,19 +1775,24 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     });
                     w.sync();
                 }
-                RegD acc;
+                RegD acc, accn;
                 w.each([&](int l) {
-                    double s = 0.0;
+                    double s = 0.0, sn = 0.0;
                     for (int jb = 0; jb < f; jb += 64) {  // uniform trip count
                         const int j = jb + l;
                         const int jc = j < f ? j : f - 1;
                         // (rolled loops, one accumulator: this path is rare, and the kernel has no registers to lend it)
 #pragma nounroll
                         for (int k = 0; k < dim; k++) {
-                            double z = 0.0;
+                            double z = 0.0, za = 0.0;
 #pragma nounroll
-                            for (int p = 0; p < P; p++) z = fma(tN[(size_t)p * f + jc], u[k * P + p], z);
+                            for (int p = 0; p < P; p++) {
+                                const double nv = tN[(size_t)p * f + jc], uv = u[k * P + p];
+                                z = fma(nv, uv, z);
+                                za = fma(fabs(nv), fabs(uv), za);
+                            }
                             s += j < f ? z * z : 0.0;
+                            sn += j < f ? za * za : 0.0;
                         }
                     }
                     for (int s0 = 0; s0 < nslk; s0 += 64) {  // uniform trip count
@@ -1796,8 +1802,11 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                         s += sidx < nslk ? v * v : 0.0;
                     }
                     acc.at(l) = s;
+                    accn.at(l) = sn;
                 });
-                return w.sum(acc);
+                double zz;
+                w.sum2(acc, accn, zz, noise2);
+                return zz;
             };
             double dd2;
             if (DXREG) {
@@ -1815,7 +1824,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             } else {
                 dd2 = z_squared();
             }
-            if (q > 0 && !(dd2 > 1e-6 * dall)) dd2 = whitened_length();  // uniform, a few per cent of the iterations
+            if (q > 0 && !(dd2 > (DXREG ? DEP_SUSPECT : DEP_SUSPECT_SLACK) * dall)) {
+                DQ_TRACE(5, dd2, dall, 0.0, 0.0);  // (the step rate that raised the suspicion)
+                dd2 = whitened_length();  // uniform, a few per cent of the iterations
+            }  // uniform, a few per cent of the iterations
             w.stamp(6);  // step direction, its whitened length
             // step lengths: t1 = min u_k / r_k over r_k > 0 (dual), t2 = viol / |z|^2 (primal)
             double t1 = 1e300;
@@ -1854,7 +1866,8 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 }
             }
             // q == r: the active rows span the whitened space, every further row depends on them
-            const bool dependent = !(dd2 > DEP_TOL * dall) || !(dd2 > 0) || q >= r;
+            // (noise2 > 0: |z|^2 was measured in the whitened space: it must also stand out of the rounding noise of that measure)
+            const bool dependent = !(dd2 > DEP_TOL * dall) || !(dd2 > DEP_NOISE * noise2) || !(dd2 > 0) || q >= r;
             const double t2 = dependent ? 1e300 : viol / dd2;
             DQ_TRACE(2, dd2, dall, t1, (double)ldrop);
             w.stamp(7);  // ratio test

@@ -66,6 +66,20 @@ struct KParams {
 // a row that cannot be satisfied but is violated by no more than this is accepted, as CPLEX would.
 constexpr double VIOL_TOL = 1e-9;
 constexpr double CPLEX_FEAS_TOL = 1e-6;
+#ifndef DQ_DEP_SUSPECT
+#define DQ_DEP_SUSPECT 1e-5
+#endif
+// Measured with tests/fuzz_cpu.py's batches (trace build): a . dx / |N'a|^2 of rows that DO depend on the active rows stays below
+// 8e-9 in the static shapes without slack variables and below 7e-7 in the others; rows that do not depend start at 1e-5.  Three orders
+// of margin each: 1e-5 where a . dx comes from registers (1e-4 there costs the S64 step 9 %: rows between 1e-5 and 1e-4 are
+// common in its crowded swarms), 1e-3 in the shapes with slack variables and the runtime shapes.
+// a . dx <= DEP_SUSPECT |N'a|^2: the row may depend on the active rows -- |z|^2 is measured again in the whitened space (plan_agent:
+// whitened_length)
+constexpr double DEP_SUSPECT = DQ_DEP_SUSPECT, DEP_SUSPECT_SLACK = 1e-3;
+// |z|^2 <= DEP_NOISE sum_j (sum_p |N_pj| |u_p|)^2: the whitened length of u = a - A' r is rounding noise.  r carries a relative error of
+// ~1e-11 (condition of the active rows' Gram matrix), u inherits it, and the quotient of a dependent row was measured between 1e-31
+// and 1e-20 over the random batches of tests/fuzz_cpu.py; rows that do not depend on the active ones start at 1e-12.
+constexpr double DEP_NOISE = 1e-17;
 constexpr double DEP_TOL = 1e-20;  // |z|^2 <= DEP_TOL |N'a|^2  -> the row's normal depends on the active rows'
 constexpr double SP_EPSILON = 1e-9;        // sp_const.hpp:3
 constexpr double SP_EPSILON_FLOAT = 1e-5;  // sp_const.hpp:4
