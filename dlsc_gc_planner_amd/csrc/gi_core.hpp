@@ -1781,19 +1781,21 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     for (int jb = 0; jb < f; jb += 64) {  // uniform trip count
                         const int j = jb + l;
                         const int jc = j < f ? j : f - 1;
-                        // (rolled loops, one accumulator: this path is rare, and the kernel has no registers to lend it)
+                        // (a rolled loop: this path is rare, and the kernel has no registers to lend it; one read of the map per control
+                        // point serves the three axes -- the reads come from L2 one after the other and are what this path costs)
+                        double z0 = 0.0, z1 = 0.0, z2 = 0.0, n0 = 0.0, n1s = 0.0, n2 = 0.0;
 #pragma nounroll
-                        for (int k = 0; k < dim; k++) {
-                            double z = 0.0, za = 0.0;
-#pragma nounroll
-                            for (int p = 0; p < P; p++) {
-                                const double nv = tN[(size_t)p * f + jc], uv = u[k * P + p];
-                                z = fma(nv, uv, z);
-                                za = fma(fabs(nv), fabs(uv), za);
-                            }
-                            s += j < f ? z * z : 0.0;
-                            sn += j < f ? za * za : 0.0;
+                        for (int p = 0; p < P; p++) {
+                            const double nv = tN[(size_t)p * f + jc], na = fabs(nv);
+                            const double u0 = u[p], u1 = u[(dim > 1 ? P : 0) + p], u2 = u[(dim > 2 ? 2 * P : 0) + p];
+                            z0 = fma(nv, u0, z0); n0 = fma(na, fabs(u0), n0);
+                            z1 = fma(nv, u1, z1); n1s = fma(na, fabs(u1), n1s);
+                            z2 = fma(nv, u2, z2); n2 = fma(na, fabs(u2), n2);
                         }
+                        const double zz3 = z0 * z0 + (dim > 1 ? z1 * z1 : 0.0) + (dim > 2 ? z2 * z2 : 0.0);
+                        const double nn3 = n0 * n0 + (dim > 1 ? n1s * n1s : 0.0) + (dim > 2 ? n2 * n2 : 0.0);
+                        s += j < f ? zz3 : 0.0;
+                        sn += j < f ? nn3 : 0.0;
                     }
                     for (int s0 = 0; s0 < nslk; s0 += 64) {  // uniform trip count
                         const int sidx = s0 + l;
