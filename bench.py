@@ -663,7 +663,8 @@ def main():
             queue run one after the other (measured: the first two streams a process creates shared a queue -- two groups on them
             took 0.49 ms per step, on any other pair 0.28): of eight new streams those are kept that overlap with every stream kept
             before, judged by launching two of the loop's own batches on a pair and on one stream."""
-            cands = [torch.cuda.Stream(dev) for _ in range(max(8, 2 * G))]
+            cands = [torch.cuda.Stream(dev) for _ in range(max(8, 2 * G) + 4)]
+            self.spare, self.span = cands[1:], None
             if G == 1:
                 return cands[:1]
             a, b = self.dbs[0][0], self.dbs[1][0]
@@ -680,14 +681,24 @@ def main():
                     best = min(best, time.perf_counter() - t0)
                 return best
             serial = span(cands[0], cands[0])
+            self.span = lambda sa, sb: span(sa, sb) < 0.8 * serial  # do sa and sb run side by side?
             kept = [cands[0]]
+            rest = []
             for s_ in cands[1:]:
-                if len(kept) == G:
-                    break
-                if all(span(k_, s_) < 0.8 * serial for k_ in kept):
+                if len(kept) < G and all(self.span(k_, s_) for k_ in kept):
                     kept.append(s_)
-            self.stream_note = "%d of %d candidate streams overlapped pairwise" % (len(kept), len(cands))
-            return kept + cands[len(kept):G] if len(kept) < G else kept
+                else:
+                    rest.append(s_)
+            self.spare = rest
+            self.stream_note = "%d streams that overlap pairwise, picked from %d new ones" % (len(kept), len(cands))
+            return kept + rest[:G - len(kept)] if len(kept) < G else kept
+
+        def spare_stream(self):
+            """a further stream that overlaps with every group's stream (the exchange's streams), if there is one"""
+            for i, s_ in enumerate(self.spare):
+                if self.span is None or all(self.span(k_, s_) for k_ in self.streams):
+                    return self.spare.pop(i)
+            return torch.cuda.Stream(dev)
 
         def make_exchange(self):
             # per agent: control points, sub-goal, status (376 B at S64) -- the broadcast payload of the reference.  ONE exchange
@@ -697,7 +708,8 @@ def main():
             from dlsc_gc_planner_amd import sharding
             shape1 = tuple(self.dbs[0][0].out_ctrl.shape[1:])
             self.xchg = sharding.PlanExchange(dist, world, N, (int(np.prod(shape1)), 3, 1), dev)
-            self.join = torch.cuda.Stream(dev)
+            self.xchg.comm = self.spare_stream()  # (not one that shares a hardware queue with a group's launches)
+            self.join = self.spare_stream()
             self.table_ready = None  # serial mode: the gathered table of the previous step (an event on `join`)
             per = self.per
             self.out = [(torch.zeros((N,) + shape1, dtype=torch.float32, device=dev), torch.zeros((N, 3), dtype=torch.float32, device=dev),
