@@ -139,7 +139,9 @@ def cpu_baseline(cfg, wl, seconds=12.0):
     oracle_lib.plan_batch(cfg, agents[:probe], ro[:probe + 1], rows[:ro[probe]], None, 0, True)
     oracle_rate = probe / (time.perf_counter() - t0)
     n_all, el_all = res["all"]
-    return {"value": n_all / el_all, "unit": "QP/s", "cores": cores, "kind": "port",
+    return {"value": n_all / el_all, "unit": "QP/s", "cores": cores, "kind": "port", "port_kind": "lane-serial port",
+            "port_note": "the wave64 program run lane by lane on the host: every lane loop runs 64 trips and every reduction walks 64 "
+                         "elements whatever the agent's active set is -- the device algorithm on a CPU, not a CPU-shaped solver",
             "sample": "%d agent-QPs (goal LP + QP each) of the timed batch in %.1f s: the kernel's own algorithm (lane-serial host build "
                       "of csrc/gi_core.hpp, g++ -O3 -march=x86-64-v3), %d native threads, each walking its own range of the batch"
                       % (n_all, el_all, cores),
@@ -426,9 +428,9 @@ class StressStep:
     def _plan(self, part):
         gen, db, _, sel = part
         gen.generate(self.goals, plans=self.plans)
-        db.launch(True, True)
         if self.order_hint:
-            db.update_order()  # the next step's launch order from this step's iteration counts, on the device
+            db.rotate_hint(2)  # launch order from the two previous steps' iteration counts, found by the plan kernel itself
+        db.launch(True, True)
         self.own_ctrl.index_copy_(0, sel, db.out_ctrl.view(len(sel), -1))
         self.own_goal.index_copy_(0, sel, db.out_goal)
         self.own_status.index_copy_(0, sel, db.out_status.view(-1, 1))
@@ -642,6 +644,9 @@ def main():
             self.dbs = [[self.opts[g].make_device_batch(h["agents"][g * per:(g + 1) * per], np.arange(per + 1) * K,
                                                          h["rows"][g * per * K:(g + 1) * per * K], None, 0, want_iters=True) for h in hist]
                         for g in range(G)]
+            for g in range(G):
+                for db in self.dbs[g]:
+                    db.use_row_pitch()  # every agent has K rows: the kernel computes where they start
             self.streams = self.pick_streams(G)
             self.counter = 0
             self.device_order = False
@@ -751,10 +756,17 @@ def main():
             torch.cuda.synchronize(dev)
 
         def timed(self, steps, pipelined, orders, record_kernel_times=False):
+            """orders: "kernel" = the plan kernel finds its launch order itself from the iteration counts of the three previous
+            replanning steps (dlscqp_device_batch.hint_iters: the other batches of the rotation, never the batch's own -- no stream
+            operation between two launches); "device" = the same key sorted by dlscqp_launch_order_history_device after every
+            step (round 3's method: two more kernels per group and step); "host" = permutations prepared before the loop;
+            None = id order."""
             self.device_order = isinstance(orders, str) and orders == "device"
+            kernel_order = isinstance(orders, str) and orders == "kernel"
             for g in range(self.G):
                 for j, db in enumerate(self.dbs[g]):
-                    db.set_order(None if orders is None or self.device_order else self.hint[g][j])
+                    db.set_order(None if orders is None or self.device_order or kernel_order else self.hint[g][j])
+                    db.set_hint([self.dbs[g][(j - k) % B].out_iters for k in (1, 2, 3) if (j - k) % B != j] if kernel_order else None)
             self.counter = 0
             for _ in range(B):
                 self.step(pipelined)
@@ -817,7 +829,7 @@ def main():
     head_pipelined = use_dist and pipelined_ok and args.exchange == "pipelined"
     if use_dist:
         assert B >= 3, "the pipelined exchange reads a step's output table while the next steps write other tables"
-    elapsed = loop.timed(args.steps, head_pipelined, "device", record_kernel_times=True)
+    elapsed = loop.timed(args.steps, head_pipelined, "kernel", record_kernel_times=True)
     kms = loop.kernel_times_ms(args.steps)
     host_queue_ms = loop.host_ms_per_step
     rank_breakdown = None
@@ -825,7 +837,7 @@ def main():
         # the stages of the exchange from a second, shorter pass of the same loop with events around them (the events cost
         # the host ~0.1 ms per step: not in the headline's pass)
         loop.xchg.enable_timing()
-        loop.timed(max(B, min(args.steps, 100)), head_pipelined, "device")
+        loop.timed(max(B, min(args.steps, 100)), head_pipelined, "kernel")
         br = exchange_breakdown(loop.xchg, skip=B)  # the first B exchanges are the untimed warm-up steps of timed()
         loop.xchg.enable_timing(False)
         br["plan_kernel_ms"] = float(np.mean(kms)) if len(kms) else float("nan")
@@ -844,12 +856,13 @@ def main():
     side_steps = max(B, min(args.steps, 200))
     el_nohint = float("nan") if args.headline_only else loop.timed(side_steps, head_pipelined, None)
     el_hostorder = float("nan") if args.headline_only else loop.timed(side_steps, head_pipelined, "host")
+    el_sorted = float("nan") if args.headline_only else loop.timed(side_steps, head_pipelined, "device")
     exch = None
     if use_dist and not args.headline_only:
         exch = {"pipelined": None, "serial": None, "steps_of_the_second_mode": side_steps}
         exch["pipelined" if head_pipelined else "serial"] = elapsed / args.steps * 1e3
         if pipelined_ok:  # the other mode, same batches, same launch order
-            el_other = loop.timed(side_steps, not head_pipelined, "device")
+            el_other = loop.timed(side_steps, not head_pipelined, "kernel")
             exch["serial" if head_pipelined else "pipelined"] = el_other / side_steps * 1e3
     G_used, per_launch = loop.G, loop.per
     stream_note = getattr(loop, "stream_note", None)
@@ -859,7 +872,9 @@ def main():
     one_launch = None
     if G_used > 1 and not args.headline_only and not use_dist:
         l1 = SwarmLoop(1)
-        one_launch = {"device_order": l1.timed(side_steps, False, "device") / side_steps * 1e3, "id_order": l1.timed(side_steps, False, None) / side_steps * 1e3}
+        one_launch = {"kernel_order": l1.timed(side_steps, False, "kernel") / side_steps * 1e3,
+                      "sorted_on_device": l1.timed(side_steps, False, "device") / side_steps * 1e3,
+                      "id_order": l1.timed(side_steps, False, None) / side_steps * 1e3}
         l1.close()
         del l1
 
@@ -912,9 +927,12 @@ def main():
         dim, M, n = cfg.world_dimension, cfg.M, cfg.n
         bytes_qp = algorithmic_bytes_per_qp(dim, M, n, K, False, 0)
         avg_kernel_s = float(np.mean(kms)) * 1e-3 if len(kms) else float("nan")
-        # G_used launches run side by side (one per group, each on its stream) and last avg_kernel_s on average: the device
-        # moves the bytes of all of them in that time
-        achieved = G_used * per_launch * bytes_qp / avg_kernel_s / 1e9
+        # the roofline figure is what the STEP achieves: the algorithmic bytes of all agents of a step over the step's wall time
+        # (the same clock as `value`).  Per launch (HIP events on the launch streams) and "if the groups' launches overlapped for
+        # their whole duration" are kept beside it as named extras: launches of different groups overlap only partly.
+        step_s = elapsed / args.steps
+        achieved = N * bytes_qp / step_s / 1e9
+        achieved_if_overlapped = G_used * per_launch * bytes_qp / avg_kernel_s / 1e9
         traffic, traffic_src, valu_frac, prof = None, None, None, {}
         try:
             with open(args.traffic_json) as fh:
@@ -923,7 +941,10 @@ def main():
             import summarize
             if prof.get("agents_per_launch") == per_launch and prof.get("csrc_sha1") == summarize.csrc_sha1():
                 traffic = prof.get("hbm_bytes_per_launch")
-                valu_frac = prof.get("valu_issue_frac")
+                if prof.get("valu_insts_per_agent"):
+                    # share of the chip's VALU issue slots over the STEP: a wave64 VALU instruction holds its SIMD's issue port
+                    # for 4 cycles; 1 024 SIMDs; 2.4 GHz nominal (the counter is per launch and does not depend on the overlap)
+                    valu_frac = prof["valu_insts_per_agent"] * N * 4.0 / (1024 * step_s * 2.4e9)
                 traffic_src = "%s: rocprofv3 --pmc passes of this command (%s), taken on these kernel sources" % (
                     os.path.relpath(args.traffic_json, ROOT), prof.get("source", ""))
             elif prof.get("agents_per_launch") == per_launch:
@@ -970,10 +991,12 @@ def main():
                     hstreams = [torch.cuda.Stream(dev) for _ in range(Gh)]
                     hdbs = [hopts[g].make_device_batch(ha[g * ph:(g + 1) * ph], np.arange(ph + 1) * K, hr[g * ph * K:(g + 1) * ph * K], None, 0,
                                                        want_iters=True) for g in range(Gh)]
+                    for db_ in hdbs:
+                        db_.use_row_pitch()
                     for tag in ("id_order", "hinted"):
                         if tag == "hinted":
                             for g in range(Gh):
-                                hdbs[g].update_order(iters=prev_t[g * ph:(g + 1) * ph])
+                                hdbs[g].set_hint([prev_t[g * ph:(g + 1) * ph]])
                         torch.cuda.synchronize(dev)
                         for rep_ in range(105):
                             if rep_ == 5:
@@ -995,7 +1018,7 @@ def main():
                         "qp_per_s_one_launch": N / hms["one_launch", "hinted"] * 1e3,
                         "mean_active_set_iterations": float(hit[:, 0].mean()), "mean_active_rows": float(hit[:, 3].mean()),
                         "note": "every agent has >= 5 active rows at its solution; launched in the order of the iteration counts the same "
-                                "agents had one replanning step earlier (dlscqp_launch_order_device), in the headline's groups; the "
+                                "agents had one replanning step earlier (dlscqp_device_batch.hint_iters), in the headline's groups; the "
                                 "one_launch figures are rounds 1-2's shape (one launch of all agents per step)"}
             closed = closed_loop_latency(local_rank)
         line = {
@@ -1031,10 +1054,14 @@ def main():
                              "while the next step plans the agents without remote neighbours (all of them here)"
                              if head_pipelined else "one RCCL all-gather of control points, sub-goal and status per step, after the launch"),
                 "exchange_modes_ms_per_step": exch,
-                "launch_order": "iteration counts of the three previous replanning steps (the other batches of the rotation, never the "
-                                "batch's own), maximum with decay 3/4 per step, descending, sorted on the device after every step "
-                                "inside the timed loop (dlscqp_launch_order_history_device); correlation of consecutive steps' "
-                                "counts %.2f" % hint_corr,
+                "launch_order": "found by the plan kernel itself (dlscqp_device_batch.hint_iters): iteration counts of the three previous "
+                                "replanning steps (the other batches of the rotation, never the batch's own), maximum with decay 3/4 per "
+                                "step, in eight classes; slot s plans the (s / n_blocks)-th most expensive agent of the block of 64 agents "
+                                "s %% n_blocks -- no sort kernel, no stream operation between two launches; correlation of consecutive "
+                                "steps' counts %.2f" % hint_corr,
+                "ms_per_step_sorted_on_device": None if args.headline_only else el_sorted / side_steps * 1e3,
+                "sorted_on_device": "round 3's method: the same key sorted by dlscqp_launch_order_history_device after every step (two "
+                                    "more kernels per group and step, inside the timed loop)",
                 "ms_per_step_host_order": None if args.headline_only else el_hostorder / side_steps * 1e3,
                 "host_order": "the same hint as permutations prepared on the host before the timed loop (round 1's method)",
                 "ms_per_step_no_order_hint": None if args.headline_only else el_nohint / side_steps * 1e3,
@@ -1063,11 +1090,16 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None if traffic is None else traffic * G_used, "traffic_source": traffic_src,
                 "valu_issue_frac": valu_frac,
                 "kernel": prof.get("kernel", "dlscqp_plan_kernel"), "avg_kernel_ms": avg_kernel_s * 1e3,
-                "algorithmic_bytes_per_qp": bytes_qp, "qp_per_launch": per_launch, "concurrent_launches": G_used,
+                "algorithmic_bytes_per_qp": bytes_qp, "qp_per_launch": per_launch, "launches_per_step": G_used,
                 "achieved_one_launch": per_launch * bytes_qp / avg_kernel_s / 1e9,
-                "note": "achieved = algorithmic bytes (SURVEY.md 8d) x agents per launch x launches running side by side (one per swarm "
-                        "group, each on its stream) / average launch duration by HIP events on the launch streams over the timed region; "
-                        "traffic likewise (per launch x concurrent launches); ~5 KB per QP can never load the HBM roof (SURVEY.md 8d)",
+                "achieved_if_launches_overlapped_fully": achieved_if_overlapped,
+                "effective_concurrency": G_used * avg_kernel_s / step_s,
+                "note": "achieved = algorithmic bytes (SURVEY.md 8d) of all agents of a step / ms_per_step -- the step's own clock, "
+                        "as `value`; achieved_one_launch = one launch's bytes / its average duration (HIP events on the launch "
+                        "streams over the timed region); achieved_if_launches_overlapped_fully = that x launches_per_step (round 3 "
+                        "reported this as `achieved`; the launches of different groups overlap only partly: effective_concurrency); "
+                        "traffic = PMC bytes per launch x launches_per_step; valu_issue_frac = VALU instructions of a step x 4 cycles / "
+                        "(1 024 SIMDs x ms_per_step x 2.4 GHz); ~5 KB per QP can never load the HBM roof (SURVEY.md 8d)",
             },
         }
         if not args.no_cpu_baseline and not args.headline_only and world == 1:

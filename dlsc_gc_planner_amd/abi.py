@@ -119,6 +119,9 @@ class DeviceBatch(C.Structure):
         ("agent_order", C.c_void_p),
         ("debug_stamps", C.c_void_p),
         ("row_counts", C.c_void_p),
+        ("row_pitch", C.c_int32),
+        ("hint_steps", C.c_int32),
+        ("hint_iters", C.c_void_p * 3),
     ]
 
 
@@ -340,6 +343,9 @@ def load_library():
     lib.dlscqp_launch_order_device.restype = C.c_int
     lib.dlscqp_launch_order_history_device.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp]
     lib.dlscqp_launch_order_history_device.restype = C.c_int
+    if hasattr(lib, "dlscqp_hint_order_preview_device"):
+        lib.dlscqp_hint_order_preview_device.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp]
+        lib.dlscqp_hint_order_preview_device.restype = C.c_int
     _LIB = lib
     return lib
 
@@ -351,4 +357,5 @@ EXPORTED_SYMBOLS = [
     "dlscqp_get_kernel_times", "dlscqp_world_create", "dlscqp_world_destroy", "dlscqp_generate_sfc_device",
     "dlscqp_advance_device", "dlscqp_waypoint_trap_device", "dlscqp_mapf_create", "dlscqp_mapf_destroy", "dlscqp_mapf_step",
     "dlscqp_launch_order_device", "dlscqp_launch_order_history_device", "dlscqp_neighbours_device", "dlscqp_selftest",
+    "dlscqp_hint_order_preview_device",
 ]

@@ -7,6 +7,8 @@
 // gi_core.hpp; this file supplies the wave primitives, the launch and the host marshalling.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -280,10 +282,48 @@ struct KernelArgs {
     int32_t *out_status;
     int32_t *out_iters;
     const int32_t *order;            // optional launch permutation
+    const int32_t *hint[3];          // launch order found by the wavefront itself (hinted_agent): out_iters of up to three previous steps
+    int n_blocks;                    // blocks of 64 consecutive agents, (n_agents + 63) / 64
+    unsigned int blocks_magic;       // ceil(2^32 / n_blocks) where slot / n_blocks = umulhi(slot, magic) for every slot of the launch, else 0
+    int row_pitch;                   // > 0: agent a's rows start at a * row_pitch (row_offsets is not read)
     unsigned long long *out_stamps;  // [n_agents][12], diagnostic build only
     unsigned char *work;             // HBM working sets [n_agents][work_stride] of the WS_HBM kernel, else null
     size_t work_stride;
 };
+
+// dlscqp_device_batch.hint_iters: the launch order without a sort between two launches.  The agents in blocks of 64 consecutive
+// ids; slot s belongs to block s % n_blocks and plans the agent of rank s / n_blocks among the block's agents, most expensive
+// first.  "Expensive" is the key of dlscqp_launch_order_history_device -- max_k (3/4)^k iterations_k over the previous steps --
+// in eight classes (0, 1, 2-3, 4-7, ..., 64 and more iterations); ties by id.  Lane l holds the key of agent 64 block + l: eight
+// ballots give the class sizes, the class the rank falls into and, inside it, the lane (v_mbcnt).  Every wavefront of a
+// workgroup computes the same answer from the same data.  Returns -1 for a slot beyond the block's agents (a last block of
+// fewer than 64).
+__device__ __forceinline__ int hinted_agent(const KernelArgs &a, int slot, int lane) {
+    const int nb = a.n_blocks;
+    const int rank = a.blocks_magic ? (int)__umulhi((unsigned int)slot, a.blocks_magic) : slot / nb;
+    const int blk = slot - rank * nb;
+    const int idx = blk * 64 + lane;
+    const bool valid = idx < a.n_agents;
+    const size_t ic = (size_t)(valid ? idx : a.n_agents - 1) * 4;
+    int it = a.hint[0][ic];
+    if (a.hint[1]) { const int v = (3 * a.hint[1][ic]) / 4; it = v > it ? v : it; }   // uniform branches
+    if (a.hint[2]) { const int v = (9 * a.hint[2][ic]) / 16; it = v > it ? v : it; }
+    int cls = it <= 0 ? 0 : 32 - __clz(it);  // 0 | 1 | 2-3 | 4-7 | ...
+    cls = cls > 7 ? 7 : cls;
+    int left = rank, pick = -1;  // wave-uniform from here on
+#pragma unroll
+    for (int c = 7; c >= 0; c--) {
+        const unsigned long long m = __ballot(valid && cls == c);
+        const int cnt = __popcll(m);
+        if (pick < 0 && left < cnt) {
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+            const unsigned long long hit = __ballot(((m >> lane) & 1ull) != 0ull && below == left);  // exactly one lane
+            pick = __builtin_ctzll(hit);
+        }
+        left -= pick < 0 ? cnt : 0;
+    }
+    return pick < 0 ? -1 : blk * 64 + pick;
+}
 
 // Two wavefronts per SIMD (256 VGPRs each) where eight agents fit the LDS of a CU; where the working set allows two or three
 // agents per CU anyway (the static shapes with reduced dimension above 64, and the 2-D M = 10 shape with its 54 KB) one
@@ -319,10 +359,13 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
     unsigned char *smem;
     if constexpr (WS == WS_HBM) smem = a.work + (size_t)slot * a.work_stride;
     else smem = lds;
-    const int ag = a.order ? a.order[slot] : slot;
-    if (ag < 0 || ag >= a.n_agents) return;  // the whole workgroup
     WaveGpu w;
     w.lane = (int)threadIdx.x & 63;
+    const int ag = a.order ? a.order[slot] : (a.hint[0] ? hinted_agent(a, slot, w.lane) : slot);
+    if (ag < 0 || ag >= a.n_agents) return;  // the whole workgroup
+    // the agent's rows: [rb, rb + nrows_ag)
+    const int rb = a.row_pitch > 0 ? ag * a.row_pitch : a.row_offsets[ag];
+    const int nrows_ag = a.row_counts ? a.row_counts[ag] : (a.row_pitch > 0 ? a.row_pitch : a.row_offsets[ag + 1] - rb);
     if constexpr (WPA > 1) {
         static_assert(WS == WS_LDS, "the helpers' mailbox is in LDS");
         w.nw = WPA;
@@ -330,7 +373,7 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
         const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);  // wave-uniform, and known to be
         if (wave > 0) {
             // ---- helper wavefront: price a share of the cold rows whenever the planning wavefront opens a pass -------------
-            const int rb = a.row_offsets[ag], K = (a.row_counts ? a.row_counts[ag] : a.row_offsets[ag + 1] - rb);
+            const int K = nrows_ag;
             const int Kc = K < 64 * KU ? K : 64 * KU;
             const dlscqp_agent *agp = a.agents + ag;
             ColdRows c;
@@ -377,10 +420,9 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
     unsigned long long tl0;
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tl0)::"memory");
 #endif
-    const int rb = a.row_offsets[ag], re = a.row_counts ? rb + a.row_counts[ag] : a.row_offsets[ag + 1];
     const int M = kp.M, n1 = kp.n1;
     const size_t xs = (size_t)kp.dim * M * n1 + (size_t)M * a.max_slack_obs;
-    plan_agent<RC, DIMS, FS, MS, KU, SU, SLK, WaveGpu>(w, kp, lay, smem, a.agents + ag, a.rows, rb, re - rb,
+    plan_agent<RC, DIMS, FS, MS, KU, SU, SLK, WaveGpu>(w, kp, lay, smem, a.agents + ag, a.rows, rb, nrows_ag,
                a.sfc ? a.sfc + (size_t)ag * M * 6 : nullptr, a.max_slack_obs, a.do_goal, a.do_traj,
                a.out_goal ? a.out_goal + (size_t)ag * 3 : nullptr,
                a.out_goal_status ? a.out_goal_status + ag : nullptr,
@@ -707,6 +749,7 @@ KernelChoice select_kernel(const KParams &kp, int max_slack_obs, int kmax, bool 
 }
 
 thread_local std::string g_last_error;
+struct NcclId { char internal[128]; };  // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES), passed by value to ncclCommInitRank
 
 bool hip_ok(hipError_t e, const char *what) {
     if (e == hipSuccess) return true;
@@ -738,6 +781,7 @@ struct dlscqp_ctx {
     int *d_order_scratch = nullptr;  // dlscqp_launch_order_device: 64 counts + 64 cursors
     void *work = nullptr;  // working sets of the WS_HBM kernel
     int force_instance = 0;  // dlscqp_selftest: 1 = the runtime-shape instantiation, 2 = its variant with the working set in HBM
+    int force_build = 0;     // dlscqp_selftest: 1 = the standard build of the instantiation, 2 = its WIDE build, 3 = the build with helper wavefronts
     int32_t *nbr_scratch = nullptr;  // dlscqp_neighbours_device: cell counts / starts, agents' cells and slots, agents by cell
     size_t nbr_scratch_ints = 0;
     size_t work_bytes = 0;
@@ -927,7 +971,7 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         kc = KernelChoice{dlscqp_plan_kernel_hbm, DQ_ID_HBM, DQ_G2_KU, DQ_G2_SU, false};
         lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, false);
         a.work_stride = ((size_t)lay.bytes + 255) & ~(size_t)255;
-        const size_t need = a.work_stride * (size_t)b->n_agents;
+        const size_t need = a.work_stride * (size_t)(64 * ((b->n_agents + 63) / 64));  // one per launch slot (hint_iters: 64 per block)
         if (need > c->work_bytes) {
             HIP_TRY(hipDeviceSynchronize());
             if (c->work) (void)hipFree(c->work);
@@ -941,6 +985,24 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
     a.n_agents = b->n_agents;
     a.slot0 = b->launch_count > 0 ? b->launch_offset : 0;
     a.n_slots_launch = b->launch_count > 0 ? b->launch_count : b->n_agents;
+    // launch order found inside the kernel (dlscqp_device_batch.hint_iters): slots are (rank, block) pairs, 64 per block
+    a.hint[0] = a.hint[1] = a.hint[2] = nullptr;
+    a.n_blocks = (b->n_agents + 63) / 64;
+    a.blocks_magic = 0;
+    if (b->hint_steps != 0 && !b->agent_order) {
+        if (b->hint_steps < 0 || b->hint_steps > 3 || !b->hint_iters[0]) { g_last_error = "hint_iters: one to three steps of iteration counts"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+        if (b->launch_count > 0) { g_last_error = "hint_iters cannot be combined with launch_offset / launch_count"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+        for (int k = 0; k < b->hint_steps; k++) {
+            if (!b->hint_iters[k]) { g_last_error = "hint_iters: null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+            a.hint[k] = b->hint_iters[k];
+        }
+        a.n_slots_launch = 64 * a.n_blocks;
+        // slot / n_blocks as one multiplication where that is exact: slot * n_blocks < 2^32 for every slot of the launch
+        if (a.n_blocks > 1 && (unsigned long long)a.n_slots_launch * (unsigned long long)a.n_blocks < (1ull << 32))
+            a.blocks_magic = (unsigned int)(((1ull << 32) + (unsigned long long)a.n_blocks - 1) / (unsigned long long)a.n_blocks);
+    }
+    a.row_pitch = b->row_pitch > 0 ? b->row_pitch : 0;
+    if (a.row_pitch > 0 && (long long)a.row_pitch * (long long)b->n_agents >= (1ll << 31)) { g_last_error = "row_pitch * n_agents exceeds 2^31 rows"; return DLSCQP_ERR_INVALID_ARGUMENT; }
     // Helper wavefronts where an agent has rows beyond the planning wavefront's register cache AND the launch is so small that
     // one wavefront per agent leaves most SIMDs of the chip without work (at most two agents per CU): measured on one MI355X,
     // LP + QP launch of the empty60 mission (60 agents x 1 593 rows) 0.053 -> 0.038 ms; a 2 048-agent crowd, whose agents
@@ -948,14 +1010,22 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
     static const char *wpa_env = getenv("DLSCQP_WPA");  // tests: "1" = never, "4" = whenever the instantiation has the build
     bool wpa = !ws_hbm && kc.fn_wpa && b->max_rows_per_agent > 64 * kc.KU && a.n_slots_launch <= DQ_WPA_MAX_SLOTS;
     if (wpa_env) wpa = !ws_hbm && kc.fn_wpa && wpa_env[0] != '1';
-    const bool wide = !wpa && kc.fn_wide && a.n_slots_launch <= DQ_WIDE_MAX_SLOTS;
+    bool wide = !wpa && kc.fn_wide && a.n_slots_launch <= DQ_WIDE_MAX_SLOTS;
+    // dlscqp_selftest pins the build: the one a launch of thousands of agents gets (two wavefronts per SIMD: the tightest register
+    // budget), the WIDE one, the one with helper wavefronts -- whatever the size of its own two-agent launch would pick
+    if (c->force_build == 1) { wpa = false; wide = false; }
+    else if (c->force_build == 2) { wpa = false; wide = kc.fn_wide != nullptr; }
+    else if (c->force_build == 3) { wpa = !ws_hbm && kc.fn_wpa != nullptr; wide = !wpa && wide; }
     kernel_t kfn = wpa ? kc.fn_wpa : (wide ? kc.fn_wide : kc.fn);
     const int attr_slot = kc.id + (wpa ? 2 * (DQ_N_INSTANCES + 1) : (wide ? DQ_N_INSTANCES + 1 : 0));
     if (!ws_hbm && lay.bytes > c->max_dyn_lds[attr_slot]) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
         c->max_dyn_lds[attr_slot] = lay.bytes;
     }
-    if (a.slot0 < 0 || a.slot0 + a.n_slots_launch > b->n_agents) { g_last_error = "launch slots out of range"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (a.slot0 < 0 || a.slot0 + a.n_slots_launch > 64 * a.n_blocks || (!a.hint[0] && a.slot0 + a.n_slots_launch > b->n_agents)) {
+        g_last_error = "launch slots out of range";
+        return DLSCQP_ERR_INVALID_ARGUMENT;
+    }
     a.max_slack_obs = b->max_slack_obs;
     a.do_goal = b->do_goal;
     a.do_traj = b->do_traj;
@@ -993,7 +1063,7 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
 extern "C" int dlscqp_plan_batch_device(dlscqp_ctx *c, const dlscqp_device_batch *b, void *stream) {
     g_last_error.clear();
     if (!c || !b) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
-    if (!b->agents || !b->row_offsets || !b->out_status) { g_last_error = "null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (!b->agents || (!b->row_offsets && b->row_pitch <= 0) || !b->out_status) { g_last_error = "null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
     (void)hipSetDevice(c->cfg.device);
     // the caller's stream exactly as given: NULL is the HIP null stream (e.g. torch's default stream), not the
     // context's private stream -- launching elsewhere would race with the caller's stream-ordered work
@@ -1398,6 +1468,38 @@ static int order_launch(dlscqp_ctx *c, const OrderHist &iters, int32_t n_agents,
     return DLSCQP_SUCCESS;
 }
 
+// What hinted_agent() answers for every launch slot, written out: the permutation a launch with these hint_iters uses (tests,
+// diagnostics).  order_out[64 * n_blocks]: the agent of slot s, or -1 for a slot beyond its block's agents.
+namespace {
+__global__ __launch_bounds__(64) void dlscqp_hint_preview_kernel(KernelArgs a, int32_t *order_out) {
+    const int slot = (int)blockIdx.x;
+    const int ag = hinted_agent(a, slot, (int)threadIdx.x);
+    if (threadIdx.x == 0) order_out[slot] = ag;
+}
+}  // namespace
+
+extern "C" int dlscqp_hint_order_preview_device(dlscqp_ctx *c, const int32_t *const *iters, int32_t n_steps, int32_t n_agents, int32_t *order_out,
+                                                void *stream) {
+    g_last_error.clear();
+    if (!c || !iters || n_steps < 1 || n_steps > 3 || n_agents < 0 || (n_agents > 0 && !order_out)) { g_last_error = "invalid argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (n_agents == 0) return DLSCQP_SUCCESS;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    KernelArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.n_agents = n_agents;
+    for (int k = 0; k < n_steps; k++) {
+        if (!iters[k]) { g_last_error = "null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+        a.hint[k] = iters[k];
+    }
+    a.n_blocks = (n_agents + 63) / 64;
+    const int slots = 64 * a.n_blocks;
+    if (a.n_blocks > 1 && (unsigned long long)slots * (unsigned long long)a.n_blocks < (1ull << 32))
+        a.blocks_magic = (unsigned int)(((1ull << 32) + (unsigned long long)a.n_blocks - 1) / (unsigned long long)a.n_blocks);
+    hipLaunchKernelGGL(dlscqp_hint_preview_kernel, dim3(slots), dim3(64), 0, (hipStream_t)stream, a, order_out);
+    HIP_TRY(hipGetLastError());
+    return DLSCQP_SUCCESS;
+}
+
 // ---------------------------------------------------------------------------------------------
 // between two launches (include/dlscqp.h: dlscqp_advance)
 // ---------------------------------------------------------------------------------------------
@@ -1708,10 +1810,14 @@ extern "C" int dlscqp_selftest(dlscqp_ctx *c) {
     const float wall = (float)(0.08 * horizon);
     dlscqp_agent ag[2];
     std::memset(ag, 0, sizeof ag);
+    // (inside any world and any communication range: agent 1 a quarter of the world's width aside at most, the waypoints within
+    // half the communication range of the start -- the rows of traj_optimizer.cpp:490-513 would cut the problem off otherwise)
+    const float aside = (float)std::min(0.5, 0.25 * std::max(0.0, c->cfg.world_max[1] - c->cfg.world_min[1]));
     for (int a = 0; a < 2; a++) {
-        ag[a].position[0] = x0; ag[a].position[1] = y0 + (a ? 0.5f : 0.0f); ag[a].position[2] = z;
+        ag[a].position[0] = x0; ag[a].position[1] = y0 + (a ? aside : 0.0f); ag[a].position[2] = z;
         ag[a].velocity[0] = 0.2f;
-        const float reach = (float)(0.45 * horizon);
+        float reach = (float)(0.45 * horizon);
+        if (c->cfg.communication_range > 0) reach = std::min(reach, (float)(0.8 * c->cfg.communication_range));  // waypoint at reach / 2
         ag[a].current_goal_point[0] = x0 + reach; ag[a].current_goal_point[1] = ag[a].position[1]; ag[a].current_goal_point[2] = z;
         ag[a].next_waypoint[0] = x0 + 0.5f * reach; ag[a].next_waypoint[1] = ag[a].position[1]; ag[a].next_waypoint[2] = z;
         ag[a].id = a; ag[a].n_obs = a == 0 ? 1 : 0; ag[a].n_slack_obs = 0;
@@ -1746,20 +1852,28 @@ extern "C" int dlscqp_selftest(dlscqp_ctx *c) {
                                 {"working set in HBM", 1, 1000, 2}};
     const size_t cs = (size_t)3 * M * n1;
     std::vector<float> ref;
-    for (const Variant &v : variants) {
+    // every BUILD of every instantiation: the standard one (what a launch of more than a thousand agents runs: two wavefronts per
+    // SIMD, the tightest register budget), the WIDE one and the one with helper wavefronts (an instantiation that has no such
+    // build runs its standard one again: a few microseconds)
+    static const char *const builds[] = {"", "standard build", "WIDE build", "build with helper wavefronts"};
+    for (const Variant &v : variants)
+    for (int build = 1; build <= 3; build++) {
+        if (v.force == 2 && build > 1) continue;  // the HBM working set has one build
         std::vector<float> ctrl(2 * cs, 0.0f);
         std::vector<double> cost(2, 0.0), slack(2, 0.0);
         int32_t st[2] = {-99, -99};
         c->force_instance = v.force;
+        c->force_build = build;
         const int rc = plan_host(c, 2, ag, ro, rows.data(), sfc.empty() ? nullptr : sfc.data(), v.slack_obs, 0, 1, nullptr, nullptr, ctrl.data(),
                                  cost.data(), slack.data(), st, v.declared_rows);
         c->force_instance = 0;
+        c->force_build = 0;
         if (rc == DLSCQP_ERR_UNSUPPORTED) continue;  // a shape this build has no such instantiation for
         if (rc != DLSCQP_SUCCESS) { g_last_error = std::string("selftest (") + v.name + "): " + g_last_error; return rc; }
         auto fail = [&](const char *what, int a, double val) {
             char buf[256];
-            std::snprintf(buf, sizeof buf, "selftest failed (%s): %s (agent %d, %.3g) -- this build of libdlscqp does not plan correctly on this "
-                          "machine; rebuild with the flags of __graft_entry__.py", v.name, what, a, val);
+            std::snprintf(buf, sizeof buf, "selftest failed (%s, %s): %s (agent %d, %.3g) -- this build of libdlscqp does not plan correctly on this "
+                          "machine; rebuild with the flags of __graft_entry__.py", v.name, builds[build], what, a, val);
             g_last_error = buf;
             return DLSCQP_ERR_SELFTEST;
         };
@@ -1798,6 +1912,268 @@ extern "C" int dlscqp_selftest(dlscqp_ctx *c) {
             for (size_t j = 0; j < ctrl.size(); j++)
                 if (std::fabs((double)ctrl[j] - (double)ref[j]) > 1e-6) return fail("differs from the first instantiation's plan", (int)(j / cs), (double)ctrl[j] - (double)ref[j]);
         }
+    }
+    return DLSCQP_SUCCESS;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the exchange of the solved plans and one call per replanning step (include/dlscqp.h: dlscqp_exchange_*, dlscqp_step_device)
+// ---------------------------------------------------------------------------------------------
+// librccl is loaded when the first exchange is created, not linked: a process that never shards its agents needs no RCCL,
+// and a process that already holds one (torch bundles its own) keeps exactly that one.
+namespace {
+struct RcclApi {
+    void *handle = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, NcclId, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+bool load_rccl() {
+    if (g_rccl.handle) return true;
+    const char *names[] = {std::getenv("DLSCQP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void *h = nullptr;
+    for (const char *n : names)  // a copy that is already in the process first (RTLD_NOLOAD), then by name
+        if (n && n[0] && (h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
+    if (!h)
+        for (const char *n : names)
+            if (n && n[0] && (h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!h) { g_last_error = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "?"); return false; }
+    RcclApi a;
+    a.handle = h;
+    a.GetUniqueId = reinterpret_cast<int (*)(void *)>(dlsym(h, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<int (*)(void **, int, NcclId, int)>(dlsym(h, "ncclCommInitRank"));
+    a.AllGather = reinterpret_cast<int (*)(const void *, void *, size_t, int, void *, hipStream_t)>(dlsym(h, "ncclAllGather"));
+    a.CommDestroy = reinterpret_cast<int (*)(void *)>(dlsym(h, "ncclCommDestroy"));
+    a.GetErrorString = reinterpret_cast<const char *(*)(int)>(dlsym(h, "ncclGetErrorString"));
+    if (!a.GetUniqueId || !a.CommInitRank || !a.AllGather || !a.CommDestroy) { g_last_error = "librccl lacks the ncclAllGather entry points"; return false; }
+    g_rccl = a;
+    return true;
+}
+bool rccl_ok(int rc, const char *what) {
+    if (rc == 0) return true;
+    g_last_error = std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
+    return false;
+}
+
+// one record per agent: control points, sub-goal, verdict (the int32's bits) -- E + 4 floats
+__global__ __launch_bounds__(128) void dlscqp_pack_kernel(const float *ctrl, const float *goal, const int32_t *status, float *rec, int n, int E) {
+    const int a = (int)blockIdx.x;
+    if (a >= n) return;
+    const int W = E + 4;
+    float *o = rec + (size_t)a * W;
+    for (int j = (int)threadIdx.x; j < W; j += 128) {
+        float v;
+        if (j < E) v = ctrl[(size_t)a * E + j];
+        else if (j < E + 3) v = goal[(size_t)a * 3 + (j - E)];
+        else v = __int_as_float(status[a]);
+        o[j] = v;
+    }
+}
+}  // namespace
+
+struct dlscqp_exchange {
+    int device = 0, rank = 0, world = 1, n_local = 0, E = 0, W = 0, local_only = 0;
+    void *comm = nullptr;                    // ncclComm_t
+    hipStream_t comm_stream = nullptr, join_stream = nullptr;
+    float *send[2] = {nullptr, nullptr}, *recv[2] = {nullptr, nullptr};
+    hipEvent_t ready[2] = {nullptr, nullptr}, packed[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+    bool posted[2] = {false, false};
+    long long k = 0;                         // exchanges posted so far
+    int last = -1;
+    std::vector<hipEvent_t> planned;         // dlscqp_step_device: one per group
+    hipEvent_t table_ready = nullptr;        // serial mode of dlscqp_step_device
+    bool have_table_ready = false;
+    // timing (dlscqp_exchange_set_timing): per exchange t0 (communication stream reached the pack), packed, gathered; ready is the compute side
+    std::vector<hipEvent_t> tev;             // 4 per exchange: ready, t0, packed, done
+    int t_cap = 0, t_used = 0;
+};
+
+extern "C" int dlscqp_exchange_unique_id(void *id_out) {
+    g_last_error.clear();
+    if (!id_out) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (!load_rccl()) return DLSCQP_ERR_UNSUPPORTED;
+    if (!rccl_ok(g_rccl.GetUniqueId(id_out), "ncclGetUniqueId")) return DLSCQP_ERR_HIP;
+    return DLSCQP_SUCCESS;
+}
+
+extern "C" void dlscqp_exchange_destroy(dlscqp_exchange *x) {
+    if (!x) return;
+    (void)hipSetDevice(x->device);
+    if (x->comm_stream) (void)hipStreamSynchronize(x->comm_stream);
+    if (x->join_stream) (void)hipStreamSynchronize(x->join_stream);
+    if (x->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(x->comm);
+    for (int b = 0; b < 2; b++) {
+        if (x->send[b]) (void)hipFree(x->send[b]);
+        if (x->recv[b]) (void)hipFree(x->recv[b]);
+        if (x->ready[b]) (void)hipEventDestroy(x->ready[b]);
+        if (x->packed[b]) (void)hipEventDestroy(x->packed[b]);
+        if (x->done[b]) (void)hipEventDestroy(x->done[b]);
+    }
+    for (auto e : x->planned) (void)hipEventDestroy(e);
+    for (auto e : x->tev) (void)hipEventDestroy(e);
+    if (x->table_ready) (void)hipEventDestroy(x->table_ready);
+    if (x->comm_stream) (void)hipStreamDestroy(x->comm_stream);
+    if (x->join_stream) (void)hipStreamDestroy(x->join_stream);
+    delete x;
+}
+
+extern "C" int dlscqp_exchange_create(dlscqp_ctx *c, const dlscqp_exchange_config *cfg, dlscqp_exchange **out) {
+    g_last_error.clear();
+    if (!c || !cfg || !out) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (cfg->world < 1 || cfg->rank < 0 || cfg->rank >= cfg->world || cfg->n_local < 1) { g_last_error = "rank / world / n_local out of range"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (cfg->local_only && cfg->world != 1) { g_last_error = "local_only needs world == 1"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (cfg->world > 1 && !cfg->unique_id) { g_last_error = "unique_id: the 128 bytes of rank 0's dlscqp_exchange_unique_id"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    dlscqp_exchange *x = new dlscqp_exchange();
+    x->device = c->cfg.device;
+    x->rank = cfg->rank; x->world = cfg->world; x->n_local = cfg->n_local; x->local_only = cfg->local_only;
+    x->E = c->M * (c->n + 1) * 3;
+    x->W = x->E + 4;
+    auto fail = [&](int rc) { const std::string why = g_last_error; dlscqp_exchange_destroy(x); g_last_error = why; return rc; };
+    if (!x->local_only) {
+        if (!load_rccl()) return fail(DLSCQP_ERR_UNSUPPORTED);
+        NcclId id;
+        if (cfg->unique_id) std::memcpy(&id, cfg->unique_id, sizeof id);
+        else if (!rccl_ok(g_rccl.GetUniqueId(&id), "ncclGetUniqueId")) return fail(DLSCQP_ERR_HIP);
+        if (!rccl_ok(g_rccl.CommInitRank(&x->comm, cfg->world, id, cfg->rank), "ncclCommInitRank")) return fail(DLSCQP_ERR_HIP);
+    }
+    // the communication stream at the highest priority: the collective's few workgroups share the GPU with the plan kernel of
+    // the next step and should get the first free slots
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&x->comm_stream, hipStreamNonBlocking, hi) != hipSuccess) { g_last_error = "hipStreamCreateWithPriority"; return fail(DLSCQP_ERR_HIP); }
+    if (hipStreamCreateWithFlags(&x->join_stream, hipStreamNonBlocking) != hipSuccess) { g_last_error = "hipStreamCreate"; return fail(DLSCQP_ERR_HIP); }
+    const size_t sb = (size_t)x->n_local * x->W * sizeof(float), rb = sb * (size_t)x->world;
+    for (int b = 0; b < 2; b++) {
+        if (hipMalloc((void **)&x->send[b], sb) != hipSuccess || hipMalloc((void **)&x->recv[b], rb) != hipSuccess) { g_last_error = "hipMalloc(exchange buffers)"; return fail(DLSCQP_ERR_HIP); }
+        if (hipEventCreateWithFlags(&x->ready[b], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&x->packed[b], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&x->done[b], hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate"; return fail(DLSCQP_ERR_HIP); }
+    }
+    if (hipEventCreateWithFlags(&x->table_ready, hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate"; return fail(DLSCQP_ERR_HIP); }
+    *out = x;
+    return DLSCQP_SUCCESS;
+}
+
+extern "C" int dlscqp_exchange_set_timing(dlscqp_exchange *x, int32_t capacity) {
+    g_last_error.clear();
+    if (!x || capacity < 0) return DLSCQP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(x->device));
+    HIP_TRY(hipStreamSynchronize(x->comm_stream));
+    while ((int)x->tev.size() < 4 * capacity) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        x->tev.push_back(e);
+    }
+    x->t_cap = capacity;
+    x->t_used = 0;
+    return DLSCQP_SUCCESS;
+}
+
+extern "C" int dlscqp_exchange_get_times(dlscqp_exchange *x, float *pack_ms, float *all_gather_ms, float *lag_ms, int32_t capacity, int32_t *n_out) {
+    g_last_error.clear();
+    if (!x || !n_out) return DLSCQP_ERR_INVALID_ARGUMENT;
+    HIP_TRY(hipSetDevice(x->device));
+    const int n = std::min<int>(x->t_used, capacity);
+    for (int i = 0; i < n; i++) {
+        hipEvent_t *e = &x->tev[4 * (size_t)i];
+        HIP_TRY(hipEventSynchronize(e[3]));
+        if (pack_ms) HIP_TRY(hipEventElapsedTime(&pack_ms[i], e[1], e[2]));
+        if (all_gather_ms) HIP_TRY(hipEventElapsedTime(&all_gather_ms[i], e[2], e[3]));
+        if (lag_ms) HIP_TRY(hipEventElapsedTime(&lag_ms[i], e[0], e[3]));
+    }
+    *n_out = n;
+    return DLSCQP_SUCCESS;
+}
+
+extern "C" int dlscqp_exchange_before_overwrite(dlscqp_exchange *x, void *stream) {
+    g_last_error.clear();
+    if (!x) return DLSCQP_ERR_INVALID_ARGUMENT;
+    const int b = (int)(x->k & 1);  // the buffers the NEXT post uses: their previous exchange (post k - 2) read the caller's tensors of then
+    if (x->posted[b]) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, x->packed[b], 0));
+    return DLSCQP_SUCCESS;
+}
+
+extern "C" int dlscqp_exchange_post(dlscqp_exchange *x, const float *ctrl, const float *goal, const int32_t *status, void *ready_stream) {
+    g_last_error.clear();
+    if (!x || !ctrl || !goal || !status) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(hipSetDevice(x->device));
+    const int b = (int)(x->k & 1);
+    x->k++;
+    const bool timed = x->t_used < x->t_cap;
+    hipEvent_t *te = timed ? &x->tev[4 * (size_t)x->t_used] : nullptr;
+    // the communication stream is in order behind exchange k - 2, which used the same buffers
+    HIP_TRY(hipEventRecord(x->ready[b], (hipStream_t)ready_stream));
+    if (timed) HIP_TRY(hipEventRecord(te[0], (hipStream_t)ready_stream));
+    HIP_TRY(hipStreamWaitEvent(x->comm_stream, x->ready[b], 0));
+    if (timed) HIP_TRY(hipEventRecord(te[1], x->comm_stream));
+    hipLaunchKernelGGL(dlscqp_pack_kernel, dim3(x->n_local), dim3(128), 0, x->comm_stream, ctrl, goal, status, x->send[b], x->n_local, x->E);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(x->packed[b], x->comm_stream));
+    if (timed) HIP_TRY(hipEventRecord(te[2], x->comm_stream));
+    if (x->local_only) {
+        HIP_TRY(hipMemcpyAsync(x->recv[b], x->send[b], (size_t)x->n_local * x->W * sizeof(float), hipMemcpyDeviceToDevice, x->comm_stream));
+    } else {
+        if (!rccl_ok(g_rccl.AllGather(x->send[b], x->recv[b], (size_t)x->n_local * x->W, /* ncclFloat32 */ 7, x->comm, x->comm_stream), "ncclAllGather")) return DLSCQP_ERR_HIP;
+    }
+    HIP_TRY(hipEventRecord(x->done[b], x->comm_stream));
+    if (timed) { HIP_TRY(hipEventRecord(te[3], x->comm_stream)); x->t_used++; }
+    x->posted[b] = true;
+    x->last = b;
+    return DLSCQP_SUCCESS;
+}
+
+extern "C" int dlscqp_exchange_wait(dlscqp_exchange *x, void *stream, const float **table_out) {
+    g_last_error.clear();
+    if (!x || x->last < 0) { g_last_error = "no exchange has been posted"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, x->done[x->last], 0));
+    if (table_out) *table_out = x->recv[x->last];
+    return DLSCQP_SUCCESS;
+}
+
+// MultiSyncSimulator::plan + broadcastMsgs (multi_sync_simulator.cpp:516-524, 468-514) for every group of swarms of this rank: ONE
+// call queues the groups' launches of a replanning step on their streams and the exchange of the step's plans behind them.
+extern "C" int dlscqp_step_device(const dlscqp_step_args *s) {
+    g_last_error.clear();
+    if (!s || s->n_groups < 1 || !s->groups) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    dlscqp_exchange *x = s->exchange;
+    const int mode = x ? s->exchange_mode : DLSCQP_EXCHANGE_NONE;
+    if (x && mode != DLSCQP_EXCHANGE_NONE && (!s->ctrl || !s->goal || !s->status)) { g_last_error = "exchange: null output table"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (x) {
+        HIP_TRY(hipSetDevice(x->device));
+        while ((int)x->planned.size() < s->n_groups) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            x->planned.push_back(e);
+        }
+    }
+    for (int g = 0; g < s->n_groups; g++) {
+        const dlscqp_step_group &G = s->groups[g];
+        if (!G.ctx || !G.batch) { g_last_error = "null group"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+        hipStream_t st = (hipStream_t)G.stream;
+        if (mode == DLSCQP_EXCHANGE_PIPELINED) {
+            // the exchange of step k (packing included) runs on the communication stream while step k + 1 writes another table of
+            // the caller's rotation: a launch only waits until the table it is about to overwrite has been packed
+            const int rc = dlscqp_exchange_before_overwrite(x, st);
+            if (rc != DLSCQP_SUCCESS) return rc;
+        } else if (mode == DLSCQP_EXCHANGE_SERIAL && x->have_table_ready) {
+            HIP_TRY(hipStreamWaitEvent(st, x->table_ready, 0));  // the next launch waits for the exchange
+        }
+        const int rc = dlscqp_plan_batch_device(G.ctx, G.batch, G.stream);
+        if (rc != DLSCQP_SUCCESS) return rc;
+        if (mode != DLSCQP_EXCHANGE_NONE) HIP_TRY(hipEventRecord(x->planned[g], st));
+    }
+    if (mode == DLSCQP_EXCHANGE_NONE) return DLSCQP_SUCCESS;
+    for (int g = 0; g < s->n_groups; g++) HIP_TRY(hipStreamWaitEvent(x->join_stream, x->planned[g], 0));
+    int rc = dlscqp_exchange_post(x, s->ctrl, s->goal, s->status, x->join_stream);
+    if (rc != DLSCQP_SUCCESS) return rc;
+    if (mode == DLSCQP_EXCHANGE_SERIAL) {
+        rc = dlscqp_exchange_wait(x, x->join_stream, nullptr);
+        if (rc != DLSCQP_SUCCESS) return rc;
+        HIP_TRY(hipEventRecord(x->table_ready, x->join_stream));
+        x->have_table_ready = true;
     }
     return DLSCQP_SUCCESS;
 }

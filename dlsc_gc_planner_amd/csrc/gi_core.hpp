@@ -193,6 +193,22 @@ DQ_FN int blend_idx(bool cond, int a, int b) {
     return b ^ ((a ^ b) & m);
 }
 
+// cond ? v : 0 by masking the bits (the same reason: a select of a loaded value against zero came out as an EXEC-masked move)
+DQ_FN float keep_f32(bool cond, float v) {
+    uint32_t b;
+    memcpy(&b, &v, 4);
+    b &= (uint32_t)(-(int32_t)cond);
+    memcpy(&v, &b, 4);
+    return v;
+}
+DQ_FN double keep_f64(bool cond, double v) {
+    uint64_t b;
+    memcpy(&b, &v, 8);
+    b &= (uint64_t)(-(int64_t)cond);
+    memcpy(&v, &b, 8);
+    return v;
+}
+
 DQ_FN int ctz64(uint64_t m) { return __builtin_ctzll(m); }
 DQ_FN int popc64(uint64_t m) { return __builtin_popcountll(m); }
 
@@ -403,6 +419,14 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     }
     const double max_vel = agp->max_vel, max_acc = agp->max_acc, radius = agp->radius;
     const double nominal_velocity = agp->nominal_velocity;
+    // the corridor box of the last segment (the goal LP's rows, goal_optimizer.cpp:158-173): read with the record, all six
+    // numbers at once (read where they are used, every one of them was a round trip of its own)
+    float lastbox[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (kp.use_sfc && sfc && do_goal) {
+        const float *lb = sfc + ((MS > 0 ? MS : kp.M) - 1) * 6;
+#pragma unroll
+        for (int t = 0; t < 6; t++) lastbox[t] = lb[t];
+    }
     int nso_rt = agp->n_slack_obs;
     if (nso_rt > max_slack_obs) nso_rt = max_slack_obs;
     if (nso_rt < 0) nso_rt = 0;
@@ -415,61 +439,146 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     const uint32_t *Rkey = rows.key + row_begin;
 
     // ---- LSC rows into registers: lane l owns rows l + 64u (coalesced loads, once) --------------
+    // Every load of every block of 64 is issued here, unconditionally (clamped index: lanes beyond the rows drop the value
+    // below), and NOTHING of it is used before the table reads further down have been issued as well: the rows' trip to HBM
+    // and the tables' trip to L2 overlap.  (With a branch and the selects per block of 64, as this was written before, the
+    // second block's loads waited for the first block's data.)
     RegF cnx[KU], cny[KU], cnz[KU], cpx[KU], cpy[KU], cpz[KU];
     RegD cd[KU];
     RegU ckey[KU];
     const int Kc = ALL_CACHED ? K : (K < 64 * KU ? K : 64 * KU);  // cached rows
+    w.each([&](int l) {
 #pragma unroll
-    for (int u = 0; u < KU; u++) {
-        w.each([&](int l) {
-            cnx[u].at(l) = 0; cny[u].at(l) = 0; cnz[u].at(l) = 0;
-            cpx[u].at(l) = 0; cpy[u].at(l) = 0; cpz[u].at(l) = 0;
-            cd[u].at(l) = 0;
-            ckey[u].at(l) = KEY_SKIP;
-        });
-        if (64 * u < Kc) {  // uniform
-            w.each([&](int l) {
+        for (int u = 0; u < KU; u++) {
+            if (Kc > 0) {  // uniform (an agent without rows may sit at the very end of the arrays: nothing is read for it)
                 const int j = l + 64 * u;
-                const bool in = j < Kc;
-                const int jc = in ? j : Kc - 1;  // clamped: every lane loads, lanes beyond the rows drop the value
-                const float a0 = Rnx[jc], a1 = Rny[jc], a2 = Rnz[jc], b0 = Rpx[jc], b1 = Rpy[jc], b2 = Rpz[jc];
-                const double dd = Rd[jc];
-                const uint32_t kk = Rkey[jc];
-                cnx[u].at(l) = in ? a0 : 0.0f; cny[u].at(l) = in ? a1 : 0.0f; cnz[u].at(l) = in ? a2 : 0.0f;
-                cpx[u].at(l) = in ? b0 : 0.0f; cpy[u].at(l) = in ? b1 : 0.0f; cpz[u].at(l) = in ? b2 : 0.0f;
-                cd[u].at(l) = in ? dd : 0.0;
-                ckey[u].at(l) = in ? kk : KEY_SKIP;
-            });
+                const int jc = j < Kc ? j : Kc - 1;
+                cnx[u].at(l) = Rnx[jc]; cny[u].at(l) = Rny[jc]; cnz[u].at(l) = Rnz[jc];
+                cpx[u].at(l) = Rpx[jc]; cpy[u].at(l) = Rpy[jc]; cpz[u].at(l) = Rpz[jc];
+                cd[u].at(l) = Rd[jc];
+                ckey[u].at(l) = Rkey[jc];
+            } else {
+                cnx[u].at(l) = 0; cny[u].at(l) = 0; cnz[u].at(l) = 0;
+                cpx[u].at(l) = 0; cpy[u].at(l) = 0; cpz[u].at(l) = 0;
+                cd[u].at(l) = 0;
+                ckey[u].at(l) = KEY_SKIP;
+            }
         }
-    }
+    });
+    auto finish_row_loads = [&]() {  // the first use of the rows: lanes beyond the agent's rows hold no row
+        w.each([&](int l) {
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                const bool in = l + 64 * u < Kc;
+                cnx[u].at(l) = keep_f32(in, cnx[u].at(l)); cny[u].at(l) = keep_f32(in, cny[u].at(l)); cnz[u].at(l) = keep_f32(in, cnz[u].at(l));
+                cpx[u].at(l) = keep_f32(in, cpx[u].at(l)); cpy[u].at(l) = keep_f32(in, cpy[u].at(l)); cpz[u].at(l) = keep_f32(in, cpz[u].at(l));
+                cd[u].at(l) = keep_f64(in, cd[u].at(l));
+                ckey[u].at(l) = ckey[u].at(l) | ~(uint32_t)(-(int32_t)in);  // KEY_SKIP = all ones
+            }
+        });
+    };
 
     // ---- structured slots into registers (issued here so that all prologue loads are in flight together)
     const Slot *slots = kp.slots + slot0;
     const int n_slots = ALL_CACHED && n_slots_all > 64 * SU ? 64 * SU : n_slots_all;
     const int Sc = ALL_CACHED ? n_slots : (n_slots < 64 * SU ? n_slots : 64 * SU);  // cached slots
     RegU sidx[SUA], scb[SUA];  // 3 x 10-bit x-space indices (0x3FF = unused) | 3 x int8 coefficients + bsel
+    RegU sraw[SUA][3];         // the slot records as they are read (16 bytes; the fourth word, the row scaling, is not cached)
+    static_assert(sizeof(Slot) == 16, "finish_slot_loads() unpacks the record from its words");
+    w.each([&](int l) {
 #pragma unroll
-    for (int u = 0; u < SU; u++) {
-        {
-            w.each([&](int l) {
-                sidx[u].at(l) = 0xBFFFFFFFu;  // bit 31: no slot in this register
-                scb[u].at(l) = 0;
-            });
-            if (64 * u < Sc) {  // uniform
-                w.each([&](int l) {
-                    const int s = l + 64 * u;
-                    const bool in = s < Sc;
-                    const Slot sl = slots[in ? s : Sc - 1];
-                    const uint32_t pi = (uint32_t)(sl.idx[0] & 0x3FF) | ((uint32_t)(sl.idx[1] & 0x3FF) << 10) |
-                                        ((uint32_t)(sl.idx[2] & 0x3FF) << 20);
-                    const uint32_t pc = (uint32_t)(uint8_t)sl.coef[0] | ((uint32_t)(uint8_t)sl.coef[1] << 8) |
-                                        ((uint32_t)(uint8_t)sl.coef[2] << 16) | ((uint32_t)sl.bsel << 24);
-                    sidx[u].at(l) = in ? pi : 0xBFFFFFFFu;
-                    scb[u].at(l) = in ? pc : 0u;
-                });
+        for (int u = 0; u < SU; u++) {
+            if (Sc > 0) {  // uniform
+                const int s = l + 64 * u;
+                const uint32_t *sw = reinterpret_cast<const uint32_t *>(slots + (s < Sc ? s : Sc - 1));
+                sraw[u][0].at(l) = sw[0]; sraw[u][1].at(l) = sw[1]; sraw[u][2].at(l) = sw[2];
+            } else {
+                sraw[u][0].at(l) = 0; sraw[u][1].at(l) = 0; sraw[u][2].at(l) = 0;
             }
         }
+    });
+    auto finish_slot_loads = [&]() {  // the first use of the slot records (little-endian words of struct Slot)
+        w.each([&](int l) {
+#pragma unroll
+            for (int u = 0; u < SU; u++) {
+                const uint32_t d0 = sraw[u][0].at(l), d1 = sraw[u][1].at(l), d2 = sraw[u][2].at(l);
+                // idx[0] idx[1] | idx[2] coef[0] coef[1] | coef[2] kind bsel
+                const uint32_t pi = (d0 & 0x3FFu) | (((d0 >> 16) & 0x3FFu) << 10) | ((d1 & 0x3FFu) << 20);
+                const uint32_t pc = ((d1 >> 16) & 0xFFu) | (((d1 >> 24) & 0xFFu) << 8) | ((d2 & 0xFFu) << 16) | ((d2 >> 16) << 24);
+                const bool in = l + 64 * u < Sc;
+                const uint32_t m = (uint32_t)(-(int32_t)in);
+                sidx[u].at(l) = (pi & m) | (0xBFFFFFFFu & ~m);  // bit 31: no slot in this register
+                scb[u].at(l) = pc & m;
+            }
+        });
+    };
+
+    // ---- static shapes: the tables of the agent's number of terminal segments T, read AHEAD of the goal LP ------------------
+    // T depends on the sub-goal, which is what the LP is about to compute -- but the LP's answer is the waypoint itself whenever
+    // the waypoint can be reached (t = 0: three of four agent-steps of the reference's logged run), so the tables of
+    // T(waypoint) are requested now, their round trip to L2 runs under the LP's arithmetic, and the few agents whose LP stops
+    // short in a way that changes T read again (uniform branch below).  Every table read of the phase -- x0 factors, pivot
+    // scalings of the rows by kind, of the slots, of the cached LSC rows, the quadratic form of the unconstrained objective -- is
+    // issued before the first use: one exposed round trip instead of one per table, and none when the guess holds.
+    constexpr int NXP = DIMS > 0 ? (DIMS * MS * 6 + 63) / 64 : 1;
+    RegD ciw[KU], siw[SUA], nnr[KU];
+    RegD kiw[NXP][3];  // BYK: pivot scalings of the bound / velocity / acceleration rows of the lane's coordinates
+    RegD xa0[NXP], xa1[NXP], xa2[NXP], xag[NXP];  // x0 = xa0 pos + xa1 vel + xa2 acc + xag goal, per coordinate of the lane
+    double phq[10] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};  // tabPhi of T (uniform)
+    auto terminal_segments = [&](const float *gl) -> int {  // traj_optimizer.cpp:543-551 (float32 point difference)
+        const double ift = f32_norm3(gl[0] - pos[0], gl[1] - pos[1], gl[2] - pos[2]) / nominal_velocity;
+        int Tt = (int)((M * kp.dt - ift + SP_EPSILON) / kp.dt);
+        Tt = Tt < 1 ? 1 : Tt;
+        return Tt > M ? M : Tt;
+    };
+    auto load_tables = [&](int Tt) {
+        const double *tXs = kp.tabX0s + (size_t)(Tt - 1) * P * 3, *tXg = kp.tabX0g + (size_t)(Tt - 1) * P;
+        const double *tSIW = kp.tabSIW + (size_t)(Tt - 1) * kp.n_slots + slot0;
+        const double *tKIW = kp.tabKIW + (size_t)(Tt - 1) * 3 * P;
+        w.each([&](int l) {
+#pragma unroll
+            for (int u = 0; u < NXP; u++) {
+                const int j = 64 * u + l;
+                const int jc = j < nxc ? j : nxc - 1;
+                const int p = jc - (jc / P) * P;
+                xa0[u].at(l) = tXs[p * 3 + 0]; xa1[u].at(l) = tXs[p * 3 + 1]; xa2[u].at(l) = tXs[p * 3 + 2]; xag[u].at(l) = tXg[p];
+                kiw[u][0].at(l) = tKIW[p]; kiw[u][1].at(l) = tKIW[P + p]; kiw[u][2].at(l) = tKIW[2 * P + p];
+            }
+#pragma unroll
+            for (int u = 0; u < SU; u++) {
+                const int s = l + 64 * u;
+                const double v = tSIW[s < Sc ? s : (Sc > 0 ? Sc - 1 : 0)];
+                siw[u].at(l) = s < Sc ? v : 0.0;
+            }
+        });
+        if (kp.phi_ok) {
+            const double *ph = kp.tabPhi + (size_t)(Tt - 1) * 10;
+#pragma unroll
+            for (int j = 0; j < 10; j++) phq[j] = ph[j];
+        }
+    };
+    auto load_row_scalings = [&](int Tt) {  // |N_T[p,:]|^2 of the cached rows' control points: needs the rows' keys
+        const double *tNN = kp.tabNN + (size_t)(Tt - 1) * P;
+        w.each([&](int l) {
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                const uint32_t key = ckey[u].at(l);
+                const bool have = key != KEY_SKIP;
+                int mi = (int)(key & 0xFF) * n1 + (int)((key >> 8) & 0xF);
+                DQ_KEEP(mi);  // computed for every lane, then selected: as one ?: expression this came out as an EXEC-masked region
+                mi = have ? mi : 0;
+                nnr[u].at(l) = tNN[mi < P ? mi : 0];
+            }
+        });
+    };
+    int T_ahead = 0;
+    if (DIMS > 0 && do_traj && !bad_shape) {
+        T_ahead = terminal_segments(do_goal ? wp : cg);
+        load_tables(T_ahead);
     }
+    finish_row_loads();
+    finish_slot_loads();
+    if (DIMS > 0 && do_traj && !bad_shape) load_row_scalings(T_ahead);
 
     // ================================ goal LP ===================================================
     // min t in [0, 1+1e-5] s.t. a_r t + b_r >= 0 (goal_optimizer.cpp:138-198), closed form.
@@ -484,7 +593,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             double t_lo = 0.0, t_hi = 1.0 + SP_EPSILON_FLOAT;
             int infeasible = 0;
             if (kp.use_sfc && sfc) {  // goal_optimizer.cpp:158-173
-                const float *bmin = sfc + (M - 1) * 6, *bmax = bmin + 3;
+                const float *bmin = lastbox, *bmax = lastbox + 3;
                 for (int k = 0; k < dim; k++) {
                     for (int side = 0; side < 2; side++) {
                         double nr = side == 0 ? 1.0 : -1.0;
@@ -569,7 +678,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 // exception branch, goal_optimizer.cpp:54-81
                 int numerical_error = 1;
                 if (kp.use_sfc && sfc) {
-                    const float *bmin = sfc + (M - 1) * 6, *bmax = bmin + 3;
+                    const float *bmin = lastbox, *bmax = lastbox + 3;
                     for (int k = 0; k < 3; k++)
                         if (!((double)cg[k] > (double)bmin[k] - SP_EPSILON_FLOAT &&
                               (double)cg[k] < (double)bmax[k] + SP_EPSILON_FLOAT))
@@ -640,14 +749,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     const int odump_rp = odump - oRp;  // the dump slots as indices of Rp
     const int ozero_rp = odump_rp + 32;  // a zero: where the reads of S below its diagonal go
 
-    // terminal segments, traj_optimizer.cpp:543-551 (float32 point difference)
-    int T;
-    {
-        double ift = f32_norm3(goal[0] - pos[0], goal[1] - pos[1], goal[2] - pos[2]) / nominal_velocity;
-        T = (int)((M * kp.dt - ift + SP_EPSILON) / kp.dt);
-        if (T < 1) T = 1;
-        if (T > M) T = M;
-    }
+    const int T = terminal_segments(goal);  // terminal segments, traj_optimizer.cpp:543-551
     int status = DLSCQP_OK;
     if (!kp.t_valid[T - 1]) status = DLSCQP_NUMERICAL;
     if (nslk > 0 && !(kp.w_s > 0)) status = DLSCQP_NUMERICAL;
@@ -663,64 +765,35 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     const double *tXg = kp.tabX0g + (size_t)(T - 1) * P;
     const double *tNN = kp.tabNN + (size_t)(T - 1) * P;
     const double *tSIW = kp.tabSIW + (size_t)(T - 1) * kp.n_slots + slot0;
-    const double *tKIW = kp.tabKIW + (size_t)(T - 1) * 3 * P;  // [kind][p]: pivot scaling of the bound / velocity / acceleration row at control point p
 
     // ---- unconstrained minimiser and bound table into LDS -------------------------------------------
     // (uniform trip counts; a lane past the end computes a clamped element and stores it to the dump slot)
-    RegD ciw[KU], siw[SUA], nnr[KU];
-    constexpr int NXP = DIMS > 0 ? (DIMS * MS * 6 + 63) / 64 : 1;
-    RegD kiw[NXP][3];  // BYK: pivot scalings of the bound / velocity / acceleration rows of the lane's coordinates
+    double fval0 = 0.0;  // objective of the unconstrained minimiser: what an agent that never iterates reports
     if (DIMS > 0) {
-        // static shapes: every table read of this phase (x0 factors, slot scalings, row scalings: L2 round trips) is
-        // issued before the first use, so the phase pays one round trip instead of one per table
+        if (T != T_ahead) {  // uniform: the LP stopped short of the waypoint far enough to change T
+            load_tables(T);
+            load_row_scalings(T);
+        }
         w.each([&](int l) {
-            double a0[NXP], a1[NXP], a2[NXP], ag[NXP], sv[SUA], nn[KU], kw[NXP][3];
-#pragma unroll
-            for (int u = 0; u < NXP; u++) {
-                const int j = 64 * u + l;
-                const int jc = j < nxc ? j : nxc - 1;
-                const int p = jc - (jc / P) * P;
-                a0[u] = tXs[p * 3 + 0]; a1[u] = tXs[p * 3 + 1]; a2[u] = tXs[p * 3 + 2]; ag[u] = tXg[p];
-                kw[u][0] = tKIW[p]; kw[u][1] = tKIW[P + p]; kw[u][2] = tKIW[2 * P + p];
-            }
-#pragma unroll
-            for (int u = 0; u < SU; u++) {
-                const int s = l + 64 * u;
-                sv[u] = tSIW[s < Sc ? s : (Sc > 0 ? Sc - 1 : 0)];
-            }
-#pragma unroll
-            for (int u = 0; u < KU; u++) {
-                const uint32_t key = ckey[u].at(l);
-                const bool have = key != KEY_SKIP;
-                int mi = (int)(key & 0xFF) * n1 + (int)((key >> 8) & 0xF);
-                DQ_KEEP(mi);  // computed for every lane, then selected: as one ?: expression this came out as an EXEC-masked region
-                mi = have ? mi : 0;
-                nn[u] = tNN[mi < P ? mi : 0];
-            }
-#pragma unroll
-            for (int u = 0; u < NXP; u++) {
-                DQ_KEEP(a0[u]); DQ_KEEP(a1[u]); DQ_KEEP(a2[u]); DQ_KEEP(ag[u]);
-                DQ_KEEP(kw[u][0]); DQ_KEEP(kw[u][1]); DQ_KEEP(kw[u][2]);
-            }
-#pragma unroll
-            for (int u = 0; u < SU; u++) DQ_KEEP(sv[u]);
-#pragma unroll
-            for (int u = 0; u < KU; u++) DQ_KEEP(nn[u]);
 #pragma unroll
             for (int u = 0; u < NXP; u++) {
                 const int j = 64 * u + l;
                 const bool in = j < nxc;
                 const int k = (in ? j : nxc - 1) / P;
-                const double v = a0[u] * (double)pick3(pos, k) + a1[u] * (double)pick3(vel, k) + a2[u] * (double)pick3(acc, k) +
-                                 ag[u] * (double)pick3(goal, k);
+                const double v = xa0[u].at(l) * (double)pick3(pos, k) + xa1[u].at(l) * (double)pick3(vel, k) + xa2[u].at(l) * (double)pick3(acc, k) +
+                                 xag[u].at(l) * (double)pick3(goal, k);
                 base[blend_idx(in, oX + j, odump + (l & 31))] = v;
-                kiw[u][0].at(l) = kw[u][0]; kiw[u][1].at(l) = kw[u][1]; kiw[u][2].at(l) = kw[u][2];
             }
-#pragma unroll
-            for (int u = 0; u < SU; u++) siw[u].at(l) = (l + 64 * u < Sc) ? sv[u] : 0.0;
-#pragma unroll
-            for (int u = 0; u < KU; u++) nnr[u].at(l) = nn[u];
         });
+        // its objective is a 4 x 4 quadratic form per axis (qp_tables.cpp: tabPhi), evaluated here, where its table has just
+        // arrived with the others, not at the exit, where the read would be a round trip of its own
+        if (out_cost && kp.phi_ok) {
+            for (int k = 0; k < dim; k++) {
+                const double s0 = (double)pos[k], s1 = (double)vel[k], s2 = (double)acc[k], s3 = (double)goal[k];
+                fval0 += s0 * (phq[0] * s0 + 2.0 * (phq[1] * s1 + phq[2] * s2 + phq[3] * s3)) + s1 * (phq[4] * s1 + 2.0 * (phq[5] * s2 + phq[6] * s3)) +
+                         s2 * (phq[7] * s2 + 2.0 * phq[8] * s3) + phq[9] * s3 * s3;
+            }
+        }
     }
     const double hv_lim = max_vel * kp.vel_scale, ha_lim = max_acc * kp.acc_scale;  // dynamic limits in metres (T3g)
     w.each([&](int l) {
@@ -1826,9 +1899,25 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             } else {
                 dd2 = z_squared();
             }
+#ifdef DLSCQP_TRACE
+            // trace builds (tests/test_dependency_margins.py): EVERY row is also measured in the whitened space, whether it raised
+            // suspicion or not -- the truth the thresholds are judged against -- without touching what the solve goes on with
+            const double dd2_first = dd2;
+            double zz_truth = 0.0, noise_truth = 0.0;
+            if (q > 0) {
+                const double keep_noise = noise2;
+                zz_truth = whitened_length();
+                noise_truth = noise2;
+                noise2 = keep_noise;
+            }
+            bool remeasured = false;
+#endif
             if (q > 0 && !(dd2 > (DXREG ? DEP_SUSPECT : DEP_SUSPECT_SLACK) * dall)) {
                 DQ_TRACE(5, dd2, dall, 0.0, 0.0);  // (the step rate that raised the suspicion)
                 dd2 = whitened_length();  // uniform, a few per cent of the iterations
+#ifdef DLSCQP_TRACE
+                remeasured = true;
+#endif
             }  // uniform, a few per cent of the iterations
             w.stamp(6);  // step direction, its whitened length
             // step lengths: t1 = min u_k / r_k over r_k > 0 (dual), t2 = viol / |z|^2 (primal)
@@ -1872,6 +1961,16 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             const bool dependent = !(dd2 > DEP_TOL * dall) || !(dd2 > DEP_NOISE * noise2) || !(dd2 > 0) || q >= r;
             const double t2 = dependent ? 1e300 : viol / dd2;
             DQ_TRACE(2, dd2, dall, t1, (double)ldrop);
+#ifdef DLSCQP_TRACE
+            if (q > 0 && q < r) {
+                // (6: a.dx / |N'a|^2 as first measured, |z|^2 / |N'a|^2 and |z|^2 / noise in the whitened space, flags: 1 = the solve
+                // took the row for dependent, 2 = it was measured again, 4 = dependent by the whitened measure, 8 = static shape
+                // without slack variables (threshold DEP_SUSPECT, else DEP_SUSPECT_SLACK))
+                const bool truth = !(zz_truth > DEP_TOL * dall) || !(zz_truth > DEP_NOISE * noise_truth) || !(zz_truth > 0);
+                DQ_TRACE(6, dd2_first / dall, zz_truth / dall, noise_truth > 0 ? zz_truth / noise_truth : -1.0,
+                         (double)((dependent ? 1 : 0) | (remeasured ? 2 : 0) | (truth ? 4 : 0) | (DXREG ? 8 : 0)));
+            }
+#endif
             w.stamp(7);  // ratio test
             if (t1 >= 1e300 && t2 >= 1e300) {
                 // no step possible: infeasible, unless within CPLEX's feasibility tolerance
@@ -2089,7 +2188,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     // iterated sits at its unconstrained minimiser: its objective is a 4 x 4 quadratic form per axis (qp_tables.cpp: tabPhi)
     double fval = 0.0;
     if (out_cost) {
-        if (iters == 0 && kp.phi_ok) {  // uniform
+        if (iters == 0 && kp.phi_ok && DIMS > 0) {  // uniform
+            fval = fval0;
+        } else if (iters == 0 && kp.phi_ok) {
             const double *ph = kp.tabPhi + (size_t)(T - 1) * 10;
             double pq[10];
 #pragma unroll

@@ -126,7 +126,8 @@ class ClosedLoop:
         (all-to-all lists grow with N^2).  corridor_margin (obstacle-free worlds with world_use_octomap set): one corridor
         box per segment, the bounding box of the segment's control points of the initial trajectory grown by that many metres
         (a stand-in for the boxes the octomap corridor generator would grow in a crowded maze).  prune: the generator's
-        presolve.  order_hint: every launch in the order of the previous step's iteration counts, sorted on the device."""
+        presolve.  order_hint: every launch in the order of the two previous steps' iteration counts, found by the plan kernel
+        itself (dlscqp_device_batch.hint_iters)."""
         import torch
         self.torch = torch
         self.cfg = cfg
@@ -213,6 +214,9 @@ class ClosedLoop:
         # sized once to the generator's capacity and never shrunk: the launch's kernel choice, LDS layout and flag array
         # follow it, and a captured graph freezes them
         self.batch.c.max_rows_per_agent = int(np.diff(ro).max()) if N else 0
+        if N > 1 and not self.comm_neighbours:
+            # lists of a fixed pitch (everybody, or the device search's lists): the kernel computes where an agent's rows start
+            self.batch.use_row_pitch(int(ro[1] - ro[0]))
         if corridor_margin is not None:
             assert world is None and cfg.world_use_octomap, "synthetic corridor boxes stand in for the octomap generator"
             self.box_margin = float(corridor_margin)
@@ -403,10 +407,12 @@ class ClosedLoop:
         if self.keep_inputs:
             self.records_in.copy_(self.batch.t["agents"])
         self._stage("traj_optimization_time")
+        if self.order_hint:
+            # launch order found by the kernel itself from the iteration counts of the two previous steps (dlscqp_device_batch.
+            # hint_iters): the counts rotate through three buffers, so that the one a launch writes is never one it reads
+            self.batch.rotate_hint(2)
         self.batch.launch(True, True)
         self._stage("state_update_time")
-        if self.order_hint:
-            self.batch.update_order()  # the next step's launch order from this step's iteration counts
         # fail-safe: keep the shifted previous plan (traj_planner.cpp:776); sub-goal from the LP (traj_planner.cpp:494);
         # doStep of the next iteration: state = desired_traj.getStateAt(dt) = start of segment 1, float32 differences
         self.advance()
@@ -418,6 +424,7 @@ class ClosedLoop:
         least one step; result files and the host-side waypoint planners keep working (they run outside the graph)."""
         torch = self.torch
         assert self.seq >= 1, "the first step differs (constant-velocity prediction, corridor initialisation)"
+        assert not self.order_hint, "the launch-order hint rotates its buffers from step to step: not in a captured graph"
         torch.cuda.synchronize(self.dev)
         state = [self.batch.t["agents"], self.cur_goal, self.plans, self.init_buf]
         if self.sfc is not None:

@@ -235,6 +235,7 @@ class DeviceBatch:
         b.out_status = self.out_status.data_ptr()
         b.out_iters = None if self.out_iters is None else self.out_iters.data_ptr()
         b.agent_order = None
+        self._row_offsets_host = row_offsets
         self.order = None
         self.c = b
         self.max_rows = kmax
@@ -256,6 +257,45 @@ class DeviceBatch:
         assert order.shape == (self.n_agents,) and np.array_equal(np.sort(order), np.arange(self.n_agents))
         self.order = self.torch.from_numpy(order).to(self.device)
         self.c.agent_order = self.order.data_ptr()
+
+    def use_row_pitch(self, pitch=None):
+        """Rows at a fixed pitch (dlscqp_device_batch.row_pitch): agent a's rows start at a * pitch, so the kernel computes the
+        address instead of loading row_offsets[a] -- one dependent load less in front of the rows.  pitch=None: take it from the
+        row_offsets the batch was made with (they must be 0, p, 2p, ...); 0 switches it off.  The caller keeps the layout:
+        whoever replaces row_offsets afterwards (neighbour lists of varying length) must switch the pitch off."""
+        if pitch is None:
+            d = np.diff(self._row_offsets_host)
+            assert len(d) and self._row_offsets_host[0] == 0 and d[0] > 0 and (d == d[0]).all(), "row_offsets are not at a fixed pitch"
+            pitch = int(d[0])
+        self.c.row_pitch = int(pitch)
+
+    def set_hint(self, iters):
+        """Launch order found by the kernel itself (dlscqp_device_batch.hint_iters): `iters` = the [n_agents, 4] int32 CUDA tensors
+        out_iters of up to three previous replanning steps of the same agents, newest first; None / () switches it off.  No sort,
+        no stream operation between two launches; replaces set_order / update_order (an explicit order wins if both are set)."""
+        iters = [] if iters is None else list(iters)[:3]
+        for k in range(3):
+            self.c.hint_iters[k] = None
+        for k, h in enumerate(iters):
+            assert h.dtype == self.torch.int32 and h.numel() == 4 * self.n_agents and h.is_contiguous()
+            self.c.hint_iters[k] = h.data_ptr()
+        self.c.hint_steps = len(iters)
+        self._keep_hint = iters
+
+    def rotate_hint(self, depth=2):
+        """Closed loops (one batch, launched step after step): call before every launch.  The iteration counts rotate through
+        depth + 1 buffers, the launch writes one of them and takes its order from the `depth` previous steps' -- a launch must
+        never read the counts it is writing (its workgroups would disagree about the order)."""
+        if getattr(self, "_hint_bufs", None) is None:
+            assert self.out_iters is not None, "make_device_batch(..., want_iters=True)"
+            self._hint_bufs = [self.out_iters] + [self.torch.zeros_like(self.out_iters) for _ in range(depth)]
+            self._hint_k = 0
+        k, n = self._hint_k, len(self._hint_bufs)
+        cur = self._hint_bufs[k % n]
+        self.out_iters = cur
+        self.c.out_iters = cur.data_ptr()
+        self.set_hint([self._hint_bufs[(k - j) % n] for j in range(1, n) if k - j >= 0])
+        self._hint_k += 1
 
     def update_order(self, stream=None, iters=None, history=()):
         """Launch order of the NEXT launch from the iteration counts of the last one, on the device

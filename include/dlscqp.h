@@ -205,6 +205,23 @@ typedef struct dlscqp_device_batch {
     const int32_t *row_counts;      /* optional [n_agents]: agent a has row_counts[a] rows starting at row_offsets[a]
                                        (a generator that pruned rows, dlscqp_lsc_gen.prune); NULL: row_offsets[a+1] -
                                        row_offsets[a].  max_rows_per_agent bounds both.                               */
+    /* ---- round 4 (appended: a caller that zero-fills the structure gets the behaviour of before) ---------------- */
+    int32_t row_pitch;              /* > 0: every agent's rows start at a * row_pitch (neighbour lists of fixed pitch, the
+                                       synthetic swarms): the wavefront computes the address of its rows instead of loading
+                                       it, one dependent load less in front of the rows.  Agent a then has row_counts[a]
+                                       rows, or row_pitch of them when row_counts is NULL; row_offsets is not read.      */
+    int32_t hint_steps;             /* 0 = none, else 1..3 entries of hint_iters                                        */
+    const int32_t *hint_iters[3];   /* LAUNCH ORDER INSIDE THE KERNEL, no sort between two launches: out_iters ([n_agents][4])
+                                       of the previous replanning steps of the same agents, newest first.  The agents are
+                                       taken in blocks of 64 consecutive ids; launch slot s plans the (s / n_blocks)-th
+                                       most expensive agent of block s % n_blocks -- expensive by the key of
+                                       dlscqp_launch_order_history_device, max_k (3/4)^k iterations_k, in eight classes
+                                       (0, 1, 2-3, 4-7, ... 64+) -- which its wavefront finds with eight ballots over the
+                                       block's 64 keys.  The first n_blocks workgroups therefore plan every block's
+                                       hardest agent, the next n_blocks the second hardest ...: the order a global sort
+                                       gives, up to ties between blocks, without the sort's two kernels and their scratch.
+                                       Used when agent_order is NULL; not with launch_offset / launch_count.  Results
+                                       do not depend on it.                                                             */
 } dlscqp_device_batch;
 
 /* key layout: bits 0-7 m, 8-11 i, 12 dynamic flag, 16-31 slack index (0xFFFF = none). */
@@ -227,6 +244,12 @@ int dlscqp_launch_order_device(dlscqp_ctx *ctx, const int32_t *iters, int32_t n_
  * that starts late is what a launch waits for (measured on the S64 loop: 0.35 -> 0.28-0.33 ms per 32 768-agent step). */
 int dlscqp_launch_order_history_device(dlscqp_ctx *ctx, const int32_t *const *iters, int32_t n_steps, int32_t n_agents, int32_t *order_out,
                                        void *stream);
+
+/* The launch order a dlscqp_device_batch with these hint_iters gets, written out (tests, diagnostics): order_out[s] = the agent
+ * launch slot s plans, s < 64 * ceil(n_agents / 64), or -1 for a slot beyond its block's agents.  Same device function as the
+ * plan kernel's.  iters: 1..3 device arrays [n_agents][4], newest first; order_out: device array. */
+int dlscqp_hint_order_preview_device(dlscqp_ctx *ctx, const int32_t *const *iters, int32_t n_steps, int32_t n_agents, int32_t *order_out,
+                                     void *stream);
 
 /* ---- DLSC-GC half-space generation on the device --------------------------------------
  * TrajPlanner::generateDLSCGC for neighbouring AGENTS (traj_planner.cpp:603-666) together with the shift of the
@@ -295,7 +318,9 @@ int dlscqp_generate_lsc_device(dlscqp_ctx *ctx, const dlscqp_lsc_gen *gen, void 
  * problem of the context's own shape (an agent drifting at a half-space that it reaches even when it brakes as gently as
  * it can, plus an agent that is free to go) is planned by every kernel instantiation a batch of this context can be handed -- the one
  * select_instance picks with all rows in the register cache, the one for longer row lists, the one for batches with slack
- * obstacles, the runtime-shape one, the variant with its working set in HBM -- and every answer must (1) report DLSCQP_OK,
+ * obstacles, the runtime-shape one, the variant with its working set in HBM; each of them in every BUILD it exists in: the standard one
+ * that launches of more than a thousand agents run (two wavefronts per SIMD), the one-wavefront-per-SIMD build of small
+ * launches, the build with helper wavefronts -- and every answer must (1) report DLSCQP_OK,
  * (2) keep the initial state, continuity to the second derivative and the terminal stop, (3) satisfy the wall, the box and
  * the velocity limit, touch the wall (agent 0) or pass where it would be (agent 1), (4) agree with the other
  * instantiations' to 1e-6 m.  Returns DLSCQP_SUCCESS or DLSCQP_ERR_SELFTEST.
@@ -457,6 +482,67 @@ typedef struct dlscqp_mapf_step_args {
 /* One decentralizedMAPP pass: next_waypoint is updated in place.  Returns DLSCQP_SUCCESS, 1 if the planner failed for
  * some group (its waypoints stay as they are, like the reference's "MAPF failed"), or a negative error code. */
 int dlscqp_mapf_step(dlscqp_mapf *mapf, const dlscqp_mapf_step_args *args);
+
+/* ---- the per-step exchange of the solved plans, and one call per replanning step -----------------------
+ * MultiSyncSimulator::broadcastMsgs (multi_sync_simulator.cpp:468-514) hands every agent's plan to every other agent; its
+ * payload per agent is AgentManager::getAgent (agent_manager.cpp:249-263): here the control points, the sub-goal and the verdict.
+ * With the agents sharded over the GPUs of a node (contiguous id ranges, every rank `n_local` agents) that is ONE ncclAllGather
+ * over xGMI per step, issued by THIS library from librccl -- loaded with dlopen when the first exchange is created, a copy that
+ * is already in the process (torch's) first -- on a communication stream the exchange owns (highest priority: its few workgroups
+ * run beside the next step's plan kernels).  Record layout of the gathered table: [world * n_local][M (n+1) 3 + 4] float32 =
+ * control points | sub-goal | verdict (the int32's bits): rank r's agents at rows [r n_local, (r+1) n_local).
+ * Bootstrap: rank 0 calls dlscqp_exchange_unique_id and hands the 128 bytes to the other ranks by whatever the host has (a file,
+ * MPI, torch.distributed's store) -- in a forked child BEFORE anything has touched the GPU; every rank then calls
+ * dlscqp_exchange_create (collective: ncclCommInitRank).  world == 1 needs no id (and with local_only != 0 no librccl: the
+ * "collective" is a device copy -- hosts without RCCL, tests). */
+typedef struct dlscqp_exchange dlscqp_exchange;
+#define DLSCQP_EXCHANGE_ID_BYTES 128
+typedef struct dlscqp_exchange_config {
+    int32_t rank, world;
+    int32_t n_local;          /* agents of every rank (pad the last rank's shard)                              */
+    int32_t local_only;       /* world == 1 only: no RCCL, the gathered table is a device copy of the record    */
+    const void *unique_id;    /* DLSCQP_EXCHANGE_ID_BYTES from rank 0 (may be NULL when world == 1)             */
+} dlscqp_exchange_config;
+int dlscqp_exchange_unique_id(void *id_out /* [DLSCQP_EXCHANGE_ID_BYTES] */);
+int dlscqp_exchange_create(dlscqp_ctx *ctx, const dlscqp_exchange_config *cfg, dlscqp_exchange **out);
+void dlscqp_exchange_destroy(dlscqp_exchange *x);
+/* Post the rank's plans of a step: ctrl [n_local][M][n+1][3] float32, goal [n_local][3] float32, status [n_local] int32 (device),
+ * complete on `ready_stream` when the call is made.  The library records an event there; on its communication stream it packs the
+ * records and starts the all-gather.  Two buffer pairs alternate: exchange k waits for exchange k - 2.  The caller keeps the three
+ * arrays untouched until dlscqp_exchange_before_overwrite() has made the stream that overwrites them wait for the packing (call
+ * it ahead of the launch after next: it refers to the post before last).  Asynchronous; no host synchronisation. */
+int dlscqp_exchange_post(dlscqp_exchange *x, const float *ctrl, const float *goal, const int32_t *status, void *ready_stream);
+int dlscqp_exchange_before_overwrite(dlscqp_exchange *x, void *stream);
+/* Make `stream` wait for the exchange posted last; *table_out (optional) = the gathered table (device memory of the exchange,
+ * valid until the post after next). */
+int dlscqp_exchange_wait(dlscqp_exchange *x, void *stream, const float **table_out);
+/* Stage times of the following `capacity` exchanges (events with timing on the two streams; a diagnosis, off by default):
+ * pack = the packing kernel, all_gather = the collective, lag = from "plans ready" on the compute side to "table gathered". */
+int dlscqp_exchange_set_timing(dlscqp_exchange *x, int32_t capacity);
+int dlscqp_exchange_get_times(dlscqp_exchange *x, float *pack_ms, float *all_gather_ms, float *lag_ms, int32_t capacity, int32_t *n_out);
+
+/* One replanning step of this rank in ONE call (MultiSyncSimulator::plan + broadcastMsgs, multi_sync_simulator.cpp:516-524,
+ * 468-514): the launches of all swarm groups on their streams, and -- with an exchange -- the events that tie the step's output
+ * table to the post.  The groups' batches of a step write slices of one table (ctrl / goal / status: what is posted); a caller
+ * that rotates through B >= 3 such tables may use DLSCQP_EXCHANGE_PIPELINED: the exchange of step k runs while step k + 1 is
+ * planned (agents whose neighbours are all local need nothing from it), a launch waits only until the table it overwrites has
+ * been packed.  DLSCQP_EXCHANGE_SERIAL: the launches of step k + 1 wait for the gathered table of step k.  No host
+ * synchronisation, no allocation after the first call. */
+enum { DLSCQP_EXCHANGE_NONE = 0, DLSCQP_EXCHANGE_PIPELINED = 1, DLSCQP_EXCHANGE_SERIAL = 2 };
+typedef struct dlscqp_step_group {
+    dlscqp_ctx *ctx;                    /* the group's context                                                   */
+    const dlscqp_device_batch *batch;   /* what it plans this step (with its hint_iters: the launch order)         */
+    void *stream;                       /* the group's stream                                                     */
+} dlscqp_step_group;
+typedef struct dlscqp_step_args {
+    int32_t n_groups;
+    int32_t exchange_mode;              /* DLSCQP_EXCHANGE_*; ignored without an exchange                         */
+    const dlscqp_step_group *groups;
+    dlscqp_exchange *exchange;          /* or NULL                                                                */
+    const float *ctrl, *goal;           /* the step's output table, [n_local] agents: what the groups' batches write */
+    const int32_t *status;
+} dlscqp_step_args;
+int dlscqp_step_device(const dlscqp_step_args *step);
 
 /* Host helper: convert n_rows AoS rows to the SoA arrays above (host memory, caller-owned). */
 void dlscqp_rows_to_soa(const dlscqp_lsc_row *rows, int64_t n_rows, float *nx, float *ny,

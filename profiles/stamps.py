@@ -39,6 +39,8 @@ def main():
     opt = BatchTrajOptimizer(cfg)
     wl = workloads.generate(cfg, lambda a, ro, r, s: opt.plan(a, ro, r, s, 0, True, True), n_swarms=args.swarms, seed=2000)
     db = opt.make_device_batch(wl["agents"], wl["row_offsets"], wl["rows"], None, 0, want_iters=True)
+    if not os.environ.get("DLSCQP_NO_ROW_PITCH"):
+        db.use_row_pitch()  # as bench.py launches the workload: every agent's rows at a fixed pitch
     N = len(wl["agents"])
     stamps = torch.zeros((N, 12), dtype=torch.int64, device="cuda")
     db.c.debug_stamps = stamps.data_ptr()

@@ -1,0 +1,97 @@
+"""How far the kernel's dependency thresholds (csrc/qp_types.hpp: DEP_SUSPECT, DEP_SUSPECT_SLACK, DEP_NOISE, DEP_TOL) are from what
+they separate -- measured, per random sweep, on the kernel's own source (lane-serial TRACE build, tests/emul).
+
+Round 3's defect: the range-space kernel took rows that DEPEND on the active rows for independent ones (6 of 17 622 infeasible QPs
+"solved").  The fix: a row whose step rate a.dx is below DEP_SUSPECT |N'a|^2 is measured again in the whitened space, |z|^2 against
+DEP_TOL |N'a|^2 and against DEP_NOISE x the scale of its own rounding noise.  Those four constants were calibrated on batches at
+the launch files' parameter values.  Here a trace build measures EVERY candidate row of every iteration in the whitened space as
+well (the truth), over random batches that include the corners of the parameter box (control_input_weight 1 and 1e-4, dt 0.1 and
+0.4, terminal_weight 20, slack_collision_weight 1), and the test asserts
+  * no row that is dependent by the whitened measure was taken for independent (the defect itself),
+  * every dependent row's first measure a.dx / |N'a|^2 is at least 100 x below the suspicion threshold of its shape,
+  * in the whitened measure dependent rows are at least 100 x below DEP_NOISE and DEP_TOL ... or independent ones 100 x above:
+    a shape or a parameter set that erodes a margin fails here before it flips a verdict.
+The seed comes from the run (printed; FUZZ_SEED replays it)."""
+import ctypes as C
+import os
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+from dlsc_gc_planner_amd import abi
+import emul_lib
+import randqp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEP_SUSPECT, DEP_SUSPECT_SLACK, DEP_NOISE, DEP_TOL = 1e-5, 1e-3, 1e-17, 1e-20  # csrc/qp_types.hpp
+SEED = int(os.environ.get("FUZZ_SEED", str(int(time.time()) % 1000000)))
+NAMES = ["empty3d_M5", "maze2d_M10_sfc_comm", "forest3d_M5_dyn", "crowd3d_M5_400rows", "long3d_M12_comm"] + randqp.OFF_DEFAULT
+
+
+@pytest.fixture(scope="module")
+def trace_lib():
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emul"), "libdlscqp_emul_trace.so"])
+    L = C.CDLL(os.path.join(ROOT, "tests", "emul", "libdlscqp_emul_trace.so"))
+    vp = C.c_void_p
+    L.emul_plan_batch.argtypes = [C.POINTER(abi.Config), C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.emul_trace.argtypes = [C.c_int, vp, C.c_int]
+    return L
+
+
+def traced_records(L, cfg, b):
+    """the (tag, a, b, c, d) records of a whole batch planned by the trace build"""
+    old = emul_lib._LIB
+    emul_lib._LIB = L
+    try:
+        L.emul_trace(1, None, 0)
+        out = emul_lib.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], b["sfc"], b["max_slack_obs"])
+        cap = 40_000_000
+        buf = np.zeros(cap)
+        n = L.emul_trace(2, buf.ctypes.data_as(C.c_void_p), cap)
+        L.emul_trace(0, None, 0)
+    finally:
+        emul_lib._LIB = old
+    assert n < cap
+    return out, buf[:n - n % 5].reshape(-1, 5)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_dependency_thresholds_keep_their_margins(trace_lib, name, record_property):
+    ck, gk = randqp.CONFIGS[name]
+    cfg = abi.make_config(**ck)
+    n = 160 if "M10" not in name and "M12" not in name else 60
+    gk = dict(gk, infeasible_frac=max(0.3, gk.get("infeasible_frac", 0.1)))  # dependent rows live in infeasible problems
+    b = randqp.random_batch(cfg, n, seed=SEED, **gk)
+    out, rec = traced_records(trace_lib, cfg, b)
+    r6 = rec[rec[:, 0] == 6]
+    assert len(r6) > 0
+    adx, zz, zn, fl = r6[:, 1], r6[:, 2], r6[:, 3], r6[:, 4].astype(np.int64)
+    taken_dep, remeasured, truth, static = (fl & 1) != 0, (fl & 2) != 0, (fl & 4) != 0, (fl & 8) != 0
+    suspect = np.where(static, DEP_SUSPECT, DEP_SUSPECT_SLACK)
+    line = "seed %d  %-32s rows measured %6d, dependent %5d" % (SEED, name, len(r6), int(truth.sum()))
+    # 1. the defect itself: dependent by the whitened measure, taken for independent
+    assert not (truth & ~taken_dep).any(), (SEED, name, r6[truth & ~taken_dep][:5])
+    # ... and nothing independent is thrown away: a row the solve calls dependent is dependent by the whitened measure
+    assert not (taken_dep & ~truth).any(), (SEED, name, r6[taken_dep & ~truth][:5])
+    if truth.any():
+        worst_first = float((adx[truth] / suspect[truth]).max())  # how close a dependent row's first measure comes to the suspicion threshold
+        dep_noise = float(zn[truth & (zn >= 0)].max()) if (truth & (zn >= 0)).any() else 0.0
+        dep_tol = float(zz[truth].max())
+        line += "; dependent rows: a.dx/|N'a|^2 at most %.1e of the suspicion threshold, |z|^2/noise <= %.1e, |z|^2/|N'a|^2 <= %.1e" % (worst_first, dep_noise, dep_tol)
+        assert worst_first <= 1e-2, (SEED, name, worst_first)
+        # dependent by at least one of the two whitened tests with 100 x to spare
+        spare = (zn[truth] <= DEP_NOISE * 1e-2) | (zz[truth] <= DEP_TOL * 1e-2) | (zz[truth] <= 0)
+        assert spare.all(), (SEED, name, r6[truth][~spare][:5])
+    ind = ~truth & (zn >= 0)
+    if ind.any():
+        ind_noise, ind_tol = float(zn[ind].min()), float(zz[ind].min())
+        line += "; independent rows: |z|^2/noise >= %.1e, |z|^2/|N'a|^2 >= %.1e" % (ind_noise, ind_tol)
+        assert ind_noise >= DEP_NOISE * 1e2 and ind_tol >= DEP_TOL * 1e2, (SEED, name, ind_noise, ind_tol)
+    print(line)
+    record_property("margins", line)
+    log = os.environ.get("DEP_MARGIN_LOG")
+    if log:
+        with open(log, "a") as fh:
+            fh.write(line + "\n")

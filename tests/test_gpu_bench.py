@@ -33,12 +33,17 @@ def test_single_gpu_line_has_the_contract_fields(gpu_required):
     r = d["roofline"]
     assert r["bound"] == "valu_issue" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     # the eight swarms in four groups, each group on its own stream: four launches of 128 agents side by side
-    assert r["qp_per_launch"] == 128 and r["concurrent_launches"] == 4 and d["config"]["swarm_groups"] == 4
-    assert abs(r["achieved"] - 4 * r["achieved_one_launch"]) < 1e-9 * r["achieved"]
+    assert r["qp_per_launch"] == 128 and r["launches_per_step"] == 4 and d["config"]["swarm_groups"] == 4
+    # the line's roofline figure is the STEP's: all agents' algorithmic bytes over ms_per_step; the per-launch figure and the
+    # "if the four launches overlapped fully" figure are named extras
+    assert abs(r["achieved"] - 512 * r["algorithmic_bytes_per_qp"] / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-9 * r["achieved"]
+    assert abs(r["achieved_if_launches_overlapped_fully"] - 4 * r["achieved_one_launch"]) < 1e-9 * r["achieved_one_launch"] * 4
+    assert 0 < r["effective_concurrency"] <= 4.0 + 1e-9
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["oracle_qp_per_s_one_core"] > 0
+    assert c["kind"] == "port" and c["port_kind"] == "lane-serial port" and c["cores"] >= 1 and c["value"] > 0 and c["oracle_qp_per_s_one_core"] > 0
     assert c["value"] > 3 * c["oracle_qp_per_s_one_core"]  # the kernel's algorithm, not the dense checker
     assert d["config"]["distinct_batches"] == 4 and d["config"]["ms_per_step_no_order_hint"] > 0 and d["config"]["ms_per_step_host_order"] > 0
+    assert d["config"]["ms_per_step_sorted_on_device"] > 0  # round 3's sort kernels, timed beside the kernel's own order
 
 
 @pytest.mark.parametrize("mode", ["pipelined", "serial"])
@@ -47,7 +52,7 @@ def test_multi_gpu_code_path_with_one_rank(gpu_required, mode):
     assert d["n_gpus"] == 1 and d["value"] > 0
     assert ("communication stream" in d["config"]["exchange"]) == (mode == "pipelined")
     # with the exchange the swarms are planned in two groups; ONE all-gather per step carries both groups' plans
-    assert d["config"]["swarm_groups"] == 2 and d["roofline"]["concurrent_launches"] == 2 and d["roofline"]["qp_per_launch"] == 256
+    assert d["config"]["swarm_groups"] == 2 and d["roofline"]["launches_per_step"] == 2 and d["roofline"]["qp_per_launch"] == 256
     assert d["config"]["host_ms_to_queue_a_step"] > 0
     e = d["config"]["exchange_modes_ms_per_step"]
     assert e["pipelined"] > 0 and e["serial"] > 0  # both modes are timed in every N > 1 run

@@ -1,7 +1,12 @@
-"""-m gpu: a small slice of the randomised sweep (tests/fuzz_gpu.py) in the suite -- every configuration of tests/randqp.py, one fresh
-seed, HIP kernel against the CPU oracle: identical verdicts, sub-goals bit for bit, solutions to 1e-6, nobody near the iteration
-limit.  The full sweep (17 622 QPs per seed offset) found the two numerical defects of round 3 that no fixture had shown; this
-keeps a fifth of one sweep in front of every change."""
+"""-m gpu: a small slice of the randomised sweep (tests/fuzz_gpu.py) in the suite -- every configuration of tests/randqp.py (since
+round 4 also the corners of the parameter box: control_input_weight 1 / 1e-4, dt 0.1 / 0.4, terminal_weight 20,
+slack_collision_weight 1), HIP kernel against the CPU oracle: identical verdicts, sub-goals bit for bit, solutions to 1e-6, nobody
+near the iteration limit.  The full sweep found the two numerical defects of round 3 that no fixture had shown; this keeps a fifth
+of one sweep in front of every change.  It SAMPLES: the seed comes from the run (printed with every failure; FUZZ_SEED=<n> replays
+it), so every run of the suite sees batches no run has seen before."""
+import os
+import time
+
 import numpy as np
 import pytest
 
@@ -11,6 +16,7 @@ import oracle_lib
 import randqp
 
 pytestmark = pytest.mark.gpu
+SEED = int(os.environ.get("FUZZ_SEED", str(int(time.time()) % 1000000)))
 
 
 @pytest.mark.parametrize("name", sorted(randqp.CONFIGS))
@@ -18,7 +24,8 @@ def test_random_batch_against_the_oracle(gpu_required, name):
     ck, gk = randqp.CONFIGS[name]
     cfg = abi.make_config(**ck)
     n = 240 if "M10" not in name and "M12" not in name else 100
-    b = randqp.random_batch(cfg, n, seed=4242, **gk)
+    print("FUZZ_SEED=%d" % SEED)
+    b = randqp.random_batch(cfg, n, seed=SEED, **gk)
     ref = oracle_lib.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], b["sfc"], b["max_slack_obs"], True)
     opt = BatchTrajOptimizer(cfg)
     try:
@@ -27,10 +34,11 @@ def test_random_batch_against_the_oracle(gpu_required, name):
         got = db.results()
     finally:
         opt.close()
-    assert np.array_equal(got["status"], ref["status"]) and np.array_equal(got["goal_status"], ref["goal_status"])
+    why = "FUZZ_SEED=%d %s" % (SEED, name)
+    assert np.array_equal(got["status"], ref["status"]) and np.array_equal(got["goal_status"], ref["goal_status"]), why
     reached = ref["goal_status"] != abi.INFEASIBLE
-    assert np.array_equal(got["goal"][reached], ref["goal"][reached])
+    assert np.array_equal(got["goal"][reached], ref["goal"][reached]), why
     ok = ref["status"] == abi.OK
-    assert ok.sum() >= n // 4 and (~ok).sum() >= 1  # solved and failed problems in every batch
-    assert np.abs(got["x"][ok] - ref["x"][ok]).max() < 1e-6
-    assert got["iters"][:, 0].max() <= 400
+    assert ok.sum() >= n // 5, why  # solved problems in every batch (failed ones in all but a rare one)
+    assert np.abs(got["x"][ok] - ref["x"][ok]).max() < 1e-6, why
+    assert got["iters"][:, 0].max() <= 400, why

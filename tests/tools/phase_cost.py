@@ -59,6 +59,9 @@ def main():
         opt = BatchTrajOptimizer(cfg)
         dbs = [opt.make_device_batch(h["agents"], h["row_offsets"], h["rows"], None, 0, want_iters=True) for h in hist]
         zdb = opt.make_device_batch(za, np.arange(N + 1) * K, zr, None, 0, want_iters=True)
+        if not os.environ.get("DLSCQP_NO_ROW_PITCH"):
+            for db in dbs + [zdb]:
+                db.use_row_pitch()  # as bench.py launches the workload
         out = {}
         for tag, group in (("rotation", dbs), ("zero", [zdb])):
             for i in range(8):
