@@ -357,6 +357,104 @@ def moving_crowd(device, steps=60, warm=20):
     return out
 
 
+def s64_closed_loop(device, n_swarms=512, groups=1, first=3, steps=8, flights=4):
+    """BASELINE.json configs[1] at the headline's scale with the WHOLE replanning step on the device (traj_planner.cpp:108-133 per
+    agent: prediction of the neighbours from their previous plans, generateDLSCGC :603-666, goal LP, QP; then doStep): the
+    `n_swarms` swarms in `groups` closed loops (harness.ClosedLoop), each on its own stream; per step and loop four launches,
+    nothing on the host in between -- neighbour lists (the workload's rule: the 5 nearest agents of the swarm,
+    dlscqp_neighbours_knn_device), half-spaces (dlscqp_lsc_kernel with the presolve: 4 x 27 + 12 rows per agent at most), goal
+    LP + QP in the kernel's own launch order (iteration counts of the two previous steps), state update (dlscqp_advance_device).
+    Timed: replanning steps [first, first + steps) of `flights` fresh flights, queued without synchronising -- the window in
+    which the swarms cross (the batches the headline rotates through are replanning steps 3..6 of the same swarms; after ~40
+    steps everybody has arrived and a step is trivial).  Statistics and stage times: a further flight of one loop, same window,
+    synchronised per step."""
+    import numpy as np
+    import torch
+    from dlsc_gc_planner_amd import abi, workloads
+    from dlsc_gc_planner_amd.harness import ClosedLoop
+    cfg = workloads.s64_config(device=device)
+    start, goal = workloads.swarm_missions(cfg, n_swarms=n_swarms, swarm_size=64, seed=2000)
+    G = groups
+    while n_swarms % G:
+        G -= 1
+    per = (n_swarms // G) * 64
+    dev = torch.device("cuda", device)
+    streams = [torch.cuda.Stream(dev) for _ in range(G)]
+
+    def take_off():
+        sims = []
+        for g in range(G):
+            with torch.cuda.stream(streams[g]):
+                sims.append(ClosedLoop(cfg, start[g * per:(g + 1) * per], goal[g * per:(g + 1) * per], radius=0.15, downwash=2.0, max_vel=1.0,
+                                       max_acc=2.0, waypoint_step=5.0, device=device, neighbours="knn", knn=(64, 5), tail=(4, 2), prune=True,
+                                       order_hint=True))
+        return sims
+
+    def advance(sims, k):
+        t0 = time.perf_counter()
+        for _ in range(k):
+            for g in range(G):
+                with torch.cuda.stream(streams[g]):
+                    sims[g].step()
+        host = time.perf_counter() - t0
+        torch.cuda.synchronize(dev)
+        return time.perf_counter() - t0, host
+    el = host = 0.0
+    for _ in range(flights):
+        sims = take_off()
+        advance(sims, first)
+        e_, h_ = advance(sims, steps)
+        el, host = el + e_, host + h_
+        for s_ in sims:
+            s_.close()
+    ms = el / (flights * steps) * 1e3
+    # statistics and stage times of the same window: one more flight of the first loop, synchronised per step
+    sim = take_off()[0] if G == 1 else ClosedLoop(cfg, start[:per], goal[:per], radius=0.15, downwash=2.0, max_vel=1.0, max_acc=2.0, waypoint_step=5.0,
+                                                   device=device, neighbours="knn", knn=(64, 5), tail=(4, 2), prune=True, order_hint=True)
+    for _ in range(first):
+        sim.step()
+    its, rows, fails, lp_fails = [], [], 0, 0
+    sim.enable_stage_timers()
+    for _ in range(steps):
+        sim.step()
+        r = sim.batch.results()
+        its.append(r["iters"][:, 0].copy())
+        fails += int((r["status"] != abi.OK).sum())
+        lp_fails += int((r["goal_status"] == abi.INFEASIBLE).sum())
+        rows.append(float(sim.row_counts.float().mean()))
+    stages = sim.stage_times()
+    its = np.stack(its)
+    N = n_swarms * 64
+    plan_ms = float(np.percentile(stages["traj_optimization_time"], 50))
+    lsc_ms = float(np.percentile(stages["lsc_generation_time"], 50))
+    nb = float(sim.nbr.counts.float().sum())
+    kept = float(sim.row_counts.float().sum())
+    rows_mean = float(np.mean(rows))
+    bytes_qp = 104 + 36 * rows_mean + 360 + 24
+    out = {"agents": N, "swarms": n_swarms, "loops": G, "agents_per_loop": per, "replanning_steps_timed": [first, first + steps], "flights": flights,
+           "ms_per_step": ms, "agent_qp_per_s": N / ms * 1e3, "host_ms_to_queue_a_step": host / (flights * steps) * 1e3,
+           "launches_per_step_and_loop": 4,
+           "mean_active_set_iterations": float(its.mean()), "max_active_set_iterations": int(its.max()),
+           "zero_iteration_fraction": float((its == 0).mean()), "rows_kept_per_agent": rows_mean, "rows_generated_per_agent": 120,
+           "qp_failsafe_fraction": fails / float(steps * per), "goal_lp_infeasible_fraction": lp_fails / float(steps * per),
+           "stage_p50_ms_one_loop_alone": {k: float(np.percentile(v, 50)) for k, v in stages.items()},
+           "stage_names": "the reference's timers (sp_const.hpp:81-122): lsc_generation_time = neighbour lists + half-spaces, "
+                          "traj_optimization_time = goal LP + QP (one launch), state_update_time = doStep; one loop of %d agents "
+                          "running alone, events around the stages" % per,
+           "includes": "neighbour lists + half-space generation (presolve) + goal LP + QP + state update, all in HBM",
+           # the dominant kernel of THIS step is still the plan kernel; the generator reads one 736-byte record per neighbour and
+           # writes 36 bytes per row it keeps
+           "roofline_plan_kernel": {"bound": "valu_issue", "algorithmic_bytes_per_qp": bytes_qp, "ms": plan_ms,
+                                    "achieved": per * bytes_qp / (plan_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                    "frac": per * bytes_qp / (plan_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+           "roofline_half_space_generator": {"bound": "valu_issue", "algorithmic_bytes_per_step": 736.0 * nb + 36.0 * kept, "ms": lsc_ms,
+                                             "achieved": (736.0 * nb + 36.0 * kept) / (lsc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                             "frac": (736.0 * nb + 36.0 * kept) / (lsc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                             "note": "736 B x neighbours read + 36 B x rows written (one loop alone; includes the neighbour search)"}}
+    sim.close()
+    return out
+
+
 class StressStep:
     """BASELINE.json configs[4] (2 048 agents, 2-D, M = 10, ~2 500 DLSC-GC rows per agent generated on the device) as a
     STRONG-scaling step: the agents are sharded by contiguous id range; every rank generates the half-spaces of its own
@@ -423,7 +521,7 @@ class StressStep:
         if dist is not None:
             pad = max(sharding.shard_sizes(N, world))
             assert pad == n_loc, "2 048 agents divide evenly over 1, 2, 4, 8 ranks"
-            self.xchg = sharding.PlanExchange(dist, world, n_loc, (E, 3, 1), dev)
+            self.xchg = sharding.make_exchange(self.opt, dist, rank, world, n_loc, dev)
 
     def _plan(self, part):
         gen, db, _, sel = part
@@ -584,6 +682,9 @@ def main():
     if one_device:
         local_rank = 0
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # streams are mapped to a few hardware queues (4 by default) and two streams on one queue run one after the other: the swarm
+    # groups' streams and the exchange's communication stream get a queue each (set before HIP starts; an explicit setting wins)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the trajectory optimizer has no CPU path")
@@ -651,6 +752,8 @@ def main():
             self.counter = 0
             self.device_order = False
             self.xchg = None
+            self.cargs = None
+            self.no_exchange = False  # time the loop with the exchange restricted to what a consumer needs (S64: nothing)
             self.older = [[[self.dbs[g][(j - k) % B].out_iters for k in (1, 2) if (j - k) % B != (j + 1) % B] for j in range(B)] for g in range(G)]
             self.planned = [[torch.cuda.Event() for _ in range(B)] for _ in range(G)]
             for i in range(max(args.warmup, B)):
@@ -712,21 +815,60 @@ def main():
             # group (four exchanges per step, one per group, were measured first: the step became bound by the host's calls)
             from dlsc_gc_planner_amd import sharding
             shape1 = tuple(self.dbs[0][0].out_ctrl.shape[1:])
-            self.xchg = sharding.PlanExchange(dist, world, N, (int(np.prod(shape1)), 3, 1), dev)
-            self.xchg.comm = self.spare_stream()  # (not one that shares a hardware queue with a group's launches)
+            # the library's own exchange (ncclAllGather called from C on a stream it owns) wherever RCCL can run; torch.distributed
+            # only for the two-ranks-on-one-device test hook (gloo)
+            self.xchg = sharding.make_exchange(opt, dist, rank, world, N, dev)
+            self.native = isinstance(self.xchg, sharding.NativeExchange)
+            if not self.native:
+                self.xchg.comm = self.spare_stream()  # (not one that shares a hardware queue with a group's launches)
             self.join = self.spare_stream()
             self.table_ready = None  # serial mode: the gathered table of the previous step (an event on `join`)
             per = self.per
-            self.out = [(torch.zeros((N,) + shape1, dtype=torch.float32, device=dev), torch.zeros((N, 3), dtype=torch.float32, device=dev),
-                         torch.full((N,), -1, dtype=torch.int32, device=dev)) for _ in range(B)]
+            # ... as RECORDS (control points | sub-goal | verdict, 94 words at S64): the plan kernel writes the layout the exchange
+            # sends (dlscqp_device_batch.out_record_stride), no packing pass between a launch and the collective
+            E_ = int(np.prod(shape1))
+            self.rec = [torch.zeros((N, E_ + 4), dtype=torch.float32, device=dev) for _ in range(B)]
+            for r_ in self.rec:
+                r_[:, E_ + 3:].view(torch.int32).fill_(-1)
+            self.out = [(r_[:, :E_], r_[:, E_:E_ + 3], r_[:, E_ + 3:].view(torch.int32)[:, 0]) for r_ in self.rec]
             for g in range(self.G):
                 for j in range(B):
-                    c_, g_, s_ = self.out[j]
-                    self.dbs[g][j].use_outputs(c_[g * per:(g + 1) * per], g_[g * per:(g + 1) * per], s_[g * per:(g + 1) * per])
+                    self.dbs[g][j].use_records(self.rec[j][g * per:(g + 1) * per])
+
+        def step_args(self):
+            """One dlscqp_step_args per batch of the rotation: the whole step -- every group's launch on its stream and, with an
+            exchange, the events that tie the step's output table to the post -- is then ONE call into the library."""
+            import ctypes as C
+            self.cargs = []
+            for j in range(B):
+                groups = (abi.StepGroup * self.G)()
+                for g in range(self.G):
+                    db = self.dbs[g][j]
+                    db.c.do_goal, db.c.do_traj, db.c.launch_offset, db.c.launch_count = 1, 1, 0, 0
+                    groups[g].ctx = self.opts[g].handle
+                    groups[g].batch = C.pointer(db.c)
+                    groups[g].stream = self.streams[g].cuda_stream
+                a = abi.StepArgs()
+                a.n_groups, a.groups, a.exchange_mode = self.G, groups, abi.EXCHANGE_NONE
+                if self.xchg is not None and getattr(self, "native", False):
+                    a.exchange = self.xchg.handle
+                    a.records = self.rec[j].data_ptr()
+                self.cargs.append((a, groups))
 
         def step(self, pipelined):
             j = self.counter % B
             self.counter += 1
+            if self.cargs is not None and not self.device_order and (self.xchg is None or self.native):
+                a = self.cargs[j][0]
+                a.exchange_mode = abi.EXCHANGE_NONE
+                if self.xchg is not None and not self.no_exchange:
+                    a.exchange_mode = abi.EXCHANGE_PIPELINED if pipelined else abi.EXCHANGE_SERIAL
+                    self.xchg.last = self.xchg.k & 1  # (the post happens inside the call)
+                    self.xchg.k += 1
+                rc = opt.lib.dlscqp_step_device(a)
+                if rc != abi.SUCCESS:
+                    raise RuntimeError("dlscqp_step_device failed (%d): %s" % (rc, opt.lib.dlscqp_last_error().decode()))
+                return
             for g in range(self.G):
                 st = self.streams[g]  # (explicit streams and events made once: a stream context or an event object per call costs
                 db, nxt = self.dbs[g][j], self.dbs[g][(j + 1) % B]  # the host ~10 us, and this loop makes dozens of calls per step)
@@ -745,7 +887,10 @@ def main():
             if use_dist:
                 for g in range(self.G):
                     self.join.wait_event(self.planned[g][j])
-                self.xchg.post(*self.out[j], pack_on_comm=pipelined, stream=self.join)
+                if self.native:
+                    self.xchg.post_records(self.rec[j], stream=self.join)
+                else:
+                    self.xchg.post(*self.out[j], pack_on_comm=pipelined, stream=self.join)
                 if not pipelined:
                     self.xchg.table(self.join)
                     if self.table_ready is None:
@@ -767,6 +912,7 @@ def main():
                 for j, db in enumerate(self.dbs[g]):
                     db.set_order(None if orders is None or self.device_order or kernel_order else self.hint[g][j])
                     db.set_hint([self.dbs[g][(j - k) % B].out_iters for k in (1, 2, 3) if (j - k) % B != j] if kernel_order else None)
+            self.step_args()
             self.counter = 0
             for _ in range(B):
                 self.step(pipelined)
@@ -848,8 +994,8 @@ def main():
         ctrl_all, goal_all, status_all = loop.xchg.unpack(loop.xchg.table(), (torch.float32, torch.float32, torch.int32))
         torch.cuda.synchronize(dev)
         own = slice(rank * N, (rank + 1) * N)
-        assert torch.equal(ctrl_all[own], last[0].view(N, -1)) and torch.equal(goal_all[own], last[1])
-        assert torch.equal(status_all[own].flatten(), last[2])
+        assert torch.equal(ctrl_all[own], last[0].reshape(N, -1)) and torch.equal(goal_all[own], last[1])
+        assert torch.equal(status_all[own].flatten(), last[2].flatten())
         assert int((last[2] >= 0).sum()) == N  # every group wrote its slice
     res = loop.results()
     # the same loop without the launch-order hint, and (N > 1) with the other exchange mode
@@ -857,6 +1003,12 @@ def main():
     el_nohint = float("nan") if args.headline_only else loop.timed(side_steps, head_pipelined, None)
     el_hostorder = float("nan") if args.headline_only else loop.timed(side_steps, head_pipelined, "host")
     el_sorted = float("nan") if args.headline_only else loop.timed(side_steps, head_pipelined, "device")
+    el_halo_only = None
+    if use_dist and pipelined_ok and not args.headline_only and getattr(loop, "native", False):
+        # the step with the exchange restricted to what a consumer needs: the S64 swarms have no halo agents, so nothing has to travel
+        loop.no_exchange = True
+        el_halo_only = loop.timed(side_steps, False, "kernel")
+        loop.no_exchange = False
     exch = None
     if use_dist and not args.headline_only:
         exch = {"pipelined": None, "serial": None, "steps_of_the_second_mode": side_steps}
@@ -865,6 +1017,7 @@ def main():
             el_other = loop.timed(side_steps, not head_pipelined, "kernel")
             exch["serial" if head_pipelined else "pipelined"] = el_other / side_steps * 1e3
     G_used, per_launch = loop.G, loop.per
+    native_xchg = bool(getattr(loop, "native", False))
     stream_note = getattr(loop, "stream_note", None)
     loop.close()
     del loop
@@ -1021,6 +1174,7 @@ def main():
                                 "agents had one replanning step earlier (dlscqp_device_batch.hint_iters), in the headline's groups; the "
                                 "one_launch figures are rounds 1-2's shape (one launch of all agents per step)"}
             closed = closed_loop_latency(local_rank)
+            closed["s64_closed_loop"] = s64_closed_loop(local_rank, n_swarms=args.swarms)
         line = {
             "metric": "agent-QP solves/sec (goal LP + trajectory QP per agent per replanning step)",
             "value": world * N * args.steps / elapsed,
@@ -1044,7 +1198,7 @@ def main():
                                      "outside themselves, so no group waits for another, and a step is every group advanced by one replanning "
                                      "step%s" % (args.swarms, G_used, "", "; one all-gather of all groups' plans per step, posted from a stream that waits for "
                                                                         "the groups' launches of that step" if use_dist else ""),
-                "swarm_group_streams": stream_note,
+                "swarm_group_streams": stream_note, "hardware_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "ms_per_step_one_launch_per_step": one_launch,
                 "host_ms_to_queue_a_step": host_queue_ms,
                 "segments": M, "degree": n, "lsc_rows_per_agent": K,
@@ -1053,7 +1207,16 @@ def main():
                              "one RCCL all-gather of control points, sub-goal and status per step, posted on a communication stream: runs "
                              "while the next step plans the agents without remote neighbours (all of them here)"
                              if head_pipelined else "one RCCL all-gather of control points, sub-goal and status per step, after the launch"),
+                "exchange_issued_by": (None if not use_dist else
+                                       "the library (dlscqp_exchange_post: ncclAllGather from librccl on a communication stream the exchange owns); "
+                                       "the whole step -- every group's launch and the post -- is one call, dlscqp_step_device" if native_xchg
+                                       else "torch.distributed.all_gather_into_tensor (gloo test hook)"),
                 "exchange_modes_ms_per_step": exch,
+                "ms_per_step_exchange_restricted_to_halo_consumers": None if el_halo_only is None else el_halo_only / side_steps * 1e3,
+                "exchange_restricted_note": "the reference broadcasts every plan to every agent (multi_sync_simulator.cpp:468-514) and the "
+                                            "headline mirrors that: every rank receives the whole table.  The S64 swarms have no neighbours "
+                                            "outside themselves, so NO agent reads a remote plan: restricted to what a consumer needs the "
+                                            "exchange moves nothing, and this is the step then",
                 "launch_order": "found by the plan kernel itself (dlscqp_device_batch.hint_iters): iteration counts of the three previous "
                                 "replanning steps (the other batches of the rotation, never the batch's own), maximum with decay 3/4 per "
                                 "step, in eight classes; slot s plans the (s / n_blocks)-th most expensive agent of the block of 64 agents "

@@ -122,6 +122,8 @@ class DeviceBatch(C.Structure):
         ("row_pitch", C.c_int32),
         ("hint_steps", C.c_int32),
         ("hint_iters", C.c_void_p * 3),
+        ("out_record_stride", C.c_int32),
+        ("reserved2_", C.c_int32),
     ]
 
 
@@ -157,6 +159,10 @@ class LscGen(C.Structure):
         ("prune_sfc_boxes", C.c_void_p),
         ("out_row_counts", C.c_void_p),
         ("nbr_counts", C.c_void_p),
+        ("tail_from", C.c_int32),
+        ("tail_segments", C.c_int32),
+        ("max_neighbours", C.c_int32),
+        ("reserved2_", C.c_int32),
     ]
 
 
@@ -175,6 +181,11 @@ class NeighbourSearch(C.Structure):  # dlscqp_neighbour_search
         ("reserved_", C.c_int32),
         ("out_overflow", C.c_void_p),
     ]
+
+
+class NeighbourKnn(C.Structure):  # dlscqp_neighbour_knn
+    _fields_ = [("n_total", C.c_int32), ("group", C.c_int32), ("k", C.c_int32), ("pitch", C.c_int32), ("position", C.c_void_p),
+                ("position_stride", C.c_int32), ("reserved_", C.c_int32), ("out_nbr_ids", C.c_void_p), ("out_nbr_counts", C.c_void_p)]
 
 
 class WaypointTrap(C.Structure):  # dlscqp_waypoint_trap
@@ -213,6 +224,23 @@ class Advance(C.Structure):
         ("waypoint_step", C.c_double),
     ]
 
+
+class ExchangeConfig(C.Structure):  # dlscqp_exchange_config
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("n_local", C.c_int32), ("local_only", C.c_int32), ("unique_id", C.c_void_p),
+                ("recv_buffers", C.c_void_p * 2)]
+
+
+class StepGroup(C.Structure):  # dlscqp_step_group
+    _fields_ = [("ctx", C.c_void_p), ("batch", C.POINTER(DeviceBatch)), ("stream", C.c_void_p)]
+
+
+class StepArgs(C.Structure):  # dlscqp_step_args
+    _fields_ = [("n_groups", C.c_int32), ("exchange_mode", C.c_int32), ("groups", C.POINTER(StepGroup)), ("exchange", C.c_void_p),
+                ("ctrl", C.c_void_p), ("goal", C.c_void_p), ("status", C.c_void_p), ("records", C.c_void_p)]
+
+
+EXCHANGE_NONE, EXCHANGE_PIPELINED, EXCHANGE_SERIAL = 0, 1, 2
+EXCHANGE_ID_BYTES = 128
 
 assert C.sizeof(Config) == 144, C.sizeof(Config)
 assert C.sizeof(Agent) == 104, C.sizeof(Agent)
@@ -343,6 +371,30 @@ def load_library():
     lib.dlscqp_launch_order_device.restype = C.c_int
     lib.dlscqp_launch_order_history_device.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp]
     lib.dlscqp_launch_order_history_device.restype = C.c_int
+    if hasattr(lib, "dlscqp_neighbours_knn_device"):
+        lib.dlscqp_neighbours_knn_device.argtypes = [vp, P(NeighbourKnn), vp]
+        lib.dlscqp_neighbours_knn_device.restype = C.c_int
+    if hasattr(lib, "dlscqp_exchange_create"):
+        lib.dlscqp_exchange_unique_id.argtypes = [vp]
+        lib.dlscqp_exchange_unique_id.restype = C.c_int
+        lib.dlscqp_exchange_create.argtypes = [vp, P(ExchangeConfig), P(vp)]
+        lib.dlscqp_exchange_create.restype = C.c_int
+        lib.dlscqp_exchange_destroy.argtypes = [vp]
+        lib.dlscqp_exchange_destroy.restype = None
+        lib.dlscqp_exchange_post.argtypes = [vp, vp, vp, vp, vp]
+        lib.dlscqp_exchange_post.restype = C.c_int
+        lib.dlscqp_exchange_post_records.argtypes = [vp, vp, vp]
+        lib.dlscqp_exchange_post_records.restype = C.c_int
+        lib.dlscqp_exchange_before_overwrite.argtypes = [vp, vp]
+        lib.dlscqp_exchange_before_overwrite.restype = C.c_int
+        lib.dlscqp_exchange_wait.argtypes = [vp, vp, P(vp)]
+        lib.dlscqp_exchange_wait.restype = C.c_int
+        lib.dlscqp_exchange_set_timing.argtypes = [vp, C.c_int32]
+        lib.dlscqp_exchange_set_timing.restype = C.c_int
+        lib.dlscqp_exchange_get_times.argtypes = [vp, vp, vp, vp, C.c_int32, P(C.c_int32)]
+        lib.dlscqp_exchange_get_times.restype = C.c_int
+        lib.dlscqp_step_device.argtypes = [P(StepArgs)]
+        lib.dlscqp_step_device.restype = C.c_int
     if hasattr(lib, "dlscqp_hint_order_preview_device"):
         lib.dlscqp_hint_order_preview_device.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp]
         lib.dlscqp_hint_order_preview_device.restype = C.c_int
@@ -358,4 +410,7 @@ EXPORTED_SYMBOLS = [
     "dlscqp_advance_device", "dlscqp_waypoint_trap_device", "dlscqp_mapf_create", "dlscqp_mapf_destroy", "dlscqp_mapf_step",
     "dlscqp_launch_order_device", "dlscqp_launch_order_history_device", "dlscqp_neighbours_device", "dlscqp_selftest",
     "dlscqp_hint_order_preview_device",
+    "dlscqp_exchange_unique_id", "dlscqp_exchange_create", "dlscqp_exchange_destroy", "dlscqp_exchange_post", "dlscqp_exchange_post_records",
+    "dlscqp_exchange_before_overwrite", "dlscqp_exchange_wait", "dlscqp_exchange_set_timing", "dlscqp_exchange_get_times",
+    "dlscqp_step_device", "dlscqp_neighbours_knn_device",
 ]

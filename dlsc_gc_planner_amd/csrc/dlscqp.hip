@@ -286,6 +286,7 @@ struct KernelArgs {
     int n_blocks;                    // blocks of 64 consecutive agents, (n_agents + 63) / 64
     unsigned int blocks_magic;       // ceil(2^32 / n_blocks) where slot / n_blocks = umulhi(slot, magic) for every slot of the launch, else 0
     int row_pitch;                   // > 0: agent a's rows start at a * row_pitch (row_offsets is not read)
+    int ctrl_stride, goal_stride, status_stride;  // words from agent to agent in out_ctrl / out_goal / out_status (dense: M (n+1) 3, 3, 1)
     unsigned long long *out_stamps;  // [n_agents][12], diagnostic build only
     unsigned char *work;             // HBM working sets [n_agents][work_stride] of the WS_HBM kernel, else null
     size_t work_stride;
@@ -424,12 +425,12 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
     const size_t xs = (size_t)kp.dim * M * n1 + (size_t)M * a.max_slack_obs;
     plan_agent<RC, DIMS, FS, MS, KU, SU, SLK, WaveGpu>(w, kp, lay, smem, a.agents + ag, a.rows, rb, nrows_ag,
                a.sfc ? a.sfc + (size_t)ag * M * 6 : nullptr, a.max_slack_obs, a.do_goal, a.do_traj,
-               a.out_goal ? a.out_goal + (size_t)ag * 3 : nullptr,
+               a.out_goal ? a.out_goal + (size_t)ag * a.goal_stride : nullptr,
                a.out_goal_status ? a.out_goal_status + ag : nullptr,
-               a.out_ctrl ? a.out_ctrl + (size_t)ag * M * n1 * 3 : nullptr,
+               a.out_ctrl ? a.out_ctrl + (size_t)ag * a.ctrl_stride : nullptr,
                a.out_x ? a.out_x + ag * xs : nullptr, a.out_cost ? a.out_cost + ag : nullptr,
                a.out_slack_cost ? a.out_slack_cost + (size_t)ag * a.max_slack_obs : nullptr,
-               a.out_status ? a.out_status + ag : nullptr,
+               a.out_status ? a.out_status + (size_t)ag * a.status_stride : nullptr,
                a.out_iters ? a.out_iters + (size_t)ag * 4 : nullptr);
     if constexpr (WPA > 1) {  // release the helpers: the solve is over
         w.mail[0] = 1.0;
@@ -481,7 +482,11 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
 // per agent: measured on the stress batch at the end of round 2 -- 64 / 128 / 192 / 256 / 512 threads: 0.072 / 0.062 / 0.072 /
 // 0.067 / 0.085 ms (440 items fill 3.4 rounds of 128 to 86 %, and eight workgroups share a CU).
 constexpr int LSC_THREADS = 128;
-__global__ __launch_bounds__(LSC_THREADS, 4) void dlscqp_lsc_kernel(LscGenArgs g) {
+// ... and one wavefront per agent (THREADS = 64) where an agent has at most 64 items -- the synthetic swarms: five neighbours x five
+// segments; with 128 threads four fifths of the lanes had nothing to do (32 768 agents: 0.28 ms per step, the largest stage of the
+// S64 closed loop)
+template <int THREADS>
+__global__ __launch_bounds__(THREADS, 4) void dlscqp_lsc_kernel(LscGenArgs g) {
     const int k = blockIdx.x;
     if (k >= g.n_local) return;
     const int self = g.local_ids ? g.local_ids[k] : k;
@@ -494,38 +499,40 @@ __global__ __launch_bounds__(LSC_THREADS, 4) void dlscqp_lsc_kernel(LscGenArgs g
     // step went from 0.51 to 0.74 ms: the scattered plan reads and row writes cost more than the branch saves.  What does
     // pay is the pass below that computes the last segments of all pairs first, one pair per thread: 0.0955 -> 0.0877 ms.)
     const int nn = p1 - p0, items = nn * g.M;
-    __shared__ float hull_pts[18 * LSC_THREADS];
-    const HullStore hull = {hull_pts + threadIdx.x, LSC_THREADS};
+    __shared__ float hull_pts[18 * THREADS];
+    const HullStore hull = {hull_pts + threadIdx.x, THREADS};
     // the last-segment geometry of every pair first, one pair per thread (lsc_item_rows says why); pairs beyond the block's
     // capacity are computed in place
     constexpr int LAST_CAP = 160;
     __shared__ LscLast last_geo[LAST_CAP];
-    for (int j = threadIdx.x; j < nn && j < LAST_CAP; j += LSC_THREADS) last_geo[j] = lsc_last_geometry(g, self, g.nbr_ids[p0 + j]);
+    for (int j = threadIdx.x; j < nn && j < LAST_CAP; j += THREADS) last_geo[j] = lsc_last_geometry(g, self, g.nbr_ids[p0 + j]);
     __syncthreads();
     if (g.row_counts) {
         // presolve: rows implied by the agent's own box rows are dropped, the others written contiguously in their original
-        // order -- per round of LSC_THREADS items an exclusive prefix sum of the kept-row counts over the workgroup (LDS)
-        __shared__ int wave_rows[2][LSC_THREADS / 64];
+        // order -- per round of THREADS items an exclusive prefix sum of the kept-row counts over the workgroup (LDS)
+        __shared__ int wave_rows[2][THREADS / 64];
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const size_t row0 = (size_t)per * pair0;
         const int all = items + g.n_dyn * g.M;
         int base = 0;  // rows the previous rounds kept (every thread carries its own copy)
-        for (int it0 = 0, round = 0; it0 < all; it0 += LSC_THREADS, round ^= 1) {
+        for (int it0 = 0, round = 0; it0 < all; it0 += THREADS, round ^= 1) {
             const int it = it0 + (int)threadIdx.x;
             LscRows r;
             r.i0 = 6;
             bool keep[6] = {false, false, false, false, false, false};
             int cnt = 0, m = 0;
+            bool tail_skip = false;  // dlscqp_lsc_gen.tail_from: a neighbour far down the list contributes its last segments only
             if (it < items) {
                 const int j = it / g.M;
                 m = it - j * g.M;
-                lsc_item_rows(g, self, g.nbr_ids[p0 + j], m, r, hull, j < LAST_CAP ? &last_geo[j] : nullptr);
+                tail_skip = g.tail_segments > 0 && j >= g.tail_from && m < g.M - g.tail_segments;
+                if (!tail_skip) lsc_item_rows(g, self, g.nbr_ids[p0 + j], m, r, hull, j < LAST_CAP ? &last_geo[j] : nullptr);
             } else if (it < all) {
                 const int q = it - items, o = q / g.M;
                 m = q - o * g.M;
                 lsc_dyn_item_rows(g, self, o, m, r);
             }
-            if (it < all) {
+            if (it < all && !tail_skip) {
                 const float *box = g.prune_sfc ? g.prune_sfc + ((size_t)k * g.M + m) * 6 : nullptr;
                 cnt = lsc_rows_kept(g, box, r, keep);
             }
@@ -539,7 +546,7 @@ __global__ __launch_bounds__(LSC_THREADS, 4) void dlscqp_lsc_kernel(LscGenArgs g
             __syncthreads();
             int before = base;
 #pragma unroll
-            for (int w = 0; w < LSC_THREADS / 64; w++) {
+            for (int w = 0; w < THREADS / 64; w++) {
                 const int t = wave_rows[round][w];
                 before += w < wave ? t : 0;
                 base += t;
@@ -549,11 +556,11 @@ __global__ __launch_bounds__(LSC_THREADS, 4) void dlscqp_lsc_kernel(LscGenArgs g
         if (threadIdx.x == 0) g.row_counts[k] = base;
         return;
     }
-    for (int it = threadIdx.x; it < items; it += LSC_THREADS) {
+    for (int it = threadIdx.x; it < items; it += THREADS) {
         const int j = it / g.M, m = it - j * g.M;
         lsc_item(g, self, g.nbr_ids[p0 + j], m, (size_t)per * (pair0 + j), hull, j < LAST_CAP ? &last_geo[j] : nullptr);
     }
-    for (int it = threadIdx.x; it < g.n_dyn * g.M; it += LSC_THREADS) {  // dynamic obstacles after the neighbour agents
+    for (int it = threadIdx.x; it < g.n_dyn * g.M; it += THREADS) {  // dynamic obstacles after the neighbour agents
         const int o = it / g.M, m = it - o * g.M;
         lsc_dyn_item(g, self, o, m, (size_t)per * (pair0 + nn + o));
     }
@@ -607,10 +614,43 @@ __global__ __launch_bounds__(64) void dlscqp_trap_kernel(TrapArgs t) {
 // L2 reads): latency, not throughput -- so the points of a slab (several hundred in the reference's 2.5 m high worlds) are
 // spread over eight wavefronts instead of being walked 64 at a time by one (10-agent maze step: 0.96 -> see profiles/).
 constexpr int SFC_THREADS = 512;
+constexpr int SFC_WINDOW_BYTES = 56 * 1024;  // cells of the lattice-point table a workgroup keeps in LDS for one expansion
 struct WaveSfc {
     int lane;
     int *flags;            // LDS [2][SFC_THREADS / 64]: one verdict per wavefront, double-buffered by round
     mutable int parity = 0;
+    // The part of the lattice-point table one expansion can look at (sfc_core.hpp: sfc_expand), as one byte per cell -- bit c =
+    // "corner c is within gap_max cells of an occupied cell" -- in LDS: a trial expansion then reads no global memory at all
+    // (a word of the table from L2 was ~1 us of every round of points, fifty rounds per box).  Windows that do not fit stay
+    // where they are; points outside the window (none, by construction) read the table.
+    unsigned char *win;    // LDS [SFC_WINDOW_BYTES]
+    mutable int wlo[3] = {0, 0, 0}, wn[3] = {0, 0, 0};
+    mutable bool have_window = false;
+    __device__ __forceinline__ void window_begin(const SfcWorldView &g, const int *lo, const int *hi, int gap_max) const {
+        const int n0 = hi[0] - lo[0], n1 = hi[1] - lo[1], n2 = hi[2] - lo[2];
+        const int cells = n0 * n1 * n2;
+        have_window = cells > 0 && cells <= SFC_WINDOW_BYTES;  // uniform
+        if (!have_window) return;
+        for (int k = 0; k < 3; k++) { wlo[k] = lo[k]; wn[k] = hi[k] - lo[k]; }
+        for (int base = 0; base < cells; base += SFC_THREADS) {  // uniform trip count; consecutive threads walk z: consecutive words
+            const int e = base + lane;
+            const int ec = e < cells ? e : cells - 1;
+            const int c2 = ec % n2, ab = ec / n2, c1 = ab % n1, c0 = ab / n1;
+            const uint32_t word = g.gaps[((size_t)(lo[0] + c0) * g.n[1] + (lo[1] + c1)) * g.n[2] + (lo[2] + c2)];
+            win[ec] = (unsigned char)sfc_gap_mask(word, gap_max);  // (lanes past the end rewrite the last cell with its own value)
+        }
+        __syncthreads();
+    }
+    __device__ __forceinline__ bool corner_blocked(const SfcWorldView &g, int ic, int jc, int kc, int corner, int gap_max) const {
+        const int a = ic - wlo[0], b = jc - wlo[1], c = kc - wlo[2];
+        const bool in_win = have_window & (a >= 0) & (b >= 0) & (c >= 0) & (a < wn[0]) & (b < wn[1]) & (c < wn[2]);
+        if (__ballot(!in_win) == 0ull) {  // wave-uniform: every point of the wavefront is in the window (always, by construction)
+            const uint32_t m = win[(a * wn[1] + b) * wn[2] + c];
+            return ((m >> corner) & 1u) != 0u;
+        }
+        const uint32_t word = g.gaps[((size_t)ic * g.n[1] + jc) * g.n[2] + kc];
+        return (int)((word >> (4 * corner)) & 15u) <= gap_max;
+    }
     // workgroup-wide OR without a lane-divergent region (the library's __syncthreads_or has one): every lane of a
     // wavefront stores the wavefront's ballot verdict to the same word, one barrier, every thread reads all words.  The
     // buffers alternate, so a round's stores cannot meet the previous round's loads.
@@ -677,9 +717,11 @@ __global__ __launch_bounds__(SFC_THREADS) void dlscqp_sfc_kernel(SfcGenArgs a) {
     const int ag = blockIdx.x;
     if (ag >= a.n_agents) return;
     __shared__ int sfc_flags[2 * (SFC_THREADS / 64)];
+    __shared__ unsigned char sfc_window[SFC_WINDOW_BYTES];
     WaveSfc w;
     w.lane = (int)threadIdx.x;
     w.flags = sfc_flags;
+    w.win = sfc_window;
     SfcParams p;
     p.margin = a.radius[ag];
     p.grid_resolution = a.grid_resolution;
@@ -1001,6 +1043,11 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         if (a.n_blocks > 1 && (unsigned long long)a.n_slots_launch * (unsigned long long)a.n_blocks < (1ull << 32))
             a.blocks_magic = (unsigned int)(((1ull << 32) + (unsigned long long)a.n_blocks - 1) / (unsigned long long)a.n_blocks);
     }
+    a.ctrl_stride = c->M * (c->n + 1) * 3; a.goal_stride = 3; a.status_stride = 1;
+    if (b->out_record_stride > 0) {
+        if (b->out_record_stride < c->M * (c->n + 1) * 3) { g_last_error = "out_record_stride is smaller than a plan"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+        a.ctrl_stride = a.goal_stride = a.status_stride = b->out_record_stride;
+    }
     a.row_pitch = b->row_pitch > 0 ? b->row_pitch : 0;
     if (a.row_pitch > 0 && (long long)a.row_pitch * (long long)b->n_agents >= (1ll << 31)) { g_last_error = "row_pitch * n_agents exceeds 2^31 rows"; return DLSCQP_ERR_INVALID_ARGUMENT; }
     // Helper wavefronts where an agent has rows beyond the planning wavefront's register cache AND the launch is so small that
@@ -1102,6 +1149,12 @@ static int lsc_gen_args(dlscqp_ctx *c, const dlscqp_lsc_gen *gen, LscGenArgs *ou
     g.use_sfc = c->kp.use_sfc;
     g.prune_sfc = nullptr;
     g.row_counts = nullptr;
+    g.tail_from = gen->tail_from;
+    g.tail_segments = gen->tail_segments > 0 ? gen->tail_segments : 0;
+    if (g.tail_segments > 0 && (!gen->prune || g.tail_segments >= c->M || g.tail_from < 0)) {
+        g_last_error = "tail_segments: only with prune, 0 < tail_segments < M, tail_from >= 0";
+        return DLSCQP_ERR_INVALID_ARGUMENT;
+    }
     if (gen->prune) {
         if (!gen->out_row_counts || (c->kp.use_sfc && !gen->prune_sfc_boxes)) { g_last_error = "prune: null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
         if (c->kp.rsfc_mode) {
@@ -1126,7 +1179,10 @@ extern "C" int dlscqp_generate_lsc_device(dlscqp_ctx *c, const dlscqp_lsc_gen *g
     LscGenArgs g;
     const int rc = lsc_gen_args(c, gen, &g);
     if (rc != DLSCQP_SUCCESS) return rc;
-    hipLaunchKernelGGL(dlscqp_lsc_kernel, dim3(gen->n_local), dim3(LSC_THREADS), 0, (hipStream_t)stream, g);
+    if (gen->max_neighbours > 0 && (gen->max_neighbours + g.n_dyn) * c->M <= 64)
+        hipLaunchKernelGGL(dlscqp_lsc_kernel<64>, dim3(gen->n_local), dim3(64), 0, (hipStream_t)stream, g);
+    else
+        hipLaunchKernelGGL(dlscqp_lsc_kernel<LSC_THREADS>, dim3(gen->n_local), dim3(LSC_THREADS), 0, (hipStream_t)stream, g);
     HIP_TRY(hipGetLastError());
     return DLSCQP_SUCCESS;
 }
@@ -1327,6 +1383,63 @@ extern "C" int dlscqp_neighbours_device(dlscqp_ctx *c, const dlscqp_neighbour_se
     hipLaunchKernelGGL(dlscqp_nbr_scan_kernel, dim3(1), dim3(1024), 0, st, a);
     hipLaunchKernelGGL(dlscqp_nbr_scatter_kernel, dim3(nb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(dlscqp_nbr_gather_kernel, dim3(ns->n_local), dim3(64), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return DLSCQP_SUCCESS;
+}
+
+// the k nearest agents of an agent's own block (include/dlscqp.h: dlscqp_neighbours_knn_device): one wavefront per agent, k rounds
+// of "the nearest candidate beyond the one taken last" -- the candidates of a block in trips of 64, keys (distance^2, id)
+namespace {
+__global__ __launch_bounds__(64) void dlscqp_nbr_knn_kernel(dlscqp_neighbour_knn a) {
+    const int self = (int)blockIdx.x, lane = (int)threadIdx.x;
+    if (self >= a.n_total) return;
+    const int g0 = (self / a.group) * a.group, g1 = g0 + a.group < a.n_total ? g0 + a.group : a.n_total;
+    const float *ps = a.position + (size_t)self * a.position_stride;
+    const double sx = ps[0], sy = ps[1], sz = ps[2];
+    const int want = a.k < g1 - g0 - 1 ? a.k : g1 - g0 - 1;
+    double last_d = -1.0;
+    int last_id = -1;
+    for (int r = 0; r < want; r++) {  // uniform
+        double best_d = 1.7976931348623157e308;
+        int best_id = 0x7fffffff;
+        for (int c0 = g0; c0 < g1; c0 += 64) {
+            const int id = c0 + lane;
+            const int ic = id < g1 ? id : g1 - 1;
+            const float *pq = a.position + (size_t)ic * a.position_stride;
+            const double dx = (double)pq[0] - sx, dy = (double)pq[1] - sy, dz = (double)pq[2] - sz;
+            const double d = dx * dx + dy * dy + dz * dz;
+            const bool after_last = d > last_d || (d == last_d && ic > last_id);
+            const bool cand = id < g1 && ic != self && after_last;
+            const bool better = cand && (d < best_d || (d == best_d && ic < best_id));
+            best_d = better ? d : best_d;
+            best_id = better ? ic : best_id;
+        }
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) {  // wave minimum of (distance, id)
+            const double od = __shfl_xor(best_d, s, 64);
+            const int oi = __shfl_xor(best_id, s, 64);
+            const bool take = od < best_d || (od == best_d && oi < best_id);
+            best_d = take ? od : best_d;
+            best_id = take ? oi : best_id;
+        }
+        last_d = best_d;
+        last_id = best_id;
+        if (lane == 0) a.out_nbr_ids[(size_t)self * a.pitch + r] = best_id;
+    }
+    if (lane == 0) a.out_nbr_counts[self] = want;
+}
+}  // namespace
+
+extern "C" int dlscqp_neighbours_knn_device(dlscqp_ctx *c, const dlscqp_neighbour_knn *nk, void *stream) {
+    g_last_error.clear();
+    if (!c || !nk) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (nk->n_total <= 0) return DLSCQP_SUCCESS;
+    if (!nk->position || !nk->out_nbr_ids || !nk->out_nbr_counts || nk->group < 1 || nk->k < 0 || nk->k > nk->pitch || nk->position_stride < 3) {
+        g_last_error = "null buffer or invalid size";
+        return DLSCQP_ERR_INVALID_ARGUMENT;
+    }
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    hipLaunchKernelGGL(dlscqp_nbr_knn_kernel, dim3(nk->n_total), dim3(64), 0, (hipStream_t)stream, *nk);
     HIP_TRY(hipGetLastError());
     return DLSCQP_SUCCESS;
 }
@@ -1602,6 +1715,7 @@ struct dlscqp_world {
     int device;
     SfcWorldView view;  // device pointers
     void *d_near;
+    void *d_gaps;
 };
 
 extern "C" int dlscqp_world_create(dlscqp_ctx *c, const double *boxes, int32_t n_boxes, double resolution,
@@ -1617,6 +1731,7 @@ extern "C" int dlscqp_world_create(dlscqp_ctx *c, const double *boxes, int32_t n
     dlscqp_world *w = new dlscqp_world();
     w->device = c->cfg.device;
     w->d_near = nullptr;
+    w->d_gaps = nullptr;
     const size_t nc = hw.cells();
     auto fail = [&](hipError_t e, const char *what) {
         g_last_error = std::string(what) + ": " + hipGetErrorString(e);
@@ -1632,6 +1747,13 @@ extern "C" int dlscqp_world_create(dlscqp_ctx *c, const double *boxes, int32_t n
         w->view.lo[k] = hw.lo[k]; w->view.n[k] = hw.n[k];
     }
     w->view.near = (const uint32_t *)w->d_near;
+    // the lattice-point table (one word per cell): DLSCQP_SFC_RECORDS=1 keeps the kernel on the 32-byte records (tests compare the two)
+    w->view.gaps = nullptr;
+    if (!std::getenv("DLSCQP_SFC_RECORDS")) {
+        if ((e = hipMalloc(&w->d_gaps, nc * 4)) != hipSuccess) return fail(e, "hipMalloc");
+        if ((e = hipMemcpy(w->d_gaps, hw.gaps.data(), nc * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
+        w->view.gaps = (const uint32_t *)w->d_gaps;
+    }
     *out = w;
     return DLSCQP_SUCCESS;
 }
@@ -1640,6 +1762,7 @@ extern "C" void dlscqp_world_destroy(dlscqp_world *w) {
     if (!w) return;
     (void)hipSetDevice(w->device);
     if (w->d_near) (void)hipFree(w->d_near);
+    if (w->d_gaps) (void)hipFree(w->d_gaps);
     delete w;
 }
 
@@ -1959,17 +2082,19 @@ bool rccl_ok(int rc, const char *what) {
 }
 
 // one record per agent: control points, sub-goal, verdict (the int32's bits) -- E + 4 floats
-__global__ __launch_bounds__(128) void dlscqp_pack_kernel(const float *ctrl, const float *goal, const int32_t *status, float *rec, int n, int E) {
-    const int a = (int)blockIdx.x;
-    if (a >= n) return;
+// (a few hundred workgroups that walk the records' words, not one workgroup per agent: beside the plan kernels of the next step a
+// launch gets its wave slots one by one, and 32 768 two-wavefront workgroups took 0.12 ms to get theirs)
+__global__ __launch_bounds__(256) void dlscqp_pack_kernel(const float *ctrl, const float *goal, const int32_t *status, float *rec, int n, int E) {
     const int W = E + 4;
-    float *o = rec + (size_t)a * W;
-    for (int j = (int)threadIdx.x; j < W; j += 128) {
+    const size_t total = (size_t)n * W;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t a = e / W;
+        const int j = (int)(e - a * W);
         float v;
-        if (j < E) v = ctrl[(size_t)a * E + j];
-        else if (j < E + 3) v = goal[(size_t)a * 3 + (j - E)];
+        if (j < E) v = ctrl[a * E + j];
+        else if (j < E + 3) v = goal[a * 3 + (j - E)];
         else v = __int_as_float(status[a]);
-        o[j] = v;
+        rec[e] = v;
     }
 }
 }  // namespace
@@ -1979,6 +2104,7 @@ struct dlscqp_exchange {
     void *comm = nullptr;                    // ncclComm_t
     hipStream_t comm_stream = nullptr, join_stream = nullptr;
     float *send[2] = {nullptr, nullptr}, *recv[2] = {nullptr, nullptr};
+    bool own_recv = true;
     hipEvent_t ready[2] = {nullptr, nullptr}, packed[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
     bool posted[2] = {false, false};
     long long k = 0;                         // exchanges posted so far
@@ -2007,7 +2133,7 @@ extern "C" void dlscqp_exchange_destroy(dlscqp_exchange *x) {
     if (x->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(x->comm);
     for (int b = 0; b < 2; b++) {
         if (x->send[b]) (void)hipFree(x->send[b]);
-        if (x->recv[b]) (void)hipFree(x->recv[b]);
+        if (x->recv[b] && x->own_recv) (void)hipFree(x->recv[b]);
         if (x->ready[b]) (void)hipEventDestroy(x->ready[b]);
         if (x->packed[b]) (void)hipEventDestroy(x->packed[b]);
         if (x->done[b]) (void)hipEventDestroy(x->done[b]);
@@ -2047,8 +2173,10 @@ extern "C" int dlscqp_exchange_create(dlscqp_ctx *c, const dlscqp_exchange_confi
     if (hipStreamCreateWithPriority(&x->comm_stream, hipStreamNonBlocking, hi) != hipSuccess) { g_last_error = "hipStreamCreateWithPriority"; return fail(DLSCQP_ERR_HIP); }
     if (hipStreamCreateWithFlags(&x->join_stream, hipStreamNonBlocking) != hipSuccess) { g_last_error = "hipStreamCreate"; return fail(DLSCQP_ERR_HIP); }
     const size_t sb = (size_t)x->n_local * x->W * sizeof(float), rb = sb * (size_t)x->world;
+    x->own_recv = !(cfg->recv_buffers[0] && cfg->recv_buffers[1]);
     for (int b = 0; b < 2; b++) {
-        if (hipMalloc((void **)&x->send[b], sb) != hipSuccess || hipMalloc((void **)&x->recv[b], rb) != hipSuccess) { g_last_error = "hipMalloc(exchange buffers)"; return fail(DLSCQP_ERR_HIP); }
+        if (!x->own_recv) x->recv[b] = cfg->recv_buffers[b];
+        if (hipMalloc((void **)&x->send[b], sb) != hipSuccess || (x->own_recv && hipMalloc((void **)&x->recv[b], rb) != hipSuccess)) { g_last_error = "hipMalloc(exchange buffers)"; return fail(DLSCQP_ERR_HIP); }
         if (hipEventCreateWithFlags(&x->ready[b], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&x->packed[b], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&x->done[b], hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate"; return fail(DLSCQP_ERR_HIP); }
     }
@@ -2096,29 +2224,49 @@ extern "C" int dlscqp_exchange_before_overwrite(dlscqp_exchange *x, void *stream
     return DLSCQP_SUCCESS;
 }
 
+static int exchange_post(dlscqp_exchange *x, const float *ctrl, const float *goal, const int32_t *status, const float *records, void *ready_stream);
+
 extern "C" int dlscqp_exchange_post(dlscqp_exchange *x, const float *ctrl, const float *goal, const int32_t *status, void *ready_stream) {
     g_last_error.clear();
     if (!x || !ctrl || !goal || !status) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    return exchange_post(x, ctrl, goal, status, nullptr, ready_stream);
+}
+
+extern "C" int dlscqp_exchange_post_records(dlscqp_exchange *x, const float *records, void *ready_stream) {
+    g_last_error.clear();
+    if (!x || !records) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    return exchange_post(x, nullptr, nullptr, nullptr, records, ready_stream);
+}
+
+static int exchange_post(dlscqp_exchange *x, const float *ctrl, const float *goal, const int32_t *status, const float *records, void *ready_stream) {
     HIP_TRY(hipSetDevice(x->device));
     const int b = (int)(x->k & 1);
     x->k++;
     const bool timed = x->t_used < x->t_cap;
     hipEvent_t *te = timed ? &x->tev[4 * (size_t)x->t_used] : nullptr;
     // the communication stream is in order behind exchange k - 2, which used the same buffers
-    HIP_TRY(hipEventRecord(x->ready[b], (hipStream_t)ready_stream));
+    if ((hipStream_t)ready_stream != x->comm_stream) {  // (dlscqp_step_device makes the communication stream wait for the launches itself)
+        HIP_TRY(hipEventRecord(x->ready[b], (hipStream_t)ready_stream));
+        HIP_TRY(hipStreamWaitEvent(x->comm_stream, x->ready[b], 0));
+    }
     if (timed) HIP_TRY(hipEventRecord(te[0], (hipStream_t)ready_stream));
-    HIP_TRY(hipStreamWaitEvent(x->comm_stream, x->ready[b], 0));
     if (timed) HIP_TRY(hipEventRecord(te[1], x->comm_stream));
-    hipLaunchKernelGGL(dlscqp_pack_kernel, dim3(x->n_local), dim3(128), 0, x->comm_stream, ctrl, goal, status, x->send[b], x->n_local, x->E);
+    const float *src = records ? records : x->send[b];
+    if (!records) {
+        const size_t words = (size_t)x->n_local * x->W;
+        const int grid = (int)std::min<size_t>((words + 255) / 256, 512);
+        hipLaunchKernelGGL(dlscqp_pack_kernel, dim3(grid), dim3(256), 0, x->comm_stream, ctrl, goal, status, x->send[b], x->n_local, x->E);
+    }
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(x->packed[b], x->comm_stream));
+    if (!records) HIP_TRY(hipEventRecord(x->packed[b], x->comm_stream));  // the caller's three arrays have been read
     if (timed) HIP_TRY(hipEventRecord(te[2], x->comm_stream));
     if (x->local_only) {
-        HIP_TRY(hipMemcpyAsync(x->recv[b], x->send[b], (size_t)x->n_local * x->W * sizeof(float), hipMemcpyDeviceToDevice, x->comm_stream));
+        HIP_TRY(hipMemcpyAsync(x->recv[b], src, (size_t)x->n_local * x->W * sizeof(float), hipMemcpyDeviceToDevice, x->comm_stream));
     } else {
-        if (!rccl_ok(g_rccl.AllGather(x->send[b], x->recv[b], (size_t)x->n_local * x->W, /* ncclFloat32 */ 7, x->comm, x->comm_stream), "ncclAllGather")) return DLSCQP_ERR_HIP;
+        if (!rccl_ok(g_rccl.AllGather(src, x->recv[b], (size_t)x->n_local * x->W, /* ncclFloat32 */ 7, x->comm, x->comm_stream), "ncclAllGather")) return DLSCQP_ERR_HIP;
     }
     HIP_TRY(hipEventRecord(x->done[b], x->comm_stream));
+    if (records) HIP_TRY(hipEventRecord(x->packed[b], x->comm_stream));  // sent as they lie: read when the collective is through
     if (timed) { HIP_TRY(hipEventRecord(te[3], x->comm_stream)); x->t_used++; }
     x->posted[b] = true;
     x->last = b;
@@ -2140,7 +2288,7 @@ extern "C" int dlscqp_step_device(const dlscqp_step_args *s) {
     if (!s || s->n_groups < 1 || !s->groups) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
     dlscqp_exchange *x = s->exchange;
     const int mode = x ? s->exchange_mode : DLSCQP_EXCHANGE_NONE;
-    if (x && mode != DLSCQP_EXCHANGE_NONE && (!s->ctrl || !s->goal || !s->status)) { g_last_error = "exchange: null output table"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (x && mode != DLSCQP_EXCHANGE_NONE && !s->records && (!s->ctrl || !s->goal || !s->status)) { g_last_error = "exchange: null output table"; return DLSCQP_ERR_INVALID_ARGUMENT; }
     if (x) {
         HIP_TRY(hipSetDevice(x->device));
         while ((int)x->planned.size() < s->n_groups) {
@@ -2166,13 +2314,13 @@ extern "C" int dlscqp_step_device(const dlscqp_step_args *s) {
         if (mode != DLSCQP_EXCHANGE_NONE) HIP_TRY(hipEventRecord(x->planned[g], st));
     }
     if (mode == DLSCQP_EXCHANGE_NONE) return DLSCQP_SUCCESS;
-    for (int g = 0; g < s->n_groups; g++) HIP_TRY(hipStreamWaitEvent(x->join_stream, x->planned[g], 0));
-    int rc = dlscqp_exchange_post(x, s->ctrl, s->goal, s->status, x->join_stream);
+    // the communication stream itself waits for the groups' launches of the step (no stream in between: streams share a few
+    // hardware queues, and a stream that only waits can hold up the queue of a group it shares one with)
+    for (int g = 0; g < s->n_groups; g++) HIP_TRY(hipStreamWaitEvent(x->comm_stream, x->planned[g], 0));
+    int rc = s->records ? dlscqp_exchange_post_records(x, s->records, x->comm_stream) : dlscqp_exchange_post(x, s->ctrl, s->goal, s->status, x->comm_stream);
     if (rc != DLSCQP_SUCCESS) return rc;
     if (mode == DLSCQP_EXCHANGE_SERIAL) {
-        rc = dlscqp_exchange_wait(x, x->join_stream, nullptr);
-        if (rc != DLSCQP_SUCCESS) return rc;
-        HIP_TRY(hipEventRecord(x->table_ready, x->join_stream));
+        HIP_TRY(hipEventRecord(x->table_ready, x->comm_stream));  // (in order behind the collective)
         x->have_table_ready = true;
     }
     return DLSCQP_SUCCESS;

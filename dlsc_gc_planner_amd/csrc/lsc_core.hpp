@@ -307,6 +307,7 @@ struct LscGenArgs {  // device mirror of dlscqp_lsc_gen (include/dlscqp.h)
     // presolve (dlscqp_lsc_gen.prune_sfc_boxes): rows implied by the agent's own box rows are not written
     const float *prune_sfc;          // [n_local][M][6] corridor boxes of the local agents, or null
     int32_t *row_counts;             // [n_local] rows written per agent (with prune_sfc), or null
+    int tail_from, tail_segments;    // neighbours at list positions >= tail_from contribute their last tail_segments segments only (0: off)
     double world_min[3], world_max[3];
     int dim;
 };

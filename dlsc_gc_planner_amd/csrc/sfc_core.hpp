@@ -28,6 +28,11 @@ struct SfcWorldView {  // device (or host) pointers of a world built by build_sf
     // word 0 = squared index distance to the nearest occupied cell (-1: none within 1 m), word 1 = how many cells at that
     // distance (up to 8), words 2..7 = their offsets, 8 x 3 signed bytes
     const uint32_t *near;
+    // [cell] one word, eight nibbles: nibble (dx + 2 dy + 4 dz) = the distance, in whole cells, from corner (dx, dy, dz) of the
+    // cell to the nearest of the record's occupied cells -- what sfc_point_blocked's arithmetic comes to for a lattice point
+    // (sfc_corner_gaps) -- or 15 when the record has no occupied cell within 1 m.  The corridor routines only ever test lattice
+    // points of the grid (box corners are multiples of the resolution), so a query is this one word.  nullptr: not built.
+    const uint32_t *gaps;
 };
 
 DQ_FN int sfc_near_offset(const uint32_t *rec, int i) {  // signed byte i (0..23) of the offsets of a record
@@ -83,18 +88,89 @@ DQ_FN bool sfc_point_blocked(const W &wave, const SfcWorldView &w, const float s
     return near_obstacle & (best < margin + SFC_EPS_F);
 }
 
+// What sfc_point_blocked computes for a LATTICE point, as integers.  A lattice point is a corner of grid cells: sp_k = I_k res up
+// to float32 rounding, and coordToKey's floor puts it into cell c_k = I_k or I_k - 1 -- whichever the rounding decides: that
+// choice is the reference's and is kept (it picks the record that is read).  Given the cell, everything else is exact: the
+// L-infinity distance from the corner I = c + delta to an occupied cell O of the record is max_k gap_k cells with
+// gap_k = O_k - I_k (O_k >= I_k) or I_k - O_k - 1, and float32 noise (1e-6 m at +-20 m) cannot move gap x res across
+// margin + 1e-5 unless the margin sits within 1e-5 of a multiple of the resolution from below.  Host, once per world:
+// nibble of corner delta = min over the record's cells of max_k gap_k (15: none, or none within 1 m).
+DQ_FN uint32_t sfc_corner_gaps(const uint32_t *rec, double res) {
+    const int d2 = (int)rec[0], nt = (int)rec[1];
+    const float dist = (float)(sqrt((double)(d2 < 0 ? 0 : d2)) * res);
+    const bool near_obstacle = (d2 >= 0) & (dist < 1);
+    uint32_t word = 0;
+    for (int corner = 0; corner < 8; corner++) {
+        int best = 15;
+        for (int t = 0; near_obstacle && t < nt; t++) {
+            int linf = 0;
+            for (int k = 0; k < 3; k++) {
+                const int off = sfc_near_offset(rec, 3 * t + k) - ((corner >> k) & 1);  // O_k - I_k
+                const int gap = off >= 0 ? off : -off - 1;
+                linf = gap > linf ? gap : linf;
+            }
+            best = linf < best ? linf : best;
+        }
+        word |= (uint32_t)(best > 15 ? 15 : best) << (4 * corner);
+    }
+    return word;
+}
+
+// sfc_point_blocked for a lattice point through the table of sfc_corner_gaps: the same cell as the reference's floor, the corner
+// from the nearest integer of sp / res, one word read.
+// (W::window_masks: the words of the cells the wavefront's points fall into -- from the window of the table that W::window_begin
+// copied next to the wavefront where it has one (GPU: LDS, as bit masks "gap <= gap_max" per corner), else from the table)
+template <class W>
+DQ_FN bool sfc_lattice_point_blocked(const W &wave, const SfcWorldView &w, const float sp[3], int gap_max) {
+    int c[3], corner = 0;
+    for (int k = 0; k < 3; k++) {
+        const double sc = (1.0 / w.res) * (double)sp[k];
+        c[k] = (int)floor(sc);  // OcTreeBaseImpl::coordToKey
+        int d = (int)floor(sc + 0.5) - c[k];
+        d = d < 0 ? 0 : (d > 1 ? 1 : d);
+        corner |= d << k;
+    }
+    const int i = c[0] - w.lo[0], j = c[1] - w.lo[1], kk = c[2] - w.lo[2];
+    const bool inside = (i >= 0) & (j >= 0) & (kk >= 0) & (i < w.n[0]) & (j < w.n[1]) & (kk < w.n[2]);
+    const int ic = i < 0 ? 0 : (i >= w.n[0] ? w.n[0] - 1 : i);
+    const int jc = j < 0 ? 0 : (j >= w.n[1] ? w.n[1] - 1 : j);
+    const int kc = kk < 0 ? 0 : (kk >= w.n[2] ? w.n[2] - 1 : kk);
+    return inside & wave.corner_blocked(w, ic, jc, kc, corner, gap_max);
+}
+
+// bit `corner` of the mask "gap <= gap_max" of a word of the table
+DQ_FN uint32_t sfc_gap_mask(uint32_t word, int gap_max) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) m |= (uint32_t)((int)((word >> (4 * c)) & 15u) <= gap_max) << c;
+    return m;
+}
+
+// the largest whole number of cells g with g res < margin + 1e-5 (-1: not even 0), what `best < margin + SFC_EPS_F` admits
+DQ_FN int sfc_gap_max(double margin, double res) {
+    int g = (int)floor((margin + SFC_EPS_F) / res);
+    if (!((double)g * res < margin + SFC_EPS_F)) g--;  // an exact multiple: strictly below
+    return g > 14 ? 14 : g;
+}
+
 // isObstacleInSFC (:859-892): the lattice points of the box, 64 at a time, one per lane.  W::any_of(n, f): true if
 // f(i) holds for some i in [0, n) (GPU: ballot over the lanes, host: a loop).
 template <class W>
 DQ_FN bool sfc_obstacle_in_box(const W &w, const SfcWorldView &g, const float *b, double margin) {
     int mi[3];
-    for (int k = 0; k < 3; k++) mi[k] = (int)floor((b[3 + k] - b[k] + SFC_EPS_F) / g.res) + 1;
+    // (the reference divides by the resolution; the quotient is a whole number of cells + 1e-4, float32 noise of the box edges 1e-5 of
+    // a cell: multiplying by the reciprocal -- a third of the instructions, and this runs between any two trial expansions -- lands
+    // on the same side of the floor)
+    const double inv_res = 1.0 / g.res;
+    for (int k = 0; k < 3; k++) mi[k] = (int)floor((b[3 + k] - b[k] + SFC_EPS_F) * inv_res) + 1;
     const int total = mi[0] * mi[1] * mi[2];
+    const int gap_max = sfc_gap_max(margin, g.res);
     return w.any_of(total, [&](int idx) {
         const int c3 = idx % mi[2], ab = idx / mi[2], b2 = ab % mi[1], a1 = ab / mi[1];
         const int it[3] = {a1, b2, c3};
         float sp[3];
         for (int k = 0; k < 3; k++) sp[k] = (float)(b[k] + it[k] * g.res);
+        if (g.gaps) return sfc_lattice_point_blocked(w, g, sp, gap_max);  // uniform
         return sfc_point_blocked(w, g, sp, margin);
     });
 }
@@ -108,11 +184,24 @@ DQ_FN bool sfc_in_boundary(const SfcWorldView &g, const float *b, double margin)
 // expandSFCIncrementally, :1023-1093
 template <class W>
 DQ_FN bool sfc_expand(const W &w, const SfcWorldView &g, const SfcParams &p, const float *init, float *out) {
+    const double mx = 2 * p.grid_resolution > p.agent_max_vel * p.dt ? 2 * p.grid_resolution : p.agent_max_vel * p.dt;
+    const int max_iter = (int)round(mx / g.res) + 1;
+    if (g.gaps) {
+        // everything this expansion can look at: the initial box and max_iter + 1 slabs on every side (+ the cell below a
+        // lattice point that coordToKey's floor may pick), inside the grid.  The GPU copies that part of the table into LDS.
+        int lo[3], hi[3];
+        for (int k = 0; k < 3; k++) {
+            lo[k] = (int)floor((double)init[k] / g.res) - max_iter - 3 - g.lo[k];
+            hi[k] = (int)ceil((double)init[3 + k] / g.res) + max_iter + 3 - g.lo[k];
+            lo[k] = lo[k] < 0 ? 0 : lo[k];
+            hi[k] = hi[k] > g.n[k] ? g.n[k] : hi[k];
+            hi[k] = hi[k] < lo[k] ? lo[k] : hi[k];
+        }
+        w.window_begin(g, lo, hi, sfc_gap_max(p.margin, g.res));
+    }
     if (sfc_obstacle_in_box(w, g, init, p.margin)) return false;
     float sfc[6], cand[6], upd[6];
     int axis_cand[6] = {0, 1, 2, 3, 4, 5}, n_cand = 6;  // -x -y -z +x +y +z
-    const double mx = 2 * p.grid_resolution > p.agent_max_vel * p.dt ? 2 * p.grid_resolution : p.agent_max_vel * p.dt;
-    const int max_iter = (int)round(mx / g.res) + 1;
     int axis_iter[6] = {0, 0, 0, 0, 0, 0};
     int i = -1;
     for (int k = 0; k < 6; k++) sfc[k] = init[k];

@@ -69,6 +69,8 @@ void build_sfc_world(const double *boxes, int n_boxes, double resolution, const 
         rec[1] = (uint32_t)w.near_n[q];
         for (int i = 0; i < 24; i++) rec[2 + (i >> 2)] |= (uint32_t)(uint8_t)w.near_off[q * 24 + i] << (8 * (i & 3));
     }
+    w.gaps.assign(nc, 0u);
+    for (size_t q = 0; q < nc; q++) w.gaps[q] = sfc_corner_gaps(&w.near_packed[q * 8], resolution);
 }
 
 }  // namespace dlscqp

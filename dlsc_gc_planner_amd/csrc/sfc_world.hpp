@@ -16,6 +16,7 @@ struct SfcWorldHost {
     std::vector<signed char> near_off;
     std::vector<unsigned char> near_n;
     std::vector<uint32_t> near_packed;  // the three arrays above as one 32-byte record per cell (SfcWorldView::near)
+    std::vector<uint32_t> gaps;         // sfc_corner_gaps of every record (SfcWorldView::gaps)
     size_t cells() const { return (size_t)n[0] * n[1] * n[2]; }
 };
 

@@ -116,7 +116,7 @@ class SpinObstacles:
 class ClosedLoop:
     def __init__(self, cfg, start, goal, radius=0.15, downwash=2.0, max_vel=1.0, max_acc=2.0, nominal_velocity=1.0,
                  waypoint_step=0.5, device=0, dyn=None, result_csv=None, world=None, neighbours=None, nbr_pitch=96,
-                 corridor_margin=None, prune=False, order_hint=False):
+                 corridor_margin=None, prune=False, order_hint=False, knn=None, tail=None):
         """dyn: None or dict(position [D,3], velocity [D,3], radius, max_acc, downwash [D], size_prediction, horizon) --
         obstacles that keep their velocity (obstacle.hpp: straight-line dynamic obstacles).  result_csv: path of a
         result file in the reference's layout.  world: None or dict(boxes [K,6] centre+size, resolution, grid_resolution)
@@ -127,7 +127,9 @@ class ClosedLoop:
         box per segment, the bounding box of the segment's control points of the initial trajectory grown by that many metres
         (a stand-in for the boxes the octomap corridor generator would grow in a crowded maze).  prune: the generator's
         presolve.  order_hint: every launch in the order of the two previous steps' iteration counts, found by the plan kernel
-        itself (dlscqp_device_batch.hint_iters)."""
+        itself (dlscqp_device_batch.hint_iters).  neighbours="knn", knn=(group, k): the synthetic swarms' rule -- the k nearest
+        agents of the agent's own block of `group` consecutive ids (dlscqp_neighbours_knn_device); tail=(tail_from, tail_segments):
+        dlscqp_lsc_gen.tail_from (needs prune): BASELINE.json configs[1] is knn=(64, 5), tail=(4, 2): 120 rows per agent."""
         import torch
         self.torch = torch
         self.cfg = cfg
@@ -158,6 +160,9 @@ class ClosedLoop:
             assert cfg.communication_range > 0
             nbr_pitch = min(int(nbr_pitch), max(N - 1, 1))
             nbr_ids, nbr_offsets = np.zeros(N * nbr_pitch, np.int32), np.arange(N + 1) * nbr_pitch
+        elif neighbours == "knn":
+            nbr_pitch = int(knn[1])
+            nbr_ids, nbr_offsets = np.zeros(N * nbr_pitch, np.int32), np.arange(N + 1) * nbr_pitch
         else:
             nbr_ids = np.concatenate([np.delete(ids, a) for a in range(N)]) if N > 1 else np.zeros(0, np.int32)
             nbr_offsets = np.arange(N + 1) * (N - 1)
@@ -174,6 +179,9 @@ class ClosedLoop:
                                                dyn=dyn)
         if neighbours == "device":
             self.nbr = self.opt.make_neighbour_search(self.gen, nbr_pitch)
+        elif neighbours == "knn":
+            self.nbr = self.opt.make_knn_search(self.gen, knn[0], knn[1])
+            assert prune, "lists of the k nearest: the generator counts the rows it writes (prune=True)"
         self.world = world
         self.sfc = None
         self.box_margin = None
@@ -228,6 +236,12 @@ class ClosedLoop:
         self.row_counts = None
         if prune:
             self.row_counts = self.gen.enable_pruning(self.sfc.sfcs if self.sfc is not None else (self.box_t if self.box_margin is not None else None))
+            if tail is not None:
+                # the rows an agent can have at most: what picks the kernel instantiation and sizes its caches
+                self.gen.set_tail(*tail)
+                per = cfg.M * (cfg.n + 1)
+                full = min(int(tail[0]), nbr_pitch)
+                self.batch.c.max_rows_per_agent = full * (per - cfg.phi) + (nbr_pitch - full) * int(tail[1]) * (cfg.n + 1) + self.D * (per - cfg.phi)
         elif self.nbr is not None:
             self.row_counts = self.nbr.row_counts
         if self.row_counts is not None:
@@ -582,7 +596,7 @@ class ShardedLoop:
                                              waypoint_step=waypoint_step)
         E = M * (n + 1) * 3
         self.E = E
-        self.xchg = sharding.PlanExchange(dist, world, self.pad, (E, 3, 1), dev)
+        self.xchg = sharding.make_exchange(self.opt, dist, rank, world, self.pad, dev)  # RCCL from the library itself; gloo: torch.distributed
         self.send_plans = torch.zeros((self.pad, E), dtype=torch.float32, device=dev)
         self.send_goal = torch.zeros((self.pad, 3), dtype=torch.float32, device=dev)
         self.send_status = torch.zeros((self.pad, 1), dtype=torch.int32, device=dev)

@@ -134,6 +134,11 @@ class BatchTrajOptimizer:
         (dlscqp_neighbours_device; `gen` must have been made with nbr_offsets = arange(n_local + 1) * pitch)."""
         return NeighbourSearch(self, gen, pitch, device)
 
+    def make_knn_search(self, gen, group, k, device=None):
+        """The synthetic swarms' neighbour rule on the device (dlscqp_neighbours_knn_device): the k nearest agents of an agent's own
+        block of `group` consecutive ids; `gen` must have been made with nbr_offsets = arange(n + 1) * k and no local_ids."""
+        return KnnSearch(self, gen, group, k, device)
+
     def make_sfc_generator(self, boxes, resolution, world_min, world_max, radius, max_vel, grid_resolution, device=None):
         """Device-resident safe-flight-corridor generator for a world given as axis-aligned boxes."""
         return SfcGenerator(self, boxes, resolution, world_min, world_max, radius, max_vel, grid_resolution, device)
@@ -347,6 +352,23 @@ class DeviceBatch:
         assert ctrl.dtype == self.out_ctrl.dtype and goal.dtype == self.out_goal.dtype and status.dtype == self.out_status.dtype
         self.out_ctrl, self.out_goal, self.out_status = ctrl, goal, status
         self.c.out_ctrl, self.c.out_goal, self.c.out_status = ctrl.data_ptr(), goal.data_ptr(), status.data_ptr()
+        self.c.out_record_stride = 0
+
+    def use_records(self, rec):
+        """Write control points, sub-goal and status as ONE record per agent (dlscqp_device_batch.out_record_stride): `rec` is a
+        float32 CUDA tensor [n_agents, M (n+1) 3 + 4] with contiguous rows (a slice of the table an exchange sends as it lies:
+        NativeExchange.post_records).  out_ctrl / out_goal / out_status become views of it."""
+        torch = self.torch
+        cfg = self.opt.cfg
+        E = cfg.M * (cfg.n + 1) * 3
+        assert rec.dtype == torch.float32 and rec.shape == (self.n_agents, E + 4) and rec.stride(1) == 1 and rec.stride(0) == E + 4
+        self._rec = rec
+        self.out_ctrl = rec[:, :E].view(self.n_agents, cfg.M, cfg.n + 1, 3)
+        self.out_goal = rec[:, E:E + 3]
+        self.out_status = rec[:, E + 3:E + 4].view(torch.int32)[:, 0]
+        p = rec.data_ptr()
+        self.c.out_ctrl, self.c.out_goal, self.c.out_status = p, p + 4 * E, p + 4 * (E + 3)
+        self.c.out_record_stride = E + 4
 
     def launch(self, do_goal=True, do_traj=True, stream=None, offset=0, count=0):
         """Asynchronous launch on `stream` (default: torch's current stream); `offset`/`count` restrict it to a
@@ -412,6 +434,7 @@ class LscGenerator:
             g.dyn_uncertainty_horizon = float(dyn.get("horizon", 1.0))
             g.dyn_radius, g.dyn_max_acc = self.t["dyn_radius"].data_ptr(), self.t["dyn_max_acc"].data_ptr()
             g.dyn_downwash = self.t["dyn_downwash"].data_ptr()
+        g.max_neighbours = int(np.diff(nbr_offsets).max()) if self.n_local else 0  # the longest list (set_neighbours updates it)
         self.c = g
         self.n_total = n_total
 
@@ -422,6 +445,7 @@ class LscGenerator:
         nbr_offsets = np.ascontiguousarray(nbr_offsets, dtype=np.int32)
         nbr_ids = np.ascontiguousarray(nbr_ids, dtype=np.int32)
         assert len(nbr_offsets) == self.n_local + 1 and len(nbr_ids) <= len(self.t["nbr_ids"])
+        self.c.max_neighbours = int(np.diff(nbr_offsets).max()) if self.n_local else 0
         pairs = nbr_offsets.astype(np.int64) + self.n_dyn * np.arange(self.n_local + 1)
         assert self.per * int(pairs[-1]) + 64 <= len(self.soa["d"])
         self.t["nbr_offsets"].copy_(self.torch.from_numpy(nbr_offsets))
@@ -442,6 +466,11 @@ class LscGenerator:
         s = self.torch.cuda.current_stream(self.device) if stream is None else stream
         rc = self.opt.lib.dlscqp_waypoint_trap_device(self.opt.handle, C.byref(self.c), C.byref(t), C.c_void_p(s.cuda_stream))
         self.opt._check(rc, "dlscqp_waypoint_trap_device")
+
+    def set_tail(self, tail_from, tail_segments):
+        """dlscqp_lsc_gen.tail_from / tail_segments: neighbours at list positions >= tail_from contribute only their last
+        tail_segments segments (the synthetic swarms: 4 x 27 + 12 rows).  Needs enable_pruning()."""
+        self.c.tail_from, self.c.tail_segments = int(tail_from), int(tail_segments)
 
     def enable_pruning(self, sfcs=None):
         """Presolve inside the generator (dlscqp_lsc_gen.prune): half-spaces implied by the agent's corridor / world box are not
@@ -547,6 +576,42 @@ class NeighbourSearch:
 
     def lists_host(self):
         """(counts, ids [n_local, pitch]) on the host (tests)."""
+        self.torch.cuda.synchronize(self.device)
+        n = self.gen.n_local
+        return self.counts.cpu().numpy(), self.gen.t["nbr_ids"][:n * self.pitch].cpu().numpy().reshape(n, self.pitch)
+
+
+class KnnSearch:
+    """dlscqp_neighbours_knn_device: every step the lists of a LscGenerator with lists of pitch k are rebuilt from the agents'
+    positions: the k nearest agents of the agent's own block of `group` consecutive ids (a swarm).  Same interface as
+    NeighbourSearch (search, counts, lists_host); `overflow` stays 0 (a list is never cut)."""
+
+    def __init__(self, opt, gen, group, k, device):
+        import torch
+        self.torch, self.opt, self.gen = torch, opt, gen
+        dev = gen.device if device is None else torch.device("cuda", device)
+        self.device = dev
+        n = gen.n_local
+        assert gen.t["local_ids"] is None and gen.n_total == n
+        self.pitch = int(k)
+        assert np.array_equal(gen.t["nbr_offsets"].cpu().numpy(), np.arange(n + 1) * self.pitch), "the generator's lists must have pitch k"
+        self.counts = torch.zeros(n, dtype=torch.int32, device=dev)
+        self.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        gen.c.nbr_counts = self.counts.data_ptr()
+        c = abi.NeighbourKnn()
+        c.n_total, c.group, c.k, c.pitch = n, int(group), int(k), self.pitch
+        c.out_nbr_ids, c.out_nbr_counts = gen.t["nbr_ids"].data_ptr(), self.counts.data_ptr()
+        self.c = c
+
+    def search(self, position, stream=None):
+        assert position.dtype == self.torch.float32 and position.stride(1) == 1
+        self.c.position, self.c.position_stride = position.data_ptr(), int(position.stride(0))
+        self._keep = position
+        s = self.torch.cuda.current_stream(self.device) if stream is None else stream
+        rc = self.opt.lib.dlscqp_neighbours_knn_device(self.opt.handle, C.byref(self.c), C.c_void_p(s.cuda_stream))
+        self.opt._check(rc, "dlscqp_neighbours_knn_device")
+
+    def lists_host(self):
         self.torch.cuda.synchronize(self.device)
         n = self.gen.n_local
         return self.counts.cpu().numpy(), self.gen.t["nbr_ids"][:n * self.pitch].cpu().numpy().reshape(n, self.pitch)

@@ -201,3 +201,158 @@ class PlanExchange:
             out.append(col)
             o += w
         return out
+
+
+def exchange_unique_id(lib, dist=None, rank=0, src=0):
+    """The 128 bytes every rank hands to dlscqp_exchange_create: made by rank `src` (dlscqp_exchange_unique_id = ncclGetUniqueId) and
+    passed on over the host's own channel -- here torch.distributed's object broadcast (any backend); dist=None: one rank."""
+    import ctypes as C
+    from . import abi
+    buf = (C.c_char * abi.EXCHANGE_ID_BYTES)()
+    if dist is None or rank == src:
+        rc = lib.dlscqp_exchange_unique_id(C.cast(buf, C.c_void_p))
+        if rc != abi.SUCCESS:
+            raise RuntimeError("dlscqp_exchange_unique_id failed (%d): %s" % (rc, lib.dlscqp_last_error().decode()))
+    if dist is not None and dist.get_world_size() > 1:
+        box = [bytes(buf.raw)]
+        dist.broadcast_object_list(box, src=src)
+        buf.raw = box[0]
+    return bytes(buf.raw)
+
+
+class NativeExchange:
+    """The per-step exchange of the solved plans issued by the library itself (include/dlscqp.h: dlscqp_exchange_*): ONE
+    ncclAllGather from librccl on a communication stream the exchange owns -- no torch.distributed call on the data path, whose
+    host cost per collective (~0.08 ms) bounded the step of round 3.  Same record layout and the same post / before_overwrite /
+    table / unpack interface as PlanExchange (which stays for the CPU tier's gloo tests); torch only owns the memory of the two
+    gathered tables, so that `table()` can hand them out as tensors.
+    opt: BatchTrajOptimizer of this rank's device; unique_id: exchange_unique_id(...) (None with world == 1); local_only: world 1
+    without librccl (the "collective" is a device copy)."""
+
+    def __init__(self, opt, rank, world, n_local, unique_id=None, local_only=False):
+        import ctypes as C
+        import torch
+        from . import abi
+        self.torch, self.C, self.abi, self.opt, self.lib = torch, C, abi, opt, opt.lib
+        cfg = opt.cfg
+        self.device = torch.device("cuda", cfg.device)
+        self.rank, self.world, self.n_local = rank, world, n_local
+        E = cfg.M * (cfg.n + 1) * 3
+        self.widths = (E, 3, 1)
+        self.W = E + 4
+        self.recv = [torch.zeros((world * n_local, self.W), dtype=torch.float32, device=self.device) for _ in range(2)]
+        c = abi.ExchangeConfig()
+        c.rank, c.world, c.n_local, c.local_only = rank, world, n_local, int(bool(local_only))
+        self._id = None if unique_id is None else C.create_string_buffer(unique_id, abi.EXCHANGE_ID_BYTES)
+        c.unique_id = None if self._id is None else C.cast(self._id, C.c_void_p)
+        for b in range(2):
+            c.recv_buffers[b] = self.recv[b].data_ptr()
+        h = C.c_void_p()
+        rc = self.lib.dlscqp_exchange_create(opt.handle, C.byref(c), C.byref(h))
+        if rc != abi.SUCCESS:
+            raise RuntimeError("dlscqp_exchange_create failed (%d): %s" % (rc, self.lib.dlscqp_last_error().decode()))
+        self.handle = h
+        self.k = 0
+        self.last = None
+        self._timed = 0
+        self._waits = []
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.dlscqp_exchange_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != self.abi.SUCCESS:
+            raise RuntimeError("%s failed (%d): %s" % (what, rc, self.lib.dlscqp_last_error().decode()))
+
+    def _stream(self, stream):
+        s = self.torch.cuda.current_stream(self.device) if stream is None else stream
+        return self.C.c_void_p(s.cuda_stream)
+
+    def post(self, ctrl, goal, status, pack_on_comm=True, stream=None):
+        """ctrl [n_local, ...] float32, goal [n_local, 3] float32, status [n_local(, 1)] int32, contiguous CUDA tensors, complete on
+        `stream` (default: the current one).  The packing always runs on the communication stream (pack_on_comm is accepted for
+        PlanExchange's callers): keep the tensors untouched until before_overwrite() ahead of the launch after next."""
+        torch = self.torch
+        assert ctrl.is_contiguous() and goal.is_contiguous() and status.is_contiguous()
+        assert ctrl.dtype == torch.float32 and goal.dtype == torch.float32 and status.dtype == torch.int32
+        assert ctrl.numel() == self.n_local * self.widths[0] and goal.numel() == self.n_local * 3 and status.numel() == self.n_local
+        self._keep = (ctrl, goal, status)
+        self._check(self.lib.dlscqp_exchange_post(self.handle, ctrl.data_ptr(), goal.data_ptr(), status.data_ptr(), self._stream(stream)),
+                    "dlscqp_exchange_post")
+        self.last = self.k & 1
+        self.k += 1
+
+    def post_records(self, records, stream=None):
+        """records [n_local, W] float32, contiguous: what the plan kernel wrote with DeviceBatch.use_records -- sent as it lies, no
+        packing pass; untouched until before_overwrite() ahead of the launch after next (it then waits for the collective)."""
+        assert records.is_contiguous() and records.dtype == self.torch.float32 and records.shape == (self.n_local, self.W)
+        self._keep = (records,)
+        self._check(self.lib.dlscqp_exchange_post_records(self.handle, records.data_ptr(), self._stream(stream)), "dlscqp_exchange_post_records")
+        self.last = self.k & 1
+        self.k += 1
+
+    def before_overwrite(self, stream=None):
+        self._check(self.lib.dlscqp_exchange_before_overwrite(self.handle, self._stream(stream)), "dlscqp_exchange_before_overwrite")
+
+    def table(self, stream=None):
+        """Make `stream` (default: the current one) wait for the exchange posted last; returns the gathered [world * n_local, W] table."""
+        torch = self.torch
+        cur = torch.cuda.current_stream(self.device) if stream is None else stream
+        if self._timed:  # how long the consumer's stream stands still for the table
+            w0 = torch.cuda.Event(enable_timing=True)
+            w0.record(cur)
+        self._check(self.lib.dlscqp_exchange_wait(self.handle, self._stream(stream), None), "dlscqp_exchange_wait")
+        if self._timed:
+            w1 = torch.cuda.Event(enable_timing=True)
+            w1.record(cur)
+            self._waits.append((w0, w1))
+        return self.recv[self.last]
+
+    def unpack(self, table, dtypes=None):
+        out, o = [], 0
+        for i, w in enumerate(self.widths):
+            col = table[:, o:o + w]
+            if dtypes is not None and dtypes[i] != self.torch.float32:
+                col = col.contiguous().view(dtypes[i])
+            out.append(col)
+            o += w
+        return out
+
+    def enable_timing(self, on=True, capacity=4096):
+        self._timed = capacity if on else 0
+        self._waits = []
+        self._check(self.lib.dlscqp_exchange_set_timing(self.handle, self._timed), "dlscqp_exchange_set_timing")
+
+    def times(self):
+        """ms per exchange: 'pack', 'all_gather', 'lag' (plans ready on the compute side -> table gathered); 'wait': how long the
+        stream given to table() stood still for the gathered table (one entry per table() call)."""
+        import numpy as np
+        C = self.C
+        if not self._timed:
+            return {}
+        self.torch.cuda.synchronize(self.device)
+        cap = self._timed
+        p, a, l = (np.zeros(cap, np.float32) for _ in range(3))
+        n = C.c_int32(0)
+        self._check(self.lib.dlscqp_exchange_get_times(self.handle, p.ctypes.data, a.ctypes.data, l.ctypes.data, cap, C.byref(n)), "dlscqp_exchange_get_times")
+        return {"pack": p[:n.value].astype(float), "all_gather": a[:n.value].astype(float), "lag": l[:n.value].astype(float),
+                "wait": np.array([w0.elapsed_time(w1) for w0, w1 in self._waits])}
+
+
+def make_exchange(opt, dist, rank, world, n_local, device):
+    """The exchange a sharded loop uses: the library's own (NativeExchange: RCCL called from C) on GPUs with an RCCL-capable group or
+    no group at all; PlanExchange over torch.distributed otherwise (gloo: the CPU tier, and the two-ranks-on-one-device test hook)."""
+    backend = None if dist is None else dist.get_backend()
+    if device.type == "cuda" and backend in (None, "nccl"):
+        uid = exchange_unique_id(opt.lib, dist, rank) if world > 1 else None
+        return NativeExchange(opt, rank, world, n_local, uid)
+    E = opt.cfg.M * (opt.cfg.n + 1) * 3
+    return PlanExchange(dist, world, n_local, (E, 3, 1), device)

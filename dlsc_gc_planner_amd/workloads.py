@@ -306,6 +306,33 @@ def generate(cfg, solver, n_swarms=1, swarm_size=64, seed=2000, steps=6, infeasi
     return out
 
 
+def swarm_missions(cfg, n_swarms=1, swarm_size=64, seed=2000, spread=1.0):
+    """Start and goal points of generate()'s swarms (the same random draws): [N, 3] float32 each.  For the device-resident closed
+    loop of the same workload (harness.ClosedLoop(neighbours="knn", knn=(swarm_size, 5), tail=(4, 2), prune=True))."""
+    rng = np.random.default_rng(seed)
+    dim = cfg.world_dimension
+    N = n_swarms * swarm_size
+    wmin = np.array(cfg.world_min[:]) + 1.0
+    wmax = np.array(cfg.world_max[:]) - 1.0
+    wmin[2], wmax[2] = cfg.world_min[2] + 0.5, cfg.world_max[2] - 0.5
+    side = int(np.ceil(np.sqrt(swarm_size)))
+    gx, gy = np.meshgrid(np.arange(side), np.arange(side), indexing="ij")
+    cell = np.stack([gx.ravel(), gy.ravel()], 1)[:swarm_size]
+    pitch = (wmax[:2] - wmin[:2]) / side * spread
+    pos = np.zeros((N, 3))
+    goal_final = np.zeros((N, 3))
+    for s in range(n_swarms):
+        sl = slice(s * swarm_size, (s + 1) * swarm_size)
+        jit = rng.uniform(0.2, 0.8, (swarm_size, 2))
+        pos[sl, :2] = wmin[:2] + (cell + jit) * pitch
+        pos[sl, 2] = rng.uniform(wmin[2], wmax[2], swarm_size) if dim == 3 else cfg.world_z_2d
+        perm = rng.permutation(swarm_size)
+        gj = rng.uniform(0.2, 0.8, (swarm_size, 2))
+        goal_final[sl, :2] = wmin[:2] + (cell[perm] + gj) * pitch
+        goal_final[sl, 2] = rng.uniform(wmin[2], wmax[2], swarm_size) if dim == 3 else cfg.world_z_2d
+    return pos.astype(np.float32), goal_final.astype(np.float32)
+
+
 def permute_batch(agents, row_offsets, rows, perm):
     """The same batch with agent `perm[s]` stored at index `s` (agent records and their CSR row blocks).
     Planners that keep their local agents sorted by expected cost (previous step's iteration count) get the

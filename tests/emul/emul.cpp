@@ -248,6 +248,8 @@ static dlscqp::LscGenArgs emul_lsc_args(const dlscqp_config *cfg, const dlscqp_l
     g.use_sfc = cfg->world_use_octomap ? 1 : 0;
     g.prune_sfc = gen->prune ? (g.use_sfc ? gen->prune_sfc_boxes : nullptr) : nullptr;
     g.row_counts = gen->prune ? gen->out_row_counts : nullptr;
+    g.tail_from = gen->tail_from;
+    g.tail_segments = gen->prune && gen->tail_segments > 0 ? gen->tail_segments : 0;
     g.dim = cfg->world_dimension;
     for (int k = 0; k < 3; k++) { g.world_min[k] = cfg->world_min[k]; g.world_max[k] = cfg->world_max[k]; }
     return g;
@@ -330,8 +332,12 @@ extern "C" int emul_generate_lsc(const dlscqp_config *cfg, const dlscqp_lsc_gen 
             for (int it = 0; it < all; it++) {
                 LscRows r;
                 int m;
-                if (it < items) { const int j = it / g.M; m = it - j * g.M; lsc_item_rows(g, self, g.nbr_ids[p0 + j], m, r, hull); }
-                else { const int q = it - items, o = q / g.M; m = q - o * g.M; lsc_dyn_item_rows(g, self, o, m, r); }
+                if (it < items) {
+                    const int j = it / g.M;
+                    m = it - j * g.M;
+                    if (g.tail_segments > 0 && j >= g.tail_from && m < g.M - g.tail_segments) continue;  // dlscqp_lsc_gen.tail_from
+                    lsc_item_rows(g, self, g.nbr_ids[p0 + j], m, r, hull);
+                } else { const int q = it - items, o = q / g.M; m = q - o * g.M; lsc_dyn_item_rows(g, self, o, m, r); }
                 const float *box = g.prune_sfc ? g.prune_sfc + ((size_t)k * g.M + m) * 6 : nullptr;
                 bool keep[6];
                 const int cnt = lsc_rows_kept(g, box, r, keep);
@@ -364,6 +370,12 @@ struct WaveSfcCpu {
     void store6(float *dst, const float *src) const { for (int k = 0; k < 6; k++) dst[k] = src[k]; }
     void fence() const {}
     int uniform_max8(int v) const { return v; }  // one point at a time on the host
+    // no copy of the table next to the "wavefront" on the host: every lattice point reads the table itself
+    void window_begin(const dlscqp::SfcWorldView &, const int *, const int *, int) const {}
+    bool corner_blocked(const dlscqp::SfcWorldView &g, int ic, int jc, int kc, int corner, int gap_max) const {
+        const uint32_t word = g.gaps[((size_t)ic * g.n[1] + jc) * g.n[2] + kc];
+        return (int)((word >> (4 * corner)) & 15u) <= gap_max;
+    }
 };
 }  // namespace
 
@@ -376,6 +388,7 @@ extern "C" int emul_generate_sfc(const dlscqp_config *cfg, const double *boxes, 
     v.res = hw.res;
     for (int k = 0; k < 3; k++) { v.wmin[k] = hw.wmin[k]; v.wmax[k] = hw.wmax[k]; v.lo[k] = hw.lo[k]; v.n[k] = hw.n[k]; }
     v.near = hw.near_packed.data();
+    v.gaps = std::getenv("EMUL_SFC_RECORDS") ? nullptr : hw.gaps.data();  // the lattice-point table, or the 32-byte records as in round 3
     WaveSfcCpu w;
     const int M = cfg->M, n1 = cfg->n + 1;
     for (int a = 0; a < gen->n_agents; a++) {
