@@ -222,6 +222,8 @@ class Advance(C.Structure):
         ("waypoints", C.c_void_p),
         ("desired_goal", C.c_void_p),
         ("waypoint_step", C.c_double),
+        ("waypoint_hold_on_lp_failure", C.c_int32),
+        ("reserved_", C.c_int32),
     ]
 
 

@@ -381,7 +381,7 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
             c.nx = a.rows.nx + rb; c.ny = a.rows.ny + rb; c.nz = a.rows.nz + rb;
             c.px = a.rows.px + rb; c.py = a.rows.py + rb; c.pz = a.rows.pz + rb;
             c.d = a.rows.d + rb; c.key = a.rows.key + rb;
-            c.flag = smem + lay.oFlag;
+            c.flag = smem + lay.oFlagRows;
             c.x = reinterpret_cast<const double *>(smem) + lay.oX;
             c.sigma = kp.sigma;
             c.K = K; c.Kc = Kc; c.M = kp.M; c.P = kp.M * kp.n1; c.dim = kp.dim; c.nxc = kp.dim * c.P;
@@ -613,41 +613,16 @@ __global__ __launch_bounds__(64) void dlscqp_trap_kernel(TrapArgs t) {
 // under test.  The routine is a chain of a few dozen trial expansions, each a table lookup per lattice point (dependent
 // L2 reads): latency, not throughput -- so the points of a slab (several hundred in the reference's 2.5 m high worlds) are
 // spread over eight wavefronts instead of being walked 64 at a time by one (10-agent maze step: 0.96 -> see profiles/).
-constexpr int SFC_THREADS = 512;
-constexpr int SFC_WINDOW_BYTES = 56 * 1024;  // cells of the lattice-point table a workgroup keeps in LDS for one expansion
-struct WaveSfc {
+constexpr int SFC_THREADS = 512;  // default; DLSCQP_SFC_THREADS = 64 / 128 / 256 picks another instantiation (measurements)
+template <int SFC_T>
+struct WaveSfcT {
     int lane;
-    int *flags;            // LDS [2][SFC_THREADS / 64]: one verdict per wavefront, double-buffered by round
+    int *flags;            // LDS [2][SFC_T / 64]: one verdict per wavefront, double-buffered by round
     mutable int parity = 0;
-    // The part of the lattice-point table one expansion can look at (sfc_core.hpp: sfc_expand), as one byte per cell -- bit c =
-    // "corner c is within gap_max cells of an occupied cell" -- in LDS: a trial expansion then reads no global memory at all
-    // (a word of the table from L2 was ~1 us of every round of points, fifty rounds per box).  Windows that do not fit stay
-    // where they are; points outside the window (none, by construction) read the table.
-    unsigned char *win;    // LDS [SFC_WINDOW_BYTES]
-    mutable int wlo[3] = {0, 0, 0}, wn[3] = {0, 0, 0};
-    mutable bool have_window = false;
-    __device__ __forceinline__ void window_begin(const SfcWorldView &g, const int *lo, const int *hi, int gap_max) const {
-        const int n0 = hi[0] - lo[0], n1 = hi[1] - lo[1], n2 = hi[2] - lo[2];
-        const int cells = n0 * n1 * n2;
-        have_window = cells > 0 && cells <= SFC_WINDOW_BYTES;  // uniform
-        if (!have_window) return;
-        for (int k = 0; k < 3; k++) { wlo[k] = lo[k]; wn[k] = hi[k] - lo[k]; }
-        for (int base = 0; base < cells; base += SFC_THREADS) {  // uniform trip count; consecutive threads walk z: consecutive words
-            const int e = base + lane;
-            const int ec = e < cells ? e : cells - 1;
-            const int c2 = ec % n2, ab = ec / n2, c1 = ab % n1, c0 = ab / n1;
-            const uint32_t word = g.gaps[((size_t)(lo[0] + c0) * g.n[1] + (lo[1] + c1)) * g.n[2] + (lo[2] + c2)];
-            win[ec] = (unsigned char)sfc_gap_mask(word, gap_max);  // (lanes past the end rewrite the last cell with its own value)
-        }
-        __syncthreads();
-    }
+    // one word of the lattice-point table (sfc_core.hpp: sfc_corner_gaps) per point.  (A copy of the part of the table an expansion
+    // can reach, as bytes in LDS, was built and measured in round 4: 0.178 ms per launch against 0.171 -- a trial expansion is
+    // not waiting for this read.)
     __device__ __forceinline__ bool corner_blocked(const SfcWorldView &g, int ic, int jc, int kc, int corner, int gap_max) const {
-        const int a = ic - wlo[0], b = jc - wlo[1], c = kc - wlo[2];
-        const bool in_win = have_window & (a >= 0) & (b >= 0) & (c >= 0) & (a < wn[0]) & (b < wn[1]) & (c < wn[2]);
-        if (__ballot(!in_win) == 0ull) {  // wave-uniform: every point of the wavefront is in the window (always, by construction)
-            const uint32_t m = win[(a * wn[1] + b) * wn[2] + c];
-            return ((m >> corner) & 1u) != 0u;
-        }
         const uint32_t word = g.gaps[((size_t)ic * g.n[1] + jc) * g.n[2] + kc];
         return (int)((word >> (4 * corner)) & 15u) <= gap_max;
     }
@@ -655,7 +630,7 @@ struct WaveSfc {
     // wavefront stores the wavefront's ballot verdict to the same word, one barrier, every thread reads all words.  The
     // buffers alternate, so a round's stores cannot meet the previous round's loads.
     __device__ __forceinline__ bool block_or(bool v) const {
-        constexpr int NW = SFC_THREADS / 64;
+        constexpr int NW = SFC_T / 64;
         int *fl = flags + parity * NW;
         parity ^= 1;
         fl[lane >> 6] = __ballot(v) != 0ull ? 1 : 0;
@@ -667,7 +642,7 @@ struct WaveSfc {
     }
     template <class F>
     __device__ __forceinline__ bool any_of(int n, F f) const {
-        for (int base = 0; base < n; base += SFC_THREADS) {
+        for (int base = 0; base < n; base += SFC_T) {
             const int idx = base + lane;
             const bool v = f(idx < n ? idx : n - 1) & (idx < n);  // every thread evaluates a valid point
             if (block_or(v)) return true;
@@ -713,15 +688,14 @@ struct SfcGenArgs {
     int32_t *out_code;
 };
 
-__global__ __launch_bounds__(SFC_THREADS) void dlscqp_sfc_kernel(SfcGenArgs a) {
+template <int SFC_T>
+__global__ __launch_bounds__(SFC_T) void dlscqp_sfc_kernel(SfcGenArgs a) {
     const int ag = blockIdx.x;
     if (ag >= a.n_agents) return;
-    __shared__ int sfc_flags[2 * (SFC_THREADS / 64)];
-    __shared__ unsigned char sfc_window[SFC_WINDOW_BYTES];
-    WaveSfc w;
+    __shared__ int sfc_flags[2 * (SFC_T / 64)];
+    WaveSfcT<SFC_T> w;
     w.lane = (int)threadIdx.x;
     w.flags = sfc_flags;
-    w.win = sfc_window;
     SfcParams p;
     p.margin = a.radius[ag];
     p.grid_resolution = a.grid_resolution;
@@ -1001,7 +975,7 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         g_last_error = "reduced dimension above 128 (dim*f + M*max_slack_obs) is not supported";
         return DLSCQP_ERR_UNSUPPORTED;
     }
-    MemLayout lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, kc.by_kind);
+    MemLayout lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, kc.by_kind);  // (sized again below, once the build is known)
     static const bool force_hbm = getenv("DLSCQP_DEBUG_WS") && std::string(getenv("DLSCQP_DEBUG_WS")) == "hbm";  // tests
     const bool ws_hbm = lay.bytes > LDS_LIMIT || force_hbm || c->force_instance == 2;
     KernelArgs a;
@@ -1064,6 +1038,15 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
     else if (c->force_build == 2) { wpa = false; wide = kc.fn_wide != nullptr; }
     else if (c->force_build == 3) { wpa = !ws_hbm && kc.fn_wpa != nullptr; wide = !wpa && wide; }
     kernel_t kfn = wpa ? kc.fn_wpa : (wide ? kc.fn_wide : kc.fn);
+    if (!ws_hbm && !wpa && b->max_rows_per_agent > 64 * kc.KU) {
+        // Rows beyond the register cache: what the build's occupancy leaves of a CU's LDS holds them (gi_core.hpp: "rows in LDS").
+        // Builds compiled for one wavefront per SIMD (WIDE; the shapes with two registers per vector; 2-D M = 10) run four agents
+        // per CU, the others eight.  DLSCQP_ROWS_IN_LDS=0: every such row from HBM in every pass, as before round 4 (tests).
+        static const bool rows_in_lds = !(getenv("DLSCQP_ROWS_IN_LDS") && getenv("DLSCQP_ROWS_IN_LDS")[0] == '0');
+        const bool one_per_simd = wide || kc.id == 3 || kc.id == 4 || kc.id == 5;
+        const int budget = (int)(LDS_LIMIT / (one_per_simd ? 4 : 8)) - 512;
+        if (rows_in_lds) lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, kc.by_kind, budget);
+    }
     const int attr_slot = kc.id + (wpa ? 2 * (DQ_N_INSTANCES + 1) : (wide ? DQ_N_INSTANCES + 1 : 0));
     if (!ws_hbm && lay.bytes > c->max_dyn_lds[attr_slot]) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
@@ -1357,8 +1340,10 @@ extern "C" int dlscqp_neighbours_device(dlscqp_ctx *c, const dlscqp_neighbour_se
         double cell = a.range > 0 ? a.range : std::max(ext, 1.0);
         if (ext / cell > 64.0) cell = ext / 64.0;
         a.grid.lo[k] = (float)c->cfg.world_min[k];
-        a.grid.inv_cell[k] = (float)(1.0 / (cell * (1.0 + 1e-6)));  // a hair larger than the range: float rounding of the cell
-                                                                      // index can then never separate two agents within range by two cells
+        // cells 1e-3 larger than the range: the cell index is computed in float32 with up to 64 cells per axis (rounding error up
+        // to ~4e-6 cell units), so the margin has to be well above that for two agents within range never to land two cells apart
+        // (the exact distance test filters afterwards: larger cells cost nothing in correctness)
+        a.grid.inv_cell[k] = (float)(1.0 / (cell * (1.0 + 1e-3)));
         a.grid.n[k] = a.range > 0 ? std::max(1, (int)std::floor(ext / cell) + 1) : 1;
         a.n_cells *= a.grid.n[k];
     }
@@ -1684,7 +1669,11 @@ __global__ __launch_bounds__(64) void dlscqp_advance_kernel(AdvanceArgs g) {
             }
             const double dist = dlscqp::f32_norm3(d3[0], d3[1], d3[2]);
             const float stepf = (float)a.waypoint_step, distf = (float)(dist > 1e-9 ? dist : 1e-9);
-            rec->next_waypoint[k] = dist <= a.waypoint_step ? dg[k] : p3[k] + d3[k] / distf * stepf;
+            float wpn = dist <= a.waypoint_step ? dg[k] : p3[k] + d3[k] / distf * stepf;
+            // an agent whose goal LP found no point towards its waypoint aims at its sub-goal for one step (the synthetic swarms'
+            // rule, workloads.generate; in the reference the grid planner hands out waypoints that can be reached)
+            if (a.waypoint_hold_on_lp_failure && !gok) wpn = cg;
+            rec->next_waypoint[k] = wpn;
         }
     }
 }
@@ -1784,7 +1773,11 @@ extern "C" int dlscqp_generate_sfc_device(dlscqp_ctx *c, const dlscqp_world *wor
     a.radius = gen->radius; a.max_vel = gen->max_vel;
     a.position = gen->position; a.initial_traj = gen->initial_traj; a.goals = gen->goals; a.waypoints = gen->waypoints;
     a.sfcs = gen->sfcs; a.out_code = gen->out_code;
-    hipLaunchKernelGGL(dlscqp_sfc_kernel, dim3(gen->n_agents), dim3(SFC_THREADS), 0, (hipStream_t)stream, a);
+    static const int sfc_threads = std::getenv("DLSCQP_SFC_THREADS") ? std::atoi(std::getenv("DLSCQP_SFC_THREADS")) : SFC_THREADS;
+    if (sfc_threads == 64) hipLaunchKernelGGL(dlscqp_sfc_kernel<64>, dim3(gen->n_agents), dim3(64), 0, (hipStream_t)stream, a);
+    else if (sfc_threads == 128) hipLaunchKernelGGL(dlscqp_sfc_kernel<128>, dim3(gen->n_agents), dim3(128), 0, (hipStream_t)stream, a);
+    else if (sfc_threads == 256) hipLaunchKernelGGL(dlscqp_sfc_kernel<256>, dim3(gen->n_agents), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(dlscqp_sfc_kernel<SFC_THREADS>, dim3(gen->n_agents), dim3(SFC_THREADS), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return DLSCQP_SUCCESS;
 }

@@ -75,8 +75,11 @@ struct MemLayout {
     int oMail;                         // 8 doubles: what the planning wavefront and its helper wavefronts tell each other (dlscqp.hip)
     int oDump;                         // 32 dump slots (lane & 31) for the lanes that have nothing to store, right behind S;
                                        // then two doubles that stay 0.0 (what a masked read of S is sent to)
-    int oFlag;                         // byte offset of the flags of rows beyond the register cache
+    int oFlag;                         // byte offset of the skip flags: two bytes per structured slot beyond the slot cache, then (oFlagRows)
+    int oFlagRows;                     // ONE BIT per LSC row that is priced from HBM (beyond the register cache and the LDS rows below)
     int kmax;                          // most LSC rows of one agent the layout was sized for (dlscqp_device_batch.max_rows_per_agent)
+    int cold_cap, oCold;               // rows [64 KU, 64 KU + cold_cap) of an agent are kept in the working set, decoded, 32 bytes each
+                                       // (plan_agent: "rows in LDS"); oCold in doubles
     int bytes;
 };
 
@@ -86,7 +89,9 @@ struct MemLayout {
 #define DQ_G_IN_LDS 0
 #endif
 DQ_FN bool gram_table_in_lds(int dim, int M, bool by_kind) { return DQ_G_IN_LDS || !(by_kind && dim == 2 && M == 10); }
-DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int KU, int SU, bool by_kind) {
+// lds_budget: bytes of LDS the launch lets one agent have (0: the working set proper, no rows): what is left after the working
+// set holds rows beyond the register cache.
+DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int KU, int SU, bool by_kind, int lds_budget = 0) {
     MemLayout L;
     const int nslk = kp.M * max_slack_obs;
     L.r_max = kp.dim * kp.f + nslk;  // the active rows are independent in the whitened space: never more than its dimension
@@ -95,7 +100,6 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
     const int cold_rows = kmax > 64 * KU ? kmax - 64 * KU : 0;
     const int gen_slots = by_kind ? kp.n_slots - kp.n_struct : kp.n_slots;  // the slots the generic code scans
     const int cold_slots = gen_slots > 64 * SU ? gen_slots - 64 * SU : 0;
-    L.nflag = cold_rows + 2 * cold_slots;
     L.kmax = kmax;
     int o = 0;
     L.oG = o; o += gram_table_in_lds(kp.dim, kp.M, by_kind) ? kp.P * L.ldg : 0;
@@ -108,7 +112,18 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
     L.oMail = o; o += 8;
     L.oU = o; o += L.nx_max;
     L.oLam = o; o += by_kind ? 2 * (L.nx_max + 2) : 0;
+    L.oCold = o;
+    L.cold_cap = 0;
+    if (lds_budget > 0 && cold_rows > 0) {
+        int cap = (lds_budget - (o * 8 + 2 * cold_slots + cold_rows / 8 + 48)) / 32;  // a row in the working set: 32 bytes (and no flag bit)
+        cap = cap > cold_rows ? cold_rows : cap;
+        cap &= ~1;
+        L.cold_cap = cap >= 64 ? cap : 0;
+        o += 4 * L.cold_cap;
+    }
+    L.nflag = 2 * cold_slots + (cold_rows - L.cold_cap + 7) / 8;
     L.oFlag = o * 8;
+    L.oFlagRows = L.oFlag + 2 * cold_slots;
     L.bytes = (L.oFlag + L.nflag + 1 + 15) & ~15;  // + one flag byte as the dump of the flag array
     return L;
 }
@@ -260,7 +275,7 @@ struct ColdRows {
     const float *nx, *ny, *nz, *px, *py, *pz;  // the agent's rows (RowsView + row_begin)
     const double *d;
     const uint32_t *key;
-    const unsigned char *flag;  // [K - Kc] skip flags in the working set
+    const unsigned char *flag;  // skip flags in the working set, one BIT per row from Kc on (Kc here: the first row that is priced from HBM)
     const double *x;            // control points and slack variables
     const double *tNN, *sigma;
     int K, Kc, P, M, dim, nxc, nso, phi, unit0;
@@ -281,7 +296,7 @@ DQ_FN double cold_rows_lane_best(const ColdRows &c, int l, int jb, int je, doubl
             g[u][0] = c.nx[jc]; g[u][1] = c.ny[jc]; g[u][2] = c.nz[jc];
             g[u][3] = c.px[jc]; g[u][4] = c.py[jc]; g[u][5] = c.pz[jc];
             gd[u] = c.d[jc];
-            cf0[u] = c.flag[jc - c.Kc];
+            cf0[u] = (c.flag[(jc - c.Kc) >> 3] >> ((jc - c.Kc) & 7)) & 1;
         }
 #pragma unroll
         for (int u = 0; u < CB; u++) {
@@ -742,10 +757,15 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     const double *G = base + oG;  // (or the table itself where it is, below)
     double *Rp = base + oRp, *x = base + oX, *dxl = base + oDx;
     double *blo = base + oBlo, *bhi = base + oBhi;
-    unsigned char *cold_flag = mem + lay.oFlag;
+    unsigned char *cold_flag = mem + lay.oFlag, *row_flag = mem + lay.oFlagRows;
     const int rc = dim * f;      // whitened control-point dimension
     const int r = rc + nslk;     // whitened dimension: the active rows are independent, there are never more than r
-    const int cold_rows = K - Kc;
+    // rows beyond the register cache: [Kc, Kl) decoded once into the working set ("rows in LDS": right-hand side, pivot scaling,
+    // normal, key -- 32 bytes a row, priced from there in every pass), [Kl, K) priced from HBM in every pass
+    const int Kl = ALL_CACHED ? K : (K < Kc + lay.cold_cap ? K : Kc + lay.cold_cap);
+    double *lrhs = base + lay.oCold, *liw = lrhs + lay.cold_cap;
+    float *lnx = reinterpret_cast<float *>(liw + lay.cold_cap), *lny = lnx + lay.cold_cap, *lnz = lny + lay.cold_cap;
+    uint32_t *lkey = reinterpret_cast<uint32_t *>(lnz + lay.cold_cap);
     const int odump_rp = odump - oRp;  // the dump slots as indices of Rp
     const int ozero_rp = odump_rp + 32;  // a zero: where the reads of S below its diagonal go
 
@@ -901,6 +921,67 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             double iw = DQ_RSQRT(live ? wsq : 1.0);
             DQ_KEEP(iw);
             ciw[u].at(l) = iw;
+        });
+    }
+    // ---- rows in LDS: the rows right behind the register cache, decoded like the cached ones, written once --------------------
+    // An agent of a crowd has a thousand rows and a few dozen pricing passes: priced from HBM a pass is three or four round
+    // trips of a couple of microseconds for ONE wavefront (the flown 2 048-agent crowd: 7 us a pass, up to 47 passes: the step
+    // was its slowest agent); from here a pass over the same rows is LDS reads.  Trips of CB blocks of 64 rows, every load of a
+    // trip issued before its first use; lanes past the last row recompute it (the same values to the same place).
+    if (!ALL_CACHED && Kl > Kc) {  // uniform
+        w.each([&](int l) {
+            for (int j0 = Kc; j0 < Kl; j0 += 64 * CB) {
+                uint32_t kk[CB];
+                float g[CB][6];
+                double gd[CB];
+#pragma unroll
+                for (int u = 0; u < CB; u++) {
+                    const int j = j0 + 64 * u + l;
+                    const int jc = j < Kl ? j : Kl - 1;
+                    kk[u] = Rkey[jc];
+                    g[u][0] = Rnx[jc]; g[u][1] = Rny[jc]; g[u][2] = Rnz[jc];
+                    g[u][3] = Rpx[jc]; g[u][4] = Rpy[jc]; g[u][5] = Rpz[jc];
+                    gd[u] = Rd[jc];
+                }
+#pragma unroll
+                for (int u = 0; u < CB; u++) {
+                    DQ_KEEP(kk[u]); DQ_KEEP(gd[u]);
+#pragma unroll
+                    for (int t = 0; t < 6; t++) DQ_KEEP(g[u][t]);
+                }
+#pragma unroll
+                for (int u = 0; u < CB; u++) {
+                    const int j = j0 + 64 * u + l;
+                    const int jc = (j < Kl ? j : Kl - 1) - Kc;
+                    const uint32_t key = kk[u];
+                    const int m = key & 0xFF, i = (key >> 8) & 0xF;
+                    const float nx = g[u][0], ny = g[u][1], nz = g[u][2];
+                    const bool in_model = !(((m == 0) & (i < kp.phi)) | f32_norm3_below_eps(nx, ny, nz)) & (m < M) & (i < n1);
+                    double rhs = gd[u] + (double)nx * (double)g[u][3] + (double)ny * (double)g[u][4];
+                    double nsq = (double)nx * (double)nx + (double)ny * (double)ny;
+                    const double rhs3 = rhs + (double)nz * (double)g[u][5], nsq3 = nsq + (double)nz * (double)nz;
+                    rhs = dim == 3 ? rhs3 : rhs;
+                    nsq = dim == 3 ? nsq3 : nsq;
+                    uint32_t sl = key >> 16;
+                    const bool no_such_slack = sl != 0xFFFFu && (int)sl >= nso;
+                    const uint32_t key2 = no_such_slack ? (key | 0xFFFF0000u) : key;
+                    sl = no_such_slack ? 0xFFFFu : sl;
+                    const int mi = in_model ? m * n1 + i : 0;
+                    double tnn = tNN[mi];
+                    DQ_KEEP(tnn);
+                    double wsq = nsq * tnn;
+                    double sg = kp.sigma[in_model ? m : 0];
+                    DQ_KEEP(sg);
+                    wsq = sl != 0xFFFFu ? wsq + sg * sg : wsq;
+                    const bool live = in_model & (wsq > 0);
+                    double iw = DQ_RSQRT(live ? wsq : 1.0);
+                    DQ_KEEP(iw);
+                    lrhs[jc] = live ? rhs : -NEVER;
+                    liw[jc] = iw;
+                    lnx[jc] = live ? nx : 0.0f; lny[jc] = live ? ny : 0.0f; lnz[jc] = live ? nz : 0.0f;
+                    lkey[jc] = live ? key2 : (key2 & 0xFFFF0000u);  // (a row that is not in the model: control point 0, zero normal)
+                }
+            }
         });
     }
     w.sync();
@@ -1090,15 +1171,23 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 #pragma unroll
                 for (int u = 0; u < KU; u++) cd[u].at(l) = ((l == own) & (u == uo)) ? nv : cd[u].at(l);
             });
+        } else if (unit < UL0 + Kl) {  // a row in LDS: its right-hand side, like a cached row's register
+            const double nv = on ? -NEVER : rhs;
+            w.each([&](int) { lrhs[unit - UL0 - Kc] = nv; });  // every lane, same word, same value
         } else if (unit < UX0) {
-            w.each([&](int) { cold_flag[unit - UL0 - Kc] = on ? 1 : 0; });  // every lane, same byte, same value
+            // (one bit per row: every lane reads the same byte and writes the same value back)
+            const int fi = unit - UL0 - Kl;
+            w.each([&](int) {
+                const unsigned char cur = row_flag[fi >> 3], bit = (unsigned char)(1u << (fi & 7));
+                row_flag[fi >> 3] = on ? (unsigned char)(cur | bit) : (unsigned char)(cur & ~bit);
+            });
         } else if (unit < US0) {
             const int s = unit - UX0, side = cc & 1;
             if (ALL_CACHED || s < Sc) {
                 if (side) upd(fl_shi, s & 63, s >> 6);
                 else upd(fl_slo, s & 63, s >> 6);
             } else {
-                w.each([&](int) { cold_flag[cold_rows + 2 * (s - Sc) + side] = on ? 1 : 0; });
+                w.each([&](int) { cold_flag[2 * (s - Sc) + side] = on ? 1 : 0; });
             }
         } else {
             const int s = unit - US0;
@@ -1109,10 +1198,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 
     ColdRows cold;
     cold.nx = Rnx; cold.ny = Rny; cold.nz = Rnz; cold.px = Rpx; cold.py = Rpy; cold.pz = Rpz; cold.d = Rd; cold.key = Rkey;
-    cold.flag = cold_flag; cold.x = x; cold.tNN = tNN; cold.sigma = kp.sigma;
-    cold.K = K; cold.Kc = Kc; cold.P = P; cold.M = M; cold.dim = dim; cold.nxc = nxc; cold.nso = nso; cold.phi = kp.phi; cold.unit0 = UL0;
+    cold.flag = row_flag; cold.x = x; cold.tNN = tNN; cold.sigma = kp.sigma;
+    cold.K = K; cold.Kc = Kl; cold.P = P; cold.M = M; cold.dim = dim; cold.nxc = nxc; cold.nso = nso; cold.phi = kp.phi; cold.unit0 = UL0;
     int cold_jb, cold_je;
-    cold_rows_share(Kc, K, 0, w.nw, cold_jb, cold_je);
+    cold_rows_share(Kl, K, 0, w.nw, cold_jb, cold_je);  // (helper wavefronts: no rows in LDS, Kl = Kc)
 
     for (;;) {
         // ---- most violated inactive row ---------------------------------------------------------
@@ -1234,6 +1323,48 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             }
             // rows beyond the register cache: this wavefront's share of them (all of them unless helper wavefronts price
             // the rest: W::nw > 1)
+            if (!ALL_CACHED)
+                for (int j0 = Kc; j0 < Kl; j0 += 128) {  // rows in LDS, two blocks of 64 a trip (uniform trip count)
+                    double xv[2][4], rh[2], iwv[2];
+                    float nv[2][3];
+                    uint32_t kq[2];
+                    int jr[2];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int j = j0 + 64 * u + l;
+                        jr[u] = (j < Kl ? j : Kl - 1) - Kc;
+                        kq[u] = lkey[jr[u]];
+                        rh[u] = lrhs[jr[u]]; iwv[u] = liw[jr[u]];
+                        nv[u][0] = lnx[jr[u]]; nv[u][1] = lny[jr[u]]; nv[u][2] = lnz[jr[u]];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        DQ_KEEP(kq[u]);
+                        const int m = kq[u] & 0xFF, p = m * n1 + (int)((kq[u] >> 8) & 0xF);
+                        const uint32_t sl = kq[u] >> 16;
+                        xv[u][0] = x[p]; xv[u][1] = x[P + p]; xv[u][2] = dim == 3 ? x[2 * P + p] : 0.0;
+                        if (SLK != 0) {  // (read by every lane through a valid index, then selected: no lane-guarded load)
+                            const bool has_slack = sl != 0xFFFFu;
+                            double xs = x[nxc + (has_slack ? (int)sl * M + m : 0)];
+                            DQ_KEEP(xs);
+                            xv[u][3] = has_slack ? xs : 0.0;
+                        } else {
+                            xv[u][3] = 0.0;
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; u++) { DQ_KEEP(xv[u][0]); DQ_KEEP(xv[u][1]); DQ_KEEP(xv[u][2]); DQ_KEEP(xv[u][3]); DQ_KEEP(rh[u]); DQ_KEEP(iwv[u]); }
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        double val = (double)nv[u][0] * xv[u][0];
+                        val = fma((double)nv[u][1], xv[u][1], val);
+                        if (dim == 3) val = fma((double)nv[u][2], xv[u][2], val);
+                        if (SLK != 0) val -= xv[u][3];
+                        const double v = (rh[u] - VIOL_TOL) - val;
+                        // (a lane past the last row has priced the last row again: the same score under the same code)
+                        bs = DQ_SCORE_MAX(bs, tag_score(v * iwv[u], (uint32_t)(UL0 + Kc + jr[u]) << 3));
+                    }
+                }
             if (!ALL_CACHED) bs = cold_rows_lane_best<CB>(cold, l, cold_jb, cold_je, bs);
             if (!ALL_CACHED)
             for (int s0 = Sc; s0 < n_slots; s0 += 64) {
@@ -1251,7 +1382,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 }
                 const double vlo = (blo[sl.bsel] - VIOL_TOL) - val, vhi = val - (bhi[sl.bsel] + VIOL_TOL);
                 const double iw = tSIW[sc2];
-                const int fo = cold_rows + 2 * (sc2 - Sc);
+                const int fo = 2 * (sc2 - Sc);
                 int f_lo = cold_flag[fo], f_hi = cold_flag[fo + 1];
                 DQ_KEEP(f_lo); DQ_KEEP(f_hi);
                 const uint32_t code = (uint32_t)(UX0 + sc2) << 3;
@@ -1365,6 +1496,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     rh = uq == u ? rq : rh;
                 }
                 row_rhs = rh;
+            } else if (row < Kl) {  // a row in LDS (every lane reads the same words)
+                key = lkey[row - Kc];
+                nn[0] = lnx[row - Kc]; nn[1] = lny[row - Kc]; nn[2] = lnz[row - Kc];
+                row_rhs = w.uni(lrhs[row - Kc]);
             } else {
                 key = Rkey[row];
                 nn[0] = Rnx[row]; nn[1] = Rny[row]; nn[2] = Rnz[row];

@@ -525,6 +525,9 @@ struct GridMapf {
         // Solver::createDistanceTable: BFS from every goal.  A table depends on the grid map and the goal node only: kept per
         // grid state (the map without dynamic obstacles never changes; the one with them is new every step)
         std::vector<LazyBfs *> table(n);
+        // (bounded: escape goals change from step to step, and a table is two vectors of n_nodes -- a long mission on a large grid
+        // would otherwise grow the cache towards n_nodes^2; a cleared cache is refilled as far as it is asked)
+        if (goal_tables[active].size() > (size_t)(8 * n + 64)) goal_tables[active].clear();
         for (int i = 0; i < n; i++) {
             auto &cache = goal_tables[active];
             auto it = cache.find(goal[i]);

@@ -118,8 +118,6 @@ DQ_FN uint32_t sfc_corner_gaps(const uint32_t *rec, double res) {
 
 // sfc_point_blocked for a lattice point through the table of sfc_corner_gaps: the same cell as the reference's floor, the corner
 // from the nearest integer of sp / res, one word read.
-// (W::window_masks: the words of the cells the wavefront's points fall into -- from the window of the table that W::window_begin
-// copied next to the wavefront where it has one (GPU: LDS, as bit masks "gap <= gap_max" per corner), else from the table)
 template <class W>
 DQ_FN bool sfc_lattice_point_blocked(const W &wave, const SfcWorldView &w, const float sp[3], int gap_max) {
     int c[3], corner = 0;
@@ -136,14 +134,6 @@ DQ_FN bool sfc_lattice_point_blocked(const W &wave, const SfcWorldView &w, const
     const int jc = j < 0 ? 0 : (j >= w.n[1] ? w.n[1] - 1 : j);
     const int kc = kk < 0 ? 0 : (kk >= w.n[2] ? w.n[2] - 1 : kk);
     return inside & wave.corner_blocked(w, ic, jc, kc, corner, gap_max);
-}
-
-// bit `corner` of the mask "gap <= gap_max" of a word of the table
-DQ_FN uint32_t sfc_gap_mask(uint32_t word, int gap_max) {
-    uint32_t m = 0;
-#pragma unroll
-    for (int c = 0; c < 8; c++) m |= (uint32_t)((int)((word >> (4 * c)) & 15u) <= gap_max) << c;
-    return m;
 }
 
 // the largest whole number of cells g with g res < margin + 1e-5 (-1: not even 0), what `best < margin + SFC_EPS_F` admits
@@ -186,19 +176,6 @@ template <class W>
 DQ_FN bool sfc_expand(const W &w, const SfcWorldView &g, const SfcParams &p, const float *init, float *out) {
     const double mx = 2 * p.grid_resolution > p.agent_max_vel * p.dt ? 2 * p.grid_resolution : p.agent_max_vel * p.dt;
     const int max_iter = (int)round(mx / g.res) + 1;
-    if (g.gaps) {
-        // everything this expansion can look at: the initial box and max_iter + 1 slabs on every side (+ the cell below a
-        // lattice point that coordToKey's floor may pick), inside the grid.  The GPU copies that part of the table into LDS.
-        int lo[3], hi[3];
-        for (int k = 0; k < 3; k++) {
-            lo[k] = (int)floor((double)init[k] / g.res) - max_iter - 3 - g.lo[k];
-            hi[k] = (int)ceil((double)init[3 + k] / g.res) + max_iter + 3 - g.lo[k];
-            lo[k] = lo[k] < 0 ? 0 : lo[k];
-            hi[k] = hi[k] > g.n[k] ? g.n[k] : hi[k];
-            hi[k] = hi[k] < lo[k] ? lo[k] : hi[k];
-        }
-        w.window_begin(g, lo, hi, sfc_gap_max(p.margin, g.res));
-    }
     if (sfc_obstacle_in_box(w, g, init, p.margin)) return false;
     float sfc[6], cand[6], upd[6];
     int axis_cand[6] = {0, 1, 2, 3, 4, 5}, n_cand = 6;  // -x -y -z +x +y +z

@@ -261,7 +261,8 @@ class ClosedLoop:
                                       self.pos + to_goal / dist.clamp_min(1e-9) * waypoint_step))
         self.advance = self.opt.make_advance(self.batch, self.plans, self.cur_goal, self.init_buf,
                                              desired_goal=self.desired_goal if world is None else None,
-                                             waypoint_step=waypoint_step if world is None else 0.0)
+                                             waypoint_step=waypoint_step if world is None else 0.0,
+                                             hold_on_lp_failure=neighbours == "knn")  # the synthetic swarms' waypoint rule
         if world is not None and world.get("prune", True) and not prune:
             # presolve in the half-space generator: rows implied by this step's corridor boxes are never written
             self.row_counts = self.gen.enable_pruning(self.sfc.sfcs)

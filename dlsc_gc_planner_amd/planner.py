@@ -144,7 +144,7 @@ class BatchTrajOptimizer:
         return SfcGenerator(self, boxes, resolution, world_min, world_max, radius, max_vel, grid_resolution, device)
 
     def make_advance(self, batch, plans, current_goal, initial_traj=None, waypoints=None, desired_goal=None,
-                     waypoint_step=0.0):
+                     waypoint_step=0.0, hold_on_lp_failure=False):
         """The bookkeeping between two launches of `batch` as one kernel (dlscqp_advance_device): fail-safe, sub-goal,
         state := plan(dt), the next step's agent records and initial trajectory.  All arguments are CUDA tensors that
         stay where they are (float32; plans / initial_traj [N, M, n+1, 3], current_goal / waypoints / desired_goal
@@ -161,6 +161,7 @@ class BatchTrajOptimizer:
         a.waypoints = None if waypoints is None else waypoints.data_ptr()
         a.desired_goal = None if desired_goal is None else desired_goal.data_ptr()
         a.waypoint_step = float(waypoint_step)
+        a.waypoint_hold_on_lp_failure = int(bool(hold_on_lp_failure))
         keep = (batch, plans, current_goal, initial_traj, waypoints, desired_goal)
         torch = self._torch()
 

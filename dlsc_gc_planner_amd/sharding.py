@@ -349,10 +349,41 @@ class NativeExchange:
 
 def make_exchange(opt, dist, rank, world, n_local, device):
     """The exchange a sharded loop uses: the library's own (NativeExchange: RCCL called from C) on GPUs with an RCCL-capable group or
-    no group at all; PlanExchange over torch.distributed otherwise (gloo: the CPU tier, and the two-ranks-on-one-device test hook)."""
+    no group at all; PlanExchange over torch.distributed otherwise (gloo: the CPU tier, and the two-ranks-on-one-device test hook).
+    The native exchange is CHECKED before it is handed out: every rank posts a table filled with its rank number and looks for
+    every rank's number in the gathered one; the ranks agree on the outcome (one all-reduce), and if any of them could not build or
+    verify its exchange all of them fall back to torch.distributed -- a multi-GPU run must not depend on a path that no one-GPU
+    box can exercise with more than one rank.  `exchange.issued_by` says which one it is."""
+    import sys
     backend = None if dist is None else dist.get_backend()
-    if device.type == "cuda" and backend in (None, "nccl"):
-        uid = exchange_unique_id(opt.lib, dist, rank) if world > 1 else None
-        return NativeExchange(opt, rank, world, n_local, uid)
     E = opt.cfg.M * (opt.cfg.n + 1) * 3
-    return PlanExchange(dist, world, n_local, (E, 3, 1), device)
+    if device.type == "cuda" and backend in (None, "nccl"):
+        import torch
+        x, ok, why = None, 1, ""
+        try:
+            uid = exchange_unique_id(opt.lib, dist, rank) if world > 1 else None
+            x = NativeExchange(opt, rank, world, n_local, uid)
+            probe = torch.full((n_local, E + 4), float(rank + 1), dtype=torch.float32, device=device)
+            x.post_records(probe)
+            got = x.table()[:, 0].clone()
+            torch.cuda.synchronize(device)
+            want = (torch.arange(world, device=device, dtype=torch.float32) + 1.0).repeat_interleave(n_local)
+            if not torch.equal(got, want):
+                ok, why = 0, "the gathered table does not hold every rank's block"
+        except Exception as e:  # noqa: BLE001 -- whatever went wrong, the run goes on over torch.distributed
+            ok, why = 0, str(e)
+        if dist is not None and world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item()) if ok else 0
+        if ok:
+            x.issued_by = "library"
+            return x
+        if x is not None:
+            x.close()
+        print("dlsc_gc_planner_amd: the library's own exchange is not used (%s): torch.distributed instead" % (why or "another rank failed"), file=sys.stderr)
+    if dist is None:
+        raise RuntimeError("no process group and no native exchange: %s" % why)
+    x = PlanExchange(dist, world, n_local, (E, 3, 1), device)
+    x.issued_by = "torch.distributed"
+    return x

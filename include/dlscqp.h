@@ -428,6 +428,9 @@ typedef struct dlscqp_advance {
      * straight line from the new position to desired_goal, desired_goal itself when it is nearer (optional) */
     const float *desired_goal;   /* optional [n][3]                                                       */
     double waypoint_step;
+    int32_t waypoint_hold_on_lp_failure; /* (with desired_goal) an agent whose goal LP was infeasible gets its sub-goal as the next
+                                            waypoint for one step: the synthetic swarms' rule (workloads.generate)          */
+    int32_t reserved_;
 } dlscqp_advance;
 
 int dlscqp_advance_device(dlscqp_ctx *ctx, const dlscqp_advance *adv, void *stream);

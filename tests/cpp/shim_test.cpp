@@ -6,6 +6,10 @@
 #include <chrono>
 #include <cmath>
 
+#ifdef SHIM_TEST_OCTOMAP  // the branch a maintainer of the reference compiles: octomap's own point3d (here: tests/cpp/octomap_double)
+#include <octomap/octomap_types.h>
+#define MATP_HAVE_OCTOMAP
+#endif
 #include "../../dlsc_gc_planner_amd/include/dlsc_gc_planner_amd/matp.hpp"
 
 using namespace MATP;

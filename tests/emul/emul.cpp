@@ -172,7 +172,10 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
         DQ_INSTANCES(DQ_CASE)
 #undef DQ_CASE
     }
-    MemLayout lay = make_layout(kp, max_slack_obs, kmax, KUsel, SUsel, ic.by_kind);
+    // rows beyond the register cache in the working set, as the launcher sizes it for a build that runs four agents per CU
+    // (EMUL_LDS_BUDGET=0: every such row from "HBM" in every pass)
+    const char *bud = std::getenv("EMUL_LDS_BUDGET");
+    MemLayout lay = make_layout(kp, max_slack_obs, kmax, KUsel, SUsel, ic.by_kind, bud ? std::atoi(bud) : 40448);
     std::vector<unsigned char> mem(lay.bytes + 64 + 4096);
     WaveCpu w;
     const char *rev = std::getenv("EMUL_REVERSE");
@@ -370,8 +373,6 @@ struct WaveSfcCpu {
     void store6(float *dst, const float *src) const { for (int k = 0; k < 6; k++) dst[k] = src[k]; }
     void fence() const {}
     int uniform_max8(int v) const { return v; }  // one point at a time on the host
-    // no copy of the table next to the "wavefront" on the host: every lattice point reads the table itself
-    void window_begin(const dlscqp::SfcWorldView &, const int *, const int *, int) const {}
     bool corner_blocked(const dlscqp::SfcWorldView &g, int ic, int jc, int kc, int corner, int gap_max) const {
         const uint32_t word = g.gaps[((size_t)ic * g.n[1] + jc) * g.n[2] + kc];
         return (int)((word >> (4 * corner)) & 15u) <= gap_max;

@@ -33,8 +33,9 @@ def test_kernel_source_matches_oracle_on_fresh_batches(name):
     assert np.array_equal(got["status"], ref["status"])
     ok = ref["status"] == abi.OK
     assert ok.sum() >= 5
-    assert np.abs(got["x"][ok] - ref["x"][ok]).max() < 1e-8
-    assert np.allclose(got["cost"][ok], ref["cost"][ok], rtol=1e-7, atol=1e-9)
+    assert np.abs(got["x"][ok] - ref["x"][ok]).max() < (1e-8 if cfg.control_input_weight <= 0.1 else 5e-8)  # (rows count as met within 1e-9 m)
+    # (the objective's gradient grows with control_input_weight: 1e-7 relative at the launch files' 0.01, 1e-6 at the code default 1)
+    assert np.allclose(got["cost"][ok], ref["cost"][ok], rtol=1e-7 if cfg.control_input_weight <= 0.1 else 1e-6, atol=1e-9)
     if b["max_slack_obs"]:
         assert np.abs(got["slack_cost"][ok] - ref["slack_cost"][ok]).max() < 1e-8
 
@@ -191,3 +192,25 @@ def test_phi_n_is_validated_and_switches_the_weak_duality_test_off():
     ref = O.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], None, 0, True)
     got = E.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], None, 0, True)
     assert np.array_equal(got["status"], ref["status"]) and (ref["status"] == abi.INFEASIBLE).sum() >= 8
+
+
+@pytest.mark.parametrize("name", ["crowd3d_M5_400rows", "forest3d_M10_dyn", "long3d_M12_comm"])
+def test_rows_in_the_working_set_change_nothing(name):
+    """Round 4: the rows right behind the register cache are decoded once into the working set (LDS on the device) and priced from
+    there in every pass instead of from HBM (gi_core.hpp: "rows in LDS").  The same arithmetic per row: with the tier switched off
+    (EMUL_LDS_BUDGET=0) the kernel's source gives the same bits -- verdicts, solutions, iteration counts."""
+    ck, gk = randqp.CONFIGS[name]
+    cfg = abi.make_config(**ck)
+    gk = dict(gk, max_rows=max(gk.get("max_rows", 60), 420), n_static_max=22, keep=0.8) if name != "crowd3d_M5_400rows" else gk
+    b = randqp.random_batch(cfg, 40, seed=123, **gk)
+    res = {}
+    for budget in ("0", "40448", "9000"):
+        os.environ["EMUL_LDS_BUDGET"] = budget
+        try:
+            res[budget] = E.plan_batch(cfg, b["agents"], b["row_offsets"], b["rows"], b["sfc"], b["max_slack_obs"], True)
+        finally:
+            del os.environ["EMUL_LDS_BUDGET"]
+    assert np.diff(b["row_offsets"]).max() > 300 and res["0"]["iters"][:, 0].max() >= 2
+    for k in ("status", "goal_status", "goal", "x", "cost", "iters"):
+        assert np.array_equal(res["0"][k], res["40448"][k]), k
+        assert np.array_equal(res["0"][k], res["9000"][k]), k  # a budget that holds only some of the rows: three tiers at once

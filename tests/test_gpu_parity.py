@@ -23,7 +23,9 @@ def _compare(cfg, got, ref, x_tol=1e-6):
         err = np.abs(got["ctrl"][ok].astype(np.float64) - ref["ctrl"][ok]).max()
         assert err <= CTRL_RTOL * scale, err
         assert err <= 1e-5, err  # in practice float32 rounding only
-        assert np.allclose(got["cost"][ok], ref["cost"][ok], rtol=1e-7, atol=1e-9)
+        # the objective at two points 1e-9 m apart differs by gradient x 1e-9, and the gradient of the jerk term grows with
+        # control_input_weight: 1e-7 relative at the launch files' 0.01, 1e-6 at the code default 1 (src/param.cpp:71-80)
+        assert np.allclose(got["cost"][ok], ref["cost"][ok], rtol=1e-7 if cfg.control_input_weight <= 0.1 else 1e-6, atol=1e-9)
     return int(ok.sum())
 
 

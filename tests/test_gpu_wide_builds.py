@@ -76,13 +76,16 @@ def test_helper_wavefronts_change_nothing(gpu_required, tmp_path, name):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     res = {}
-    for wpa in ("1", "4"):
-        out = str(tmp_path / ("wpa%s.npz" % wpa))
-        env = dict(os.environ, DLSCQP_WPA=wpa)
+    # ... and without helpers the rows right behind the register cache are decoded once into LDS and priced from there (round 4,
+    # gi_core.hpp: "rows in LDS"; DLSCQP_ROWS_IN_LDS=0: from HBM in every pass, as the helpers price theirs): the same bits again
+    for tag, wpa, in_lds in (("1", "1", "1"), ("1-hbm", "1", "0"), ("4", "4", "1")):
+        out = str(tmp_path / ("wpa%s.npz" % tag))
+        env = dict(os.environ, DLSCQP_WPA=wpa, DLSCQP_ROWS_IN_LDS=in_lds)
         r = subprocess.run([sys.executable, "-c", SCRIPT % dict(root=os.path.dirname(here), here=here, name=name), out], env=env,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
-        res[wpa] = np.load(out)
+        res[tag] = np.load(out)
     assert res["1"]["iters"][:, 0].max() >= 2
     for k in ("status", "goal_status", "goal", "ctrl", "x", "cost", "iters"):
         assert np.array_equal(res["1"][k], res["4"][k]), k
+        assert np.array_equal(res["1"][k], res["1-hbm"][k]), k
