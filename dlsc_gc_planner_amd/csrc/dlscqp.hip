@@ -337,7 +337,10 @@ __device__ __forceinline__ int hinted_agent(const KernelArgs &a, int slot, int l
 #ifndef DQ_WPA_OCC
 #define DQ_WPA_OCC 1  // wavefronts per SIMD the builds with helper wavefronts are compiled for
 #endif
-#define DQ_KERNEL_ATTR __launch_bounds__(64 * WPA, WPA > 1 ? DQ_WPA_OCC : ((WIDE || (DIMS > 0 && (RC == 2 || (DIMS == 2 && FS == 28)))) ? 1 : 2))
+#ifndef DQ_M10_2D_ONE  // the 2-D, M = 10 shape at one wavefront per SIMD (0: two -- an experiment of round 4, profiles/)
+#define DQ_M10_2D_ONE 1
+#endif
+#define DQ_KERNEL_ATTR __launch_bounds__(64 * WPA, WPA > 1 ? DQ_WPA_OCC : ((WIDE || (DIMS > 0 && (RC == 2 || (DIMS == 2 && FS == 28 && DQ_M10_2D_ONE)))) ? 1 : 2))
 #endif
 // WS_HBM: the agent's working set (MemLayout) lives in a per-slot HBM buffer instead of LDS -- for batches whose working
 // set exceeds the 160 KiB of a CU.  Since the solver keeps no orthogonal factor (gi_core.hpp) that is only a batch with
@@ -1043,7 +1046,7 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         // Builds compiled for one wavefront per SIMD (WIDE; the shapes with two registers per vector; 2-D M = 10) run four agents
         // per CU, the others eight.  DLSCQP_ROWS_IN_LDS=0: every such row from HBM in every pass, as before round 4 (tests).
         static const bool rows_in_lds = !(getenv("DLSCQP_ROWS_IN_LDS") && getenv("DLSCQP_ROWS_IN_LDS")[0] == '0');
-        const bool one_per_simd = wide || kc.id == 3 || kc.id == 4 || kc.id == 5;
+        const bool one_per_simd = wide || (kc.id == 3 && DQ_M10_2D_ONE) || kc.id == 4 || kc.id == 5;
         const int budget = (int)(LDS_LIMIT / (one_per_simd ? 4 : 8)) - 512;
         if (rows_in_lds) lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, kc.by_kind, budget);
     }
