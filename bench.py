@@ -346,7 +346,7 @@ def moving_crowd(device, steps=60, warm=20):
                                       "achieved": lsc_bytes / (lsc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": lsc_bytes / (lsc_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                       "note": "736 B x neighbours read + 36 B x rows written; the kernel is arithmetic (hull search per "
-                                              "neighbour and segment), not HBM bound: profiles/r02_other_kernels_pmc.md"}
+                                              "neighbour and segment), not HBM bound: profiles/r04_other_kernels_pmc.md"}
     try:
         cms, nt = cpu_port_step_ms(cfg, inputs, seconds=2.0)
         out["cpu_port_ms"], out["cpu_port_threads"] = cms, nt

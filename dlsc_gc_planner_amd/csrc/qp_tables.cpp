@@ -162,6 +162,10 @@ bool build_tables(const dlscqp_config &cfg, int dim, int M, int n, int phi, doub
     // objective_upper_bound() of gi_core.hpp bounds c'Q_base c by the integral of jerk^2 only: with phi_n > 1 Q_base also
     // holds the lower-derivative Gram terms (traj_optimizer.cpp:172-187) and the bound would not hold
     kp.wd_cut = cfg.phi_n == 1 ? 1 : 0;
+    // the parameter values of the reference's launch files (all 143 of them: SURVEY.md appendix C): what gi_core.hpp's narrow
+    // dependency threshold was calibrated on
+    kp.dep_calibrated = (std::fabs(cfg.control_input_weight - 0.01) < 1e-12 && std::fabs(cfg.terminal_weight - 1.0) < 1e-12 &&
+                         std::fabs(dt - 0.2) < 1e-12 && cfg.phi_n == 1) ? 1 : 0;
     if (std::getenv("DLSCQP_DEBUG_NO_WD")) kp.wd_cut = 0;  // debugging aid: verdicts with and without the test must agree (tests)
     kp.vel_scale = dt / n;
     kp.acc_scale = dt * dt / (n * (n - 1));

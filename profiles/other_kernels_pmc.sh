@@ -1,7 +1,8 @@
 #!/bin/bash
 # PMC counters of the other kernels of the path (half-space generator on the stress batch, corridor kernel on the maze mission),
-# one rocprofv3 run per counter group, the program itself after "--":   bash profiles/other_kernels_pmc.sh
+# one rocprofv3 run per counter group, the program itself after "--":   bash profiles/other_kernels_pmc.sh r04  ->  profiles/r04_other_kernels_pmc.md
 set -u
+NAME=${1:-r04}
 export TMPDIR=/tmp
 O=gpurun_out/other_pmc
 mkdir -p $O
@@ -42,6 +43,6 @@ for tag, kern, grid in (("lsc", "lsc_kernel", "max"), ("sfc", "sfc_kernel", None
     if "SQ_WAIT_ANY" in acc:
         out.append("SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.2f" % (sum(acc["SQ_WAIT_ANY"]) / sum(acc["SQ_WAVE_CYCLES"])))
     out.append("")
-open("profiles/r02_other_kernels_pmc.md", "w").write("\n".join(out))
+open("profiles/${NAME}_other_kernels_pmc.md", "w").write("\n".join(out))
 print("\n".join(out))
 PY
