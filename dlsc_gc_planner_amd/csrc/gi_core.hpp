@@ -1953,18 +1953,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             // read-modify-write, one active row after the other), z = N_T' u with the whitening map itself (read from HBM / L2,
             // here only), |z|^2 = sum z_j^2 -- the error is (eps |N| |u|)^2, a dependent row gives ~1e-28.
             double noise2 = 0.0;  // (set by whitened_length) sum_j (sum_p |N_pj| |u_p|)^2: eps^2 times it is the rounding noise of |z|^2
-            double u_sq = -1.0;   // (set by whitened_length) |u|^2, u = a - A' rv in the variables' own space
-            // |a|^2 there, over the entries that are variables of the whitened problem (see whitened_length): a control point that the
-            // initial state fixes has a row of the whitening map that is zero up to the rounding of the host's QR (1e-33, not 0)
-            double a_sq = 1.0;  // (set by whitened_length, like u_sq: the table reads belong to the rare path)
             auto whitened_length = [&]() -> double {
                 double *u = base + lay.oU;
                 const double *tN = kp.tabN + (size_t)(T - 1) * P * f;
                 const int nx = nxc + nslk;
-                const double free_min = 1e-16 * tNN[P - 1];
-                a_sq = w.uni((new_line ? (tNN[np0] > free_min ? ncf[0] * ncf[0] : 0.0) + (tNN[np1] > free_min ? ncf[1] * ncf[1] : 0.0) +
-                                             (tNN[np2] > free_min ? ncf[2] * ncf[2] : 0.0)
-                                       : (tNN[np0] > free_min ? ncf[0] * ncf[0] + ncf[1] * ncf[1] + ncf[2] * ncf[2] : 0.0)) + (sidx_row >= 0 ? 1.0 : 0.0));
                 w.each([&](int l) {
                     for (int j0 = 0; j0 < nx; j0 += 64) base[blend_idx(j0 + l < nx, lay.oU + j0 + l, odump + (l & 31))] = 0.0;  // uniform trip count
                 });
@@ -2018,33 +2010,17 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                         const int sc = sidx < nslk ? sidx : 0;
                         const double v = kp.sigma[sc % M] * u[nxc + sc];
                         s += sidx < nslk ? v * v : 0.0;
+                        sn += sidx < nslk ? v * v : 0.0;  // (a slack variable's own term: its absolute value is itself)
                     }
                     acc.at(l) = s;
                     accn.at(l) = sn;
                 });
                 double zz;
                 w.sum2(acc, accn, zz, noise2);
-                // |u|^2 in the variables' own space (see `dependent` below)
-                RegD au;
-                w.each([&](int l) {
-                    double su = 0.0;
-                    for (int j0 = 0; j0 < nx; j0 += 64) {  // uniform trip count
-                        const int j = j0 + l;
-                        const int jc = j < nx ? j : nx - 1;
-                        const double v = u[jc];
-                        // (only where the whitening map has a row: the control points that the initial state fixes are no variables
-                        // of the whitened problem, and u may be anything there)
-                        const int jm = blend_idx(jc < nxc, jc, 0);  // (mask arithmetic, not ?: -- the table read below must not become lane-guarded)
-                        const int pj = jm - (jm / P) * P;
-                        double tq = tNN[pj];
-                        DQ_KEEP(tq);
-                        const bool free_var = (jc >= nxc) | (tq > free_min);
-                        su += (j < nx && free_var) ? v * v : 0.0;
-                    }
-                    au.at(l) = su;
-                });
-                u_sq = w.sum(au);
-                return zz;
+                // nothing is left of the normal even in absolute values (DEP_XSPACE, qp_types.hpp): the answer is "zero" -- decided here, so
+                // that the iteration outside is the code it was (round 4: a select on a flag of the parameter block in the iteration
+                // cost the S64 launch 3 % -- register allocation --, the threshold as a number of the block 0.6 %)
+                return noise2 > DEP_XSPACE * dall ? zz : 0.0;
             };
             double dd2;
             if (DXREG) {
@@ -2066,18 +2042,16 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             // trace builds (tests/test_dependency_margins.py): EVERY row is also measured in the whitened space, whether it raised
             // suspicion or not -- the truth the thresholds are judged against -- without touching what the solve goes on with
             const double dd2_first = dd2;
-            double zz_truth = 0.0, noise_truth = 0.0, usq_truth = 0.0;
+            double zz_truth = 0.0, noise_truth = 0.0;
             if (q > 0) {
-                const double keep_noise = noise2, keep_u = u_sq;
+                const double keep_noise = noise2;
                 zz_truth = whitened_length();
                 noise_truth = noise2;
-                usq_truth = u_sq;
                 noise2 = keep_noise;
-                u_sq = keep_u;
             }
             bool remeasured = false;
 #endif
-            const double suspect = (DXREG && kp.dep_calibrated) ? DEP_SUSPECT : DEP_SUSPECT_SLACK;
+            const double suspect = DXREG ? kp.dep_suspect : DEP_SUSPECT_SLACK;  // (KParams: the narrow threshold only where it was calibrated)
             if (q > 0 && !(dd2 > suspect * dall)) {
                 DQ_TRACE(5, dd2, dall, 0.0, 0.0);  // (the step rate that raised the suspicion)
                 dd2 = whitened_length();  // uniform, a few per cent of the iterations
@@ -2124,9 +2098,8 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             }
             // q == r: the active rows span the whitened space, every further row depends on them
             // (noise2 > 0: |z|^2 was measured in the whitened space: it must also stand out of the rounding noise of that measure)
-            // (u_sq >= 0: it was measured there; then also: is a - A' rv itself nothing but rounding in the variables' own space?)
-            const bool dependent = !(dd2 > DEP_TOL * dall) || !(dd2 > DEP_NOISE * noise2) || !(dd2 > 0) || q >= r ||
-                                   (u_sq >= 0.0 && !(u_sq > DEP_XSPACE * a_sq));
+            // (whitened_length answers 0 where nothing is left of the normal even in absolute values: DEP_XSPACE)
+            const bool dependent = !(dd2 > DEP_TOL * dall) || !(dd2 > DEP_NOISE * noise2) || !(dd2 > 0) || q >= r;
             const double t2 = dependent ? 1e300 : viol / dd2;
             DQ_TRACE(2, dd2, dall, t1, (double)ldrop);
 #ifdef DLSCQP_TRACE
@@ -2135,10 +2108,11 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 // took the row for dependent, 2 = it was measured again, 4 = dependent by the whitened measure, 8 = the narrow suspicion
                 // threshold DEP_SUSPECT applies (static shape without slack variables at the calibrated parameter values; else
                 // DEP_SUSPECT_SLACK))
-                const bool truth = !(zz_truth > DEP_TOL * dall) || !(zz_truth > DEP_NOISE * noise_truth) || !(zz_truth > 0) || !(usq_truth > DEP_XSPACE * a_sq);
+                const bool truth = !(zz_truth > DEP_TOL * dall) || !(zz_truth > DEP_NOISE * noise_truth) || !(zz_truth > 0) ||
+                                   !(noise_truth > DEP_XSPACE * dall);
                 DQ_TRACE(6, dd2_first / dall, zz_truth / dall, noise_truth > 0 ? zz_truth / noise_truth : -1.0,
                          (double)((dependent ? 1 : 0) | (remeasured ? 2 : 0) | (truth ? 4 : 0) | ((DXREG && kp.dep_calibrated) ? 8 : 0)));
-                DQ_TRACE(7, usq_truth / a_sq, zz_truth / dall, 0.0, truth ? 1.0 : 0.0);  // |u|^2 / |a|^2 in the variables' own space
+                DQ_TRACE(7, noise_truth / dall, zz_truth / dall, 0.0, truth ? 1.0 : 0.0);  // what DEP_XSPACE is compared with
             }
 #endif
             w.stamp(7);  // ratio test

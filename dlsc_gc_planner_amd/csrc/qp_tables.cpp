@@ -166,6 +166,7 @@ bool build_tables(const dlscqp_config &cfg, int dim, int M, int n, int phi, doub
     // dependency threshold was calibrated on
     kp.dep_calibrated = (std::fabs(cfg.control_input_weight - 0.01) < 1e-12 && std::fabs(cfg.terminal_weight - 1.0) < 1e-12 &&
                          std::fabs(dt - 0.2) < 1e-12 && cfg.phi_n == 1) ? 1 : 0;
+    kp.dep_suspect = kp.dep_calibrated ? DEP_SUSPECT : DEP_SUSPECT_SLACK;
     if (std::getenv("DLSCQP_DEBUG_NO_WD")) kp.wd_cut = 0;  // debugging aid: verdicts with and without the test must agree (tests)
     kp.vel_scale = dt / n;
     kp.acc_scale = dt * dt / (n * (n - 1));

@@ -48,6 +48,7 @@ struct KParams {
     double z_2d;
     double world_min[3], world_max[3];
     double vel_scale, acc_scale;  // dt/n, dt^2/(n(n-1))
+    double dep_suspect;           // DEP_SUSPECT where dep_calibrated, else DEP_SUSPECT_SLACK
     double Qb[36];                // control_input_weight * Q_base (traj_optimizer.cpp:172-187)
     double sigma[32];             // slack whitening 1/sqrt(2 w_s (M-m)/M), m < M <= 32
     int t_valid[32];              // reduced Hessian positive definite for T = idx+1
@@ -87,12 +88,13 @@ constexpr double DEP_SUSPECT = DQ_DEP_SUSPECT, DEP_SUSPECT_SLACK = 1e-3;
 // ~1e-11 (condition of the active rows' Gram matrix), u inherits it, and the quotient of a dependent row was measured between 1e-31
 // and 1e-20 over the random batches of tests/fuzz_cpu.py; rows that do not depend on the active ones start at 1e-12.
 constexpr double DEP_NOISE = 1e-17;
-// |u|^2 <= DEP_XSPACE |a|^2, u = a - A' r in the variables' OWN space: the row's normal is, to nine digits, a combination of the
-// active rows' normals there (the same half-space twice, or its opposite: what an infeasible pair is made of).  For such a row
-// |z|^2 / |N'a|^2 is the squared relative error of r -- 1e-23 ... 5e-21 measured, i.e. within a factor of two of DEP_TOL (round 4:
-// a fresh seed of tests/test_dependency_margins.py found 4.5e-21) -- while |u|^2 / |a|^2 (over the variables of the whitened
-// problem) is <= 1.1e-19 for every such row and >= 2e-3 for every row that does not depend on the active ones (thirteen
-// configurations, fifty seeds); two float32 normals one ulp apart give 4e-15: they stay independent, as the oracle has them.
+// noise^2 <= DEP_XSPACE |N'a|^2, noise^2 = sum_j (sum_p |N_pj| |u_p|)^2 with u = a - A' r: nothing is left of the row's normal
+// even in absolute values -- u is zero, to eight digits, on every variable of the whitened problem: the same half-space twice, or
+// its opposite (what an infeasible pair is made of).  For such a row |z|^2 / |N'a|^2 is the squared relative error of r: 1e-23 ...
+// 6e-20 measured, i.e. on both sides of DEP_TOL (round 4: fresh seeds of tests/test_dependency_margins.py found 4.5e-21 and
+// 5.8e-20), and the noise test does not apply (|z|^2 is of the size of noise^2 there).  noise^2 / |N'a|^2 is <= 2.3e-19 for every
+// such row and >= 3e-7 for every row that does not depend on the active ones (sixteen configurations, fifty seeds); two float32
+// normals one ulp apart give >= 4e-15: they stay independent, as the oracle has them.
 constexpr double DEP_XSPACE = 1e-16;
 constexpr double DEP_TOL = 1e-20;  // |z|^2 <= DEP_TOL |N'a|^2  -> the row's normal depends on the active rows'
 constexpr double SP_EPSILON = 1e-9;        // sp_const.hpp:3
