@@ -621,6 +621,7 @@ template <int SFC_T>
 struct WaveSfcT {
     int lane;
     int *flags;            // LDS [2][SFC_T / 64]: one verdict per wavefront, double-buffered by round
+    uint32_t *axis;        // LDS [SFC_T / 64][3][SFC_AXIS_CAP]: the per-axis entries of the box under test, one copy per wavefront
     mutable int parity = 0;
     // one word of the lattice-point table (sfc_core.hpp: sfc_corner_gaps) per point.  (A copy of the part of the table an expansion
     // can reach, as bytes in LDS, was built and measured in round 4: 0.178 ms per launch against 0.171 -- a trial expansion is
@@ -643,14 +644,32 @@ struct WaveSfcT {
         for (int k = 0; k < NW; k++) r |= fl[k];
         return r != 0;
     }
+    // every thread takes its share of the points and ORs its verdicts; ONE workgroup-wide OR at the end.  (Until round 4 the
+    // workgroup agreed after every SFC_T points and left at the first blocked one: a box of 11 000 lattice points was 22 table
+    // reads one after the other, each with a barrier behind it, and almost every box that is tested is free.)
     template <class F>
     __device__ __forceinline__ bool any_of(int n, F f) const {
+        bool acc = false;
+#pragma unroll 4
         for (int base = 0; base < n; base += SFC_T) {
             const int idx = base + lane;
-            const bool v = f(idx < n ? idx : n - 1) & (idx < n);  // every thread evaluates a valid point
-            if (block_or(v)) return true;
+            acc |= f(idx < n ? idx : n - 1) & (idx < n);  // every thread evaluates a valid point
         }
-        return false;
+        return block_or(acc);
+    }
+    // sfc_core.hpp: sfc_axis_entry of every lattice index of the box, per axis.  Each wavefront keeps its own copy (lane l computes
+    // index l of the three axes): no barrier, a wavefront's LDS accesses are served in order.
+    __device__ __forceinline__ void axis_fill(const SfcWorldView &g, const float *b) const {
+        uint32_t *t = axis + (lane >> 6) * (3 * SFC_AXIS_CAP);
+        const int l = lane & 63;
+#pragma unroll
+        for (int k = 0; k < 3; k++) t[k * SFC_AXIS_CAP + l] = sfc_axis_entry(g, k, b[k], l);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __device__ __forceinline__ uint32_t axis_entry(int k, int it) const {
+        return axis[(lane >> 6) * (3 * SFC_AXIS_CAP) + k * SFC_AXIS_CAP + it];
     }
     // largest v (0..8) over the lanes of the wavefront, as a wave-uniform value: ballots and scalar selects
     __device__ __forceinline__ int uniform_max8(int v) const {
@@ -696,9 +715,11 @@ __global__ __launch_bounds__(SFC_T) void dlscqp_sfc_kernel(SfcGenArgs a) {
     const int ag = blockIdx.x;
     if (ag >= a.n_agents) return;
     __shared__ int sfc_flags[2 * (SFC_T / 64)];
+    __shared__ uint32_t sfc_axis[(SFC_T / 64) * 3 * SFC_AXIS_CAP];
     WaveSfcT<SFC_T> w;
     w.lane = (int)threadIdx.x;
     w.flags = sfc_flags;
+    w.axis = sfc_axis;
     SfcParams p;
     p.margin = a.radius[ag];
     p.grid_resolution = a.grid_resolution;
@@ -1741,7 +1762,7 @@ extern "C" int dlscqp_world_create(dlscqp_ctx *c, const double *boxes, int32_t n
     w->view.near = (const uint32_t *)w->d_near;
     // the lattice-point table (one word per cell): DLSCQP_SFC_RECORDS=1 keeps the kernel on the 32-byte records (tests compare the two)
     w->view.gaps = nullptr;
-    if (!std::getenv("DLSCQP_SFC_RECORDS")) {
+    if (!std::getenv("DLSCQP_SFC_RECORDS") && nc < (size_t)SFC_GAPS_MAX_CELLS) {
         if ((e = hipMalloc(&w->d_gaps, nc * 4)) != hipSuccess) return fail(e, "hipMalloc");
         if ((e = hipMemcpy(w->d_gaps, hw.gaps.data(), nc * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
         w->view.gaps = (const uint32_t *)w->d_gaps;

@@ -143,8 +143,30 @@ DQ_FN int sfc_gap_max(double margin, double res) {
     return g > 14 ? 14 : g;
 }
 
-// isObstacleInSFC (:859-892): the lattice points of the box, 64 at a time, one per lane.  W::any_of(n, f): true if
-// f(i) holds for some i in [0, n) (GPU: ballot over the lanes, host: a loop).
+// One axis of sfc_lattice_point_blocked, for the lattice index `it` of a box that starts at b_k: which cell the reference's floor
+// picks along the axis and which of the cell's two ends the point is.  Packed so that the three axes' entries ADD to the query:
+// bits 0..25 the clamped cell index times the axis' stride in the table, bit 26 + k the corner bit of axis k, bits 29..30 count
+// the axes along which the point lies outside the grid (a sum of at most three ones).
+constexpr int SFC_AXIS_CAP = 64;               // lattice points per axis the entry tables hold
+constexpr uint32_t SFC_GAPS_MAX_CELLS = 1u << 26;  // the offset field; larger worlds keep the 32-byte records (gaps == nullptr)
+DQ_FN uint32_t sfc_axis_entry(const SfcWorldView &w, int k, float bk, int it) {
+    const float sp = (float)(bk + it * w.res);
+    const double sc = (1.0 / w.res) * (double)sp;
+    const int c = (int)floor(sc);  // OcTreeBaseImpl::coordToKey
+    int d = (int)floor(sc + 0.5) - c;
+    d = d < 0 ? 0 : (d > 1 ? 1 : d);
+    const int i = c - w.lo[k];
+    const uint32_t outside = (uint32_t)((i < 0) | (i >= w.n[k]));
+    const int ic = i < 0 ? 0 : (i >= w.n[k] ? w.n[k] - 1 : i);
+    const uint32_t stride = k == 0 ? (uint32_t)(w.n[1] * w.n[2]) : (k == 1 ? (uint32_t)w.n[2] : 1u);
+    return (uint32_t)ic * stride + ((uint32_t)d << (26 + k)) + (outside << 29);
+}
+
+// isObstacleInSFC (:859-892): the lattice points of the box, one per lane.  W::any_of(n, f): true if f(i) holds for some i in
+// [0, n) (GPU: every thread of the workgroup takes its share of the points, one OR at the end; host: a loop).
+// A point's coordinates are functions of one axis each, and the reference computes them in float32 / double from the box's own
+// corner (the rounding decides which cell is read): with the lattice-point table the per-axis part -- everything but one add, one
+// table word and one compare -- is done once per box and axis (W::axis_fill / W::axis_entry) instead of once per point.
 template <class W>
 DQ_FN bool sfc_obstacle_in_box(const W &w, const SfcWorldView &g, const float *b, double margin) {
     int mi[3];
@@ -155,6 +177,21 @@ DQ_FN bool sfc_obstacle_in_box(const W &w, const SfcWorldView &g, const float *b
     for (int k = 0; k < 3; k++) mi[k] = (int)floor((b[3 + k] - b[k] + SFC_EPS_F) * inv_res) + 1;
     const int total = mi[0] * mi[1] * mi[2];
     const int gap_max = sfc_gap_max(margin, g.res);
+    const bool small = (mi[0] <= SFC_AXIS_CAP) & (mi[1] <= SFC_AXIS_CAP) & (mi[2] <= SFC_AXIS_CAP);
+    if (g.gaps && small) {  // uniform
+        w.axis_fill(g, b);
+        // idx -> (a1, b2, c3) without integer division: idx + 0.5 is exact in float32 (idx < 2^18), the product with the rounded
+        // reciprocal is off by at most (idx / m) 2^-23 < 1 / (32 m), and (idx + 0.5) / m is never closer than 1 / (2 m) to a whole
+        // number -- the truncation is floor(idx / m)
+        const float r2 = 1.0f / (float)mi[2], r1 = 1.0f / (float)mi[1];
+        return w.any_of(total, [&](int idx) {
+            const int ab = (int)(((float)idx + 0.5f) * r2), c3 = idx - ab * mi[2];
+            const int a1 = (int)(((float)ab + 0.5f) * r1), b2 = ab - a1 * mi[1];
+            const uint32_t s = w.axis_entry(0, a1) + w.axis_entry(1, b2) + w.axis_entry(2, c3);
+            const uint32_t word = g.gaps[s & (SFC_GAPS_MAX_CELLS - 1u)];
+            return ((s >> 29) == 0u) & ((int)((word >> (4u * ((s >> 26) & 7u))) & 15u) <= gap_max);
+        });
+    }
     return w.any_of(total, [&](int idx) {
         const int c3 = idx % mi[2], ab = idx / mi[2], b2 = ab % mi[1], a1 = ab / mi[1];
         const int it[3] = {a1, b2, c3};

@@ -373,6 +373,12 @@ struct WaveSfcCpu {
     void store6(float *dst, const float *src) const { for (int k = 0; k < 6; k++) dst[k] = src[k]; }
     void fence() const {}
     int uniform_max8(int v) const { return v; }  // one point at a time on the host
+    mutable uint32_t axis[3][dlscqp::SFC_AXIS_CAP];
+    void axis_fill(const dlscqp::SfcWorldView &g, const float *b) const {
+        for (int k = 0; k < 3; k++)
+            for (int l = 0; l < dlscqp::SFC_AXIS_CAP; l++) axis[k][l] = dlscqp::sfc_axis_entry(g, k, b[k], l);
+    }
+    uint32_t axis_entry(int k, int it) const { return axis[k][it]; }
     bool corner_blocked(const dlscqp::SfcWorldView &g, int ic, int jc, int kc, int corner, int gap_max) const {
         const uint32_t word = g.gaps[((size_t)ic * g.n[1] + jc) * g.n[2] + kc];
         return (int)((word >> (4 * corner)) & 15u) <= gap_max;
@@ -389,7 +395,7 @@ extern "C" int emul_generate_sfc(const dlscqp_config *cfg, const double *boxes, 
     v.res = hw.res;
     for (int k = 0; k < 3; k++) { v.wmin[k] = hw.wmin[k]; v.wmax[k] = hw.wmax[k]; v.lo[k] = hw.lo[k]; v.n[k] = hw.n[k]; }
     v.near = hw.near_packed.data();
-    v.gaps = std::getenv("EMUL_SFC_RECORDS") ? nullptr : hw.gaps.data();  // the lattice-point table, or the 32-byte records as in round 3
+    v.gaps = std::getenv("EMUL_SFC_RECORDS") || hw.cells() >= (size_t)SFC_GAPS_MAX_CELLS ? nullptr : hw.gaps.data();  // the lattice-point table, or the 32-byte records as in round 3
     WaveSfcCpu w;
     const int M = cfg->M, n1 = cfg->n + 1;
     for (int a = 0; a < gen->n_agents; a++) {
