@@ -616,7 +616,7 @@ __global__ __launch_bounds__(64) void dlscqp_trap_kernel(TrapArgs t) {
 // under test.  The routine is a chain of a few dozen trial expansions, each a table lookup per lattice point (dependent
 // L2 reads): latency, not throughput -- so the points of a slab (several hundred in the reference's 2.5 m high worlds) are
 // spread over eight wavefronts instead of being walked 64 at a time by one (10-agent maze step: 0.96 -> see profiles/).
-constexpr int SFC_THREADS = 512;  // default; DLSCQP_SFC_THREADS = 64 / 128 / 256 picks another instantiation (measurements)
+constexpr int SFC_THREADS = 256;  // default: one wavefront per SIMD; DLSCQP_SFC_THREADS = 64 / 128 / 512 picks another instantiation (measurements)
 template <int SFC_T>
 struct WaveSfcT {
     int lane;
@@ -659,11 +659,13 @@ struct WaveSfcT {
     }
     // sfc_core.hpp: sfc_axis_entry of every lattice index of the box, per axis.  Each wavefront keeps its own copy (lane l computes
     // index l of the three axes): no barrier, a wavefront's LDS accesses are served in order.
-    __device__ __forceinline__ void axis_fill(const SfcWorldView &g, const float *b) const {
+    __device__ __forceinline__ float rcp(float x) const { return __builtin_amdgcn_rcpf(x); }
+    __device__ __forceinline__ int uniform(int v) const { return __builtin_amdgcn_readfirstlane(v); }
+    __device__ __forceinline__ void axis_fill(const SfcWorldView &g, double inv_res, const float *b) const {
         uint32_t *t = axis + (lane >> 6) * (3 * SFC_AXIS_CAP);
         const int l = lane & 63;
 #pragma unroll
-        for (int k = 0; k < 3; k++) t[k * SFC_AXIS_CAP + l] = sfc_axis_entry(g, k, b[k], l);
+        for (int k = 0; k < 3; k++) t[k * SFC_AXIS_CAP + l] = sfc_axis_entry(g, inv_res, k, b[k], l);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -725,6 +727,7 @@ __global__ __launch_bounds__(SFC_T) void dlscqp_sfc_kernel(SfcGenArgs a) {
     p.grid_resolution = a.grid_resolution;
     p.agent_max_vel = a.max_vel[ag];
     p.dt = a.dt;
+    sfc_prepare(a.world, p);
     float *sfcs = a.sfcs + (size_t)ag * a.M * 6;
     int code;
     if (a.initialize) {
@@ -1729,7 +1732,44 @@ struct dlscqp_world {
     SfcWorldView view;  // device pointers
     void *d_near;
     void *d_gaps;
+    // The summed-volume tables (SfcWorldView::svt) are built when the first launch names its agents: which tables are needed
+    // depends on the agents' radii, and those live in device memory.  Host copy of the lattice-point table to build them from;
+    // svt_key = the (radius pointer, count) the tables were last checked against.  A launch whose agents need a table that is
+    // not there (radii changed behind the same pointer) still runs: those agents test their boxes point by point.
+    mutable SfcWorldHost host;       // only res, lo, n, gaps kept
+    mutable void *d_svt_ptrs = nullptr;  // device [15] pointers
+    mutable void *d_svt[15] = {};
+    mutable const void *svt_key_ptr = nullptr;
+    mutable int svt_key_n = 0;
 };
+
+namespace {
+// Build the tables the agents of this launch need and do not have.  Synchronises with `stream` (the radii may be the result of
+// work queued on it) -- once per (radius pointer, count); never during a stream capture.
+int world_prepare_svt(const dlscqp_world *w, const double *d_radius, int n_agents, hipStream_t stream) {
+    if (!w->view.svt || (w->svt_key_ptr == (const void *)d_radius && w->svt_key_n == n_agents)) return DLSCQP_SUCCESS;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return DLSCQP_SUCCESS;
+    std::vector<double> radius((size_t)n_agents);
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipMemcpy(radius.data(), d_radius, sizeof(double) * (size_t)n_agents, hipMemcpyDeviceToHost));
+    const size_t entries = ((size_t)w->host.n[0] + 2) * ((size_t)w->host.n[1] + 2) * ((size_t)w->host.n[2] + 2);
+    bool added = false;
+    for (int i = 0; i < n_agents; i++) {
+        const int g = sfc_gap_max(radius[(size_t)i], w->host.res);
+        if (g < 0 || g > 14 || w->d_svt[g] || entries * 4 > ((size_t)1 << 30)) continue;
+        std::vector<int32_t> svt;
+        build_sfc_svt(w->host, g, svt);
+        HIP_TRY(hipMalloc(&w->d_svt[g], entries * 4));
+        HIP_TRY(hipMemcpy(w->d_svt[g], svt.data(), entries * 4, hipMemcpyHostToDevice));
+        added = true;
+    }
+    if (added) HIP_TRY(hipMemcpy(w->d_svt_ptrs, w->d_svt, sizeof(w->d_svt), hipMemcpyHostToDevice));
+    w->svt_key_ptr = d_radius;
+    w->svt_key_n = n_agents;
+    return DLSCQP_SUCCESS;
+}
+}  // namespace
 
 extern "C" int dlscqp_world_create(dlscqp_ctx *c, const double *boxes, int32_t n_boxes, double resolution,
                                    const float world_min[3], const float world_max[3], dlscqp_world **out) {
@@ -1767,6 +1807,17 @@ extern "C" int dlscqp_world_create(dlscqp_ctx *c, const double *boxes, int32_t n
         if ((e = hipMemcpy(w->d_gaps, hw.gaps.data(), nc * 4, hipMemcpyHostToDevice)) != hipSuccess) return fail(e, "hipMemcpy");
         w->view.gaps = (const uint32_t *)w->d_gaps;
     }
+    // DLSCQP_SFC_SVT=0: every box test walks its lattice points (tests compare the two)
+    w->view.svt = nullptr;
+    const char *svt_env = std::getenv("DLSCQP_SFC_SVT");
+    if (w->view.gaps && !(svt_env && svt_env[0] == '0')) {
+        if ((e = hipMalloc(&w->d_svt_ptrs, sizeof(w->d_svt))) != hipSuccess) return fail(e, "hipMalloc");
+        if ((e = hipMemset(w->d_svt_ptrs, 0, sizeof(w->d_svt))) != hipSuccess) return fail(e, "hipMemset");
+        w->view.svt = (const int32_t *const *)w->d_svt_ptrs;
+        w->host.res = hw.res;
+        for (int k = 0; k < 3; k++) { w->host.lo[k] = hw.lo[k]; w->host.n[k] = hw.n[k]; }
+        w->host.gaps.swap(hw.gaps);
+    }
     *out = w;
     return DLSCQP_SUCCESS;
 }
@@ -1776,6 +1827,9 @@ extern "C" void dlscqp_world_destroy(dlscqp_world *w) {
     (void)hipSetDevice(w->device);
     if (w->d_near) (void)hipFree(w->d_near);
     if (w->d_gaps) (void)hipFree(w->d_gaps);
+    if (w->d_svt_ptrs) (void)hipFree(w->d_svt_ptrs);
+    for (void *t : w->d_svt)
+        if (t) (void)hipFree(t);
     delete w;
 }
 
@@ -1789,6 +1843,10 @@ extern "C" int dlscqp_generate_sfc_device(dlscqp_ctx *c, const dlscqp_world *wor
         return DLSCQP_ERR_INVALID_ARGUMENT;
     }
     (void)hipSetDevice(c->cfg.device);
+    {
+        const int rc = world_prepare_svt(world, gen->radius, gen->n_agents, (hipStream_t)stream);
+        if (rc != DLSCQP_SUCCESS) return rc;
+    }
     SfcGenArgs a;
     a.world = world->view;
     a.n_agents = gen->n_agents; a.initialize = gen->initialize;
@@ -1800,7 +1858,7 @@ extern "C" int dlscqp_generate_sfc_device(dlscqp_ctx *c, const dlscqp_world *wor
     static const int sfc_threads = std::getenv("DLSCQP_SFC_THREADS") ? std::atoi(std::getenv("DLSCQP_SFC_THREADS")) : SFC_THREADS;
     if (sfc_threads == 64) hipLaunchKernelGGL(dlscqp_sfc_kernel<64>, dim3(gen->n_agents), dim3(64), 0, (hipStream_t)stream, a);
     else if (sfc_threads == 128) hipLaunchKernelGGL(dlscqp_sfc_kernel<128>, dim3(gen->n_agents), dim3(128), 0, (hipStream_t)stream, a);
-    else if (sfc_threads == 256) hipLaunchKernelGGL(dlscqp_sfc_kernel<256>, dim3(gen->n_agents), dim3(256), 0, (hipStream_t)stream, a);
+    else if (sfc_threads == 512) hipLaunchKernelGGL(dlscqp_sfc_kernel<512>, dim3(gen->n_agents), dim3(512), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(dlscqp_sfc_kernel<SFC_THREADS>, dim3(gen->n_agents), dim3(SFC_THREADS), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
     return DLSCQP_SUCCESS;

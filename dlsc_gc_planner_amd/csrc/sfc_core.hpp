@@ -33,6 +33,13 @@ struct SfcWorldView {  // device (or host) pointers of a world built by build_sf
     // (sfc_corner_gaps) -- or 15 when the record has no occupied cell within 1 m.  The corridor routines only ever test lattice
     // points of the grid (box corners are multiples of the resolution), so a query is this one word.  nullptr: not built.
     const uint32_t *gaps;
+    // [15] pointers, entry g = the summed-volume table for agents with sfc_gap_max = g, or nullptr (not built; the array itself
+    // may be nullptr).  The table counts, over the lattice points I of the grid (n_k + 1 per axis), those that `gaps` calls blocked
+    // in ANY of the eight (cell, corner) readings of I -- which reading a box test takes is float32 rounding of the box's corner
+    // (see sfc_corner_gaps), so a count of zero over a box's lattice range means "free" whatever the rounding, in eight reads;
+    // a positive count proves nothing and the points are tested one by one as before.  Layout: (n_0 + 2)(n_1 + 2)(n_2 + 2) int32,
+    // entry [i][j][k] = number of such points with local lattice index < i, < j, < k (sfc_world.cpp: build_sfc_svt).
+    const int32_t *const *svt;
 };
 
 DQ_FN int sfc_near_offset(const uint32_t *rec, int i) {  // signed byte i (0..23) of the offsets of a record
@@ -45,6 +52,11 @@ struct SfcParams {
     double grid_resolution;  // param.grid_resolution
     double agent_max_vel;
     double dt;
+    // what every box test needs of the above and of the world, computed once per agent (sfc_prepare): the divisions would
+    // otherwise sit between any two trial expansions
+    double inv_res;      // 1 / world resolution
+    int gap_max;         // sfc_gap_max(margin, world resolution)
+    const int32_t *svt;  // SfcWorldView::svt[gap_max] or nullptr
 };
 
 // getDistanceAndClosestObstacle + collision_constraints.cpp:878-886 for one search point.  Written without
@@ -149,9 +161,9 @@ DQ_FN int sfc_gap_max(double margin, double res) {
 // the axes along which the point lies outside the grid (a sum of at most three ones).
 constexpr int SFC_AXIS_CAP = 64;               // lattice points per axis the entry tables hold
 constexpr uint32_t SFC_GAPS_MAX_CELLS = 1u << 26;  // the offset field; larger worlds keep the 32-byte records (gaps == nullptr)
-DQ_FN uint32_t sfc_axis_entry(const SfcWorldView &w, int k, float bk, int it) {
+DQ_FN uint32_t sfc_axis_entry(const SfcWorldView &w, double inv_res, int k, float bk, int it) {
     const float sp = (float)(bk + it * w.res);
-    const double sc = (1.0 / w.res) * (double)sp;
+    const double sc = inv_res * (double)sp;  // inv_res = 1.0 / w.res, as sfc_lattice_point_blocked forms it
     const int c = (int)floor(sc);  // OcTreeBaseImpl::coordToKey
     int d = (int)floor(sc + 0.5) - c;
     d = d < 0 ? 0 : (d > 1 ? 1 : d);
@@ -167,23 +179,68 @@ DQ_FN uint32_t sfc_axis_entry(const SfcWorldView &w, int k, float bk, int it) {
 // A point's coordinates are functions of one axis each, and the reference computes them in float32 / double from the box's own
 // corner (the rounding decides which cell is read): with the lattice-point table the per-axis part -- everything but one add, one
 // table word and one compare -- is done once per box and axis (W::axis_fill / W::axis_entry) instead of once per point.
+DQ_FN void sfc_prepare(const SfcWorldView &g, SfcParams &p) {
+    p.inv_res = 1.0 / g.res;
+    p.gap_max = sfc_gap_max(p.margin, g.res);
+    p.svt = nullptr;
+    if (g.svt && g.gaps && p.gap_max >= 0) p.svt = g.svt[p.gap_max];  // uniform
+}
+
+// The lattice index (nearest whole multiple of the resolution) of point `it` along one axis of a box that starts at bk: the cell
+// and corner bit of sfc_axis_entry, added.  Non-decreasing in `it`.
+DQ_FN int sfc_axis_lattice(const SfcWorldView &w, double inv_res, float bk, int it) {
+    const float sp = (float)(bk + it * w.res);
+    const double sc = inv_res * (double)sp;
+    const int c = (int)floor(sc);
+    int d = (int)floor(sc + 0.5) - c;
+    d = d < 0 ? 0 : (d > 1 ? 1 : d);
+    return c + d;
+}
+
+// true: no lattice point of the box is blocked in any reading (SfcWorldView::svt) -- the box test's answer is "free".
+// W::uniform(v): the value as a wave-uniform scalar (it is the same in every lane).
 template <class W>
-DQ_FN bool sfc_obstacle_in_box(const W &w, const SfcWorldView &g, const float *b, double margin) {
+DQ_FN bool sfc_box_surely_free(const W &w, const SfcWorldView &g, const SfcParams &p, const float *b, const int *mi) {
+    int a[3], e[3];  // local lattice range per axis, [a, e)
+    bool none = false;
+    for (int k = 0; k < 3; k++) {
+        const int first = sfc_axis_lattice(g, p.inv_res, b[k], 0) - g.lo[k];
+        const int last = sfc_axis_lattice(g, p.inv_res, b[k], mi[k] - 1) - g.lo[k];
+        a[k] = w.uniform(first < 0 ? 0 : first);
+        e[k] = w.uniform((last > g.n[k] ? g.n[k] : last) + 1);
+        none |= e[k] <= a[k];  // all of the box lies outside the grid along this axis: no point is inside, none is blocked
+    }
+    if (none) return true;  // uniform
+    const int s1 = g.n[2] + 2, s0 = (g.n[1] + 2) * s1;
+    const int32_t *t = p.svt;
+    const int count = t[e[0] * s0 + e[1] * s1 + e[2]] - t[a[0] * s0 + e[1] * s1 + e[2]] - t[e[0] * s0 + a[1] * s1 + e[2]] -
+                      t[e[0] * s0 + e[1] * s1 + a[2]] + t[a[0] * s0 + a[1] * s1 + e[2]] + t[a[0] * s0 + e[1] * s1 + a[2]] +
+                      t[e[0] * s0 + a[1] * s1 + a[2]] - t[a[0] * s0 + a[1] * s1 + a[2]];
+    return w.uniform(count) == 0;
+}
+
+template <class W>
+DQ_FN bool sfc_obstacle_in_box(const W &w, const SfcWorldView &g, const float *b, const SfcParams &p) {
+    const double margin = p.margin;
     int mi[3];
     // (the reference divides by the resolution; the quotient is a whole number of cells + 1e-4, float32 noise of the box edges 1e-5 of
     // a cell: multiplying by the reciprocal -- a third of the instructions, and this runs between any two trial expansions -- lands
     // on the same side of the floor)
-    const double inv_res = 1.0 / g.res;
+    const double inv_res = p.inv_res;
     for (int k = 0; k < 3; k++) mi[k] = (int)floor((b[3 + k] - b[k] + SFC_EPS_F) * inv_res) + 1;
+    // (a box that is inside out along an axis has no points: the reference's three nested loops do not run)
+    const bool has_points = w.uniform((int)((mi[0] > 0) & (mi[1] > 0) & (mi[2] > 0))) != 0;
+    if (!has_points) return false;  // uniform
+    if (p.svt && sfc_box_surely_free(w, g, p, b, mi)) return false;  // uniform
     const int total = mi[0] * mi[1] * mi[2];
-    const int gap_max = sfc_gap_max(margin, g.res);
+    const int gap_max = p.gap_max;
     const bool small = (mi[0] <= SFC_AXIS_CAP) & (mi[1] <= SFC_AXIS_CAP) & (mi[2] <= SFC_AXIS_CAP);
     if (g.gaps && small) {  // uniform
-        w.axis_fill(g, b);
+        w.axis_fill(g, inv_res, b);
         // idx -> (a1, b2, c3) without integer division: idx + 0.5 is exact in float32 (idx < 2^18), the product with the rounded
         // reciprocal is off by at most (idx / m) 2^-23 < 1 / (32 m), and (idx + 0.5) / m is never closer than 1 / (2 m) to a whole
-        // number -- the truncation is floor(idx / m)
-        const float r2 = 1.0f / (float)mi[2], r1 = 1.0f / (float)mi[1];
+        // number -- the truncation is floor(idx / m) (and stays it with a reciprocal that is an ulp off: W::rcp)
+        const float r2 = w.rcp((float)mi[2]), r1 = w.rcp((float)mi[1]);
         return w.any_of(total, [&](int idx) {
             const int ab = (int)(((float)idx + 0.5f) * r2), c3 = idx - ab * mi[2];
             const int a1 = (int)(((float)ab + 0.5f) * r1), b2 = ab - a1 * mi[1];
@@ -213,7 +270,7 @@ template <class W>
 DQ_FN bool sfc_expand(const W &w, const SfcWorldView &g, const SfcParams &p, const float *init, float *out) {
     const double mx = 2 * p.grid_resolution > p.agent_max_vel * p.dt ? 2 * p.grid_resolution : p.agent_max_vel * p.dt;
     const int max_iter = (int)round(mx / g.res) + 1;
-    if (sfc_obstacle_in_box(w, g, init, p.margin)) return false;
+    if (sfc_obstacle_in_box(w, g, init, p)) return false;
     float sfc[6], cand[6], upd[6];
     int axis_cand[6] = {0, 1, 2, 3, 4, 5}, n_cand = 6;  // -x -y -z +x +y +z
     int axis_iter[6] = {0, 0, 0, 0, 0, 0};
@@ -221,7 +278,7 @@ DQ_FN bool sfc_expand(const W &w, const SfcWorldView &g, const SfcParams &p, con
     for (int k = 0; k < 6; k++) sfc[k] = init[k];
     while (n_cand > 0) {
         for (int k = 0; k < 6; k++) { cand[k] = sfc[k]; upd[k] = sfc[k]; }
-        while (sfc_in_boundary(g, upd, 0) && !sfc_obstacle_in_box(w, g, upd, p.margin)) {
+        while (sfc_in_boundary(g, upd, 0) && !sfc_obstacle_in_box(w, g, upd, p)) {
             i++;
             if (i >= n_cand) i = 0;
             // axis_cand[i] without dynamic indexing of a local array

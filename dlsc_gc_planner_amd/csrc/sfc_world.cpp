@@ -73,4 +73,33 @@ void build_sfc_world(const double *boxes, int n_boxes, double resolution, const 
     for (size_t q = 0; q < nc; q++) w.gaps[q] = sfc_corner_gaps(&w.near_packed[q * 8], resolution);
 }
 
+void build_sfc_svt(const SfcWorldHost &w, int gap_max, std::vector<int32_t> &svt) {
+    const int n0 = w.n[0], n1 = w.n[1], n2 = w.n[2];
+    const size_t s1 = (size_t)n2 + 2, s0 = ((size_t)n1 + 2) * s1;
+    svt.assign(((size_t)n0 + 2) * s0, 0);
+    // blocked[i][j][k] of lattice point (i, j, k), 0 <= i <= n0 ...: some cell c = I - v (v in {0,1}^3) of the grid reads its
+    // corner v as at most gap_max cells from an occupied cell of its record; stored at [i + 1][j + 1][k + 1], then summed in place
+    for (int i = 0; i <= n0; i++)
+        for (int j = 0; j <= n1; j++)
+            for (int k = 0; k <= n2; k++) {
+                int blocked = 0;
+                for (int v = 0; v < 8; v++) {
+                    const int ci = i - (v & 1), cj = j - ((v >> 1) & 1), ck = k - ((v >> 2) & 1);
+                    if (ci < 0 || cj < 0 || ck < 0 || ci >= n0 || cj >= n1 || ck >= n2) continue;
+                    const uint32_t word = w.gaps[((size_t)ci * n1 + cj) * n2 + ck];
+                    if ((int)((word >> (4 * v)) & 15u) <= gap_max) blocked = 1;
+                }
+                svt[(size_t)(i + 1) * s0 + (size_t)(j + 1) * s1 + (k + 1)] = blocked;
+            }
+    for (int i = 1; i <= n0 + 1; i++)  // prefix sums along k, j, i in turn
+        for (int j = 1; j <= n1 + 1; j++)
+            for (int k = 2; k <= n2 + 1; k++) svt[i * s0 + j * s1 + k] += svt[i * s0 + j * s1 + k - 1];
+    for (int i = 1; i <= n0 + 1; i++)
+        for (int j = 2; j <= n1 + 1; j++)
+            for (int k = 1; k <= n2 + 1; k++) svt[i * s0 + j * s1 + k] += svt[i * s0 + (j - 1) * s1 + k];
+    for (int i = 2; i <= n0 + 1; i++)
+        for (int j = 1; j <= n1 + 1; j++)
+            for (int k = 1; k <= n2 + 1; k++) svt[i * s0 + j * s1 + k] += svt[(i - 1) * s0 + j * s1 + k];
+}
+
 }  // namespace dlscqp

@@ -25,4 +25,7 @@ struct SfcWorldHost {
 void build_sfc_world(const double *boxes, int n_boxes, double resolution, const float wmin[3], const float wmax[3],
                      SfcWorldHost &w);
 
+// SfcWorldView::svt[gap_max] of a built world: (n_0 + 2)(n_1 + 2)(n_2 + 2) entries.
+void build_sfc_svt(const SfcWorldHost &w, int gap_max, std::vector<int32_t> &svt);
+
 }  // namespace dlscqp

@@ -362,11 +362,14 @@ extern "C" int emul_generate_lsc(const dlscqp_config *cfg, const dlscqp_lsc_gen 
 // Row N2: the device code of sfc_core.hpp with the lanes of a wave run one after another, on the world table that
 // the product's host code (sfc_world.cpp) builds.
 namespace {
+int64_t g_sfc_stats[4];  // box tests, lattice points of those boxes, tests that found an obstacle, agents (developer aid, emul_sfc_stats)
 struct WaveSfcCpu {
     template <class F>
     bool any_of(int n, F f) const {
+        g_sfc_stats[0]++;
+        g_sfc_stats[1] += n;
         for (int i = 0; i < n; i++)
-            if (f(i)) return true;
+            if (f(i)) { g_sfc_stats[2]++; return true; }
         return false;
     }
     void load6(const float *src, float *dst) const { for (int k = 0; k < 6; k++) dst[k] = src[k]; }
@@ -374,9 +377,11 @@ struct WaveSfcCpu {
     void fence() const {}
     int uniform_max8(int v) const { return v; }  // one point at a time on the host
     mutable uint32_t axis[3][dlscqp::SFC_AXIS_CAP];
-    void axis_fill(const dlscqp::SfcWorldView &g, const float *b) const {
+    float rcp(float x) const { return 1.0f / x; }
+    int uniform(int v) const { return v; }
+    void axis_fill(const dlscqp::SfcWorldView &g, double inv_res, const float *b) const {
         for (int k = 0; k < 3; k++)
-            for (int l = 0; l < dlscqp::SFC_AXIS_CAP; l++) axis[k][l] = dlscqp::sfc_axis_entry(g, k, b[k], l);
+            for (int l = 0; l < dlscqp::SFC_AXIS_CAP; l++) axis[k][l] = dlscqp::sfc_axis_entry(g, inv_res, k, b[k], l);
     }
     uint32_t axis_entry(int k, int it) const { return axis[k][it]; }
     bool corner_blocked(const dlscqp::SfcWorldView &g, int ic, int jc, int kc, int corner, int gap_max) const {
@@ -385,6 +390,10 @@ struct WaveSfcCpu {
     }
 };
 }  // namespace
+
+extern "C" void emul_sfc_stats(int64_t *out, int reset) {
+    for (int k = 0; k < 4; k++) { out[k] = g_sfc_stats[k]; if (reset) g_sfc_stats[k] = 0; }
+}
 
 extern "C" int emul_generate_sfc(const dlscqp_config *cfg, const double *boxes, int n_boxes, double resolution,
                                  const float *world_min, const float *world_max, const dlscqp_sfc_gen *gen) {
@@ -396,16 +405,32 @@ extern "C" int emul_generate_sfc(const dlscqp_config *cfg, const double *boxes, 
     for (int k = 0; k < 3; k++) { v.wmin[k] = hw.wmin[k]; v.wmax[k] = hw.wmax[k]; v.lo[k] = hw.lo[k]; v.n[k] = hw.n[k]; }
     v.near = hw.near_packed.data();
     v.gaps = std::getenv("EMUL_SFC_RECORDS") || hw.cells() >= (size_t)SFC_GAPS_MAX_CELLS ? nullptr : hw.gaps.data();  // the lattice-point table, or the 32-byte records as in round 3
+    // the summed-volume tables the agents' radii ask for (the product builds them the same way on the first launch); EMUL_SFC_SVT=0: none
+    std::vector<int32_t> svt[15];
+    const int32_t *svt_ptrs[15] = {};
+    v.svt = nullptr;
+    const char *svt_env = std::getenv("EMUL_SFC_SVT");
+    if (v.gaps && !(svt_env && svt_env[0] == '0')) {
+        for (int a = 0; a < gen->n_agents; a++) {
+            const int gm = sfc_gap_max(gen->radius[a], hw.res);
+            if (gm < 0 || gm > 14 || svt_ptrs[gm]) continue;
+            build_sfc_svt(hw, gm, svt[gm]);
+            svt_ptrs[gm] = svt[gm].data();
+        }
+        v.svt = svt_ptrs;
+    }
     WaveSfcCpu w;
     const int M = cfg->M, n1 = cfg->n + 1;
     for (int a = 0; a < gen->n_agents; a++) {
-        SfcParams p{gen->radius[a], gen->grid_resolution, gen->max_vel[a], cfg->dt};
+        SfcParams p{gen->radius[a], gen->grid_resolution, gen->max_vel[a], cfg->dt, 0.0, 0, nullptr};
+        sfc_prepare(v, p);
         float *sfcs = gen->sfcs + (size_t)a * M * 6;
         int code;
         if (gen->initialize) code = sfc_initialize(w, v, p, gen->position + 3 * (size_t)a, M, sfcs) ? 0 : -1;
         else code = sfc_construct(w, v, p, gen->initial_traj + (size_t)a * M * n1 * 3, M, n1, gen->goals + 3 * (size_t)a,
                                   gen->waypoints + 3 * (size_t)a, sfcs);
         if (gen->out_code) gen->out_code[a] = code;
+        g_sfc_stats[3]++;
     }
     return 0;
 }
