@@ -622,6 +622,8 @@ struct WaveSfcT {
     int lane;
     int *flags;            // LDS [2][SFC_T / 64]: one verdict per wavefront, double-buffered by round
     uint32_t *axis;        // LDS [SFC_T / 64][3][SFC_AXIS_CAP]: the per-axis entries of the box under test, one copy per wavefront
+    float *chainv;         // LDS [SFC_T / 64][6][SFC_CHAIN_CAP]
+    mutable int chain_n = 1;
     mutable int parity = 0;
     // one word of the lattice-point table (sfc_core.hpp: sfc_corner_gaps) per point.  (A copy of the part of the table an expansion
     // can reach, as bytes in LDS, was built and measured in round 4: 0.178 ms per launch against 0.171 -- a trial expansion is
@@ -659,8 +661,41 @@ struct WaveSfcT {
     }
     // sfc_core.hpp: sfc_axis_entry of every lattice index of the box, per axis.  Each wavefront keeps its own copy (lane l computes
     // index l of the three axes): no barrier, a wavefront's LDS accesses are served in order.
+    // sfc_expand's lanes: every wavefront of the workgroup evaluates the same 64 trials (the control flow stays workgroup-uniform;
+    // the wavefronts sit on different SIMDs, the repetition costs nothing) and gets the same two masks
+    template <class F>
+    __device__ __forceinline__ void lanes(F f, uint64_t &m0, uint64_t &m1) const {
+        const int fl = f(lane & 63);
+        m0 = __ballot((fl & 1) != 0);
+        m1 = __ballot((fl & 2) != 0);
+    }
+    // where a face of the box is after c moves (sfc_core.hpp: SfcTurns): lane d % 6 walks direction d, one copy per wavefront
+    __device__ __forceinline__ void chain_fill(const float *init, double res, int n) const {
+        float *t = chainv + (lane >> 6) * (6 * SFC_CHAIN_CAP);
+        const int d = (lane & 63) % 6;
+        float v = init[5];
+        v = d == 4 ? init[4] : v;
+        v = d == 3 ? init[3] : v;
+        v = d == 2 ? init[2] : v;
+        v = d == 1 ? init[1] : v;
+        v = d == 0 ? init[0] : v;
+        const double step = d < 3 ? -res : res;
+        for (int c = 0; c < n; c++) {
+            t[d * SFC_CHAIN_CAP + c] = v;
+            v = (float)((double)v + step);
+        }
+        chain_n = n;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    __device__ __forceinline__ float chain(int d, int c) const {
+        c = c < 0 ? 0 : (c >= chain_n ? chain_n - 1 : c);
+        return chainv[(lane >> 6) * (6 * SFC_CHAIN_CAP) + d * SFC_CHAIN_CAP + c];
+    }
     __device__ __forceinline__ float rcp(float x) const { return __builtin_amdgcn_rcpf(x); }
     __device__ __forceinline__ int uniform(int v) const { return __builtin_amdgcn_readfirstlane(v); }
+    __device__ __forceinline__ float uniform_f(float v) const { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
     __device__ __forceinline__ void axis_fill(const SfcWorldView &g, double inv_res, const float *b) const {
         uint32_t *t = axis + (lane >> 6) * (3 * SFC_AXIS_CAP);
         const int l = lane & 63;
@@ -721,7 +756,9 @@ __global__ __launch_bounds__(SFC_T) void dlscqp_sfc_kernel(SfcGenArgs a) {
     WaveSfcT<SFC_T> w;
     w.lane = (int)threadIdx.x;
     w.flags = sfc_flags;
+    __shared__ float sfc_chain[(SFC_T / 64) * 6 * SFC_CHAIN_CAP];
     w.axis = sfc_axis;
+    w.chainv = sfc_chain;
     SfcParams p;
     p.margin = a.radius[ag];
     p.grid_resolution = a.grid_resolution;

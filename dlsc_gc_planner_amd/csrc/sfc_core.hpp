@@ -20,6 +20,8 @@ namespace dlscqp {
 
 constexpr double SFC_EPS_F = 1e-5;  // SP_EPSILON_FLOAT, sp_const.hpp:4
 
+DQ_FN int sfc_ctz64(uint64_t v) { return __builtin_ctzll(v); }
+
 struct SfcWorldView {  // device (or host) pointers of a world built by build_sfc_world (sfc_world.cpp)
     double res;
     float wmin[3], wmax[3];
@@ -197,30 +199,32 @@ DQ_FN int sfc_axis_lattice(const SfcWorldView &w, double inv_res, float bk, int 
     return c + d;
 }
 
-// true: no lattice point of the box is blocked in any reading (SfcWorldView::svt) -- the box test's answer is "free".
-// W::uniform(v): the value as a wave-uniform scalar (it is the same in every lane).
-template <class W>
-DQ_FN bool sfc_box_surely_free(const W &w, const SfcWorldView &g, const SfcParams &p, const float *b, const int *mi) {
+// How many lattice points of the box are blocked in some reading (SfcWorldView::svt; p.svt != nullptr): 0 = the box test's
+// answer is "free" (also for a box without points, which the reference's loops do not enter).  No branches, every table index
+// clamped into the table: the lanes of a wavefront may each ask about a box of their own (sfc_expand).
+DQ_FN int sfc_box_count(const SfcWorldView &g, const SfcParams &p, const float *b) {
     int a[3], e[3];  // local lattice range per axis, [a, e)
-    bool none = false;
+    bool some = true;
     for (int k = 0; k < 3; k++) {
+        const int mi = (int)floor((b[3 + k] - b[k] + SFC_EPS_F) * p.inv_res) + 1;
+        some &= mi > 0;
         const int first = sfc_axis_lattice(g, p.inv_res, b[k], 0) - g.lo[k];
-        const int last = sfc_axis_lattice(g, p.inv_res, b[k], mi[k] - 1) - g.lo[k];
-        a[k] = w.uniform(first < 0 ? 0 : first);
-        e[k] = w.uniform((last > g.n[k] ? g.n[k] : last) + 1);
-        none |= e[k] <= a[k];  // all of the box lies outside the grid along this axis: no point is inside, none is blocked
+        const int last = sfc_axis_lattice(g, p.inv_res, b[k], (mi > 0 ? mi : 1) - 1) - g.lo[k];
+        const int top = g.n[k] + 1;
+        a[k] = first < 0 ? 0 : (first > top ? top : first);
+        e[k] = last + 1 < 0 ? 0 : (last + 1 > top ? top : last + 1);
+        some &= e[k] > a[k];  // else all of the box lies outside the grid along this axis: no point is inside, none is blocked
     }
-    if (none) return true;  // uniform
     const int s1 = g.n[2] + 2, s0 = (g.n[1] + 2) * s1;
     const int32_t *t = p.svt;
     const int count = t[e[0] * s0 + e[1] * s1 + e[2]] - t[a[0] * s0 + e[1] * s1 + e[2]] - t[e[0] * s0 + a[1] * s1 + e[2]] -
                       t[e[0] * s0 + e[1] * s1 + a[2]] + t[a[0] * s0 + a[1] * s1 + e[2]] + t[a[0] * s0 + e[1] * s1 + a[2]] +
                       t[e[0] * s0 + a[1] * s1 + a[2]] - t[a[0] * s0 + a[1] * s1 + a[2]];
-    return w.uniform(count) == 0;
+    return some ? count : 0;
 }
 
 template <class W>
-DQ_FN bool sfc_obstacle_in_box(const W &w, const SfcWorldView &g, const float *b, const SfcParams &p) {
+DQ_FN bool sfc_obstacle_in_box(const W &w, const SfcWorldView &g, const float *b, const SfcParams &p, bool use_svt = true) {
     const double margin = p.margin;
     int mi[3];
     // (the reference divides by the resolution; the quotient is a whole number of cells + 1e-4, float32 noise of the box edges 1e-5 of
@@ -231,7 +235,7 @@ DQ_FN bool sfc_obstacle_in_box(const W &w, const SfcWorldView &g, const float *b
     // (a box that is inside out along an axis has no points: the reference's three nested loops do not run)
     const bool has_points = w.uniform((int)((mi[0] > 0) & (mi[1] > 0) & (mi[2] > 0))) != 0;
     if (!has_points) return false;  // uniform
-    if (p.svt && sfc_box_surely_free(w, g, p, b, mi)) return false;  // uniform
+    if (use_svt && p.svt && w.uniform(sfc_box_count(g, p, b)) == 0) return false;  // uniform
     const int total = mi[0] * mi[1] * mi[2];
     const int gap_max = p.gap_max;
     const bool small = (mi[0] <= SFC_AXIS_CAP) & (mi[1] <= SFC_AXIS_CAP) & (mi[2] <= SFC_AXIS_CAP);
@@ -265,11 +269,9 @@ DQ_FN bool sfc_in_boundary(const SfcWorldView &g, const float *b, double margin)
     return true;
 }
 
-// expandSFCIncrementally, :1023-1093
+// expandSFCIncrementally, :1023-1093, one trial expansion after the other as the reference writes it
 template <class W>
-DQ_FN bool sfc_expand(const W &w, const SfcWorldView &g, const SfcParams &p, const float *init, float *out) {
-    const double mx = 2 * p.grid_resolution > p.agent_max_vel * p.dt ? 2 * p.grid_resolution : p.agent_max_vel * p.dt;
-    const int max_iter = (int)round(mx / g.res) + 1;
+DQ_FN bool sfc_expand_in_sequence(const W &w, const SfcWorldView &g, const SfcParams &p, const float *init, int max_iter, float *out) {
     if (sfc_obstacle_in_box(w, g, init, p)) return false;
     float sfc[6], cand[6], upd[6];
     int axis_cand[6] = {0, 1, 2, 3, 4, 5}, n_cand = 6;  // -x -y -z +x +y +z
@@ -307,6 +309,129 @@ DQ_FN bool sfc_expand(const W &w, const SfcWorldView &g, const SfcParams &p, con
         n_cand--;
         if (i > 0) i--; else i = n_cand - 1;
     }
+    const double delta = p.margin - ((int)(p.margin / g.res) * g.res);  // SFC margin compensation
+    for (int k = 0; k < 3; k++) {
+        if (sfc[k] > g.wmin[k] + SFC_EPS_F) sfc[k] = (float)(sfc[k] - delta);
+        if (sfc[3 + k] < g.wmax[k] - SFC_EPS_F) sfc[3 + k] = (float)(sfc[3 + k] + delta);
+    }
+    for (int k = 0; k < 6; k++) out[k] = sfc[k];
+    return true;
+}
+
+// ---- the same routine, many trial expansions at a time ------------------------------------------------------------------------
+// The reference's loop is a chain: whether trial t + 1 is even made depends on trial t's box test.  But almost every trial is
+// accepted, and IF trials 1 .. t - 1 are accepted, trial t is known in advance: the directions take turns (axis_cand, i), each
+// accepted trial moves one face by one cell, and a face after c moves is c float32 subtractions from where it started
+// (W::chain, filled once).  So lane t of the wavefront evaluates trial t under that assumption -- limit of moves, boundary, and
+// the box test where the summed-volume table settles it -- and the first lane that does not pass tells how many trials really
+// were accepted; a trial the table cannot settle is tested point by point and the lanes behind it stay valid if it is free.
+// ~65 dependent rounds become one round per direction that closes.  Same trials, same boxes, same floats as sfc_expand_in_sequence.
+constexpr int SFC_CHAIN_CAP = 64;  // moves per direction the chain holds (max_iter + 2 entries are used)
+
+struct SfcTurns {   // uniform state of the reference's loop
+    int moves[6];   // accepted trials per direction (-x -y -z +x +y +z) = axis_iter of the directions still in play
+    int cand[6];    // axis_cand
+    int n_cand, i, max_iter;
+};
+
+// Trial tau >= 1 counted from the state (tau = 0: the test of the whole box that opens a round): the box `upd` that is tested;
+// returns bit 0: the round ends here without a box test (limit of moves, or upd outside the boundary).  Branch-free in tau.
+template <class W>
+DQ_FN int sfc_turn(const W &w, const SfcWorldView &g, const SfcTurns &st, int tau, float *upd) {
+    const bool is_trial = tau >= 1;
+    const int q = is_trial ? tau - 1 : 0;
+    const int r = (int)(((float)q + 0.5f) * w.rcp((float)st.n_cand)), sl = q - r * st.n_cand;  // q / n_cand, q % n_cand (exact: q < 128)
+    int axis = 0, at = 0;   // the direction whose turn it is, and how often it has moved by then
+    float face[6];
+    for (int d = 0; d < 6; d++) {
+        int pos = -1;
+        for (int t = 0; t < 6; t++) pos = (t < st.n_cand) & (st.cand[t] == d) ? t : pos;  // uniform
+        // turns go i + 1, i + 2, ... (mod n_cand): direction d is the o-th of a round
+        int o = pos - st.i - 1;
+        o = o < 0 ? o + st.n_cand : o;
+        o = o < 0 ? o + st.n_cand : o;  // (i may be n_cand - 1 and pos 0: -n_cand <= pos - i - 1)
+        const bool live = pos >= 0;
+        const int done = st.moves[d] + ((is_trial & live) ? r + (o < sl ? 1 : 0) : 0);
+        const bool mine = is_trial & live & (o == sl);
+        axis = mine ? d : axis;
+        at = mine ? done : at;
+        face[d] = w.chain(d, done);
+    }
+    const float moved = w.chain(axis, at + 1);
+    for (int d = 0; d < 6; d++) upd[d] = face[d];
+    for (int k = 0; k < 3; k++) {
+        const bool lo = is_trial & (axis == k), hi = is_trial & (axis == 3 + k);
+        upd[3 + k] = lo ? face[k] : (hi ? moved : upd[3 + k]);  // -k: the new slab is [min - res, min]; +k: [max, max + res]
+        upd[k] = lo ? moved : (hi ? face[3 + k] : upd[k]);
+    }
+    bool inb = true;
+    for (int k = 0; k < 3; k++) inb &= (upd[k] > g.wmin[k] + 0.0 - SFC_EPS_F) & (upd[3 + k] < g.wmax[k] - 0.0 + SFC_EPS_F);  // sfc_in_boundary, margin 0
+    const bool over = is_trial & (at + 1 > st.max_iter);
+    return (int)(over | !inb);
+}
+
+template <class W>
+DQ_FN bool sfc_expand(const W &w, const SfcWorldView &g, const SfcParams &p, const float *init, float *out) {
+    const double mx = 2 * p.grid_resolution > p.agent_max_vel * p.dt ? 2 * p.grid_resolution : p.agent_max_vel * p.dt;
+    const int max_iter = (int)round(mx / g.res) + 1;
+    if (!p.svt || max_iter + 2 > SFC_CHAIN_CAP) return sfc_expand_in_sequence(w, g, p, init, max_iter, out);  // uniform
+    if (sfc_obstacle_in_box(w, g, init, p)) return false;
+    w.chain_fill(init, g.res, max_iter + 2);
+    SfcTurns st;
+    for (int d = 0; d < 6; d++) { st.moves[d] = 0; st.cand[d] = d; }
+    st.n_cand = 6; st.i = -1; st.max_iter = max_iter;
+    bool whole = true;  // the next lane 0 is the test of the whole box that opens a round
+    while (st.n_cand > 0) {
+        const int tau0 = whole ? 0 : 1;
+        uint64_t ends = 0, open = 0;  // per lane: the round ends there for sure / the table does not settle the box
+        w.lanes([&](int lane) {
+            float upd[6];
+            const int hard = sfc_turn(w, g, st, tau0 + lane, upd);
+            const int count = sfc_box_count(g, p, upd);
+            return hard | ((count != 0) << 1);
+        }, ends, open);
+        open &= ~ends;
+        // the first lane that is not simply accepted
+        int f = 0, ended = 0;
+        for (;;) {
+            const uint64_t rest = f < 64 ? ((ends | open) >> f) << f : 0;
+            if (rest == 0) { f = 64; break; }
+            f = w.uniform(sfc_ctz64(rest));
+            if ((ends >> f) & 1) { ended = 1; break; }
+            float upd[6];
+            (void)sfc_turn(w, g, st, tau0 + f, upd);  // uniform: every lane forms lane f's box
+            for (int k = 0; k < 6; k++) upd[k] = w.uniform_f(upd[k]);
+            if (w.uniform((int)sfc_obstacle_in_box(w, g, upd, p, false)) != 0) { ended = 1; break; }
+            f++;
+        }
+        // lanes [0, f) passed: f - (whole ? 1 : 0) trials accepted (lane 0 of an opening pass is not a trial)
+        const int taken = f - (whole ? 1 : 0) < 0 ? 0 : f - (whole ? 1 : 0);
+        const int tau_end = tau0 + f;  // the trial (or the opening test, 0) at which the round ended, if it did
+        {
+            const int r = taken / st.n_cand, sl = taken % st.n_cand;
+            for (int d = 0; d < 6; d++) {
+                int pos = -1;
+                for (int t = 0; t < 6; t++) pos = (t < st.n_cand) & (st.cand[t] == d) ? t : pos;
+                int o = pos - st.i - 1;
+                o = o < 0 ? o + st.n_cand : o;
+                o = o < 0 ? o + st.n_cand : o;
+                st.moves[d] += pos >= 0 ? r + (o < sl ? 1 : 0) : 0;
+            }
+            const int turns = ended ? tau_end : taken;  // i++ happened for the trial that ended the round, too
+            if (turns > 0) st.i = (st.i + turns) % st.n_cand;
+        }
+        if (ended) {
+            for (int t = 0; t < 5; t++)  // axis_cand.erase(begin + i)
+                if (t >= st.i && t + 1 < st.n_cand) st.cand[t] = st.cand[t + 1];
+            st.n_cand--;
+            if (st.i > 0) st.i--; else st.i = st.n_cand - 1;
+            whole = true;
+        } else {
+            whole = false;
+        }
+    }
+    float sfc[6];
+    for (int d = 0; d < 6; d++) sfc[d] = w.uniform_f(w.chain(d, st.moves[d]));
     const double delta = p.margin - ((int)(p.margin / g.res) * g.res);  // SFC margin compensation
     for (int k = 0; k < 3; k++) {
         if (sfc[k] > g.wmin[k] + SFC_EPS_F) sfc[k] = (float)(sfc[k] - delta);

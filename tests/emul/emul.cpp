@@ -362,7 +362,7 @@ extern "C" int emul_generate_lsc(const dlscqp_config *cfg, const dlscqp_lsc_gen 
 // Row N2: the device code of sfc_core.hpp with the lanes of a wave run one after another, on the world table that
 // the product's host code (sfc_world.cpp) builds.
 namespace {
-int64_t g_sfc_stats[4];  // box tests, lattice points of those boxes, tests that found an obstacle, agents (developer aid, emul_sfc_stats)
+int64_t g_sfc_stats[5];  // box tests point by point, lattice points of those boxes, tests that found an obstacle, agents, passes of 64 trials (developer aid, emul_sfc_stats)
 struct WaveSfcCpu {
     template <class F>
     bool any_of(int n, F f) const {
@@ -377,8 +377,32 @@ struct WaveSfcCpu {
     void fence() const {}
     int uniform_max8(int v) const { return v; }  // one point at a time on the host
     mutable uint32_t axis[3][dlscqp::SFC_AXIS_CAP];
+    template <class F>
+    void lanes(F f, uint64_t &m0, uint64_t &m1) const {
+        m0 = m1 = 0;
+        for (int l = 0; l < 64; l++) {
+            const int fl = f(l);
+            m0 |= (uint64_t)(fl & 1) << l;
+            m1 |= (uint64_t)((fl >> 1) & 1) << l;
+        }
+        g_sfc_stats[4]++;
+    }
+    mutable float chainv[6][dlscqp::SFC_CHAIN_CAP];
+    mutable int chain_n = 1;
+    void chain_fill(const float *init, double res, int n) const {
+        for (int d = 0; d < 6; d++) {
+            float v = init[d];
+            for (int c = 0; c < n; c++) {
+                chainv[d][c] = v;
+                v = (float)((double)v + (d < 3 ? -res : res));
+            }
+        }
+        chain_n = n;
+    }
+    float chain(int d, int c) const { return chainv[d][c < 0 ? 0 : (c >= chain_n ? chain_n - 1 : c)]; }
     float rcp(float x) const { return 1.0f / x; }
     int uniform(int v) const { return v; }
+    float uniform_f(float v) const { return v; }
     void axis_fill(const dlscqp::SfcWorldView &g, double inv_res, const float *b) const {
         for (int k = 0; k < 3; k++)
             for (int l = 0; l < dlscqp::SFC_AXIS_CAP; l++) axis[k][l] = dlscqp::sfc_axis_entry(g, inv_res, k, b[k], l);
@@ -392,7 +416,7 @@ struct WaveSfcCpu {
 }  // namespace
 
 extern "C" void emul_sfc_stats(int64_t *out, int reset) {
-    for (int k = 0; k < 4; k++) { out[k] = g_sfc_stats[k]; if (reset) g_sfc_stats[k] = 0; }
+    for (int k = 0; k < 5; k++) { out[k] = g_sfc_stats[k]; if (reset) g_sfc_stats[k] = 0; }
 }
 
 extern "C" int emul_generate_sfc(const dlscqp_config *cfg, const double *boxes, int n_boxes, double resolution,

@@ -155,7 +155,15 @@ def _flights(m, n_agents=10, steps=8, M=10, n=5, seed=3):
     return start, frames
 
 
-def test_device_source_matches_oracle_bit_for_bit(maze):
+@pytest.mark.parametrize("variant", ["turns", "in_sequence", "records"])
+def test_device_source_matches_oracle_bit_for_bit(maze, variant, monkeypatch):
+    """variant: how sfc_core.hpp gets through the trial expansions -- "turns": 64 trials per pass with the summed-volume table
+    (the default); "in_sequence": one trial after the other, every box point by point through the lattice-point table
+    (worlds without the table, or a limit of moves beyond the chain); "records": the same on the 32-byte records of round 3."""
+    if variant == "in_sequence":
+        monkeypatch.setenv("EMUL_SFC_SVT", "0")
+    if variant == "records":
+        monkeypatch.setenv("EMUL_SFC_RECORDS", "1")
     import emul_lib as E
     from dlsc_gc_planner_amd import abi
     m, w, occ = maze
