@@ -29,7 +29,7 @@ for tag, kern, grid in (("lsc", "lsc_kernel", "max"), ("sfc", "sfc_kernel", None
             if kern in r["Kernel_Name"] and (grid is None or r["Grid_Size_X"] == grid):
                 dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     us = sum(dur) / max(len(dur), 1)
-    out.append("## dlscqp_%s (%s), %.1f us per launch under the profiler" % (kern, "2 048 workgroups, %s threads in all, stress batch" % grid if tag == "lsc" else "10 workgroups of 512 threads, maze mission", us))
+    out.append("## dlscqp_%s (%s), %.1f us per launch under the profiler" % (kern, "2 048 workgroups, %s threads in all, stress batch" % grid if tag == "lsc" else "10 workgroups of 256 threads, maze mission", us))
     out.append("")
     out.append("| counter | per launch |")
     out.append("|---|---|")

@@ -10,7 +10,7 @@ import torch
 from dlsc_gc_planner_amd import abi
 from dlsc_gc_planner_amd.planner import BatchTrajOptimizer
 import oracle_lib as O
-from test_sfc import _flights
+from test_sfc import _flights, mixed_classes_check
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -68,3 +68,56 @@ def test_device_corridors_match_oracle_and_feed_the_qp(gpu_required):
     inside = (x >= lo - 1e-6) & (x <= hi + 1e-6)
     inside[:, :, 0, :3] = True
     assert inside.all()
+
+
+def _device_generate(opt, m, radius, vmax, sfcs=None, position=None, initial_traj=None, goals=None, waypoints=None):
+    """emul_lib.generate_sfc's signature over dlscqp_generate_sfc_device: a fresh world and generator per call (as a caller
+    that changes its agents would), boxes in and out through the host"""
+    gen = opt.make_sfc_generator(m["boxes"], m["world_resolution"], m["world"][:3], m["world"][3:], radius, vmax, m["grid_resolution"])
+    try:
+        if position is not None:
+            gen.initialize(torch.from_numpy(position).cuda())
+        else:
+            gen.sfcs.copy_(torch.from_numpy(sfcs))
+            gen.update(torch.from_numpy(initial_traj).cuda(), torch.from_numpy(goals).cuda(), torch.from_numpy(waypoints).cuda())
+        return gen.sfcs.cpu().numpy().copy(), gen.codes.cpu().numpy().copy()
+    finally:
+        gen.close()
+
+
+@pytest.mark.parametrize("variant", ["turns", "in_sequence", "records"])
+def test_device_corridors_of_mixed_radius_and_speed_classes(gpu_required, variant, monkeypatch):
+    """The variants of tests/test_sfc.py on the device (the world reads DLSCQP_SFC_SVT / DLSCQP_SFC_RECORDS when it is created)."""
+    if variant == "in_sequence":
+        monkeypatch.setenv("DLSCQP_SFC_SVT", "0")
+    if variant == "records":
+        monkeypatch.setenv("DLSCQP_SFC_RECORDS", "1")
+    m = json.load(open(os.path.join(HERE, "golden", "world_maze1.json")))
+    cfg = abi.make_config(dim=2, M=10, dt=0.2, world_use_octomap=True, world_min=tuple(m["world"][:3]), world_max=tuple(m["world"][3:]))
+    opt = BatchTrajOptimizer(cfg)
+    try:
+        mixed_classes_check(m, lambda radius, vmax, **kw: _device_generate(opt, m, radius, vmax, **kw))
+    finally:
+        opt.close()
+
+
+def test_device_corridors_in_open_space(gpu_required):
+    """tests/test_sfc.py: test_device_source_open_space on the device (rounds of more than 64 trials)."""
+    m = json.load(open(os.path.join(HERE, "golden", "world_maze1.json")))
+    m["boxes"] = [[-1.8, -0.1, 0.25, 0.2, 0.2, 0.5]]
+    m["world"] = [-2.0, -0.3, 0.0, 6.0, 4.3, 6.0]
+    cfg = abi.make_config(dim=3, M=5, dt=0.2, world_use_octomap=True, world_min=tuple(m["world"][:3]), world_max=tuple(m["world"][3:]))
+    pos = np.float32([[2.0, 2.0, 3.0], [0.5, 1.0, 1.0], [5.5, 4.0, 5.5]])
+    opt = BatchTrajOptimizer(cfg)
+    try:
+        for vmax in (1.0, 25.0):
+            w = O.SfcWorld(m["boxes"], m["world_resolution"], m["world"][:3], m["world"][3:], margin=m["radius"],
+                           grid_resolution=m["grid_resolution"], max_vel=vmax, dt=0.2)
+            try:
+                dev, codes = _device_generate(opt, m, np.full(3, m["radius"]), np.full(3, vmax), position=pos)
+                ref = np.stack([w.initialize(p, cfg.M)[1] for p in pos])
+                assert (codes == 0).all() and np.array_equal(dev, ref)
+            finally:
+                w.close()
+    finally:
+        opt.close()

@@ -187,3 +187,68 @@ def test_device_source_matches_oracle_bit_for_bit(maze, variant, monkeypatch):
     # a blocked start cell is reported, not thrown
     _, codes = E.generate_sfc(cfg, world, radius[:1], vmax[:1], m["grid_resolution"], position=np.float32([[0.0, 0.0, 1.0]]))
     assert codes[0] == -1
+
+
+CLASSES = [(0.15, 1.0), (0.26, 1.0), (0.15, 25.0), (0.15, 40.0)]  # (radius, max_vel)
+
+
+def mixed_classes_check(m, generate):
+    """Agents of several radius / speed classes in one launch against one oracle world per class.  Radius 0.26 asks for another
+    summed-volume table than 0.15 (sfc_gap_max 2 and 1); max_vel 25 lifts the limit of moves per direction to 51 (one pass of 64
+    trials no longer covers a round of six directions), 40 to 81 -- beyond the chain of face positions, so that agent grows its
+    boxes one trial after the other.  generate(radius, vmax, **kw) -> (sfcs, codes) as emul_lib.generate_sfc."""
+    start, frames = _flights(m, n_agents=8, steps=4)
+    N = len(start)
+    cls = [CLASSES[a % len(CLASSES)] for a in range(N)]
+    radius, vmax = np.array([c[0] for c in cls]), np.array([c[1] for c in cls])
+    worlds = {c: O.SfcWorld(m["boxes"], m["world_resolution"], m["world"][:3], m["world"][3:], margin=c[0],
+                            grid_resolution=m["grid_resolution"], max_vel=c[1], dt=0.2) for c in CLASSES}
+    try:
+        dev, codes = generate(radius, vmax, position=start)
+        ref = np.zeros_like(dev)
+        for a in range(N):
+            ok, ref[a] = worlds[cls[a]].initialize(start[a], dev.shape[1])
+            assert (codes[a] == 0) == bool(ok)
+        live = codes == 0
+        assert live.sum() >= N - 2 and np.array_equal(dev[live], ref[live])
+        for traj, goals, wps in frames:
+            dev, codes = generate(radius, vmax, sfcs=dev, initial_traj=traj, goals=goals, waypoints=wps)
+            for a in np.nonzero(live)[0]:
+                code, ref[a] = worlds[cls[a]].construct(traj[a], goals[a], wps[a], ref[a])
+                assert code == codes[a], (a, code, codes[a])
+            assert np.array_equal(dev[live], ref[live])
+    finally:
+        for w in worlds.values():
+            w.close()
+
+
+def test_device_source_mixed_radius_and_speed_classes(maze):
+    import emul_lib as E
+    from dlsc_gc_planner_amd import abi
+    m = maze[0]
+    cfg = abi.make_config(dim=2, M=10, dt=0.2, world_use_octomap=True, world_min=tuple(m["world"][:3]), world_max=tuple(m["world"][3:]))
+    world = dict(boxes=m["boxes"], resolution=m["world_resolution"], world_min=m["world"][:3], world_max=m["world"][3:])
+    mixed_classes_check(m, lambda radius, vmax, **kw: E.generate_sfc(cfg, world, radius, vmax, m["grid_resolution"], **kw))
+
+
+def test_device_source_open_space(maze):
+    """No obstacle within reach: every trial is accepted until the limit of moves or the boundary -- rounds of more than 64
+    trials (a pass that ends without a lane that fails, then continues), 6 x 51 moves."""
+    import emul_lib as E
+    from dlsc_gc_planner_amd import abi
+    m = dict(maze[0])
+    m["boxes"] = [[-1.8, -0.1, 0.25, 0.2, 0.2, 0.5]]  # one small box in a corner of the world
+    m["world"] = [-2.0, -0.3, 0.0, 6.0, 4.3, 6.0]
+    cfg = abi.make_config(dim=3, M=5, dt=0.2, world_use_octomap=True, world_min=tuple(m["world"][:3]), world_max=tuple(m["world"][3:]))
+    world = dict(boxes=m["boxes"], resolution=m["world_resolution"], world_min=m["world"][:3], world_max=m["world"][3:])
+    pos = np.float32([[2.0, 2.0, 3.0], [0.5, 1.0, 1.0], [5.5, 4.0, 5.5]])
+    for vmax in (1.0, 25.0):
+        w = O.SfcWorld(m["boxes"], m["world_resolution"], m["world"][:3], m["world"][3:], margin=m["radius"],
+                       grid_resolution=m["grid_resolution"], max_vel=vmax, dt=0.2)
+        try:
+            dev, codes = E.generate_sfc(cfg, world, np.full(3, m["radius"]), np.full(3, vmax), m["grid_resolution"], position=pos)
+            ref = np.stack([w.initialize(p, cfg.M)[1] for p in pos])
+            assert (codes == 0).all() and np.array_equal(dev, ref)
+            assert vmax == 1.0 or (ref[0, 0, 3:] - ref[0, 0, :3]).min() > 3.0  # grown far beyond one pass of trials
+        finally:
+            w.close()
