@@ -1234,6 +1234,10 @@ def main():
                 "seed": args.seed, "workload_generation_s": t_gen,
             },
             "n_gpus_requested": args.gpus, "n_gpus_visible": int(torch.cuda.device_count()),
+            # the figure that compares like for like with rounds 1-2 (ONE launch of all the GPU's agents per step, in lockstep); `value`
+            # is the swarm groups advancing independently on their own streams (config.swarm_groups_note)
+            "one_launch_per_step": None if not isinstance(one_launch, dict) or not one_launch.get("kernel_order") else
+                                   {"ms_per_step": one_launch["kernel_order"], "qp_per_s": world * N / one_launch["kernel_order"] * 1e3},
             "per_rank_ms": rank_breakdown,
             "empty60_sharded": sharded,
             "hard_batch": hard,
