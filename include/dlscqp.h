@@ -446,13 +446,18 @@ int dlscqp_world_create(dlscqp_ctx *ctx, const double *boxes /*[n_boxes][6]*/, i
                         const float world_min[3], const float world_max[3], dlscqp_world **out);
 void dlscqp_world_destroy(dlscqp_world *world);
 
-/* One replanning step of CollisionConstraints' corridor logic for n_agents agents, one wavefront each, device pointers:
+/* One replanning step of CollisionConstraints' corridor logic for n_agents agents, device pointers:
  *   initialize != 0: initializeSFC (collision_constraints.cpp:435-452) from `position`; out_code 0 = ok, -1 = the start
  *                    cell is blocked (the reference throws std::invalid_argument);
  *   initialize == 0: constructSFCFromInitialTraj (:502-536): boxes shift by one segment, the last box is grown from
  *                    {last point of initial_traj, current goal, next waypoint}; out_code 0 = that box, 1 = the box grown
  *                    inside the previous one without the waypoint, 2 = previous box kept.
- * sfcs: [n_agents][M][6] float32 {min x,y,z, max x,y,z}, in/out; feeds dlscqp_device_batch.sfc_boxes directly. */
+ * sfcs: [n_agents][M][6] float32 {min x,y,z, max x,y,z}, in/out; feeds dlscqp_device_batch.sfc_boxes directly.
+ * The world keeps one summed-volume table per agent radius class (what makes a box test eight reads); which classes there are
+ * is only known from `radius`, which lives in device memory: the FIRST call with a given (radius pointer, n_agents)
+ * synchronises with `stream`, reads the radii and builds the tables that are missing -- later calls are asynchronous like
+ * every other *_device entry.  Inside a stream capture nothing is built (agents without their table grow their boxes the slow
+ * way, same boxes): run one step before capturing.  One workgroup of 256 threads per agent. */
 typedef struct dlscqp_sfc_gen {
     int32_t n_agents;
     int32_t initialize;
