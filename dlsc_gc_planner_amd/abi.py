@@ -224,6 +224,11 @@ class Advance(C.Structure):
         ("waypoint_step", C.c_double),
         ("waypoint_hold_on_lp_failure", C.c_int32),
         ("reserved_", C.c_int32),
+        ("out_boxes", C.c_void_p),
+        ("box_margin", C.c_float),
+        ("box_min", C.c_float * 3),
+        ("box_max", C.c_float * 3),
+        ("reserved2_", C.c_int32),
     ]
 
 

@@ -1705,6 +1705,22 @@ __global__ __launch_bounds__(64) void dlscqp_advance_kernel(AdvanceArgs g) {
             const int e = l + 64 * u;
             if (e < E) init[e] = plan[shifted(e)];
         }
+        if (a.out_boxes) {  // uniform
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the initial trajectory is in memory before it is read back
+            for (int j = l; j < M * 3; j += 64) {  // face (segment m, axis k): minimum and maximum over the segment's control points
+                const int m = j / 3, k = j - 3 * m;
+                float mn = init[m * seg + k], mx = mn;
+                for (int i = 1; i < n1; i++) {
+                    const float v = init[m * seg + 3 * i + k];
+                    mn = v < mn ? v : mn;
+                    mx = v > mx ? v : mx;
+                }
+                const float lo = mn - a.box_margin, hi = mx + a.box_margin;
+                float *box = a.out_boxes + ((size_t)ag * M + m) * 6;
+                box[k] = lo > a.box_min[k] ? lo : a.box_min[k];
+                box[3 + k] = hi < a.box_max[k] ? hi : a.box_max[k];
+            }
+        }
     }
     if (l < 3) {
         const int k = l;
@@ -1752,6 +1768,7 @@ extern "C" int dlscqp_advance_device(dlscqp_ctx *c, const dlscqp_advance *adv, v
         return DLSCQP_ERR_INVALID_ARGUMENT;
     }
     if (c->M * (c->n + 1) * 3 > 512) { g_last_error = "plans of more than 512 floats are not supported"; return DLSCQP_ERR_UNSUPPORTED; }
+    if (adv->out_boxes && !adv->initial_traj) { g_last_error = "out_boxes are the boxes of initial_traj: null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
     (void)hipSetDevice(c->cfg.device);
     AdvanceArgs g;
     g.a = *adv;

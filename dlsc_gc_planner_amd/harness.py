@@ -15,6 +15,7 @@ dlscqp_generate_lsc_device's dynamic branch, soft constraints with slack variabl
 ResultCsv writes the reference's log/result_*.csv layout (multi_sync_simulator.cpp:735-850), so that its replay and
 analysis scripts can read a run of this harness.
 """
+import os
 import time
 
 import numpy as np
@@ -259,10 +260,13 @@ class ClosedLoop:
             dist = to_goal.norm(dim=1, keepdim=True)
             self.wp.copy_(torch.where(dist <= waypoint_step, self.desired_goal,
                                       self.pos + to_goal / dist.clamp_min(1e-9) * waypoint_step))
+        # (the boxes of a world without obstacles are written by the same kernel, for the step that follows: box_in_advance)
+        self.box_in_advance = self.box_margin is not None and os.environ.get("DLSCQP_BOX_IN_ADVANCE", "1") != "0"
+        bkw = dict(boxes=self.box_t, box_margin=self.box_margin, box_min=cfg.world_min, box_max=cfg.world_max) if self.box_in_advance else {}
         self.advance = self.opt.make_advance(self.batch, self.plans, self.cur_goal, self.init_buf,
                                              desired_goal=self.desired_goal if world is None else None,
                                              waypoint_step=waypoint_step if world is None else 0.0,
-                                             hold_on_lp_failure=neighbours == "knn")  # the synthetic swarms' waypoint rule
+                                             hold_on_lp_failure=neighbours == "knn", **bkw)  # the synthetic swarms' waypoint rule
         if world is not None and world.get("prune", True) and not prune:
             # presolve in the half-space generator: rows implied by this step's corridor boxes are never written
             self.row_counts = self.gen.enable_pruning(self.sfc.sfcs)
@@ -401,8 +405,9 @@ class ClosedLoop:
         self._stage("sfc_generation_time")
         if self.sfc is not None:
             self.sfc.update(self.init_buf, self.cur_goal, self.wp)
-        if self.box_margin is not None:
-            # one box per segment around the initial trajectory (the shifted previous plan), inside the world box
+        if self.box_margin is not None and (first or not self.box_in_advance):
+            # one box per segment around the initial trajectory (the shifted previous plan), inside the world box (after the
+            # first step dlscqp_advance_device has written them at the end of the step before: five small launches less)
             torch = self.torch
             lo = torch.maximum(self.init_buf.amin(dim=2) - self.box_margin, self.box_lo)
             hi = torch.minimum(self.init_buf.amax(dim=2) + self.box_margin, self.box_hi)
@@ -444,6 +449,8 @@ class ClosedLoop:
         state = [self.batch.t["agents"], self.cur_goal, self.plans, self.init_buf]
         if self.sfc is not None:
             state.append(self.sfc.sfcs)  # the corridor boxes are shifted in place every step
+        if self.box_margin is not None:
+            state.append(self.box_t)
         keep = [t.clone() for t in state]
         side = torch.cuda.Stream(self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))

@@ -144,11 +144,13 @@ class BatchTrajOptimizer:
         return SfcGenerator(self, boxes, resolution, world_min, world_max, radius, max_vel, grid_resolution, device)
 
     def make_advance(self, batch, plans, current_goal, initial_traj=None, waypoints=None, desired_goal=None,
-                     waypoint_step=0.0, hold_on_lp_failure=False):
+                     waypoint_step=0.0, hold_on_lp_failure=False, boxes=None, box_margin=0.0, box_min=None, box_max=None):
         """The bookkeeping between two launches of `batch` as one kernel (dlscqp_advance_device): fail-safe, sub-goal,
         state := plan(dt), the next step's agent records and initial trajectory.  All arguments are CUDA tensors that
         stay where they are (float32; plans / initial_traj [N, M, n+1, 3], current_goal / waypoints / desired_goal
-        [N, 3]); returns a callable(stream=None)."""
+        [N, 3]); returns a callable(stream=None).  boxes [N, M, 6] (with initial_traj): the kernel also writes the next step's
+        boxes of a world without obstacles -- bounding box of each segment of initial_traj, box_margin wider, cut to
+        [box_min, box_max]."""
         a = abi.Advance()
         a.n_agents = batch.n_agents
         a.status, a.goal_status = batch.out_status.data_ptr(), batch.out_goal_status.data_ptr()
@@ -162,7 +164,13 @@ class BatchTrajOptimizer:
         a.desired_goal = None if desired_goal is None else desired_goal.data_ptr()
         a.waypoint_step = float(waypoint_step)
         a.waypoint_hold_on_lp_failure = int(bool(hold_on_lp_failure))
-        keep = (batch, plans, current_goal, initial_traj, waypoints, desired_goal)
+        if boxes is not None:
+            assert initial_traj is not None and boxes.is_contiguous() and boxes.dtype == self._torch().float32
+            a.out_boxes = boxes.data_ptr()
+            a.box_margin = float(box_margin)
+            for k in range(3):
+                a.box_min[k], a.box_max[k] = float(box_min[k]), float(box_max[k])
+        keep = (batch, plans, current_goal, initial_traj, waypoints, desired_goal, boxes)
         torch = self._torch()
 
         def run(stream=None, _keep=keep):

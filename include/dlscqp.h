@@ -431,6 +431,13 @@ typedef struct dlscqp_advance {
     int32_t waypoint_hold_on_lp_failure; /* (with desired_goal) an agent whose goal LP was infeasible gets its sub-goal as the next
                                             waypoint for one step: the synthetic swarms' rule (workloads.generate)          */
     int32_t reserved_;
+    /* optional (with initial_traj): the next step's boxes of a world WITHOUT obstacles -- per segment the bounding box of the
+     * initial trajectory's control points, `box_margin` wider on every side, cut to [box_min, box_max] (float32 arithmetic) --
+     * written where dlscqp_device_batch.sfc_boxes reads them: [n][M][6] {min x,y,z, max x,y,z}                              */
+    float *out_boxes;
+    float box_margin;
+    float box_min[3], box_max[3];
+    int32_t reserved2_;
 } dlscqp_advance;
 
 int dlscqp_advance_device(dlscqp_ctx *ctx, const dlscqp_advance *adv, void *stream);

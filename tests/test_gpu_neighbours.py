@@ -123,3 +123,35 @@ def test_x2048_flies_as_a_moving_crowd(gpu_required):
         assert fails <= 0.02 * 60 * N
     finally:
         sim.close()
+
+
+def test_boxes_of_an_open_world_come_out_of_the_state_update(gpu_required, monkeypatch):
+    """dlscqp_advance.out_boxes: the next step's per-segment boxes written by the state-update kernel are, bit for bit, what the
+    harness computed with five tensor operations at the start of that step -- and so are the flights."""
+    cfg = workloads.x2048_config()
+    N = 128
+    start, goal = workloads.swapping_pairs(cfg, N)
+    flights = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DLSCQP_BOX_IN_ADVANCE", mode)
+        sim = ClosedLoop(cfg, start, goal, radius=0.15, downwash=2.0, max_vel=1.0, max_acc=2.0, waypoint_step=0.5,
+                         neighbours="device", nbr_pitch=64, corridor_margin=0.5, prune=True)
+        try:
+            assert sim.box_in_advance == (mode == "1")
+            rec = []
+            for k in range(12):
+                sim.step()
+                # (the boxes the step's launch READ: with the kernel's boxes box_t already holds the next step's)
+                rec.append((sim.plans.cpu().numpy().copy(), sim.batch.results()["status"].copy()))
+            boxes_next = sim.box_t.cpu().numpy().copy()
+            if mode == "0":  # what the tensor operations would hand the next step
+                import torch
+                lo = torch.maximum(sim.init_buf.amin(dim=2) - sim.box_margin, sim.box_lo)
+                hi = torch.minimum(sim.init_buf.amax(dim=2) + sim.box_margin, sim.box_hi)
+                boxes_next = torch.cat([lo, hi], dim=2).cpu().numpy()
+            flights.append((rec, boxes_next))
+        finally:
+            sim.close()
+    for (p0, s0), (p1, s1) in zip(flights[0][0], flights[1][0]):
+        assert np.array_equal(s0, s1) and np.array_equal(p0, p1)
+    assert np.array_equal(flights[0][1], flights[1][1])
