@@ -488,8 +488,12 @@ constexpr int LSC_THREADS = 128;
 // ... and one wavefront per agent (THREADS = 64) where an agent has at most 64 items -- the synthetic swarms: five neighbours x five
 // segments; with 128 threads four fifths of the lanes had nothing to do (32 768 agents: 0.28 ms per step, the largest stage of the
 // S64 closed loop)
+#ifndef DQ_LSC_OCC
+#define DQ_LSC_OCC 4  // wavefronts per SIMD the half-space generator is compiled for (128 VGPRs, 26 of them spilled; 3 = 158 VGPRs and no
+                      // spill was measured in round 4: crowd stage 0.099 -> 0.113 ms, stress step 0.133 -> 0.144 -- the fourth wavefront is worth more)
+#endif
 template <int THREADS>
-__global__ __launch_bounds__(THREADS, 4) void dlscqp_lsc_kernel(LscGenArgs g) {
+__global__ __launch_bounds__(THREADS, DQ_LSC_OCC) void dlscqp_lsc_kernel(LscGenArgs g) {
     const int k = blockIdx.x;
     if (k >= g.n_local) return;
     const int self = g.local_ids ? g.local_ids[k] : k;

@@ -345,7 +345,7 @@ DQ_FN int sfc_turn(const W &w, const SfcWorldView &g, const SfcTurns &st, int ta
     float face[6];
     for (int d = 0; d < 6; d++) {
         int pos = -1;
-        for (int t = 0; t < 6; t++) pos = (t < st.n_cand) & (st.cand[t] == d) ? t : pos;  // uniform
+        for (int t = 0; t < 6; t++) pos = ((t < st.n_cand) & (st.cand[t] == d)) ? t : pos;  // uniform
         // turns go i + 1, i + 2, ... (mod n_cand): direction d is the o-th of a round
         int o = pos - st.i - 1;
         o = o < 0 ? o + st.n_cand : o;
@@ -411,7 +411,7 @@ DQ_FN bool sfc_expand(const W &w, const SfcWorldView &g, const SfcParams &p, con
             const int r = taken / st.n_cand, sl = taken % st.n_cand;
             for (int d = 0; d < 6; d++) {
                 int pos = -1;
-                for (int t = 0; t < 6; t++) pos = (t < st.n_cand) & (st.cand[t] == d) ? t : pos;
+                for (int t = 0; t < 6; t++) pos = ((t < st.n_cand) & (st.cand[t] == d)) ? t : pos;
                 int o = pos - st.i - 1;
                 o = o < 0 ? o + st.n_cand : o;
                 o = o < 0 ? o + st.n_cand : o;
