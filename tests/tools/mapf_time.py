@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--world", default="world_forest1.json")
     a = ap.parse_args()
     m = json.load(open(os.path.join(ROOT, "tests", "golden", a.world)))
+    m = dict(dict(dim=2, M=10, dt=0.2, communication_range=3.0, downwash=2.0), **m)  # (the maze file: the launch file's values)
     cfg = abi.make_config(dim=m["dim"], M=m["M"], dt=m["dt"], communication_range=m["communication_range"], world_use_octomap=True,
                           world_min=tuple(m["world"][:3]), world_max=tuple(m["world"][3:]))
     start, goal = np.array(m["start"], np.float32), np.array(m["goal"], np.float32)
