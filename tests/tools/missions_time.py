@@ -12,5 +12,5 @@ if __name__ == "__main__":
     out = bench.closed_loop_latency(0)
     for k, v in out.items():
         if isinstance(v, dict):
-            print("%-24s p50 %.4f  p99 %.4f  stages %s" % (k, v.get("p50_ms", float("nan")), v.get("p99_ms", float("nan")),
+            print("%-24s p50 %.4f  p99 %.4f  graph %s stages %s" % (k, v.get("p50_ms", float("nan")), v.get("p99_ms", float("nan")), v.get("p50_ms_as_one_hip_graph"),
                                                          {a: round(b, 4) for a, b in (v.get("stage_p50_ms") or {}).items()}))
