@@ -739,6 +739,30 @@ struct WaveSfcT {
         __syncthreads();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+    // the agent's boxes at hand (sfc_construct): old[M][6] as read, kept[M][6] as they will be written.  Every wavefront reads
+    // only `old` and writes all of `kept` itself (the same values as the others): no barrier after the one that ends the load.
+    float *boxes;  // LDS [2][SFC_BOXES_CAP][6]
+    __device__ __forceinline__ void boxes_load(const float *sfcs, int M) const {
+        const int n = 6 * M;
+        for (int i0 = 0; i0 < n; i0 += SFC_T) {  // uniform trip count; a lane past the end repeats the last element
+            const int i = i0 + lane < n ? i0 + lane : n - 1;
+            boxes[i] = sfcs[i];
+        }
+        fence();
+    }
+    __device__ __forceinline__ void box(int m, float *out) const {
+        for (int k = 0; k < 6; k++) out[k] = boxes[6 * m + k];
+    }
+    __device__ __forceinline__ void box_keep(int m, const float *in) const {
+        for (int k = 0; k < 6; k++) boxes[6 * SFC_BOXES_CAP + 6 * m + k] = in[k];  // every lane, the same words, the same values
+    }
+    __device__ __forceinline__ void boxes_store(float *sfcs, int M) const {
+        const int n = 6 * M;
+        for (int i0 = 0; i0 < n; i0 += SFC_T) {
+            const int i = i0 + lane < n ? i0 + lane : n - 1;
+            sfcs[i] = boxes[6 * SFC_BOXES_CAP + i];
+        }
+    }
 };
 
 struct SfcGenArgs {
@@ -761,8 +785,10 @@ __global__ __launch_bounds__(SFC_T) void dlscqp_sfc_kernel(SfcGenArgs a) {
     w.lane = (int)threadIdx.x;
     w.flags = sfc_flags;
     __shared__ float sfc_chain[(SFC_T / 64) * 6 * SFC_CHAIN_CAP];
+    __shared__ float sfc_boxes[2 * SFC_BOXES_CAP * 6];
     w.axis = sfc_axis;
     w.chainv = sfc_chain;
+    w.boxes = sfc_boxes;
     SfcParams p;
     p.margin = a.radius[ag];
     p.grid_resolution = a.grid_resolution;

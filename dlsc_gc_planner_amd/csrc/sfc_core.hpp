@@ -507,27 +507,69 @@ DQ_FN bool sfc_initialize(const W &w, const SfcWorldView &g, const SfcParams &p,
     return true;
 }
 
+// Box::isSuperSetOfConvexHull without branches (the lanes of a wavefront ask about different boxes)
+DQ_FN bool sfc_superset_of_hull_lane(const float *b, const float *pts, int n) {
+    bool ok = true;
+    for (int k = 0; k < 3; k++) {
+        float mn = pts[k], mxv = pts[k];
+        for (int q = 1; q < n; q++) {
+            mn = pts[3 * q + k] < mn ? pts[3 * q + k] : mn;
+            mxv = pts[3 * q + k] > mxv ? pts[3 * q + k] : mxv;
+        }
+        ok &= !((mn < b[k] - SFC_EPS_F) | (mxv > b[3 + k] + SFC_EPS_F));
+    }
+    return ok;
+}
+
+constexpr int SFC_BOXES_CAP = 32;  // segments whose boxes W keeps at hand (W::boxes_load); more: the boxes are walked in memory
+
 // constructSFCFromInitialTraj (:502-536).  initial_traj [M][n1][3]; sfcs [M][6] in/out.
 // Returns 0: greedy box (hull incl. waypoint), 1: box inside the previous one, 2: previous box reused.
 template <class W>
 DQ_FN int sfc_construct(const W &w, const SfcWorldView &g, const SfcParams &p, const float *initial_traj, int M, int n1,
                         const float *goal, const float *waypoint, float *sfcs) {
     float cur[6], nxt[6];
-    // W::fence() orders the global accesses of all threads that work on this agent (GPU: several wavefronts): every thread has
-    // read box m + 1 before any thread overwrites it in the next iteration
-    for (int m = 0; m < M - 1; m++) {  // shift, then the minor refinement reads the shifted boxes
-        w.load6(sfcs + 6 * (m + 1), nxt);
-        w.fence();
-        w.store6(sfcs + 6 * m, nxt);
-    }
-    w.fence();
-    for (int m = 0; m < M - 2; m++) {
-        w.load6(sfcs + 6 * (m + 1), nxt);
-        w.fence();
-        if (sfc_superset_of_hull(nxt, initial_traj + (size_t)m * n1 * 3, n1)) {
-            w.store6(sfcs + 6 * m, nxt);
-            w.fence();
+    const bool at_hand = M <= SFC_BOXES_CAP && M >= 2;
+    if (at_hand) {  // uniform
+        // The reference shifts the boxes by one segment and then lets box m take over box m + 1 where that one holds segment m of
+        // the initial trajectory -- two loops over M of load, test, store.  No iteration reads what another wrote (iteration m
+        // writes box m and reads box m + 1 of the SHIFTED list), so with the old boxes b at hand:
+        //     box m = holds(b[m + 2], segment m) ? b[m + 2] : b[m + 1]   (m <= M - 3),   box M - 2 = b[M - 1],
+        // every test on a lane of its own, one trip to memory in and one out.
+        w.boxes_load(sfcs, M);
+        uint64_t takes_next = 0, unused = 0;
+        w.lanes([&](int lane) {
+            const int m = lane < M - 2 ? lane : (M > 2 ? M - 3 : 0);
+            float b[6];
+            w.box(m + 2 < M ? m + 2 : M - 1, b);
+            return (int)(sfc_superset_of_hull_lane(b, initial_traj + (size_t)m * n1 * 3, n1) & (lane < M - 2));
+        }, takes_next, unused);
+        w.box(M - 1, cur);
+        for (int k = 0; k < 6; k++) cur[k] = w.uniform_f(cur[k]);
+        for (int m = 0; m < M - 1; m++) {
+            const bool next = m < M - 2 && ((takes_next >> m) & 1);  // uniform
+            w.box(next ? m + 2 : m + 1, nxt);
+            w.box_keep(m, nxt);  // (box m is not read again: m + 1 and m + 2 are what the later iterations read)
         }
+    } else {
+        // W::fence() orders the global accesses of all threads that work on this agent (GPU: several wavefronts): every thread has
+        // read box m + 1 before any thread overwrites it in the next iteration
+        for (int m = 0; m < M - 1; m++) {  // shift, then the minor refinement reads the shifted boxes
+            w.load6(sfcs + 6 * (m + 1), nxt);
+            w.fence();
+            w.store6(sfcs + 6 * m, nxt);
+        }
+        w.fence();
+        for (int m = 0; m < M - 2; m++) {
+            w.load6(sfcs + 6 * (m + 1), nxt);
+            w.fence();
+            if (sfc_superset_of_hull(nxt, initial_traj + (size_t)m * n1 * 3, n1)) {
+                w.store6(sfcs + 6 * m, nxt);
+                w.fence();
+            }
+        }
+        w.load6(sfcs + 6 * (M - 1), cur);
+        w.fence();
     }
     float hull[9];
     for (int k = 0; k < 3; k++) {
@@ -537,8 +579,6 @@ DQ_FN int sfc_construct(const W &w, const SfcWorldView &g, const SfcParams &p, c
     }
     float upd[6];
     int code = 0;
-    w.load6(sfcs + 6 * (M - 1), cur);
-    w.fence();
     if (!sfc_from_hull(w, g, p, hull, 3, (const float *)nullptr, upd)) {
         code = 1;
         if (!sfc_from_hull(w, g, p, hull, 2, cur, upd)) {
@@ -546,7 +586,12 @@ DQ_FN int sfc_construct(const W &w, const SfcWorldView &g, const SfcParams &p, c
             for (int k = 0; k < 6; k++) upd[k] = cur[k];
         }
     }
-    w.store6(sfcs + 6 * (M - 1), upd);
+    if (at_hand) {  // uniform
+        w.box_keep(M - 1, upd);
+        w.boxes_store(sfcs, M);
+    } else {
+        w.store6(sfcs + 6 * (M - 1), upd);
+    }
     return code;
 }
 

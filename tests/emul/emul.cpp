@@ -400,6 +400,11 @@ struct WaveSfcCpu {
         chain_n = n;
     }
     float chain(int d, int c) const { return chainv[d][c < 0 ? 0 : (c >= chain_n ? chain_n - 1 : c)]; }
+    mutable float boxes[2][dlscqp::SFC_BOXES_CAP][6];
+    void boxes_load(const float *sfcs, int M) const { std::memcpy(boxes[0], sfcs, sizeof(float) * 6 * M); }
+    void box(int m, float *out) const { for (int k = 0; k < 6; k++) out[k] = boxes[0][m][k]; }
+    void box_keep(int m, const float *in) const { for (int k = 0; k < 6; k++) boxes[1][m][k] = in[k]; }
+    void boxes_store(float *sfcs, int M) const { std::memcpy(sfcs, boxes[1], sizeof(float) * 6 * M); }
     float rcp(float x) const { return 1.0f / x; }
     int uniform(int v) const { return v; }
     float uniform_f(float v) const { return v; }
