@@ -360,6 +360,22 @@ def make_exchange(opt, dist, rank, world, n_local, device):
     if device.type == "cuda" and backend in (None, "nccl"):
         import torch
         x, ok, why = None, 1, ""
+        if dist is not None and world > 1:
+            # Before anything collective: can EVERY rank reach librccl through the library?  (A rank that cannot would leave the
+            # others waiting -- in the broadcast of the id if it is rank 0, in ncclCommInitRank otherwise.)  Each rank makes an id of
+            # its own, throws it away, and the ranks agree.
+            try:
+                exchange_unique_id(opt.lib, None, rank)
+            except Exception as e:  # noqa: BLE001
+                ok, why = 0, str(e)
+            flag = torch.tensor([ok], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                print("dlsc_gc_planner_amd: the library's own exchange is not used (%s): torch.distributed instead" % (why or "another rank cannot load librccl"),
+                      file=sys.stderr)
+                x = PlanExchange(dist, world, n_local, (E, 3, 1), device)
+                x.issued_by = "torch.distributed"
+                return x
         try:
             uid = exchange_unique_id(opt.lib, dist, rank) if world > 1 else None
             x = NativeExchange(opt, rank, world, n_local, uid)
