@@ -1297,6 +1297,7 @@ struct NbrArgs {
     int per;
     int32_t *cell_count, *cell_start, *agent_cell, *agent_slot, *by_cell;
     int n_cells;
+    int direct;  // 1: few agents -- every agent is a candidate, no cells (the gather kernel alone)
 };
 
 __device__ __forceinline__ int nbr_cell_of(const NbrGrid &g, const float *p, int *c3) {
@@ -1356,6 +1357,7 @@ __global__ __launch_bounds__(256) void dlscqp_nbr_scatter_kernel(NbrArgs a) {
 // 4: one wavefront per local agent: the members of the 27 cells around its own (nine runs of up to three cells that are
 // contiguous in by_cell), LInfinityDistance test, compaction into LDS, rank sort by id, the first `pitch` ids out
 constexpr int NBR_LIST_CAP = 4096;
+constexpr int NBR_DIRECT_MAX = 256;  // (DLSCQP_NBR_DIRECT_MAX in the environment: tests compare the two ways on the same agents)
 __global__ __launch_bounds__(64) void dlscqp_nbr_gather_kernel(NbrArgs a) {
     __shared__ int list[NBR_LIST_CAP];
     const int k = (int)blockIdx.x, lane = (int)threadIdx.x;
@@ -1367,7 +1369,7 @@ __global__ __launch_bounds__(64) void dlscqp_nbr_gather_kernel(NbrArgs a) {
     auto consider = [&](int lo, int hi) {  // candidates by_cell[lo .. hi), uniform bounds
         for (int b = lo; b < hi; b += 64) {
             const int j = b + lane;
-            const int id = j < hi ? a.by_cell[j] : self;
+            const int id = j < hi ? (a.direct ? j : a.by_cell[j]) : self;
             const float *pq = a.ns.position + (size_t)id * a.ns.position_stride;
             // util.hpp:131-140: float32 differences, the largest of their absolute values, compared in double
             float d = fabsf(sx - pq[0]);
@@ -1380,7 +1382,7 @@ __global__ __launch_bounds__(64) void dlscqp_nbr_gather_kernel(NbrArgs a) {
             count += __popcll(m);
         }
     };
-    if (a.range > 0) {
+    if (a.range > 0 && !a.direct) {
         int c3[3];
         nbr_cell_of(a.grid, ps, c3);
         for (int dz = -1; dz <= 1; dz++) {
@@ -1441,6 +1443,18 @@ extern "C" int dlscqp_neighbours_device(dlscqp_ctx *c, const dlscqp_neighbour_se
         a.grid.n[k] = a.range > 0 ? std::max(1, (int)std::floor(ext / cell) + 1) : 1;
         a.n_cells *= a.grid.n[k];
     }
+    hipStream_t st = (hipStream_t)stream;
+    // Few agents (every mission of the reference): the cells cost four launches to spare each agent a look at a handful of others.
+    // The candidates are everybody, the test and the order of the list are the same: the same lists (tests/test_gpu_neighbours.py).
+    const char *direct_env = std::getenv("DLSCQP_NBR_DIRECT_MAX");
+    const int direct_max = direct_env ? std::atoi(direct_env) : NBR_DIRECT_MAX;
+    a.direct = ns->n_total <= direct_max ? 1 : 0;
+    if (a.direct) {
+        a.cell_count = a.cell_start = a.agent_cell = a.agent_slot = a.by_cell = nullptr;
+        hipLaunchKernelGGL(dlscqp_nbr_gather_kernel, dim3(ns->n_local), dim3(64), 0, st, a);
+        HIP_TRY(hipGetLastError());
+        return DLSCQP_SUCCESS;
+    }
     const size_t need = (size_t)2 * (a.n_cells + 1) + (size_t)3 * ns->n_total + 16;
     if (need > c->nbr_scratch_ints) {
         HIP_TRY(hipDeviceSynchronize());
@@ -1455,7 +1469,6 @@ extern "C" int dlscqp_neighbours_device(dlscqp_ctx *c, const dlscqp_neighbour_se
     a.agent_cell = a.cell_start + a.n_cells + 1;
     a.agent_slot = a.agent_cell + ns->n_total;
     a.by_cell = a.agent_slot + ns->n_total;
-    hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipMemsetAsync(a.cell_count, 0, (size_t)(a.n_cells + 1) * sizeof(int32_t), st));
     const int nb = (ns->n_total + 255) / 256;
     hipLaunchKernelGGL(dlscqp_nbr_bin_kernel, dim3(nb), dim3(256), 0, st, a);

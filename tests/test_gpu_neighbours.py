@@ -27,8 +27,12 @@ def host_lists(pos, rng_, local=None):
     return out
 
 
+@pytest.mark.parametrize("way", ["cells", "direct"])
 @pytest.mark.parametrize("dim,rng_", [(3, 3.0), (2, 3.0), (3, -1.0), (3, 0.7)])
-def test_device_lists_equal_the_reference_filter(gpu_required, dim, rng_):
+def test_device_lists_equal_the_reference_filter(gpu_required, dim, rng_, way, monkeypatch):
+    """way: through the cells of one communication range (four launches: more than 256 agents), or every agent a candidate of every
+    other (one launch: the reference's missions) -- here both on the same 700 agents."""
+    monkeypatch.setenv("DLSCQP_NBR_DIRECT_MAX", "100000" if way == "direct" else "0")
     N, pitch = 700, 256
     cfg = abi.make_config(dim=dim, M=5, communication_range=rng_, world_min=(-8.0, -8.0, 0.0), world_max=(8.0, 8.0, 2.5))
     r = np.random.default_rng(3)
