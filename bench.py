@@ -194,7 +194,7 @@ def closed_loop_latency(device):
     out = {}
     missions = json.load(open(os.path.join(g, "missions_empty.json")))
 
-    def fly(sim, steps, graph_at=None, skip=5):
+    def fly(sim, steps, graph_at=None, skip=5, port=True):
         """Wall time per step (synchronised), then -- for the eager steps -- the stages in the reference's columns (HIP
         events; host time of the waypoint planner) and the same step on the host (the kernel's algorithm, all granted cores,
         the inputs of one mid-flight step read back from HBM)."""
@@ -223,6 +223,8 @@ def closed_loop_latency(device):
                  "stage_names": "the reference's timers (sp_const.hpp:81-122, summary columns multi_sync_simulator.cpp:863-871): "
                                 "traj_optimization_time = goal LP + QP in one launch; mapf_time = host waypoint planner with its transfers"}
         try:
+            if not port:
+                raise RuntimeError("not asked for")
             ms, nt = cpu_port_step_ms(sim.cfg, inputs)
             extra["cpu_port_ms"] = ms
             extra["cpu_port_threads"] = nt
@@ -261,9 +263,18 @@ def closed_loop_latency(device):
     sim = ClosedLoop(cfg, np.array(w["start"], np.float32), np.array(w["goal"], np.float32), radius=w["radius"], downwash=2.0,
                      max_vel=w["max_vel"], max_acc=w["max_acc"], nominal_velocity=1.0, waypoint_step=w["grid_resolution"],
                      world=world, device=device)
+    def maze_sim():
+        return ClosedLoop(cfg, np.array(w["start"], np.float32), np.array(w["goal"], np.float32), radius=w["radius"], downwash=2.0,
+                          max_vel=w["max_vel"], max_acc=w["max_acc"], nominal_velocity=1.0, waypoint_step=w["grid_resolution"],
+                          world=world, device=device)
     ts, fails, extra = fly(sim, 171)
+    ts_g = fly(maze_sim(), 171, graph_at=5, port=False)[0]  # the same flight again, the device part of every step as one graph
     out["maze10_dense_1"] = {"agents": 10, "steps": len(ts["eager"]), "p50_ms": float(np.percentile(ts["eager"], 50)),
                              "p99_ms": float(np.percentile(ts["eager"], 99)), "qp_failsafes": fails,
+                             "p50_ms_as_one_hip_graph": float(np.percentile(ts_g["graph"], 50)),
+                             "as_one_hip_graph": "the same flight flown again with the device part of the step (neighbour lists, corridors, half-spaces, "
+                                                 "LP + QP, state update: five launches) replayed as one graph from step 5 on; the waypoint planner stays "
+                                                 "on the host in front of it",
                              "includes": "host-side waypoint planner (PIBT) and the per-step neighbour lists",
                              "reference_log_planning_time_ms_per_agent": 12.17,
                              "reference_log_stage_ms_per_agent": {"lsc_generation_time": 0.145, "sfc_generation_time": 0.542,
@@ -283,9 +294,13 @@ def closed_loop_latency(device):
                      max_vel=f["max_vel"], max_acc=f["max_acc"], nominal_velocity=1.0, waypoint_step=f["grid_resolution"],
                      world=world, dyn=spin.dyn(horizon=f["uncertainty_horizon"], duration=f["obs_duration"]), device=device)
     ts, fails, extra = fly(sim, 80)
+    sim_g = ClosedLoop(cfg, np.array(f["start"], np.float32), np.array(f["goal"], np.float32), radius=f["radius"], downwash=f["downwash"],
+                       max_vel=f["max_vel"], max_acc=f["max_acc"], nominal_velocity=1.0, waypoint_step=f["grid_resolution"],
+                       world=world, dyn=SpinObstacles(f["obstacles"]).dyn(horizon=f["uncertainty_horizon"], duration=f["obs_duration"]), device=device)
+    ts_g = fly(sim_g, 80, graph_at=5, port=False)[0]
     out["forest10_spin4_100_1"] = {"agents": len(f["start"]), "dynamic_obstacles": len(f["obstacles"]), "steps": len(ts["eager"]),
                                    "p50_ms": float(np.percentile(ts["eager"], 50)), "p99_ms": float(np.percentile(ts["eager"], 99)),
-                                   "qp_failsafes": fails,
+                                   "qp_failsafes": fails, "p50_ms_as_one_hip_graph": float(np.percentile(ts_g["graph"], 50)),
                                    "note": "220 variables, up to 124 active rows: the working set (96 KB) fits the LDS of a CU since the solver "
                                            "keeps no orthogonal factor (DESIGN.md 6f); includes the host-side waypoint planner"}
     out["forest10_spin4_100_1"].update(extra)

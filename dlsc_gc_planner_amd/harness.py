@@ -445,9 +445,10 @@ class ClosedLoop:
         torch = self.torch
         assert self.seq >= 1, "the first step differs (constant-velocity prediction, corridor initialisation)"
         assert not self.order_hint, "the launch-order hint rotates its buffers from step to step: not in a captured graph"
-        # (measured in round 4: capturing the step of the maze mission WITH the device neighbour search ended in a memory access
-        # fault on replay; not looked into -- the search is refused here rather than left to fault)
-        assert self.nbr is None, "the device neighbour search has not been made safe for capture"
+        # (measured in round 4: capturing a step WITH the device neighbour search through cells -- a memset and four launches on a
+        # scratch buffer of the context -- ended in a memory access fault on replay; not looked into.  The one-launch search of up
+        # to 256 agents captures and replays bit-equal to the eager step (tests/test_gpu_closed_loop.py); the other is refused)
+        assert self.nbr is None or getattr(self.nbr, "direct", False), "the neighbour search through cells has not been made safe for capture"
         torch.cuda.synchronize(self.dev)
         state = [self.batch.t["agents"], self.cur_goal, self.plans, self.init_buf]
         if self.sfc is not None:

@@ -572,6 +572,9 @@ class NeighbourSearch:
         c.n_dyn = gen.n_dyn
         c.out_overflow = self.overflow.data_ptr()
         self.c = c
+        # dlscqp_neighbours_device: up to NBR_DIRECT_MAX agents in one launch, every agent a candidate of every other (no cells)
+        import os
+        self.direct = gen.n_total <= int(os.environ.get("DLSCQP_NBR_DIRECT_MAX", "256"))
 
     def search(self, position, stream=None):
         """position: CUDA float32 tensor [n_total, >= 3] whose rows are `position.stride(0)` floats apart (a dense table or a

@@ -277,16 +277,30 @@ def test_forest_mission_with_spinning_obstacles(gpu_required):
     assert done is not None and done <= 30.0
 
 
-@pytest.mark.parametrize("with_world", [False, True])
+@pytest.mark.parametrize("with_world", [False, True, "reference", "forest"])
 def test_hip_graph_step_equals_eager_step(gpu_required, with_world):
     """ClosedLoop.enable_graph(): the steady-state step captured once in a HIP graph and replayed gives the same plans,
-    states and verdicts, bit for bit, as the eager sequence of launches -- in an empty world (waypoints inside the graph)
-    and in the maze (corridor generator inside the graph, waypoints from the host outside)."""
+    states and verdicts, bit for bit, as the eager sequence of launches -- in an empty world (waypoints inside the graph),
+    in the maze (corridor generator inside the graph, waypoints from the host outside), in the maze as the reference's
+    mission runs it (communication-range neighbour lists rebuilt on the device every step: the one-launch search) and in the
+    forest (dynamic obstacles, waypoint trap)."""
     import torch
-    if with_world:
+    if with_world == "forest":
+        from dlsc_gc_planner_amd.harness import SpinObstacles
+        m = json.load(open(os.path.join(HERE, "golden", "world_forest1.json")))
+        cfg = abi.make_config(dim=m["dim"], M=m["M"], dt=m["dt"], control_input_weight=0.01, terminal_weight=1.0,
+                              communication_range=m["communication_range"], slack_collision_weight=m["slack_collision_weight"],
+                              world_use_octomap=True, world_min=tuple(m["world"][:3]), world_max=tuple(m["world"][3:]))
+        world = dict(boxes=m["boxes"], resolution=m["world_resolution"], grid_resolution=m["grid_resolution"], pibt="reference",
+                     uncertainty_horizon=m["uncertainty_horizon"])
+        kw = dict(radius=m["radius"], downwash=m["downwash"], max_vel=m["max_vel"], max_acc=m["max_acc"], nominal_velocity=1.0,
+                  waypoint_step=m["grid_resolution"], world=world)
+        kw_dyn = lambda: SpinObstacles(m["obstacles"]).dyn(size_prediction=1, horizon=m["uncertainty_horizon"], duration=m["obs_duration"])  # noqa: E731
+        start, goal = np.array(m["start"], np.float32), np.array(m["goal"], np.float32)
+    elif with_world:
         m, cfg, world = _maze()
         kw = dict(radius=m["radius"], downwash=2.0, max_vel=m["max_vel"], max_acc=m["max_acc"], nominal_velocity=1.0,
-                  waypoint_step=m["grid_resolution"], world=dict(world, pibt=True))
+                  waypoint_step=m["grid_resolution"], world=dict(world, pibt=True if with_world is True else "reference"))
         start, goal = np.array(m["start"], np.float32), np.array(m["goal"], np.float32)
     else:
         cfg, m = _mission("empty10_1")
@@ -295,7 +309,7 @@ def test_hip_graph_step_equals_eager_step(gpu_required, with_world):
         start, goal = np.array(m["start"], np.float32), np.array(m["goal"], np.float32)
     runs = []
     for use_graph in (False, True):
-        sim = ClosedLoop(cfg, start, goal, **kw)
+        sim = ClosedLoop(cfg, start, goal, **(dict(kw, dyn=kw_dyn()) if with_world == "forest" else kw))
         try:
             hist = []
             for k in range(40):
