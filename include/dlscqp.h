@@ -349,7 +349,10 @@ int dlscqp_selftest(dlscqp_ctx *ctx);
  * the configuration) bins the agents; every local agent then searches the 27 cells around its own.  Lists have a fixed
  * pitch, so nothing is scanned or sized on the host: out_nbr_ids[k * pitch ...] holds out_nbr_counts[k] ids; a list longer
  * than `pitch` is cut to its `pitch` smallest ids and *out_overflow is set.  communication_range <= 0 (no limit): every
- * other agent.  Asynchronous on `stream`; scratch memory belongs to the context (calls of one context must not overlap). */
+ * other agent.  Asynchronous on `stream`; scratch memory belongs to the context (calls of one context must not overlap).
+ * Up to 256 agents (every mission of the reference) there are no cells: one launch in which every agent is a candidate of
+ * every other -- same test, same order, same lists, no scratch memory, and safe to capture into a HIP graph (the search
+ * through cells is not: a captured step with it faulted on replay). */
 typedef struct dlscqp_neighbour_search {
     int32_t n_total;            /* agents in the position table                                         */
     int32_t n_local;            /* agents to build lists for                                            */
