@@ -231,9 +231,13 @@ def test_device_source_mixed_radius_and_speed_classes(maze):
     mixed_classes_check(m, lambda radius, vmax, **kw: E.generate_sfc(cfg, world, radius, vmax, m["grid_resolution"], **kw))
 
 
-def test_device_source_open_space(maze):
+@pytest.mark.parametrize("variant", ["turns", "in_sequence"])
+def test_device_source_open_space(maze, variant, monkeypatch):
     """No obstacle within reach: every trial is accepted until the limit of moves or the boundary -- rounds of more than 64
-    trials (a pass that ends without a lane that fails, then continues), 6 x 51 moves."""
+    trials (a pass that ends without a lane that fails, then continues), 6 x 51 moves.  in_sequence: the same boxes grown one
+    trial after the other, point by point -- boxes of more than 64 lattice points along an axis (beyond the per-axis tables)."""
+    if variant == "in_sequence":
+        monkeypatch.setenv("EMUL_SFC_SVT", "0")
     import emul_lib as E
     from dlsc_gc_planner_amd import abi
     m = dict(maze[0])
