@@ -21,15 +21,20 @@ PHASES = ["agent+goalLP", "init(x0,bounds,G->LDS)", "scan+argmax", "decode,|N'a|
           "dx=G(a-A'rv),|z|^2", "ratio test", "primal/dual step", "add row", "givens drop", "readout"]
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--swarms", type=int, default=256)
-    args = ap.parse_args()
+def ensure_lib():
+    """(re)build the stamped library when a source is newer than it"""
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".cpp"))]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs):  # never a stale diagnostic build
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
                                "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-DDLSCQP_STAMPS", "-o", LIB, os.path.join(CSRC, "dlscqp.hip"),
                                os.path.join(CSRC, "qp_tables.cpp"), os.path.join(CSRC, "sfc_world.cpp"), os.path.join(CSRC, "grid_mapf.cpp")])
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--swarms", type=int, default=256)
+    args = ap.parse_args()
+    ensure_lib()
     os.environ["DLSCQP_LIB"] = LIB
     import numpy as np
     import torch

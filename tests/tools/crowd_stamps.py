@@ -8,14 +8,14 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "profiles"))
-import stamps as S  # noqa: E402  (LIB, PHASES; the build recipe is stamps.py's: run it once first)
+import stamps as S  # noqa: E402  (LIB, PHASES, ensure_lib)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--warm", type=int, default=25)
     ap.add_argument("--steps", type=int, default=10)
     a = ap.parse_args()
-    assert os.path.exists(S.LIB), "python profiles/stamps.py builds the stamped library"
+    S.ensure_lib()
     os.environ["DLSCQP_LIB"] = S.LIB
     import numpy as np
     import torch
