@@ -573,6 +573,64 @@ __global__ __launch_bounds__(THREADS, DQ_LSC_OCC) void dlscqp_lsc_kernel(LscGenA
     }
 }
 
+// Two agents per wavefront, for lists so short that one agent leaves most of a wavefront without an item (the synthetic swarms of
+// BASELINE.json configs[1]: 4 x 5 + 2 = 22 items -- with a wavefront per agent three fifths of the lanes of the S64 closed loop's
+// largest stage after the plan kernel had nothing to do).  Lanes 0-31 work for agent 2 b, lanes 32-63 for agent 2 b + 1; the
+// presolve's scan runs over the half-wavefront.  Same items in the same order: the same rows at the same places.  The odd agent
+// out repeats the last agent's work and writes nothing.  Presolve path only (row_counts).
+__global__ __launch_bounds__(64, DQ_LSC_OCC) void dlscqp_lsc_pair_kernel(LscGenArgs g) {
+    const int half = (int)threadIdx.x >> 5, l32 = (int)threadIdx.x & 31;
+    const int k = 2 * (int)blockIdx.x + half;
+    const bool have = k < g.n_local;
+    const int kc = have ? k : g.n_local - 1;
+    const int self = g.local_ids ? g.local_ids[kc] : kc;
+    const int p0 = g.nbr_offsets[kc], p1 = g.nbr_counts ? p0 + g.nbr_counts[kc] : g.nbr_offsets[kc + 1];
+    const int per = g.M * g.n1 - g.phi;
+    const size_t pair0 = (size_t)p0 + (size_t)kc * g.n_dyn;
+    const int nn = p1 - p0, items = nn * g.M;
+    __shared__ float hull_pts[18 * 64];
+    const HullStore hull = {hull_pts + threadIdx.x, 64};
+    __shared__ LscLast last_geo[2][32];
+    if (l32 < nn) last_geo[half][l32] = lsc_last_geometry(g, self, g.nbr_ids[p0 + l32]);
+    __syncthreads();
+    const size_t row0 = (size_t)per * pair0;
+    const int all = items + g.n_dyn * g.M;
+    const int all0 = __shfl(all, 0), all1 = __shfl(all, 32);
+    const int rounds_to = all0 > all1 ? all0 : all1;  // wave-uniform: both halves walk as many rounds as the longer list needs
+    int base = 0;  // rows the previous rounds of this agent kept
+    for (int it0 = 0; it0 < rounds_to; it0 += 32) {
+        const int it = it0 + l32;
+        LscRows r;
+        r.i0 = 6;
+        bool keep[6] = {false, false, false, false, false, false};
+        int cnt = 0, m = 0;
+        bool tail_skip = false;
+        if (it < items) {
+            const int j = it / g.M;
+            m = it - j * g.M;
+            tail_skip = g.tail_segments > 0 && j >= g.tail_from && m < g.M - g.tail_segments;
+            if (!tail_skip) lsc_item_rows(g, self, g.nbr_ids[p0 + j], m, r, hull, j < 32 ? &last_geo[half][j] : nullptr);
+        } else if (it < all) {
+            const int q = it - items, o = q / g.M;
+            m = q - o * g.M;
+            lsc_dyn_item_rows(g, self, o, m, r);
+        }
+        if (it < all && !tail_skip) {
+            const float *box = g.prune_sfc ? g.prune_sfc + ((size_t)kc * g.M + m) * 6 : nullptr;
+            cnt = lsc_rows_kept(g, box, r, keep);
+        }
+        int incl = cnt;  // inclusive scan over the half-wavefront (a lane below s never takes what the other half shifted in)
+#pragma unroll
+        for (int s = 1; s < 32; s <<= 1) {
+            const int v = __shfl_up(incl, s);
+            incl += l32 >= s ? v : 0;
+        }
+        if (cnt && have) lsc_store_rows(g, r, row0 + (size_t)(base + incl - cnt), keep);
+        base += __shfl(incl, 31 + 32 * half);
+    }
+    if (l32 == 0 && have) g.row_counts[k] = base;
+}
+
 // TrajPlanner::checkWaypointTrap: one wavefront per local agent.  The lanes test the agent's neighbour rows (ballot), the
 // verdict is wave-uniform, then the lanes empty the rows of the dynamic obstacles that can reach the waypoint.
 struct TrapArgs {
@@ -1256,7 +1314,11 @@ extern "C" int dlscqp_generate_lsc_device(dlscqp_ctx *c, const dlscqp_lsc_gen *g
     LscGenArgs g;
     const int rc = lsc_gen_args(c, gen, &g);
     if (rc != DLSCQP_SUCCESS) return rc;
-    if (gen->max_neighbours > 0 && (gen->max_neighbours + g.n_dyn) * c->M <= 64)
+    const char *pairs_env = std::getenv("DLSCQP_LSC_PAIRS");  // "0": one wavefront per agent as before (tests compare the two)
+    const bool pairs = !(pairs_env && pairs_env[0] == '0');
+    if (pairs && g.row_counts && gen->max_neighbours > 0 && (gen->max_neighbours + g.n_dyn) * c->M <= 32)
+        hipLaunchKernelGGL(dlscqp_lsc_pair_kernel, dim3((gen->n_local + 1) / 2), dim3(64), 0, (hipStream_t)stream, g);
+    else if (gen->max_neighbours > 0 && (gen->max_neighbours + g.n_dyn) * c->M <= 64)
         hipLaunchKernelGGL(dlscqp_lsc_kernel<64>, dim3(gen->n_local), dim3(64), 0, (hipStream_t)stream, g);
     else
         hipLaunchKernelGGL(dlscqp_lsc_kernel<LSC_THREADS>, dim3(gen->n_local), dim3(LSC_THREADS), 0, (hipStream_t)stream, g);

@@ -95,3 +95,31 @@ def test_s64_flies_with_every_stage_on_the_device(gpu_required):
         assert np.mean(its[3:]) > 0.3 and d1 < d0 - 1.0 and fails <= 0.1 * 14 * N
     finally:
         sim.close()
+
+
+def test_two_agents_per_wavefront_write_the_same_rows(gpu_required, monkeypatch):
+    """dlscqp_lsc_pair_kernel (short lists: two agents share a wavefront) against one wavefront per agent: the same rows at the
+    same places, the same counts, the same flight -- with an odd number of agents (the last wavefront has one)."""
+    cfg = workloads.s64_config()
+    start, goal = workloads.swarm_missions(cfg, n_swarms=3, swarm_size=64, seed=2001)
+    start, goal = start[:-1], goal[:-1]  # 191 agents
+    flights = []
+    for pairs in ("0", "1"):
+        monkeypatch.setenv("DLSCQP_LSC_PAIRS", pairs)
+        sim = ClosedLoop(cfg, start, goal, radius=0.15, downwash=2.0, max_vel=1.0, max_acc=2.0, waypoint_step=5.0, neighbours="knn",
+                         knn=(64, 5), tail=(4, 2), prune=True)
+        try:
+            sim.keep_inputs = True
+            rec = []
+            for step in range(8):
+                sim.step()
+                _, rows_off, rows, _, _ = sim.step_inputs()
+                rec.append((rows_off.copy(), rows.copy(), sim.plans.cpu().numpy().copy()))
+            flights.append(rec)
+        finally:
+            sim.close()
+    for k, (a, b) in enumerate(zip(*flights)):
+        assert np.array_equal(a[0], b[0]), k
+        assert a[1].tobytes() == b[1].tobytes(), k
+        assert np.array_equal(a[2], b[2]), k
+    assert np.diff(flights[0][-1][0]).mean() > 20  # rows were written
