@@ -467,7 +467,8 @@ void dlscqp_world_destroy(dlscqp_world *world);
  * is only known from `radius`, which lives in device memory: the FIRST call with a given (radius pointer, n_agents)
  * synchronises with `stream`, reads the radii and builds the tables that are missing -- later calls are asynchronous like
  * every other *_device entry.  Inside a stream capture nothing is built (agents without their table grow their boxes the slow
- * way, same boxes): run one step before capturing.  One workgroup of 256 threads per agent. */
+ * way, same boxes): run one step before capturing.  Launches on ONE world from several host threads have to be serialised by
+ * the caller (the table bookkeeping is not locked).  One workgroup of 256 threads per agent. */
 typedef struct dlscqp_sfc_gen {
     int32_t n_agents;
     int32_t initialize;
