@@ -1320,7 +1320,15 @@ extern "C" int dlscqp_generate_lsc_device(dlscqp_ctx *c, const dlscqp_lsc_gen *g
         hipLaunchKernelGGL(dlscqp_lsc_pair_kernel, dim3((gen->n_local + 1) / 2), dim3(64), 0, (hipStream_t)stream, g);
     else if (gen->max_neighbours > 0 && (gen->max_neighbours + g.n_dyn) * c->M <= 64)
         hipLaunchKernelGGL(dlscqp_lsc_kernel<64>, dim3(gen->n_local), dim3(64), 0, (hipStream_t)stream, g);
-    else
+    else if (gen->n_local <= 64 && gen->max_neighbours > 0 && (gen->max_neighbours + g.n_dyn) * c->M > LSC_THREADS)
+        // a handful of agents with more items than one round of 128 threads takes (the forest mission: 13 x 10): the chip is empty
+        // anyway, a workgroup of 256 or 512 threads takes them in one round or two
+    {
+        if ((gen->max_neighbours + g.n_dyn) * c->M > 256)  // (empty60: 59 x 5)
+            hipLaunchKernelGGL(dlscqp_lsc_kernel<512>, dim3(gen->n_local), dim3(512), 0, (hipStream_t)stream, g);
+        else
+            hipLaunchKernelGGL(dlscqp_lsc_kernel<256>, dim3(gen->n_local), dim3(256), 0, (hipStream_t)stream, g);
+    } else
         hipLaunchKernelGGL(dlscqp_lsc_kernel<LSC_THREADS>, dim3(gen->n_local), dim3(LSC_THREADS), 0, (hipStream_t)stream, g);
     HIP_TRY(hipGetLastError());
     return DLSCQP_SUCCESS;
