@@ -578,7 +578,10 @@ __global__ __launch_bounds__(THREADS, DQ_LSC_OCC) void dlscqp_lsc_kernel(LscGenA
 // largest stage after the plan kernel had nothing to do).  Lanes 0-31 work for agent 2 b, lanes 32-63 for agent 2 b + 1; the
 // presolve's scan runs over the half-wavefront.  Same items in the same order: the same rows at the same places.  The odd agent
 // out repeats the last agent's work and writes nothing.  Presolve path only (row_counts).
-__global__ __launch_bounds__(64, DQ_LSC_OCC) void dlscqp_lsc_pair_kernel(LscGenArgs g) {
+#ifndef DQ_LSC_PAIR_OCC
+#define DQ_LSC_PAIR_OCC 3  // (measured: 4 wavefronts per SIMD spill 248 B a lane here -- generator stage 0.190 against 0.175 ms)
+#endif
+__global__ __launch_bounds__(64, DQ_LSC_PAIR_OCC) void dlscqp_lsc_pair_kernel(LscGenArgs g) {
     const int half = (int)threadIdx.x >> 5, l32 = (int)threadIdx.x & 31;
     const int k = 2 * (int)blockIdx.x + half;
     const bool have = k < g.n_local;
