@@ -492,8 +492,13 @@ constexpr int LSC_THREADS = 128;
 #define DQ_LSC_OCC 4  // wavefronts per SIMD the half-space generator is compiled for (128 VGPRs, 26 of them spilled; 3 = 158 VGPRs and no
                       // spill was measured in round 4: crowd stage 0.099 -> 0.113 ms, stress step 0.133 -> 0.144 -- the fourth wavefront is worth more)
 #endif
-template <int THREADS>
-__global__ __launch_bounds__(THREADS, DQ_LSC_OCC) void dlscqp_lsc_kernel(LscGenArgs g) {
+// OCC: wavefronts per SIMD the build is compiled for.  Launches that fill the chip want four (DQ_LSC_OCC, above); a launch of a
+// handful of agents has the SIMDs to itself, and a build without the spills (FEW) is what its latency asks for.
+#ifndef DQ_LSC_OCC_FEW
+#define DQ_LSC_OCC_FEW 2
+#endif
+template <int THREADS, int OCC = DQ_LSC_OCC>
+__global__ __launch_bounds__(THREADS, OCC) void dlscqp_lsc_kernel(LscGenArgs g) {
     const int k = blockIdx.x;
     if (k >= g.n_local) return;
     const int self = g.local_ids ? g.local_ids[k] : k;
@@ -1321,6 +1326,8 @@ extern "C" int dlscqp_generate_lsc_device(dlscqp_ctx *c, const dlscqp_lsc_gen *g
     const bool pairs = !(pairs_env && pairs_env[0] == '0');
     if (pairs && g.row_counts && gen->max_neighbours > 0 && (gen->max_neighbours + g.n_dyn) * c->M <= 32)
         hipLaunchKernelGGL(dlscqp_lsc_pair_kernel, dim3((gen->n_local + 1) / 2), dim3(64), 0, (hipStream_t)stream, g);
+    else if (gen->max_neighbours > 0 && (gen->max_neighbours + g.n_dyn) * c->M <= 64 && gen->n_local <= 64)
+        hipLaunchKernelGGL((dlscqp_lsc_kernel<64, DQ_LSC_OCC_FEW>), dim3(gen->n_local), dim3(64), 0, (hipStream_t)stream, g);
     else if (gen->max_neighbours > 0 && (gen->max_neighbours + g.n_dyn) * c->M <= 64)
         hipLaunchKernelGGL(dlscqp_lsc_kernel<64>, dim3(gen->n_local), dim3(64), 0, (hipStream_t)stream, g);
     else if (gen->n_local <= 64 && gen->max_neighbours > 0 && (gen->max_neighbours + g.n_dyn) * c->M > LSC_THREADS)
@@ -1328,10 +1335,12 @@ extern "C" int dlscqp_generate_lsc_device(dlscqp_ctx *c, const dlscqp_lsc_gen *g
         // anyway, a workgroup of 256 or 512 threads takes them in one round or two
     {
         if ((gen->max_neighbours + g.n_dyn) * c->M > 256)  // (empty60: 59 x 5)
-            hipLaunchKernelGGL(dlscqp_lsc_kernel<512>, dim3(gen->n_local), dim3(512), 0, (hipStream_t)stream, g);
+            hipLaunchKernelGGL((dlscqp_lsc_kernel<512, DQ_LSC_OCC_FEW>), dim3(gen->n_local), dim3(512), 0, (hipStream_t)stream, g);
         else
-            hipLaunchKernelGGL(dlscqp_lsc_kernel<256>, dim3(gen->n_local), dim3(256), 0, (hipStream_t)stream, g);
-    } else
+            hipLaunchKernelGGL((dlscqp_lsc_kernel<256, DQ_LSC_OCC_FEW>), dim3(gen->n_local), dim3(256), 0, (hipStream_t)stream, g);
+    } else if (gen->n_local <= 64)
+        hipLaunchKernelGGL((dlscqp_lsc_kernel<LSC_THREADS, DQ_LSC_OCC_FEW>), dim3(gen->n_local), dim3(LSC_THREADS), 0, (hipStream_t)stream, g);
+    else
         hipLaunchKernelGGL(dlscqp_lsc_kernel<LSC_THREADS>, dim3(gen->n_local), dim3(LSC_THREADS), 0, (hipStream_t)stream, g);
     HIP_TRY(hipGetLastError());
     return DLSCQP_SUCCESS;
