@@ -124,6 +124,8 @@ class DeviceBatch(C.Structure):
         ("hint_iters", C.c_void_p * 3),
         ("out_record_stride", C.c_int32),
         ("reserved2_", C.c_int32),
+        ("workspace", C.c_void_p),
+        ("workspace_bytes", C.c_int64),
     ]
 
 
@@ -342,6 +344,8 @@ def load_library():
     lib.dlscqp_last_error.restype = C.c_char_p
     lib.dlscqp_lds_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.dlscqp_lds_bytes.restype = C.c_int64
+    lib.dlscqp_workspace_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+    lib.dlscqp_workspace_bytes.restype = C.c_int64
     vp = C.c_void_p
     lib.dlscqp_solve_batch.argtypes = [vp, C.c_int32, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp]
     lib.dlscqp_solve_batch.restype = C.c_int
@@ -419,5 +423,5 @@ EXPORTED_SYMBOLS = [
     "dlscqp_hint_order_preview_device",
     "dlscqp_exchange_unique_id", "dlscqp_exchange_create", "dlscqp_exchange_destroy", "dlscqp_exchange_post", "dlscqp_exchange_post_records",
     "dlscqp_exchange_before_overwrite", "dlscqp_exchange_wait", "dlscqp_exchange_set_timing", "dlscqp_exchange_get_times",
-    "dlscqp_step_device", "dlscqp_neighbours_knn_device",
+    "dlscqp_step_device", "dlscqp_neighbours_knn_device", "dlscqp_workspace_bytes",
 ]

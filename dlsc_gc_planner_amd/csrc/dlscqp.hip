@@ -290,6 +290,8 @@ struct KernelArgs {
     unsigned long long *out_stamps;  // [n_agents][12], diagnostic build only
     unsigned char *work;             // HBM working sets [n_agents][work_stride] of the WS_HBM kernel, else null
     size_t work_stride;
+    double *spill;                   // spill records [launch slots][spill_stride doubles] (MemLayout::spill_doubles), or null: every column
+    size_t spill_stride;             // record of the active rows fits the working set
 };
 
 // dlscqp_device_batch.hint_iters: the launch order without a sort between two launches.  The agents in blocks of 64 consecutive
@@ -426,7 +428,8 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
 #endif
     const int M = kp.M, n1 = kp.n1;
     const size_t xs = (size_t)kp.dim * M * n1 + (size_t)M * a.max_slack_obs;
-    plan_agent<RC, DIMS, FS, MS, KU, SU, SLK, WaveGpu>(w, kp, lay, smem, a.agents + ag, a.rows, rb, nrows_ag,
+    plan_agent<RC, DIMS, FS, MS, KU, SU, SLK, WaveGpu>(w, kp, lay, smem, a.spill ? a.spill + (size_t)slot * a.spill_stride : nullptr,
+               a.agents + ag, a.rows, rb, nrows_ag,
                a.sfc ? a.sfc + (size_t)ag * M * 6 : nullptr, a.max_slack_obs, a.do_goal, a.do_traj,
                a.out_goal ? a.out_goal + (size_t)ag * a.goal_stride : nullptr,
                a.out_goal_status ? a.out_goal_status + ag : nullptr,
@@ -465,8 +468,8 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
         unsigned long long *o = a.out_stamps + (size_t)ag * 20992;
         const unsigned long long *src = reinterpret_cast<const unsigned long long *>(smem);
         if (threadIdx.x == 0) {
-            o[0] = lay.bytes; o[1] = lay.oG; o[2] = lay.oRp; o[3] = lay.oDx; o[4] = lay.oX; o[5] = lay.oBlo; o[6] = lay.oBhi;
-            o[7] = lay.oFlag; o[8] = lay.ldg; o[9] = lay.r_max;
+            o[0] = lay.bytes; o[1] = lay.oC; o[2] = lay.cs; o[3] = lay.oDx; o[4] = lay.oX; o[5] = lay.oBlo; o[6] = lay.oBhi;
+            o[7] = lay.oFlag; o[8] = lay.qz; o[9] = lay.r_max;
         }
         int nd = lay.bytes / 8;
 #ifdef DLSCQP_TRACE_LDS
@@ -961,6 +964,8 @@ struct dlscqp_ctx {
     int32_t *nbr_scratch = nullptr;  // dlscqp_neighbours_device: cell counts / starts, agents' cells and slots, agents by cell
     size_t nbr_scratch_ints = 0;
     size_t work_bytes = 0;
+    void *spill = nullptr;  // spill records of a launch whose batch names no workspace (grown on demand, never inside a stream capture)
+    size_t spill_bytes = 0;
     // staging for the host-buffer entry points
     unsigned char *h_stage = nullptr, *d_stage = nullptr;
     size_t stage_cap = 0;
@@ -1052,6 +1057,7 @@ extern "C" void dlscqp_destroy(dlscqp_ctx *c) {
     if (c->d_slots) (void)hipFree(c->d_slots);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->work) (void)hipFree(c->work);
+    if (c->spill) (void)hipFree(c->spill);
     if (c->d_order_scratch) (void)hipFree(c->d_order_scratch);
     if (c->nbr_scratch) (void)hipFree(c->nbr_scratch);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
@@ -1083,7 +1089,18 @@ extern "C" int64_t dlscqp_lds_bytes(const dlscqp_ctx *c, int32_t max_slack_obs, 
     if (!c) return -1;
     KernelChoice kc = select_kernel(c->tb.kp, max_slack_obs, max_rows_per_agent);
     if (!kc.fn) return -1;
-    return make_layout(c->tb.kp, max_slack_obs, max_rows_per_agent, kc.KU, kc.SU, kc.by_kind).bytes;
+    // the smallest working set a launch of this shape can run with: eight column records in it, the others spilled (choose_layout)
+    return make_layout(c->tb.kp, max_slack_obs, max_rows_per_agent, kc.KU, kc.SU, kc.by_kind, 0, 8).bytes;
+}
+
+extern "C" int64_t dlscqp_workspace_bytes(const dlscqp_ctx *c, int32_t n_agents, int32_t max_slack_obs, int32_t max_rows_per_agent) {
+    if (!c || n_agents < 0) return -1;
+    KernelChoice kc = select_kernel(c->tb.kp, max_slack_obs, max_rows_per_agent);
+    if (!kc.fn) return -1;
+    // the smallest number of records the launcher ever keeps in the working set (choose_layout) gives the largest spill record
+    const MemLayout lay = make_layout(c->tb.kp, max_slack_obs, max_rows_per_agent, kc.KU, kc.SU, kc.by_kind, 0, 8);
+    const size_t stride = ((size_t)lay.spill_doubles + 31) & ~(size_t)31;
+    return (int64_t)(stride * 8 * (size_t)(64 * ((n_agents + 63) / 64)));
 }
 
 extern "C" int dlscqp_set_timing(dlscqp_ctx *c, int32_t capacity) {
@@ -1123,6 +1140,36 @@ extern "C" int dlscqp_get_kernel_times(dlscqp_ctx *c, float *ms_out, int32_t cap
 // ---------------------------------------------------------------------------------------------
 // launch
 // ---------------------------------------------------------------------------------------------
+// Working set of a launch.  The column records of the active rows (gi_core.hpp: MemLayout) are the largest part of it: r_max of them
+// would leave a CU's LDS to two or three agents, and a launch of thousands of agents wants eight (four in the builds compiled for
+// one wavefront per SIMD).  So: `budget` = the LDS one agent may have at the occupancy the launch can use (a launch of at most 256
+// agents gets a CU each); if every record fits it, no spill; else qz records stay in the working set -- 16, which covers all but a
+// few per mille of the agents of the synthetic swarms; 8 where the budget is shared with rows beyond the register cache (a
+// crowd prices ~700 rows from LDS in every pass; DLSCQP_QZ overrides: measurements) -- and the others go to a spill record in HBM.
+struct LayoutChoice {
+    MemLayout lay;
+    int budget;
+};
+static LayoutChoice choose_layout(const KParams &kp, const dlscqp_device_batch *b, const KernelChoice &kc, int n_slots, int max_per_cu,
+                                  bool rows_in_lds) {
+    int per_cu = (n_slots + 255) / 256;
+    per_cu = per_cu < 1 ? 1 : (per_cu > max_per_cu ? max_per_cu : per_cu);
+    const int budget = (int)(LDS_LIMIT / per_cu) - 512;
+    const bool cold = b->max_rows_per_agent > 64 * kc.KU;
+    const int row_budget = (cold && rows_in_lds) ? budget : 0;
+    static const char *qz_env = getenv("DLSCQP_QZ");  // records in the working set: 0 = all of them, whatever the occupancy
+    LayoutChoice out;
+    out.budget = budget;
+    const MemLayout full = make_layout(kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, kc.by_kind, 0, 0);
+    if (qz_env ? atoi(qz_env) <= 0 : full.bytes <= budget) {
+        out.lay = make_layout(kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, kc.by_kind, row_budget, 0);
+        return out;
+    }
+    const int qz_want = qz_env ? atoi(qz_env) : (cold ? 8 : 16);
+    out.lay = make_layout(kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, kc.by_kind, row_budget, qz_want);
+    return out;
+}
+
 static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t stream) {
     if (b->n_agents <= 0) return DLSCQP_SUCCESS;
     if (b->max_slack_obs < 0 || b->max_rows_per_agent < 0) { g_last_error = "negative size"; return DLSCQP_ERR_INVALID_ARGUMENT; }
@@ -1135,20 +1182,27 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         g_last_error = "reduced dimension above 128 (dim*f + M*max_slack_obs) is not supported";
         return DLSCQP_ERR_UNSUPPORTED;
     }
-    MemLayout lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, kc.by_kind);  // (sized again below, once the build is known)
+    // (the working set is sized below, once the build and the number of launch slots are known; this first look only decides
+    // whether it can live in LDS at all: with eight column records in the working set, the smallest the layout goes)
+    MemLayout lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, kc.by_kind, 0, 8);
     static const bool force_hbm = getenv("DLSCQP_DEBUG_WS") && std::string(getenv("DLSCQP_DEBUG_WS")) == "hbm";  // tests
     const bool ws_hbm = lay.bytes > LDS_LIMIT || force_hbm || c->force_instance == 2;
     KernelArgs a;
     a.work = nullptr;
     a.work_stride = 0;
+    a.spill = nullptr;
+    a.spill_stride = 0;
     if (ws_hbm) {
         // Working set beyond the LDS of a CU: the runtime-shape kernel with its working set in a per-slot HBM buffer.  The
         // buffer belongs to the context: launches of one context that use it must not overlap.
         kc = KernelChoice{dlscqp_plan_kernel_hbm, DQ_ID_HBM, DQ_G2_KU, DQ_G2_SU, false};
-        lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, false);
+        lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, false);  // (every column record in the working set)
         a.work_stride = ((size_t)lay.bytes + 255) & ~(size_t)255;
         const size_t need = a.work_stride * (size_t)(64 * ((b->n_agents + 63) / 64));  // one per launch slot (hint_iters: 64 per block)
         if (need > c->work_bytes) {
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            (void)hipStreamIsCapturing(stream, &cap);
+            if (cap != hipStreamCaptureStatusNone) { g_last_error = "the HBM working sets must grow: not inside a stream capture (launch once eagerly first)"; return DLSCQP_ERR_INVALID_ARGUMENT; }
             HIP_TRY(hipDeviceSynchronize());
             if (c->work) (void)hipFree(c->work);
             c->work = nullptr;
@@ -1198,14 +1252,41 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
     else if (c->force_build == 2) { wpa = false; wide = kc.fn_wide != nullptr; }
     else if (c->force_build == 3) { wpa = !ws_hbm && kc.fn_wpa != nullptr; wide = !wpa && wide; }
     kernel_t kfn = wpa ? kc.fn_wpa : (wide ? kc.fn_wide : kc.fn);
-    if (!ws_hbm && !wpa && b->max_rows_per_agent > 64 * kc.KU) {
-        // Rows beyond the register cache: what the build's occupancy leaves of a CU's LDS holds them (gi_core.hpp: "rows in LDS").
-        // Builds compiled for one wavefront per SIMD (WIDE; the shapes with two registers per vector; 2-D M = 10) run four agents
-        // per CU, the others eight.  DLSCQP_ROWS_IN_LDS=0: every such row from HBM in every pass, as before round 4 (tests).
+    if (!ws_hbm) {
+        // Rows beyond the register cache: what the working set leaves of the agent's LDS budget holds them (gi_core.hpp: "rows in
+        // LDS"); not in the builds with helper wavefronts (their helpers split those rows and price them from HBM).
+        // DLSCQP_ROWS_IN_LDS=0: every such row from HBM in every pass, as before round 4 (tests).
         static const bool rows_in_lds = !(getenv("DLSCQP_ROWS_IN_LDS") && getenv("DLSCQP_ROWS_IN_LDS")[0] == '0');
         const bool one_per_simd = wide || (kc.id == 3 && DQ_M10_2D_ONE) || kc.id == 4 || kc.id == 5;
-        const int budget = (int)(LDS_LIMIT / (one_per_simd ? 4 : 8)) - 512;
-        if (rows_in_lds) lay = make_layout(c->kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, kc.by_kind, budget);
+        const int max_per_cu = wpa ? (DQ_WPA_OCC * 4) / DQ_WPA : (one_per_simd ? 4 : 8);
+        const LayoutChoice lc = choose_layout(c->kp, b, kc, a.n_slots_launch, max_per_cu < 1 ? 1 : max_per_cu, rows_in_lds && !wpa);
+        lay = lc.lay;
+        if (lay.bytes > LDS_LIMIT) { g_last_error = "working set exceeds the LDS of a CU"; return DLSCQP_ERR_UNSUPPORTED; }  // (ws_hbm above rules it out)
+        if (lay.spill_doubles > 0) {
+            // spill records, one per launch slot: the batch's own workspace if it names one that is large enough, else a buffer of
+            // the context (launches of one context that rely on it must not overlap; it never grows inside a stream capture)
+            a.spill_stride = ((size_t)lay.spill_doubles + 31) & ~(size_t)31;
+            const size_t need = a.spill_stride * 8 * (size_t)(a.slot0 + a.n_slots_launch);
+            if (b->workspace && b->workspace_bytes >= (int64_t)need) {
+                a.spill = static_cast<double *>(b->workspace);
+            } else {
+                if (need > c->spill_bytes) {
+                    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+                    (void)hipStreamIsCapturing(stream, &cap);
+                    if (cap != hipStreamCaptureStatusNone) {
+                        g_last_error = "the spill records must grow: not inside a stream capture (pass dlscqp_device_batch.workspace, or launch once eagerly first)";
+                        return DLSCQP_ERR_INVALID_ARGUMENT;
+                    }
+                    HIP_TRY(hipDeviceSynchronize());
+                    if (c->spill) (void)hipFree(c->spill);
+                    c->spill = nullptr;
+                    c->spill_bytes = 0;
+                    HIP_TRY(hipMalloc(&c->spill, need));
+                    c->spill_bytes = need;
+                }
+                a.spill = static_cast<double *>(c->spill);
+            }
+        }
     }
     const int attr_slot = kc.id + (wpa ? 2 * (DQ_N_INSTANCES + 1) : (wide ? DQ_N_INSTANCES + 1 : 0));
     if (!ws_hbm && lay.bytes > c->max_dyn_lds[attr_slot]) {

@@ -68,50 +68,53 @@ namespace dlscqp {
 
 struct MemLayout {
     int r_max, nx_max, ldg, nflag;
-    int oG, oRp, oX, oDx, oBlo, oBhi;  // in doubles
-    int oLam;                          // by-kind shapes: two tables of nx_max + 2 doubles, the weights of the active velocity and acceleration
-                                       // rows by coordinate (plan_agent: dense step direction)
-    int oU;                            // nx_max doubles: a - A' r in the variables' own space (plan_agent: whitened_length)
-    int oMail;                         // 8 doubles: what the planning wavefront and its helper wavefronts tell each other (dlscqp.hip)
-    int oDump;                         // 32 dump slots (lane & 31) for the lanes that have nothing to store, right behind S;
-                                       // then two doubles that stay 0.0 (what a masked read of S is sent to)
-    int oFlag;                         // byte offset of the skip flags: two bytes per structured slot beyond the slot cache, then (oFlagRows)
-    int oFlagRows;                     // ONE BIT per LSC row that is priced from HBM (beyond the register cache and the LDS rows below)
-    int kmax;                          // most LSC rows of one agent the layout was sized for (dlscqp_device_batch.max_rows_per_agent)
-    int cold_cap, oCold;               // rows [64 KU, 64 KU + cold_cap) of an agent are kept in the working set, decoded, 32 bytes each
-                                       // (plan_agent: "rows in LDS"); oCold in doubles
+    // COLUMN RECORDS of the active rows, one per active row k: [ column k of S = R^-1, r_max entries, zeros below the diagonal |
+    // column k of Z = G A' S, nx_max entries ] -- cs doubles apart (odd: lane k reading its own column and lane p reading one
+    // column are both conflict-free).  The first qz records live in the working set, records qz .. r_max - 1 in the agent's SPILL
+    // record in HBM (plan_agent's `spill` argument: 32 dump doubles, then the records); qz == r_max: no spill needed.
+    int oC, cs, qz;
+    int oX, oDx, oBlo, oBhi;  // in doubles (oDx < 0: the instantiation keeps the step direction in registers, DXREG)
+    int oU;                   // nx_max doubles: a - A' r in the variables' own space (plan_agent: whitened_length)
+    int oMail;                // 8 doubles: what the planning wavefront and its helper wavefronts tell each other (dlscqp.hip)
+    int oDump;                // 32 dump slots (lane & 31) for the lanes that have nothing to store; then two doubles that stay 0.0
+    int oFlag;                // byte offset of the skip flags: two bytes per structured slot beyond the slot cache, then (oFlagRows)
+    int oFlagRows;            // ONE BIT per LSC row that is priced from HBM (beyond the register cache and the LDS rows below)
+    int kmax;                 // most LSC rows of one agent the layout was sized for (dlscqp_device_batch.max_rows_per_agent)
+    int cold_cap, oCold;      // rows [64 KU, 64 KU + cold_cap) of an agent are kept in the working set, decoded, 32 bytes each
+                              // (plan_agent: "rows in LDS"); oCold in doubles
+    int spill_doubles;        // doubles of one agent's spill record (0: none needed)
     int bytes;
 };
 
-// The Gram table of the 2-D, M = 10 shape (P = 60: 29 KB) stays in HBM / L2: with it in LDS three agents fit a CU, without it
-// the registers' eight (DQ_G_IN_LDS=1 puts it back).
-#ifndef DQ_G_IN_LDS
-#define DQ_G_IN_LDS 0
-#endif
-DQ_FN bool gram_table_in_lds(int dim, int M, bool by_kind) { return DQ_G_IN_LDS || !(by_kind && dim == 2 && M == 10); }
-// lds_budget: bytes of LDS the launch lets one agent have (0: the working set proper, no rows): what is left after the working
-// set holds rows beyond the register cache.
-DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int KU, int SU, bool by_kind, int lds_budget = 0) {
+// The Gram tables stay in HBM / L2 for every shape (round 5): an iteration reads one to three ROWS of G_T (coalesced, the row of
+// every control point the new row touches), everything else it needs of the whitened space is in the column records.
+// lds_budget: bytes of LDS the launch lets one agent have (0: the working set proper, no rows beyond the register cache in it).
+// qz_want: column records in the working set (0 or >= r_max: all of them; else rounded down to a multiple of 8, at least 8: the
+// loops over the records go in blocks of 8 and of 4 that must not straddle the boundary); the rest is spilled.
+DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int KU, int SU, bool by_kind, int lds_budget = 0, int qz_want = 0) {
     MemLayout L;
     const int nslk = kp.M * max_slack_obs;
     L.r_max = kp.dim * kp.f + nslk;  // the active rows are independent in the whitened space: never more than its dimension
     L.nx_max = kp.dim * kp.P + nslk;
-    L.ldg = kp.P | 1;  // odd leading dimension of the Gram table: conflict-free row reads and gathers along a column
+    L.ldg = kp.P | 1;  // odd leading dimension of the Gram table (as the host builds it)
     const int cold_rows = kmax > 64 * KU ? kmax - 64 * KU : 0;
     const int gen_slots = by_kind ? kp.n_slots - kp.n_struct : kp.n_slots;  // the slots the generic code scans
     const int cold_slots = gen_slots > 64 * SU ? gen_slots - 64 * SU : 0;
+    const bool dxreg = by_kind && nslk == 0 && kp.P <= 64;  // plan_agent: DXREG
     L.kmax = kmax;
+    L.cs = (L.r_max + L.nx_max) | 1;
+    L.qz = (qz_want <= 0 || qz_want >= L.r_max) ? L.r_max : ((qz_want & ~7) < 8 ? 8 : (qz_want & ~7));
+    if (L.qz >= L.r_max) L.qz = L.r_max;
+    L.spill_doubles = L.qz < L.r_max ? 32 + (L.r_max - L.qz) * L.cs : 0;
     int o = 0;
-    L.oG = o; o += gram_table_in_lds(kp.dim, kp.M, by_kind) ? kp.P * L.ldg : 0;
-    L.oRp = o; o += L.r_max * (L.r_max + 1) / 2;
     L.oDump = o; o += 32 + 2;
     L.oX = o; o += L.nx_max;
-    L.oDx = o; o += L.nx_max;
+    L.oDx = dxreg ? -1 : o; o += dxreg ? 0 : L.nx_max;
+    L.oC = o; o += L.qz * L.cs;
     L.oBlo = o; o += kp.nb;
     L.oBhi = o; o += kp.nb;
     L.oMail = o; o += 8;
     L.oU = o; o += L.nx_max;
-    L.oLam = o; o += by_kind ? 2 * (L.nx_max + 2) : 0;
     L.oCold = o;
     L.cold_cap = 0;
     if (lds_budget > 0 && cold_rows > 0) {
@@ -259,7 +262,6 @@ DQ_FN T pick3(const T *v, int k) {
     return r;
 }
 
-#define DQ_RP(i, j) Rp[(j) * ((j) + 1) / 2 + (i)]
 // element e of a per-lane vector spread over RC registers
 #define DQ_BC(arr, e) (RC == 1 ? w.bcast((arr)[0], (e)) : ((e) < 64 ? w.bcast((arr)[0], (e)) : w.bcast((arr)[RC - 1], (e) - 64)))
 #define DQ_BCI(arr, e) DQ_BC(arr, e)
@@ -383,10 +385,12 @@ DQ_FN void cold_rows_share(int Kc, int K, int wave, int nw, int &jb, int &je) {
 #endif
 
 // SLK: compile-time number of slack obstacles of the batch (0), or -1 = read it from the arguments.  With
-// DIMS > 0 and SLK = 0 the whole LDS layout up to the bound table (offsets of G, S, x, dx, dump) is made of
+// DIMS > 0 and SLK = 0 the LDS layout up to the column records (dump, x, stride and place of the records) is made of
 // constants: LDS addresses become "lane part + immediate", no address arithmetic in the loops.
+// spill: the agent's spill record in HBM (MemLayout::spill_doubles doubles), or null where the layout keeps every column
+// record in the working set (lay.qz == lay.r_max).
 template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK, class W>
-DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsigned char *mem,
+DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsigned char *mem, double *spill,
                       const dlscqp_agent *agp, const RowsView &rows, int row_begin, int K_rows,
                       const float *sfc, int max_slack_obs, int do_goal, int do_traj,
                       float *out_goal, int *out_goal_status, float *out_ctrl, double *out_x,
@@ -742,20 +746,22 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     double *base = reinterpret_cast<double *>(mem);
     // layout (make_layout): compile-time for static shapes without slack obstacles, else from the arguments
     constexpr bool ST = DIMS > 0 && SLK == 0;
-    constexpr int P_ST = MS * 6, LDG_ST = (MS * 6) | 1, R_ST = DIMS * FS, NX_ST = DIMS * MS * 6;
-    constexpr bool GLDS = DQ_G_IN_LDS || !(DIMS == 2 && MS == 10);  // gram_table_in_lds
-    constexpr int ORP_ST = GLDS ? P_ST * LDG_ST : 0, ODUMP_ST = ORP_ST + R_ST * (R_ST + 1) / 2, OX_ST = ODUMP_ST + 32 + 2;
+    constexpr int LDG_ST = (MS * 6) | 1, R_ST = DIMS * FS, NX_ST = DIMS * MS * 6;
+    constexpr int ODUMP_ST = 0, OX_ST = 32 + 2, OC_ST = OX_ST + NX_ST, CS_ST = (R_ST + NX_ST) | 1;  // (make_layout; ST shapes keep no dx in LDS)
     const int r_max = ST ? R_ST : lay.r_max;
     const int ldg = DIMS > 0 ? LDG_ST : lay.ldg;
-    const int oG = 0;
-    const int oRp = DIMS > 0 ? ORP_ST : lay.oRp;
     const int odump = ST ? ODUMP_ST : lay.oDump;  // 32 dump slots, base[odump + (lane & 31)]
     const int oX = ST ? OX_ST : lay.oX;
-    const int oDx = ST ? OX_ST + NX_ST : lay.oDx;
-    const int oBlo = ST ? OX_ST + 2 * NX_ST : lay.oBlo;
-    const int oBhi = lay.oBhi;
-    const double *G = base + oG;  // (or the table itself where it is, below)
-    double *Rp = base + oRp, *x = base + oX, *dxl = base + oDx;
+    const int oDx = lay.oDx;  // (DXREG: none)
+    const int oBlo = lay.oBlo, oBhi = lay.oBhi;
+    // column records of the active rows (MemLayout): record k = [ S(0..r_max-1, k) | Z(0..nx-1, k) ]
+    const int oC = ST ? OC_ST : lay.oC;
+    const int cs = ST ? CS_ST : lay.cs;
+    const int zo = r_max;   // where the Z part of a record starts
+    const int qz = lay.qz;  // records in the working set; records qz .. live in the spill record
+    double *colw = base + oC;
+    double *colsp = spill ? spill + 32 : nullptr;  // (32 dump doubles in front: colsp[-32 + (lane & 31)])
+    double *x = base + oX, *dxl = base + (oDx < 0 ? 0 : oDx);
     double *blo = base + oBlo, *bhi = base + oBhi;
     unsigned char *cold_flag = mem + lay.oFlag, *row_flag = mem + lay.oFlagRows;
     const int rc = dim * f;      // whitened control-point dimension
@@ -766,21 +772,20 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     double *lrhs = base + lay.oCold, *liw = lrhs + lay.cold_cap;
     float *lnx = reinterpret_cast<float *>(liw + lay.cold_cap), *lny = lnx + lay.cold_cap, *lnz = lny + lay.cold_cap;
     uint32_t *lkey = reinterpret_cast<uint32_t *>(lnz + lay.cold_cap);
-    const int odump_rp = odump - oRp;  // the dump slots as indices of Rp
-    const int ozero_rp = odump_rp + 32;  // a zero: where the reads of S below its diagonal go
 
     const int T = terminal_segments(goal);  // terminal segments, traj_optimizer.cpp:543-551
     int status = DLSCQP_OK;
     if (!kp.t_valid[T - 1]) status = DLSCQP_NUMERICAL;
     if (nslk > 0 && !(kp.w_s > 0)) status = DLSCQP_NUMERICAL;
     if (r > 64 * RC || r > r_max || P > 255 || dim != kp.dim || f != kp.f || M != kp.M || n1 != kp.n1) status = DLSCQP_NUMERICAL;  // the launcher picks the instantiation; defensive
+    if (qz < r_max && !spill) status = DLSCQP_NUMERICAL;  // (the launcher sizes the layout for the spill record it has; defensive)
+    if (ST && (lay.oX != OX_ST || lay.oC != OC_ST || lay.cs != CS_ST || lay.oDump != ODUMP_ST)) status = DLSCQP_NUMERICAL;  // make_layout and the constants above agree
     if (status != DLSCQP_OK) {
         exit_stores(status, true, 0, 0, 0, 0, false, 0.0);
         return;
     }
 
-    const double *tG = kp.tabG + (size_t)(T - 1) * P * ldg;
-    if (!GLDS) G = tG;
+    const double *G = kp.tabG + (size_t)(T - 1) * P * ldg;  // the Gram table of T, in HBM / L2: an iteration reads rows of it
     const double *tXs = kp.tabX0s + (size_t)(T - 1) * P * 3;
     const double *tXg = kp.tabX0g + (size_t)(T - 1) * P;
     const double *tNN = kp.tabNN + (size_t)(T - 1) * P;
@@ -1031,12 +1036,12 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         }
     });
 
-    constexpr int QB = 8;  // block of the two triangular products over the active rows
-    constexpr int DB = 4;  // block of the step direction's loop over them
+    constexpr int QB = 8;  // block of the product rv = S d1 over the active rows' records
+    constexpr int JB = 4;  // block of the step direction's loop over them
     constexpr bool DXREG = DIMS > 0 && SLK == 0 && MS * 6 <= 64;  // the step direction stays in registers (see there)
-    static_assert((64 % QB) == 0 && (64 % DB) == 0, "a block never runs past the last lane");
+    constexpr bool P64 = DIMS > 0;  // P = 6 M <= 64 is known at compile time: lane p is control point p, one trip
+    static_assert((64 % QB) == 0 && (64 % JB) == 0 && (QB % JB) == 0, "a block never runs past the last lane, nor across lay.qz");
     int q = 0, iters = 0, n_add = 0, n_drop = 0;
-    bool factors_ready = false;
     const int max_iter = kp.max_iter > 0 ? kp.max_iter : 20 * (r + 8) + 200;
     // Row codes, code = unit * 8 + c (tag_score):
     //   units [0, UL0)   BYK: coordinate j of the control polygon; c = 2 kind + side, kind 0 bound / 1 velocity / 2 acceleration
@@ -1418,30 +1423,6 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         DQ_TRACE(3, objective(), 0.0, 0.0, 0.0);
 #endif
 
-        if (!factors_ready) {
-            // first violated row: the Gram table G_T of this agent's number of terminal segments into LDS (agents that
-            // never get here skip all of this)
-            w.each([&](int l0) {
-                // the lane index through an opaque copy: the addresses below must be computed here, not hoisted
-                // out of the iteration loop (where loop-invariant address registers were kept alive in scratch)
-                int l = l0;
-                DQ_KEEP(l);
-                const int ng = GLDS ? P * ldg : 0;
-                for (int j0 = 0; j0 < ng; j0 += 64) {
-                    const int j = j0 + l;
-                    const bool in = j < ng;
-                    const double v = tG[in ? j : ng - 1];
-                    base[blend_idx(in, oG + j, odump + (l & 31))] = v;
-                }
-                if (BYK && DXREG)  // the weight tables of the dense step direction: zero wherever no such row is active
-                    for (int j0 = 0; j0 < 2 * (nxc + 2); j0 += 64)
-                        base[blend_idx(j0 + l < 2 * (nxc + 2), lay.oLam + j0 + l, odump + (l & 31))] = 0.0;
-            });
-            w.sync();
-            factors_ready = true;
-            w.stamp(1);
-        }
-
         // ---- decode the row into sparse x-space entries and evaluate its violation (uniform) ----------------------
         // Two shapes of rows.  POINT rows touch one control point on up to three axes (LSC rows, box faces, waypoint range, and
         // the rows of a slack variable alone): point p, one coefficient per axis.  LINE rows touch up to three control points of
@@ -1582,191 +1563,141 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         DQ_TRACE(1, (double)ip, viol, top, (double)q);
         const double sig_row = kp.sigma[(sidx_row < 0 ? 0 : sidx_row) % M];
         const double sig2_row = sidx_row >= 0 ? sig_row * sig_row : 0.0;
-        // squared whitened length of the row, a' G a (every lane reads the same entries of G)
-        double dall;
-        if (new_line) {  // uniform
-            const double g00 = G[np0 * ldg + np0], g01 = G[np0 * ldg + np1], g02 = G[np0 * ldg + np2];
-            const double g11 = G[np1 * ldg + np1], g12 = G[np1 * ldg + np2], g22 = G[np2 * ldg + np2];
-            const double line = ncf[0] * (ncf[0] * g00 + 2.0 * (ncf[1] * g01 + ncf[2] * g02)) +
-                                ncf[1] * (ncf[1] * g11 + 2.0 * ncf[2] * g12) + ncf[2] * ncf[2] * g22;
-            dall = w.uni(line + sig2_row);
-        } else {
-            dall = w.uni((ncf[0] * ncf[0] + ncf[1] * ncf[1] + ncf[2] * ncf[2]) * G[np0 * ldg + np0] + sig2_row);
+        // ---- the rows of G_T at the control points the new row touches (G a: lane p holds control point p) --------------------
+        // requested HERE and used after d1 and rv below: their trip to L2 runs under those two.  The Gram table is never copied:
+        // an iteration needs one row of it (POINT row) or three (LINE row), 8 P bytes each, coalesced.
+        RegD gq[3];
+        if (P64) {
+            w.each([&](int l) {
+                const int pc = l < P ? l : P - 1;
+                const double g0 = G[np0 * ldg + pc];
+                gq[0].at(l) = g0;
+                if (new_line) {  // uniform
+                    gq[1].at(l) = G[np1 * ldg + pc];
+                    gq[2].at(l) = G[np2 * ldg + pc];
+                } else {
+                    gq[1].at(l) = g0;
+                    gq[2].at(l) = g0;
+                }
+            });
         }
+        // where the new row's entries sit in a Z column (x-space index = axis P + control point), as z_squared() has them: a POINT
+        // row in 2-D has a zero third coefficient and no third axis
+        const int ze0 = (new_line ? new_axis : 0) * P + np0;
+        const int ze1 = (new_line ? new_axis : (dim > 1 ? 1 : 0)) * P + np1;
+        const int ze2 = (new_line ? new_axis : (dim > 2 ? 2 : 0)) * P + np2;
+        const double zc2 = (new_line || dim > 2) ? ncf[2] : 0.0;
+        const int zes = nxc + (sidx_row >= 0 ? sidx_row : 0);
         w.stamp(3);  // decode
 
         double uq = 0.0;
+        double dall = 0.0;  // squared whitened length of the row, a' G a (set in the loop, behind the reads of G)
         bool resolved = false;
         while (!resolved) {
             if (++iters > max_iter) { status = DLSCQP_ITERATION_LIMIT; break; }
-            // ---- g = A G a (lane i: a_i' G a, nine table entries at most), d1 = S' g, rv = S d1 = (A G A')^-1 g --------
-            // (nothing to do while no row is active: rv keeps its zeros)
-            if (q > 0) {  // uniform
-                RegD gv[RC], d1[RC];
-                w.each([&](int l) {
-#pragma unroll
-                    for (int c = 0; c < RC; c++) {
-                        const int i = l + 64 * c;
-                        const uint32_t pk = a_pk[c].at(l);
-                        const int p0 = pk & 0xFF, p1 = (pk >> 8) & 0xFF, p2 = (pk >> 16) & 0xFF;
-                        const int ka = (pk >> 24) & 3;
-                        const bool line = (pk >> 26) & 1;
-                        const double c0 = (double)a_cf[c][0].at(l), c1 = (double)a_cf[c][1].at(l), c2 = (double)a_cf[c][2].at(l);
-                        double s;
-                        if (!new_line) {  // uniform
-                            // the new row touches one control point: one table entry per point of this lane's row
-                            double g0 = G[p0 * ldg + np0], g1 = G[p1 * ldg + np0], g2 = G[p2 * ldg + np0];
-                            DQ_KEEP(g0); DQ_KEEP(g1); DQ_KEEP(g2);
-                            const double s_point = (c0 * ncf[0] + c1 * ncf[1] + c2 * ncf[2]) * g0;
-                            const double s_line = pick3(ncf, ka) * (c0 * g0 + c1 * g1 + c2 * g2);
-                            s = line ? s_line : s_point;
-                        } else {
-                            double ga[3][3];
-                            ga[0][0] = G[p0 * ldg + np0]; ga[0][1] = G[p0 * ldg + np1]; ga[0][2] = G[p0 * ldg + np2];
-                            ga[1][0] = G[p1 * ldg + np0]; ga[1][1] = G[p1 * ldg + np1]; ga[1][2] = G[p1 * ldg + np2];
-                            ga[2][0] = G[p2 * ldg + np0]; ga[2][1] = G[p2 * ldg + np1]; ga[2][2] = G[p2 * ldg + np2];
-#pragma unroll
-                            for (int t = 0; t < 3; t++) { DQ_KEEP(ga[t][0]); DQ_KEEP(ga[t][1]); DQ_KEEP(ga[t][2]); }
-                            const double r0 = ncf[0] * ga[0][0] + ncf[1] * ga[0][1] + ncf[2] * ga[0][2];
-                            const double r1 = ncf[0] * ga[1][0] + ncf[1] * ga[1][1] + ncf[2] * ga[1][2];
-                            const double r2 = ncf[0] * ga[2][0] + ncf[1] * ga[2][1] + ncf[2] * ga[2][2];
-                            const double cax[3] = {c0, c1, c2};
-                            const double s_point = pick3(cax, new_axis) * r0;
-                            double s_all = c0 * r0 + c1 * r1 + c2 * r2;
-                            DQ_KEEP(s_all);  // a select, not a branch around the arithmetic
-                            const double s_line = ka == new_axis ? s_all : 0.0;
-                            s = line ? s_line : s_point;
-                        }
-                        s += (sidx_row >= 0 && a_sl[c].at(l) == sidx_row) ? sig2_row : 0.0;
-                        gv[c].at(l) = i < q ? s : 0.0;
-                    }
-                });
-                w.stamp(4);  // g
-                // Both products walk the active rows in blocks of QB with every LDS read of a block issued before its first
-                // use: a trip costs one LDS round trip, not QB of them.  Entries beyond the active rows meet a zero of gv / d1.
-                w.each([&](int l) {  // d1 = S' g: lane k walks column k of the packed triangle
-#pragma unroll
-                    for (int c = 0; c < RC; c++) {
-                        const int k = l + 64 * c;
-                        const int kc = k < q ? k : 0;
-                        const int col = kc * (kc + 1) / 2;
-                        double a0 = 0.0, a1 = 0.0;
-                        for (int i0 = 0; i0 < q; i0 += QB) {  // S(i,k) = 0 below the diagonal: those reads go to the zero slot
-                            double sv[QB];
-#pragma unroll
-                            for (int u = 0; u < QB; u++) sv[u] = Rp[blend_idx(i0 + u <= kc, col + i0 + u, ozero_rp)];
-#pragma unroll
-                            for (int u = 0; u < QB; u++) DQ_KEEP(sv[u]);
-#pragma unroll
-                            for (int u = 0; u < QB; u += 2) {
-                                a0 = fma(sv[u], DQ_BC(gv, i0 + u), a0);
-                                a1 = fma(sv[u + 1], DQ_BC(gv, i0 + u + 1), a1);
-                            }
-                        }
-                        d1[c].at(l) = k < q ? a0 + a1 : 0.0;
-                    }
-                });
-                w.each([&](int l) {  // rv = S d1: lane i accumulates row i of S; no dependence between lanes
-#pragma unroll
-                    for (int c = 0; c < RC; c++) {
-                        const int i = l + 64 * c;
-                        double a0 = 0.0, a1 = 0.0;
-                        for (int k0 = 0; k0 < q; k0 += QB) {
-                            double sv[QB];
-#pragma unroll
-                            for (int u = 0; u < QB; u++) {
-                                const int k = k0 + u < q ? k0 + u : q - 1;  // uniform: a column that exists
-                                sv[u] = Rp[blend_idx(i <= k, k * (k + 1) / 2 + i, ozero_rp)];
-                            }
-#pragma unroll
-                            for (int u = 0; u < QB; u++) DQ_KEEP(sv[u]);
-#pragma unroll
-                            for (int u = 0; u < QB; u += 2) {
-                                a0 = fma(sv[u], DQ_BC(d1, k0 + u), a0);
-                                a1 = fma(sv[u + 1], DQ_BC(d1, k0 + u + 1), a1);
-                            }
-                        }
-                        rv[c].at(l) = a0 + a1;
-                    }
-                });
-                w.stamp(5);  // two triangular products
-            }
-            // ---- step direction in control-point space: dx = G (a - A' rv) ------------------------------------------
-            // lane p: row p of G against the sparse vector a - A' rv -- one table entry per POINT row, three per LINE row
-            RegD wc[RC][3], wcp[RC][3];  // -rv_i x coefficient; wcp: the same with zeros for LINE rows
-            RegI is_line[RC], is_point[RC], is_kline[RC];
+            const int q_in = q < qz ? q : qz;  // active rows whose records are in the working set (the others: spill record)
+            // ---- d1 = Z' a, rv = S d1 = (A G A')^-1 A G a ---------------------------------------------------------------------
+            // Z = G A' S holds, column by column, the active rows' normals made orthonormal in the whitened space and mapped back
+            // to control-point space (Z' G^-1 Z = I on the range of G): lane j reads ITS column at the new row's three entries --
+            // no decode of the active rows, no gather from the Gram table, no product with S'.  (nd1 = -d1; zero beyond the
+            // active rows.  Nothing to do while no row is active: rv keeps its zeros.)
+            RegD nd1[RC];
             w.each([&](int l) {
 #pragma unroll
-                for (int c = 0; c < RC; c++) {
-                    const bool on = l + 64 * c < q;
-                    const bool line = (a_pk[c].at(l) >> 26) & 1;
-                    const int cd = act[c].at(l);
-                    is_kline[c].at(l) = (BYK && DXREG && on && (cd >> 3) < UL0 && (cd & 7) >= 2) ? 1 : 0;  // velocity / acceleration row of a coordinate
-                    is_point[c].at(l) = (on & !line) ? 1 : 0;
-                    const double mr = on ? -rv[c].at(l) : 0.0;
-#pragma unroll
-                    for (int t = 0; t < 3; t++) {
-                        const double v = mr * (double)a_cf[c][t].at(l);
-                        wc[c][t].at(l) = v;
-                        wcp[c][t].at(l) = line ? 0.0 : v;
-                    }
-                    is_line[c].at(l) = (on & line) ? 1 : 0;
-                }
+                for (int c = 0; c < RC; c++) nd1[c].at(l) = 0.0;
             });
-            uint64_t line_rows[RC], point_rows[RC];
-            // Many active velocity / acceleration rows (static shapes): the loops over the active rows below cost ~250 cycles per
-            // such row and the agents that set the length of a launch have thirty of them (infeasible agents: acceleration rows
-            // all along the horizon).  Such a row is (coordinate j, kind) and nothing else -- its entries are (-1, 1) or (1, -2, 1)
-            // times one weight at j, j+1, j+2 -- so every row's lane stores that weight at [kind][j] of a table in LDS (no two
-            // active rows share a slot; a slot is zeroed when its row is dropped), lane p gathers
-            // u_j = v_j - v_(j-1) + a_j - 2 a_(j-1) + a_(j-2) for its control point (a velocity row never starts on the last point of
-            // a segment, an acceleration row not on the last two: the entries read across a segment or axis boundary are zeros)
-            // and dx gets G u as a dense product: P table reads and dim P FMAs per lane whatever the number of rows (~2 800 cycles
-            // for P = 30 against ~7 000 for 25 such rows; measured: the slowest agent of the S64 batch 238 -> 214 us, the launch
-            // 0.359 -> 0.325 ms).  Bound rows in a third table were tried and lost 1 % (more LDS, a longer gather).
-            bool dense_dx = false;
-            RegD ureg[3];  // dense_dx: lane p holds u of control point p
-            if (BYK && DXREG) {
-                int n_kline = 0;
-#pragma unroll
-                for (int c = 0; c < RC; c++) n_kline += popc64(w.ballot(is_kline[c]));
-                dense_dx = n_kline >= kp.dense_min;  // uniform
-            }
-#pragma unroll
-            for (int c = 0; c < RC; c++) {
-                line_rows[c] = w.ballot(is_line[c]);
-                point_rows[c] = w.ballot(is_point[c]);
-                if (dense_dx) line_rows[c] &= ~w.ballot(is_kline[c]);
-            }
-            if (dense_dx) {  // uniform
-                double *lam = base + lay.oLam;
-                const int LS = nxc + 2;
+            if (q > 0) {  // uniform
                 w.each([&](int l) {
 #pragma unroll
                     for (int c = 0; c < RC; c++) {
-                        const int cd = act[c].at(l);
-                        const bool kl = is_kline[c].at(l) != 0;
-                        const int slot = ((cd & 7) >= 4 ? LS : 0) + 2 + (kl ? cd >> 3 : 0);
-                        base[blend_idx(kl, lay.oLam + slot, odump + (l & 31))] = wc[c][0].at(l);  // the weight of the row's first point
+                        const int j = l + 64 * c;
+                        const bool on = j < q;
+                        const double *zj = colw + ((on & (j < qz)) ? j : 0) * cs + zo;  // (a lane without a row reads record 0 and drops it)
+                        double z0 = zj[ze0], z1 = zj[ze1], z2 = zj[ze2], zs = SLK != 0 ? zj[zes] : 0.0;
+                        DQ_KEEP(z0); DQ_KEEP(z1); DQ_KEEP(z2);
+                        if (SLK != 0) DQ_KEEP(zs);
+                        if (q > qz) {  // uniform: some records live in the spill record
+                            const bool sp = on & (j >= qz);
+                            const double *zg = colsp + (size_t)(sp ? j - qz : 0) * cs + zo;
+                            double y0 = zg[ze0], y1 = zg[ze1], y2 = zg[ze2], ys = SLK != 0 ? zg[zes] : 0.0;
+                            DQ_KEEP(y0); DQ_KEEP(y1); DQ_KEEP(y2);
+                            if (SLK != 0) DQ_KEEP(ys);
+                            z0 = sp ? y0 : z0; z1 = sp ? y1 : z1; z2 = sp ? y2 : z2; zs = sp ? ys : zs;
+                        }
+                        double sd = fma(zc2, z2, fma(ncf[1], z1, ncf[0] * z0));
+                        sd -= (SLK != 0 && sidx_row >= 0) ? zs : 0.0;  // the slack variable's coefficient is -1
+                        nd1[c].at(l) = on ? -sd : 0.0;
                     }
                 });
-                w.sync();
+                w.stamp(4);  // d1
+                // rv = S d1: lane i accumulates row i of S over the records, in blocks of QB with every read of a block issued before
+                // its first use (S is zero below its diagonal: stored so; a block's records beyond the active rows meet a zero of nd1)
                 w.each([&](int l) {
-                    const bool in = l < P;
-                    const int pc = in ? l : P - 1;
 #pragma unroll
-                    for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++) {
-                        const int j = k * P + pc;
-                        double v0 = lam[j + 2], v1 = lam[j + 1], a0 = lam[LS + j + 2], a1 = lam[LS + j + 1], a2 = lam[LS + j];
-                        DQ_KEEP(v0); DQ_KEEP(v1); DQ_KEEP(a0); DQ_KEEP(a1); DQ_KEEP(a2);
-                        ureg[k].at(l) = in ? (v0 - v1) + ((a0 - 2.0 * a1) + a2) : 0.0;
+                    for (int c = 0; c < RC; c++) {
+                        const int i = l + 64 * c;
+                        const int ir = i < r_max ? i : r_max - 1;
+                        double a0 = 0.0, a1 = 0.0;
+                        for (int k0 = 0; k0 < q_in; k0 += QB) {
+                            double sv[QB];
+#pragma unroll
+                            for (int u = 0; u < QB; u++) sv[u] = colw[(k0 + u < q_in ? k0 + u : q_in - 1) * cs + ir];  // uniform: a record that exists
+#pragma unroll
+                            for (int u = 0; u < QB; u++) DQ_KEEP(sv[u]);
+#pragma unroll
+                            for (int u = 0; u < QB; u += 2) {
+                                a0 = fma(sv[u], DQ_BC(nd1, k0 + u), a0);
+                                a1 = fma(sv[u + 1], DQ_BC(nd1, k0 + u + 1), a1);
+                            }
+                        }
+                        for (int k0 = qz; k0 < q; k0 += QB) {  // records in the spill record (rare: more than qz active rows)
+                            double sv[QB];
+#pragma unroll
+                            for (int u = 0; u < QB; u++) sv[u] = colsp[(size_t)((k0 + u < q ? k0 + u : q - 1) - qz) * cs + ir];
+#pragma unroll
+                            for (int u = 0; u < QB; u++) DQ_KEEP(sv[u]);
+#pragma unroll
+                            for (int u = 0; u < QB; u += 2) {
+                                a0 = fma(sv[u], DQ_BC(nd1, k0 + u), a0);
+                                a1 = fma(sv[u + 1], DQ_BC(nd1, k0 + u + 1), a1);
+                            }
+                        }
+                        rv[c].at(l) = i < q ? -(a0 + a1) : 0.0;
                     }
-                    if ((DIMS > 0 ? DIMS : 3) < 3) ureg[2].at(l) = 0.0;
                 });
+                w.stamp(5);  // rv = S d1
             }
+            // squared whitened length of the row, a' G a: the entries of G at the row's own control points
+            {
+                double g00, g01 = 0.0, g02 = 0.0, g11 = 0.0, g12 = 0.0, g22 = 0.0;
+                if (P64) {
+                    g00 = w.bcast(gq[0], np0);
+                    if (new_line) {  // uniform
+                        g01 = w.bcast(gq[0], np1); g02 = w.bcast(gq[0], np2);
+                        g11 = w.bcast(gq[1], np1); g12 = w.bcast(gq[1], np2); g22 = w.bcast(gq[2], np2);
+                    }
+                } else {
+                    g00 = G[np0 * ldg + np0];
+                    if (new_line) {  // uniform
+                        g01 = G[np0 * ldg + np1]; g02 = G[np0 * ldg + np2];
+                        g11 = G[np1 * ldg + np1]; g12 = G[np1 * ldg + np2]; g22 = G[np2 * ldg + np2];
+                    }
+                }
+                if (new_line) {  // uniform
+                    const double line = ncf[0] * (ncf[0] * g00 + 2.0 * (ncf[1] * g01 + ncf[2] * g02)) +
+                                        ncf[1] * (ncf[1] * g11 + 2.0 * ncf[2] * g12) + ncf[2] * ncf[2] * g22;
+                    dall = w.uni(line + sig2_row);
+                } else {
+                    dall = w.uni((ncf[0] * ncf[0] + ncf[1] * ncf[1] + ncf[2] * ncf[2]) * g00 + sig2_row);
+                }
+            }
+            // ---- step direction in control-point space: dx = G a - Z d1 = G (a - A' rv) ----------------------------------------
+            // lane p: its control point's entry of G a, then one AXPY per active row on that row's Z column -- three reads and
+            // three FMAs per row, whatever kind of row it is
             // DXREG (static shapes without slack variables, P <= 64): lane p keeps dx of control point p in registers; the
-            // step is taken from there and dx goes to LDS only when |z|^2 has to be evaluated as a quadratic form (below)
+            // step is taken from there (lanes beyond P hold control point P - 1 once more)
             RegD dkr[3];
+            constexpr int DD = DIMS > 0 ? DIMS : 3;
             w.each([&](int l) {
                 for (int pb = 0; pb < P; pb += 64) {  // uniform trip count
                     const int p = pb + l;
@@ -1774,134 +1705,75 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     const int pc = in ? p : P - 1;
                     double dk[3];
                     {
-                        double g0 = G[np0 * ldg + pc], g1 = G[np1 * ldg + pc], g2 = G[np2 * ldg + pc];
-                        DQ_KEEP(g0); DQ_KEEP(g1); DQ_KEEP(g2);
+                        double g0, g1, g2;
+                        if (P64) {
+                            g0 = gq[0].at(l); g1 = gq[1].at(l); g2 = gq[2].at(l);
+                        } else {
+                            g0 = G[np0 * ldg + pc]; g1 = G[np1 * ldg + pc]; g2 = G[np2 * ldg + pc];
+                            DQ_KEEP(g0); DQ_KEEP(g1); DQ_KEEP(g2);
+                        }
                         const double sl = ncf[0] * g0 + ncf[1] * g1 + ncf[2] * g2;
                         dk[0] = new_line ? (new_axis == 0 ? sl : 0.0) : ncf[0] * g0;
                         dk[1] = new_line ? (new_axis == 1 ? sl : 0.0) : ncf[1] * g0;
                         dk[2] = new_line ? (new_axis == 2 ? sl : 0.0) : ncf[2] * g0;
                     }
-                    if (BYK && DXREG && dense_dx) {  // uniform
-                        const double *gr = G + pc * ldg;
-                        // (u through v_readlane: wave-uniform operands in scalar registers, like the weights of the loops below;
-                        // the kernel has no vector registers left for a block of u read from LDS)
-                        constexpr int UB = 6;  // P = 6 M: no remainder
-                        for (int pp = 0; pp < P; pp += UB) {
-                            double gq[UB];
+                    for (int j0 = 0; j0 < q_in; j0 += JB) {  // uniform; every read of a block issued before its first use
+                        double zc[JB][DD];
 #pragma unroll
-                            for (int u = 0; u < UB; u++) gq[u] = gr[pp + u];
+                        for (int u = 0; u < JB; u++) {
+                            const double *zj = colw + (j0 + u < q_in ? j0 + u : q_in - 1) * cs + zo + pc;
 #pragma unroll
-                            for (int u = 0; u < UB; u++) DQ_KEEP(gq[u]);
-#pragma unroll
-                            for (int u = 0; u < UB; u++) {
-#pragma unroll
-                                for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++) dk[k] = fma(gq[u], w.bcast(ureg[k], pp + u), dk[k]);
-                            }
-                        }
-                        // the POINT rows by their mask: the loop over all active rows below would spend most of its trips on
-                        // the rows the dense product has dealt with
-#pragma unroll
-                        for (int c = 0; c < RC; c++) {
-                            uint64_t todo = point_rows[c];
-                            while (todo) {  // uniform
-                                double gq[DB], wq[DB][3];
-#pragma unroll
-                                for (int u = 0; u < DB; u++) {
-                                    const bool have = todo != 0;
-                                    const int il = have ? ctz64(todo) : 0;
-                                    todo &= todo - (have ? 1 : 0);
-                                    gq[u] = G[(int)(w.bcast(a_pk[c], il) & 0xFF) * ldg + pc];
-#pragma unroll
-                                    for (int t = 0; t < 3; t++) {
-                                        const double wv = w.bcast(wcp[c][t], il);
-                                        wq[u][t] = have ? wv : 0.0;
-                                    }
-                                }
-#pragma unroll
-                                for (int u = 0; u < DB; u++) DQ_KEEP(gq[u]);
-#pragma unroll
-                                for (int u = 0; u < DB; u++) {
-                                    dk[0] = fma(wq[u][0], gq[u], dk[0]);
-                                    dk[1] = fma(wq[u][1], gq[u], dk[1]);
-                                    if (DIMS != 2) dk[2] = fma(wq[u][2], gq[u], dk[2]);
-                                }
-                            }
-                        }
-                    } else
-                    // POINT rows, in blocks of DB (its weights are wave-uniform: a block must fit the scalar registers) with the table reads of a block issued together (a LINE row, and what the last
-                    // block holds beyond the active rows, multiplies a valid table entry by zero)
-                    for (int i0 = 0; i0 < q; i0 += DB) {
-                        double gq[DB];
-#pragma unroll
-                        for (int u = 0; u < DB; u++) {
-                            const int i = i0 + u;
-                            const uint32_t pk = RC == 1 ? w.bcast(a_pk[0], i) : (i < 64 ? w.bcast(a_pk[0], i) : w.bcast(a_pk[RC - 1], i - 64));
-                            gq[u] = G[(int)(pk & 0xFF) * ldg + pc];
+                            for (int k = 0; k < DD; k++) zc[u][k] = zj[(k < dim ? k : 0) * P];
                         }
 #pragma unroll
-                        for (int u = 0; u < DB; u++) DQ_KEEP(gq[u]);
+                        for (int u = 0; u < JB; u++) {
 #pragma unroll
-                        for (int u = 0; u < DB; u++) {
-                            dk[0] = fma(DQ_BC2(wcp, 0, i0 + u), gq[u], dk[0]);
-                            dk[1] = fma(DQ_BC2(wcp, 1, i0 + u), gq[u], dk[1]);
-                            if (DIMS != 2) dk[2] = fma(DQ_BC2(wcp, 2, i0 + u), gq[u], dk[2]);
+                            for (int k = 0; k < DD; k++) DQ_KEEP(zc[u][k]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < JB; u++) {
+                            const double wj = DQ_BC(nd1, j0 + u);
+#pragma unroll
+                            for (int k = 0; k < DD; k++) dk[k] = fma(wj, zc[u][k], dk[k]);
                         }
                     }
-                    // LINE rows: three table entries each, LB rows per trip with every read of the trip issued together (rows that
-                    // the last trip does not have get weight zero)
+                    for (int j0 = qz; j0 < q; j0 += JB) {  // records in the spill record
+                        double zc[JB][DD];
 #pragma unroll
-                    for (int c = 0; c < RC; c++) {
-                        constexpr int LB = 2;
-                        uint64_t todo = line_rows[c];
-                        while (todo) {  // uniform
-                            double gl[LB][3], wl[LB][3], ax[LB][3];
+                        for (int u = 0; u < JB; u++) {
+                            const double *zj = colsp + (size_t)((j0 + u < q ? j0 + u : q - 1) - qz) * cs + zo + pc;
 #pragma unroll
-                            for (int u = 0; u < LB; u++) {
-                                const bool have = todo != 0;
-                                const int il = have ? ctz64(todo) : 0;
-                                todo &= todo - (have ? 1 : 0);
-                                const uint32_t pk = w.bcast(a_pk[c], il);
-                                const int ka = (pk >> 24) & 3;
-                                gl[u][0] = G[(int)(pk & 0xFF) * ldg + pc];
-                                gl[u][1] = G[(int)((pk >> 8) & 0xFF) * ldg + pc];
-                                gl[u][2] = G[(int)((pk >> 16) & 0xFF) * ldg + pc];
+                            for (int k = 0; k < DD; k++) zc[u][k] = zj[(k < dim ? k : 0) * P];
+                        }
 #pragma unroll
-                                for (int t = 0; t < 3; t++) {
-                                    const double wv = w.bcast(wc[c][t], il);
-                                    wl[u][t] = have ? wv : 0.0;
-                                    ax[u][t] = ka == t ? 1.0 : 0.0;
-                                }
-                            }
+                        for (int u = 0; u < JB; u++) {
 #pragma unroll
-                            for (int u = 0; u < LB; u++) { DQ_KEEP(gl[u][0]); DQ_KEEP(gl[u][1]); DQ_KEEP(gl[u][2]); }
+                            for (int k = 0; k < DD; k++) DQ_KEEP(zc[u][k]);
+                        }
 #pragma unroll
-                            for (int u = 0; u < LB; u++) {
-                                const double sl = wl[u][0] * gl[u][0] + wl[u][1] * gl[u][1] + wl[u][2] * gl[u][2];
-                                dk[0] = fma(ax[u][0], sl, dk[0]);
-                                dk[1] = fma(ax[u][1], sl, dk[1]);
-                                if (DIMS != 2) dk[2] = fma(ax[u][2], sl, dk[2]);
-                            }
+                        for (int u = 0; u < JB; u++) {
+                            const double wj = DQ_BC(nd1, j0 + u);
+#pragma unroll
+                            for (int k = 0; k < DD; k++) dk[k] = fma(wj, zc[u][k], dk[k]);
                         }
                     }
                     if (DXREG) {
-                        dkr[0].at(l) = in ? dk[0] : 0.0; dkr[1].at(l) = in ? dk[1] : 0.0; dkr[2].at(l) = (in && dim > 2) ? dk[2] : 0.0;
+                        dkr[0].at(l) = dk[0]; dkr[1].at(l) = dk[1]; dkr[2].at(l) = dim > 2 ? dk[2] : 0.0;
                     } else {
 #pragma unroll
-                        for (int k = 0; k < (DIMS > 0 ? DIMS : 3); k++)
+                        for (int k = 0; k < DD; k++)
                             if (k < dim) base[blend_idx(in, oDx + k * P + p, odump + (l & 31))] = dk[k];  // uniform condition
                     }
                 }
-                // slack variables: dx_s = sigma_s^2 (a_s - sum_i rv_i a_is), every slack coefficient is -1
+                // slack variables: G is diag(sigma^2) there and every slack coefficient is -1
                 for (int s0 = 0; s0 < nslk; s0 += 64) {  // uniform trip count
                     const int s = s0 + l;
-                    double v = s == sidx_row ? -1.0 : 0.0;
-                    for (int i = 0; i < q; i++) {
-                        const int si = RC == 1 ? w.bcast(a_sl[0], i) : (i < 64 ? w.bcast(a_sl[0], i) : w.bcast(a_sl[RC - 1], i - 64));
-                        const double rvi = DQ_BC(rv, i);
-                        v += si == s ? rvi : 0.0;
-                    }
-                    const double sg = kp.sigma[(s < nslk ? s : 0) % M];
-                    base[blend_idx(s < nslk, oDx + nxc + s, odump + (l & 31))] = sg * sg * v;
+                    const int sc = s < nslk ? s : nslk - 1;
+                    const double sg = kp.sigma[sc % M];
+                    double v = s == sidx_row ? -(sg * sg) : 0.0;
+                    for (int j = 0; j < q_in; j++) v = fma(DQ_BC(nd1, j), colw[j * cs + zo + nxc + sc], v);
+                    for (int j = qz; j < q; j++) v = fma(DQ_BC(nd1, j), colsp[(size_t)(j - qz) * cs + zo + nxc + sc], v);
+                    base[blend_idx(s < nslk, oDx + nxc + s, odump + (l & 31))] = v;
                 }
             });
             w.sync();
@@ -1933,8 +1805,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                         double x2 = dxl[(line ? ka : (dim > 2 ? 2 : 0)) * P + (int)((pk >> 16) & 0xFF)];
                         double xs = SLK != 0 ? dxl[nxc + (sl >= 0 ? sl : 0)] : 0.0;
                         DQ_KEEP(x0); DQ_KEEP(x1); DQ_KEEP(x2); DQ_KEEP(xs);
-                        // wc = -rv c (zero beyond the active rows); POINT rows in 2-D carry a zero third coefficient
-                        double s = wc[c][0].at(l) * x0 + wc[c][1].at(l) * x1 + wc[c][2].at(l) * x2;
+                        // weights -rv x coefficient (zero beyond the active rows); POINT rows in 2-D carry a zero third coefficient
+                        const double mr = l + 64 * c < q ? -rv[c].at(l) : 0.0;
+                        double s = (mr * (double)a_cf[c][0].at(l)) * x0 + (mr * (double)a_cf[c][1].at(l)) * x1 + (mr * (double)a_cf[c][2].at(l)) * x2;
                         s += (SLK != 0 && sl >= 0 && l + 64 * c < q) ? rv[c].at(l) * xs : 0.0;
                         acc += s;
                     }
@@ -1965,9 +1838,11 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     const bool act = i < q;
                     const int ic = act ? i : 0;
                     const uint32_t pk = act ? (uint32_t)DQ_BC(a_pk, ic) : pk_new;
-                    const double c0 = act ? DQ_BC2(wc, 0, ic) : ncf[0], c1 = act ? DQ_BC2(wc, 1, ic) : ncf[1], c2 = act ? DQ_BC2(wc, 2, ic) : ncf[2];
+                    const double mrv = -DQ_BC(rv, ic);  // active row i enters u with the weight -rv_i
+                    const double c0 = act ? mrv * (double)DQ_BC2(a_cf, 0, ic) : ncf[0], c1 = act ? mrv * (double)DQ_BC2(a_cf, 1, ic) : ncf[1],
+                                 c2 = act ? mrv * (double)DQ_BC2(a_cf, 2, ic) : ncf[2];
                     const int sl = act ? DQ_BCI(a_sl, ic) : sidx_row;
-                    const double cs = act ? DQ_BC(rv, ic) : -1.0;  // the slack variable's coefficient is -1: -rv x -1
+                    const double csl = act ? DQ_BC(rv, ic) : -1.0;  // the slack variable's coefficient is -1: -rv x -1
                     const int ka = (pk >> 24) & 3;
                     const bool line = (pk >> 26) & 1;
                     const int p0 = pk & 0xFF, p1 = (pk >> 8) & 0xFF, p2 = (pk >> 16) & 0xFF;
@@ -1979,7 +1854,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                         u[j0] += c0;
                         u[j1] += c1;
                         u[j2] += c2u;
-                        if (SLK != 0 && sl >= 0) u[nxc + sl] += cs;  // uniform
+                        if (SLK != 0 && sl >= 0) u[nxc + sl] += csl;  // uniform
                     });
                     w.sync();
                 }
@@ -2179,14 +2054,37 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             w.sync();
             w.stamp(8);  // primal / dual step
             if (!dependent && t2 <= t1) {
-                // ---- add row ip: R gains the column (d1; alpha), alpha = |z|  <=>  S = R^-1 gains (-S d1 / alpha; 1 / alpha) ----
+                // ---- add row ip: R gains the column (d1; alpha), alpha = |z|  <=>  S = R^-1 gains (-S d1 / alpha; 1 / alpha; zeros),
+                // and Z = G A' S the column G (a - A' rv) / alpha = dx / alpha: record q, every entry of it written ----
                 const double inv_alpha = 1.0 / sqrt(dd2);
+                auto write_record = [&](double *rec) {  // (called with a pointer into the working set or into the spill record)
+                    w.each([&](int l) {
+#pragma unroll
+                        for (int c = 0; c < RC; c++) {
+                            const int i = l + 64 * c;
+                            const int ic = i < r_max ? i : r_max - 1;  // (lanes beyond r_max: entry r_max - 1 once more, the same value)
+                            const double sv = ic < q ? -rv[c].at(l) * inv_alpha : (ic == q ? inv_alpha : 0.0);
+                            rec[ic] = sv;
+                        }
+                        if (DXREG) {
+                            const int pc = l < P ? l : P - 1;
+#pragma unroll
+                            for (int k = 0; k < DD; k++) rec[zo + k * P + pc] = dkr[k].at(l) * inv_alpha;
+                        } else {
+                            const int nx = nxc + nslk;
+                            for (int j0 = 0; j0 < nx; j0 += 64) {  // uniform trip count
+                                const int jc = j0 + l < nx ? j0 + l : nx - 1;
+                                rec[zo + jc] = dxl[jc] * inv_alpha;
+                            }
+                        }
+                    });
+                };
+                if (q < qz) write_record(colw + q * cs);  // uniform
+                else write_record(colsp + (size_t)(q - qz) * cs);
                 w.each([&](int l) {
 #pragma unroll
                     for (int c = 0; c < RC; c++) {
                         const int i = l + 64 * c;
-                        const double sv = i < q ? -rv[c].at(l) * inv_alpha : inv_alpha;
-                        Rp[blend_idx(i <= q, q * (q + 1) / 2 + i, odump_rp + (l & 31))] = sv;
                         const bool me = i == q;
                         uu[c].at(l) = me ? uq : uu[c].at(l);
                         act[c].at(l) = me ? ip : act[c].at(l);
@@ -2206,22 +2104,33 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 // ---- drop active row ldrop: delete column l of R, restore the triangle with Givens ----
                 const int lcol = ldrop;
                 set_skip(DQ_BCI(act, lcol), false, DQ_BC(a_rhs, lcol));
-                if (BYK && DXREG) {  // its entry of the weight tables (dense step direction) back to zero
-                    const int cd = DQ_BCI(act, lcol);
-                    const bool sl = (cd >> 3) < UL0 && (cd & 7) >= 2;
-                    const int slot = ((cd & 7) >= 4 ? nxc + 2 : 0) + 2 + (sl ? cd >> 3 : 0);
-                    w.each([&](int l) { base[blend_idx(sl, lay.oLam + slot, odump + (l & 31))] = 0.0; });
-                }
-                // Deleting column lcol of R: the rotations G of columns (t, t+1), t = lcol..q-2, that restore the
+                // entry `idx` of record k (k uniform): from the working set or from the spill record
+                auto rec_ld = [&](int k, int idx) -> double {
+                    if (k < qz) return colw[k * cs + idx];
+                    return colsp[(size_t)(k - qz) * cs + idx];
+                };
+                auto rec_st = [&](int k, bool cond, int idx, double v, int l) {  // lanes with nothing to store: to a dump slot
+                    if (k < qz) base[blend_idx(cond, oC + k * cs + idx, odump + (l & 31))] = v;
+                    else colsp[blend_idx(cond, (k - qz) * cs + idx, -32 + (l & 31))] = v;
+                };
+                // Deleting column lcol of R: the rotations of columns (t, t+1), t = lcol..q-2, that restore the
                 // triangle are those that sweep row lcol of S into its last entry; S' = (S without row lcol) G'
-                // without its last column.  All angles come from one prefix sum of squares.
+                // without its last column, and Z = G A' S takes the same rotations of its columns (what row lcol of S
+                // multiplied -- G a_lcol -- is gone from all but the last).  All angles come from one prefix sum of squares.
                 RegD srow[RC], pre[RC], gc[RC], gs[RC];
                 w.each([&](int l) {
 #pragma unroll
                     for (int c = 0; c < RC; c++) {
                         const int k = l + 64 * c;
                         const bool in = k >= lcol && k < q;
-                        const double sv = DQ_RP(lcol, in ? k : lcol);
+                        double sv = colw[((in & (k < qz)) ? k : 0) * cs + lcol];  // S(lcol, k): lane k reads ITS record
+                        DQ_KEEP(sv);
+                        if (q > qz) {  // uniform
+                            const bool sp = in & (k >= qz);
+                            double sg = colsp[(size_t)(sp ? k - qz : 0) * cs + lcol];
+                            DQ_KEEP(sg);
+                            sv = sp ? sg : sv;
+                        }
                         const double v = in ? sv : 0.0;
                         srow[c].at(l) = v;
                         pre[c].at(l) = v * v;
@@ -2254,27 +2163,45 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 #pragma unroll
                     for (int c = 0; c < RC; c++) {
                         const int i = l + 64 * c;
-                        const double s0 = DQ_RP(i <= lcol ? i : 0, lcol);
+                        const double s0 = rec_ld(lcol, i <= lcol ? i : 0);
                         yS[c].at(l) = i <= lcol ? s0 : 0.0;
                     }
                 });
                 for (int t = lcol; t < q - 1; t++) {
-                    const double cs = DQ_BC(gc, t + 1), sn = DQ_BC(gs, t + 1);
+                    const double rc_ = DQ_BC(gc, t + 1), rs_ = DQ_BC(gs, t + 1);
                     w.each([&](int l) {
 #pragma unroll
                         for (int c = 0; c < RC; c++) {
                             const int i = l + 64 * c;
                             // S: old column t+1 has rows 0..t+1; row lcol is deleted, rows below it move up
-                            const double cS0 = DQ_RP(i <= t + 1 ? i : 0, t + 1);
+                            const double cS0 = rec_ld(t + 1, i <= t + 1 ? i : 0);
                             const double cS = i <= t + 1 ? cS0 : 0.0;
-                            const double oS = cs * yS[c].at(l) - sn * cS;
-                            yS[c].at(l) = sn * yS[c].at(l) + cs * cS;
+                            const double oS = rc_ * yS[c].at(l) - rs_ * cS;
+                            yS[c].at(l) = rs_ * yS[c].at(l) + rc_ * cS;
                             const int inew = i < lcol ? i : i - 1;
-                            Rp[blend_idx((i != lcol) & (inew <= t), t * (t + 1) / 2 + inew, odump_rp + (l & 31))] = oS;
+                            rec_st(t, (i != lcol) & (inew <= t), inew, oS, l);
                         }
                     });
                     w.sync();
                 }
+                // the same rotations on the columns of Z, 64 entries of a column per trip (a lane keeps its entry of the column
+                // that is carried along in a register; no lane touches another lane's entries: no sync between the steps)
+                w.each([&](int l) {
+                    const int nx = nxc + nslk;
+                    for (int j0 = 0; j0 < nx; j0 += 64) {  // uniform trip count
+                        const bool in = j0 + l < nx;
+                        const int e = zo + (in ? j0 + l : nx - 1);
+                        double y = rec_ld(lcol, e);
+                        for (int t = lcol; t < q - 1; t++) {
+                            const double rc_ = DQ_BC(gc, t + 1), rs_ = DQ_BC(gs, t + 1);
+                            const double cz = rec_ld(t + 1, e);
+                            const double oz = rc_ * y - rs_ * cz;
+                            y = rs_ * y + rc_ * cz;
+                            rec_st(t, in, e, oz, l);
+                        }
+                    }
+                });
+                w.sync();
                 // compact the per-lane state of the active rows: element k takes element k+1, k >= lcol
                 {
                     RegD nu[RC], nrh[RC];
@@ -2383,7 +2310,6 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     w.stamp(11);  // read-out
 }
 
-#undef DQ_RP
 #undef DQ_BC
 #undef DQ_BCI
 #undef DQ_BC2

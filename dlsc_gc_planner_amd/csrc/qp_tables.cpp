@@ -426,8 +426,6 @@ bool build_tables(const dlscqp_config &cfg, int dim, int M, int n, int phi, doub
     }
     kp.max_iter = 0;  // 0: 20 (r + 8) + 200, chosen per agent in plan_agent
     kp.dbg_exit_phase = -1;
-    kp.dense_min = kp.P > 5 * DQ_QDENSE ? kp.P / 5 : DQ_QDENSE;  // the dense product costs ~40 cycles per control point
-    if (const char *dm = std::getenv("DLSCQP_DENSE_MIN")) kp.dense_min = std::max(1, std::atoi(dm));
     if (const char *dbg = std::getenv("DLSCQP_DEBUG_EXIT_PHASE")) kp.dbg_exit_phase = std::atoi(dbg);  // read by -DDQ_PHASE_PROFILE builds only
     if (const char *dbg = std::getenv("DLSCQP_DEBUG_MAX_ITER")) kp.max_iter = std::atoi(dbg);  // debugging aid
     return true;

@@ -23,9 +23,6 @@ struct Slot {
 };
 static_assert(sizeof(Slot) == 16, "Slot layout");
 
-#ifndef DQ_QDENSE  // plan_agent: from this many active velocity / acceleration rows on, their part of the step direction is a dense product
-#define DQ_QDENSE 8
-#endif
 struct KParams {
     // dimensions
     int dim, M, n1, P, f, phi;
@@ -36,8 +33,6 @@ struct KParams {
     int max_iter;
     int phi_ok;    // tabPhi is valid
     int dbg_exit_phase;  // profiling builds only (gi_core.hpp: DQ_PHASE_EXIT), else -1
-    int dense_min;       // plan_agent: from this many active velocity / acceleration rows on the step direction is a dense product
-                         // (DQ_QDENSE, or P / 5 for long horizons; DLSCQP_DENSE_MIN in the environment: tests force the path)
     int wd_cut;    // the weak-duality infeasibility test of gi_core.hpp is valid (its objective bound assumes phi_n = 1)
     int dep_calibrated;  // weights and dt are the launch files' (control_input_weight 0.01, terminal_weight 1, dt 0.2, phi_n 1): the values
                          // DEP_SUSPECT was calibrated on; elsewhere every shape uses the wide threshold DEP_SUSPECT_SLACK (qp_tables.cpp)

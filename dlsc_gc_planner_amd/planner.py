@@ -255,6 +255,16 @@ class DeviceBatch:
         self.max_rows = kmax
         self.max_slack_obs = max_slack_obs
 
+    def use_workspace(self):
+        """A buffer of this batch's own for the launch's spill records (dlscqp_device_batch.workspace): launches of several batches
+        of one context may then overlap, and the batch can be captured into a graph without a first eager launch."""
+        need = int(self.opt.lib.dlscqp_workspace_bytes(self.opt.handle, self.n_agents, self.max_slack_obs, self.max_rows))
+        if need > 0:
+            self._workspace = self.torch.empty(need, dtype=self.torch.uint8, device=self.device)
+            self.c.workspace = self._workspace.data_ptr()
+            self.c.workspace_bytes = need
+        return need
+
     def use_row_counts(self, counts):
         """counts: int32 CUDA tensor [n_agents] (LscGenerator.enable_pruning) or None: rows per agent from row_offsets on."""
         self._row_counts = counts

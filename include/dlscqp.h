@@ -135,8 +135,9 @@ void dlscqp_destroy(dlscqp_ctx *ctx);
 int dlscqp_update_param(dlscqp_ctx *ctx, const dlscqp_config *cfg);
 /* Text of the last error on this thread ("" if none). */
 const char *dlscqp_last_error(void);
-/* Bytes of the working set of one agent (= one wavefront) for this context; diagnostic.  Up to 160 KiB it lives in LDS;
- * above (3-D, M = 10 with four or more slack obstacles) the launch uses per-agent working sets in HBM owned by the
+/* Bytes of the smallest working set of one agent (= one wavefront) a launch of this shape can run with (the records of eight
+ * active rows in it, the others in the spill records: dlscqp_device_batch.workspace); diagnostic.  Up to 160 KiB it lives in LDS;
+ * above (a flag array of tens of thousands of rows per agent) the launch uses per-agent working sets in HBM owned by the
  * context -- slower per iteration, and launches of one context that need them must not overlap. */
 int64_t dlscqp_lds_bytes(const dlscqp_ctx *ctx, int32_t max_slack_obs, int32_t max_rows_per_agent);
 
@@ -228,6 +229,16 @@ typedef struct dlscqp_device_batch {
                                        are written in the layout the exchange sends (dlscqp_exchange_post_records: control points |
                                        sub-goal | verdict, M (n+1) 3 + 4 words), no packing pass in between.  0: three dense arrays. */
     int32_t reserved2_;
+    /* ---- round 5 (appended, zero = the behaviour of before) -------------------------------------------------------------- */
+    void *workspace;                /* optional device buffer of workspace_bytes bytes for the launch's SPILL RECORDS: an agent's
+                                       working set keeps the records of its first 8 or 16 active rows in LDS (the inverse factor's and
+                                       the orthonormalised normals' columns, csrc/gi_core.hpp: MemLayout); the few agents of a large
+                                       launch that activate more rows keep the others here, in HBM.  dlscqp_workspace_bytes() says how
+                                       much a launch can need.  NULL (or too small): the library uses a buffer of the CONTEXT, grown
+                                       on demand -- which launches of the same context on different streams would share (do not
+                                       overlap them) and which cannot grow inside a stream capture.  Launches small enough to give
+                                       every agent the LDS for all its records need neither.  Contents are scratch.              */
+    int64_t workspace_bytes;
 } dlscqp_device_batch;
 
 /* key layout: bits 0-7 m, 8-11 i, 12 dynamic flag, 16-31 slack index (0xFFFF = none). */
@@ -236,6 +247,8 @@ typedef struct dlscqp_device_batch {
      ((uint32_t)((slack) < 0 ? 0xFFFFu : (uint32_t)(slack)) << 16))
 
 int dlscqp_plan_batch_device(dlscqp_ctx *ctx, const dlscqp_device_batch *batch, void *stream);
+/* bytes of dlscqp_device_batch.workspace that suffice for any launch of up to n_agents agents of this shape (0: none needed) */
+int64_t dlscqp_workspace_bytes(const dlscqp_ctx *ctx, int32_t n_agents, int32_t max_slack_obs, int32_t max_rows_per_agent);
 
 /* Launch order for the NEXT replanning step from the iteration counts of the one just planned (out_iters of
  * dlscqp_device_batch, 4 int32 per agent): order_out[b] = the agent workgroup b plans, agents with the most active-set

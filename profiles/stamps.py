@@ -17,8 +17,8 @@ sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "dlsc_gc_planner_amd", "csrc")
 LIB = os.environ.get("DLSCQP_STAMPS_LIB", os.path.join(CSRC, "libdlscqp_stamps.so"))
 
-PHASES = ["agent+goalLP", "init(x0,bounds,G->LDS)", "scan+argmax", "decode,|N'a|^2", "g=AGa", "d1=S'g,rv=S d1",
-          "dx=G(a-A'rv),|z|^2", "ratio test", "primal/dual step", "add row", "givens drop", "readout"]
+PHASES = ["agent+goalLP", "init(x0,bounds)", "scan+argmax", "decode,G rows asked", "d1=Z'a", "rv=S d1",
+          "|N'a|^2,dx=Ga-Z d1,|z|^2", "ratio test", "primal/dual step", "add row", "givens drop", "readout"]
 
 
 def ensure_lib():

@@ -162,7 +162,7 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
     const InstanceChoice ic = select_instance(kp, max_slack_obs, kmax, std::getenv("EMUL_GENERIC") != nullptr);
     if (ic.id < 0) return -2;
     const int KUsel = ic.KU, SUsel = ic.SU;
-    typedef void (*fn_t)(const WaveCpu &, const KParams &, const MemLayout &, unsigned char *, const dlscqp_agent *,
+    typedef void (*fn_t)(const WaveCpu &, const KParams &, const MemLayout &, unsigned char *, double *, const dlscqp_agent *,
                          const RowsView &, int, int, const float *, int, int, int, float *, int *, float *, double *,
                          double *, double *, int *, int *);
     fn_t fn = nullptr;
@@ -175,8 +175,12 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
     // rows beyond the register cache in the working set, as the launcher sizes it for a build that runs four agents per CU
     // (EMUL_LDS_BUDGET=0: every such row from "HBM" in every pass)
     const char *bud = std::getenv("EMUL_LDS_BUDGET");
-    MemLayout lay = make_layout(kp, max_slack_obs, kmax, KUsel, SUsel, ic.by_kind, bud ? std::atoi(bud) : 40448);
+    // column records of the active rows: EMUL_QZ of them in the working set, the rest in a spill record (0: all in the working
+    // set); the launcher's default for launches that fill the chip is 16
+    const char *qzs = std::getenv("EMUL_QZ");
+    MemLayout lay = make_layout(kp, max_slack_obs, kmax, KUsel, SUsel, ic.by_kind, bud ? std::atoi(bud) : 40448, qzs ? std::atoi(qzs) : 16);
     std::vector<unsigned char> mem(lay.bytes + 64 + 4096);
+    std::vector<double> spill(lay.spill_doubles + 8);
     WaveCpu w;
     const char *rev = std::getenv("EMUL_REVERSE");
     w.reverse = rev && rev[0] == '1';
@@ -184,7 +188,8 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
     const size_t xs = (size_t)dim * M * n1 + (size_t)M * max_slack_obs;
     for (int a = 0; a < n_agents; a++) {
         std::memset(mem.data(), 0xCD, mem.size());  // poison: nothing may rely on zero-initialised LDS
-        fn(w, kp, lay, mem.data(), agents + a, rv, (int)row_offsets[a],
+        std::memset(spill.data(), 0xCD, spill.size() * sizeof(double));
+        fn(w, kp, lay, mem.data(), lay.spill_doubles ? spill.data() : nullptr, agents + a, rv, (int)row_offsets[a],
                    (int)(row_offsets[a + 1] - row_offsets[a]), sfc ? sfc + (size_t)a * M * 6 : nullptr,
                    max_slack_obs, do_goal, do_traj, out_goal ? out_goal + (size_t)a * 3 : nullptr,
                    out_goal_status ? out_goal_status + a : nullptr,
@@ -490,7 +495,7 @@ extern "C" int emul_throughput(const dlscqp_config *cfg, int n_agents, const dls
     RowsView rv{nx.data(), ny.data(), nz.data(), px.data(), py.data(), pz.data(), d.data(), key.data()};
     const InstanceChoice ic = select_instance(kp, max_slack_obs, kmax, false);
     if (ic.id < 0) return -2;
-    typedef void (*fn_t)(const WaveCpu &, const KParams &, const MemLayout &, unsigned char *, const dlscqp_agent *,
+    typedef void (*fn_t)(const WaveCpu &, const KParams &, const MemLayout &, unsigned char *, double *, const dlscqp_agent *,
                          const RowsView &, int, int, const float *, int, int, int, float *, int *, float *, double *,
                          double *, double *, int *, int *);
     fn_t fn = nullptr;
@@ -518,7 +523,7 @@ extern "C" int emul_throughput(const dlscqp_config *cfg, int n_agents, const dls
         if (hi <= lo) return;
         int a = lo;
         for (;;) {
-            fn(w, kp, lay, mem.data(), agents + a, rv, (int)row_offsets[a], (int)(row_offsets[a + 1] - row_offsets[a]),
+            fn(w, kp, lay, mem.data(), nullptr, agents + a, rv, (int)row_offsets[a], (int)(row_offsets[a + 1] - row_offsets[a]),
                sfc ? sfc + (size_t)a * M * 6 : nullptr, max_slack_obs, 1, 1, goal, &gst, ctrl.data(), nullptr, &cost,
                max_slack_obs ? slack.data() : nullptr, &st, it);
             done[t]++;

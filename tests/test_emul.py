@@ -93,7 +93,7 @@ def test_host_tables_dimensions():
     assert E.table_info(abi.make_config(dim=2, M=10))["f"] == 28
     assert E.table_info(abi.make_config(dim=2, M=4, planner_mode=abi.PLANNER_BVC))["f"] == 12
     i = E.table_info(abi.make_config(dim=3, M=5), 0, 120)
-    assert i["n_slots"] == 81 + 69 + 57 and i["lds_bytes"] < 32 * 1024
+    assert i["n_slots"] == 81 + 69 + 57 and i["lds_bytes"] < 48 * 1024  # every column record in the working set (no spill record)
     with pytest.raises(ValueError):
         E.table_info(abi.make_config(dim=3, M=5, n=4))  # only n=5, phi=3 (traj_optimizer.cpp:209)
 
