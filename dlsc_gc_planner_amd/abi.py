@@ -344,8 +344,9 @@ def load_library():
     lib.dlscqp_last_error.restype = C.c_char_p
     lib.dlscqp_lds_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.dlscqp_lds_bytes.restype = C.c_int64
-    lib.dlscqp_workspace_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
-    lib.dlscqp_workspace_bytes.restype = C.c_int64
+    if hasattr(lib, "dlscqp_workspace_bytes"):  # (tests/tools/ab.py also loads libraries built from earlier rounds' sources)
+        lib.dlscqp_workspace_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        lib.dlscqp_workspace_bytes.restype = C.c_int64
     vp = C.c_void_p
     lib.dlscqp_solve_batch.argtypes = [vp, C.c_int32, vp, vp, vp, vp, C.c_int32, vp, vp, vp, vp]
     lib.dlscqp_solve_batch.restype = C.c_int

@@ -107,6 +107,13 @@ struct WaveGpu {
         acc[p] += t - last;
         last = t;
     }
+#elif defined(DLSCQP_ISA_MARKS)
+    // diagnostic compile only (tests/tools/isa_phases.py): the phase boundaries as comments in the assembly
+    __device__ __forceinline__ void stamp(int p) const {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("; DQ_STAMP %0" ::"i"(p));
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #else
     __device__ __forceinline__ void stamp(int) const {}
 #endif

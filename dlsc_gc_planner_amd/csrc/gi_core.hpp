@@ -1668,13 +1668,25 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 w.stamp(5);  // rv = S d1
             }
             // squared whitened length of the row, a' G a: the entries of G at the row's own control points
+            // (the rows of G through an opaque copy made HERE: everything computed from them is invariant in this loop, and
+            // hoisted in front of it -- as the compiler did -- it waits for their trip to L2 before d1 and rv instead of after)
+            RegD gk[3];
+            if (P64) {
+                w.each([&](int l) {
+#pragma unroll
+                    for (int t = 0; t < 3; t++) {
+                        gk[t].at(l) = gq[t].at(l);
+                        DQ_KEEP(gk[t].at(l));
+                    }
+                });
+            }
             {
                 double g00, g01 = 0.0, g02 = 0.0, g11 = 0.0, g12 = 0.0, g22 = 0.0;
                 if (P64) {
-                    g00 = w.bcast(gq[0], np0);
+                    g00 = w.bcast(gk[0], np0);
                     if (new_line) {  // uniform
-                        g01 = w.bcast(gq[0], np1); g02 = w.bcast(gq[0], np2);
-                        g11 = w.bcast(gq[1], np1); g12 = w.bcast(gq[1], np2); g22 = w.bcast(gq[2], np2);
+                        g01 = w.bcast(gk[0], np1); g02 = w.bcast(gk[0], np2);
+                        g11 = w.bcast(gk[1], np1); g12 = w.bcast(gk[1], np2); g22 = w.bcast(gk[2], np2);
                     }
                 } else {
                     g00 = G[np0 * ldg + np0];
@@ -1707,7 +1719,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     {
                         double g0, g1, g2;
                         if (P64) {
-                            g0 = gq[0].at(l); g1 = gq[1].at(l); g2 = gq[2].at(l);
+                            g0 = gk[0].at(l); g1 = gk[1].at(l); g2 = gk[2].at(l);
                         } else {
                             g0 = G[np0 * ldg + pc]; g1 = G[np1 * ldg + pc]; g2 = G[np2 * ldg + pc];
                             DQ_KEEP(g0); DQ_KEEP(g1); DQ_KEEP(g2);

@@ -18,7 +18,7 @@ CSRC = os.path.join(ROOT, "dlsc_gc_planner_amd", "csrc")
 LIB = os.environ.get("DLSCQP_STAMPS_LIB", os.path.join(CSRC, "libdlscqp_stamps.so"))
 
 PHASES = ["agent+goalLP", "init(x0,bounds)", "scan+argmax", "decode,G rows asked", "d1=Z'a", "rv=S d1",
-          "|N'a|^2,dx=Ga-Z d1,|z|^2", "ratio test", "primal/dual step", "add row", "givens drop", "readout"]
+          "a'Ga,dx=Ga-Z d1,a.dx", "ratio test", "primal/dual step", "add row", "givens drop", "readout"]
 
 
 def ensure_lib():
