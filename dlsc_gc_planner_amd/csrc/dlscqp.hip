@@ -342,14 +342,17 @@ __device__ __forceinline__ int hinted_agent(const KernelArgs &a, int slot, int l
 // developer-only compiler configuration of tests/flag_matrix.py, -sgpr-regalloc=fast, produced a wrong forest batch with it.)
 // The instantiations that keep two wavefronts per SIMD exist a second time, WIDE, for launches too small to put a second
 // wavefront on a SIMD at all (at most one agent per SIMD of the chip: every mission of the reference).
-#ifndef DQ_KERNEL_ATTR
 #ifndef DQ_WPA_OCC
 #define DQ_WPA_OCC 1  // wavefronts per SIMD the builds with helper wavefronts are compiled for
 #endif
 #ifndef DQ_M10_2D_ONE  // the 2-D, M = 10 shape at one wavefront per SIMD (0: two -- an experiment of round 4, profiles/)
 #define DQ_M10_2D_ONE 1
 #endif
-#define DQ_KERNEL_ATTR __launch_bounds__(64 * WPA, WPA > 1 ? DQ_WPA_OCC : ((WIDE || (DIMS > 0 && (RC == 2 || (DIMS == 2 && FS == 28 && DQ_M10_2D_ONE)))) ? 1 : 2))
+#ifndef DQ_PLAN_OCC  // wavefronts per SIMD the standard builds are compiled for (3: an experiment of round 5)
+#define DQ_PLAN_OCC 2
+#endif
+#ifndef DQ_KERNEL_ATTR
+#define DQ_KERNEL_ATTR __launch_bounds__(64 * WPA, WPA > 1 ? DQ_WPA_OCC : ((WIDE || (DIMS > 0 && (RC == 2 || (DIMS == 2 && FS == 28 && DQ_M10_2D_ONE)))) ? 1 : DQ_PLAN_OCC))
 #endif
 // WS_HBM: the agent's working set (MemLayout) lives in a per-slot HBM buffer instead of LDS -- for batches whose working
 // set exceeds the 160 KiB of a CU.  Since the solver keeps no orthogonal factor (gi_core.hpp) that is only a batch with
@@ -1172,7 +1175,8 @@ static LayoutChoice choose_layout(const KParams &kp, const dlscqp_device_batch *
         out.lay = make_layout(kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, kc.by_kind, row_budget, 0);
         return out;
     }
-    const int qz_want = qz_env ? atoi(qz_env) : (cold ? 8 : 16);
+    int qz_want = qz_env ? atoi(qz_env) : (cold ? 8 : 16);
+    if (!qz_env && qz_want > 8 && make_layout(kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, kc.by_kind, 0, qz_want).bytes > budget) qz_want = 8;
     out.lay = make_layout(kp, b->max_slack_obs, b->max_rows_per_agent, kc.KU, kc.SU, kc.by_kind, row_budget, qz_want);
     return out;
 }
@@ -1265,7 +1269,7 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         // DLSCQP_ROWS_IN_LDS=0: every such row from HBM in every pass, as before round 4 (tests).
         static const bool rows_in_lds = !(getenv("DLSCQP_ROWS_IN_LDS") && getenv("DLSCQP_ROWS_IN_LDS")[0] == '0');
         const bool one_per_simd = wide || (kc.id == 3 && DQ_M10_2D_ONE) || kc.id == 4 || kc.id == 5;
-        const int max_per_cu = wpa ? (DQ_WPA_OCC * 4) / DQ_WPA : (one_per_simd ? 4 : 8);
+        const int max_per_cu = wpa ? (DQ_WPA_OCC * 4) / DQ_WPA : (one_per_simd ? 4 : 4 * DQ_PLAN_OCC);
         const LayoutChoice lc = choose_layout(c->kp, b, kc, a.n_slots_launch, max_per_cu < 1 ? 1 : max_per_cu, rows_in_lds && !wpa);
         lay = lc.lay;
         if (lay.bytes > LDS_LIMIT) { g_last_error = "working set exceeds the LDS of a CU"; return DLSCQP_ERR_UNSUPPORTED; }  // (ws_hbm above rules it out)

@@ -405,6 +405,8 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     // select_instance() hands the KU = 2 instantiation only batches whose rows and slots all fit the register caches
     // (kmax <= 128, n_slots <= 256): it is compiled without the loops over rows and slots beyond them
     constexpr bool ALL_CACHED = KU == 2 && SU == 0;
+    // ... and, knowing all of an agent's rows, it asks first whether any of them is violated at all (the screen, below)
+    constexpr bool SCREEN = ALL_CACHED && DIMS > 0 && SLK == 0;
     constexpr int SUA = SU > 0 ? SU : 1;  // register arrays of the slot cache (never empty)
     // BYK (static shapes): the rows of one KIND that every agent has -- variable bounds / box faces, velocity and
     // acceleration limits (traj_optimizer.cpp:237-270, 385-410, 453-487) -- are not decoded from the slot table: lane l owns
@@ -628,34 +630,74 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             // One pass over the rows: per-lane bounds, then max / min / any across the wave.
             RegD llo, lhi;
             RegI lbad, lviol;
-            auto lp_row = [&](uint32_t key, float nx, float ny, float nz, float qx, float qy, float qz, double dd,
-                              double &lo, double &hi, int &bad, int &viol) {
-                // select form (no lane-dependent branch): rows that are not part of the LP leave lo/hi/bad/viol as they are
+            // a row's coefficients (select form, no lane-dependent branch), then its bound t >= -b / a or t <= -b / a
+            auto lp_coeff = [&](uint32_t key, float nx, float ny, float nz, float qx, float qy, float qz, double dd,
+                                bool &in_lp, double &a, double &b, int &viol) {
                 const int m = key & 0xFF, i = (key >> 8) & 0xF, dyn = (key >> 12) & 1;
-                const bool in_lp = (key != KEY_SKIP) & (dyn == 0) & (m == M - 1) & (i == n) & !f32_norm3_below_eps(nx, ny, nz);
+                in_lp = (key != KEY_SKIP) & (dyn == 0) & (m == M - 1) & (i == n) & !f32_norm3_below_eps(nx, ny, nz);
                 const float ox = wp[0] - qx, oy = wp[1] - qy, oz = wp[2] - qz;
-                double a = (double)nx * (double)diff[0] + (double)ny * (double)diff[1];
-                double b = -dd + (double)nx * (double)ox + (double)ny * (double)oy;
+                a = (double)nx * (double)diff[0] + (double)ny * (double)diff[1];
+                b = -dd + (double)nx * (double)ox + (double)ny * (double)oy;
                 const double a3 = a + (double)nz * (double)diff[2], b3 = b + (double)nz * (double)oz;
                 a = dim == 3 ? a3 : a;
                 b = dim == 3 ? b3 : b;
-                double tq = -b / a;  // not finite when a == 0: never selected then
-                DQ_KEEP(tq);
-                lo = (in_lp & (a > 0) & (tq > lo)) ? tq : lo;
-                hi = (in_lp & (a < 0) & (tq < hi)) ? tq : hi;
-                bad = (in_lp & !(a > 0) & !(a < 0) & (b < -CPLEX_FEAS_TOL)) ? 1 : bad;
                 // exception branch of goal_optimizer.cpp:63-77: does current_goal_point violate the row?
                 const float e0 = cg[0] - qx, e1 = cg[1] - qy, e2 = cg[2] - qz;
                 const float dot = nx * e0 + ny * e1 + nz * e2;  // float32 dot of float32 differences
                 viol = (in_lp & ((double)dot - dd < -SP_EPSILON_FLOAT)) ? 1 : viol;
             };
+            auto lp_bound = [&](bool in_lp, double a, double b, double &lo, double &hi, int &bad) {
+                // rows that are not part of the LP leave lo / hi / bad as they are
+                double tq = -b / a;  // not finite when a == 0: never selected then
+                DQ_KEEP(tq);
+                lo = (in_lp & (a > 0) & (tq > lo)) ? tq : lo;
+                hi = (in_lp & (a < 0) & (tq < hi)) ? tq : hi;
+                bad = (in_lp & !(a > 0) & !(a < 0) & (b < -CPLEX_FEAS_TOL)) ? 1 : bad;
+            };
+            auto lp_row = [&](uint32_t key, float nx, float ny, float nz, float qx, float qy, float qz, double dd,
+                              double &lo, double &hi, int &bad, int &viol) {
+                bool in_lp;
+                double a, b;
+                lp_coeff(key, nx, ny, nz, qx, qy, qz, dd, in_lp, a, b, viol);
+                lp_bound(in_lp, a, b, lo, hi, bad);
+            };
+            // The rows of the LP are those of the last control point: a few of an agent's rows, and hardly ever two of one lane's
+            // cached rows.  Where no lane has two (one ballot), each lane divides once, for the row it has (a double-precision
+            // division is ~35 instructions); else row by row.
+            RegD c_a[KU], c_b[KU];
+            RegI c_in_r[KU], lviol0, lmulti;
+            w.each([&](int l) {
+                int viol = 0, cnt = 0;
+#pragma unroll
+                for (int u = 0; u < KU; u++) {
+                    double a, b;
+                    bool in_u;
+                    lp_coeff(ckey[u].at(l), cnx[u].at(l), cny[u].at(l), cnz[u].at(l), cpx[u].at(l), cpy[u].at(l), cpz[u].at(l), cd[u].at(l),
+                             in_u, a, b, viol);
+                    c_a[u].at(l) = a; c_b[u].at(l) = b; c_in_r[u].at(l) = in_u ? 1 : 0;
+                    cnt += in_u ? 1 : 0;
+                }
+                lviol0.at(l) = viol;
+                lmulti.at(l) = cnt > 1 ? 1 : 0;
+            });
+            const bool lp_multi = w.any(lmulti);
             w.each([&](int l) {
                 double lo = -1e300, hi = 1e300;
-                int bad = 0, viol = 0;
+                int bad = 0, viol = lviol0.at(l);
+                if (!lp_multi) {  // uniform
+                    bool in = false;
+                    double a = 1.0, b = 0.0;
 #pragma unroll
-                for (int u = 0; u < KU; u++)
-                        lp_row(ckey[u].at(l), cnx[u].at(l), cny[u].at(l), cnz[u].at(l), cpx[u].at(l), cpy[u].at(l),
-                               cpz[u].at(l), cd[u].at(l), lo, hi, bad, viol);
+                    for (int u = 0; u < KU; u++) {
+                        const bool iu = c_in_r[u].at(l) != 0;
+                        a = iu ? c_a[u].at(l) : a; b = iu ? c_b[u].at(l) : b;
+                        in |= iu;
+                    }
+                    lp_bound(in, a, b, lo, hi, bad);
+                } else {
+#pragma unroll
+                    for (int u = 0; u < KU; u++) lp_bound(c_in_r[u].at(l) != 0, c_a[u].at(l), c_b[u].at(l), lo, hi, bad);
+                }
                 // rows beyond the register cache (uniform trip count): CB blocks of 64 rows per trip, all their loads
                 // issued before the first use (one HBM round trip per CB blocks)
                 if (!ALL_CACHED)
@@ -773,7 +815,11 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     float *lnx = reinterpret_cast<float *>(liw + lay.cold_cap), *lny = lnx + lay.cold_cap, *lnz = lny + lay.cold_cap;
     uint32_t *lkey = reinterpret_cast<uint32_t *>(lnz + lay.cold_cap);
 
-    const int T = terminal_segments(goal);  // terminal segments, traj_optimizer.cpp:543-551
+    // terminal segments, traj_optimizer.cpp:543-551 (the value computed ahead of the LP stands whenever the LP answered with the
+    // very point it was computed from -- the waypoint: three agent-steps of four --: a norm, a square root and two divisions less)
+    const float *gl_ahead = do_goal ? wp : cg;
+    const bool same_goal = T_ahead > 0 && goal[0] == gl_ahead[0] && goal[1] == gl_ahead[1] && goal[2] == gl_ahead[2];
+    const int T = same_goal ? T_ahead : terminal_segments(goal);
     int status = DLSCQP_OK;
     if (!kp.t_valid[T - 1]) status = DLSCQP_NUMERICAL;
     if (nslk > 0 && !(kp.w_s > 0)) status = DLSCQP_NUMERICAL;
@@ -923,9 +969,13 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             ckey[u].at(l) = live ? key2 : KEY_SKIP;
             cpo[u].at(l) = live && mi < P ? mi : 0;
             ltag[u].at(l) = (uint32_t)((BYK ? nxc : 0) + l + 64 * u) << 3;
-            double iw = DQ_RSQRT(live ? wsq : 1.0);
-            DQ_KEEP(iw);
-            ciw[u].at(l) = iw;
+            if (SCREEN) {
+                ciw[u].at(l) = live ? wsq : 1.0;  // (its reciprocal square root behind the screen, below: most agents never need it)
+            } else {
+                double iw = DQ_RSQRT(live ? wsq : 1.0);
+                DQ_KEEP(iw);
+                ciw[u].at(l) = iw;
+            }
         });
     }
     // ---- rows in LDS: the rows right behind the register cache, decoded like the cached ones, written once --------------------
@@ -1006,13 +1056,69 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 const bool has_b = in & !((m == 0) & (i < 3));              // traj_optimizer.cpp:260-262, 390-392
                 const bool has_v = in & (i < n) & !((m == 0) & (i < 2));    // :457-459
                 const bool has_a = in & (i < n - 1) & !((m == 0) & (i == 0));  // :471-473
-                blo_r[u].at(l) = has_b ? lo : -NEVER;
-                bhi_r[u].at(l) = has_b ? hi : NEVER;
-                hv_r[u].at(l) = has_v ? hv_lim : NEVER;
-                ha_r[u].at(l) = has_a ? ha_lim : NEVER;
+                // (the registers hold limit -/+ tolerance, what the pricing pass compares with: NEVER stays NEVER)
+                blo_r[u].at(l) = has_b ? lo - VIOL_TOL : -NEVER;
+                bhi_r[u].at(l) = has_b ? hi + VIOL_TOL : NEVER;
+                hv_r[u].at(l) = has_v ? hv_lim + VIOL_TOL : NEVER;
+                ha_r[u].at(l) = has_a ? ha_lim + VIOL_TOL : NEVER;
                 jtag[u].at(l) = (uint32_t)jc << 3;
             }
         });
+    }
+    // ---- SCREEN (the instantiation whose rows are all in registers): is any row violated at the unconstrained minimiser? --------
+    // Two agents of three of the synthetic swarms sit at their unconstrained optimum: for them the first pricing pass only has
+    // to say "none", and this says it without pivot scalings, row codes, the arg-max and everything the iterations set up before
+    // their first pass.  Every row's violation is the pricing pass's own expression, (limit - tolerance) - value, so a row that
+    // pass would pick (violation x scaling >= SCORE_MIN, scaling >= 0) is violated here as well: the screen lets through a
+    // superset, and an agent it lets through by a hair finds no row in its first pass and leaves with zero iterations like the others.
+    bool screened = false;
+    if (SCREEN) {
+        RegI sv;
+        w.each([&](int l) {
+            double xr[KU][3], c0[NXP], c1[NXP], c2[NXP];
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                const int p = cpo[u].at(l);
+                xr[u][0] = x[p]; xr[u][1] = x[P + p]; xr[u][2] = dim == 3 ? x[2 * P + p] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < NXP; u++) {
+                const int j = 64 * u + l;
+                const int j0 = j < nxc ? j : nxc - 1, j1 = j + 1 < nxc ? j + 1 : nxc - 1, j2 = j + 2 < nxc ? j + 2 : nxc - 1;
+                c0[u] = x[j0]; c1[u] = x[j1]; c2[u] = x[j2];
+            }
+#pragma unroll
+            for (int u = 0; u < KU; u++) { DQ_KEEP(xr[u][0]); DQ_KEEP(xr[u][1]); DQ_KEEP(xr[u][2]); }
+#pragma unroll
+            for (int u = 0; u < NXP; u++) { DQ_KEEP(c0[u]); DQ_KEEP(c1[u]); DQ_KEEP(c2[u]); }
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < KU; u++) {
+                double val = (double)cnx[u].at(l) * xr[u][0];
+                val = fma((double)cny[u].at(l), xr[u][1], val);
+                if (dim == 3) val = fma((double)cnz[u].at(l), xr[u][2], val);
+                any |= (cd[u].at(l) - VIOL_TOL) - val > 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < NXP; u++) {
+                const double dv = c1[u] - c0[u], da = (c2[u] - c1[u]) - dv;
+                const double hv = hv_r[u].at(l), ha = ha_r[u].at(l);
+                any |= (blo_r[u].at(l) - c0[u] > 0.0) | (c0[u] - bhi_r[u].at(l) > 0.0) | (-hv - dv > 0.0) | (dv - hv > 0.0) |
+                       (-ha - da > 0.0) | (da - ha > 0.0);
+            }
+            sv.at(l) = any ? 1 : 0;
+        });
+        screened = !w.any(sv);
+        if (!screened) {  // uniform: the pivot scalings of the cached rows, now that they are needed
+            w.each([&](int l) {
+#pragma unroll
+                for (int u = 0; u < KU; u++) {
+                    double iw = DQ_RSQRT(ciw[u].at(l));
+                    DQ_KEEP(iw);
+                    ciw[u].at(l) = iw;
+                }
+            });
+        }
     }
     w.stamp(1);  // slot cache, x0, bounds
     DQ_PHASE_EXIT(1);
@@ -1154,8 +1260,8 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             const int own = unit & 63, uo = unit >> 6, kind = cc >> 1, side = cc & 1;
             const int k = unit / P, m = (unit - k * P) / n1;
             double lim;  // what the register goes back to
-            if (kind == 0) lim = side ? bhi[k * M + m] : blo[k * M + m];
-            else lim = kind == 1 ? hv_lim : ha_lim;
+            if (kind == 0) lim = side ? bhi[k * M + m] + VIOL_TOL : blo[k * M + m] - VIOL_TOL;  // (limit -/+ tolerance, as the registers hold it)
+            else lim = (kind == 1 ? hv_lim : ha_lim) + VIOL_TOL;
             lim = w.uni(lim);
             const double off = (kind == 0 && side == 0) ? -NEVER : NEVER;
             const double nv = on ? off : lim;
@@ -1208,7 +1314,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     int cold_jb, cold_je;
     cold_rows_share(Kl, K, 0, w.nw, cold_jb, cold_je);  // (helper wavefronts: no rows in LDS, Kl = Kc)
 
-    for (;;) {
+    for (; !(SCREEN && screened);) {  // (a screened agent has nothing to do here: straight to the read-out)
         // ---- most violated inactive row ---------------------------------------------------------
         // Every candidate row: violation v = limit - value (or value - limit), pivot score (v - VIOL_TOL) / |N'a| tagged with
         // the row's code, running maximum.  Rows that are not in the model, or are active, have a limit that is never
@@ -1266,9 +1372,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 for (int u = 0; u < NXP; u++) {
                     const double dv = c1[u] - c0[u], da = (c2[u] - c1[u]) - dv;
                     const double wb = kiw[u][0].at(l), wv = kiw[u][1].at(l), wa = kiw[u][2].at(l);
-                    const double hv = hv_r[u].at(l) + VIOL_TOL, ha = ha_r[u].at(l) + VIOL_TOL;
-                    double sb = DQ_SCORE_MAX(tag_score(((blo_r[u].at(l) - VIOL_TOL) - c0[u]) * wb, 0u),
-                                     tag_score((c0[u] - (bhi_r[u].at(l) + VIOL_TOL)) * wb, 1u));
+                    const double hv = hv_r[u].at(l), ha = ha_r[u].at(l);  // (limit + tolerance: the registers hold that)
+                    double sb = DQ_SCORE_MAX(tag_score((blo_r[u].at(l) - c0[u]) * wb, 0u),
+                                     tag_score((c0[u] - bhi_r[u].at(l)) * wb, 1u));
                     sb = DQ_SCORE_MAX(sb, tag_score((-hv - dv) * wv, 2u));
                     sb = DQ_SCORE_MAX(sb, tag_score((dv - hv) * wv, 3u));
                     sb = DQ_SCORE_MAX(sb, tag_score((-ha - da) * wa, 4u));
