@@ -918,15 +918,27 @@ def main():
         def timed(self, steps, pipelined, orders, record_kernel_times=False):
             """orders: "kernel" = the plan kernel finds its launch order itself from the iteration counts of the three previous
             replanning steps (dlscqp_device_batch.hint_iters: the other batches of the rotation, never the batch's own -- no stream
-            operation between two launches); "device" = the same key sorted by dlscqp_launch_order_history_device after every
+            operation between two launches; round 5: from the class masks the previous step's launch left behind,
+            dlscqp_device_batch.hint_mask_*, "iters" = round 4's form, a load of the 64 keys of the block in front of every agent);
+            "device" = the same key sorted by dlscqp_launch_order_history_device after every
             step (round 3's method: two more kernels per group and step); "host" = permutations prepared before the loop;
             None = id order."""
             self.device_order = isinstance(orders, str) and orders == "device"
-            kernel_order = isinstance(orders, str) and orders == "kernel"
+            kernel_order = isinstance(orders, str) and orders == "kernel"   # class masks (round 5)
+            iters_order = isinstance(orders, str) and orders == "iters"     # the keys themselves (round 4's hint_iters)
+            if kernel_order and not hasattr(self, "masks"):
+                self.masks = [[db.new_hint_masks() for db in self.dbs[g]] for g in range(self.G)]
             for g in range(self.G):
                 for j, db in enumerate(self.dbs[g]):
-                    db.set_order(None if orders is None or self.device_order or kernel_order else self.hint[g][j])
-                    db.set_hint([self.dbs[g][(j - k) % B].out_iters for k in (1, 2, 3) if (j - k) % B != j] if kernel_order else None)
+                    db.set_order(None if orders is None or self.device_order or kernel_order or iters_order else self.hint[g][j])
+                    db.set_hint([self.dbs[g][(j - k) % B].out_iters for k in (1, 2, 3) if (j - k) % B != j] if iters_order else None)
+                    if kernel_order and B >= 3:
+                        # batch j is ordered by the masks batch j - 1 (the same agents one step earlier) left behind, writes its own,
+                        # and clears those of batch j + 1 (last read a rotation ago)
+                        self.masks[g][j].zero_()
+                        db.set_hint_masks(self.masks[g][(j - 1) % B], self.masks[g][j], self.masks[g][(j + 1) % B])
+                    else:
+                        db.set_hint_masks(None, None, None)
             self.step_args()
             self.counter = 0
             for _ in range(B):
@@ -1016,6 +1028,7 @@ def main():
     # the same loop without the launch-order hint, and (N > 1) with the other exchange mode
     side_steps = max(B, min(args.steps, 200))
     el_nohint = float("nan") if args.headline_only else loop.timed(side_steps, head_pipelined, None)
+    el_itershint = float("nan") if args.headline_only else loop.timed(side_steps, head_pipelined, "iters")
     el_hostorder = float("nan") if args.headline_only else loop.timed(side_steps, head_pipelined, "host")
     el_sorted = float("nan") if args.headline_only else loop.timed(side_steps, head_pipelined, "device")
     el_halo_only = None
@@ -1232,17 +1245,20 @@ def main():
                                             "headline mirrors that: every rank receives the whole table.  The S64 swarms have no neighbours "
                                             "outside themselves, so NO agent reads a remote plan: restricted to what a consumer needs the "
                                             "exchange moves nothing, and this is the step then",
-                "launch_order": "found by the plan kernel itself (dlscqp_device_batch.hint_iters): iteration counts of the three previous "
-                                "replanning steps (the other batches of the rotation, never the batch's own), maximum with decay 3/4 per "
-                                "step, in eight classes; slot s plans the (s / n_blocks)-th most expensive agent of the block of 64 agents "
-                                "s %% n_blocks -- no sort kernel, no stream operation between two launches; correlation of consecutive "
-                                "steps' counts %.2f" % hint_corr,
+                "launch_order": "found by the plan kernel itself from the class masks the previous replanning step's launch of the same agents "
+                                "left behind (dlscqp_device_batch.hint_mask_*: per block of 64 agents eight 64-bit masks, one per class of "
+                                "iteration counts -- this step's count or one class below the class the agent was scheduled with -- into "
+                                "which every agent ORs its bit when it finishes): slot s plans the (s / n_blocks)-th most expensive agent of "
+                                "the block s %% n_blocks -- 64 bytes of scalar loads and ~40 scalar instructions per agent, no sort kernel, no "
+                                "stream operation between two launches; correlation of consecutive steps' counts %.2f.  Round 4's form (every "
+                                "wavefront loads its block's 64 keys, hint_iters) is timed as ms_per_step_order_from_hint_iters" % hint_corr,
                 "ms_per_step_sorted_on_device": None if args.headline_only else el_sorted / side_steps * 1e3,
                 "sorted_on_device": "round 3's method: the same key sorted by dlscqp_launch_order_history_device after every step (two "
                                     "more kernels per group and step, inside the timed loop)",
                 "ms_per_step_host_order": None if args.headline_only else el_hostorder / side_steps * 1e3,
                 "host_order": "the same hint as permutations prepared on the host before the timed loop (round 1's method)",
                 "ms_per_step_no_order_hint": None if args.headline_only else el_nohint / side_steps * 1e3,
+                "ms_per_step_order_from_hint_iters": None if args.headline_only else el_itershint / side_steps * 1e3,
                 "qp_per_s_no_order_hint": None if args.headline_only else world * N * side_steps / el_nohint,
                 "solved_fraction": float(ok.mean()), "mean_active_set_iterations": float(it[:, 0].mean()),
                 "max_active_set_iterations": int(it[:, 0].max()), "zero_iteration_fraction": float((it[:, 0] == 0).mean()),

@@ -126,6 +126,9 @@ class DeviceBatch(C.Structure):
         ("reserved2_", C.c_int32),
         ("workspace", C.c_void_p),
         ("workspace_bytes", C.c_int64),
+        ("hint_mask_in", C.c_void_p),
+        ("hint_mask_out", C.c_void_p),
+        ("hint_mask_zero", C.c_void_p),
     ]
 
 
@@ -407,6 +410,9 @@ def load_library():
         lib.dlscqp_exchange_get_times.restype = C.c_int
         lib.dlscqp_step_device.argtypes = [P(StepArgs)]
         lib.dlscqp_step_device.restype = C.c_int
+    if hasattr(lib, "dlscqp_mask_order_preview_device"):
+        lib.dlscqp_mask_order_preview_device.argtypes = [vp, vp, C.c_int32, vp, vp]
+        lib.dlscqp_mask_order_preview_device.restype = C.c_int
     if hasattr(lib, "dlscqp_hint_order_preview_device"):
         lib.dlscqp_hint_order_preview_device.argtypes = [vp, vp, C.c_int32, C.c_int32, vp, vp]
         lib.dlscqp_hint_order_preview_device.restype = C.c_int
@@ -424,5 +430,5 @@ EXPORTED_SYMBOLS = [
     "dlscqp_hint_order_preview_device",
     "dlscqp_exchange_unique_id", "dlscqp_exchange_create", "dlscqp_exchange_destroy", "dlscqp_exchange_post", "dlscqp_exchange_post_records",
     "dlscqp_exchange_before_overwrite", "dlscqp_exchange_wait", "dlscqp_exchange_set_timing", "dlscqp_exchange_get_times",
-    "dlscqp_step_device", "dlscqp_neighbours_knn_device", "dlscqp_workspace_bytes",
+    "dlscqp_step_device", "dlscqp_neighbours_knn_device", "dlscqp_workspace_bytes", "dlscqp_mask_order_preview_device",
 ]

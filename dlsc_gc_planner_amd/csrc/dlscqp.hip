@@ -299,6 +299,9 @@ struct KernelArgs {
     size_t work_stride;
     double *spill;                   // spill records [launch slots][spill_stride doubles] (MemLayout::spill_doubles), or null: every column
     size_t spill_stride;             // record of the active rows fits the working set
+    const unsigned long long *mask_in;  // launch order from class masks (masked_agent): [n_blocks][8], written by the previous step's launch
+    unsigned long long *mask_out;       // ... this launch's own: every agent sets its bit in the mask of its class
+    unsigned long long *mask_zero;      // ... and a third table that this launch clears (for a later launch to write)
 };
 
 // dlscqp_device_batch.hint_iters: the launch order without a sort between two launches.  The agents in blocks of 64 consecutive
@@ -333,6 +336,55 @@ __device__ __forceinline__ int hinted_agent(const KernelArgs &a, int slot, int l
         left -= pick < 0 ? cnt : 0;
     }
     return pick < 0 ? -1 : blk * 64 + pick;
+}
+
+// dlscqp_device_batch.hint_mask_in: the same order -- blocks of 64 agents, slot s plans the (s / n_blocks)-th most expensive agent
+// of block s % n_blocks -- from a table the PREVIOUS step's launch left behind: per block eight 64-bit masks, one per class of
+// iteration counts, in which every agent set its own bit when it finished (one atomic OR without a return value, nothing waits
+// for it).  The wavefront reads its block's 64 bytes with scalar loads and walks the classes with population counts: no vector
+// load of 64 keys in front of the agent's record (that dependent trip cost every agent ~1.3 us), ~40 scalar instructions.
+// The masks must partition the block's agents; if they do not (the first step: all zero) the block is planned in id order.
+// cls_in: the class the agent was scheduled with (its own history: the class it reports decays by one per step).
+__device__ __forceinline__ int masked_agent(const KernelArgs &a, int slot, int lane, int &cls_in) {
+    const int nb = a.n_blocks;
+    const int rank = a.blocks_magic ? (int)__umulhi((unsigned int)slot, a.blocks_magic) : slot / nb;
+    const int blk = slot - rank * nb;
+    const unsigned long long *m = a.mask_in + (size_t)blk * 8;
+    unsigned long long mk[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) mk[c] = __builtin_nontemporal_load(m + c);
+    const int nvalid = a.n_agents - 64 * blk >= 64 ? 64 : a.n_agents - 64 * blk;
+    const unsigned long long vmask = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull);
+    unsigned long long all = 0ull;
+    int tot = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        mk[c] = ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(mk[c] >> 32)) << 32) |
+                (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)mk[c]);  // (every lane read the same words)
+        all |= mk[c];
+        tot += __popcll(mk[c]);
+    }
+    cls_in = 0;
+    if (all != vmask || tot != nvalid) return rank < nvalid ? 64 * blk + rank : -1;  // not a partition of the block: id order
+    int left = rank, pick = -1;
+#pragma unroll
+    for (int c = 7; c >= 0; c--) {
+        const int cnt = __popcll(mk[c]);
+        if (pick < 0 && left < cnt) {
+            const unsigned long long mm = mk[c];
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)mm, 0u));
+            const unsigned long long hit = __ballot(((mm >> lane) & 1ull) != 0ull && below == left);  // exactly one lane
+            pick = __builtin_ctzll(hit);
+            cls_in = c;
+        }
+        left -= pick < 0 ? cnt : 0;
+    }
+    return pick < 0 ? -1 : blk * 64 + pick;
+}
+// the class of an iteration count: 0 | 1 | 2-3 | 4-7 | ... | 64 and more
+__device__ __forceinline__ int iteration_class(int it) {
+    const int c = it <= 0 ? 0 : 32 - __clz(it);
+    return c > 7 ? 7 : c;
 }
 
 // Two wavefronts per SIMD (256 VGPRs each) where eight agents fit the LDS of a CU; where the working set allows two or three
@@ -377,7 +429,9 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
     else smem = lds;
     WaveGpu w;
     w.lane = (int)threadIdx.x & 63;
-    const int ag = a.order ? a.order[slot] : (a.hint[0] ? hinted_agent(a, slot, w.lane) : slot);
+    int cls_in = 0;
+    const int ag = a.order ? a.order[slot] : (a.mask_in ? masked_agent(a, slot, w.lane, cls_in) : (a.hint[0] ? hinted_agent(a, slot, w.lane) : slot));
+    if (a.mask_zero && slot < a.n_blocks && threadIdx.x < 8) a.mask_zero[(size_t)slot * 8 + threadIdx.x] = 0ull;  // (slot < n_blocks: block `slot`'s first wavefront)
     if (ag < 0 || ag >= a.n_agents) return;  // the whole workgroup
     // the agent's rows: [rb, rb + nrows_ag)
     const int rb = a.row_pitch > 0 ? ag * a.row_pitch : a.row_offsets[ag];
@@ -438,6 +492,7 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
 #endif
     const int M = kp.M, n1 = kp.n1;
     const size_t xs = (size_t)kp.dim * M * n1 + (size_t)M * a.max_slack_obs;
+    int iters_done = 0;
     plan_agent<RC, DIMS, FS, MS, KU, SU, SLK, WaveGpu>(w, kp, lay, smem, a.spill ? a.spill + (size_t)slot * a.spill_stride : nullptr,
                a.agents + ag, a.rows, rb, nrows_ag,
                a.sfc ? a.sfc + (size_t)ag * M * 6 : nullptr, a.max_slack_obs, a.do_goal, a.do_traj,
@@ -447,7 +502,15 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
                a.out_x ? a.out_x + ag * xs : nullptr, a.out_cost ? a.out_cost + ag : nullptr,
                a.out_slack_cost ? a.out_slack_cost + (size_t)ag * a.max_slack_obs : nullptr,
                a.out_status ? a.out_status + (size_t)ag * a.status_stride : nullptr,
-               a.out_iters ? a.out_iters + (size_t)ag * 4 : nullptr);
+               a.out_iters ? a.out_iters + (size_t)ag * 4 : nullptr, &iters_done);
+    if (a.mask_out) {
+        // the agent's bit into the mask of its class, for the next step's launch order (masked_agent): the class of this step's
+        // iteration count, or one below the class it was scheduled with if that is higher (an agent that was expensive a step or
+        // two ago is still likely to be); no return value, nothing waits
+        const int c_now = iteration_class(iters_done);
+        const int cls = c_now > cls_in - 1 ? c_now : cls_in - 1;
+        if (threadIdx.x == 0) __hip_atomic_fetch_or(a.mask_out + (size_t)(ag >> 6) * 8 + cls, 1ull << (ag & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     if constexpr (WPA > 1) {  // release the helpers: the solve is over
         w.mail[0] = 1.0;
         __syncthreads();
@@ -1242,6 +1305,21 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         if (a.n_blocks > 1 && (unsigned long long)a.n_slots_launch * (unsigned long long)a.n_blocks < (1ull << 32))
             a.blocks_magic = (unsigned int)(((1ull << 32) + (unsigned long long)a.n_blocks - 1) / (unsigned long long)a.n_blocks);
     }
+    // ... or from the class masks the previous step's launch left behind (dlscqp_device_batch.hint_mask_in): the same slots
+    a.mask_in = nullptr; a.mask_out = nullptr; a.mask_zero = nullptr;
+    if (b->hint_mask_in || b->hint_mask_out || b->hint_mask_zero) {
+        if (b->launch_count > 0) { g_last_error = "hint_mask_* cannot be combined with launch_offset / launch_count"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+        if ((b->hint_mask_out && (b->hint_mask_out == b->hint_mask_in || b->hint_mask_out == b->hint_mask_zero)) ||
+            (b->hint_mask_in && b->hint_mask_in == b->hint_mask_zero)) { g_last_error = "hint_mask_in / _out / _zero must be three different tables"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+        a.mask_out = reinterpret_cast<unsigned long long *>(b->hint_mask_out);
+        a.mask_zero = reinterpret_cast<unsigned long long *>(b->hint_mask_zero);
+        if (b->hint_mask_in && !b->agent_order && !a.hint[0]) {
+            a.mask_in = reinterpret_cast<const unsigned long long *>(b->hint_mask_in);
+            a.n_slots_launch = 64 * a.n_blocks;
+            if (a.n_blocks > 1 && (unsigned long long)a.n_slots_launch * (unsigned long long)a.n_blocks < (1ull << 32))
+                a.blocks_magic = (unsigned int)(((1ull << 32) + (unsigned long long)a.n_blocks - 1) / (unsigned long long)a.n_blocks);
+        }
+    }
     a.ctrl_stride = c->M * (c->n + 1) * 3; a.goal_stride = 3; a.status_stride = 1;
     if (b->out_record_stride > 0) {
         if (b->out_record_stride < c->M * (c->n + 1) * 3) { g_last_error = "out_record_stride is smaller than a plan"; return DLSCQP_ERR_INVALID_ARGUMENT; }
@@ -1304,7 +1382,7 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
         c->max_dyn_lds[attr_slot] = lay.bytes;
     }
-    if (a.slot0 < 0 || a.slot0 + a.n_slots_launch > 64 * a.n_blocks || (!a.hint[0] && a.slot0 + a.n_slots_launch > b->n_agents)) {
+    if (a.slot0 < 0 || a.slot0 + a.n_slots_launch > 64 * a.n_blocks || (!a.hint[0] && !a.mask_in && a.slot0 + a.n_slots_launch > b->n_agents)) {
         g_last_error = "launch slots out of range";
         return DLSCQP_ERR_INVALID_ARGUMENT;
     }
@@ -1856,6 +1934,33 @@ __global__ __launch_bounds__(64) void dlscqp_hint_preview_kernel(KernelArgs a, i
     if (threadIdx.x == 0) order_out[slot] = ag;
 }
 }  // namespace
+
+namespace {
+__global__ __launch_bounds__(64) void dlscqp_mask_preview_kernel(KernelArgs a, int32_t *order_out) {
+    const int slot = (int)blockIdx.x;
+    int cls_in;
+    const int ag = masked_agent(a, slot, (int)threadIdx.x, cls_in);
+    if (threadIdx.x == 0) order_out[slot] = ag;
+}
+}  // namespace
+
+extern "C" int dlscqp_mask_order_preview_device(dlscqp_ctx *c, const uint64_t *masks, int32_t n_agents, int32_t *order_out, void *stream) {
+    g_last_error.clear();
+    if (!c || !masks || n_agents < 0 || (n_agents > 0 && !order_out)) { g_last_error = "invalid argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (n_agents == 0) return DLSCQP_SUCCESS;
+    HIP_TRY(hipSetDevice(c->cfg.device));
+    KernelArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.n_agents = n_agents;
+    a.mask_in = reinterpret_cast<const unsigned long long *>(masks);
+    a.n_blocks = (n_agents + 63) / 64;
+    const int slots = 64 * a.n_blocks;
+    if (a.n_blocks > 1 && (unsigned long long)slots * (unsigned long long)a.n_blocks < (1ull << 32))
+        a.blocks_magic = (unsigned int)(((1ull << 32) + (unsigned long long)a.n_blocks - 1) / (unsigned long long)a.n_blocks);
+    hipLaunchKernelGGL(dlscqp_mask_preview_kernel, dim3(slots), dim3(64), 0, (hipStream_t)stream, a, order_out);
+    HIP_TRY(hipGetLastError());
+    return DLSCQP_SUCCESS;
+}
 
 extern "C" int dlscqp_hint_order_preview_device(dlscqp_ctx *c, const int32_t *const *iters, int32_t n_steps, int32_t n_agents, int32_t *order_out,
                                                 void *stream) {

@@ -394,7 +394,8 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                       const dlscqp_agent *agp, const RowsView &rows, int row_begin, int K_rows,
                       const float *sfc, int max_slack_obs, int do_goal, int do_traj,
                       float *out_goal, int *out_goal_status, float *out_ctrl, double *out_x,
-                      double *out_cost, double *out_slack_cost, int *out_status, int *out_iters) {
+                      double *out_cost, double *out_slack_cost, int *out_status, int *out_iters, int *iters_done = nullptr) {
+    // iters_done (optional, the caller's own variable -- not device memory): the number of iterations of this solve
     static_assert(RC == 1 || RC == 2, "r <= 128");
     typedef typename W::template Reg<double> RegD;
     typedef typename W::template Reg<float> RegF;
@@ -755,6 +756,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     // allowed only where nothing is live after it (see "NO DIVERGENCE").
     auto exit_stores = [&](int st_traj, bool have_traj, int it0, int it1, int it2, int it3, bool have_cost, double fval) {
         DQ_MARK("DQ_EXIT_STORES");
+        if (iters_done) *iters_done = it0;
         w.each([&](int l) {
             if (do_goal) {
                 if (l < 3 && out_goal && goal_status != DLSCQP_INFEASIBLE && goal_status != DLSCQP_NUMERICAL) out_goal[l] = pick3(goal, l);

@@ -306,6 +306,29 @@ class DeviceBatch:
         self.c.hint_steps = len(iters)
         self._keep_hint = iters
 
+    def new_hint_masks(self):
+        """A zeroed table of class masks for this batch's agents (dlscqp_device_batch.hint_mask_*): [ceil(n / 64), 8] int64."""
+        return self.torch.zeros(((self.n_agents + 63) // 64, 8), dtype=self.torch.int64, device=self.device)
+
+    def set_hint_masks(self, mask_in=None, mask_out=None, mask_zero=None):
+        """Launch order from class masks (dlscqp_device_batch.hint_mask_in / _out / _zero): `mask_in` = the table the previous step's
+        launch of the same agents wrote (None: id order), `mask_out` = the table this launch writes (all zero when it starts),
+        `mask_zero` = a table this launch clears for a later launch to write.  Tables from new_hint_masks(); three in rotation."""
+        for name, t in (("hint_mask_in", mask_in), ("hint_mask_out", mask_out), ("hint_mask_zero", mask_zero)):
+            assert t is None or (t.dtype == self.torch.int64 and t.numel() == 8 * ((self.n_agents + 63) // 64) and t.is_contiguous())
+            setattr(self.c, name, None if t is None else t.data_ptr())
+        self._keep_masks = (mask_in, mask_out, mask_zero)
+
+    def rotate_hint_masks(self):
+        """Closed loops (one batch, launched step after step): call before every launch.  Three tables rotate: the one the previous
+        launch wrote orders this launch, this launch writes the one the launch before last cleared, and clears the third."""
+        if not hasattr(self, "_mask_ring"):
+            self._mask_ring = [self.new_hint_masks() for _ in range(3)]
+            self._mask_step = 0
+        r, k = self._mask_ring, self._mask_step
+        self.set_hint_masks(r[(k - 1) % 3] if k > 0 else None, r[k % 3], r[(k + 1) % 3])
+        self._mask_step = k + 1
+
     def rotate_hint(self, depth=2):
         """Closed loops (one batch, launched step after step): call before every launch.  The iteration counts rotate through
         depth + 1 buffers, the launch writes one of them and takes its order from the `depth` previous steps' -- a launch must

@@ -239,6 +239,20 @@ typedef struct dlscqp_device_batch {
                                        overlap them) and which cannot grow inside a stream capture.  Launches small enough to give
                                        every agent the LDS for all its records need neither.  Contents are scratch.              */
     int64_t workspace_bytes;
+    const uint64_t *hint_mask_in;   /* LAUNCH ORDER FROM CLASS MASKS (preferred over hint_iters: no load of 64 keys in front of every agent's
+                                       record).  Three tables of [ceil(n_agents / 64)][8] 64-bit words.  A launch with hint_mask_out
+                                       leaves, per block of 64 consecutive agents, eight masks -- one per class of iteration counts
+                                       (0, 1, 2-3, 4-7, ... 64+; an agent's class is that of this step's count or one below the class
+                                       it was scheduled with, whichever is higher) -- in which every planned agent has set its bit.
+                                       The NEXT step's launch of the same agents names that table as hint_mask_in: launch slot s then
+                                       plans the (s / n_blocks)-th most expensive agent of block s % n_blocks, as with hint_iters.  A
+                                       table that is not a partition of its block's agents (all zero: the first step) gives id order.
+                                       hint_mask_zero: a table this launch clears -- hint_mask_out must be all zero when its launch
+                                       starts, so name here the table a LATER launch will write (three tables in rotation: in = what
+                                       the previous launch wrote, out, zero = the next launch's out).  Used when agent_order is NULL
+                                       and hint_steps is 0; not with launch_offset / launch_count.  Results do not depend on it.   */
+    uint64_t *hint_mask_out;
+    uint64_t *hint_mask_zero;
 } dlscqp_device_batch;
 
 /* key layout: bits 0-7 m, 8-11 i, 12 dynamic flag, 16-31 slack index (0xFFFF = none). */
@@ -267,6 +281,8 @@ int dlscqp_launch_order_history_device(dlscqp_ctx *ctx, const int32_t *const *it
 /* The launch order a dlscqp_device_batch with these hint_iters gets, written out (tests, diagnostics): order_out[s] = the agent
  * launch slot s plans, s < 64 * ceil(n_agents / 64), or -1 for a slot beyond its block's agents.  Same device function as the
  * plan kernel's.  iters: 1..3 device arrays [n_agents][4], newest first; order_out: device array. */
+/* the same for hint_mask_in: masks [ceil(n_agents / 64)][8] */
+int dlscqp_mask_order_preview_device(dlscqp_ctx *ctx, const uint64_t *masks, int32_t n_agents, int32_t *order_out, void *stream);
 int dlscqp_hint_order_preview_device(dlscqp_ctx *ctx, const int32_t *const *iters, int32_t n_steps, int32_t n_agents, int32_t *order_out,
                                      void *stream);
 

@@ -147,3 +147,90 @@ def test_a_launch_in_the_kernels_own_order_computes_the_same(gpu_required, n_swa
         db.launch(offset=0, count=len(wl["agents"]) // 2)
     finally:
         opt.close()
+
+
+def _classes(it):
+    it = np.asarray(it)
+    return np.where(it <= 0, 0, np.minimum(7, np.floor(np.log2(np.maximum(it, 1))).astype(np.int64) + 1))
+
+
+def _mask_order(masks, n):
+    """numpy restatement of masked_agent (csrc/dlscqp.hip): slot s = rank * n_blocks + block"""
+    nb = (n + 63) // 64
+    out = np.full(64 * nb, -1, np.int64)
+    for b in range(nb):
+        nvalid = min(64, n - 64 * b)
+        bits = [[(int(masks[b, c]) >> l) & 1 for l in range(64)] for c in range(8)]
+        tot = np.sum(bits, axis=0)
+        ok = all(tot[l] == (1 if l < nvalid else 0) for l in range(64))
+        lanes = [l for c in range(7, -1, -1) for l in range(64) if bits[c][l]] if ok else list(range(nvalid))
+        for r, l in enumerate(lanes):
+            out[r * nb + b] = 64 * b + l
+    return out
+
+
+@pytest.mark.parametrize("n_swarms,swarm_size", [(1, 64), (3, 50), (40, 64)])  # 150 agents: a ragged last block
+def test_class_masks_order_the_next_launch(gpu_required, n_swarms, swarm_size):
+    """dlscqp_device_batch.hint_mask_*: the masks a launch leaves behind hold every agent's bit in the class of its iteration count;
+    the next launch's order from them equals the numpy restatement, plans every agent exactly once and computes the same bits as
+    the launch in id order; a table that is no partition of a block (all zero) gives id order; the class decays by one per step."""
+    import ctypes as C
+    cfg = workloads.s64_config()
+    opt = BatchTrajOptimizer(cfg)
+    try:
+        wl = workloads.generate(cfg, lambda a, ro, r, s: opt.plan(a, ro, r, s, 0, True, True), n_swarms=n_swarms, swarm_size=swarm_size, seed=78)
+        db = opt.make_device_batch(wl["agents"], wl["row_offsets"], wl["rows"], None, 0, want_iters=True)
+        n = db.n_agents
+        db.launch()
+        first = db.results()
+        m = [db.new_hint_masks() for _ in range(3)]
+        m[2].fill_(-1)  # the table the launch is told to clear
+        db.set_hint_masks(None, m[0], m[2])
+        db.launch()
+        torch.cuda.synchronize()
+        assert int(m[2].abs().sum()) == 0
+        masks = m[0].cpu().numpy().view(np.uint64)
+        cls = _classes(first["iters"][:, 0])
+        want = np.zeros_like(masks)
+        for a in range(n):
+            want[a // 64, cls[a]] |= np.uint64(1) << np.uint64(a % 64)
+        assert np.array_equal(masks, want)
+        # the order the next launch takes from them
+        order = torch.full((64 * ((n + 63) // 64),), -7, dtype=torch.int32, device="cuda")
+        rc = opt.lib.dlscqp_mask_order_preview_device(opt.handle, C.c_void_p(m[0].data_ptr()), n, C.c_void_p(order.data_ptr()), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        got = order.cpu().numpy()
+        assert np.array_equal(got, _mask_order(masks, n))
+        assert np.array_equal(np.sort(got[got >= 0]), np.arange(n))
+        # ... plans the same bits, and leaves masks of its own: this step's class or one below the class it was scheduled with
+        db.set_hint_masks(m[0], m[1], m[2])
+        db.launch()
+        second = db.results()
+        for k in ("status", "goal", "ctrl", "cost", "iters"):
+            assert np.array_equal(first[k], second[k]), k
+        masks2 = m[1].cpu().numpy().view(np.uint64)
+        assert np.array_equal(masks2, want)  # (the same counts again: max(class, class - 1) = class)
+        # a table that is not a partition (all zero) = id order
+        z = db.new_hint_masks()
+        rc = opt.lib.dlscqp_mask_order_preview_device(opt.handle, C.c_void_p(z.data_ptr()), n, C.c_void_p(order.data_ptr()), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(order.cpu().numpy(), _mask_order(z.cpu().numpy().view(np.uint64), n))
+        # decay: an agent scheduled from class c that needs no iteration now reports class c - 1
+        hi = db.new_hint_masks()
+        hv = np.zeros((hi.shape[0], 8), np.uint64)
+        for a in range(n):
+            hv[a // 64, 5] |= np.uint64(1) << np.uint64(a % 64)  # everybody in class 5
+        hi.copy_(torch.from_numpy(hv.view(np.int64)).cuda())
+        out = db.new_hint_masks()
+        db.set_hint_masks(hi, out, None)
+        db.launch()
+        torch.cuda.synchronize()
+        o = out.cpu().numpy().view(np.uint64)
+        want3 = np.zeros_like(o)
+        for a in range(n):
+            want3[a // 64, max(cls[a], 4)] |= np.uint64(1) << np.uint64(a % 64)
+        assert np.array_equal(o, want3)
+    finally:
+        opt.close()

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--seed", type=int, default=2000)
     ap.add_argument("--no-hard", action="store_true")
+    ap.add_argument("--order", default="masks", help="masks (hint_mask_*: round 5), iters (hint_iters: round 4), none; comma-separated: one line each")
     args = ap.parse_args()
     import numpy as np
     import torch
@@ -38,6 +39,7 @@ def main():
     wl, ref = None, None
     streams = None
     for rep in range(args.reps):
+      for order in args.order.split(","):
         for lib in libs:
             abi._LIB = None
             os.environ["DLSCQP_LIB"] = os.path.abspath(lib)
@@ -83,9 +85,13 @@ def main():
                     for g in range(G):
                         dbs[g][i % B].launch(True, True, stream=streams[g])
                 torch.cuda.synchronize(dev)
+                masks = [[db.new_hint_masks() for db in dbs[g]] for g in range(G)] if order == "masks" and hasattr(opt.lib, "dlscqp_mask_order_preview_device") else None
                 for g in range(G):
                     for j, db in enumerate(dbs[g]):
-                        db.set_hint([dbs[g][(j - k) % B].out_iters for k in (1, 2, 3) if (j - k) % B != j])
+                        if order == "iters" or (order == "masks" and masks is None):
+                            db.set_hint([dbs[g][(j - k) % B].out_iters for k in (1, 2, 3) if (j - k) % B != j])
+                        elif order == "masks":
+                            db.set_hint_masks(masks[g][(j - 1) % B], masks[g][j], masks[g][(j + 1) % B])
 
                 def step(c):
                     for g in range(G):
@@ -132,8 +138,8 @@ def main():
                 hit = hdb.results()["iters"]
                 hard = " | hard %.4f ms (%.1f M), iters %.2f active %.2f" % (hms, N / hms / 1e3, hit[:, 0].mean(), hit[:, 3].mean())
                 del hdb
-            print("%-34s groups %.4f ms (%.1f M QP/s) | one launch %.4f ms (%.1f M)%s | iters mean %.2f max %d zero %.2f | %s" %
-                  (os.path.basename(lib), out[4], N / out[4] / 1e3, out[1], N / out[1] / 1e3, hard, it.mean(), it.max(), (it == 0).mean(), same), flush=True)
+            print("%-5s %-28s groups %.4f ms (%.1f M QP/s) | one launch %.4f ms (%.1f M)%s | iters mean %.2f max %d zero %.2f | %s" %
+                  (order, os.path.basename(lib), out[4], N / out[4] / 1e3, out[1], N / out[1] / 1e3, hard, it.mean(), it.max(), (it == 0).mean(), same), flush=True)
             opt.close()
 
 
