@@ -542,7 +542,7 @@ class StressStep:
         gen, db, _, sel = part
         gen.generate(self.goals, plans=self.plans)
         if self.order_hint:
-            db.rotate_hint(2)  # launch order from the two previous steps' iteration counts, found by the plan kernel itself
+            db.rotate_hint_masks()  # launch order from the class masks of the previous step's launch, found by the plan kernel itself
         db.launch(True, True)
         self.own_ctrl.index_copy_(0, sel, db.out_ctrl.view(len(sel), -1))
         self.own_goal.index_copy_(0, sel, db.out_goal)
@@ -1177,7 +1177,12 @@ def main():
                     for tag in ("id_order", "hinted"):
                         if tag == "hinted":
                             for g in range(Gh):
-                                hdbs[g].set_hint([prev_t[g * ph:(g + 1) * ph]])
+                                # the class masks a launch of the same agents one step earlier would have left (hint_mask_in)
+                                pc = prev_t[g * ph:(g + 1) * ph, 0].cpu().numpy().astype(np.int64)
+                                cl = np.where(pc <= 0, 0, np.minimum(7, np.floor(np.log2(np.maximum(pc, 1))).astype(np.int64) + 1))
+                                mk = np.zeros(((ph + 63) // 64, 8), np.uint64)
+                                np.bitwise_or.at(mk, (np.arange(ph) // 64, cl), np.uint64(1) << (np.arange(ph) % 64).astype(np.uint64))
+                                hdbs[g].set_hint_masks(torch.from_numpy(mk.view(np.int64)).to(dev), None, None)
                         torch.cuda.synchronize(dev)
                         for rep_ in range(105):
                             if rep_ == 5:

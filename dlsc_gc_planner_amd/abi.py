@@ -402,6 +402,9 @@ def load_library():
         lib.dlscqp_exchange_post_records.restype = C.c_int
         lib.dlscqp_exchange_before_overwrite.argtypes = [vp, vp]
         lib.dlscqp_exchange_before_overwrite.restype = C.c_int
+        if hasattr(lib, "dlscqp_exchange_wait_packed"):
+            lib.dlscqp_exchange_wait_packed.argtypes = [vp, vp]
+            lib.dlscqp_exchange_wait_packed.restype = C.c_int
         lib.dlscqp_exchange_wait.argtypes = [vp, vp, P(vp)]
         lib.dlscqp_exchange_wait.restype = C.c_int
         lib.dlscqp_exchange_set_timing.argtypes = [vp, C.c_int32]
@@ -430,5 +433,5 @@ EXPORTED_SYMBOLS = [
     "dlscqp_hint_order_preview_device",
     "dlscqp_exchange_unique_id", "dlscqp_exchange_create", "dlscqp_exchange_destroy", "dlscqp_exchange_post", "dlscqp_exchange_post_records",
     "dlscqp_exchange_before_overwrite", "dlscqp_exchange_wait", "dlscqp_exchange_set_timing", "dlscqp_exchange_get_times",
-    "dlscqp_step_device", "dlscqp_neighbours_knn_device", "dlscqp_workspace_bytes", "dlscqp_mask_order_preview_device",
+    "dlscqp_step_device", "dlscqp_neighbours_knn_device", "dlscqp_workspace_bytes", "dlscqp_mask_order_preview_device", "dlscqp_exchange_wait_packed",
 ]

@@ -2675,6 +2675,14 @@ extern "C" int dlscqp_exchange_before_overwrite(dlscqp_exchange *x, void *stream
     return DLSCQP_SUCCESS;
 }
 
+// `stream` waits until the communication stream has read the arrays of the post just made (a caller that rewrites them right away)
+extern "C" int dlscqp_exchange_wait_packed(dlscqp_exchange *x, void *stream) {
+    g_last_error.clear();
+    if (!x || x->last < 0) { g_last_error = "no exchange has been posted"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, x->packed[x->last], 0));
+    return DLSCQP_SUCCESS;
+}
+
 static int exchange_post(dlscqp_exchange *x, const float *ctrl, const float *goal, const int32_t *status, const float *records, void *ready_stream);
 
 extern "C" int dlscqp_exchange_post(dlscqp_exchange *x, const float *ctrl, const float *goal, const int32_t *status, void *ready_stream) {

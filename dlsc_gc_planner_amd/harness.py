@@ -428,9 +428,9 @@ class ClosedLoop:
             self.records_in.copy_(self.batch.t["agents"])
         self._stage("traj_optimization_time")
         if self.order_hint:
-            # launch order found by the kernel itself from the iteration counts of the two previous steps (dlscqp_device_batch.
-            # hint_iters): the counts rotate through three buffers, so that the one a launch writes is never one it reads
-            self.batch.rotate_hint(2)
+            # launch order found by the kernel itself from the class masks the previous step's launch left behind
+            # (dlscqp_device_batch.hint_mask_*): three tables in rotation
+            self.batch.rotate_hint_masks()
         self.batch.launch(True, True)
         self._stage("state_update_time")
         # fail-safe: keep the shifted previous plan (traj_planner.cpp:776); sub-goal from the LP (traj_planner.cpp:494);

@@ -8,6 +8,8 @@ kernel launch, and ONE collective (torch.distributed all_gather_into_tensor = RC
 xGMI on GPUs, gloo in the CPU tests) rebuilds the full table of solved control points on every
 rank.  No other communication exists on the path.
 """
+import os
+import time
 
 
 def shard_range(n_agents, rank, world):
@@ -278,8 +280,9 @@ class NativeExchange:
 
     def post(self, ctrl, goal, status, pack_on_comm=True, stream=None):
         """ctrl [n_local, ...] float32, goal [n_local, 3] float32, status [n_local(, 1)] int32, contiguous CUDA tensors, complete on
-        `stream` (default: the current one).  The packing always runs on the communication stream (pack_on_comm is accepted for
-        PlanExchange's callers): keep the tensors untouched until before_overwrite() ahead of the launch after next."""
+        `stream` (default: the current one).  The packing runs on the communication stream.  pack_on_comm=True: keep the tensors
+        untouched until before_overwrite() ahead of the launch after next; False (PlanExchange's default, what a caller that
+        rewrites the tensors right away needs): `stream` waits until the communication stream has read them."""
         torch = self.torch
         assert ctrl.is_contiguous() and goal.is_contiguous() and status.is_contiguous()
         assert ctrl.dtype == torch.float32 and goal.dtype == torch.float32 and status.dtype == torch.int32
@@ -287,6 +290,10 @@ class NativeExchange:
         self._keep = (ctrl, goal, status)
         self._check(self.lib.dlscqp_exchange_post(self.handle, ctrl.data_ptr(), goal.data_ptr(), status.data_ptr(), self._stream(stream)),
                     "dlscqp_exchange_post")
+        if not pack_on_comm:
+            # the caller goes on to overwrite the three tensors on its stream (PlanExchange packed on that stream): it waits until
+            # the communication stream has read them
+            self._check(self.lib.dlscqp_exchange_wait_packed(self.handle, self._stream(stream)), "dlscqp_exchange_wait_packed")
         self.last = self.k & 1
         self.k += 1
 
@@ -353,11 +360,15 @@ def make_exchange(opt, dist, rank, world, n_local, device):
     The native exchange is CHECKED before it is handed out: every rank posts a table filled with its rank number and looks for
     every rank's number in the gathered one; the ranks agree on the outcome (one all-reduce), and if any of them could not build or
     verify its exchange all of them fall back to torch.distributed -- a multi-GPU run must not depend on a path that no one-GPU
-    box can exercise with more than one rank.  `exchange.issued_by` says which one it is."""
+    box can exercise with more than one rank.  `exchange.issued_by` says which one it is.
+    The library's communicator is its own, beside torch.distributed's: while an exchange is in flight no torch.distributed collective
+    may be issued on another stream in an order that differs between the ranks (bench.py and harness.ShardedLoop issue none inside
+    their timed loops).  DLSCQP_NATIVE_EXCHANGE=0 keeps torch.distributed; DLSCQP_EXCHANGE_WATCHDOG_S bounds the attempt (90 s)."""
     import sys
     backend = None if dist is None else dist.get_backend()
     E = opt.cfg.M * (opt.cfg.n + 1) * 3
-    if device.type == "cuda" and backend in (None, "nccl"):
+    native = os.environ.get("DLSCQP_NATIVE_EXCHANGE", "1") != "0"  # (0: torch.distributed, whatever the backend)
+    if device.type == "cuda" and backend in (None, "nccl") and (native or dist is None):
         import torch
         x, ok, why = None, 1, ""
         if dist is not None and world > 1:
@@ -376,18 +387,52 @@ def make_exchange(opt, dist, rank, world, n_local, device):
                 x = PlanExchange(dist, world, n_local, (E, 3, 1), device)
                 x.issued_by = "torch.distributed"
                 return x
-        try:
-            uid = exchange_unique_id(opt.lib, dist, rank) if world > 1 else None
-            x = NativeExchange(opt, rank, world, n_local, uid)
-            probe = torch.full((n_local, E + 4), float(rank + 1), dtype=torch.float32, device=device)
-            x.post_records(probe)
-            got = x.table()[:, 0].clone()
-            torch.cuda.synchronize(device)
-            want = (torch.arange(world, device=device, dtype=torch.float32) + 1.0).repeat_interleave(n_local)
-            if not torch.equal(got, want):
-                ok, why = 0, "the gathered table does not hold every rank's block"
-        except Exception as e:  # noqa: BLE001 -- whatever went wrong, the run goes on over torch.distributed
-            ok, why = 0, str(e)
+        # Building the communicator (ncclCommInitRank) and the first collective run under a WATCHDOG: a rank that gets stuck inside
+        # RCCL (its peers then wait in the same call) must cost the run a minute, not the run -- after `budget` seconds the attempt
+        # counts as failed on this rank, the ranks agree below, and the stuck call is left behind on its helper thread.
+        import threading
+        box = {}
+
+        def attempt():
+            try:
+                uid = exchange_unique_id(opt.lib, dist, rank) if world > 1 else None
+                try:
+                    xx = NativeExchange(opt, rank, world, n_local, uid)
+                except Exception:  # noqa: BLE001
+                    if dist is not None or world > 1:
+                        raise
+                    xx = NativeExchange(opt, rank, world, n_local, None, local_only=True)  # one rank, no librccl: a device copy
+                box["x"] = xx
+                probe = torch.full((n_local, E + 4), float(rank + 1), dtype=torch.float32, device=device)
+                xx.post_records(probe)
+                got = xx.table()[:, 0].clone()
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream(device))
+                box["event"] = (done, got, probe)
+            except Exception as e:  # noqa: BLE001 -- whatever went wrong, the run goes on over torch.distributed
+                box["error"] = str(e)
+
+        budget = float(os.environ.get("DLSCQP_EXCHANGE_WATCHDOG_S", "90"))
+        th = threading.Thread(target=attempt, daemon=True)
+        with torch.cuda.device(device):
+            th.start()
+            th.join(budget)
+        if th.is_alive():
+            ok, why = 0, "no answer from RCCL within %.0f s (ncclCommInitRank / first ncclAllGather)" % budget
+        elif "error" in box:
+            ok, why = 0, box["error"]
+        else:
+            x = box["x"]
+            done, got, _probe = box["event"]
+            t_end = time.time() + budget
+            while not done.query() and time.time() < t_end:  # (never a blocking wait on a collective that may not come back)
+                time.sleep(0.002)
+            if not done.query():
+                ok, why, x = 0, "the first ncclAllGather did not complete within %.0f s" % budget, None  # (left behind, not destroyed: that would wait too)
+            else:
+                want = (torch.arange(world, device=device, dtype=torch.float32) + 1.0).repeat_interleave(n_local)
+                if not torch.equal(got, want):
+                    ok, why = 0, "the gathered table does not hold every rank's block"
         if dist is not None and world > 1:
             flag = torch.tensor([ok], dtype=torch.int32, device=device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)

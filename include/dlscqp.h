@@ -597,6 +597,9 @@ void dlscqp_exchange_destroy(dlscqp_exchange *x);
  * it ahead of the launch after next: it refers to the post before last).  Asynchronous; no host synchronisation. */
 int dlscqp_exchange_post(dlscqp_exchange *x, const float *ctrl, const float *goal, const int32_t *status, void *ready_stream);
 int dlscqp_exchange_before_overwrite(dlscqp_exchange *x, void *stream);
+/* `stream` waits until the communication stream has read the arrays (or records) of the post just made: for a caller that goes on
+ * to rewrite them on `stream` at once instead of rotating its tables (dlscqp_exchange_before_overwrite) */
+int dlscqp_exchange_wait_packed(dlscqp_exchange *x, void *stream);
 /* The same without the packing pass: `records` [n_local][M (n+1) 3 + 4] is what the plan kernel wrote
  * (dlscqp_device_batch.out_record_stride) and is sent as it lies.  The caller keeps it untouched until the all-gather has read
  * it: dlscqp_exchange_before_overwrite (which then waits for the collective of the post before last, not for a packing pass). */

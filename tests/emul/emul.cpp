@@ -164,7 +164,7 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
     const int KUsel = ic.KU, SUsel = ic.SU;
     typedef void (*fn_t)(const WaveCpu &, const KParams &, const MemLayout &, unsigned char *, double *, const dlscqp_agent *,
                          const RowsView &, int, int, const float *, int, int, int, float *, int *, float *, double *,
-                         double *, double *, int *, int *);
+                         double *, double *, int *, int *, int *);
     fn_t fn = nullptr;
     switch (ic.id) {
 #define DQ_CASE(ID, RC, DIMS, FS, MS, KU, SU, SLK) \
@@ -196,7 +196,7 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
                    out_ctrl ? out_ctrl + (size_t)a * M * n1 * 3 : nullptr, out_x ? out_x + a * xs : nullptr,
                    out_cost ? out_cost + a : nullptr,
                    out_slack_cost ? out_slack_cost + (size_t)a * max_slack_obs : nullptr,
-                   out_status ? out_status + a : nullptr, out_iters ? out_iters + (size_t)a * 4 : nullptr);
+                   out_status ? out_status + a : nullptr, out_iters ? out_iters + (size_t)a * 4 : nullptr, nullptr);
         g_last_lds = mem;
     }
     return 0;
@@ -497,7 +497,7 @@ extern "C" int emul_throughput(const dlscqp_config *cfg, int n_agents, const dls
     if (ic.id < 0) return -2;
     typedef void (*fn_t)(const WaveCpu &, const KParams &, const MemLayout &, unsigned char *, double *, const dlscqp_agent *,
                          const RowsView &, int, int, const float *, int, int, int, float *, int *, float *, double *,
-                         double *, double *, int *, int *);
+                         double *, double *, int *, int *, int *);
     fn_t fn = nullptr;
     switch (ic.id) {
 #define DQ_CASE(ID, RC, DIMS, FS, MS, KU, SU, SLK) \
@@ -525,7 +525,7 @@ extern "C" int emul_throughput(const dlscqp_config *cfg, int n_agents, const dls
         for (;;) {
             fn(w, kp, lay, mem.data(), nullptr, agents + a, rv, (int)row_offsets[a], (int)(row_offsets[a + 1] - row_offsets[a]),
                sfc ? sfc + (size_t)a * M * 6 : nullptr, max_slack_obs, 1, 1, goal, &gst, ctrl.data(), nullptr, &cost,
-               max_slack_obs ? slack.data() : nullptr, &st, it);
+               max_slack_obs ? slack.data() : nullptr, &st, it, nullptr);
             done[t]++;
             if (++a == hi) a = lo;
             if ((done[t] & 15) == 0 &&

@@ -184,3 +184,36 @@ def test_plans_written_as_records_are_sent_as_they_lie(gpu_required):
         x.close()
     finally:
         opt.close()
+
+
+def test_a_post_that_does_not_pack_on_the_communication_stream_may_be_overwritten_at_once(gpu_required):
+    """NativeExchange.post(pack_on_comm=False): the caller rewrites its three tensors on its stream right after the post (bench.py's
+    sharded mission does: `own_ctrl.index_copy_` of the next step); the record that is gathered must be the one that was posted.  The
+    communication stream is held back by a long copy queued in front of the post, so that without the wait the packing would run
+    long after the tensors have been overwritten."""
+    cfg = workloads.s64_config()
+    opt = BatchTrajOptimizer(cfg)
+    try:
+        N, E = 4096, cfg.M * (cfg.n + 1) * 3
+        x = sharding.NativeExchange(opt, 0, 1, N, None, local_only=True)
+        big = torch.zeros(64 << 20, dtype=torch.float32, device="cuda")
+        for rep in range(6):
+            ctrl = torch.full((N, E), float(rep + 1), dtype=torch.float32, device="cuda")
+            goal = torch.full((N, 3), float(rep + 1) * 0.5, dtype=torch.float32, device="cuda")
+            status = torch.full((N,), rep, dtype=torch.int32, device="cuda")
+            # two exchanges in flight occupy the communication stream (each waits for its own ready event: give them slow ones)
+            for _ in range(4):
+                big.add_(1.0)
+            x.post(ctrl, goal, status, pack_on_comm=False)
+            ctrl.fill_(-1.0)
+            goal.fill_(-1.0)
+            status.fill_(-9)
+            got = x.table().clone()
+            torch.cuda.synchronize()
+            c, g, s = x.unpack(got, (torch.float32, torch.float32, torch.int32))
+            assert float(c.min()) == float(c.max()) == float(rep + 1)
+            assert float(g.min()) == float(g.max()) == float(rep + 1) * 0.5
+            assert int(s.min()) == int(s.max()) == rep
+        x.close()
+    finally:
+        opt.close()
