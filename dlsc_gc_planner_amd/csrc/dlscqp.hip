@@ -1651,6 +1651,11 @@ __global__ __launch_bounds__(64) void dlscqp_nbr_gather_kernel(NbrArgs a) {
     } else {
         consider(0, a.ns.n_total);  // no communication limit: by_cell holds every agent
     }
+    // the cell counts back to zero for the next search (their last reader, the prefix sum, ran before this kernel): the search
+    // has no memset of its own -- a memset node inside a captured step was seen to leave the counts standing on the second
+    // replay of the graph (round 4's memory access fault: slots beyond a cell's run, a scatter out of bounds)
+    if (!a.direct)
+        for (int e = k * 64 + lane; e <= a.n_cells; e += a.ns.n_local * 64) a.cell_count[e] = 0;
     __syncthreads();
     const int kept = count < NBR_LIST_CAP ? count : NBR_LIST_CAP;
     for (int e = lane; e < kept; e += 64) {
@@ -1709,11 +1714,15 @@ extern "C" int dlscqp_neighbours_device(dlscqp_ctx *c, const dlscqp_neighbour_se
     }
     const size_t need = (size_t)2 * (a.n_cells + 1) + (size_t)3 * ns->n_total + 16;
     if (need > c->nbr_scratch_ints) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        if (cap != hipStreamCaptureStatusNone) { g_last_error = "the neighbour search's scratch must grow: not inside a stream capture (search once eagerly first)"; return DLSCQP_ERR_INVALID_ARGUMENT; }
         HIP_TRY(hipDeviceSynchronize());
         if (c->nbr_scratch) (void)hipFree(c->nbr_scratch);
         c->nbr_scratch = nullptr;
         c->nbr_scratch_ints = 0;
         HIP_TRY(hipMalloc((void **)&c->nbr_scratch, need * sizeof(int32_t)));
+        HIP_TRY(hipMemset(c->nbr_scratch, 0, need * sizeof(int32_t)));  // (the cell counts start at zero; every search leaves them so)
         c->nbr_scratch_ints = need;
     }
     a.cell_count = c->nbr_scratch;
@@ -1721,8 +1730,7 @@ extern "C" int dlscqp_neighbours_device(dlscqp_ctx *c, const dlscqp_neighbour_se
     a.agent_cell = a.cell_start + a.n_cells + 1;
     a.agent_slot = a.agent_cell + ns->n_total;
     a.by_cell = a.agent_slot + ns->n_total;
-    HIP_TRY(hipMemsetAsync(a.cell_count, 0, (size_t)(a.n_cells + 1) * sizeof(int32_t), st));
-    const int nb = (ns->n_total + 255) / 256;
+    const int nb = (ns->n_total + 255) / 256;  // (cell_count is zero: the gather kernel of the search before left it so)
     hipLaunchKernelGGL(dlscqp_nbr_bin_kernel, dim3(nb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(dlscqp_nbr_scan_kernel, dim3(1), dim3(1024), 0, st, a);
     hipLaunchKernelGGL(dlscqp_nbr_scatter_kernel, dim3(nb), dim3(256), 0, st, a);

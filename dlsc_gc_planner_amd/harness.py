@@ -444,11 +444,10 @@ class ClosedLoop:
         least one step; result files and the host-side waypoint planners keep working (they run outside the graph)."""
         torch = self.torch
         assert self.seq >= 1, "the first step differs (constant-velocity prediction, corridor initialisation)"
-        assert not self.order_hint, "the launch-order hint rotates its buffers from step to step: not in a captured graph"
-        # (measured in round 4: capturing a step WITH the device neighbour search through cells -- a memset and four launches on a
-        # scratch buffer of the context -- ended in a memory access fault on replay; not looked into.  The one-launch search of up
-        # to 256 agents captures and replays bit-equal to the eager step (tests/test_gpu_closed_loop.py); the other is refused)
-        assert self.nbr is None or getattr(self.nbr, "direct", False), "the neighbour search through cells has not been made safe for capture"
+        # (the launch-order hint rotates three mask tables from step to step: three graphs, one per phase of the rotation, replayed in turn)
+        # (round 4 refused the device neighbour search through cells here: its captured step faulted on the second replay.  The
+        # cause was the search's memset node -- the cell counts were not cleared again on replay, the slots ran past their cells'
+        # runs and the scatter wrote out of bounds; the search now clears its counts itself, in its last kernel)
         torch.cuda.synchronize(self.dev)
         state = [self.batch.t["agents"], self.cur_goal, self.plans, self.init_buf]
         if self.sfc is not None:
@@ -461,13 +460,17 @@ class ClosedLoop:
         with torch.cuda.stream(side):  # warm-up on a side stream, as torch asks before a capture
             self._body(False)
         torch.cuda.current_stream(self.dev).wait_stream(side)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._body(False)
+        graphs = []
+        for _ in range(3 if self.order_hint else 1):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._body(False)
+            graphs.append(g)
         torch.cuda.synchronize(self.dev)
         for t, k in zip(state, keep):
             t.copy_(k)  # the warm-up advanced the state: put it back
-        self.graph = g
+        self.graph = graphs
+        self._graph_k = 0
 
     def step(self):
         """One replanning step of every agent; returns (status [N] tensor, iterations tensor)."""
@@ -481,7 +484,8 @@ class ClosedLoop:
             if getattr(self, "_stage_ev", None) is not None:
                 self._mapf_ms.append((time.perf_counter() - t_mapf) * 1e3)
         if self.graph is not None and not first:
-            self.graph.replay()
+            self.graph[self._graph_k % len(self.graph)].replay()
+            self._graph_k += 1
         else:
             self._body(first)
         if self.csv:

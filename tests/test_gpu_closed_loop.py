@@ -277,7 +277,7 @@ def test_forest_mission_with_spinning_obstacles(gpu_required):
     assert done is not None and done <= 30.0
 
 
-@pytest.mark.parametrize("with_world", [False, True, "reference", "forest"])
+@pytest.mark.parametrize("with_world", [False, True, "reference", "forest", "crowd"])
 def test_hip_graph_step_equals_eager_step(gpu_required, with_world):
     """ClosedLoop.enable_graph(): the steady-state step captured once in a HIP graph and replayed gives the same plans,
     states and verdicts, bit for bit, as the eager sequence of launches -- in an empty world (waypoints inside the graph),
@@ -285,7 +285,15 @@ def test_hip_graph_step_equals_eager_step(gpu_required, with_world):
     mission runs it (communication-range neighbour lists rebuilt on the device every step: the one-launch search) and in the
     forest (dynamic obstacles, waypoint trap)."""
     import torch
-    if with_world == "forest":
+    if with_world == "crowd":
+        # BASELINE.json configs[4] as bench.py flies it: 2 048 agents, neighbour lists through cells (a memset-free search: round 4's
+        # captured step faulted on its second replay), presolve, launch order from class masks (three graphs, one per phase)
+        from dlsc_gc_planner_amd import workloads
+        cfg = workloads.x2048_config(device=0)
+        start, goal = workloads.swapping_pairs(cfg, 2048)
+        kw = dict(radius=0.15, downwash=2.0, max_vel=1.0, max_acc=2.0, waypoint_step=0.5, device=0, neighbours="device", nbr_pitch=256,
+                  corridor_margin=0.5, prune=True, order_hint=True)
+    elif with_world == "forest":
         from dlsc_gc_planner_amd.harness import SpinObstacles
         m = json.load(open(os.path.join(HERE, "golden", "world_forest1.json")))
         cfg = abi.make_config(dim=m["dim"], M=m["M"], dt=m["dt"], control_input_weight=0.01, terminal_weight=1.0,
@@ -312,7 +320,7 @@ def test_hip_graph_step_equals_eager_step(gpu_required, with_world):
         sim = ClosedLoop(cfg, start, goal, **(dict(kw, dyn=kw_dyn()) if with_world == "forest" else kw))
         try:
             hist = []
-            for k in range(40):
+            for k in range(40 if with_world != "crowd" else 14):
                 if use_graph and k == 3:
                     sim.enable_graph()
                 status, iters = sim.step()
@@ -326,7 +334,7 @@ def test_hip_graph_step_equals_eager_step(gpu_required, with_world):
         for x, y in zip(e, g):
             assert np.array_equal(x, y), k
     moved = np.linalg.norm(runs[1][-1][1] - start, axis=1)
-    assert moved.mean() > 1.0  # the agents did fly
+    assert moved.mean() > (1.0 if with_world != "crowd" else 0.5)  # the agents did fly (the crowd: 14 steps)
 
 
 @pytest.mark.parametrize("M", [2, 5, 10])
