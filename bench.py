@@ -368,11 +368,27 @@ def moving_crowd(device, steps=60, warm=20):
         out["cpu_port_note"] = "goal LP + QP only (no neighbour search, no half-space generation) on the host, inputs read back from HBM"
     except Exception as e:
         out["cpu_port_ms"], out["cpu_port_note"] = None, "unavailable: %s" % e
+    # the same step as HIP graphs (three: the phases of the launch-order masks' rotation), neighbour search through cells included
+    try:
+        sim.enable_stage_timers(False)
+        sim.keep_inputs = False
+        sim.enable_graph()
+        for _ in range(6):
+            sim.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            sim.step()
+        torch.cuda.synchronize()
+        out["ms_per_step_as_hip_graphs"] = (time.perf_counter() - t0) / steps * 1e3
+    except Exception as e:  # noqa: BLE001
+        out["ms_per_step_as_hip_graphs"] = None
+        out["hip_graphs_note"] = "unavailable: %s" % e
     sim.close()
     return out
 
 
-def s64_closed_loop(device, n_swarms=512, groups=1, first=3, steps=8, flights=4):
+def s64_closed_loop(device, n_swarms=512, groups=1, first=3, steps=8, flights=4, graph=False):
     """BASELINE.json configs[1] at the headline's scale with the WHOLE replanning step on the device (traj_planner.cpp:108-133 per
     agent: prediction of the neighbours from their previous plans, generateDLSCGC :603-666, goal LP, QP; then doStep): the
     `n_swarms` swarms in `groups` closed loops (harness.ClosedLoop), each on its own stream; per step and loop four launches,
@@ -418,6 +434,11 @@ def s64_closed_loop(device, n_swarms=512, groups=1, first=3, steps=8, flights=4)
     for _ in range(flights):
         sims = take_off()
         advance(sims, first)
+        if graph:  # the steady-state step of every loop as HIP graphs (three per loop: the phases of the launch-order masks' rotation)
+            for g in range(G):
+                with torch.cuda.stream(streams[g]):
+                    sims[g].enable_graph()
+            torch.cuda.synchronize(dev)
         e_, h_ = advance(sims, steps)
         el, host = el + e_, host + h_
         for s_ in sims:
@@ -1207,7 +1228,11 @@ def main():
                                 "agents had one replanning step earlier (dlscqp_device_batch.hint_iters), in the headline's groups; the "
                                 "one_launch figures are rounds 1-2's shape (one launch of all agents per step)"}
             closed = closed_loop_latency(local_rank)
-            closed["s64_closed_loop"] = s64_closed_loop(local_rank, n_swarms=args.swarms)
+            # two loops of 256 swarms on two streams (round 5, one MI355X: one loop 0.515 ms per step, two 0.436, four 0.564; as HIP
+            # graphs the same within 1 % -- the step is not bound by the host)
+            closed["s64_closed_loop"] = s64_closed_loop(local_rank, n_swarms=args.swarms, groups=2)
+            one = s64_closed_loop(local_rank, n_swarms=args.swarms, groups=1, flights=2)
+            closed["s64_closed_loop"]["ms_per_step_one_loop"] = one["ms_per_step"]
         line = {
             "metric": "agent-QP solves/sec (goal LP + trajectory QP per agent per replanning step)",
             "value": world * N * args.steps / elapsed,
