@@ -103,18 +103,33 @@ def host_cores():
     return cores
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(cfg, wl, seconds=12.0):
-    """Two CPU numbers on this host, same batch (rank 0, N = 1 only):
-      value             the KERNEL'S OWN ALGORITHM on the CPU (kind "port"): the lane-serial build of csrc/gi_core.hpp -- host
-                        tables, whitened dual active-set, weak-duality test, everything the GPU kernel does -- compiled
-                        -O3 (tests/emul/libdlscqp_cpu.so), one native thread per core the container may use, each walking
-                        its own range of the batch for `seconds`;
+    """CPU numbers on this host, same batch (rank 0, N = 1 only):
+      value             a CPU-SHAPED SOLVER (kind "port"): tests/native/native_qp.cpp -- the kernel's mathematics (host tables, whitened
+                        dual active-set method in range-space form) written a second time as a scalar program: plain loops over an
+                        agent's own rows, variables and active rows, g++ -O3 -march=x86-64-v3, one native thread per core the
+                        container may use, each walking its own range of the batch for most of `seconds`; parity-checked against
+                        the oracle by tests/test_native.py;
+      lane_serial_*     the kernel's own SOURCE on the CPU: the lane-serial build of csrc/gi_core.hpp (tests/emul/libdlscqp_cpu.so:
+                        every lane loop 64 trips whatever the agent needs) -- what rounds 2-4 reported as `value`;
       oracle_qp_per_s   the checker (oracle/dlsc_oracle.c: dense model in the reference's row order, generic
                         Goldfarb-Idnani with a fresh QR per QP), one core, for orientation only.
-    Both are this repository's code: CPLEX, which the reference calls here, is not available on either machine."""
+    All are this repository's code: CPLEX, which the reference calls here, is not available on either machine."""
     import ctypes as C
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import native_lib
     import oracle_lib
     from dlsc_gc_planner_amd import abi
     agents = np.ascontiguousarray(wl["agents"])
@@ -122,13 +137,15 @@ def cpu_baseline(cfg, wl, seconds=12.0):
     rows = np.ascontiguousarray(wl["rows"])
     N = len(agents)
     cores = host_cores()
+    nat_one = native_lib.bench(cfg, agents, ro, rows, None, 0, 1, min(2.0, seconds))
+    nat_all = native_lib.bench(cfg, agents, ro, rows, None, 0, cores, max(2.0, seconds - 5.0))
     lib_path = os.path.join(ROOT, "tests", "emul", "libdlscqp_cpu.so")
     L = C.CDLL(lib_path)
     vp = C.c_void_p
     L.emul_throughput.argtypes = [C.POINTER(abi.Config), C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int64),
                                   C.POINTER(C.c_double)]
     res = {}
-    for label, nt, secs in (("one", 1, min(3.0, seconds)), ("all", cores, seconds)):
+    for label, nt, secs in (("one", 1, 1.0), ("all", cores, 2.0)):
         n, el = C.c_int64(), C.c_double()
         rc = L.emul_throughput(C.byref(cfg), N, agents.ctypes.data, ro.ctypes.data, rows.ctypes.data, None, 0, nt, secs, C.byref(n), C.byref(el))
         if rc != 0:
@@ -138,14 +155,18 @@ def cpu_baseline(cfg, wl, seconds=12.0):
     t0 = time.perf_counter()
     oracle_lib.plan_batch(cfg, agents[:probe], ro[:probe + 1], rows[:ro[probe]], None, 0, True)
     oracle_rate = probe / (time.perf_counter() - t0)
-    n_all, el_all = res["all"]
-    return {"value": n_all / el_all, "unit": "QP/s", "cores": cores, "kind": "port", "port_kind": "lane-serial port",
-            "port_note": "the wave64 program run lane by lane on the host: every lane loop runs 64 trips and every reduction walks 64 "
-                         "elements whatever the agent's active set is -- the device algorithm on a CPU, not a CPU-shaped solver",
-            "sample": "%d agent-QPs (goal LP + QP each) of the timed batch in %.1f s: the kernel's own algorithm (lane-serial host build "
-                      "of csrc/gi_core.hpp, g++ -O3 -march=x86-64-v3), %d native threads, each walking its own range of the batch"
-                      % (n_all, el_all, cores),
-            "one_core_qp_per_s": res["one"][0] / res["one"][1],
+    return {"value": nat_all[0], "unit": "QP/s", "cores": cores, "kind": "port", "port_kind": "native scalar solver",
+            "native_qp_per_s": nat_all[0], "native_one_core_qp_per_s": nat_one[0], "nproc": os.cpu_count(), "cpu_model": cpu_model(),
+            "port_note": "tests/native/native_qp.cpp: a scalar C++ program -- loops over the agent's own rows, variables and active rows -- "
+                         "with the kernel's mathematics (equalities eliminated and Hessian whitened by the host tables of csrc/qp_tables.cpp, "
+                         "Goldfarb-Idnani dual active-set method in range-space form), written independently of the kernel's source and "
+                         "checked against the oracle; one agent per thread",
+            "sample": "%d agent-QPs (goal LP + QP each) of the timed batch in %.1f s, g++ -O3 -march=x86-64-v3, %d native threads, each "
+                      "walking its own range of the batch" % (nat_all[1], nat_all[2], cores),
+            "one_core_qp_per_s": nat_one[0],
+            "lane_serial_qp_per_s": res["all"][0] / res["all"][1], "lane_serial_one_core_qp_per_s": res["one"][0] / res["one"][1],
+            "lane_serial_note": "the kernel's own source run lane by lane on the host (tests/emul/libdlscqp_cpu.so: every lane loop 64 trips, "
+                                "every reduction 64 elements): the device algorithm on a CPU, what rounds 2-4 reported as `value`",
             "oracle_qp_per_s_one_core": oracle_rate,
             "oracle_note": "oracle/dlsc_oracle.c (the parity checker: dense, generic) on %d agent-QPs, one core" % probe,
             "ref_published_qp_per_s": 89.4,

@@ -55,6 +55,11 @@
 #ifndef DQ_RSQRT
 #define DQ_RSQRT(x) (1.0 / sqrt(x))
 #endif
+// DQ_WAVE_ALL(c): c holds for every lane of the wavefront (wave-uniform, a real branch can test it); lane-serial host build: c itself --
+// only where both sides of the branch compute the same thing for a lane for which c holds
+#ifndef DQ_WAVE_ALL
+#define DQ_WAVE_ALL(c) (c)
+#endif
 // DQ_MARK(text): a comment in the generated assembly (tests/divergence_check.py recognises the exit stores by it)
 #ifndef DQ_MARK
 #define DQ_MARK(text) ((void)0)
@@ -721,10 +726,29 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 #pragma unroll
                         for (int t = 0; t < 6; t++) DQ_KEEP(g[u][t]);
                     }
+                    // (one division per lane and trip where no lane has two rows of the LP among its CB rows: the rows of the last
+                    // control point are one in 27 of a neighbour's rows)
+                    bool tin[CB];
+                    double ta[CB], tb[CB];
+                    int tcnt = 0;
 #pragma unroll
                     for (int u = 0; u < CB; u++) {
                         const uint32_t kq = blend_idx(j0 + 64 * u + l < K, (int)kk[u], (int)KEY_SKIP);
-                        lp_row(kq, g[u][0], g[u][1], g[u][2], g[u][3], g[u][4], g[u][5], gd[u], lo, hi, bad, viol);
+                        lp_coeff(kq, g[u][0], g[u][1], g[u][2], g[u][3], g[u][4], g[u][5], gd[u], tin[u], ta[u], tb[u], viol);
+                        tcnt += tin[u] ? 1 : 0;
+                    }
+                    if (DQ_WAVE_ALL(tcnt <= 1)) {  // uniform
+                        bool in = false;
+                        double a = 1.0, b = 0.0;
+#pragma unroll
+                        for (int u = 0; u < CB; u++) {
+                            a = tin[u] ? ta[u] : a; b = tin[u] ? tb[u] : b;
+                            in |= tin[u];
+                        }
+                        lp_bound(in, a, b, lo, hi, bad);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < CB; u++) lp_bound(tin[u], ta[u], tb[u], lo, hi, bad);
                     }
                 }
                 llo.at(l) = lo; lhi.at(l) = hi; lbad.at(l) = bad; lviol.at(l) = viol;
