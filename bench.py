@@ -1165,9 +1165,12 @@ def main():
             if prof.get("agents_per_launch") == per_launch and prof.get("csrc_sha1") == summarize.csrc_sha1():
                 traffic = prof.get("hbm_bytes_per_launch")
                 if prof.get("valu_insts_per_agent"):
-                    # share of the chip's VALU issue slots over the STEP: a wave64 VALU instruction holds its SIMD's issue port
-                    # for 4 cycles; 1 024 SIMDs; 2.4 GHz nominal (the counter is per launch and does not depend on the overlap)
-                    valu_frac = prof["valu_insts_per_agent"] * N * 4.0 / (1024 * step_s * 2.4e9)
+                    # share of the chip's vector-pipe cycles over the STEP: a wave64 FP64 instruction holds its SIMD's pipe for 4
+                    # cycles, any other VALU instruction for 2; 1 024 SIMDs; 2.4 GHz nominal (the counters are per launch and do
+                    # not depend on the overlap).  Without FP64 counters in the profile: every instruction at 4.
+                    f64 = prof.get("valu_f64_insts_per_agent")
+                    cyc = 4.0 * prof["valu_insts_per_agent"] if f64 is None else 4.0 * f64 + 2.0 * (prof["valu_insts_per_agent"] - f64)
+                    valu_frac = cyc * N / (1024 * step_s * 2.4e9)
                 traffic_src = "%s: rocprofv3 --pmc passes of this command (%s), taken on these kernel sources" % (
                     os.path.relpath(args.traffic_json, ROOT), prof.get("source", ""))
             elif prof.get("agents_per_launch") == per_launch:
@@ -1333,11 +1336,18 @@ def main():
             # of an orthogonal factor) no longer describes what the kernel does -- its arithmetic per iteration is O(active rows)
             "fp64_valu": fp64,
             "roofline": {
-                # what binds the kernel according to the counters (profiles/): the VALU issue rate of the SIMDs -- neither of
-                # the two classical roofs.  achieved / peak / frac are the HBM figures the contract asks for.
-                "bound": "valu_issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                # achieved / peak / frac are the HBM figures the contract asks for.  What binds the kernel is neither classical roof
+                # (SURVEY.md 8d): ~5 KB and ~0.1 MFLOP per QP.  `limiter` says what the counters show (profiles/): the SIMDs' vector
+                # pipes are busy for valu_issue_frac of their cycles (FP64 instructions at 4 cycles, the others at 2), the wavefronts
+                # wait for wait_any_frac of theirs -- two wavefronts per SIMD (244-250 VGPRs) of dependent short phases: wave
+                # issue / latency, not a throughput roof.
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None if traffic is None else traffic * G_used, "traffic_source": traffic_src,
-                "valu_issue_frac": valu_frac,
+                "limiter": "wave issue and dependent latencies at two wavefronts per SIMD (neither the HBM nor the FP64 roof)",
+                "valu_issue_frac": valu_frac, "wait_any_frac": prof.get("wait_any_frac") if traffic is not None else None,
+                "valu_insts_per_qp": prof.get("valu_insts_per_agent") if traffic is not None else None,
+                "valu_f64_insts_per_qp": prof.get("valu_f64_insts_per_agent") if traffic is not None else None,
+                "salu_insts_per_qp": prof.get("salu_insts_per_agent") if traffic is not None else None,
                 "kernel": prof.get("kernel", "dlscqp_plan_kernel"), "avg_kernel_ms": avg_kernel_s * 1e3,
                 "algorithmic_bytes_per_qp": bytes_qp, "qp_per_launch": per_launch, "launches_per_step": G_used,
                 "achieved_one_launch": per_launch * bytes_qp / avg_kernel_s / 1e9,
@@ -1347,8 +1357,8 @@ def main():
                         "as `value`; achieved_one_launch = one launch's bytes / its average duration (HIP events on the launch "
                         "streams over the timed region); achieved_if_launches_overlapped_fully = that x launches_per_step (round 3 "
                         "reported this as `achieved`; the launches of different groups overlap only partly: effective_concurrency); "
-                        "traffic = PMC bytes per launch x launches_per_step; valu_issue_frac = VALU instructions of a step x 4 cycles / "
-                        "(1 024 SIMDs x ms_per_step x 2.4 GHz); ~5 KB per QP can never load the HBM roof (SURVEY.md 8d)",
+                        "traffic = PMC bytes per launch x launches_per_step; valu_issue_frac = (4 x FP64 + 2 x other VALU instructions "
+                        "of a step) / (1 024 SIMDs x ms_per_step x 2.4 GHz); ~5 KB per QP can never load the HBM roof (SURVEY.md 8d)",
             },
         }
         if not args.no_cpu_baseline and not args.headline_only and world == 1:

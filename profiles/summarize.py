@@ -22,15 +22,24 @@ KERNEL = "dlscqp_plan_kernel"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
+PLAN_KERNEL_SOURCES = ("gi_core.hpp", "qp_types.hpp", "dlscqp.hip up to the half-space generator (wave primitives, launch order, dlscqp_plan_kernel)")
+
+
 def csrc_sha1():
-    """Hash of the kernel sources a profile was measured on (bench.py compares it with the tree it runs from)."""
+    """Hash of the PLAN KERNEL's sources a profile was measured on (bench.py compares it with the tree it runs from): gi_core.hpp,
+    qp_types.hpp and the part of dlscqp.hip in front of the half-space generator -- the wave primitives, the launch order and
+    dlscqp_plan_kernel itself.  An edit to a generator kernel, the exchange or the host code behind that point does not
+    invalidate the plan kernel's counters (round 4 lost its driver line's counter fields to such an edit)."""
     import hashlib
     h = hashlib.sha1()
     d = os.path.join(os.path.dirname(HERE), "dlsc_gc_planner_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp", ".cpp")):
-            h.update(f.encode())
-            h.update(open(os.path.join(d, f), "rb").read())
+    for f in ("gi_core.hpp", "qp_types.hpp"):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    hip = open(os.path.join(d, "dlscqp.hip"), "rb").read()
+    cut = hip.find(b"// SURVEY.md row N1: one workgroup")
+    h.update(b"dlscqp.hip")
+    h.update(hip if cut < 0 else hip[:cut])
     return h.hexdigest()
 
 
@@ -129,13 +138,26 @@ def main():
             out.append("| %s | %.6g |" % (k, v))
         out.append("")
     if "pmc_SQ_INSTS_VALU" in summary and "avg_kernel_us" in summary:
-        # share of the VALU issue slots of the chip that the kernel uses: a wave64 VALU instruction occupies its SIMD's issue
-        # port for 4 cycles; 256 CUs x 4 SIMDs; 2.4 GHz peak engine clock (a lower real clock makes the true share higher)
-        frac = args.concurrent * summary["pmc_SQ_INSTS_VALU"] * 4.0 / (1024 * summary["avg_kernel_us"] * 1e-6 * 2.4e9)
+        # share of the VALU pipes' cycles that the kernel's instructions occupy: a wave64 FP64 instruction holds its SIMD's vector
+        # pipe for 4 cycles, any other VALU instruction for 2 (MI355X_MICROARCH.md: SIMD-32, FP64 at half rate); 256 CUs x 4 SIMDs;
+        # 2.4 GHz peak engine clock (a lower real clock makes the true share higher).  FP64 = the ADD / MUL / FMA / TRANS_F64 counters
+        # (comparisons, v_max_f64 and moves of doubles are priced at 2: a lower bound)
+        f64 = sum(summary.get("pmc_SQ_INSTS_VALU_%s_F64" % k, 0.0) for k in ("ADD", "MUL", "FMA", "TRANS"))
+        have_f64 = "pmc_SQ_INSTS_VALU_FMA_F64" in summary
+        other = summary["pmc_SQ_INSTS_VALU"] - f64
+        cyc = 4.0 * f64 + 2.0 * other if have_f64 else 4.0 * summary["pmc_SQ_INSTS_VALU"]
+        frac = args.concurrent * cyc / (1024 * summary["avg_kernel_us"] * 1e-6 * 2.4e9)
         summary["valu_issue_frac"] = frac
-        out.append("VALU issue: %d launch(es) x SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x %.1f us x 2.4 GHz) = %.3f of the chip's VALU issue slots "
-                   "(%.0f VALU instructions per agent; the launch duration is the kernel trace's, where the launches overlap; the counter is "
-                   "per launch)\n" % (args.concurrent, summary["avg_kernel_us"], frac, summary["pmc_SQ_INSTS_VALU"] / args.agents))
+        summary["valu_f64_insts_per_agent"] = f64 / args.agents if have_f64 else None
+        out.append("VALU pipe: %d launch(es) x (4 x %.0f FP64 + 2 x %.0f other VALU instructions per agent) / (1024 SIMDs x %.1f us x 2.4 GHz) = %.3f of "
+                   "the chip's vector-pipe cycles (%.0f VALU instructions per agent%s; the launch duration is the kernel trace's, where the "
+                   "launches overlap; the counters are per launch)\n" % (
+                       args.concurrent, f64 / args.agents, other / args.agents, summary["avg_kernel_us"], frac, summary["pmc_SQ_INSTS_VALU"] / args.agents,
+                       "" if have_f64 else "; no FP64 counters in this run: every instruction priced at 4"))
+        for k in ("SALU", "LDS", "SMEM", "VMEM_RD", "VMEM_WR"):
+            if "pmc_SQ_INSTS_" + k in summary:
+                out.append("%s instructions per agent: %.1f" % (k, summary["pmc_SQ_INSTS_" + k] / args.agents))
+        out.append("")
     if "pmc_SQ_WAIT_ANY" in summary and "pmc_SQ_WAVE_CYCLES" in summary:
         out.append("SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.3f of the wave-cycles waiting\n" % (summary["pmc_SQ_WAIT_ANY"] / summary["pmc_SQ_WAVE_CYCLES"]))
     if "pmc_FETCH_SIZE" in summary and "pmc_WRITE_SIZE" in summary:
@@ -155,7 +177,10 @@ def main():
             json.dump({"agents_per_launch": args.agents, "hbm_bytes_per_launch": summary["hbm_bytes_per_launch"],
                        "valu_issue_frac": summary.get("valu_issue_frac"), "kernel": KERNEL, "source": args.name,
                        "valu_insts_per_agent": summary.get("pmc_SQ_INSTS_VALU", 0.0) / args.agents if "pmc_SQ_INSTS_VALU" in summary else None,
-                       "csrc_sha1": csrc_sha1()}, fh)
+                       "valu_f64_insts_per_agent": summary.get("valu_f64_insts_per_agent"),
+                       "salu_insts_per_agent": summary.get("pmc_SQ_INSTS_SALU", 0.0) / args.agents if "pmc_SQ_INSTS_SALU" in summary else None,
+                       "wait_any_frac": (summary["pmc_SQ_WAIT_ANY"] / summary["pmc_SQ_WAVE_CYCLES"]) if "pmc_SQ_WAIT_ANY" in summary and "pmc_SQ_WAVE_CYCLES" in summary else None,
+                       "csrc_sha1": csrc_sha1(), "csrc_hashed": list(PLAN_KERNEL_SOURCES)}, fh)
     print("\n".join(out))
 
 
