@@ -613,7 +613,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     int goal_status = DLSCQP_OK;
     if (do_goal && !bad_shape) {
         float dx = cg[0] - wp[0], dy = cg[1] - wp[1], dz = cg[2] - wp[2];
-        if (f32_norm3(dx, dy, dz) < SP_EPSILON_FLOAT) {  // goal_optimizer.cpp:12-14
+        if (f32_norm3_below_eps(dx, dy, dz)) {  // goal_optimizer.cpp:12-14 (the same test without the square root)
             goal[0] = wp[0]; goal[1] = wp[1]; goal[2] = wp[2];
         } else {
             const float diff[3] = {dx, dy, dz};
