@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # API return codes
 SUCCESS = 0

@@ -660,13 +660,6 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 hi = (in_lp & (a < 0) & (tq < hi)) ? tq : hi;
                 bad = (in_lp & !(a > 0) & !(a < 0) & (b < -CPLEX_FEAS_TOL)) ? 1 : bad;
             };
-            auto lp_row = [&](uint32_t key, float nx, float ny, float nz, float qx, float qy, float qz, double dd,
-                              double &lo, double &hi, int &bad, int &viol) {
-                bool in_lp;
-                double a, b;
-                lp_coeff(key, nx, ny, nz, qx, qy, qz, dd, in_lp, a, b, viol);
-                lp_bound(in_lp, a, b, lo, hi, bad);
-            };
             // The rows of the LP are those of the last control point: a few of an agent's rows, and hardly ever two of one lane's
             // cached rows.  Where no lane has two (one ballot), each lane divides once, for the row it has (a double-precision
             // division is ~35 instructions); else row by row.

@@ -151,6 +151,8 @@ class BatchTrajOptimizer:
         [N, 3]); returns a callable(stream=None).  boxes [N, M, 6] (with initial_traj): the kernel also writes the next step's
         boxes of a world without obstacles -- bounding box of each segment of initial_traj, box_margin wider, cut to
         [box_min, box_max]."""
+        # dlscqp_advance reads dense arrays: not after DeviceBatch.use_records (one strided record per agent)
+        assert batch.c.out_record_stride == 0, "make_advance: the batch writes its plans as records (use_records); dlscqp_advance reads dense arrays"
         a = abi.Advance()
         a.n_agents = batch.n_agents
         a.status, a.goal_status = batch.out_status.data_ptr(), batch.out_goal_status.data_ptr()

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DLSCQP_ABI_VERSION 1
+#define DLSCQP_ABI_VERSION 2
 
 /* Return codes of the API calls themselves (not per-agent verdicts). */
 enum {

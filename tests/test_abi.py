@@ -50,6 +50,33 @@ int main(void) {
     assert got == exp
 
 
+def test_every_struct_of_the_header_has_the_mirror_s_size_and_last_field():
+    """Every structure that crosses the boundary, not only the first four: the size and the offset of the LAST field of each (the
+    structures grow by appended fields; a mirror that lags behind reads garbage there -- ADVICE, round 4)."""
+    pairs = [("dlscqp_config", abi.Config), ("dlscqp_agent", abi.Agent), ("dlscqp_lsc_row", abi.LscRow), ("dlscqp_device_batch", abi.DeviceBatch),
+             ("dlscqp_lsc_gen", abi.LscGen), ("dlscqp_neighbour_search", abi.NeighbourSearch), ("dlscqp_neighbour_knn", abi.NeighbourKnn),
+             ("dlscqp_waypoint_trap", abi.WaypointTrap), ("dlscqp_sfc_gen", abi.SfcGen), ("dlscqp_advance", abi.Advance),
+             ("dlscqp_exchange_config", abi.ExchangeConfig), ("dlscqp_step_group", abi.StepGroup), ("dlscqp_step_args", abi.StepArgs),
+             ("dlscqp_mapf_config", abi.MapfConfig), ("dlscqp_mapf_step_args", abi.MapfStepArgs)]
+    body = "".join('  printf("%%zu %%zu ", sizeof(%s), offsetof(%s, %s));\n' % (c, c, m._fields_[-1][0]) for c, m in pairs)
+    code = "#include <stdio.h>\n#include <stddef.h>\n#include \"dlscqp.h\"\nint main(void) {\n" + body + "  return 0;\n}\n"
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "t.c")
+        open(src, "w").write(code)
+        exe = os.path.join(td, "t")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        got = [int(v) for v in subprocess.check_output([exe]).split()]
+    for k, (c, m) in enumerate(pairs):
+        assert got[2 * k] == C.sizeof(m), (c, got[2 * k], C.sizeof(m))
+        assert got[2 * k + 1] == getattr(m, m._fields_[-1][0]).offset, (c, m._fields_[-1][0])
+
+
+def test_abi_version_is_checked():
+    assert abi.ABI_VERSION == 2  # round 5: dlscqp_device_batch grew (workspace, hint_mask_*): a caller built against version 1 is refused
+    hdr = open(os.path.join(ROOT, "include", "dlscqp.h")).read()
+    assert "#define DLSCQP_ABI_VERSION 2" in hdr
+
+
 def test_key_packing_matches_macro():
     import numpy as np
     assert int(abi.key_of(4, 5, -1, 0)) == (4 | (5 << 8) | (0xFFFF << 16))
