@@ -1262,6 +1262,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     };
     int n_price = 0;
     double f_max = -1.0;  // computed when first needed
+#ifdef DLSCQP_TRACE
+    double trace_min_ratio = 1.0;
+#endif
 
     // Takes a row out of the pricing passes (on: it became active, or was accepted within CPLEX's tolerance) or puts it back
     // (off: it left the active set; `rhs` = its right-hand side if it is a cached LSC row).  code and on are uniform, the
@@ -2124,7 +2127,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                                    !(noise_truth > DEP_XSPACE * dall);
                 DQ_TRACE(6, dd2_first / dall, zz_truth / dall, noise_truth > 0 ? zz_truth / noise_truth : -1.0,
                          (double)((dependent ? 1 : 0) | (remeasured ? 2 : 0) | (truth ? 4 : 0) | ((DXREG && kp.dep_calibrated) ? 8 : 0)));
-                DQ_TRACE(7, noise_truth / dall, zz_truth / dall, 0.0, truth ? 1.0 : 0.0);  // what DEP_XSPACE is compared with
+                DQ_TRACE(7, noise_truth / dall, zz_truth / dall, trace_min_ratio, truth ? 1.0 : 0.0);  // what DEP_XSPACE is compared with; [3]: the smallest |z|^2 / |N'a|^2 a row was added with so far
             }
 #endif
             w.stamp(7);  // ratio test
@@ -2194,6 +2197,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 // ---- add row ip: R gains the column (d1; alpha), alpha = |z|  <=>  S = R^-1 gains (-S d1 / alpha; 1 / alpha; zeros),
                 // and Z = G A' S the column G (a - A' rv) / alpha = dx / alpha: record q, every entry of it written ----
                 const double inv_alpha = 1.0 / sqrt(dd2);
+#ifdef DLSCQP_TRACE
+                trace_min_ratio = dd2 / dall < trace_min_ratio ? dd2 / dall : trace_min_ratio;
+#endif
                 auto write_record = [&](double *rec) {  // (called with a pointer into the working set or into the spill record)
                     w.each([&](int l) {
 #pragma unroll

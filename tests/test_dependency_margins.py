@@ -26,7 +26,7 @@ import emul_lib
 import randqp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-DEP_SUSPECT, DEP_SUSPECT_SLACK, DEP_NOISE, DEP_TOL, DEP_XSPACE = 1e-5, 1e-3, 1e-17, 1e-20, 1e-16  # csrc/qp_types.hpp
+DEP_SUSPECT, DEP_SUSPECT_SLACK, DEP_NOISE, DEP_TOL, DEP_XSPACE = 1e-5, 1e-2, 1e-17, 1e-20, 1e-16  # csrc/qp_types.hpp
 EPS = 2.2e-16
 SEED = int(os.environ.get("FUZZ_SEED", str(int(time.time()) % 1000000)))
 NAMES = ["empty3d_M5", "maze2d_M10_sfc_comm", "forest3d_M5_dyn", "crowd3d_M5_400rows", "long3d_M12_comm"] + randqp.OFF_DEFAULT
