@@ -1596,13 +1596,12 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 const int own = row & 63, u = row >> 6;
                 double rh = 0.0;
 #pragma unroll
-                for (int uq = 0; uq < KU; uq++) {  // uniform selects, no branches
-                    const uint32_t kq = w.bcast(ckey[uq], own);
-                    const float a0 = w.bcast(cnx[uq], own), a1 = w.bcast(cny[uq], own), a2 = w.bcast(cnz[uq], own);
-                    const double rq = w.bcast(cd[uq], own);
-                    key = uq == u ? kq : key;
-                    nn[0] = uq == u ? a0 : nn[0]; nn[1] = uq == u ? a1 : nn[1]; nn[2] = uq == u ? a2 : nn[2];
-                    rh = uq == u ? rq : rh;
+                for (int uq = 0; uq < KU; uq++) {
+                    if (uq == u) {  // uniform: the register set of the row, broadcast from its owner lane
+                        key = w.bcast(ckey[uq], own);
+                        nn[0] = w.bcast(cnx[uq], own); nn[1] = w.bcast(cny[uq], own); nn[2] = w.bcast(cnz[uq], own);
+                        rh = w.bcast(cd[uq], own);
+                    }
                 }
                 row_rhs = rh;
             } else if (row < Kl) {  // a row in LDS (every lane reads the same words)
@@ -2042,13 +2041,18 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 // a.dx from the registers: the rate at which the step moves the row it is taken for.  Equal to |z|^2 up to the
                 // rounding of rv (~1e-16 x the conditioning of the active rows, relative to |N'a|^2); only a row that looks
                 // nearly dependent that way is measured again as the quadratic form
-                const int ax0 = new_line ? new_axis : 0, ax1 = new_line ? new_axis : 1, ax2 = new_line ? new_axis : 2;
-                const double e00 = w.bcast(dkr[0], np0), e01 = w.bcast(dkr[1], np0), e02 = w.bcast(dkr[2], np0);
-                const double e10 = w.bcast(dkr[0], np1), e11 = w.bcast(dkr[1], np1), e12 = w.bcast(dkr[2], np1);
-                const double e20 = w.bcast(dkr[0], np2), e21 = w.bcast(dkr[1], np2), e22 = w.bcast(dkr[2], np2);
-                const double y0 = ax0 == 0 ? e00 : (ax0 == 1 ? e01 : e02);
-                const double y1 = ax1 == 0 ? e10 : (ax1 == 1 ? e11 : e12);
-                const double y2 = ax2 == 0 ? e20 : (ax2 == 1 ? e21 : e22);
+                // (a POINT row: one control point, its three axes -- three broadcasts; a LINE row: three points of one axis)
+                double y0, y1, y2;
+                if (!new_line) {  // uniform
+                    y0 = w.bcast(dkr[0], np0); y1 = w.bcast(dkr[1], np0); y2 = w.bcast(dkr[2], np0);
+                } else {
+                    const double e00 = w.bcast(dkr[0], np0), e01 = w.bcast(dkr[1], np0), e02 = w.bcast(dkr[2], np0);
+                    const double e10 = w.bcast(dkr[0], np1), e11 = w.bcast(dkr[1], np1), e12 = w.bcast(dkr[2], np1);
+                    const double e20 = w.bcast(dkr[0], np2), e21 = w.bcast(dkr[1], np2), e22 = w.bcast(dkr[2], np2);
+                    y0 = new_axis == 0 ? e00 : (new_axis == 1 ? e01 : e02);
+                    y1 = new_axis == 0 ? e10 : (new_axis == 1 ? e11 : e12);
+                    y2 = new_axis == 0 ? e20 : (new_axis == 1 ? e21 : e22);
+                }
                 dd2 = ncf[0] * y0 + ncf[1] * y1 + ncf[2] * y2;
             } else {
                 dd2 = z_squared();
@@ -2200,7 +2204,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 #ifdef DLSCQP_TRACE
                 trace_min_ratio = dd2 / dall < trace_min_ratio ? dd2 / dall : trace_min_ratio;
 #endif
-                auto write_record = [&](double *rec) {  // (called with a pointer into the working set or into the spill record)
+                // (called with a pointer into the working set or into the spill record: inlined at both places, so that each copy knows
+                // its address space -- as a function of its own it would take a generic pointer, and the flat-address code that goes
+                // with one hit "Illegal instruction detected: Operand has incorrect register class" in this compiler)
+                auto write_record = [&](double *rec) __attribute__((always_inline)) {
                     w.each([&](int l) {
 #pragma unroll
                         for (int c = 0; c < RC; c++) {
