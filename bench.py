@@ -329,7 +329,7 @@ def closed_loop_latency(device):
     return out
 
 
-def moving_crowd(device, steps=60, warm=20):
+def moving_crowd(device, steps=60, warm=20, heavy_ranks=0):
     """BASELINE.json configs[4] FLOWN: 2 048 agents in one 2-D arena, every agent swapping places with a partner 3.4 m away
     (workloads.swapping_pairs); every step, all in HBM: communication-range neighbour search (dlscqp_neighbours_device),
     corridor boxes, DLSC-GC half-spaces with the generator's presolve, goal LP + QP in the order of the previous step's
@@ -342,7 +342,7 @@ def moving_crowd(device, steps=60, warm=20):
     N = 2048
     start, goal = workloads.swapping_pairs(cfg, N)
     sim = ClosedLoop(cfg, start, goal, radius=0.15, downwash=2.0, max_vel=1.0, max_acc=2.0, waypoint_step=0.5, device=device,
-                     neighbours="device", nbr_pitch=256, corridor_margin=0.5, prune=True, order_hint=True)
+                     neighbours="device", nbr_pitch=256, corridor_margin=0.5, prune=True, order_hint=True, heavy_ranks=heavy_ranks)
     sim.keep_inputs = True
     for _ in range(warm):
         sim.step()

@@ -431,7 +431,7 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
     w.lane = (int)threadIdx.x & 63;
     int cls_in = 0;
     const int ag = a.order ? a.order[slot] : (a.mask_in ? masked_agent(a, slot, w.lane, cls_in) : (a.hint[0] ? hinted_agent(a, slot, w.lane) : slot));
-    if (a.mask_zero && slot < a.n_blocks && threadIdx.x < 8) a.mask_zero[(size_t)slot * 8 + threadIdx.x] = 0ull;  // (slot < n_blocks: block `slot`'s first wavefront)
+    if (a.mask_zero && slot < a.n_blocks) a.mask_zero[(size_t)slot * 8 + (threadIdx.x & 7)] = 0ull;  // (uniform condition; every lane stores, eight lanes to a word: no lane-guarded store)
     if (ag < 0 || ag >= a.n_agents) return;  // the whole workgroup
     // the agent's rows: [rb, rb + nrows_ag)
     const int rb = a.row_pitch > 0 ? ag * a.row_pitch : a.row_offsets[ag];
@@ -459,14 +459,29 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
             c.nso = SLK == 0 ? 0 : nso;
             c.phi = kp.phi;
             c.unit0 = DIMS > 0 ? c.nxc : 0;
+            // this helper's share of the rows beyond the register cache: its part of the rows the planning wavefront has decoded into
+            // LDS (round 5: the helpers price those too -- a crowd agent's pass is mostly those), its part of the rows in HBM
+            const int Kl = K < Kc + lay.cold_cap ? K : Kc + lay.cold_cap;
+            c.Kc = Kl;  // (the skip flags are one bit per row from Kl on)
             int jb, je;
             cold_rows_share(Kc, K, wave, WPA, jb, je);
+            const int ljb = jb < Kl ? jb : Kl, lje = je < Kl ? je : Kl, hjb = jb > Kl ? jb : Kl, hje = je > Kl ? je : Kl;
+            LdsRows lr;
+            {
+                const double *base = reinterpret_cast<const double *>(smem);
+                lr.rhs = base + lay.oCold; lr.iw = lr.rhs + lay.cold_cap;
+                lr.nx = reinterpret_cast<const float *>(lr.iw + lay.cold_cap); lr.ny = lr.nx + lay.cold_cap; lr.nz = lr.ny + lay.cold_cap;
+                lr.key = reinterpret_cast<const uint32_t *>(lr.nz + lay.cold_cap);
+                lr.x = c.x; lr.Kc = Kc; lr.P = c.P; lr.M = c.M; lr.dim = c.dim; lr.nxc = c.nxc; lr.unit0 = c.unit0;
+            }
             for (;;) {
                 __syncthreads();  // pass_begin (or the end of the solve)
                 if (uniform_f64(w.mail[0]) != 0.0) break;  // every lane reads the same word
                 c.tNN = kp.tabNN + (size_t)((int)uniform_f64(w.mail[1]) - 1) * c.P;
                 WaveGpu::Reg<double> best;
-                best.v = cold_rows_lane_best<4>(c, w.lane, jb, je, 0.0);
+                double least = 0.0;  // (the helpers price all of their shares in every pass)
+                best.v = lds_rows_lane_best<SLK != 0>(lr, w.lane, ljb, lje, 0.0, least);
+                best.v = cold_rows_lane_best<4>(c, w.lane, hjb, hje, best.v, least);
                 const double top = w.max_pos(best);
                 w.mail[1 + wave] = top;  // every lane, the same word, the same value
                 __syncthreads();  // pass_end
@@ -1308,14 +1323,15 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
     // ... or from the class masks the previous step's launch left behind (dlscqp_device_batch.hint_mask_in): the same slots
     a.mask_in = nullptr; a.mask_out = nullptr; a.mask_zero = nullptr;
     if (b->hint_mask_in || b->hint_mask_out || b->hint_mask_zero) {
-        if (b->launch_count > 0) { g_last_error = "hint_mask_* cannot be combined with launch_offset / launch_count"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+        // (launch_offset / launch_count then count LAUNCH SLOTS of the 64 n_blocks: slots [0, R n_blocks) are every block's R most
+        // expensive agents -- a caller can plan those in a launch of their own, e.g. one small enough to get helper wavefronts)
         if ((b->hint_mask_out && (b->hint_mask_out == b->hint_mask_in || b->hint_mask_out == b->hint_mask_zero)) ||
             (b->hint_mask_in && b->hint_mask_in == b->hint_mask_zero)) { g_last_error = "hint_mask_in / _out / _zero must be three different tables"; return DLSCQP_ERR_INVALID_ARGUMENT; }
         a.mask_out = reinterpret_cast<unsigned long long *>(b->hint_mask_out);
         a.mask_zero = reinterpret_cast<unsigned long long *>(b->hint_mask_zero);
         if (b->hint_mask_in && !b->agent_order && !a.hint[0]) {
             a.mask_in = reinterpret_cast<const unsigned long long *>(b->hint_mask_in);
-            a.n_slots_launch = 64 * a.n_blocks;
+            if (b->launch_count <= 0) a.n_slots_launch = 64 * a.n_blocks;
             if (a.n_blocks > 1 && (unsigned long long)a.n_slots_launch * (unsigned long long)a.n_blocks < (1ull << 32))
                 a.blocks_magic = (unsigned int)(((1ull << 32) + (unsigned long long)a.n_blocks - 1) / (unsigned long long)a.n_blocks);
         }
@@ -1343,12 +1359,12 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
     kernel_t kfn = wpa ? kc.fn_wpa : (wide ? kc.fn_wide : kc.fn);
     if (!ws_hbm) {
         // Rows beyond the register cache: what the working set leaves of the agent's LDS budget holds them (gi_core.hpp: "rows in
-        // LDS"); not in the builds with helper wavefronts (their helpers split those rows and price them from HBM).
+        // LDS"); in the builds with helper wavefronts too (round 5: the helpers price their shares of those rows from LDS).
         // DLSCQP_ROWS_IN_LDS=0: every such row from HBM in every pass, as before round 4 (tests).
         static const bool rows_in_lds = !(getenv("DLSCQP_ROWS_IN_LDS") && getenv("DLSCQP_ROWS_IN_LDS")[0] == '0');
         const bool one_per_simd = wide || (kc.id == 3 && DQ_M10_2D_ONE) || kc.id == 4 || kc.id == 5;
         const int max_per_cu = wpa ? (DQ_WPA_OCC * 4) / DQ_WPA : (one_per_simd ? 4 : 4 * DQ_PLAN_OCC);
-        const LayoutChoice lc = choose_layout(c->kp, b, kc, a.n_slots_launch, max_per_cu < 1 ? 1 : max_per_cu, rows_in_lds && !wpa);
+        const LayoutChoice lc = choose_layout(c->kp, b, kc, a.n_slots_launch, max_per_cu < 1 ? 1 : max_per_cu, rows_in_lds);
         lay = lc.lay;
         if (lay.bytes > LDS_LIMIT) { g_last_error = "working set exceeds the LDS of a CU"; return DLSCQP_ERR_UNSUPPORTED; }  // (ws_hbm above rules it out)
         if (lay.spill_doubles > 0) {

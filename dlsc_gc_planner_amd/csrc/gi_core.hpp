@@ -140,6 +140,9 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
 // files (3-D M=5: f=13; 2-D / 3-D M=10: f=28) with register caches sized to the row counts, with and without
 // slack (dynamic) obstacles; runtime-shape instantiations for everything else.  One list for the HIP launcher
 // and for the lane-serial test build.
+#ifndef DQ_C3_KU  // register cache of the 2-D, M = 10 instantiation: it runs one wavefront per SIMD (dlscqp.hip: DQ_KERNEL_ATTR) and has the
+#define DQ_C3_KU 12  // whole register file -- 768 rows of a crowd's ~1 035 in (accumulation) registers (3 / 8 / 12: flown crowd 0.311 / 0.306 / 0.292 ms)
+#endif
 #ifndef DQ_G2_KU  // register caches of the two-register runtime-shape instantiation (also the one with HBM working-set variants)
 #define DQ_G2_KU 2
 #define DQ_G2_SU 6
@@ -148,7 +151,7 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
     X(0, 1, 3, 13, 5, 2, 0, 0)   \
     X(1, 1, 3, 13, 5, 4, 4, 0)   \
     X(2, 1, 3, 13, 5, 4, 4, -1)  \
-    X(3, 1, 2, 28, 10, 3, 3, 0)  \
+    X(3, 1, 2, 28, 10, DQ_C3_KU, 3, 0)  \
     X(4, 2, 3, 28, 10, 2, 4, 0)  \
     X(5, 2, 3, 28, 10, 2, 4, -1) \
     X(6, 1, 0, 0, 0, 2, 6, -1)   \
@@ -276,7 +279,7 @@ DQ_FN T pick3(const T *v, int k) {
 // The rows of an agent that do not fit the register cache of the wavefront that plans it ("cold" rows): priced straight from
 // HBM, CB blocks of 64 rows per trip -- first every row's record, then the loads that depend on it (control points, scaling,
 // slack variable), then the arithmetic.  One lane's share of rows [jb, je) of the agent's K rows; returns the lane's best
-// tagged pivot score (tag_score).  Shared by the planning wavefront and the HELPER wavefronts of a workgroup that only
+// tagged pivot score (tag_score); `least` = min(least, the smallest scaled slack -score the lane saw).  Shared by the planning wavefront and the HELPER wavefronts of a workgroup that only
 // price cold rows (dlscqp.hip: WPA > 1).
 struct ColdRows {
     const float *nx, *ny, *nz, *px, *py, *pz;  // the agent's rows (RowsView + row_begin)
@@ -288,7 +291,7 @@ struct ColdRows {
     int K, Kc, P, M, dim, nxc, nso, phi, unit0;
 };
 template <int CB>
-DQ_FN double cold_rows_lane_best(const ColdRows &c, int l, int jb, int je, double bs) {
+DQ_FN double cold_rows_lane_best(const ColdRows &c, int l, int jb, int je, double bs, double &least) {
     constexpr int n1 = 6;
     for (int j0 = jb; j0 < je; j0 += 64 * CB) {  // uniform trip count
         uint32_t key[CB];
@@ -344,6 +347,7 @@ DQ_FN double cold_rows_lane_best(const ColdRows &c, int l, int jb, int je, doubl
             double qv = v * DQ_RSQRT(wsq > 0 ? wsq : 1.0);
             DQ_KEEP(qv);
             const double sc = (inm[u] & (wsq > 0)) ? qv : -1.0;
+            least = -sc < least ? -sc : least;
             bs = DQ_SCORE_MAX(bs, tag_score(sc, (uint32_t)(c.unit0 + (j < je ? j : je - 1)) << 3));
         }
     }
@@ -356,6 +360,65 @@ DQ_FN void cold_rows_share(int Kc, int K, int wave, int nw, int &jb, int &je) {
     je = Kc + 64 * per * (wave + 1);
     jb = jb < K ? jb : K;
     je = je < K ? je : K;
+}
+
+// The rows right behind the register cache, decoded once into the working set ("rows in LDS": right-hand side, pivot scaling, normal,
+// key -- 32 bytes a row): one lane's share of rows [jb, je) of them (global row numbers; the first row in LDS is row Kc), two blocks
+// of 64 a trip.  Shared by the planning wavefront and the helper wavefronts, like cold_rows_lane_best.
+struct LdsRows {
+    const double *rhs, *iw;
+    const float *nx, *ny, *nz;
+    const uint32_t *key;
+    const double *x;  // control points and slack variables
+    int Kc, P, M, dim, nxc, unit0;
+};
+template <bool HAS_SLACK>
+DQ_FN double lds_rows_lane_best(const LdsRows &r, int l, int jb, int je, double bs, double &least) {
+    constexpr int n1 = 6;
+    for (int j0 = jb; j0 < je; j0 += 128) {  // uniform trip count
+        double xv[2][4], rh[2], iwv[2];
+        float nv[2][3];
+        uint32_t kq[2];
+        int jr[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int j = j0 + 64 * u + l;
+            jr[u] = (j < je ? j : je - 1) - r.Kc;
+            kq[u] = r.key[jr[u]];
+            rh[u] = r.rhs[jr[u]]; iwv[u] = r.iw[jr[u]];
+            nv[u][0] = r.nx[jr[u]]; nv[u][1] = r.ny[jr[u]]; nv[u][2] = r.nz[jr[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            DQ_KEEP(kq[u]);
+            const int m = kq[u] & 0xFF, p = m * n1 + (int)((kq[u] >> 8) & 0xF);
+            const uint32_t sl = kq[u] >> 16;
+            xv[u][0] = r.x[p]; xv[u][1] = r.x[r.P + p]; xv[u][2] = r.dim == 3 ? r.x[2 * r.P + p] : 0.0;
+            if (HAS_SLACK) {  // (read by every lane through a valid index, then selected: no lane-guarded load)
+                const bool has_slack = sl != 0xFFFFu;
+                double xs = r.x[r.nxc + (has_slack ? (int)sl * r.M + m : 0)];
+                DQ_KEEP(xs);
+                xv[u][3] = has_slack ? xs : 0.0;
+            } else {
+                xv[u][3] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) { DQ_KEEP(xv[u][0]); DQ_KEEP(xv[u][1]); DQ_KEEP(xv[u][2]); DQ_KEEP(xv[u][3]); DQ_KEEP(rh[u]); DQ_KEEP(iwv[u]); }
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            double val = (double)nv[u][0] * xv[u][0];
+            val = fma((double)nv[u][1], xv[u][1], val);
+            if (r.dim == 3) val = fma((double)nv[u][2], xv[u][2], val);
+            if (HAS_SLACK) val -= xv[u][3];
+            const double v = (rh[u] - VIOL_TOL) - val;
+            // (a lane past the last row has priced the last row again: the same score under the same code)
+            const double sc = v * iwv[u];
+            least = -sc < least ? -sc : least;
+            bs = DQ_SCORE_MAX(bs, tag_score(sc, (uint32_t)(r.unit0 + r.Kc + jr[u]) << 3));
+        }
+    }
+    return bs;
 }
 
 // RC: registers per per-lane vector over the active rows (at most 64 RC of them; the whitened dimension r bounds their number).
@@ -1333,9 +1396,22 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     cold.nx = Rnx; cold.ny = Rny; cold.nz = Rnz; cold.px = Rpx; cold.py = Rpy; cold.pz = Rpz; cold.d = Rd; cold.key = Rkey;
     cold.flag = row_flag; cold.x = x; cold.tNN = tNN; cold.sigma = kp.sigma;
     cold.K = K; cold.Kc = Kl; cold.P = P; cold.M = M; cold.dim = dim; cold.nxc = nxc; cold.nso = nso; cold.phi = kp.phi; cold.unit0 = UL0;
-    int cold_jb, cold_je;
-    cold_rows_share(Kl, K, 0, w.nw, cold_jb, cold_je);  // (helper wavefronts: no rows in LDS, Kl = Kc)
+    // this wavefront's share of the rows beyond the register cache [Kc, K) (all of them unless helper wavefronts price the rest):
+    // its part in LDS [lds_jb, lds_je), its part in HBM [cold_jb, cold_je)
+    int share_jb, share_je;
+    cold_rows_share(Kc, K, 0, w.nw, share_jb, share_je);
+    const int lds_jb = share_jb < Kl ? share_jb : Kl, lds_je = share_je < Kl ? share_je : Kl;
+    const int cold_jb = share_jb > Kl ? share_jb : Kl, cold_je = share_je > Kl ? share_je : Kl;
+    LdsRows ldsr;
+    ldsr.rhs = lrhs; ldsr.iw = liw; ldsr.nx = lnx; ldsr.ny = lny; ldsr.nz = lnz; ldsr.key = lkey; ldsr.x = x;
+    ldsr.Kc = Kc; ldsr.P = P; ldsr.M = M; ldsr.dim = dim; ldsr.nxc = nxc; ldsr.unit0 = UL0;
 
+    // the path x has gone, in the metric of the Hessian and rounded up; per group of rows beyond the register cache the length at which
+    // the group has to be priced again (see the pricing pass)
+    double path = 0.0;
+    RegD expiry;
+    if (!ALL_CACHED) w.each([&](int l) { expiry.at(l) = -1e300; });
+    auto expiry_of = [&](double at, double least) { return least > 0 ? at + least * (1.0 - 1e-6) - 1e-7 : -1e300; };
     for (; !(SCREEN && screened);) {  // (a screened agent has nothing to do here: straight to the read-out)
         // ---- most violated inactive row ---------------------------------------------------------
         // Every candidate row: violation v = limit - value (or value - limit), pivot score (v - VIOL_TOL) / |N'a| tagged with
@@ -1454,51 +1530,6 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 DQ_KEEP(qv);
                 bs = DQ_SCORE_MAX(bs, tag_score(cand ? qv : -1.0, (uint32_t)(US0 + sc2) << 3));
             }
-            // rows beyond the register cache: this wavefront's share of them (all of them unless helper wavefronts price
-            // the rest: W::nw > 1)
-            if (!ALL_CACHED)
-                for (int j0 = Kc; j0 < Kl; j0 += 128) {  // rows in LDS, two blocks of 64 a trip (uniform trip count)
-                    double xv[2][4], rh[2], iwv[2];
-                    float nv[2][3];
-                    uint32_t kq[2];
-                    int jr[2];
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const int j = j0 + 64 * u + l;
-                        jr[u] = (j < Kl ? j : Kl - 1) - Kc;
-                        kq[u] = lkey[jr[u]];
-                        rh[u] = lrhs[jr[u]]; iwv[u] = liw[jr[u]];
-                        nv[u][0] = lnx[jr[u]]; nv[u][1] = lny[jr[u]]; nv[u][2] = lnz[jr[u]];
-                    }
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        DQ_KEEP(kq[u]);
-                        const int m = kq[u] & 0xFF, p = m * n1 + (int)((kq[u] >> 8) & 0xF);
-                        const uint32_t sl = kq[u] >> 16;
-                        xv[u][0] = x[p]; xv[u][1] = x[P + p]; xv[u][2] = dim == 3 ? x[2 * P + p] : 0.0;
-                        if (SLK != 0) {  // (read by every lane through a valid index, then selected: no lane-guarded load)
-                            const bool has_slack = sl != 0xFFFFu;
-                            double xs = x[nxc + (has_slack ? (int)sl * M + m : 0)];
-                            DQ_KEEP(xs);
-                            xv[u][3] = has_slack ? xs : 0.0;
-                        } else {
-                            xv[u][3] = 0.0;
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 2; u++) { DQ_KEEP(xv[u][0]); DQ_KEEP(xv[u][1]); DQ_KEEP(xv[u][2]); DQ_KEEP(xv[u][3]); DQ_KEEP(rh[u]); DQ_KEEP(iwv[u]); }
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        double val = (double)nv[u][0] * xv[u][0];
-                        val = fma((double)nv[u][1], xv[u][1], val);
-                        if (dim == 3) val = fma((double)nv[u][2], xv[u][2], val);
-                        if (SLK != 0) val -= xv[u][3];
-                        const double v = (rh[u] - VIOL_TOL) - val;
-                        // (a lane past the last row has priced the last row again: the same score under the same code)
-                        bs = DQ_SCORE_MAX(bs, tag_score(v * iwv[u], (uint32_t)(UL0 + Kc + jr[u]) << 3));
-                    }
-                }
-            if (!ALL_CACHED) bs = cold_rows_lane_best<CB>(cold, l, cold_jb, cold_je, bs);
             if (!ALL_CACHED)
             for (int s0 = Sc; s0 < n_slots; s0 += 64) {
                 const int s = s0 + l;
@@ -1524,6 +1555,41 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             }
             best.at(l) = bs;
         });
+        if (!ALL_CACHED) {
+            // Rows beyond the register cache: this wavefront's share of them (all of them unless helper wavefronts price the rest:
+            // W::nw > 1), in groups of one trip each -- 128 rows in LDS, 64 CB rows in HBM.  A group is LEFT OUT while none of its
+            // rows can be violated: the scaled score (limit - a.x) / |N'a| of a row changes by at most |dx|_H = t sqrt(a.dx) in a
+            // step x += t dx (Cauchy-Schwarz in the metric of the Hessian; a.dx = dx' H dx for the projected direction), so a group
+            // whose smallest scaled slack was s when the path of x was p long has no violated row before the path reaches p + s.
+            // Lane g of `expiry` keeps that length for group g (groups from 64 on are priced in every pass); a row that comes
+            // back into the model (a drop) resets all of them.  Same winner as the full pass: a group that is left out holds no
+            // candidate.  (In a crowd the heavy agents price 36 % of their groups: tests/tools/crowd_skip_study.py.)
+            const int n_lt = (lds_je - lds_jb + 127) / 128;
+            for (int g = 0; g < n_lt; g++) {  // rows in LDS
+                if (g < 64 && path < w.bcast(expiry, g)) continue;  // uniform
+                const int j0 = lds_jb + 128 * g, j1 = j0 + 128 < lds_je ? j0 + 128 : lds_je;
+                RegD ls;
+                w.each([&](int l) {
+                    double least = 1e300;
+                    best.at(l) = lds_rows_lane_best<SLK != 0>(ldsr, l, j0, j1, best.at(l), least);
+                    ls.at(l) = least;
+                });
+                const double e = expiry_of(path, w.min(ls));
+                w.each([&](int l) { expiry.at(l) = l == g ? e : expiry.at(l); });
+            }
+            for (int g = n_lt, j0 = cold_jb; j0 < cold_je; g++, j0 += 64 * CB) {  // rows in HBM
+                if (g < 64 && path < w.bcast(expiry, g)) continue;  // uniform
+                const int j1 = j0 + 64 * CB < cold_je ? j0 + 64 * CB : cold_je;
+                RegD ls;
+                w.each([&](int l) {
+                    double least = 1e300;
+                    best.at(l) = cold_rows_lane_best<CB>(cold, l, j0, j1, best.at(l), least);
+                    ls.at(l) = least;
+                });
+                const double e = expiry_of(path, w.min(ls));
+                w.each([&](int l) { expiry.at(l) = l == g ? e : expiry.at(l); });
+            }
+        }
         double top = w.max_pos(best);  // best pivot score over all violated rows, with the row's code
         if (!ALL_CACHED && w.nw > 1) top = w.pass_end(top);  // ... the helpers' included
         w.stamp(2);                       // row scan + arg-max
@@ -2186,6 +2252,8 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     }
                 });
                 viol -= t * dd2;
+                // |t dx|_H = t sqrt(a.dx); single precision and 2 % on top (a.dx of a nearly dependent row carries its rounding)
+                if (!ALL_CACHED) path += 1.02 * t * (double)sqrtf((float)dd2);
             }
             w.each([&](int l) {
 #pragma unroll
@@ -2254,6 +2322,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 // ---- drop active row ldrop: delete column l of R, restore the triangle with Givens ----
                 const int lcol = ldrop;
                 set_skip(DQ_BCI(act, lcol), false, DQ_BC(a_rhs, lcol));
+                if (!ALL_CACHED) w.each([&](int l) { expiry.at(l) = -1e300; });  // the row is priced again: its group, whichever it is
                 // entry `idx` of record k (k uniform): from the working set or from the spill record
                 auto rec_ld = [&](int k, int idx) -> double {
                     if (k < qz) return colw[k * cs + idx];

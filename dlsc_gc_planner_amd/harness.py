@@ -117,7 +117,7 @@ class SpinObstacles:
 class ClosedLoop:
     def __init__(self, cfg, start, goal, radius=0.15, downwash=2.0, max_vel=1.0, max_acc=2.0, nominal_velocity=1.0,
                  waypoint_step=0.5, device=0, dyn=None, result_csv=None, world=None, neighbours=None, nbr_pitch=96,
-                 corridor_margin=None, prune=False, order_hint=False, knn=None, tail=None):
+                 corridor_margin=None, prune=False, order_hint=False, knn=None, tail=None, heavy_ranks=0):
         """dyn: None or dict(position [D,3], velocity [D,3], radius, max_acc, downwash [D], size_prediction, horizon) --
         obstacles that keep their velocity (obstacle.hpp: straight-line dynamic obstacles).  result_csv: path of a
         result file in the reference's layout.  world: None or dict(boxes [K,6] centre+size, resolution, grid_resolution)
@@ -187,6 +187,14 @@ class ClosedLoop:
         self.sfc = None
         self.box_margin = None
         self.order_hint = bool(order_hint)
+        # heavy_ranks = R > 0 (with order_hint): every block's R most expensive agents -- launch slots [0, R n_blocks) of the class-mask
+        # order -- are planned by a launch of their own on a second stream, beside the launch of the others: small enough
+        # (<= 512 workgroups) to get the build with helper wavefronts, whose helpers price the rows in LDS.  An experiment, off by
+        # default: measured on the flown crowd it LOSES (0.31 -> 0.35-0.37 ms per step) -- the previous step's iteration counts do
+        # not say who the slowest agent of this step will be (tests/tools/crowd_tail.py), so the launch of the others is as long
+        # as the whole launch was.
+        self.heavy_ranks = int(heavy_ranks) if order_hint else 0
+        self._heavy_stream = None
         self.comm_neighbours = False
         self.slack_threshold = float(world.get("slack_threshold", 0.1)) if world is not None else 0.1  # param.slack_threshold
         if world is not None:
@@ -431,7 +439,23 @@ class ClosedLoop:
             # launch order found by the kernel itself from the class masks the previous step's launch left behind
             # (dlscqp_device_batch.hint_mask_*): three tables in rotation
             self.batch.rotate_hint_masks()
-        self.batch.launch(True, True)
+        if self.heavy_ranks > 0:
+            torch = self.torch
+            nb = (self.N + 63) // 64
+            ordered = bool(self.batch.c.hint_mask_in)
+            total = 64 * nb if ordered else self.N
+            h = min(self.heavy_ranks * nb, total)
+            cur = torch.cuda.current_stream(self.dev)
+            if self._heavy_stream is None:
+                self._heavy_stream = torch.cuda.Stream(self.dev)
+            side = self._heavy_stream
+            side.wait_stream(cur)
+            self.batch.launch(True, True, stream=side, offset=0, count=h)
+            if total > h:
+                self.batch.launch(True, True, stream=cur, offset=h, count=total - h)
+            cur.wait_stream(side)
+        else:
+            self.batch.launch(True, True)
         self._stage("state_update_time")
         # fail-safe: keep the shifted previous plan (traj_planner.cpp:776); sub-goal from the LP (traj_planner.cpp:494);
         # doStep of the next iteration: state = desired_traj.getStateAt(dt) = start of segment 1, float32 differences

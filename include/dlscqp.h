@@ -250,7 +250,10 @@ typedef struct dlscqp_device_batch {
                                        hint_mask_zero: a table this launch clears -- hint_mask_out must be all zero when its launch
                                        starts, so name here the table a LATER launch will write (three tables in rotation: in = what
                                        the previous launch wrote, out, zero = the next launch's out).  Used when agent_order is NULL
-                                       and hint_steps is 0; not with launch_offset / launch_count.  Results do not depend on it.   */
+                                       and hint_steps is 0.  With launch_offset / launch_count the range counts LAUNCH SLOTS of the
+                                       64 n_blocks: slots [0, R n_blocks) are every block's R most expensive agents, which a caller may
+                                       plan in a launch of their own beside the others' (small enough for helper wavefronts: the
+                                       flown crowd).  Results do not depend on it.                                                 */
     uint64_t *hint_mask_out;
     uint64_t *hint_mask_zero;
 } dlscqp_device_batch;

@@ -29,7 +29,16 @@ struct SparseRow {   // a . x >= rhs
     double cf[4];
     int n;
     double rhs, iw, scale;  // pivot scaling 1 / |N'a|, factor back to the reference's row scaling
+    int src;                // the agent's input row it came from, -1: a row of the model's own
 };
+
+#ifdef SKIP_STUDY
+// tests/tools/crowd_skip_study.py: how many blocks of 64 input rows a pricing pass could leave out if it kept, per block, the smallest
+// scaled slack it saw and the length of the path x has gone since (a scaled slack changes by at most |dx|_H = t sqrt(a.dx) per step)
+struct SkipStudy { double passes, blocks, priced, blocks_late, priced_late, agents; };
+SkipStudy g_study;
+int g_study_first = 3, g_study_gran = 1;
+#endif
 
 struct Problem {
     const HostTables *tb;
@@ -169,7 +178,7 @@ struct Solver {
                 wsq += sig2(R.slack * M + m);
             }
             if (!(wsq > 0)) continue;
-            a.rhs = rhs; a.iw = 1.0 / sqrt(wsq); a.scale = 1.0;
+            a.rhs = rhs; a.iw = 1.0 / sqrt(wsq); a.scale = 1.0; a.src = j;
             rows.push_back(a);
         }
         for (int s = 0; s < kp.n_slots; s++) {
@@ -184,13 +193,14 @@ struct Solver {
                 a.rhs = side == 0 ? blo[sl.bsel] : -bhi[sl.bsel];
                 a.iw = SIW[s];
                 a.scale = sl.bsel == dim * M ? 1.0 / kp.vel_scale : (sl.bsel == dim * M + 1 ? 1.0 / kp.acc_scale : 1.0);
+                a.src = -1;
                 rows.push_back(a);
             }
         }
         for (int s = 0; s < nslk; s++) {  // eps <= 0 (:276)
             if (!(kp.sigma[s % M] > 0)) continue;
             SparseRow a;
-            a.n = 1; a.idx[0] = nxc + s; a.cf[0] = -1.0; a.rhs = 0.0; a.iw = 1.0 / kp.sigma[s % M]; a.scale = 1.0;
+            a.n = 1; a.idx[0] = nxc + s; a.cf[0] = -1.0; a.rhs = 0.0; a.iw = 1.0 / kp.sigma[s % M]; a.scale = 1.0; a.src = -1;
             rows.push_back(a);
         }
         const int R_ = (int)rows.size();
@@ -202,7 +212,35 @@ struct Solver {
         int q = 0, iters = 0, n_add = 0, n_drop = 0, status = DLSCQP_OK;
         const int max_iter = 20 * (r + 8) + 200;
         auto value = [&](const SparseRow &a) { double v = 0; for (int e = 0; e < a.n; e++) v += a.cf[e] * x[a.idx[e]]; return v; };
+#ifdef SKIP_STUDY
+        const int nblk = (K + 64 * g_study_gran - 1) / (64 * g_study_gran);
+        std::vector<double> bmin(nblk, -1e300), bmark(nblk, 0.0);
+        double path = 0.0;
+        int pass_no = 0;
+        g_study.agents += 1;
+#endif
         for (;;) {
+#ifdef SKIP_STUDY
+            {
+                g_study.passes += 1;
+                for (int b = g_study_first / g_study_gran; b < nblk; b++) {
+                    g_study.blocks += 1;
+                    if (pass_no >= 2) g_study.blocks_late += 1;
+                    if (bmin[b] - (path - bmark[b]) > 1e-7) continue;  // no row of the block can be violated
+                    g_study.priced += 1;
+                    if (pass_no >= 2) g_study.priced_late += 1;
+                    double mn = 1e300;
+                    for (int j = 0; j < R_; j++) {
+                        if (rows[j].src < 0 || rows[j].src / (64 * g_study_gran) != b || skip[j]) continue;
+                        double v = 0;
+                        for (int e = 0; e < rows[j].n; e++) v += rows[j].cf[e] * x[rows[j].idx[e]];
+                        mn = std::min(mn, (v - (rows[j].rhs - VIOL_TOL)) * rows[j].iw);
+                    }
+                    bmin[b] = mn; bmark[b] = path;
+                }
+                pass_no++;
+            }
+#endif
             int ip = -1;
             double best = 0.0;
             for (int j = 0; j < R_; j++) {
@@ -285,6 +323,9 @@ struct Solver {
                 if (!dependent) {
                     for (int j = 0; j < nx; j++) x[j] += t * dx[j];
                     viol -= t * dd2;
+#ifdef SKIP_STUDY
+                    path += 1.02 * t * sqrt(dd2);
+#endif
                 }
                 for (int k = 0; k < q; k++) dual[k] -= t * rv[k];
                 uq += t;
@@ -301,6 +342,9 @@ struct Solver {
                     // drop active row ldrop: delete row l of S, rotate columns (t, t+1) so that row l's entries are swept away
                     const int l = ldrop;
                     skip[act[l]] = 0;
+#ifdef SKIP_STUDY
+                    if (rows[act[l]].src >= 0) bmin[rows[act[l]].src / (64 * g_study_gran)] = -1e300;  // back among the priced rows with slack 0
+#endif
                     double carry = 0;  // running |s_l..s_t|, the first pivot keeps its sign
                     for (int t2i = l; t2i < q - 1; t2i++) {
                         const double a0 = t2i == l ? S[(size_t)l * r + l] : carry, b0 = S[(size_t)l * r + t2i + 1];
@@ -362,6 +406,14 @@ struct Solver {
 };
 
 }  // namespace
+
+#ifdef SKIP_STUDY
+extern "C" void native_study(int first_block, int gran, double *out) {
+    if (out) memcpy(out, &g_study, sizeof(g_study));
+    g_study = SkipStudy();
+    g_study_first = first_block; g_study_gran = gran;
+}
+#endif
 
 // one agent after another: the interface of tests/emul's emul_plan_batch
 extern "C" int native_plan_batch(const dlscqp_config *cfg, int n_agents, const dlscqp_agent *agents, const int64_t *row_offsets,

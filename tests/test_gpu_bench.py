@@ -31,7 +31,7 @@ def test_single_gpu_line_has_the_contract_fields(gpu_required):
     assert d["n_gpus"] == 1 and d["steps"] == 6 and d["unit"] == "QP/s" and d["dtype"] == "f64" and d["vs_baseline"] is None
     assert d["config"]["agents_per_gpu"] == 512 and d["value"] > 0
     r = d["roofline"]
-    assert r["bound"] == "valu_issue" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["bound"] == "hbm" and r["limiter"] and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     # the eight swarms in four groups, each group on its own stream: four launches of 128 agents side by side
     assert r["qp_per_launch"] == 128 and r["launches_per_step"] == 4 and d["config"]["swarm_groups"] == 4
     # the line's roofline figure is the STEP's: all agents' algorithmic bytes over ms_per_step; the per-launch figure and the
@@ -40,7 +40,8 @@ def test_single_gpu_line_has_the_contract_fields(gpu_required):
     assert abs(r["achieved_if_launches_overlapped_fully"] - 4 * r["achieved_one_launch"]) < 1e-9 * r["achieved_one_launch"] * 4
     assert 0 < r["effective_concurrency"] <= 4.0 + 1e-9
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["port_kind"] == "lane-serial port" and c["cores"] >= 1 and c["value"] > 0 and c["oracle_qp_per_s_one_core"] > 0
+    assert c["kind"] == "port" and c["port_kind"] == "native scalar solver" and c["cores"] >= 1 and c["value"] > 0 and c["oracle_qp_per_s_one_core"] > 0
+    assert c["value"] == c["native_qp_per_s"] and c["lane_serial_qp_per_s"] > 0  # the CPU-shaped solver is the baseline, the lane-serial port beside it
     assert c["value"] > 3 * c["oracle_qp_per_s_one_core"]  # the kernel's algorithm, not the dense checker
     assert d["config"]["distinct_batches"] == 4 and d["config"]["ms_per_step_no_order_hint"] > 0 and d["config"]["ms_per_step_host_order"] > 0
     assert d["config"]["ms_per_step_sorted_on_device"] > 0  # round 3's sort kernels, timed beside the kernel's own order

@@ -78,7 +78,8 @@ def test_helper_wavefronts_change_nothing(gpu_required, tmp_path, name):
     res = {}
     # ... and without helpers the rows right behind the register cache are decoded once into LDS and priced from there (round 4,
     # gi_core.hpp: "rows in LDS"; DLSCQP_ROWS_IN_LDS=0: from HBM in every pass, as the helpers price theirs): the same bits again
-    for tag, wpa, in_lds in (("1", "1", "1"), ("1-hbm", "1", "0"), ("4", "4", "1")):
+    # (round 5: the helpers price their shares of the rows in LDS as well; "4-hbm": helpers with every row from HBM, as before)
+    for tag, wpa, in_lds in (("1", "1", "1"), ("1-hbm", "1", "0"), ("4", "4", "1"), ("4-hbm", "4", "0")):
         out = str(tmp_path / ("wpa%s.npz" % tag))
         env = dict(os.environ, DLSCQP_WPA=wpa, DLSCQP_ROWS_IN_LDS=in_lds)
         r = subprocess.run([sys.executable, "-c", SCRIPT % dict(root=os.path.dirname(here), here=here, name=name), out], env=env,
@@ -89,3 +90,4 @@ def test_helper_wavefronts_change_nothing(gpu_required, tmp_path, name):
     for k in ("status", "goal_status", "goal", "ctrl", "x", "cost", "iters"):
         assert np.array_equal(res["1"][k], res["4"][k]), k
         assert np.array_equal(res["1"][k], res["1-hbm"][k]), k
+        assert np.array_equal(res["1"][k], res["4-hbm"][k]), k
