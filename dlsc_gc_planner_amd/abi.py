@@ -234,6 +234,11 @@ class Advance(C.Structure):
         ("box_min", C.c_float * 3),
         ("box_max", C.c_float * 3),
         ("reserved2_", C.c_int32),
+        ("out_host_pack", C.c_void_p),
+        ("alert_slack_cost", C.c_void_p),
+        ("alert_slack_stride", C.c_int32),
+        ("n_alert_obs", C.c_int32),
+        ("alert_threshold", C.c_double),
     ]
 
 

@@ -2044,6 +2044,17 @@ __global__ __launch_bounds__(64) void dlscqp_advance_kernel(AdvanceArgs g) {
         if (e < E) plan[e] = v[u];  // ... the first write (one wavefront: memory operations in program order)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the new plan is in memory before other lanes' elements are read back
+    if (a.out_host_pack) {  // uniform: the plan and the alerts for the host-side waypoint planner (pinned host memory)
+        float *hp = a.out_host_pack + (size_t)a.n_agents * 6;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = l + 64 * u;
+            if (e < E) hp[(size_t)ag * E + e] = v[u];
+        }
+        hp += (size_t)a.n_agents * E;
+        for (int j = l; j < a.n_alert_obs; j += 64)
+            hp[(size_t)ag * a.n_alert_obs + j] = a.alert_slack_cost[(size_t)ag * a.alert_slack_stride + j] > a.alert_threshold ? 1.0f : 0.0f;
+    }
     if (a.initial_traj) {
         float *init = a.initial_traj + (size_t)ag * E;
 #pragma unroll
@@ -2083,6 +2094,10 @@ __global__ __launch_bounds__(64) void dlscqp_advance_kernel(AdvanceArgs g) {
         rec->velocity[k] = vel;
         rec->acceleration[k] = acc;
         rec->current_goal_point[k] = cg;
+        if (a.out_host_pack) {
+            a.out_host_pack[(size_t)ag * 3 + k] = p;
+            a.out_host_pack[(size_t)a.n_agents * 3 + (size_t)ag * 3 + k] = cg;
+        }
         if (a.waypoints) {
             rec->next_waypoint[k] = a.waypoints[(size_t)ag * 3 + k];
         } else if (a.desired_goal) {
@@ -2115,6 +2130,11 @@ extern "C" int dlscqp_advance_device(dlscqp_ctx *c, const dlscqp_advance *adv, v
     }
     if (c->M * (c->n + 1) * 3 > 512) { g_last_error = "plans of more than 512 floats are not supported"; return DLSCQP_ERR_UNSUPPORTED; }
     if (adv->out_boxes && !adv->initial_traj) { g_last_error = "out_boxes are the boxes of initial_traj: null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (adv->out_host_pack && adv->n_alert_obs > 0 && (!adv->alert_slack_cost || adv->alert_slack_stride < adv->n_alert_obs)) {
+        g_last_error = "out_host_pack with n_alert_obs > 0 needs alert_slack_cost [n][alert_slack_stride >= n_alert_obs]";
+        return DLSCQP_ERR_INVALID_ARGUMENT;
+    }
+    if (adv->n_alert_obs < 0) { g_last_error = "n_alert_obs < 0"; return DLSCQP_ERR_INVALID_ARGUMENT; }
     (void)hipSetDevice(c->cfg.device);
     AdvanceArgs g;
     g.a = *adv;

@@ -176,6 +176,8 @@ class ClosedLoop:
             self._dyn_dev = torch.stack([f32(dyn["position"]), f32(dyn["velocity"])])
             self.dyn_pos, self.dyn_vel = self._dyn_dev[0], self._dyn_dev[1]
             self._dyn_pin = torch.empty((2, self.D, 3), dtype=torch.float32).pin_memory()
+            # the same states on the host, for the host-side waypoint planner (float32, the same arithmetic as on the device)
+            self._dyn_host = [np.array(dyn["position"], np.float32).reshape(self.D, 3), np.array(dyn["velocity"], np.float32).reshape(self.D, 3)]
         self.gen = self.opt.make_lsc_generator(N, nbr_offsets, nbr_ids, np.full(N, radius), np.full(N, downwash), device=device,
                                                dyn=dyn)
         if neighbours == "device":
@@ -195,6 +197,7 @@ class ClosedLoop:
         # as the whole launch was.
         self.heavy_ranks = int(heavy_ranks) if order_hint else 0
         self._heavy_stream = None
+        self.pack_in_advance = False
         self.comm_neighbours = False
         self.slack_threshold = float(world.get("slack_threshold", 0.1)) if world is not None else 0.1  # param.slack_threshold
         if world is not None:
@@ -271,6 +274,15 @@ class ClosedLoop:
         # (the boxes of a world without obstacles are written by the same kernel, for the step that follows: box_in_advance)
         self.box_in_advance = self.box_margin is not None and os.environ.get("DLSCQP_BOX_IN_ADVANCE", "1") != "0"
         bkw = dict(boxes=self.box_t, box_margin=self.box_margin, box_min=cfg.world_min, box_max=cfg.world_max) if self.box_in_advance else {}
+        if world is not None and isinstance(self.grid, MapfWaypoints) and os.environ.get("DLSCQP_HOST_PACK", "1") != "0":
+            # what the host-side waypoint planner reads (positions, sub-goals, previous plans, collision alerts) is written into
+            # pinned host memory by the step's last kernel: no pack, no device-to-host copy, no unpack (step(): one stream
+            # synchronisation, which the planner needs anyway)
+            E = M * (cfg.n + 1) * 3
+            self._adv_pack = torch.zeros(N * (6 + E + self.D), dtype=torch.float32).pin_memory()
+            self._wp_pin = torch.empty((N, 3), dtype=torch.float32).pin_memory()
+            bkw.update(host_pack=self._adv_pack, alert_obs=self.D, alert_threshold=self.slack_threshold)
+            self.pack_in_advance = True
         self.advance = self.opt.make_advance(self.batch, self.plans, self.cur_goal, self.init_buf,
                                              desired_goal=self.desired_goal if world is None else None,
                                              waypoint_step=waypoint_step if world is None else 0.0,
@@ -288,6 +300,8 @@ class ClosedLoop:
             self.sfc.close()
         if self.csv:
             self.csv.close()
+        if hasattr(getattr(self, "grid", None), "close"):
+            self.grid.close()  # (the host planner's handle; with DLSCQP_MAPF_PROFILE it prints where its time went)
         self.opt.close()
 
     def _waypoints_host(self):
@@ -298,6 +312,22 @@ class ClosedLoop:
             # one device-to-host transfer for everything the planner reads (positions, sub-goals, waypoints, previous plans,
             # obstacle states, slack costs): packed on the device, copied into a pinned buffer
             N, D, E = self.N, self.D, cfg.M * (cfg.n + 1) * 3
+            if self.pack_in_advance and self.seq > 0:
+                # written by dlscqp_advance_device at the end of the previous step (dlscqp_advance.out_host_pack); the waypoints
+                # are where the planner left them (nothing on the device changes them), the obstacle states came from the host
+                torch.cuda.current_stream(self.dev).synchronize()
+                h = self._adv_pack.numpy()
+                o = np.cumsum([0, 3 * N, 3 * N, N * E, N * D])
+                gdyn = None
+                if D:
+                    gdyn = dict(position=self._dyn_host[0], velocity=self._dyn_host[1], radius=self.dyn["radius"], max_acc=self.dyn["max_acc"])
+                alert = (h[o[3]:o[4]].reshape(N, D) > 0.5).astype(np.uint8) if D else None
+                pos = h[o[0]:o[1]].reshape(N, 3)
+                self.mapf_rc = self.grid.step(pos, h[o[1]:o[2]].reshape(N, 3), self._wp_pin.numpy(), h[o[2]:o[3]].reshape(N, cfg.M, cfg.n + 1, 3),
+                                              dyn=gdyn, alert=alert)
+                if self.comm_neighbours:
+                    self._set_comm_neighbours(pos)
+                return self._wp_pin
             parts = [self.pos.reshape(-1), self.cur_goal.reshape(-1), self.wp.reshape(-1), self.plans.reshape(-1)]
             if D:
                 # TrajOptimizer::solve's collision alert (traj_optimizer.cpp:85-106): obstacles whose slack cost in the last
@@ -478,6 +508,8 @@ class ClosedLoop:
             state.append(self.sfc.sfcs)  # the corridor boxes are shifted in place every step
         if self.box_margin is not None:
             state.append(self.box_t)
+        if self.pack_in_advance:
+            state.append(self._adv_pack)  # (pinned host memory: the warm-up's last kernel writes it)
         keep = [t.clone() for t in state]
         side = torch.cuda.Stream(self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
@@ -526,14 +558,17 @@ class ClosedLoop:
             self.dyn_model = None
             self.dyn_pos.fill_(1000.0)
             self.dyn_vel.zero_()
+            self._dyn_host = [np.full((self.D, 3), 1000.0, np.float32), np.zeros((self.D, 3), np.float32)]
         elif self.dyn_model is not None:
             # (computed while the step's kernels run: nothing here waits for them)
             p, v = self.dyn_model.state(self.sim_time)
             pin = self._dyn_pin.numpy()
             pin[0], pin[1] = p, v
+            self._dyn_host = [pin[0].copy(), pin[1].copy()]
             self._dyn_dev.copy_(self._dyn_pin, non_blocking=True)
         elif self.D:
             self.dyn_pos.add_(self.dyn_vel * np.float32(dt))
+            self._dyn_host[0] = self._dyn_host[0] + self._dyn_host[1] * np.float32(dt)
         self.seq += 1
         return self.batch.out_status, self.batch.out_iters
 

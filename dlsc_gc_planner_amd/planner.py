@@ -144,13 +144,16 @@ class BatchTrajOptimizer:
         return SfcGenerator(self, boxes, resolution, world_min, world_max, radius, max_vel, grid_resolution, device)
 
     def make_advance(self, batch, plans, current_goal, initial_traj=None, waypoints=None, desired_goal=None,
-                     waypoint_step=0.0, hold_on_lp_failure=False, boxes=None, box_margin=0.0, box_min=None, box_max=None):
+                     waypoint_step=0.0, hold_on_lp_failure=False, boxes=None, box_margin=0.0, box_min=None, box_max=None,
+                     host_pack=None, alert_obs=0, alert_threshold=0.0):
         """The bookkeeping between two launches of `batch` as one kernel (dlscqp_advance_device): fail-safe, sub-goal,
         state := plan(dt), the next step's agent records and initial trajectory.  All arguments are CUDA tensors that
         stay where they are (float32; plans / initial_traj [N, M, n+1, 3], current_goal / waypoints / desired_goal
         [N, 3]); returns a callable(stream=None).  boxes [N, M, 6] (with initial_traj): the kernel also writes the next step's
         boxes of a world without obstacles -- bounding box of each segment of initial_traj, box_margin wider, cut to
-        [box_min, box_max]."""
+        [box_min, box_max].  host_pack: a PINNED float32 host tensor of 3 N + 3 N + N M (n+1) 3 + N alert_obs elements the kernel
+        writes position | current_goal | plans | alert into (alert: slack cost of obstacle j in the last QP > alert_threshold), for a
+        host-side waypoint planner: no device-to-host copy, the host reads it once the stream has run dry."""
         # dlscqp_advance reads dense arrays: not after DeviceBatch.use_records (one strided record per agent)
         assert batch.c.out_record_stride == 0, "make_advance: the batch writes its plans as records (use_records); dlscqp_advance reads dense arrays"
         a = abi.Advance()
@@ -172,7 +175,16 @@ class BatchTrajOptimizer:
             a.box_margin = float(box_margin)
             for k in range(3):
                 a.box_min[k], a.box_max[k] = float(box_min[k]), float(box_max[k])
-        keep = (batch, plans, current_goal, initial_traj, waypoints, desired_goal, boxes)
+        if host_pack is not None:
+            N, E = batch.n_agents, self.cfg.M * (self.cfg.n + 1) * 3
+            assert host_pack.is_pinned() and host_pack.dtype == self._torch().float32 and host_pack.is_contiguous()
+            assert host_pack.numel() == N * (6 + E + int(alert_obs)), "host_pack: 3 N + 3 N + N M (n+1) 3 + N alert_obs floats"
+            a.out_host_pack = host_pack.data_ptr()
+            if alert_obs:
+                assert batch.out_slack.dtype == self._torch().float64 and batch.out_slack.is_contiguous() and batch.out_slack.shape[1] >= alert_obs
+                a.alert_slack_cost, a.alert_slack_stride = batch.out_slack.data_ptr(), int(batch.out_slack.shape[1])
+                a.n_alert_obs, a.alert_threshold = int(alert_obs), float(alert_threshold)
+        keep = (batch, plans, current_goal, initial_traj, waypoints, desired_goal, boxes, host_pack)
         torch = self._torch()
 
         def run(stream=None, _keep=keep):

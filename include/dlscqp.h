@@ -473,6 +473,18 @@ typedef struct dlscqp_advance {
     float box_margin;
     float box_min[3], box_max[3];
     int32_t reserved2_;
+    /* optional: what a HOST-side waypoint planner reads before the next step (MultiSyncSimulator::decentralizedMAPP,
+     * multi_sync_simulator.cpp:505-560: positions, sub-goals, previous plans, collision alerts), written by this kernel straight
+     * into pinned host memory (hipHostMalloc: the device writes it over the bus), so that the step needs no device-to-host copy
+     * of its own -- the host reads it once `stream` has run dry.  float32, in this order:
+     *   position [n][3] | current_goal [n][3] | plans [n][M][n+1][3] | alert [n][n_alert_obs]
+     * alert = 1.0f where the agent's slack cost of that obstacle in the last QP exceeded alert_threshold (TrajOptimizer::solve's
+     * collision alert, traj_optimizer.cpp:85-106; compared in double), else 0.0f; absent when n_alert_obs is 0.            */
+    float *out_host_pack;
+    const double *alert_slack_cost; /* [n][alert_slack_stride] out_slack_cost of the launch (with n_alert_obs > 0)        */
+    int32_t alert_slack_stride;
+    int32_t n_alert_obs;
+    double alert_threshold;
 } dlscqp_advance;
 
 int dlscqp_advance_device(dlscqp_ctx *ctx, const dlscqp_advance *adv, void *stream);

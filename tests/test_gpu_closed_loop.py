@@ -337,6 +337,58 @@ def test_hip_graph_step_equals_eager_step(gpu_required, with_world):
     assert moved.mean() > (1.0 if with_world != "crowd" else 0.5)  # the agents did fly (the crowd: 14 steps)
 
 
+@pytest.mark.parametrize("mission", ["maze", "forest"])
+def test_planner_inputs_written_by_the_advance_kernel_equal_the_packed_copy(gpu_required, mission, monkeypatch):
+    """dlscqp_advance.out_host_pack: positions, sub-goals, plans and collision alerts for the host-side waypoint planner, written
+    into pinned host memory by the step's last kernel, give the same flight, bit for bit, as packing them on the device and copying
+    them (DLSCQP_HOST_PACK=0: what rounds 3-5 did) -- the maze as the reference's mission runs it, and the forest with its spinning
+    obstacles (obstacle states mirrored on the host, alerts from the slack costs), also replayed as a HIP graph."""
+    if mission == "forest":
+        from dlsc_gc_planner_amd.harness import SpinObstacles
+        m = json.load(open(os.path.join(HERE, "golden", "world_forest1.json")))
+        cfg = abi.make_config(dim=m["dim"], M=m["M"], dt=m["dt"], control_input_weight=0.01, terminal_weight=1.0,
+                              communication_range=m["communication_range"], slack_collision_weight=m["slack_collision_weight"],
+                              world_use_octomap=True, world_min=tuple(m["world"][:3]), world_max=tuple(m["world"][3:]))
+        world = dict(boxes=m["boxes"], resolution=m["world_resolution"], grid_resolution=m["grid_resolution"], pibt="reference",
+                     uncertainty_horizon=m["uncertainty_horizon"])
+        kw = dict(radius=m["radius"], downwash=m["downwash"], max_vel=m["max_vel"], max_acc=m["max_acc"], nominal_velocity=1.0,
+                  waypoint_step=m["grid_resolution"], world=world)
+        kw_dyn = lambda: SpinObstacles(m["obstacles"]).dyn(size_prediction=1, horizon=m["uncertainty_horizon"], duration=m["obs_duration"])  # noqa: E731
+    else:
+        m, cfg, world = _maze()
+        kw = dict(radius=m["radius"], downwash=2.0, max_vel=m["max_vel"], max_acc=m["max_acc"], nominal_velocity=1.0,
+                  waypoint_step=m["grid_resolution"], world=dict(world, pibt="reference"))
+    start, goal = np.array(m["start"], np.float32), np.array(m["goal"], np.float32)
+    runs = []
+    for mode in ("0", "1", "graph"):
+        monkeypatch.setenv("DLSCQP_HOST_PACK", "0" if mode == "0" else "1")
+        sim = ClosedLoop(cfg, start, goal, **(dict(kw, dyn=kw_dyn()) if mission == "forest" else kw))
+        try:
+            assert sim.pack_in_advance == (mode != "0")
+            hist = []
+            for k in range(160 if mission == "forest" else 60):
+                if mode == "graph" and k == 3:
+                    sim.enable_graph()
+                status, iters = sim.step()
+                hist.append((sim.plans.cpu().numpy().copy(), sim.pos.cpu().numpy().copy(), sim.cur_goal.cpu().numpy().copy(),
+                             sim.wp.cpu().numpy().copy(), status.cpu().numpy().copy()))
+                if mode != "0":  # what the kernel wrote for the planner is this step's state
+                    N, E = sim.N, cfg.M * (cfg.n + 1) * 3
+                    h = sim._adv_pack.numpy()
+                    assert np.array_equal(h[:3 * N].reshape(N, 3), hist[-1][1]) and np.array_equal(h[3 * N:6 * N].reshape(N, 3), hist[-1][2])
+                    assert np.array_equal(h[6 * N:6 * N + N * E].reshape(hist[-1][0].shape), hist[-1][0])
+                    if sim.D:
+                        assert np.array_equal(h[6 * N + N * E:].reshape(N, sim.D) > 0.5, sim.batch.out_slack.cpu().numpy()[:, :sim.D] > sim.slack_threshold)
+        finally:
+            sim.close()
+        runs.append(hist)
+    for other in runs[1:]:
+        for k, (e, g) in enumerate(zip(runs[0], other)):
+            for x, y in zip(e, g):
+                assert np.array_equal(x, y), k
+    assert np.linalg.norm(runs[1][-1][1] - start, axis=1).mean() > 1.0  # the agents did fly
+
+
 @pytest.mark.parametrize("M", [2, 5, 10])
 def test_advance_kernel_equals_its_numpy_restatement(gpu_required, M):
     """dlscqp_advance_device (fail-safe, sub-goal, state := plan(dt), next records, initial trajectory, straight-line
