@@ -129,6 +129,7 @@ class DeviceBatch(C.Structure):
         ("hint_mask_in", C.c_void_p),
         ("hint_mask_out", C.c_void_p),
         ("hint_mask_zero", C.c_void_p),
+        ("advance_after", C.c_void_p),
     ]
 
 

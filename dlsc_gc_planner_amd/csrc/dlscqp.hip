@@ -272,6 +272,114 @@ struct WaveGpu {
     }
 };
 
+// ---- between two launches (include/dlscqp.h: dlscqp_advance): one wavefront per agent ----
+struct AdvanceArgs {
+    dlscqp_advance a;
+    int M, n1;
+    float s1, s2;  // n / dt and (n - 1) / dt in float32 (Trajectory::getStateAt differences)
+};
+
+// one wavefront per agent; E = M (n+1) 3 floats of a plan, lane l owns elements l, l + 64, ...
+// (shared by dlscqp_advance_kernel and the plan kernel's epilogue: dlscqp_device_batch.advance_after)
+__device__ __forceinline__ void advance_agent(const AdvanceArgs &g, int ag, int l) {
+    const dlscqp_advance &a = g.a;
+    const int M = g.M, n1 = g.n1, seg = n1 * 3, E = M * seg;
+    float *plan = a.plans + (size_t)ag * E;
+    const float *ctrl = a.ctrl + (size_t)ag * E;
+    const bool ok = a.status[ag] == DLSCQP_OK;
+    // element e of a plan shifted by one segment: segment m+1, the last segment repeats its end point
+    auto shifted = [&](int e) {
+        const int m = e / seg, k = e % 3;
+        return m < M - 1 ? e + seg : (M - 1) * seg + (n1 - 1) * 3 + k;
+    };
+    constexpr int U = 8;  // E <= 512 (M <= 28 at n = 5)
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int e = l + 64 * u;
+        v[u] = e < E ? (ok ? ctrl[e] : plan[shifted(e)]) : 0.0f;  // every read of the old plan happens before ...
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int e = l + 64 * u;
+        if (e < E) plan[e] = v[u];  // ... the first write (one wavefront: memory operations in program order)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the new plan is in memory before other lanes' elements are read back
+    if (a.out_host_pack) {  // uniform: the plan and the alerts for the host-side waypoint planner (pinned host memory)
+        float *hp = a.out_host_pack + (size_t)a.n_agents * 6;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = l + 64 * u;
+            if (e < E) hp[(size_t)ag * E + e] = v[u];
+        }
+        hp += (size_t)a.n_agents * E;
+        for (int j = l; j < a.n_alert_obs; j += 64)
+            hp[(size_t)ag * a.n_alert_obs + j] = a.alert_slack_cost[(size_t)ag * a.alert_slack_stride + j] > a.alert_threshold ? 1.0f : 0.0f;
+    }
+    if (a.initial_traj) {
+        float *init = a.initial_traj + (size_t)ag * E;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int e = l + 64 * u;
+            if (e < E) init[e] = plan[shifted(e)];
+        }
+        if (a.out_boxes) {  // uniform
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the initial trajectory is in memory before it is read back
+            for (int j = l; j < M * 3; j += 64) {  // face (segment m, axis k): minimum and maximum over the segment's control points
+                const int m = j / 3, k = j - 3 * m;
+                float mn = init[m * seg + k], mx = mn;
+                for (int i = 1; i < n1; i++) {
+                    const float v = init[m * seg + 3 * i + k];
+                    mn = v < mn ? v : mn;
+                    mx = v > mx ? v : mx;
+                }
+                const float lo = mn - a.box_margin, hi = mx + a.box_margin;
+                float *box = a.out_boxes + ((size_t)ag * M + m) * 6;
+                box[k] = lo > a.box_min[k] ? lo : a.box_min[k];
+                box[3 + k] = hi < a.box_max[k] ? hi : a.box_max[k];
+            }
+        }
+    }
+    if (l < 3) {
+        const int k = l;
+        const bool gok = a.goal_status[ag] != DLSCQP_INFEASIBLE;
+        const float cg = gok ? a.goal[(size_t)ag * 3 + k] : a.current_goal[(size_t)ag * 3 + k];
+        a.current_goal[(size_t)ag * 3 + k] = cg;
+        // state at dt: first three control points of segment 1 (M >= 2, dlscqp_create)
+        const int b = seg;
+        const float c0 = plan[b + k], c1 = plan[b + 3 + k], c2 = plan[b + 6 + k];
+        const float v0 = (c1 - c0) * g.s1, v1 = (c2 - c1) * g.s1;
+        const float p = c0, vel = v0, acc = (v1 - v0) * g.s2;
+        dlscqp_agent *rec = a.agents + ag;
+        rec->position[k] = p;
+        rec->velocity[k] = vel;
+        rec->acceleration[k] = acc;
+        rec->current_goal_point[k] = cg;
+        if (a.out_host_pack) {
+            a.out_host_pack[(size_t)ag * 3 + k] = p;
+            a.out_host_pack[(size_t)a.n_agents * 3 + (size_t)ag * 3 + k] = cg;
+        }
+        if (a.waypoints) {
+            rec->next_waypoint[k] = a.waypoints[(size_t)ag * 3 + k];
+        } else if (a.desired_goal) {
+            const float *dg = a.desired_goal + (size_t)ag * 3;
+            // the other two axes of the new position: recomputed by this lane (three lanes, three axes each)
+            float d3[3], p3[3];
+            for (int j = 0; j < 3; j++) {
+                p3[j] = plan[b + j];
+                d3[j] = dg[j] - p3[j];
+            }
+            const double dist = dlscqp::f32_norm3(d3[0], d3[1], d3[2]);
+            const float stepf = (float)a.waypoint_step, distf = (float)(dist > 1e-9 ? dist : 1e-9);
+            float wpn = dist <= a.waypoint_step ? dg[k] : p3[k] + d3[k] / distf * stepf;
+            // an agent whose goal LP found no point towards its waypoint aims at its sub-goal for one step (the synthetic swarms'
+            // rule, workloads.generate; in the reference the grid planner hands out waypoints that can be reached)
+            if (a.waypoint_hold_on_lp_failure && !gok) wpn = cg;
+            rec->next_waypoint[k] = wpn;
+        }
+    }
+}
+
 struct KernelArgs {
     int n_agents, max_slack_obs, do_goal, do_traj;
     int slot0, n_slots_launch;  // launch slots [slot0, slot0 + n_slots_launch)
@@ -302,6 +410,8 @@ struct KernelArgs {
     const unsigned long long *mask_in;  // launch order from class masks (masked_agent): [n_blocks][8], written by the previous step's launch
     unsigned long long *mask_out;       // ... this launch's own: every agent sets its bit in the mask of its class
     unsigned long long *mask_zero;      // ... and a third table that this launch clears (for a later launch to write)
+    int adv_on;                         // dlscqp_device_batch.advance_after: the planning wavefront also does the agent's bookkeeping between
+    AdvanceArgs adv;                    // two launches (advance_agent), right behind its final stores
 };
 
 // dlscqp_device_batch.hint_iters: the launch order without a sort between two launches.  The agents in blocks of 64 consecutive
@@ -529,6 +639,12 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
     if constexpr (WPA > 1) {  // release the helpers: the solve is over
         w.mail[0] = 1.0;
         __syncthreads();
+    }
+    if (a.adv_on) {  // uniform
+        // what dlscqp_advance_device would do for this agent in a launch of its own: it reads the verdicts and the plan this wavefront
+        // has just stored (a wavefront's memory operations are performed in program order) and touches this agent's entries only
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        advance_agent(a.adv, ag, w.lane);
     }
 #ifdef DLSCQP_STAMPS
     if (a.out_stamps && threadIdx.x == 0)
@@ -1259,6 +1375,27 @@ static LayoutChoice choose_layout(const KParams &kp, const dlscqp_device_batch *
     return out;
 }
 
+// dlscqp_advance checked and turned into the kernel's arguments (dlscqp_advance_device, dlscqp_device_batch.advance_after)
+static int advance_args(const dlscqp_ctx *c, const dlscqp_advance *adv, AdvanceArgs &g) {
+    if (!adv->status || !adv->goal_status || !adv->ctrl || !adv->goal || !adv->plans || !adv->current_goal || !adv->agents) {
+        g_last_error = "dlscqp_advance: null buffer";
+        return DLSCQP_ERR_INVALID_ARGUMENT;
+    }
+    if (c->M * (c->n + 1) * 3 > 512) { g_last_error = "plans of more than 512 floats are not supported"; return DLSCQP_ERR_UNSUPPORTED; }
+    if (adv->out_boxes && !adv->initial_traj) { g_last_error = "out_boxes are the boxes of initial_traj: null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (adv->out_host_pack && adv->n_alert_obs > 0 && (!adv->alert_slack_cost || adv->alert_slack_stride < adv->n_alert_obs)) {
+        g_last_error = "out_host_pack with n_alert_obs > 0 needs alert_slack_cost [n][alert_slack_stride >= n_alert_obs]";
+        return DLSCQP_ERR_INVALID_ARGUMENT;
+    }
+    if (adv->n_alert_obs < 0) { g_last_error = "n_alert_obs < 0"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    g.a = *adv;
+    g.M = c->M;
+    g.n1 = c->n + 1;
+    g.s1 = (float)((double)c->n / c->dt);
+    g.s2 = (float)((double)(c->n - 1) / c->dt);
+    return DLSCQP_SUCCESS;
+}
+
 static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t stream) {
     if (b->n_agents <= 0) return DLSCQP_SUCCESS;
     if (b->max_slack_obs < 0 || b->max_rows_per_agent < 0) { g_last_error = "negative size"; return DLSCQP_ERR_INVALID_ARGUMENT; }
@@ -1337,6 +1474,21 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         }
     }
     a.ctrl_stride = c->M * (c->n + 1) * 3; a.goal_stride = 3; a.status_stride = 1;
+    a.adv_on = 0;
+    if (b->advance_after) {
+        // the bookkeeping between two launches in the plan kernel's epilogue: it reads what this launch writes, as dense arrays
+        const dlscqp_advance *adv = b->advance_after;
+        if (b->out_record_stride != 0 || !b->do_goal || !b->do_traj || adv->n_agents != b->n_agents || adv->status != b->out_status ||
+            adv->goal_status != b->out_goal_status || adv->ctrl != b->out_ctrl || adv->goal != b->out_goal ||
+            (adv->n_alert_obs > 0 && adv->alert_slack_cost != b->out_slack_cost)) {
+            g_last_error = "advance_after: for a launch of goal LP + QP whose dense outputs (out_status, out_goal_status, out_ctrl, out_goal, "
+                           "out_slack_cost) are the structure's inputs, over the same agents";
+            return DLSCQP_ERR_INVALID_ARGUMENT;
+        }
+        const int rc = advance_args(c, adv, a.adv);
+        if (rc != DLSCQP_SUCCESS) return rc;
+        a.adv_on = 1;
+    }
     if (b->out_record_stride > 0) {
         if (b->out_record_stride < c->M * (c->n + 1) * 3) { g_last_error = "out_record_stride is smaller than a plan"; return DLSCQP_ERR_INVALID_ARGUMENT; }
         a.ctrl_stride = a.goal_stride = a.status_stride = b->out_record_stride;
@@ -2012,136 +2164,17 @@ extern "C" int dlscqp_hint_order_preview_device(dlscqp_ctx *c, const int32_t *co
 // between two launches (include/dlscqp.h: dlscqp_advance)
 // ---------------------------------------------------------------------------------------------
 namespace {
-struct AdvanceArgs {
-    dlscqp_advance a;
-    int M, n1;
-    float s1, s2;  // n / dt and (n - 1) / dt in float32 (Trajectory::getStateAt differences)
-};
-
-// one wavefront per agent; E = M (n+1) 3 floats of a plan, lane l owns elements l, l + 64, ...
-__global__ __launch_bounds__(64) void dlscqp_advance_kernel(AdvanceArgs g) {
-    const int ag = (int)blockIdx.x, l = (int)threadIdx.x;
-    const dlscqp_advance &a = g.a;
-    const int M = g.M, n1 = g.n1, seg = n1 * 3, E = M * seg;
-    float *plan = a.plans + (size_t)ag * E;
-    const float *ctrl = a.ctrl + (size_t)ag * E;
-    const bool ok = a.status[ag] == DLSCQP_OK;
-    // element e of a plan shifted by one segment: segment m+1, the last segment repeats its end point
-    auto shifted = [&](int e) {
-        const int m = e / seg, k = e % 3;
-        return m < M - 1 ? e + seg : (M - 1) * seg + (n1 - 1) * 3 + k;
-    };
-    constexpr int U = 8;  // E <= 512 (M <= 28 at n = 5)
-    float v[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        const int e = l + 64 * u;
-        v[u] = e < E ? (ok ? ctrl[e] : plan[shifted(e)]) : 0.0f;  // every read of the old plan happens before ...
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-        const int e = l + 64 * u;
-        if (e < E) plan[e] = v[u];  // ... the first write (one wavefront: memory operations in program order)
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the new plan is in memory before other lanes' elements are read back
-    if (a.out_host_pack) {  // uniform: the plan and the alerts for the host-side waypoint planner (pinned host memory)
-        float *hp = a.out_host_pack + (size_t)a.n_agents * 6;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int e = l + 64 * u;
-            if (e < E) hp[(size_t)ag * E + e] = v[u];
-        }
-        hp += (size_t)a.n_agents * E;
-        for (int j = l; j < a.n_alert_obs; j += 64)
-            hp[(size_t)ag * a.n_alert_obs + j] = a.alert_slack_cost[(size_t)ag * a.alert_slack_stride + j] > a.alert_threshold ? 1.0f : 0.0f;
-    }
-    if (a.initial_traj) {
-        float *init = a.initial_traj + (size_t)ag * E;
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int e = l + 64 * u;
-            if (e < E) init[e] = plan[shifted(e)];
-        }
-        if (a.out_boxes) {  // uniform
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the initial trajectory is in memory before it is read back
-            for (int j = l; j < M * 3; j += 64) {  // face (segment m, axis k): minimum and maximum over the segment's control points
-                const int m = j / 3, k = j - 3 * m;
-                float mn = init[m * seg + k], mx = mn;
-                for (int i = 1; i < n1; i++) {
-                    const float v = init[m * seg + 3 * i + k];
-                    mn = v < mn ? v : mn;
-                    mx = v > mx ? v : mx;
-                }
-                const float lo = mn - a.box_margin, hi = mx + a.box_margin;
-                float *box = a.out_boxes + ((size_t)ag * M + m) * 6;
-                box[k] = lo > a.box_min[k] ? lo : a.box_min[k];
-                box[3 + k] = hi < a.box_max[k] ? hi : a.box_max[k];
-            }
-        }
-    }
-    if (l < 3) {
-        const int k = l;
-        const bool gok = a.goal_status[ag] != DLSCQP_INFEASIBLE;
-        const float cg = gok ? a.goal[(size_t)ag * 3 + k] : a.current_goal[(size_t)ag * 3 + k];
-        a.current_goal[(size_t)ag * 3 + k] = cg;
-        // state at dt: first three control points of segment 1 (M >= 2, dlscqp_create)
-        const int b = seg;
-        const float c0 = plan[b + k], c1 = plan[b + 3 + k], c2 = plan[b + 6 + k];
-        const float v0 = (c1 - c0) * g.s1, v1 = (c2 - c1) * g.s1;
-        const float p = c0, vel = v0, acc = (v1 - v0) * g.s2;
-        dlscqp_agent *rec = a.agents + ag;
-        rec->position[k] = p;
-        rec->velocity[k] = vel;
-        rec->acceleration[k] = acc;
-        rec->current_goal_point[k] = cg;
-        if (a.out_host_pack) {
-            a.out_host_pack[(size_t)ag * 3 + k] = p;
-            a.out_host_pack[(size_t)a.n_agents * 3 + (size_t)ag * 3 + k] = cg;
-        }
-        if (a.waypoints) {
-            rec->next_waypoint[k] = a.waypoints[(size_t)ag * 3 + k];
-        } else if (a.desired_goal) {
-            const float *dg = a.desired_goal + (size_t)ag * 3;
-            // the other two axes of the new position: recomputed by this lane (three lanes, three axes each)
-            float d3[3], p3[3];
-            for (int j = 0; j < 3; j++) {
-                p3[j] = plan[b + j];
-                d3[j] = dg[j] - p3[j];
-            }
-            const double dist = dlscqp::f32_norm3(d3[0], d3[1], d3[2]);
-            const float stepf = (float)a.waypoint_step, distf = (float)(dist > 1e-9 ? dist : 1e-9);
-            float wpn = dist <= a.waypoint_step ? dg[k] : p3[k] + d3[k] / distf * stepf;
-            // an agent whose goal LP found no point towards its waypoint aims at its sub-goal for one step (the synthetic swarms'
-            // rule, workloads.generate; in the reference the grid planner hands out waypoints that can be reached)
-            if (a.waypoint_hold_on_lp_failure && !gok) wpn = cg;
-            rec->next_waypoint[k] = wpn;
-        }
-    }
-}
+__global__ __launch_bounds__(64) void dlscqp_advance_kernel(AdvanceArgs g) { advance_agent(g, (int)blockIdx.x, (int)threadIdx.x); }
 }  // namespace
 
 extern "C" int dlscqp_advance_device(dlscqp_ctx *c, const dlscqp_advance *adv, void *stream) {
     g_last_error.clear();
     if (!c || !adv) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
     if (adv->n_agents <= 0) return DLSCQP_SUCCESS;
-    if (!adv->status || !adv->goal_status || !adv->ctrl || !adv->goal || !adv->plans || !adv->current_goal || !adv->agents) {
-        g_last_error = "null buffer";
-        return DLSCQP_ERR_INVALID_ARGUMENT;
-    }
-    if (c->M * (c->n + 1) * 3 > 512) { g_last_error = "plans of more than 512 floats are not supported"; return DLSCQP_ERR_UNSUPPORTED; }
-    if (adv->out_boxes && !adv->initial_traj) { g_last_error = "out_boxes are the boxes of initial_traj: null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
-    if (adv->out_host_pack && adv->n_alert_obs > 0 && (!adv->alert_slack_cost || adv->alert_slack_stride < adv->n_alert_obs)) {
-        g_last_error = "out_host_pack with n_alert_obs > 0 needs alert_slack_cost [n][alert_slack_stride >= n_alert_obs]";
-        return DLSCQP_ERR_INVALID_ARGUMENT;
-    }
-    if (adv->n_alert_obs < 0) { g_last_error = "n_alert_obs < 0"; return DLSCQP_ERR_INVALID_ARGUMENT; }
-    (void)hipSetDevice(c->cfg.device);
     AdvanceArgs g;
-    g.a = *adv;
-    g.M = c->M;
-    g.n1 = c->n + 1;
-    g.s1 = (float)((double)c->n / c->dt);
-    g.s2 = (float)((double)(c->n - 1) / c->dt);
+    const int rc = advance_args(c, adv, g);
+    if (rc != DLSCQP_SUCCESS) return rc;
+    (void)hipSetDevice(c->cfg.device);
     hipLaunchKernelGGL(dlscqp_advance_kernel, dim3(adv->n_agents), dim3(64), 0, (hipStream_t)stream, g);
     HIP_TRY(hipGetLastError());
     return DLSCQP_SUCCESS;

@@ -287,6 +287,11 @@ class ClosedLoop:
                                              desired_goal=self.desired_goal if world is None else None,
                                              waypoint_step=waypoint_step if world is None else 0.0,
                                              hold_on_lp_failure=neighbours == "knn", **bkw)  # the synthetic swarms' waypoint rule
+        # ... and the plan kernel does that bookkeeping itself, in its epilogue: one launch less per step (DLSCQP_FUSED_ADVANCE=0: the
+        # launch of its own, as rounds 2-5 had it)
+        self.fused_advance = os.environ.get("DLSCQP_FUSED_ADVANCE", "1") != "0" and self.heavy_ranks == 0
+        if self.fused_advance:
+            self.batch.set_advance_after(self.advance)
         if world is not None and world.get("prune", True) and not prune:
             # presolve in the half-space generator: rows implied by this step's corridor boxes are never written
             self.row_counts = self.gen.enable_pruning(self.sfc.sfcs)
@@ -489,7 +494,8 @@ class ClosedLoop:
         self._stage("state_update_time")
         # fail-safe: keep the shifted previous plan (traj_planner.cpp:776); sub-goal from the LP (traj_planner.cpp:494);
         # doStep of the next iteration: state = desired_traj.getStateAt(dt) = start of segment 1, float32 differences
-        self.advance()
+        if not self.fused_advance:
+            self.advance()
         self._stage("end")
 
     def enable_graph(self):

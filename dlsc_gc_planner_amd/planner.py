@@ -190,6 +190,7 @@ class BatchTrajOptimizer:
         def run(stream=None, _keep=keep):
             s = torch.cuda.current_stream(batch.device) if stream is None else stream
             self._check(self.lib.dlscqp_advance_device(self.handle, C.byref(a), C.c_void_p(s.cuda_stream)), "dlscqp_advance_device")
+        run.args = a  # (DeviceBatch.set_advance_after: the same bookkeeping in the plan kernel's epilogue instead of a launch of its own)
         return run
 
     def _torch(self):
@@ -332,6 +333,12 @@ class DeviceBatch:
             assert t is None or (t.dtype == self.torch.int64 and t.numel() == 8 * ((self.n_agents + 63) // 64) and t.is_contiguous())
             setattr(self.c, name, None if t is None else t.data_ptr())
         self._keep_masks = (mask_in, mask_out, mask_zero)
+
+    def set_advance_after(self, advance):
+        """dlscqp_device_batch.advance_after: `advance` = what make_advance returned for THIS batch (or None to take it back) -- every
+        following launch also does the bookkeeping between two launches, in its epilogue; the caller then no longer calls `advance`."""
+        self._advance_after = advance  # keep the structure alive
+        self.c.advance_after = None if advance is None else C.addressof(advance.args)
 
     def rotate_hint_masks(self):
         """Closed loops (one batch, launched step after step): call before every launch.  Three tables rotate: the one the previous

@@ -171,6 +171,7 @@ int dlscqp_plan_batch(dlscqp_ctx *ctx, int32_t n_agents, const dlscqp_agent *age
  * 64 consecutive rows with one coalesced load per field.  Asynchronous on `stream`
  * (a hipStream_t passed as void*; NULL = the HIP null stream, exactly as for hipLaunchKernel);
  * no allocation, no synchronisation inside.                                                 */
+struct dlscqp_advance;
 typedef struct dlscqp_device_batch {
     int32_t n_agents;
     int32_t max_slack_obs;          /* stride of out_slack_cost                                 */
@@ -256,6 +257,13 @@ typedef struct dlscqp_device_batch {
                                        flown crowd).  Results do not depend on it.                                                 */
     uint64_t *hint_mask_out;
     uint64_t *hint_mask_zero;
+    const struct dlscqp_advance *advance_after; /* optional: the bookkeeping between two launches (dlscqp_advance, below) done by the
+                                       plan kernel itself -- the wavefront that planned an agent applies the structure to that agent
+                                       right behind its final stores: one launch less per replanning step (a ten-agent step is four
+                                       launches of a few microseconds each).  The structure is read when the launch is queued; its
+                                       status / goal_status / ctrl / goal (/ alert_slack_cost) must be this batch's dense outputs
+                                       and its n_agents this batch's; with do_goal and do_traj.  Same results as
+                                       dlscqp_advance_device after the launch (tests/test_gpu_closed_loop.py).                   */
 } dlscqp_device_batch;
 
 /* key layout: bits 0-7 m, 8-11 i, 12 dynamic flag, 16-31 slack index (0xFFFF = none). */

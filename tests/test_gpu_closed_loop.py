@@ -337,6 +337,62 @@ def test_hip_graph_step_equals_eager_step(gpu_required, with_world):
     assert moved.mean() > (1.0 if with_world != "crowd" else 0.5)  # the agents did fly (the crowd: 14 steps)
 
 
+@pytest.mark.parametrize("mission", ["empty", "maze", "forest", "crowd"])
+def test_bookkeeping_in_the_plan_kernels_epilogue_equals_the_advance_launch(gpu_required, mission, monkeypatch):
+    """dlscqp_device_batch.advance_after: the wavefront that planned an agent also applies dlscqp_advance to it (fail-safe, sub-goal,
+    state at dt, next records, initial trajectory, boxes, the planner's inputs in pinned memory) -- the same flight, bit for bit, as
+    with dlscqp_advance_device in a launch of its own (DLSCQP_FUSED_ADVANCE=0), eager and as a HIP graph."""
+    kw_dyn = None
+    if mission == "crowd":
+        from dlsc_gc_planner_amd import workloads
+        cfg = workloads.x2048_config(device=0)
+        start, goal = workloads.swapping_pairs(cfg, 2048)
+        kw = dict(radius=0.15, downwash=2.0, max_vel=1.0, max_acc=2.0, waypoint_step=0.5, device=0, neighbours="device", nbr_pitch=256,
+                  corridor_margin=0.5, prune=True, order_hint=True)
+    elif mission == "forest":
+        from dlsc_gc_planner_amd.harness import SpinObstacles
+        m = json.load(open(os.path.join(HERE, "golden", "world_forest1.json")))
+        cfg = abi.make_config(dim=m["dim"], M=m["M"], dt=m["dt"], control_input_weight=0.01, terminal_weight=1.0,
+                              communication_range=m["communication_range"], slack_collision_weight=m["slack_collision_weight"],
+                              world_use_octomap=True, world_min=tuple(m["world"][:3]), world_max=tuple(m["world"][3:]))
+        world = dict(boxes=m["boxes"], resolution=m["world_resolution"], grid_resolution=m["grid_resolution"], pibt="reference",
+                     uncertainty_horizon=m["uncertainty_horizon"])
+        kw = dict(radius=m["radius"], downwash=m["downwash"], max_vel=m["max_vel"], max_acc=m["max_acc"], nominal_velocity=1.0,
+                  waypoint_step=m["grid_resolution"], world=world)
+        kw_dyn = lambda: SpinObstacles(m["obstacles"]).dyn(size_prediction=1, horizon=m["uncertainty_horizon"], duration=m["obs_duration"])  # noqa: E731
+        start, goal = np.array(m["start"], np.float32), np.array(m["goal"], np.float32)
+    elif mission == "maze":
+        m, cfg, world = _maze()
+        kw = dict(radius=m["radius"], downwash=2.0, max_vel=m["max_vel"], max_acc=m["max_acc"], nominal_velocity=1.0,
+                  waypoint_step=m["grid_resolution"], world=dict(world, pibt="reference"))
+        start, goal = np.array(m["start"], np.float32), np.array(m["goal"], np.float32)
+    else:
+        cfg, m = _mission("empty60_1")
+        kw = dict(radius=m["radius"], downwash=m["downwash"], max_vel=m["max_vel"], max_acc=m["max_acc"], nominal_velocity=m["nominal_velocity"])
+        start, goal = np.array(m["start"], np.float32), np.array(m["goal"], np.float32)
+    steps = 14 if mission == "crowd" else 80
+    runs = []
+    for mode in ("0", "1", "graph"):
+        monkeypatch.setenv("DLSCQP_FUSED_ADVANCE", "0" if mode == "0" else "1")
+        sim = ClosedLoop(cfg, start, goal, **(dict(kw, dyn=kw_dyn()) if kw_dyn else kw))
+        try:
+            assert sim.fused_advance == (mode != "0")
+            hist = []
+            for k in range(steps):
+                if mode == "graph" and k == 3:
+                    sim.enable_graph()
+                status, iters = sim.step()
+                hist.append((sim.plans.cpu().numpy().copy(), sim.batch.t["agents"].cpu().numpy().copy(), sim.cur_goal.cpu().numpy().copy(),
+                             sim.init_buf.cpu().numpy().copy(), status.cpu().numpy().copy()))
+        finally:
+            sim.close()
+        runs.append(hist)
+    for other in runs[1:]:
+        for k, (e, g) in enumerate(zip(runs[0], other)):
+            for x, y in zip(e, g):
+                assert np.array_equal(x, y), k
+
+
 @pytest.mark.parametrize("mission", ["maze", "forest"])
 def test_planner_inputs_written_by_the_advance_kernel_equal_the_packed_copy(gpu_required, mission, monkeypatch):
     """dlscqp_advance.out_host_pack: positions, sub-goals, plans and collision alerts for the host-side waypoint planner, written
