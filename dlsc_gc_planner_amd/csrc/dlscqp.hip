@@ -414,6 +414,21 @@ struct KernelArgs {
     AdvanceArgs adv;                    // two launches (advance_agent), right behind its final stores
 };
 
+// A 32-bit word (two consecutive ones) at a wave-uniform index of a table that no store of the running kernel touches, through
+// the scalar cache: s_load_dword, its result in scalar registers.  (The tables are written by EARLIER launches at most: the scalar
+// cache is invalidated when a kernel starts.)
+__device__ __forceinline__ int scalar_load_i32(const int32_t *p, int idx) {
+    int v;
+    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p), "s"(idx * 4) : "memory");
+    return v;
+}
+__device__ __forceinline__ void scalar_load_i32x2(const int32_t *p, int idx, int &v0, int &v1) {
+    unsigned long long v;
+    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p), "s"(idx * 4) : "memory");
+    v0 = (int)(unsigned int)v;
+    v1 = (int)(unsigned int)(v >> 32);
+}
+
 // dlscqp_device_batch.hint_iters: the launch order without a sort between two launches.  The agents in blocks of 64 consecutive
 // ids; slot s belongs to block s % n_blocks and plans the agent of rank s / n_blocks among the block's agents, most expensive
 // first.  "Expensive" is the key of dlscqp_launch_order_history_device -- max_k (3/4)^k iterations_k over the previous steps --
@@ -455,15 +470,14 @@ __device__ __forceinline__ int hinted_agent(const KernelArgs &a, int slot, int l
 // load of 64 keys in front of the agent's record (that dependent trip cost every agent ~1.3 us), ~40 scalar instructions.
 // The masks must partition the block's agents; if they do not (the first step: all zero) the block is planned in id order.
 // cls_in: the class the agent was scheduled with (its own history: the class it reports decays by one per step).
-__device__ __forceinline__ int masked_agent(const KernelArgs &a, int slot, int lane, int &cls_in) {
-    const int nb = a.n_blocks;
-    const int rank = a.blocks_magic ? (int)__umulhi((unsigned int)slot, a.blocks_magic) : slot / nb;
+__device__ __forceinline__ int masked_agent(const unsigned long long *mask_in, int nb, unsigned int blocks_magic, int n_agents, int slot, int lane, int &cls_in) {
+    const int rank = blocks_magic ? (int)__umulhi((unsigned int)slot, blocks_magic) : slot / nb;
     const int blk = slot - rank * nb;
-    const unsigned long long *m = a.mask_in + (size_t)blk * 8;
+    const unsigned long long *m = mask_in + (size_t)blk * 8;
     unsigned long long mk[8];
 #pragma unroll
     for (int c = 0; c < 8; c++) mk[c] = __builtin_nontemporal_load(m + c);
-    const int nvalid = a.n_agents - 64 * blk >= 64 ? 64 : a.n_agents - 64 * blk;
+    const int nvalid = n_agents - 64 * blk >= 64 ? 64 : n_agents - 64 * blk;
     const unsigned long long vmask = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull);
     unsigned long long all = 0ull;
     int tot = 0;
@@ -540,12 +554,23 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
     WaveGpu w;
     w.lane = (int)threadIdx.x & 63;
     int cls_in = 0;
-    const int ag = a.order ? a.order[slot] : (a.mask_in ? masked_agent(a, slot, w.lane, cls_in) : (a.hint[0] ? hinted_agent(a, slot, w.lane) : slot));
+    // (wave-uniform by construction -- ballots and scalar loads; said aloud: it indexes scalar loads below)
+    const int ag = __builtin_amdgcn_readfirstlane(a.order ? a.order[slot] : (a.mask_in ? masked_agent(a.mask_in, a.n_blocks, a.blocks_magic, a.n_agents, slot, w.lane, cls_in)
+                                                                                      : (a.hint[0] ? hinted_agent(a, slot, w.lane) : slot)));
     if (a.mask_zero && slot < a.n_blocks) a.mask_zero[(size_t)slot * 8 + (threadIdx.x & 7)] = 0ull;  // (uniform condition; every lane stores, eight lanes to a word: no lane-guarded store)
     if (ag < 0 || ag >= a.n_agents) return;  // the whole workgroup
-    // the agent's rows: [rb, rb + nrows_ag)
-    const int rb = a.row_pitch > 0 ? ag * a.row_pitch : a.row_offsets[ag];
-    const int nrows_ag = a.row_counts ? a.row_counts[ag] : (a.row_pitch > 0 ? a.row_pitch : a.row_offsets[ag + 1] - rb);
+    // the agent's rows: [rb, rb + nrows_ag).  Scalar loads, both offsets in one (the compiler reads them with vector loads, one
+    // dependent trip to L2 each, although the index is uniform: it cannot tell that no store of this kernel touches them)
+    int rb, nrows_ag;
+    if (a.row_pitch > 0) {
+        rb = ag * a.row_pitch;
+        nrows_ag = a.row_counts ? scalar_load_i32(a.row_counts, ag) : a.row_pitch;
+    } else {
+        int re;
+        scalar_load_i32x2(a.row_offsets, ag, rb, re);
+        nrows_ag = re - rb;
+        if (a.row_counts) nrows_ag = scalar_load_i32(a.row_counts, ag);
+    }
     if constexpr (WPA > 1) {
         static_assert(WS == WS_LDS, "the helpers' mailbox is in LDS");
         w.nw = WPA;
@@ -2115,7 +2140,7 @@ namespace {
 __global__ __launch_bounds__(64) void dlscqp_mask_preview_kernel(KernelArgs a, int32_t *order_out) {
     const int slot = (int)blockIdx.x;
     int cls_in;
-    const int ag = masked_agent(a, slot, (int)threadIdx.x, cls_in);
+    const int ag = masked_agent(a.mask_in, a.n_blocks, a.blocks_magic, a.n_agents, slot, (int)threadIdx.x, cls_in);
     if (threadIdx.x == 0) order_out[slot] = ag;
 }
 }  // namespace

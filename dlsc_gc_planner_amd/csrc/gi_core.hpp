@@ -498,6 +498,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     // with some of its rows dropped -- it fails with DLSCQP_NUMERICAL.
     const bool bad_shape = K_rows < 0 || K_rows > lay.kmax || (ALL_CACHED && (K_rows > 64 * KU || n_slots_all > 64 * SU)) ||
                            (nxc + K_rows + n_slots_all + M * max_slack_obs) >= (1 << (TAG_BITS - 3));
+#ifdef DQ_PROLOGUE_STAMPS
+    w.stamp(3);
+#endif
     // ---- agent record (uniform) ---------------------------------------------------------------
     float pos[3], vel[3], acc[3], cg[3], wp[3];
     for (int k = 0; k < 3; k++) {
@@ -528,6 +531,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     const double *Rd = rows.d + row_begin;
     const uint32_t *Rkey = rows.key + row_begin;
 
+#ifdef DQ_PROLOGUE_STAMPS
+    w.stamp(4);
+#endif
     // ---- LSC rows into registers: lane l owns rows l + 64u (coalesced loads, once) --------------
     // Every load of every block of 64 is issued here, unconditionally (clamped index: lanes beyond the rows drop the value
     // below), and NOTHING of it is used before the table reads further down have been issued as well: the rows' trip to HBM
@@ -662,6 +668,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         });
     };
     int T_ahead = 0;
+#ifdef DQ_PROLOGUE_STAMPS
+    w.stamp(5);
+#endif
     if (DIMS > 0 && do_traj && !bad_shape) {
         T_ahead = terminal_segments(do_goal ? wp : cg);
         load_tables(T_ahead);
@@ -674,6 +683,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     // min t in [0, 1+1e-5] s.t. a_r t + b_r >= 0 (goal_optimizer.cpp:138-198), closed form.
     float goal[3] = {cg[0], cg[1], cg[2]};
     int goal_status = DLSCQP_OK;
+#ifdef DQ_PROLOGUE_STAMPS
+    w.stamp(6);
+#endif
     if (do_goal && !bad_shape) {
         float dx = cg[0] - wp[0], dy = cg[1] - wp[1], dz = cg[2] - wp[2];
         if (f32_norm3_below_eps(dx, dy, dz)) {  // goal_optimizer.cpp:12-14 (the same test without the square root)
@@ -859,6 +871,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         exit_stores(DLSCQP_INFEASIBLE, do_traj != 0, 0, 0, 0, 0, false, 0.0);
         return;
     }
+#ifdef DQ_PROLOGUE_STAMPS
+    w.stamp(7);
+#endif
     w.stamp(0);  // agent record, row cache, goal LP
     DQ_PHASE_EXIT(0);
     if (!do_traj) {
@@ -919,6 +934,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     const double *tNN = kp.tabNN + (size_t)(T - 1) * P;
     const double *tSIW = kp.tabSIW + (size_t)(T - 1) * kp.n_slots + slot0;
 
+#ifdef DQ_PROLOGUE_STAMPS
+    w.stamp(8);
+#endif
     // ---- unconstrained minimiser and bound table into LDS -------------------------------------------
     // (uniform trip counts; a lane past the end computes a clamped element and stores it to the dump slot)
     double fval0 = 0.0;  // objective of the unconstrained minimiser: what an agent that never iterates reports
@@ -1014,6 +1032,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             }
         }
     }
+#ifdef DQ_PROLOGUE_STAMPS
+    w.stamp(9);
+#endif
     // finish the LSC cache: rhs = d + n.p (traj_optimizer.cpp:427-439); a row that is not part of the model keeps a zero
     // normal and the right-hand side -NEVER: it is never violated, and the pricing pass needs no test for it
     RegI cpo[KU];   // control point of the row
@@ -1041,9 +1062,11 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             double tnn = DIMS > 0 ? nnr[u].at(l) : tNN[mi < P ? mi : 0];
             DQ_KEEP(tnn);
             double wsq = nsq * tnn;
-            double sg = kp.sigma[m < M ? m : 0];
-            DQ_KEEP(sg);
-            wsq = sl != 0xFFFFu ? wsq + sg * sg : wsq;
+            if (SLK != 0) {  // (a build without slack variables has no use for the weight: two dependent trips to the table less)
+                double sg = kp.sigma[m < M ? m : 0];
+                DQ_KEEP(sg);
+                wsq = sl != 0xFFFFu ? wsq + sg * sg : wsq;
+            }
             DQ_KEEP(rhs);
             const bool live = in_model & (wsq > 0);
             cd[u].at(l) = live ? rhs : -NEVER;
@@ -1147,6 +1170,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             }
         });
     }
+#ifdef DQ_PROLOGUE_STAMPS
+    w.stamp(10);
+#endif
     // ---- SCREEN (the instantiation whose rows are all in registers): is any row violated at the unconstrained minimiser? --------
     // Two agents of three of the synthetic swarms sit at their unconstrained optimum: for them the first pricing pass only has
     // to say "none", and this says it without pivot scalings, row codes, the arg-max and everything the iterations set up before
