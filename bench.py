@@ -1046,6 +1046,8 @@ def main():
         assert B >= 3, "the pipelined exchange reads a step's output table while the next steps write other tables"
     elapsed = loop.timed(args.steps, head_pipelined, "kernel", record_kernel_times=True)
     kms = loop.kernel_times_ms(args.steps)
+    if os.environ.get("DLSCQP_BENCH_DUMP_KMS"):  # developer aid: the launches' durations in the order each group recorded them
+        print("kernel ms per launch, by group:", [[round(float(v), 4) for v in o.kernel_times_ms(args.steps)] for o in loop.opts], file=sys.stderr)
     host_queue_ms = loop.host_ms_per_step
     rank_breakdown = None
     if use_dist:

@@ -416,15 +416,16 @@ struct KernelArgs {
 
 // A 32-bit word (two consecutive ones) at a wave-uniform index of a table that no store of the running kernel touches, through
 // the scalar cache: s_load_dword, its result in scalar registers.  (The tables are written by EARLIER launches at most: the scalar
-// cache is invalidated when a kernel starts.)
+// cache is invalidated when a kernel starts.  A plain statement, neither volatile nor with a memory clobber: behind either the
+// compiler no longer knows that the agent's record is unchanged and reads it with vector loads instead of scalar ones.)
 __device__ __forceinline__ int scalar_load_i32(const int32_t *p, int idx) {
     int v;
-    asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p), "s"(idx * 4) : "memory");
+    asm("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p), "s"(idx * 4));
     return v;
 }
 __device__ __forceinline__ void scalar_load_i32x2(const int32_t *p, int idx, int &v0, int &v1) {
     unsigned long long v;
-    asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p), "s"(idx * 4) : "memory");
+    asm("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p), "s"(idx * 4));
     v0 = (int)(unsigned int)v;
     v1 = (int)(unsigned int)(v >> 32);
 }

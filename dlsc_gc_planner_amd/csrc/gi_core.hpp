@@ -260,6 +260,12 @@ constexpr double SCORE_MIN = 2.2250738585072014e-308;
 constexpr double NEVER = 1e200;  // limit of a row that is not in the model (or is active): never violated (times a pivot scaling it stays finite:
                                  // an infinite score would turn into a NaN under its tag)
 
+// the element `bytes` behind a (uniform) base: a 32-bit byte offset, so that a vector load can take the base from scalar registers
+template <class T>
+DQ_FN T at_offset(const T *base, uint32_t bytes) {
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (size_t)bytes);
+}
+
 // v[k] for a per-lane k without dynamic indexing of a register array (which would go through scratch memory)
 template <class T>
 DQ_FN T pick3(const T *v, int k) {
@@ -302,10 +308,11 @@ DQ_FN double cold_rows_lane_best(const ColdRows &c, int l, int jb, int je, doubl
         for (int u = 0; u < CB; u++) {
             const int j = j0 + 64 * u + l;
             const int jc = j < je ? j : je - 1;
-            key[u] = c.key[jc];
-            g[u][0] = c.nx[jc]; g[u][1] = c.ny[jc]; g[u][2] = c.nz[jc];
-            g[u][3] = c.px[jc]; g[u][4] = c.py[jc]; g[u][5] = c.pz[jc];
-            gd[u] = c.d[jc];
+            const uint32_t o4 = (uint32_t)jc * 4u, o8 = (uint32_t)jc * 8u;  // (32-bit byte offsets: at_offset)
+            key[u] = at_offset(c.key, o4);
+            g[u][0] = at_offset(c.nx, o4); g[u][1] = at_offset(c.ny, o4); g[u][2] = at_offset(c.nz, o4);
+            g[u][3] = at_offset(c.px, o4); g[u][4] = at_offset(c.py, o4); g[u][5] = at_offset(c.pz, o4);
+            gd[u] = at_offset(c.d, o8);
             cf0[u] = (c.flag[(jc - c.Kc) >> 3] >> ((jc - c.Kc) & 7)) & 1;
         }
 #pragma unroll
@@ -549,10 +556,13 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             if (Kc > 0) {  // uniform (an agent without rows may sit at the very end of the arrays: nothing is read for it)
                 const int j = l + 64 * u;
                 const int jc = j < Kc ? j : Kc - 1;
-                cnx[u].at(l) = Rnx[jc]; cny[u].at(l) = Rny[jc]; cnz[u].at(l) = Rnz[jc];
-                cpx[u].at(l) = Rpx[jc]; cpy[u].at(l) = Rpy[jc]; cpz[u].at(l) = Rpz[jc];
-                cd[u].at(l) = Rd[jc];
-                ckey[u].at(l) = Rkey[jc];
+                // (byte offsets of 32 bits: one shift for the seven 4-byte arrays, one for the 8-byte one, added to the arrays' uniform
+                // bases by the load itself -- instead of a 64-bit address per array and row)
+                const uint32_t o4 = (uint32_t)jc * 4u, o8 = (uint32_t)jc * 8u;
+                cnx[u].at(l) = at_offset(Rnx, o4); cny[u].at(l) = at_offset(Rny, o4); cnz[u].at(l) = at_offset(Rnz, o4);
+                cpx[u].at(l) = at_offset(Rpx, o4); cpy[u].at(l) = at_offset(Rpy, o4); cpz[u].at(l) = at_offset(Rpz, o4);
+                cd[u].at(l) = at_offset(Rd, o8);
+                ckey[u].at(l) = at_offset(Rkey, o4);
             } else {
                 cnx[u].at(l) = 0; cny[u].at(l) = 0; cnz[u].at(l) = 0;
                 cpx[u].at(l) = 0; cpy[u].at(l) = 0; cpz[u].at(l) = 0;
@@ -783,10 +793,11 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     for (int u = 0; u < CB; u++) {
                         const int j = j0 + 64 * u + l;
                         const int jc = j < K ? j : K - 1;
-                        kk[u] = Rkey[jc];
-                        g[u][0] = Rnx[jc]; g[u][1] = Rny[jc]; g[u][2] = Rnz[jc];
-                        g[u][3] = Rpx[jc]; g[u][4] = Rpy[jc]; g[u][5] = Rpz[jc];
-                        gd[u] = Rd[jc];
+                        const uint32_t o4 = (uint32_t)jc * 4u, o8 = (uint32_t)jc * 8u;  // (32-bit byte offsets: at_offset)
+                        kk[u] = at_offset(Rkey, o4);
+                        g[u][0] = at_offset(Rnx, o4); g[u][1] = at_offset(Rny, o4); g[u][2] = at_offset(Rnz, o4);
+                        g[u][3] = at_offset(Rpx, o4); g[u][4] = at_offset(Rpy, o4); g[u][5] = at_offset(Rpz, o4);
+                        gd[u] = at_offset(Rd, o8);
                     }
 #pragma unroll
                     for (int u = 0; u < CB; u++) {  // loaded by every lane: no branch around the loads of rows past the end
@@ -1098,10 +1109,11 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 for (int u = 0; u < CB; u++) {
                     const int j = j0 + 64 * u + l;
                     const int jc = j < Kl ? j : Kl - 1;
-                    kk[u] = Rkey[jc];
-                    g[u][0] = Rnx[jc]; g[u][1] = Rny[jc]; g[u][2] = Rnz[jc];
-                    g[u][3] = Rpx[jc]; g[u][4] = Rpy[jc]; g[u][5] = Rpz[jc];
-                    gd[u] = Rd[jc];
+                    const uint32_t o4 = (uint32_t)jc * 4u, o8 = (uint32_t)jc * 8u;  // (32-bit byte offsets: at_offset)
+                    kk[u] = at_offset(Rkey, o4);
+                    g[u][0] = at_offset(Rnx, o4); g[u][1] = at_offset(Rny, o4); g[u][2] = at_offset(Rnz, o4);
+                    g[u][3] = at_offset(Rpx, o4); g[u][4] = at_offset(Rpy, o4); g[u][5] = at_offset(Rpz, o4);
+                    gd[u] = at_offset(Rd, o8);
                 }
 #pragma unroll
                 for (int u = 0; u < CB; u++) {
