@@ -433,7 +433,7 @@ EXPORTED_SYMBOLS = [
     "dlscqp_create", "dlscqp_destroy", "dlscqp_update_param", "dlscqp_last_error",
     "dlscqp_lds_bytes", "dlscqp_solve_batch", "dlscqp_goal_batch", "dlscqp_plan_batch",
     "dlscqp_plan_batch_device", "dlscqp_generate_lsc_device", "dlscqp_rows_to_soa", "dlscqp_set_timing",
-    "dlscqp_get_kernel_times", "dlscqp_world_create", "dlscqp_world_destroy", "dlscqp_generate_sfc_device",
+    "dlscqp_get_kernel_times", "dlscqp_world_create", "dlscqp_world_destroy", "dlscqp_world_prepare", "dlscqp_generate_sfc_device",
     "dlscqp_advance_device", "dlscqp_waypoint_trap_device", "dlscqp_mapf_create", "dlscqp_mapf_destroy", "dlscqp_mapf_step",
     "dlscqp_launch_order_device", "dlscqp_launch_order_history_device", "dlscqp_neighbours_device", "dlscqp_selftest",
     "dlscqp_hint_order_preview_device",

@@ -2220,30 +2220,51 @@ struct dlscqp_world {
     mutable void *d_svt[15] = {};
     mutable const void *svt_key_ptr = nullptr;
     mutable int svt_key_n = 0;
+    mutable bool prepared = false;  // dlscqp_world_prepare named the radii: launches no longer look at theirs
 };
 
 namespace {
 // Build the tables the agents of this launch need and do not have.  Synchronises with `stream` (the radii may be the result of
 // work queued on it) -- once per (radius pointer, count); never during a stream capture.
+// the tables of the gap classes of `radius[0..n)` that are not there yet (host radii).  Bounded: a table of more than 1 GiB, or
+// one that would take the world's tables beyond SVT_TOTAL_LIMIT bytes, is not built (its agents test their boxes point by point);
+// a table whose upload fails is freed again and the pointer table on the device is left as it was.
+constexpr size_t SVT_TOTAL_LIMIT = (size_t)4 << 30;
+int world_build_svt(const dlscqp_world *w, const double *radius, int n_agents) {
+    const size_t entries = ((size_t)w->host.n[0] + 2) * ((size_t)w->host.n[1] + 2) * ((size_t)w->host.n[2] + 2);
+    size_t have = 0;
+    for (void *t : w->d_svt)
+        if (t) have += entries * 4;
+    bool added = false;
+    for (int i = 0; i < n_agents; i++) {
+        const int g = sfc_gap_max(radius[(size_t)i], w->host.res);
+        if (g < 0 || g > 14 || w->d_svt[g] || entries * 4 > ((size_t)1 << 30) || have + entries * 4 > SVT_TOTAL_LIMIT) continue;
+        std::vector<int32_t> svt;
+        build_sfc_svt(w->host, g, svt);
+        void *t = nullptr;
+        hipError_t e = hipMalloc(&t, entries * 4);
+        if (e == hipSuccess && (e = hipMemcpy(t, svt.data(), entries * 4, hipMemcpyHostToDevice)) != hipSuccess) (void)hipFree(t);
+        if (e != hipSuccess) {
+            g_last_error = std::string("summed-volume table: ") + hipGetErrorString(e);
+            return DLSCQP_ERR_HIP;
+        }
+        w->d_svt[g] = t;
+        have += entries * 4;
+        added = true;
+    }
+    if (added) HIP_TRY(hipMemcpy(w->d_svt_ptrs, w->d_svt, sizeof(w->d_svt), hipMemcpyHostToDevice));
+    return DLSCQP_SUCCESS;
+}
+
 int world_prepare_svt(const dlscqp_world *w, const double *d_radius, int n_agents, hipStream_t stream) {
-    if (!w->view.svt || (w->svt_key_ptr == (const void *)d_radius && w->svt_key_n == n_agents)) return DLSCQP_SUCCESS;
+    if (!w->view.svt || w->prepared || (w->svt_key_ptr == (const void *)d_radius && w->svt_key_n == n_agents)) return DLSCQP_SUCCESS;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return DLSCQP_SUCCESS;
     std::vector<double> radius((size_t)n_agents);
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipMemcpy(radius.data(), d_radius, sizeof(double) * (size_t)n_agents, hipMemcpyDeviceToHost));
-    const size_t entries = ((size_t)w->host.n[0] + 2) * ((size_t)w->host.n[1] + 2) * ((size_t)w->host.n[2] + 2);
-    bool added = false;
-    for (int i = 0; i < n_agents; i++) {
-        const int g = sfc_gap_max(radius[(size_t)i], w->host.res);
-        if (g < 0 || g > 14 || w->d_svt[g] || entries * 4 > ((size_t)1 << 30)) continue;
-        std::vector<int32_t> svt;
-        build_sfc_svt(w->host, g, svt);
-        HIP_TRY(hipMalloc(&w->d_svt[g], entries * 4));
-        HIP_TRY(hipMemcpy(w->d_svt[g], svt.data(), entries * 4, hipMemcpyHostToDevice));
-        added = true;
-    }
-    if (added) HIP_TRY(hipMemcpy(w->d_svt_ptrs, w->d_svt, sizeof(w->d_svt), hipMemcpyHostToDevice));
+    const int rc = world_build_svt(w, radius.data(), n_agents);
+    if (rc != DLSCQP_SUCCESS) return rc;
     w->svt_key_ptr = d_radius;
     w->svt_key_n = n_agents;
     return DLSCQP_SUCCESS;
@@ -2298,6 +2319,19 @@ extern "C" int dlscqp_world_create(dlscqp_ctx *c, const double *boxes, int32_t n
         w->host.gaps.swap(hw.gaps);
     }
     *out = w;
+    return DLSCQP_SUCCESS;
+}
+
+extern "C" int dlscqp_world_prepare(dlscqp_world *w, const double *radius, int32_t n_agents) {
+    g_last_error.clear();
+    if (!w || (n_agents > 0 && !radius) || n_agents < 0) { g_last_error = "null or invalid argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    (void)hipSetDevice(w->device);
+    if (w->view.svt) {
+        HIP_TRY(hipDeviceSynchronize());  // (a launch that reads the pointer table may be running)
+        const int rc = world_build_svt(w, radius, n_agents);
+        if (rc != DLSCQP_SUCCESS) return rc;
+    }
+    w->prepared = true;
     return DLSCQP_SUCCESS;
 }
 

@@ -10,6 +10,7 @@ All arithmetic happens in the HIP library (csrc/libdlscqp.so); there is no CPU p
 torch is used only as plumbing for device-resident buffers and streams.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -704,6 +705,11 @@ class SfcGenerator:
                                            C.byref(self.world)), "dlscqp_world_create")
         N = len(radius)
         self.N = N
+        # the per-radius-class tables now, from the host's radii: the launches then neither synchronise nor allocate
+        lib.dlscqp_world_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        r64 = np.ascontiguousarray(radius, dtype=np.float64)
+        if os.environ.get("DLSCQP_WORLD_PREPARE", "1") != "0":  # (0: left to the first launch, as rounds 3-4 did -- tests compare the two)
+            opt._check(lib.dlscqp_world_prepare(self.world, r64.ctypes.data, N), "dlscqp_world_prepare")
         up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(self.device)  # noqa: E731
         self.radius, self.max_vel = up(radius, np.float64), up(max_vel, np.float64)
         self.sfcs = torch.zeros((N, cfg.M, 6), dtype=torch.float32, device=self.device)

@@ -507,6 +507,13 @@ typedef struct dlscqp_world dlscqp_world;
 int dlscqp_world_create(dlscqp_ctx *ctx, const double *boxes /*[n_boxes][6]*/, int32_t n_boxes, double resolution,
                         const float world_min[3], const float world_max[3], dlscqp_world **out);
 void dlscqp_world_destroy(dlscqp_world *world);
+/* Optional, synchronous: build the per-radius-class tables (summed volumes of the lattice-point table) that the agents of the
+ * following dlscqp_generate_sfc_device launches need -- `radius` is a HOST array of the radii that will occur.  Without this call
+ * the first launch with a given (radius pointer, count) builds them itself: it synchronises with its stream once, reads the radii
+ * back and allocates (never inside a stream capture) -- and does not notice radii that change behind the same pointer.  After this
+ * call launches no longer look at their radii: an agent whose class has no table tests its boxes point by point (same boxes,
+ * slower).  Tables are bounded (1 GiB each, 4 GiB per world); on an allocation or upload error nothing is left half-built. */
+int dlscqp_world_prepare(dlscqp_world *world, const double *radius /*[n_agents], host*/, int32_t n_agents);
 
 /* One replanning step of CollisionConstraints' corridor logic for n_agents agents, device pointers:
  *   initialize != 0: initializeSFC (collision_constraints.cpp:435-452) from `position`; out_code 0 = ok, -1 = the start

@@ -85,9 +85,13 @@ def _device_generate(opt, m, radius, vmax, sfcs=None, position=None, initial_tra
         gen.close()
 
 
-@pytest.mark.parametrize("variant", ["turns", "in_sequence", "records"])
+@pytest.mark.parametrize("variant", ["turns", "tables_on_first_launch", "in_sequence", "records"])
 def test_device_corridors_of_mixed_radius_and_speed_classes(gpu_required, variant, monkeypatch):
-    """The variants of tests/test_sfc.py on the device (the world reads DLSCQP_SFC_SVT / DLSCQP_SFC_RECORDS when it is created)."""
+    """The variants of tests/test_sfc.py on the device (the world reads DLSCQP_SFC_SVT / DLSCQP_SFC_RECORDS when it is created).
+    "turns": the per-radius-class tables built by dlscqp_world_prepare from the host's radii (SfcGenerator does that);
+    "tables_on_first_launch": without that call, by the first launch from the radii it reads back."""
+    if variant == "tables_on_first_launch":
+        monkeypatch.setenv("DLSCQP_WORLD_PREPARE", "0")
     if variant == "in_sequence":
         monkeypatch.setenv("DLSCQP_SFC_SVT", "0")
     if variant == "records":
