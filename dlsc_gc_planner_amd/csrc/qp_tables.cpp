@@ -244,6 +244,9 @@ bool build_tables(const dlscqp_config &cfg, int dim, int M, int n, int phi, doub
     out.tabX0s.assign((size_t)M * P * 3, 0.0);
     out.tabX0g.assign((size_t)M * P, 0.0);
     out.tabPhi.assign((size_t)M * 10, 0.0);
+    out.hr_cond.assign((size_t)M, 0.0);
+    out.hr_lmax.assign((size_t)M, 0.0);
+    out.hr_lmin.assign((size_t)M, 0.0);
     kp.phi_ok = 1;
     Mat H((size_t)P * P), HZ((size_t)P * f), Hr((size_t)f * f), Nt((size_t)P * f), HXp((size_t)P * 3), G((size_t)f * 3), tv(f);
     for (int T = 1; T <= M; T++) {
@@ -275,6 +278,35 @@ bool build_tables(const dlscqp_config &cfg, int dim, int M, int n, int phi, doub
         Mat L = Hr;
         if (!cholesky_lower(L, f)) { kp.t_valid[T - 1] = 0; continue; }
         kp.t_valid[T - 1] = 1;
+        {
+            // condition number of the reduced Hessian: largest eigenvalue by power iteration, smallest by inverse iteration with
+            // the factor just made (what the rounding noise of everything computed with the whitening map scales with)
+            std::vector<double> v(f, 1.0), y(f);
+            double lmax = 0.0, lmin_inv = 0.0;
+            for (int it = 0; it < 200; it++) {
+                double nrm = 0;
+                for (int a = 0; a < f; a++) { double t = 0; for (int b = 0; b < f; b++) t += Hr[a * f + b] * v[b]; y[a] = t; nrm += t * t; }
+                nrm = std::sqrt(nrm);
+                if (!(nrm > 0)) break;
+                lmax = nrm;
+                for (int a = 0; a < f; a++) v[a] = y[a] / nrm;
+            }
+            std::fill(v.begin(), v.end(), 1.0);
+            for (int a = 0; a < f; a++) v[a] += 0.01 * a;  // (not an eigenvector of a symmetric pattern by accident)
+            for (int it = 0; it < 200; it++) {
+                for (int i = 0; i < f; i++) { double t = v[i]; for (int k = 0; k < i; k++) t -= L[i * f + k] * y[k]; y[i] = t / L[i * f + i]; }
+                for (int i = f - 1; i >= 0; i--) { double t = y[i]; for (int k = i + 1; k < f; k++) t -= L[k * f + i] * v[k]; v[i] = t / L[i * f + i]; }
+                double nrm = 0;
+                for (int a = 0; a < f; a++) nrm += v[a] * v[a];
+                nrm = std::sqrt(nrm);
+                if (!(nrm > 0)) break;
+                lmin_inv = nrm;
+                for (int a = 0; a < f; a++) v[a] /= nrm;
+            }
+            out.hr_cond[T - 1] = lmax * lmin_inv;
+            out.hr_lmax[T - 1] = lmax;
+            out.hr_lmin[T - 1] = lmin_inv > 0 ? 1.0 / lmin_inv : 0.0;
+        }
         // N = Z L^{-T}:  row p of N solves  L N[p,:]' = Z[p,:]'
         for (int p = 0; p < P; p++)
             for (int i = 0; i < f; i++) {

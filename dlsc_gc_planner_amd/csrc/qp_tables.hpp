@@ -18,6 +18,8 @@ struct HostTables {
     std::vector<double> tabSIW;  // [M][n_slots]
     std::vector<double> tabKIW;  // [M][3][P]
     std::vector<double> tabPhi;  // [M][10]
+    std::vector<double> hr_lmax, hr_lmin;  // [M] its largest and smallest eigenvalue
+    std::vector<double> hr_cond; // [M]           condition number of the reduced Hessian of T terminal segments (0 where it is not positive definite)
     std::vector<Slot> slots;
 };
 

@@ -233,6 +233,16 @@ extern "C" int emul_table_info(const dlscqp_config *cfg, int *f, int *n_slots, i
     return 0;
 }
 
+// condition numbers of the reduced Hessians (one per number of terminal segments; study tool of the dependency thresholds)
+extern "C" int emul_table_cond(const dlscqp_config *cfg, double *out /*[4][M]: condition, largest, smallest eigenvalue, slack whitening sigma*/) {
+    using namespace dlscqp;
+    HostTables tb;
+    std::string err;
+    if (!build_tables(*cfg, cfg->world_dimension, cfg->M, cfg->n, cfg->phi, cfg->dt, tb, err)) return -1;
+    for (int m = 0; m < cfg->M; m++) { out[m] = tb.hr_cond[(size_t)m]; out[cfg->M + m] = tb.hr_lmax[(size_t)m]; out[2 * cfg->M + m] = tb.hr_lmin[(size_t)m]; out[3 * cfg->M + m] = tb.kp.sigma[m]; }
+    return 0;
+}
+
 // Row N1: the device code of lsc_core.hpp run item by item on the host (same source as dlscqp_lsc_kernel).
 static dlscqp::LscGenArgs emul_lsc_args(const dlscqp_config *cfg, const dlscqp_lsc_gen *gen) {
     using namespace dlscqp;
