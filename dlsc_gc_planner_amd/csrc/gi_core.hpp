@@ -1366,6 +1366,14 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 #ifdef DLSCQP_TRACE
     double trace_min_ratio = 1.0;
 #endif
+    // the largest |N'a|^2 / |z|^2 a row was added with so far (1 / the smallest pivot ratio): what the rounding noise of every later
+    // a.dx scales with.  After a pivot of 1e-12 |N'a|^2 -- a row that is independent of the active ones in exact arithmetic and by both
+    // tests -- the active rows' records are numerically singular and a.dx of a DEPENDENT row came out at 0.12 |N'a|^2
+    // (tests/tools/margins_long.py, seed 80048: an infeasible agent with slack variables on its way to the iteration limit); from
+    // such a pivot on every row is measured in the whitened space (DEP_PIVOT below)
+    // (kept as the threshold itself, raised where a row is added: the iteration compares with one number as before.  KParams: the
+    // narrow constant only where it was calibrated)
+    double suspect_now = DXREG ? kp.dep_suspect : DEP_SUSPECT_SLACK;
 
     // Takes a row out of the pricing passes (on: it became active, or was accepted within CPLEX's tolerance) or puts it back
     // (off: it left the active set; `rhs` = its right-hand side if it is a cached LSC row).  code and on are uniform, the
@@ -2174,8 +2182,9 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             }
             bool remeasured = false;
 #endif
-            const double suspect = DXREG ? kp.dep_suspect : DEP_SUSPECT_SLACK;  // (KParams: the narrow threshold only where it was calibrated)
-            if (q > 0 && !(dd2 > suspect * dall)) {
+            // (suspect_now: the shape's constant, or what the worst pivot so far asks for -- DEP_PIVOT eps kappa / pivot ratio -- once that is
+            // beyond the wide constant; beyond 1: every row)
+            if (q > 0 && !(dd2 > suspect_now * dall)) {
                 DQ_TRACE(5, dd2, dall, 0.0, 0.0);  // (the step rate that raised the suspicion)
                 dd2 = whitened_length();  // uniform, a few per cent of the iterations
 #ifdef DLSCQP_TRACE
@@ -2307,6 +2316,12 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 // ---- add row ip: R gains the column (d1; alpha), alpha = |z|  <=>  S = R^-1 gains (-S d1 / alpha; 1 / alpha; zeros),
                 // and Z = G A' S the column G (a - A' rv) / alpha = dx / alpha: record q, every entry of it written ----
                 const double inv_alpha = 1.0 / sqrt(dd2);
+                {
+                    // the threshold this pivot asks for (1e300: every row from here on -- dd2 > 1e300 dall never holds)
+                    double by_pivot = kp.dep_pivot * (dall * inv_alpha * inv_alpha);
+                    by_pivot = by_pivot >= 1.0 ? 1e300 : by_pivot;
+                    suspect_now = (by_pivot > DEP_SUSPECT_SLACK && by_pivot > suspect_now) ? by_pivot : suspect_now;
+                }
 #ifdef DLSCQP_TRACE
                 trace_min_ratio = dd2 / dall < trace_min_ratio ? dd2 / dall : trace_min_ratio;
 #endif

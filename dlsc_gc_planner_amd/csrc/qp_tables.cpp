@@ -460,6 +460,18 @@ bool build_tables(const dlscqp_config &cfg, int dim, int M, int n, int phi, doub
     kp.dbg_exit_phase = -1;
     if (const char *dbg = std::getenv("DLSCQP_DEBUG_EXIT_PHASE")) kp.dbg_exit_phase = std::atoi(dbg);  // read by -DDQ_PHASE_PROFILE builds only
     if (const char *dbg = std::getenv("DLSCQP_DEBUG_MAX_ITER")) kp.max_iter = std::atoi(dbg);  // debugging aid
+    {
+        // DEP_PIVOT x eps x the condition number of the Hessian the solve works with: the reduced Hessians of all T and the slack
+        // variables' diagonal 2 w_s (M - m) / M = 1 / sigma_m^2 (present or not: the larger number is the careful one)
+        double lmax = 0.0, lmin = 1e300;
+        for (int T = 1; T <= M; T++)
+            if (kp.t_valid[T - 1]) { lmax = std::max(lmax, out.hr_lmax[T - 1]); lmin = std::min(lmin, out.hr_lmin[T - 1]); }
+        if (cfg.slack_collision_weight > 0)
+            for (int m = 0; m < M; m++)
+                if (kp.sigma[m] > 0) { const double h = 1.0 / (kp.sigma[m] * kp.sigma[m]); lmax = std::max(lmax, h); lmin = std::min(lmin, h); }
+        const double kappa = (lmax > 0 && lmin > 0 && lmin < 1e300) ? lmax / lmin : 1.0;
+        kp.dep_pivot = DEP_PIVOT * 2.220446049250313e-16 * kappa;
+    }
     return true;
 }
 

@@ -210,6 +210,7 @@ struct Solver {
         dual.assign(r, 0.0); act.assign(r, -1);
         Ga.assign(nx, 0.0); dx.assign(nx, 0.0); u.assign(nx, 0.0); d1.assign(r, 0.0); rv.assign(r, 0.0); z.assign(f, 0.0);
         int q = 0, iters = 0, n_add = 0, n_drop = 0, status = DLSCQP_OK;
+        double suspect_now = DEP_SUSPECT_SLACK;  // raised by a tiny pivot (qp_types.hpp: DEP_PIVOT)
         const int max_iter = 20 * (r + 8) + 200;
         auto value = [&](const SparseRow &a) { double v = 0; for (int e = 0; e < a.n; e++) v += a.cf[e] * x[a.idx[e]]; return v; };
 #ifdef SKIP_STUDY
@@ -290,7 +291,7 @@ struct Solver {
                 double dd2 = 0;
                 for (int e = 0; e < a.n; e++) dd2 += a.cf[e] * dx[a.idx[e]];
                 double noise2 = 0.0;
-                if (q > 0 && !(dd2 > DEP_SUSPECT_SLACK * dall)) {
+                if (q > 0 && !(dd2 > suspect_now * dall)) {
                     // measured again in the whitened space: u = a - A' rv, z = N' u (gi_core.hpp: whitened_length)
                     std::fill(u.begin(), u.end(), 0.0);
                     for (int e = 0; e < a.n; e++) u[a.idx[e]] += a.cf[e];
@@ -331,6 +332,11 @@ struct Solver {
                 uq += t;
                 if (!dependent && t2 <= t1) {
                     const double ia = 1.0 / sqrt(dd2);
+                    {
+                        double by_pivot = kp.dep_pivot * (dall * ia * ia);
+                        by_pivot = by_pivot >= 1.0 ? 1e300 : by_pivot;
+                        if (by_pivot > suspect_now) suspect_now = by_pivot;
+                    }
                     for (int i = 0; i < q; i++) S[(size_t)i * r + q] = -rv[i] * ia;
                     S[(size_t)q * r + q] = ia;
                     double *zq = &Zc[(size_t)q * nx];
