@@ -409,6 +409,37 @@ def moving_crowd(device, steps=60, warm=20, heavy_ranks=0):
     return out
 
 
+def overlapping_streams(dev, G):
+    """G streams whose work runs side by side: streams are mapped to a few hardware queues, and two streams on one queue run one after
+    the other (SwarmLoop.pick_streams measures that with the loop's own batches; here with torch's spin kernel: a pair that takes
+    as long as the two spins in a row shares a queue)."""
+    import torch
+    cands = [torch.cuda.Stream(dev) for _ in range(max(8, 2 * G) + 4)]
+    if G == 1 or not hasattr(torch.cuda, "_sleep"):
+        return cands[:G]
+
+    def span(sa, sb):
+        best = float("inf")
+        for _ in range(3):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            with torch.cuda.stream(sa):
+                torch.cuda._sleep(1000000)
+            with torch.cuda.stream(sb):
+                torch.cuda._sleep(1000000)
+            torch.cuda.synchronize(dev)
+            best = min(best, time.perf_counter() - t0)
+        return best
+    serial = span(cands[0], cands[0])
+    kept, rest = [cands[0]], []
+    for s_ in cands[1:]:
+        if len(kept) < G and all(span(k_, s_) < 0.75 * serial for k_ in kept):
+            kept.append(s_)
+        else:
+            rest.append(s_)
+    return kept + rest[:G - len(kept)] if len(kept) < G else kept
+
+
 def s64_closed_loop(device, n_swarms=512, groups=1, first=3, steps=8, flights=4, graph=False):
     """BASELINE.json configs[1] at the headline's scale with the WHOLE replanning step on the device (traj_planner.cpp:108-133 per
     agent: prediction of the neighbours from their previous plans, generateDLSCGC :603-666, goal LP, QP; then doStep): the
@@ -431,7 +462,7 @@ def s64_closed_loop(device, n_swarms=512, groups=1, first=3, steps=8, flights=4,
         G -= 1
     per = (n_swarms // G) * 64
     dev = torch.device("cuda", device)
-    streams = [torch.cuda.Stream(dev) for _ in range(G)]
+    streams = overlapping_streams(dev, G)
 
     def take_off():
         sims = []
