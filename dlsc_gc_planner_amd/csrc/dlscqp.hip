@@ -23,6 +23,9 @@
 #define DQ_KEEP(v) asm volatile("" : "+v"(v))
 #define DQ_MARK(text) asm volatile("; " text)
 #if defined(__HIP_DEVICE_COMPILE__)
+#define DQ_SETPRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
 static __device__ __forceinline__ double dq_score_max(double a, double b) {
     double r;
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -70,7 +73,9 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 
 // One wavefront = one agent.  Reg<T> is a VGPR; each() is the lane itself; cross-lane traffic is
 // v_readlane (broadcasts), ds_bpermute butterflies (reductions) and ballots.
-struct WaveGpu {
+// FRESH_LANE: every each() block starts from a lane number the compiler cannot see through (see each()).
+template <bool FRESH_LANE>
+struct WaveGpuT {
     int lane;
     // Helper wavefronts (WPA > 1): the workgroup of an agent has nw wavefronts; wavefront 0 plans, the others price their
     // share of the rows beyond the register cache in every pricing pass.  mail (LDS, 8 doubles): [0] = 1.0 when the planning
@@ -130,8 +135,16 @@ struct WaveGpu {
         trn++;
     }
 #endif
+    // FRESH_LANE: the lane number goes through an empty statement first.  Everything a block derives from it -- LDS addresses (lane x 8
+    // + constant), row codes, clamped indices -- is then computed where it is used, one or two instructions each, instead of being
+    // hoisted in front of the iteration loop and kept in registers across it: in the S64 instantiation that was ~45 of 250 vector
+    // registers (tests/tools/isa_liveness.py), the difference between two and three wavefronts per SIMD.
     template <class F>
-    __device__ __forceinline__ void each(F f) const { f(lane); }
+    __device__ __forceinline__ void each(F f) const {
+        int l = lane;
+        if constexpr (FRESH_LANE) asm volatile("" : "+v"(l));
+        f(l);
+    }
     // wave-uniform work on the working set: every lane reads, computes and writes the same (lock step: all lanes read before any writes)
     template <class F>
     __device__ __forceinline__ void once(F f) const { f(); }
@@ -271,6 +284,7 @@ struct WaveGpu {
         out.v = nxt;
     }
 };
+typedef WaveGpuT<false> WaveGpu;
 
 // ---- between two launches (include/dlscqp.h: dlscqp_advance): one wavefront per agent ----
 struct AdvanceArgs {
@@ -528,8 +542,12 @@ __device__ __forceinline__ int iteration_class(int it) {
 #ifndef DQ_PLAN_OCC  // wavefronts per SIMD the standard builds are compiled for (3: an experiment of round 5)
 #define DQ_PLAN_OCC 2
 #endif
+#ifndef DQ_S64_OCC  // ... and the instantiation whose rows are all in registers (S64; gi_core.hpp: LEAN) -- round 6: three, in 168 registers without a
+#define DQ_S64_OCC 3  // byte of scratch memory, since nothing lane-derived or converted is kept across the iteration loop any more
+#endif
 #ifndef DQ_KERNEL_ATTR
-#define DQ_KERNEL_ATTR __launch_bounds__(64 * WPA, WPA > 1 ? DQ_WPA_OCC : ((WIDE || (DIMS > 0 && (RC == 2 || (DIMS == 2 && FS == 28 && DQ_M10_2D_ONE)))) ? 1 : DQ_PLAN_OCC))
+#define DQ_KERNEL_ATTR __launch_bounds__(64 * WPA, WPA > 1 ? DQ_WPA_OCC : ((WIDE || (DIMS > 0 && (RC == 2 || (DIMS == 2 && FS == 28 && DQ_M10_2D_ONE)))) ? 1 : \
+                                                             ((DIMS > 0 && KU == 2 && SU == 0 && SLK == 0) ? DQ_S64_OCC : DQ_PLAN_OCC)))
 #endif
 // WS_HBM: the agent's working set (MemLayout) lives in a per-slot HBM buffer instead of LDS -- for batches whose working
 // set exceeds the 160 KiB of a CU.  Since the solver keeps no orthogonal factor (gi_core.hpp) that is only a batch with
@@ -552,7 +570,10 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
     unsigned char *smem;
     if constexpr (WS == WS_HBM) smem = a.work + (size_t)slot * a.work_stride;
     else smem = lds;
-    WaveGpu w;
+    // the instantiation whose rows are all in registers (S64) is compiled for three wavefronts per SIMD: gi_core.hpp "LEAN"
+    constexpr bool LEAN_K = DIMS > 0 && KU == 2 && SU == 0 && SLK == 0 && !WIDE && WPA == 1 && WS == WS_LDS;
+    typedef WaveGpuT<LEAN_K> Wave;
+    Wave w;
     w.lane = (int)threadIdx.x & 63;
     int cls_in = 0;
     // (wave-uniform by construction -- ballots and scalar loads; said aloud: it indexes scalar loads below)
@@ -614,7 +635,7 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
                 __syncthreads();  // pass_begin (or the end of the solve)
                 if (uniform_f64(w.mail[0]) != 0.0) break;  // every lane reads the same word
                 c.tNN = kp.tabNN + (size_t)((int)uniform_f64(w.mail[1]) - 1) * c.P;
-                WaveGpu::Reg<double> best;
+                typename Wave::template Reg<double> best;
                 double least = 0.0;  // (the helpers price all of their shares in every pass)
                 best.v = lds_rows_lane_best<SLK != 0>(lr, w.lane, ljb, lje, 0.0, least);
                 best.v = cold_rows_lane_best<4>(c, w.lane, hjb, hje, best.v, least);
@@ -644,7 +665,7 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
     const int M = kp.M, n1 = kp.n1;
     const size_t xs = (size_t)kp.dim * M * n1 + (size_t)M * a.max_slack_obs;
     int iters_done = 0;
-    plan_agent<RC, DIMS, FS, MS, KU, SU, SLK, WaveGpu>(w, kp, lay, smem, a.spill ? a.spill + (size_t)slot * a.spill_stride : nullptr,
+    plan_agent<RC, DIMS, FS, MS, KU, SU, SLK, Wave>(w, kp, lay, smem, a.spill ? a.spill + (size_t)slot * a.spill_stride : nullptr,
                a.agents + ag, a.rows, rb, nrows_ag,
                a.sfc ? a.sfc + (size_t)ag * M * 6 : nullptr, a.max_slack_obs, a.do_goal, a.do_traj,
                a.out_goal ? a.out_goal + (size_t)ag * a.goal_stride : nullptr,
@@ -1117,7 +1138,11 @@ constexpr int DQ_WPA = 4;
 constexpr int DQ_WPA_MAX_SLOTS = 512;  // launches of at most this many agents use the builds with helper wavefronts
 constexpr int DQ_WIDE_MAX_SLOTS = 1024;  // launches of at most this many agents use it: one agent per SIMD of the chip
 constexpr int DQ_ID_HBM = 7;  // the runtime-shape two-register instantiation is the one that also exists as WS_HBM
+#ifdef DLSCQP_ONLY_S64
+const kernel_t dlscqp_plan_kernel_hbm = nullptr;
+#else
 const kernel_t dlscqp_plan_kernel_hbm = dlscqp_plan_kernel<2, 0, 0, 0, DQ_G2_KU, DQ_G2_SU, -1, WS_HBM>;
+#endif
 
 // The WIDE build of an instantiation, for those that have one: two wavefronts per SIMD normally, and register caches
 // beyond the all-in-registers instantiation (which does not spill).
@@ -1141,7 +1166,10 @@ kernel_t wpa_kernel() {
 KernelChoice select_kernel(const KParams &kp, int max_slack_obs, int kmax, bool force_runtime_shape = false) {
     static const bool force_env = std::getenv("DLSCQP_FORCE_GENERIC") != nullptr;  // debugging aid
     const bool force_generic = force_env || force_runtime_shape;
-#ifdef DLSCQP_ONLY_G2  // debugging aid: compile only the generic two-register instantiation
+#ifdef DLSCQP_ONLY_S64  // developer aid (tests/tools/s64_only.sh): only the S64 instantiation -- a quarter of the compile time; run with DLSCQP_NO_SELFTEST=1
+    (void)force_generic; (void)max_slack_obs; (void)kmax;
+    return {dlscqp_plan_kernel<1, 3, 13, 5, 2, 0, 0>, 0, 2, 0, true};
+#elif defined(DLSCQP_ONLY_G2)  // debugging aid: compile only the generic two-register instantiation
     (void)force_generic;
     return {dlscqp_plan_kernel<2, 0, 0, 0, DQ_G2_KU, DQ_G2_SU, -1>, 7, DQ_G2_KU, DQ_G2_SU, false};
 #else
@@ -1541,7 +1569,7 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         // DLSCQP_ROWS_IN_LDS=0: every such row from HBM in every pass, as before round 4 (tests).
         static const bool rows_in_lds = !(getenv("DLSCQP_ROWS_IN_LDS") && getenv("DLSCQP_ROWS_IN_LDS")[0] == '0');
         const bool one_per_simd = wide || (kc.id == 3 && DQ_M10_2D_ONE) || kc.id == 4 || kc.id == 5;
-        const int max_per_cu = wpa ? (DQ_WPA_OCC * 4) / DQ_WPA : (one_per_simd ? 4 : 4 * DQ_PLAN_OCC);
+        const int max_per_cu = wpa ? (DQ_WPA_OCC * 4) / DQ_WPA : (one_per_simd ? 4 : 4 * (kc.id == 0 ? DQ_S64_OCC : DQ_PLAN_OCC));
         const LayoutChoice lc = choose_layout(c->kp, b, kc, a.n_slots_launch, max_per_cu < 1 ? 1 : max_per_cu, rows_in_lds);
         lay = lc.lay;
         if (lay.bytes > LDS_LIMIT) { g_last_error = "working set exceeds the LDS of a CU"; return DLSCQP_ERR_UNSUPPORTED; }  // (ws_hbm above rules it out)
@@ -1604,7 +1632,11 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kc.fn), hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes + 8016));
     hipLaunchKernelGGL(kfn, dim3(a.n_slots_launch), dim3(wpa ? 64 * DQ_WPA : 64), lay.bytes + 8016, stream, c->kp, lay, a);
 #else
-    hipLaunchKernelGGL(kfn, dim3(a.n_slots_launch), dim3(wpa ? 64 * DQ_WPA : 64), ws_hbm ? 0 : lay.bytes, stream, c->kp, lay, a);
+    // DLSCQP_LDS_TOTAL (developer experiment): the workgroup asks for at least this much LDS -- fewer agents per CU than the registers would allow
+    static const int lds_total = getenv("DLSCQP_LDS_TOTAL") ? atoi(getenv("DLSCQP_LDS_TOTAL")) : 0;
+    const int lds_bytes = ws_hbm ? 0 : (lds_total > lay.bytes ? lds_total : lay.bytes);
+    if (lds_total > lay.bytes && !ws_hbm) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL(kfn, dim3(a.n_slots_launch), dim3(wpa ? 64 * DQ_WPA : 64), lds_bytes, stream, c->kp, lay, a);
 #endif
     HIP_TRY(hipGetLastError());
     if (timed) {

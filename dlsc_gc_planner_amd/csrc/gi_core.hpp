@@ -60,6 +60,18 @@
 #ifndef DQ_WAVE_ALL
 #define DQ_WAVE_ALL(c) (c)
 #endif
+// DQ_SETPRIO(n): the wavefront's issue priority, 0 .. 3 (s_setprio; nothing on the host)
+#ifndef DQ_SETPRIO
+#define DQ_SETPRIO(n) ((void)0)
+#endif
+#ifndef DQ_PRIO_STEPS  // 1: an iterating agent's wavefront raises its priority to 1, 2, 3 at its DQ_PRIO_AT1 / 2 / 3-th pricing pass (0: never)
+#define DQ_PRIO_STEPS 1
+#endif
+#ifndef DQ_PRIO_AT1
+#define DQ_PRIO_AT1 3
+#define DQ_PRIO_AT2 8
+#define DQ_PRIO_AT3 16
+#endif
 // DQ_MARK(text): a comment in the generated assembly (tests/divergence_check.py recognises the exit stores by it)
 #ifndef DQ_MARK
 #define DQ_MARK(text) ((void)0)
@@ -80,6 +92,7 @@ struct MemLayout {
     int oC, cs, qz;
     int oX, oDx, oBlo, oBhi;  // in doubles (oDx < 0: the instantiation keeps the step direction in registers, DXREG)
     int oU;                   // nx_max doubles: a - A' r in the variables' own space (plan_agent: whitened_length)
+    int oKiw;                 // LEAN instantiation: 3 nxc doubles, pivot scalings of the bound / velocity / acceleration rows by coordinate (else -1)
     int oMail;                // 8 doubles: what the planning wavefront and its helper wavefronts tell each other (dlscqp.hip)
     int oDump;                // 32 dump slots (lane & 31) for the lanes that have nothing to store; then two doubles that stay 0.0
     int oFlag;                // byte offset of the skip flags: two bytes per structured slot beyond the slot cache, then (oFlagRows)
@@ -120,6 +133,9 @@ DQ_FN MemLayout make_layout(const KParams &kp, int max_slack_obs, int kmax, int 
     L.oBhi = o; o += kp.nb;
     L.oMail = o; o += 8;
     L.oU = o; o += L.nx_max;
+    // (plan_agent: LEAN -- the instantiation whose rows and slots are all in registers keeps the coordinates' pivot scalings here)
+    const bool lean = by_kind && nslk == 0 && KU == 2 && SU == 0;
+    L.oKiw = lean ? o : -1; o += lean ? 3 * kp.dim * kp.P : 0;
     L.oCold = o;
     L.cold_cap = 0;
     if (lds_budget > 0 && cold_rows > 0) {
@@ -483,6 +499,12 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     constexpr bool ALL_CACHED = KU == 2 && SU == 0;
     // ... and, knowing all of an agent's rows, it asks first whether any of them is violated at all (the screen, below)
     constexpr bool SCREEN = ALL_CACHED && DIMS > 0 && SLK == 0;
+    // LEAN (the same instantiation: S64): compiled for THREE wavefronts per SIMD -- 168 vector registers.  What the pricing pass alone
+    // reads does not sit in registers across the iteration: the coordinates' pivot scalings live in LDS (lay.oKiw), the velocity and
+    // acceleration limits are one uniform number each plus a bit per coordinate ("this row is out of the pass": lim_off), row codes
+    // are computed from the lane number, and the float32 normals go through DQ_KEEP at the head of a pass, so that their
+    // conversions to double are made there instead of once in front of the loop (twelve registers).  Same arithmetic, same bits.
+    constexpr bool LEAN = SCREEN;
     constexpr int SUA = SU > 0 ? SU : 1;  // register arrays of the slot cache (never empty)
     // BYK (static shapes): the rows of one KIND that every agent has -- variable bounds / box faces, velocity and
     // acceleration limits (traj_optimizer.cpp:237-270, 385-410, 453-487) -- are not decoded from the slot table: lane l owns
@@ -965,6 +987,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 const double v = xa0[u].at(l) * (double)pick3(pos, k) + xa1[u].at(l) * (double)pick3(vel, k) + xa2[u].at(l) * (double)pick3(acc, k) +
                                  xag[u].at(l) * (double)pick3(goal, k);
                 base[blend_idx(in, oX + j, odump + (l & 31))] = v;
+                if (LEAN) {  // the coordinate's pivot scalings: read back by every pricing pass (kind-major: the lane's address + a constant)
+#pragma unroll
+                    for (int t = 0; t < 3; t++) base[blend_idx(in, lay.oKiw + t * nxc + j, odump + (l & 31))] = kiw[u][t].at(l);
+                }
             }
         });
         // its objective is a 4 x 4 quadratic form per axis (qp_tables.cpp: tabPhi), evaluated here, where its table has just
@@ -1160,6 +1186,8 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
     // BYK: the limits of the lane's coordinates (after the sync: the box faces come from the bound table in LDS)
     RegD blo_r[NXP], bhi_r[NXP], hv_r[NXP], ha_r[NXP];
     RegU jtag[NXP];
+    RegU lim_off;  // LEAN: bit 2 u = the velocity rows of the lane's coordinate u are out of the pass (not in the model, or one is active), 2 u + 1: acceleration
+    const double hv_c = hv_lim + VIOL_TOL, ha_c = ha_lim + VIOL_TOL;  // (limit + tolerance: what a pass compares with)
     if (BYK) {
         w.each([&](int l) {
 #pragma unroll
@@ -1179,9 +1207,14 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 hv_r[u].at(l) = has_v ? hv_lim + VIOL_TOL : NEVER;
                 ha_r[u].at(l) = has_a ? ha_lim + VIOL_TOL : NEVER;
                 jtag[u].at(l) = (uint32_t)jc << 3;
+                const uint32_t ob = ((has_v ? 0u : 1u) | (has_a ? 0u : 2u)) << (2 * u);
+                lim_off.at(l) = u == 0 ? ob : (lim_off.at(l) | ob);
             }
         });
     }
+    // the velocity / acceleration limit of the lane's coordinate u as a pass (or the screen) sees it
+    auto lim_v = [&](uint32_t off, int u) -> double { return LEAN ? (((off >> (2 * u)) & 1u) ? NEVER : hv_c) : 0.0; };
+    auto lim_a = [&](uint32_t off, int u) -> double { return LEAN ? (((off >> (2 * u + 1)) & 1u) ? NEVER : ha_c) : 0.0; };
 #ifdef DQ_PROLOGUE_STAMPS
     w.stamp(10);
 #endif
@@ -1222,13 +1255,16 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
 #pragma unroll
             for (int u = 0; u < NXP; u++) {
                 const double dv = c1[u] - c0[u], da = (c2[u] - c1[u]) - dv;
-                const double hv = hv_r[u].at(l), ha = ha_r[u].at(l);
+                const double hv = LEAN ? lim_v(lim_off.at(l), u) : hv_r[u].at(l), ha = LEAN ? lim_a(lim_off.at(l), u) : ha_r[u].at(l);
                 any |= (blo_r[u].at(l) - c0[u] > 0.0) | (c0[u] - bhi_r[u].at(l) > 0.0) | (-hv - dv > 0.0) | (dv - hv > 0.0) |
                        (-ha - da > 0.0) | (da - ha > 0.0);
             }
             sv.at(l) = any ? 1 : 0;
         });
         screened = !w.any(sv);
+#ifdef DQ_CUT_AFTER_SCREEN  // developer experiment (tests/tools/zero_ab.py): no iteration code in the kernel at all -- what the prologue, the screen and
+        screened = true;    // the read-out cost at other register budgets / occupancies (wrong plans for agents with a violated row)
+#endif
         if (!screened) {  // uniform: the pivot scalings of the cached rows, now that they are needed
             w.each([&](int l) {
 #pragma unroll
@@ -1396,16 +1432,26 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             lim = w.uni(lim);
             const double off = (kind == 0 && side == 0) ? -NEVER : NEVER;
             const double nv = on ? off : lim;
-            w.each([&](int l) {
+            if (LEAN && kind != 0) {  // uniform: the coordinate's bit
+                const uint32_t bit = 1u << (2 * uo + (kind - 1));
+                w.each([&](int l) {
+                    const uint32_t cur = lim_off.at(l);
+                    lim_off.at(l) = l == own ? (on ? (cur | bit) : (cur & ~bit)) : cur;
+                });
+            } else {
+                w.each([&](int l) {
 #pragma unroll
-                for (int u = 0; u < NXP; u++) {
-                    const bool me = (l == own) & (u == uo);
-                    blo_r[u].at(l) = (me & (kind == 0) & (side == 0)) ? nv : blo_r[u].at(l);
-                    bhi_r[u].at(l) = (me & (kind == 0) & (side == 1)) ? nv : bhi_r[u].at(l);
-                    hv_r[u].at(l) = (me & (kind == 1)) ? nv : hv_r[u].at(l);
-                    ha_r[u].at(l) = (me & (kind == 2)) ? nv : ha_r[u].at(l);
-                }
-            });
+                    for (int u = 0; u < NXP; u++) {
+                        const bool me = (l == own) & (u == uo);
+                        blo_r[u].at(l) = (me & (kind == 0) & (side == 0)) ? nv : blo_r[u].at(l);
+                        bhi_r[u].at(l) = (me & (kind == 0) & (side == 1)) ? nv : bhi_r[u].at(l);
+                        if (!LEAN) {
+                            hv_r[u].at(l) = (me & (kind == 1)) ? nv : hv_r[u].at(l);
+                            ha_r[u].at(l) = (me & (kind == 2)) ? nv : ha_r[u].at(l);
+                        }
+                    }
+                });
+            }
         } else if (unit < UL0 + Kc) {
             const int row = unit - UL0, own = row & 63, uo = row >> 6;
             const double nv = on ? -NEVER : rhs;
@@ -1467,6 +1513,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         if (!ALL_CACHED && w.nw > 1) w.pass_begin(T);  // the helper wavefronts start on their shares of the cold rows
         w.each([&](int l) {
             double xr[KU][4];
+            if (LEAN) {  // (the conversions of the normals to double belong to this pass: not in front of the loop, in twelve registers)
+#pragma unroll
+                for (int u = 0; u < KU; u++) { DQ_KEEP(cnx[u].at(l)); DQ_KEEP(cny[u].at(l)); DQ_KEEP(cnz[u].at(l)); }
+            }
 #pragma unroll
             for (int u = 0; u < KU; u++) {
                 const int p = cpo[u].at(l);
@@ -1485,13 +1535,17 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             }
             // BYK: x_j, x_{j+1}, x_{j+2} of the lane's coordinates (the neighbours that do not exist meet a limit that is never
             // violated)
-            double c0[NXP], c1[NXP], c2[NXP];
+            double c0[NXP], c1[NXP], c2[NXP], kw[NXP][3];
             if (BYK) {
 #pragma unroll
                 for (int u = 0; u < NXP; u++) {
                     const int j = 64 * u + l;
                     const int j0 = j < nxc ? j : nxc - 1, j1 = j + 1 < nxc ? j + 1 : nxc - 1, j2 = j + 2 < nxc ? j + 2 : nxc - 1;
                     c0[u] = x[j0]; c1[u] = x[j1]; c2[u] = x[j2];
+                    if (LEAN) {
+#pragma unroll
+                        for (int t = 0; t < 3; t++) kw[u][t] = base[lay.oKiw + t * nxc + j0];
+                    }
                 }
             }
 #pragma unroll
@@ -1499,6 +1553,10 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             if (BYK) {
 #pragma unroll
                 for (int u = 0; u < NXP; u++) { DQ_KEEP(c0[u]); DQ_KEEP(c1[u]); DQ_KEEP(c2[u]); }
+                if (LEAN) {
+#pragma unroll
+                    for (int u = 0; u < NXP; u++) { DQ_KEEP(kw[u][0]); DQ_KEEP(kw[u][1]); DQ_KEEP(kw[u][2]); }
+                }
             }
             double bs = 0.0;
 #pragma unroll
@@ -1508,15 +1566,15 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                 if (dim == 3) val = fma((double)cnz[u].at(l), xr[u][2], val);
                 if (SLK != 0) val -= xr[u][3];
                 const double v = (cd[u].at(l) - VIOL_TOL) - val;
-                bs = DQ_SCORE_MAX(bs, tag_score(v * ciw[u].at(l), ltag[u].at(l)));
+                bs = DQ_SCORE_MAX(bs, tag_score(v * ciw[u].at(l), LEAN ? (uint32_t)((BYK ? nxc : 0) + l + 64 * u) << 3 : ltag[u].at(l)));
             }
             if (BYK) {
                 // the six rows of each of the lane's coordinates
 #pragma unroll
                 for (int u = 0; u < NXP; u++) {
                     const double dv = c1[u] - c0[u], da = (c2[u] - c1[u]) - dv;
-                    const double wb = kiw[u][0].at(l), wv = kiw[u][1].at(l), wa = kiw[u][2].at(l);
-                    const double hv = hv_r[u].at(l), ha = ha_r[u].at(l);  // (limit + tolerance: the registers hold that)
+                    const double wb = LEAN ? kw[u][0] : kiw[u][0].at(l), wv = LEAN ? kw[u][1] : kiw[u][1].at(l), wa = LEAN ? kw[u][2] : kiw[u][2].at(l);
+                    const double hv = LEAN ? lim_v(lim_off.at(l), u) : hv_r[u].at(l), ha = LEAN ? lim_a(lim_off.at(l), u) : ha_r[u].at(l);  // (limit + tolerance)
                     double sb = DQ_SCORE_MAX(tag_score((blo_r[u].at(l) - c0[u]) * wb, 0u),
                                      tag_score((c0[u] - bhi_r[u].at(l)) * wb, 1u));
                     sb = DQ_SCORE_MAX(sb, tag_score((-hv - dv) * wv, 2u));
@@ -1526,7 +1584,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     // the coordinate's number above the row's (tag_score keeps the three low bits of the lane's winner)
                     uint64_t b;
                     memcpy(&b, &sb, 8);
-                    b |= (uint64_t)jtag[u].at(l);
+                    b |= (uint64_t)(LEAN ? (uint32_t)(64 * u + l < nxc ? 64 * u + l : nxc - 1) << 3 : jtag[u].at(l));
                     memcpy(&sb, &b, 8);
                     bs = DQ_SCORE_MAX(bs, sb);
 #ifdef DLSCQP_DEBUG_SCAN
@@ -1649,6 +1707,14 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         // slow as its slowest agent, and those were the infeasible ones).  Checked every second pricing pass from the
         // eighth on.
         n_price++;
+        // A launch is as long as its slowest agent, and with three wavefronts on a SIMD every one of them is slower than with two: an agent
+        // that keeps iterating raises its wavefront's issue priority (the SIMD's arbiter serves the highest ready priority first) -- the
+        // few agents on the launch's critical path run at the pace they had alone, the many that never iterate give way for a moment.
+        if (DQ_PRIO_STEPS) {
+            if (n_price == DQ_PRIO_AT1) DQ_SETPRIO(1);
+            else if (n_price == DQ_PRIO_AT2) DQ_SETPRIO(2);
+            else if (n_price == DQ_PRIO_AT3) DQ_SETPRIO(3);
+        }
         if (kp.wd_cut && nslk == 0 && n_price >= 8 && (n_price & 1) == 0) {
             if (n_price == 8) f_max = objective_upper_bound();  // first check of this agent
             const double f_now = objective();
@@ -1857,7 +1923,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                         if (SLK != 0) DQ_KEEP(zs);
                         if (q > qz) {  // uniform: some records live in the spill record
                             const bool sp = on & (j >= qz);
-                            const double *zg = colsp + (size_t)(sp ? j - qz : 0) * cs + zo;
+                            const double *zg = colsp + (size_t)blend_idx(sp, j - qz, 0) * cs + zo;  // (mask arithmetic: as ?: this came out as an EXEC-masked branch)
                             double y0 = zg[ze0], y1 = zg[ze1], y2 = zg[ze2], ys = SLK != 0 ? zg[zes] : 0.0;
                             DQ_KEEP(y0); DQ_KEEP(y1); DQ_KEEP(y2);
                             if (SLK != 0) DQ_KEEP(ys);
@@ -2399,7 +2465,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                         DQ_KEEP(sv);
                         if (q > qz) {  // uniform
                             const bool sp = in & (k >= qz);
-                            double sg = colsp[(size_t)(sp ? k - qz : 0) * cs + lcol];
+                            double sg = colsp[(size_t)blend_idx(sp, k - qz, 0) * cs + lcol];
                             DQ_KEEP(sg);
                             sv = sp ? sg : sv;
                         }

@@ -20,6 +20,8 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_
 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS --output-format csv -d $OUT/sq4 -- $B > $OUT/sq4.log 2>&1
 # the FP64 share of the VALU instructions (4 cycles of a SIMD's vector pipe each, the others 2): what valu_issue_frac is priced with
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT --output-format csv -d $OUT/sq5 -- $B > $OUT/sq5.log 2>&1
+# matrix-core instructions: ZERO by design (active-set method: matrix-vector products with <= 16 columns) -- said with the counter
+rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/sq6 -- $B > $OUT/sq6.log 2>&1
 python3 profiles/summarize.py $OUT $NAME --steps $((STEPS * GROUPS_)) --agents $((32768 / GROUPS_)) --concurrent $GROUPS_ > $OUT/summary.txt 2>&1
 cp profiles/$NAME.md profiles/$NAME.json profiles/hbm_traffic_latest.json $OUT/ 2>/dev/null
 # (the diagnostic builds are compiled on first use: their compiler output stays out of the files)
@@ -38,5 +40,5 @@ python3 profiles/kernels.py $OUT/all $NAME > $OUT/kernels.txt 2>&1
 # what is to be committed under profiles/ travels back with gpurun_out/
 mkdir -p $OUT/for_profiles
 cp profiles/${NAME}* profiles/hbm_traffic_latest.json $OUT/for_profiles/ 2>/dev/null
-rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/sq1 $OUT/sq2 $OUT/sq3 $OUT/sq4 $OUT/sq5 $OUT/all
+rm -rf $OUT/trace $OUT/fetch $OUT/write $OUT/sq1 $OUT/sq2 $OUT/sq3 $OUT/sq4 $OUT/sq5 $OUT/sq6 $OUT/all
 tail -5 $OUT/summary.txt

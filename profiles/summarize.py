@@ -160,6 +160,9 @@ def main():
         out.append("")
     if "pmc_SQ_WAIT_ANY" in summary and "pmc_SQ_WAVE_CYCLES" in summary:
         out.append("SQ_WAIT_ANY / SQ_WAVE_CYCLES = %.3f of the wave-cycles waiting\n" % (summary["pmc_SQ_WAIT_ANY"] / summary["pmc_SQ_WAVE_CYCLES"]))
+    if "pmc_SQ_INSTS_MFMA" in summary:
+        out.append("MFMA instructions per launch: %.0f (SQ_INSTS_MFMA; FP64: %s; SQ_VALU_MFMA_BUSY_CYCLES %s) -- the method has no GEMM-shaped "
+                   "work: zero by design\n" % (summary["pmc_SQ_INSTS_MFMA"], summary.get("pmc_SQ_INSTS_VALU_MFMA_F64"), summary.get("pmc_SQ_VALU_MFMA_BUSY_CYCLES")))
     if "pmc_FETCH_SIZE" in summary and "pmc_WRITE_SIZE" in summary:
         hbm = (2 * summary["pmc_FETCH_SIZE"] + summary["pmc_WRITE_SIZE"]) * 1024
         summary["hbm_bytes_per_launch"] = hbm
@@ -180,6 +183,7 @@ def main():
                        "valu_f64_insts_per_agent": summary.get("valu_f64_insts_per_agent"),
                        "salu_insts_per_agent": summary.get("pmc_SQ_INSTS_SALU", 0.0) / args.agents if "pmc_SQ_INSTS_SALU" in summary else None,
                        "wait_any_frac": (summary["pmc_SQ_WAIT_ANY"] / summary["pmc_SQ_WAVE_CYCLES"]) if "pmc_SQ_WAIT_ANY" in summary and "pmc_SQ_WAVE_CYCLES" in summary else None,
+                       "mfma_insts_per_launch": summary.get("pmc_SQ_INSTS_MFMA"), "mfma_busy_cycles_per_launch": summary.get("pmc_SQ_VALU_MFMA_BUSY_CYCLES"),
                        "csrc_sha1": csrc_sha1(), "csrc_hashed": list(PLAN_KERNEL_SOURCES)}, fh)
     print("\n".join(out))
 

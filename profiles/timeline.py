@@ -12,6 +12,9 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# the product's scheduling strategy (iterative-ilp) crashes this compiler's register allocator on the S64 kernel once the diagnostic
+# statements are in it (round 6: ROCm 7.2 clang 22, "Greedy Register Allocator"): the diagnostic builds take the default strategy
+DIAG_SCHED = ["-Wno-pass-failed"] if not os.environ.get("DLSCQP_DIAG_ILP") else ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "dlsc_gc_planner_amd", "csrc")
 LIB = os.path.join(CSRC, "libdlscqp_timeline.so")
@@ -25,7 +28,7 @@ def main():
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".cpp"))]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs):  # never a stale diagnostic build
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                               "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-DDLSCQP_TIMELINE", "-I" + os.path.join(ROOT, "include"), "-o", LIB]
+                               *DIAG_SCHED, "-DDLSCQP_TIMELINE", "-I" + os.path.join(ROOT, "include"), "-o", LIB]
                               + [os.path.join(CSRC, f) for f in ("dlscqp.hip", "qp_tables.cpp", "sfc_world.cpp", "grid_mapf.cpp")])
     os.environ["DLSCQP_LIB"] = LIB
     import numpy as np
