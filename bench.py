@@ -40,7 +40,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--swarms", type=int, default=512, help="64-agent swarms per GPU per step")
+    ap.add_argument("--swarms", type=int, default=1024,
+                    help="64-agent swarms per GPU per step.  A step is never shorter than its slowest agent (30-46 active-set iterations: ~0.2 ms); "
+                         "1 024 swarms are what one MI355X needs to be busy for longer than that (round 6: three wavefronts per SIMD).  The same "
+                         "loop over the first 512 swarms -- rounds 1-5's batch -- is reported as at_512_swarms")
     ap.add_argument("--batches", type=int, default=4, help="distinct consecutive replanning steps rotated through the timed loop")
     ap.add_argument("--groups", type=int, default=0,
                     help="independent groups the swarms of a GPU are planned in, each on its own stream with its own sequence of replanning steps "
@@ -827,9 +830,10 @@ def main():
         nothing requires them to replan in lockstep, and the tail of one group's launch (its few 30-iteration agents) runs
         beside the other groups' launches instead of holding an empty GPU.  G = 1 is one launch of all agents per step."""
 
-        def __init__(self, G):
-            assert (N // 64) % G == 0, "whole swarms per group"
-            self.G, self.per = G, N // G
+        def __init__(self, G, n_use=None):
+            n_use = N if n_use is None else n_use  # the first n_use agents of the workload (whole swarms)
+            assert n_use % 64 == 0 and (n_use // 64) % G == 0, "whole swarms per group"
+            self.G, self.per, self.n_use = G, n_use // G, n_use
             per = self.per
             self.opts = [opt] + [BatchTrajOptimizer(cfg) for _ in range(G - 1)]  # a context per group: launch-order scratch, event pairs
             self.dbs = [[self.opts[g].make_device_batch(h["agents"][g * per:(g + 1) * per], np.arange(per + 1) * K,
@@ -1189,6 +1193,26 @@ def main():
         l1.close()
         del l1
 
+    # rounds 1-5's batch: the same loop over the first 512 swarms of the workload (a step of 32 768 agents is as long as its slowest agent)
+    at_512 = None
+    if N > 512 * 64 and not args.headline_only and not use_dist:
+        G5 = G_used
+        while 512 % G5:
+            G5 -= 1
+        l5 = SwarmLoop(G5, n_use=512 * 64)
+        ms5 = l5.timed(side_steps, False, "kernel") / side_steps * 1e3
+        l5.close()
+        del l5
+        l51 = SwarmLoop(1, n_use=512 * 64)
+        ms51 = l51.timed(side_steps, False, "kernel") / side_steps * 1e3
+        l51.close()
+        del l51
+        at_512 = {"agents_per_gpu": 512 * 64, "swarm_groups": G5, "ms_per_step": ms5, "qp_per_s": 512 * 64 / ms5 * 1e3,
+                  "one_launch_per_step": {"ms_per_step": ms51, "qp_per_s": 512 * 64 / ms51 * 1e3},
+                  "note": "rounds 1-5 timed 512 swarms per GPU.  A step cannot be shorter than its slowest agent's solve (30-46 iterations, "
+                          "~0.2 ms at three wavefronts per SIMD), and 32 768 agents no longer keep the chip busy for that long: the larger "
+                          "batch is the same workload with enough of it (DESIGN.md section 8)"}
+
     # BASELINE.json configs[4] as a strong-scaling step on the same ranks (every N, so that the scaling runs carry it)
     stress = None
     if not args.no_extras and not args.headline_only:
@@ -1342,8 +1366,8 @@ def main():
             closed = closed_loop_latency(local_rank)
             # two loops of 256 swarms on two streams (round 5, one MI355X: one loop 0.515 ms per step, two 0.436, four 0.564; as HIP
             # graphs the same within 1 % -- the step is not bound by the host)
-            closed["s64_closed_loop"] = s64_closed_loop(local_rank, n_swarms=args.swarms, groups=2)
-            one = s64_closed_loop(local_rank, n_swarms=args.swarms, groups=1, flights=2)
+            closed["s64_closed_loop"] = s64_closed_loop(local_rank, n_swarms=min(args.swarms, 512), groups=2)
+            one = s64_closed_loop(local_rank, n_swarms=min(args.swarms, 512), groups=1, flights=2)
             closed["s64_closed_loop"]["ms_per_step_one_loop"] = one["ms_per_step"]
         line = {
             "metric": "agent-QP solves/sec (goal LP + trajectory QP per agent per replanning step)",
@@ -1413,6 +1437,7 @@ def main():
             "n_gpus_requested": args.gpus, "n_gpus_visible": int(torch.cuda.device_count()),
             # the figure that compares like for like with rounds 1-2 (ONE launch of all the GPU's agents per step, in lockstep); `value`
             # is the swarm groups advancing independently on their own streams (config.swarm_groups_note)
+            "at_512_swarms": at_512,
             "one_launch_per_step": None if not isinstance(one_launch, dict) or not one_launch.get("kernel_order") else
                                    {"ms_per_step": one_launch["kernel_order"], "qp_per_s": world * N / one_launch["kernel_order"] * 1e3},
             "per_rank_ms": rank_breakdown,

@@ -1221,6 +1221,7 @@ struct dlscqp_ctx {
     int force_build = 0;     // dlscqp_selftest: 1 = the standard build of the instantiation, 2 = its WIDE build, 3 = the build with helper wavefronts
     int32_t *nbr_scratch = nullptr;  // dlscqp_neighbours_device: cell counts / starts, agents' cells and slots, agents by cell
     size_t nbr_scratch_ints = 0;
+    int nbr_cells_clean = -1;  // cell counts [0, nbr_cells_clean] of nbr_scratch are zero (what the last complete search left); -1: unknown
     size_t work_bytes = 0;
     void *spill = nullptr;  // spill records of a launch whose batch names no workspace (grown on demand, never inside a stream capture)
     size_t spill_bytes = 0;
@@ -1950,7 +1951,18 @@ extern "C" int dlscqp_neighbours_device(dlscqp_ctx *c, const dlscqp_neighbour_se
         HIP_TRY(hipMalloc((void **)&c->nbr_scratch, need * sizeof(int32_t)));
         HIP_TRY(hipMemset(c->nbr_scratch, 0, need * sizeof(int32_t)));  // (the cell counts start at zero; every search leaves them so)
         c->nbr_scratch_ints = need;
+        c->nbr_cells_clean = a.n_cells;
     }
+    // The counts are zero only where the last complete search of THIS grid left them so: another number of cells (dlscqp_update_param
+    // with another communication range or world box) lays the scratch out differently -- what were cell starts or agents' cells are
+    // counts now -- and a search that failed between its kernels left them dirty.  Then they are cleared here, on the stream.
+    if (c->nbr_cells_clean != a.n_cells) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(st, &cap);
+        if (cap != hipStreamCaptureStatusNone) { g_last_error = "the neighbour search's cell counts must be cleared for a new grid: not inside a stream capture (search once eagerly first)"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+        HIP_TRY(hipMemsetAsync(c->nbr_scratch, 0, (size_t)(a.n_cells + 1) * sizeof(int32_t), st));
+    }
+    c->nbr_cells_clean = -1;  // (until all four kernels are queued)
     a.cell_count = c->nbr_scratch;
     a.cell_start = a.cell_count + a.n_cells + 1;
     a.agent_cell = a.cell_start + a.n_cells + 1;
@@ -1962,6 +1974,7 @@ extern "C" int dlscqp_neighbours_device(dlscqp_ctx *c, const dlscqp_neighbour_se
     hipLaunchKernelGGL(dlscqp_nbr_scatter_kernel, dim3(nb), dim3(256), 0, st, a);
     hipLaunchKernelGGL(dlscqp_nbr_gather_kernel, dim3(ns->n_local), dim3(64), 0, st, a);
     HIP_TRY(hipGetLastError());
+    c->nbr_cells_clean = a.n_cells;  // (the gather kernel clears the counts of this grid behind itself)
     return DLSCQP_SUCCESS;
 }
 

@@ -47,6 +47,10 @@ class BatchTrajOptimizer:
         self.handle = h
 
     def close(self):
+        # a helper thread that was left behind inside the library with this context (sharding.make_exchange's watchdog) must not find
+        # it destroyed: the context then stays (a leak of one context in a run that has already lost its native exchange)
+        if any(t.is_alive() for t in getattr(self, "busy_threads", [])):
+            return
         if getattr(self, "handle", None):
             self.lib.dlscqp_destroy(self.handle)
             self.handle = None

@@ -392,10 +392,14 @@ def make_exchange(opt, dist, rank, world, n_local, device):
         # counts as failed on this rank, the ranks agree below, and the stuck call is left behind on its helper thread.
         import threading
         box = {}
+        cancelled = threading.Event()  # set when the watchdog gives the attempt up: the helper thread then touches neither the GPU nor RCCL again
 
         def attempt():
             try:
+                torch.cuda.set_device(device)  # (the current device is per thread)
                 uid = exchange_unique_id(opt.lib, dist, rank) if world > 1 else None
+                if cancelled.is_set():
+                    return
                 try:
                     xx = NativeExchange(opt, rank, world, n_local, uid)
                 except Exception:  # noqa: BLE001
@@ -403,8 +407,12 @@ def make_exchange(opt, dist, rank, world, n_local, device):
                         raise
                     xx = NativeExchange(opt, rank, world, n_local, None, local_only=True)  # one rank, no librccl: a device copy
                 box["x"] = xx
+                if cancelled.is_set():  # a slow ncclCommInitRank came back after all: no collective on the library's communicator now,
+                    return              # the run is on torch.distributed's (two communicators posting side by side can deadlock the ranks)
                 probe = torch.full((n_local, E + 4), float(rank + 1), dtype=torch.float32, device=device)
                 xx.post_records(probe)
+                if cancelled.is_set():
+                    return
                 got = xx.table()[:, 0].clone()
                 done = torch.cuda.Event()
                 done.record(torch.cuda.current_stream(device))
@@ -413,18 +421,21 @@ def make_exchange(opt, dist, rank, world, n_local, device):
                 box["error"] = str(e)
 
         budget = float(os.environ.get("DLSCQP_EXCHANGE_WATCHDOG_S", "90"))
+        deadline = time.time() + budget  # ONE budget for the thread and for the first collective's completion
         th = threading.Thread(target=attempt, daemon=True)
-        with torch.cuda.device(device):
-            th.start()
-            th.join(budget)
+        th.start()
+        th.join(budget)
         if th.is_alive():
+            cancelled.set()
+            # the thread may still be inside the library with `opt`'s context: the optimizer must outlive it (BatchTrajOptimizer.close)
+            opt.busy_threads = getattr(opt, "busy_threads", []) + [th]
             ok, why = 0, "no answer from RCCL within %.0f s (ncclCommInitRank / first ncclAllGather)" % budget
         elif "error" in box:
             ok, why = 0, box["error"]
         else:
             x = box["x"]
             done, got, _probe = box["event"]
-            t_end = time.time() + budget
+            t_end = max(deadline, time.time() + 1.0)
             while not done.query() and time.time() < t_end:  # (never a blocking wait on a collective that may not come back)
                 time.sleep(0.002)
             if not done.query():

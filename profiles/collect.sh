@@ -7,9 +7,10 @@ set -u
 NAME=${1:-r05_final}
 OUT=gpurun_out/prof_$NAME
 STEPS=30
-GROUPS_=4   # bench.py's default on one GPU: four swarm groups, four launches of 8 192 agents side by side per step
+SWARMS=1024 # bench.py's default (round 6)
+GROUPS_=4   # bench.py's default on one GPU: four swarm groups, four launches of 16 384 agents side by side per step
 export TMPDIR=/tmp
-B="python3 bench.py --steps $STEPS --warmup 4 --swarms 512 --groups $GROUPS_ --headline-only"
+B="python3 bench.py --steps $STEPS --warmup 4 --swarms $SWARMS --groups $GROUPS_ --headline-only"
 mkdir -p $OUT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B > $OUT/trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $B > $OUT/fetch.log 2>&1
@@ -22,7 +23,7 @@ rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_IN
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT --output-format csv -d $OUT/sq5 -- $B > $OUT/sq5.log 2>&1
 # matrix-core instructions: ZERO by design (active-set method: matrix-vector products with <= 16 columns) -- said with the counter
 rocprofv3 --kernel-trace --pmc SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_F64 SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $OUT/sq6 -- $B > $OUT/sq6.log 2>&1
-python3 profiles/summarize.py $OUT $NAME --steps $((STEPS * GROUPS_)) --agents $((32768 / GROUPS_)) --concurrent $GROUPS_ > $OUT/summary.txt 2>&1
+python3 profiles/summarize.py $OUT $NAME --steps $((STEPS * GROUPS_)) --agents $((SWARMS * 64 / GROUPS_)) --concurrent $GROUPS_ > $OUT/summary.txt 2>&1
 cp profiles/$NAME.md profiles/$NAME.json profiles/hbm_traffic_latest.json $OUT/ 2>/dev/null
 # (the diagnostic builds are compiled on first use: their compiler output stays out of the files)
 CLEAN='warning|^ +[0-9]+ \||^ +\||amdgpu.ids|warnings? generated|^In file included|note:'

@@ -70,6 +70,35 @@ def test_device_lists_equal_the_reference_filter(gpu_required, dim, rng_, way, m
         opt.close()
 
 
+def test_search_after_the_grid_changed(gpu_required, monkeypatch):
+    """the search has no memset of its own -- its last kernel leaves the cell counts at zero for the next search.  That
+    holds for the SAME grid only: dlscqp_update_param with another communication range lays the scratch out differently (what were cell
+    starts are counts now).  Ranges 0.7 -> 3.0 -> 0.7 -> 1.3 on one context: every search's lists equal the reference filter."""
+    monkeypatch.setenv("DLSCQP_NBR_DIRECT_MAX", "0")
+    N, p = 700, 256
+    r = np.random.default_rng(11)
+    pos = r.uniform(-9.0, 9.0, (N, 3)).astype(np.float32)
+    pos[:, 2] = r.uniform(0.0, 2.5, N)
+    mk = lambda rng_: abi.make_config(dim=3, M=5, communication_range=rng_, world_min=(-8.0, -8.0, 0.0), world_max=(8.0, 8.0, 2.5))
+    opt = BatchTrajOptimizer(mk(0.7))
+    try:
+        gen = opt.make_lsc_generator(N, np.arange(N + 1) * p, np.zeros(N * p, np.int32), np.full(N, 0.15), np.full(N, 2.0))
+        ns = opt.make_neighbour_search(gen, p)
+        dpos = torch.from_numpy(pos).cuda()
+        for rng_ in (0.7, 3.0, 0.7, 1.3, 3.0):
+            opt.update_param(mk(rng_))
+            for _ in range(2):  # (the second search of a grid runs on the counts the first one left)
+                ns.search(dpos)
+                counts, ids = ns.lists_host()
+                want = host_lists(pos, rng_)
+                for k in range(N):
+                    w = want[k][:p]
+                    assert counts[k] == len(w), (rng_, k, counts[k], len(w))
+                    assert np.array_equal(ids[k, :counts[k]], w), (rng_, k)
+    finally:
+        opt.close()
+
+
 def test_x2048_flies_as_a_moving_crowd(gpu_required):
     """2 048 agents cross one arena for 60 steps; at several steps (also late ones, when the crowd is interleaved) the
     device's neighbour lists equal the reference filter on that step's positions, and on the last checked step a sample of
