@@ -130,6 +130,9 @@ class DeviceBatch(C.Structure):
         ("hint_mask_out", C.c_void_p),
         ("hint_mask_zero", C.c_void_p),
         ("advance_after", C.c_void_p),
+        ("out_conflict", C.c_void_p),      # round 6: the certificates of INFEASIBLE verdicts ([n_agents][conflict_stride] doubles)
+        ("conflict_stride", C.c_int32),
+        ("reserved3_", C.c_int32),
     ]
 
 
@@ -353,6 +356,14 @@ def load_library():
     lib.dlscqp_last_error.restype = C.c_char_p
     lib.dlscqp_lds_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.dlscqp_lds_bytes.restype = C.c_int64
+    if hasattr(lib, "dlscqp_conflict_doubles"):  # (round 6; tests/tools/ab.py also loads libraries built from earlier rounds' sources)
+        lib.dlscqp_conflict_doubles.argtypes = [C.c_void_p, C.c_int32]
+        lib.dlscqp_conflict_doubles.restype = C.c_int32
+        lib.dlscqp_write_lp.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_char_p]
+        lib.dlscqp_write_lp.restype = C.c_int
+        lib.dlscqp_conflict_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                               C.POINTER(ConflictMember), C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+        lib.dlscqp_conflict_decode.restype = C.c_int
     if hasattr(lib, "dlscqp_workspace_bytes"):  # (tests/tools/ab.py also loads libraries built from earlier rounds' sources)
         lib.dlscqp_workspace_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
         lib.dlscqp_workspace_bytes.restype = C.c_int64
@@ -429,6 +440,13 @@ def load_library():
     return lib
 
 
+class ConflictMember(C.Structure):  # dlscqp_conflict_member
+    _fields_ = [("ref_index", C.c_int32), ("kind", C.c_int32), ("n", C.c_int32), ("var", C.c_int32 * 4), ("coef", C.c_double * 4),
+                ("lo", C.c_double), ("hi", C.c_double), ("lam", C.c_double)]
+
+
+MODEL_KINDS = ("EQ", "SFC", "LSC", "VEL", "ACC", "COMM", "WAYPOINT", "VAR_LB", "VAR_UB")  # DLSCQP_MODEL_*
+
 EXPORTED_SYMBOLS = [
     "dlscqp_create", "dlscqp_destroy", "dlscqp_update_param", "dlscqp_last_error",
     "dlscqp_lds_bytes", "dlscqp_solve_batch", "dlscqp_goal_batch", "dlscqp_plan_batch",
@@ -440,4 +458,5 @@ EXPORTED_SYMBOLS = [
     "dlscqp_exchange_unique_id", "dlscqp_exchange_create", "dlscqp_exchange_destroy", "dlscqp_exchange_post", "dlscqp_exchange_post_records",
     "dlscqp_exchange_before_overwrite", "dlscqp_exchange_wait", "dlscqp_exchange_set_timing", "dlscqp_exchange_get_times",
     "dlscqp_step_device", "dlscqp_neighbours_knn_device", "dlscqp_workspace_bytes", "dlscqp_mask_order_preview_device", "dlscqp_exchange_wait_packed",
+    "dlscqp_conflict_doubles", "dlscqp_write_lp", "dlscqp_conflict_decode", "dlscqp_solve_batch_conflict",
 ]

@@ -43,6 +43,7 @@ static __device__ __forceinline__ double dq_rsqrt(double x) {
 #endif
 #include "gi_core.hpp"
 #include "lsc_core.hpp"
+#include "model_rows.hpp"
 #include "qp_tables.hpp"
 #include "sfc_core.hpp"
 #include "sfc_world.hpp"
@@ -424,6 +425,8 @@ struct KernelArgs {
     const unsigned long long *mask_in;  // launch order from class masks (masked_agent): [n_blocks][8], written by the previous step's launch
     unsigned long long *mask_out;       // ... this launch's own: every agent sets its bit in the mask of its class
     unsigned long long *mask_zero;      // ... and a third table that this launch clears (for a later launch to write)
+    double *out_conflict;               // dlscqp_device_batch.out_conflict: [n_agents][conflict_stride] doubles, or null
+    int conflict_stride;
     int adv_on;                         // dlscqp_device_batch.advance_after: the planning wavefront also does the agent's bookkeeping between
     AdvanceArgs adv;                    // two launches (advance_agent), right behind its final stores
 };
@@ -572,7 +575,10 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
     else smem = lds;
     // the instantiation whose rows are all in registers (S64) is compiled for three wavefronts per SIMD: gi_core.hpp "LEAN"
     constexpr bool LEAN_K = DIMS > 0 && KU == 2 && SU == 0 && SLK == 0 && !WIDE && WPA == 1 && WS == WS_LDS;
-    typedef WaveGpuT<LEAN_K> Wave;
+#ifndef DQ_FRESH_LANE_ALL  // 1: every instantiation starts its each() blocks from a fresh lane number (measured per instantiation: DESIGN.md section 8)
+#define DQ_FRESH_LANE_ALL 0
+#endif
+    typedef WaveGpuT<LEAN_K || DQ_FRESH_LANE_ALL != 0> Wave;
     Wave w;
     w.lane = (int)threadIdx.x & 63;
     int cls_in = 0;
@@ -674,7 +680,8 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
                a.out_x ? a.out_x + ag * xs : nullptr, a.out_cost ? a.out_cost + ag : nullptr,
                a.out_slack_cost ? a.out_slack_cost + (size_t)ag * a.max_slack_obs : nullptr,
                a.out_status ? a.out_status + (size_t)ag * a.status_stride : nullptr,
-               a.out_iters ? a.out_iters + (size_t)ag * 4 : nullptr, &iters_done);
+               a.out_iters ? a.out_iters + (size_t)ag * 4 : nullptr, &iters_done,
+               a.out_conflict ? a.out_conflict + (size_t)ag * a.conflict_stride : nullptr);
     if (a.mask_out) {
         // the agent's bit into the mask of its class, for the next step's launch order (masked_agent): the class of this step's
         // iteration count, or one below the class it was scheduled with if that is higher (an agent that was expensive a step or
@@ -1362,6 +1369,65 @@ extern "C" int64_t dlscqp_workspace_bytes(const dlscqp_ctx *c, int32_t n_agents,
     return (int64_t)(stride * 8 * (size_t)(64 * ((n_agents + 63) / 64)));
 }
 
+extern "C" int32_t dlscqp_conflict_doubles(const dlscqp_ctx *c, int32_t max_slack_obs) {
+    if (!c || max_slack_obs < 0) return -1;
+    return 4 + 2 * (c->tb.kp.dim * c->tb.kp.f + c->tb.kp.M * max_slack_obs + 1);
+}
+
+// ---- the reference's failure path on the host (model_rows.hpp): model export, conflict ----------------------------------------------
+// (the shape the context was constructed with: TrajOptimizer caches dim / M / n / phi / dt, updateParam does not refresh them)
+static dlscqp_config model_config(const dlscqp_ctx *c) {
+    dlscqp_config cf = c->cfg;
+    cf.world_dimension = c->dim; cf.M = c->M; cf.n = c->n; cf.phi = c->phi; cf.dt = c->dt;
+    return cf;
+}
+extern "C" int dlscqp_write_lp(const dlscqp_ctx *c, const dlscqp_agent *agent, const dlscqp_lsc_row *rows, int32_t n_rows, const float *sfc,
+                               int32_t max_slack_obs, const float *goal, const char *path) {
+    g_last_error.clear();
+    if (!c || !agent || !path || n_rows < 0 || (n_rows > 0 && !rows) || max_slack_obs < 0) { g_last_error = "invalid argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    HostModel md;
+    std::string err;
+    const dlscqp_config cf = model_config(c);
+    if (!build_host_model(cf, c->tb.kp, *agent, rows, n_rows, sfc, max_slack_obs, goal, md, err) || !write_lp(md, path, err)) {
+        g_last_error = "[TrajOptimizer] " + err;
+        return DLSCQP_ERR_INVALID_ARGUMENT;
+    }
+    return DLSCQP_SUCCESS;
+}
+
+extern "C" int dlscqp_conflict_decode(const dlscqp_ctx *c, const dlscqp_agent *agent, const dlscqp_lsc_row *rows, int32_t n_rows, const float *sfc,
+                                      int32_t max_slack_obs, const float *goal, const double *record, dlscqp_conflict_member *out, int32_t capacity,
+                                      int32_t *n_out, int32_t *n_con_out, double *gap_out) {
+    g_last_error.clear();
+    if (!c || !agent || !record || !n_out || n_rows < 0 || (n_rows > 0 && !rows) || capacity < 0 || (capacity > 0 && !out)) {
+        g_last_error = "invalid argument";
+        return DLSCQP_ERR_INVALID_ARGUMENT;
+    }
+    *n_out = 0;
+    HostModel md;
+    std::string err;
+    const dlscqp_config cf = model_config(c);
+    if (!build_host_model(cf, c->tb.kp, *agent, rows, n_rows, sfc, max_slack_obs, goal, md, err)) {
+        g_last_error = "[TrajOptimizer] " + err;
+        return DLSCQP_ERR_INVALID_ARGUMENT;
+    }
+    if (n_con_out) *n_con_out = (int32_t)md.con.size();
+    const int n = (int)record[0];
+    if (gap_out) *gap_out = n > 0 ? record[1] : 0.0;
+    if (n <= 0) return DLSCQP_SUCCESS;
+    if (n > capacity) { g_last_error = "dlscqp_conflict_decode: capacity is smaller than the certificate"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    for (int t = 0; t < n; t++) {
+        double scale = 1.0;
+        if (!conflict_member(cf, c->tb.kp, c->tb.slots.data(), md, sfc, (uint32_t)record[4 + 2 * t], out[t], scale, err)) {
+            g_last_error = err;
+            return DLSCQP_ERR_INVALID_ARGUMENT;
+        }
+        out[t].lambda = record[5 + 2 * t] / scale;
+    }
+    *n_out = n;
+    return DLSCQP_SUCCESS;
+}
+
 extern "C" int dlscqp_set_timing(dlscqp_ctx *c, int32_t capacity) {
     g_last_error.clear();
     if (!c || capacity < 0) return DLSCQP_ERR_INVALID_ARGUMENT;
@@ -1627,6 +1693,17 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
     a.out_iters = b->out_iters;
     a.order = b->agent_order;
     a.out_stamps = (unsigned long long *)b->debug_stamps;
+    a.out_conflict = nullptr;
+    a.conflict_stride = 0;
+    if (b->out_conflict) {
+        // the certificates of this launch's INFEASIBLE verdicts (include/dlscqp.h); records of agents without one read "0 members"
+        const int need = 4 + 2 * (lay.r_max + 1);
+        if (b->conflict_stride < need) { g_last_error = "conflict_stride is smaller than dlscqp_conflict_doubles()"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+        if (!b->do_traj) { g_last_error = "out_conflict: the certificate is the trajectory QP's"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+        a.out_conflict = b->out_conflict;
+        a.conflict_stride = b->conflict_stride;
+        HIP_TRY(hipMemsetAsync(b->out_conflict, 0, (size_t)b->n_agents * (size_t)b->conflict_stride * sizeof(double), stream));
+    }
     const bool timed = c->ev_used < (int)c->ev0.size();
     if (timed) HIP_TRY(hipEventRecord(c->ev0[c->ev_used], stream));
 #ifdef DLSCQP_TRACE_LDS
@@ -2442,7 +2519,8 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static int plan_host(dlscqp_ctx *c, int32_t n_agents, const dlscqp_agent *agents, const int64_t *row_offsets,
                      const dlscqp_lsc_row *rows, const float *sfc_boxes, int32_t max_slack_obs, int do_goal,
                      int do_traj, float *out_goal, int32_t *out_goal_status, float *out_ctrl, double *out_cost,
-                     double *out_slack_cost, int32_t *out_status, int declared_rows_per_agent = 0) {
+                     double *out_slack_cost, int32_t *out_status, int declared_rows_per_agent = 0,
+                     double *out_conflict = nullptr, int conflict_stride = 0) {
     g_last_error.clear();
     if (!c) { g_last_error = "null context"; return DLSCQP_ERR_INVALID_ARGUMENT; }
     if (n_agents < 0) { g_last_error = "negative n_agents"; return DLSCQP_ERR_INVALID_ARGUMENT; }
@@ -2472,6 +2550,7 @@ static int plan_host(dlscqp_ctx *c, int32_t n_agents, const dlscqp_agent *agents
     const size_t o_cost = take(8 * (size_t)n_agents);
     const size_t o_slk = take(8 * (size_t)n_agents * std::max(max_slack_obs, 1));
     const size_t o_st = take(4 * (size_t)n_agents);
+    const size_t o_cf = take(out_conflict ? 8 * (size_t)n_agents * (size_t)conflict_stride : 0);  // dlscqp_device_batch.out_conflict
     const size_t total = o;
     if (total > c->stage_cap) {
         if (c->d_stage) (void)hipFree(c->d_stage);
@@ -2522,6 +2601,10 @@ static int plan_host(dlscqp_ctx *c, int32_t n_agents, const dlscqp_agent *agents
     b.out_cost = (double *)(d + o_cost);
     b.out_slack_cost = max_slack_obs > 0 ? (double *)(d + o_slk) : nullptr;
     b.out_status = (int32_t *)(d + o_st);
+    if (out_conflict) {
+        b.out_conflict = (double *)(d + o_cf);
+        b.conflict_stride = conflict_stride;
+    }
     int rc = launch(c, &b, c->stream);
     if (rc != DLSCQP_SUCCESS) return rc;
     HIP_TRY(hipMemcpyAsync(h + in_bytes, d + in_bytes, total - in_bytes, hipMemcpyDeviceToHost, c->stream));
@@ -2546,6 +2629,7 @@ static int plan_host(dlscqp_ctx *c, int32_t n_agents, const dlscqp_agent *agents
             }
         }
     }
+    if (out_conflict) std::memcpy(out_conflict, h + o_cf, 8 * (size_t)n_agents * (size_t)conflict_stride);
     return DLSCQP_SUCCESS;
 }
 
@@ -2973,6 +3057,14 @@ extern "C" int dlscqp_solve_batch(dlscqp_ctx *ctx, int32_t n_agents, const dlscq
                                   int32_t *out_status) {
     return plan_host(ctx, n_agents, agents, row_offsets, rows, sfc_boxes, max_slack_obs, 0, 1, nullptr, nullptr,
                      out_ctrl, out_cost, out_slack_cost, out_status);
+}
+
+extern "C" int dlscqp_solve_batch_conflict(dlscqp_ctx *ctx, int32_t n_agents, const dlscqp_agent *agents, const int64_t *row_offsets,
+                                           const dlscqp_lsc_row *rows, const float *sfc_boxes, int32_t max_slack_obs, int32_t *out_status,
+                                           double *out_conflict, int32_t conflict_stride) {
+    if (!out_conflict || conflict_stride <= 0) { g_last_error = "null conflict buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    return plan_host(ctx, n_agents, agents, row_offsets, rows, sfc_boxes, max_slack_obs, 0, 1, nullptr, nullptr, nullptr, nullptr, nullptr,
+                     out_status, 0, out_conflict, conflict_stride);
 }
 
 extern "C" int dlscqp_goal_batch(dlscqp_ctx *ctx, int32_t n_agents, const dlscqp_agent *agents,

@@ -485,7 +485,12 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                       const dlscqp_agent *agp, const RowsView &rows, int row_begin, int K_rows,
                       const float *sfc, int max_slack_obs, int do_goal, int do_traj,
                       float *out_goal, int *out_goal_status, float *out_ctrl, double *out_x,
-                      double *out_cost, double *out_slack_cost, int *out_status, int *out_iters, int *iters_done = nullptr) {
+                      double *out_cost, double *out_slack_cost, int *out_status, int *out_iters, int *iters_done = nullptr,
+                      double *out_conflict = nullptr) {
+    // out_conflict (optional, device memory: dlscqp_device_batch.out_conflict, 4 + 2 (r_max + 1) doubles): the certificate of an
+    // INFEASIBLE verdict -- [0] members n (0: none), [1] how far the blocked row is violated (metres), then n pairs (row id,
+    // multiplier): the active rows with -rv, the blocked row with 1 (conflict_id() below; include/dlscqp.h).  While it is asked for,
+    // the early proof by weak duality is off: the active-set method runs until no step is possible, which is what the certificate says.
     // iters_done (optional, the caller's own variable -- not device memory): the number of iterations of this solve
     static_assert(RC == 1 || RC == 2, "r <= 128");
     typedef typename W::template Reg<double> RegD;
@@ -1715,7 +1720,7 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
             else if (n_price == DQ_PRIO_AT2) DQ_SETPRIO(2);
             else if (n_price == DQ_PRIO_AT3) DQ_SETPRIO(3);
         }
-        if (kp.wd_cut && nslk == 0 && n_price >= 8 && (n_price & 1) == 0) {
+        if (kp.wd_cut && !out_conflict && nslk == 0 && n_price >= 8 && (n_price & 1) == 0) {
             if (n_price == 8) f_max = objective_upper_bound();  // first check of this agent
             const double f_now = objective();
             DQ_TRACE(4, f_now, f_max, (double)n_price, (double)q);
@@ -2322,6 +2327,45 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
                     break;
                 }
                 status = DLSCQP_INFEASIBLE;
+                if (out_conflict) {  // uniform
+                    // The certificate (Farkas): no step is possible means  a - A' rv  lies in the range of the equalities' transpose
+                    // (|z| = 0) and rv <= 0 on every active row (no dual step is blocked).  With lambda = -rv >= 0 on the active rows
+                    // (which x meets with equality) and 1 on the blocked row:  sum lambda_i a_i . x'  is the same number for every x'
+                    // that satisfies the equalities, and at x it is  sum lambda_i b_i - viol:  no such x' satisfies all these rows.
+                    // Row ids that do not depend on the instantiation: type << 24 | index << 3 | sub -- 0: row `sub` (2 kind + side) of
+                    // coordinate `index`; 1: LSC row `index` of the agent's list; 2: side `sub` of slot `index` of the context's table;
+                    // 3: the bound eps <= 0 of slack variable `index`.
+                    auto conflict_id = [&](int code) -> double {
+                        // (sums of comparisons and flat selects: nested ?: on a lane's code came out as EXEC-masked branches)
+                        const int un = code >> 3, cc = code & 7;
+                        const int g1 = un >= UL0 ? 1 : 0, g2 = un >= UX0 ? 1 : 0, g3 = un >= US0 ? 1 : 0;
+                        const int ty = g1 + g2 + g3;
+                        int ix = un;
+                        ix = g1 ? un - UL0 : ix;
+                        ix = g2 ? un - UX0 + slot0 : ix;
+                        ix = g3 ? un - US0 : ix;
+                        return (double)((ty << 24) | (ix << 3) | (cc & ((ty & 1) - 1)));  // (types 1 and 3 have no sub-row)
+                    };
+                    // (every lane stores: lanes beyond the active rows to the blocked row's pair, which is written after them)
+                    w.each([&](int l) {
+#pragma unroll
+                        for (int c = 0; c < RC; c++) {
+                            const int i = l + 64 * c;
+                            const int t_ = i < q ? i : q;
+                            out_conflict[4 + 2 * t_] = conflict_id(act[c].at(l) < 0 ? 0 : act[c].at(l));
+                            out_conflict[5 + 2 * t_] = -rv[c].at(l);
+                        }
+                    });
+                    w.sync();
+                    w.each([&](int) {  // every lane, the same words, the same values
+                        out_conflict[4 + 2 * q] = conflict_id(ip);
+                        out_conflict[5 + 2 * q] = 1.0;
+                        out_conflict[0] = (double)(q + 1);
+                        out_conflict[1] = viol;
+                        out_conflict[2] = row_scale;
+                        out_conflict[3] = 0.0;
+                    });
+                }
                 break;
             }
             const double t = t1 < t2 ? t1 : t2;

@@ -21,8 +21,11 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <fstream>
+#include <iostream>
 #include <memory>
 #include <mutex>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -394,6 +397,12 @@ public:
         if (rc != DLSCQP_SUCCESS) throw std::runtime_error(std::string("[TrajOptimizer] ") + dlscqp_last_error());
         std::vector<TrajOptResult> out(N);
         status.assign(st.begin(), st.end());
+        // the reference's catch block (traj_optimizer.cpp:112-146): the model of a failed agent as an .lp file and the rows that prove it
+        // infeasible ("Conflict :" ... "Proved  : c<i> ...") -- here from the solver's own certificate, not from a second search
+        for (int a = 0; a < N; a++)
+            if (st[a] != DLSCQP_OK)
+                reportFailure(*agents[a], ag[a], rows.data() + offs[a], (int)(offs[a + 1] - offs[a]),
+                              sfc.empty() ? nullptr : sfc.data() + (size_t)a * M * 6, max_slack, st[a]);
         for (int a = 0; a < N; a++) {
             TrajOptResult &r = out[a];
             r.desired_traj = traj_t(M, n_cached, dt_cached);
@@ -431,7 +440,69 @@ public:
         shared = detail::acquire_context(c);
     }
 
+    // Where the last failed agent's conflict went (tests): "Proved  : c<i> ..." lines as the reference's refiner prints them.
+    const std::string &lastConflict() const { return last_conflict; }
+
 private:
+    void reportFailure(const Agent &agent, const dlscqp_agent &ag, const dlscqp_lsc_row *rows, int n_rows, const float *sfc, int max_slack, int st) {
+        const std::string model_path = param.package_path + "/log/QPmodel_trajOpt.lp";  // traj_optimizer.cpp:45-46
+        last_conflict.clear();
+        {
+            std::lock_guard<std::mutex> lock(shared->use);
+            (void)dlscqp_write_lp(shared->ctx, &ag, rows, n_rows, sfc, max_slack, nullptr, model_path.c_str());  // cplex.exportModel, :113
+        }
+        if (st != DLSCQP_INFEASIBLE) {
+            std::cerr << "[TrajOptimizer] solver failed at mav " << agent.id << " (status " << st << ")" << std::endl;
+            return;
+        }
+        std::cerr << "[TrajOptimizer] No solution at mav " << agent.id << ", starting Conflict refinement" << std::endl;  // :116-117
+        int32_t st1 = DLSCQP_NUMERICAL, n = 0, n_con = 0;
+        double gap = 0;
+        const int64_t offs[2] = {0, n_rows};
+        std::vector<double> rec;
+        std::vector<dlscqp_conflict_member> mem;
+        int rc;
+        {
+            std::lock_guard<std::mutex> lock(shared->use);
+            const int w = dlscqp_conflict_doubles(shared->ctx, max_slack);
+            rec.assign((size_t)(w > 0 ? w : 4), 0.0);
+            rc = dlscqp_solve_batch_conflict(shared->ctx, 1, &ag, offs, rows, sfc, max_slack, &st1, rec.data(), (int)rec.size());
+            if (rc == DLSCQP_SUCCESS) {
+                mem.resize((size_t)(rec[0] > 0 ? rec[0] : 1));
+                rc = dlscqp_conflict_decode(shared->ctx, &ag, rows, n_rows, sfc, max_slack, nullptr, rec.data(), mem.data(), (int)mem.size(), &n, &n_con, &gap);
+            }
+        }
+        if (rc != DLSCQP_SUCCESS || n <= 0) {
+            std::cerr << "[TrajOptimizer] Conflict could not be refined" << std::endl;  // :141
+            return;
+        }
+        // "Proved  : c<i> <row>" for the members (:133-136), in the reference's variable names; the multipliers beside them
+        static const char axis[3] = {'x', 'y', 'z'};
+        const int N1 = n_cached + 1, od = M_cached * N1, osl = dim_cached * od;
+        auto var_name = [&](int v) {
+            std::ostringstream o;
+            if (v < osl) { const int k = v / od, p = v - k * od; o << axis[k] << "_" << p / N1 << "_" << p % N1; }
+            else o << "epsilon_slack_col_" << (v - osl) / M_cached << "_" << (v - osl) % M_cached;
+            return o.str();
+        };
+        std::ostringstream out;
+        out << "Conflict :" << std::endl;
+        for (int t = 0; t < n; t++) {
+            const dlscqp_conflict_member &m = mem[(size_t)t];
+            out << "Proved  : c" << m.ref_index << " ";
+            if (m.lo > -1e299 && m.hi < 1e299 && m.kind < DLSCQP_MODEL_VAR_LB) out << m.lo << " <= ";
+            for (int e = 0; e < m.n; e++) out << (m.coef[e] >= 0 && e > 0 ? "+ " : "") << m.coef[e] << " * " << var_name(m.var[e]) << " ";
+            if (m.kind == DLSCQP_MODEL_VAR_LB || (m.lo > -1e299 && m.hi >= 1e299)) out << ">= " << m.lo;
+            else out << "<= " << m.hi;
+            out << "   (multiplier " << m.lambda << ")" << std::endl;
+        }
+        out << "violated by " << gap << " whatever the other variables do" << std::endl;
+        last_conflict = out.str();
+        std::cout << last_conflict;
+        const std::string conflict_path = param.package_path + "/log/conflict_trajOpt.lp";  // cplex.writeConflict, :139
+        std::ofstream cf(conflict_path);
+        if (cf) cf << "\\ dlsc_gc_planner_amd: the rows that prove mav " << agent.id << " infeasible (numbers: rows of QPmodel_trajOpt.lp)\n" << last_conflict;
+    }
     void create() {
         shared = detail::acquire_context(detail::make_config(param, mission));
         M_cached = param.M; n_cached = param.n; dt_cached = param.dt;  // traj_optimizer.cpp:7-11
@@ -442,6 +513,7 @@ private:
     std::shared_ptr<detail::SharedContext> shared;
     int M_cached = 0, n_cached = 0, dim_cached = 0, phi_cached = 0;
     double dt_cached = 0;
+    std::string last_conflict;
 };
 
 class GoalOptimizer {

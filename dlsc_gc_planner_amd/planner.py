@@ -70,6 +70,34 @@ class BatchTrajOptimizer:
         self._check(self.lib.dlscqp_update_param(self.handle, C.byref(cfg)), "dlscqp_update_param")
         self.cfg = cfg
 
+    # ---- the reference's failure path on the host: model export, conflict (traj_optimizer.cpp:45-52, 113-146) -----------------------
+    def write_lp(self, agent, rows, path, sfc=None, max_slack_obs=0, goal=None):
+        """The agent's model as a CPLEX-LP file (cplex.exportModel): rows in populatebyrow's order, named c0, c1, ..."""
+        agent = np.ascontiguousarray(agent, dtype=abi.AGENT_DTYPE).reshape(1)
+        rows = np.ascontiguousarray(rows, dtype=abi.ROW_DTYPE)
+        sfc = None if sfc is None else np.ascontiguousarray(sfc, dtype=np.float32)
+        goal = None if goal is None else np.ascontiguousarray(goal, dtype=np.float32)
+        self._check(self.lib.dlscqp_write_lp(self.handle, _ptr(agent), _ptr(rows) if len(rows) else None, len(rows), None if sfc is None else _ptr(sfc),
+                                             max_slack_obs, None if goal is None else _ptr(goal), str(path).encode()), "dlscqp_write_lp")
+
+    def conflict_decode(self, agent, rows, record, sfc=None, max_slack_obs=0, goal=None):
+        """One record of DeviceBatch.conflicts() -> (members, n_con, gap): members = list of dicts {ref_index, kind, var, coef, lo, hi,
+        lam} -- rows of the reference's model, in its scaling, numbered like the conflict refiner's `infeas` array."""
+        agent = np.ascontiguousarray(agent, dtype=abi.AGENT_DTYPE).reshape(1)
+        rows = np.ascontiguousarray(rows, dtype=abi.ROW_DTYPE)
+        sfc = None if sfc is None else np.ascontiguousarray(sfc, dtype=np.float32)
+        goal = None if goal is None else np.ascontiguousarray(goal, dtype=np.float32)
+        record = np.ascontiguousarray(record, dtype=np.float64)
+        cap = max(int(record[0]), 1)
+        out = (abi.ConflictMember * cap)()
+        n, ncon, gap = C.c_int32(0), C.c_int32(0), C.c_double(0.0)
+        self._check(self.lib.dlscqp_conflict_decode(self.handle, _ptr(agent), _ptr(rows) if len(rows) else None, len(rows),
+                                                    None if sfc is None else _ptr(sfc), max_slack_obs, None if goal is None else _ptr(goal),
+                                                    _ptr(record), out, cap, C.byref(n), C.byref(ncon), C.byref(gap)), "dlscqp_conflict_decode")
+        mem = [dict(ref_index=int(m.ref_index), kind=abi.MODEL_KINDS[m.kind], var=[int(m.var[t]) for t in range(m.n)],
+                    coef=[float(m.coef[t]) for t in range(m.n)], lo=float(m.lo), hi=float(m.hi), lam=float(m.lam)) for m in out[:n.value]]
+        return mem, int(ncon.value), float(gap.value)
+
     def lds_bytes(self, max_slack_obs=0, max_rows=0):
         return int(self.lib.dlscqp_lds_bytes(self.handle, max_slack_obs, max_rows))
 
@@ -274,6 +302,21 @@ class DeviceBatch:
         self.c = b
         self.max_rows = kmax
         self.max_slack_obs = max_slack_obs
+
+    def want_conflict(self):
+        """dlscqp_device_batch.out_conflict: the following launches also write, for every agent whose trajectory QP is INFEASIBLE, the
+        rows that prove it and their multipliers (the reference's conflict refiner, traj_optimizer.cpp:118-146).  A debugging aid:
+        the kernel's early infeasibility proof is off meanwhile.  conflicts() returns the records."""
+        w = int(self.opt.lib.dlscqp_conflict_doubles(self.opt.handle, self.max_slack_obs))
+        self.out_conflict = self.torch.zeros((self.n_agents, w), dtype=self.torch.float64, device=self.device)
+        self.c.out_conflict = self.out_conflict.data_ptr()
+        self.c.conflict_stride = w
+        return w
+
+    def conflicts(self):
+        """[n_agents, dlscqp_conflict_doubles()] float64 (host): record a is [members, violation, scale, 0, (row id, multiplier) ...]"""
+        self.torch.cuda.synchronize(self.device)
+        return self.out_conflict.cpu().numpy()
 
     def use_workspace(self):
         """A buffer of this batch's own for the launch's spill records (dlscqp_device_batch.workspace): launches of several batches

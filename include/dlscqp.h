@@ -154,6 +154,13 @@ int dlscqp_solve_batch(dlscqp_ctx *ctx, int32_t n_agents, const dlscqp_agent *ag
                        const float *sfc_boxes, int32_t max_slack_obs, float *out_ctrl,
                        double *out_cost, double *out_slack_cost, int32_t *out_status);
 
+/* TrajOptimizer::solve once more for agents whose verdict was DLSCQP_INFEASIBLE, this time with the certificate: out_conflict
+ * [n_agents][conflict_stride >= dlscqp_conflict_doubles()] doubles, the records of dlscqp_device_batch.out_conflict (decode them with
+ * dlscqp_conflict_decode).  What the reference does in its catch block (traj_optimizer.cpp:113-146). */
+int dlscqp_solve_batch_conflict(dlscqp_ctx *ctx, int32_t n_agents, const dlscqp_agent *agents, const int64_t *row_offsets,
+                                const dlscqp_lsc_row *rows, const float *sfc_boxes, int32_t max_slack_obs, int32_t *out_status,
+                                double *out_conflict, int32_t conflict_stride);
+
 /* GoalOptimizer::solve for a batch: out_goal [n_agents][3]. */
 int dlscqp_goal_batch(dlscqp_ctx *ctx, int32_t n_agents, const dlscqp_agent *agents,
                       const int64_t *row_offsets, const dlscqp_lsc_row *rows,
@@ -264,6 +271,24 @@ typedef struct dlscqp_device_batch {
                                        status / goal_status / ctrl / goal (/ alert_slack_cost) must be this batch's dense outputs
                                        and its n_agents this batch's; with do_goal and do_traj.  Same results as
                                        dlscqp_advance_device after the launch (tests/test_gpu_closed_loop.py).                   */
+    /* ---- round 6 (appended, zero = the behaviour of before) -------------------------------------------------------------- */
+    double *out_conflict;           /* optional [n_agents][conflict_stride] doubles: for every agent whose trajectory QP is
+                                       DLSCQP_INFEASIBLE the rows that PROVE it and their multipliers -- what CPLEX's conflict refiner
+                                       prints in the reference (traj_optimizer.cpp:118-146).  Record: [0] members n (0: no certificate:
+                                       the agent is not infeasible, or failed otherwise), [1] the violation (metres) of the row no
+                                       step could repair, [2] that row's factor to the reference's scaling, [3] 0, then n pairs
+                                       (row id, multiplier >= 0): ids as type << 24 | index << 3 | sub -- type 0: row sub = 2 kind + side
+                                       (kind 0 bound / box face, 1 velocity, 2 acceleration; side 0 lower) of control-point coordinate
+                                       index = axis P + point; 1: row `index` of the agent's LSC list; 2: side `sub` of structured
+                                       slot `index` (bound, velocity, acceleration, communication range, waypoint range); 3: the
+                                       bound eps <= 0 of slack variable `index`.  dlscqp_conflict_decode() turns a record into rows of
+                                       the reference's model.  The multipliers are those of the rows in the KERNEL's scaling (metres);
+                                       with them sum lambda_i a_i vanishes on the null space of the equality rows and
+                                       sum lambda_i b_i exceeds what the equalities allow by [1] (Farkas).  While certificates are
+                                       asked for the kernel's early infeasibility proof by weak duality is off (same verdicts, a
+                                       slower launch): a debugging aid like the reference's, not for the timed path.               */
+    int32_t conflict_stride;        /* doubles per agent, >= dlscqp_conflict_doubles()                                            */
+    int32_t reserved3_;
 } dlscqp_device_batch;
 
 /* key layout: bits 0-7 m, 8-11 i, 12 dynamic flag, 16-31 slack index (0xFFFF = none). */
@@ -272,6 +297,46 @@ typedef struct dlscqp_device_batch {
      ((uint32_t)((slack) < 0 ? 0xFFFFu : (uint32_t)(slack)) << 16))
 
 int dlscqp_plan_batch_device(dlscqp_ctx *ctx, const dlscqp_device_batch *batch, void *stream);
+/* doubles of one agent's record of dlscqp_device_batch.out_conflict: 4 + 2 (dim f + M max_slack_obs + 1) */
+int32_t dlscqp_conflict_doubles(const dlscqp_ctx *ctx, int32_t max_slack_obs);
+
+/* ---- the reference's failure path: model export and conflict (traj_optimizer.cpp:45-52, 113-146) -- host only, one agent ------------
+ * Both work on the agent's model as TrajOptimizer::populatebyrow (:225-527) builds it -- same variables (x_m_i, y_m_i, z_m_i,
+ * epsilon_slack_col_oi_m), same rows in the same order -- from what the host-buffer entry points take: the agent's record, its LSC rows
+ * in populatebyrow's order (obstacle, segment, control point), its M corridor boxes (NULL without world_use_octomap).
+ * goal: the point the terminal cost pulls to, float[3] -- the goal LP's answer in the fused launch (traj_planner.cpp:494); NULL =
+ * the record's current_goal_point. */
+enum {  /* kinds of rows, dlscqp_conflict_member.kind */
+    DLSCQP_MODEL_EQ = 0,       /* initial state, continuity, stop at the end of the horizon (:333-381, :515-524) */
+    DLSCQP_MODEL_SFC = 1,      /* corridor box face (:385-410)                                                   */
+    DLSCQP_MODEL_LSC = 2,      /* DLSC-GC / dynamic-obstacle half-space (:412-450)                               */
+    DLSCQP_MODEL_VEL = 3,      /* velocity limit (:453-468)                                                      */
+    DLSCQP_MODEL_ACC = 4,      /* acceleration limit (:469-485)                                                  */
+    DLSCQP_MODEL_COMM = 5,     /* communication range between segment ends and starts (:490-503)                 */
+    DLSCQP_MODEL_WAYPOINT = 6, /* communication range around the waypoint (:505-512)                             */
+    DLSCQP_MODEL_VAR_LB = 7,   /* a variable's lower bound (:251-265)                                            */
+    DLSCQP_MODEL_VAR_UB = 8    /* ... upper bound (:251-265; a slack variable's eps <= 0, :276)                  */
+};
+typedef struct dlscqp_conflict_member {
+    int32_t ref_index;  /* the row's number in the reference's `infeas` array (traj_optimizer.cpp:118-127): rows of `con` in populatebyrow's
+                           order (what the refiner prints as c<i>), then for every variable v its lower (n_con + 2 v) and upper (+ 1) bound */
+    int32_t kind;       /* DLSCQP_MODEL_*                                                                                          */
+    int32_t n;          /* entries (<= 4)                                                                                          */
+    int32_t var[4];     /* variables in the reference's order: axis offset_dim + segment offset_seg + point; slack: offset_slack_col + ... */
+    double coef[4];     /* in the reference's row scaling                                                                          */
+    double lo, hi;      /* lo <= sum coef x <= hi, one of them +-1e300 (none)                                                      */
+    double lambda;      /* multiplier of the row as written here, >= 0 (of "sum coef x >= lo", or of "-sum coef x >= -hi")          */
+} dlscqp_conflict_member;
+/* Writes the agent's model as a CPLEX-LP file (cplex.exportModel). */
+int dlscqp_write_lp(const dlscqp_ctx *ctx, const dlscqp_agent *agent, const dlscqp_lsc_row *rows, int32_t n_rows, const float *sfc_boxes,
+                    int32_t max_slack_obs, const float *goal, const char *path);
+/* One record of dlscqp_device_batch.out_conflict (copied to the host) -> the rows of the reference's model that prove the agent's QP
+ * infeasible, with their multipliers: sum lambda_i (row_i as ">=") is a combination of the equality rows alone, and its right-hand
+ * side exceeds theirs by *gap_out > 0 (Farkas).  n_out: members written (0: the record holds no certificate); *n_con_out: rows of
+ * `con` (for the refiner's numbering of the variable bounds). */
+int dlscqp_conflict_decode(const dlscqp_ctx *ctx, const dlscqp_agent *agent, const dlscqp_lsc_row *rows, int32_t n_rows, const float *sfc_boxes,
+                           int32_t max_slack_obs, const float *goal, const double *record, dlscqp_conflict_member *out, int32_t capacity,
+                           int32_t *n_out, int32_t *n_con_out, double *gap_out);
 /* bytes of dlscqp_device_batch.workspace that suffice for any launch of up to n_agents agents of this shape (0: none needed) */
 int64_t dlscqp_workspace_bytes(const dlscqp_ctx *ctx, int32_t n_agents, int32_t max_slack_obs, int32_t max_rows_per_agent);
 

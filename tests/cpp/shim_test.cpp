@@ -114,6 +114,18 @@ int main() {
             thrown = rep == PlanningReport::QPFAILED;  // traj_optimizer.cpp:152
         }
         CHECK(thrown);
+        // ... and, like the reference's catch block (traj_optimizer.cpp:112-146), leaves the conflict behind: the two opposite
+        // half-spaces y <= -0.1 and y >= 0.3 on one control point prove it, each with the multiplier 1 (violated by 0.4)
+        {
+            const std::string &cf = opt3.lastConflict();
+            std::printf("%s", cf.c_str());
+            CHECK(cf.find("Conflict :") == 0);
+            size_t proved = 0, at = 0;
+            while ((at = cf.find("Proved  : c", at)) != std::string::npos) { proved++; at++; }
+            CHECK(proved == 2);
+            CHECK(cf.find("violated by 0.4") != std::string::npos);
+            CHECK(cf.find("(multiplier 1)") != std::string::npos);
+        }
         // the batch entry reports the same verdict without throwing
         std::vector<const Agent *> as{&a3, &a3};
         CollisionConstraints free_cons(p3, m3);

@@ -18,6 +18,7 @@
 #define DQ_FN inline
 #include "../../dlsc_gc_planner_amd/csrc/gi_core.hpp"
 #include "../../dlsc_gc_planner_amd/csrc/lsc_core.hpp"
+#include "../../dlsc_gc_planner_amd/csrc/model_rows.hpp"
 #include "../../dlsc_gc_planner_amd/csrc/qp_tables.hpp"
 #include "../../dlsc_gc_planner_amd/csrc/sfc_core.hpp"
 #include "../../dlsc_gc_planner_amd/csrc/sfc_world.hpp"
@@ -26,6 +27,9 @@ namespace {
 
 std::vector<double> *g_trace = nullptr;
 std::vector<unsigned char> g_last_lds;  // debug: LDS image of the last agent solved  // -DDLSCQP_TRACE builds: records of the agent being solved
+
+static double *g_conflict = nullptr;  // emul_set_conflict
+static int g_conflict_stride = 0;
 
 struct WaveCpu {
     bool reverse;
@@ -164,7 +168,7 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
     const int KUsel = ic.KU, SUsel = ic.SU;
     typedef void (*fn_t)(const WaveCpu &, const KParams &, const MemLayout &, unsigned char *, double *, const dlscqp_agent *,
                          const RowsView &, int, int, const float *, int, int, int, float *, int *, float *, double *,
-                         double *, double *, int *, int *, int *);
+                         double *, double *, int *, int *, int *, double *);
     fn_t fn = nullptr;
     switch (ic.id) {
 #define DQ_CASE(ID, RC, DIMS, FS, MS, KU, SU, SLK) \
@@ -196,9 +200,54 @@ extern "C" int emul_plan_batch(const dlscqp_config *cfg, int n_agents, const dls
                    out_ctrl ? out_ctrl + (size_t)a * M * n1 * 3 : nullptr, out_x ? out_x + a * xs : nullptr,
                    out_cost ? out_cost + a : nullptr,
                    out_slack_cost ? out_slack_cost + (size_t)a * max_slack_obs : nullptr,
-                   out_status ? out_status + a : nullptr, out_iters ? out_iters + (size_t)a * 4 : nullptr, nullptr);
+                   out_status ? out_status + a : nullptr, out_iters ? out_iters + (size_t)a * 4 : nullptr, nullptr,
+                   g_conflict ? g_conflict + (size_t)a * g_conflict_stride : nullptr);
         g_last_lds = mem;
     }
+    return 0;
+}
+
+// dlscqp_device_batch.out_conflict for the following emul_plan_batch calls ([n_agents][stride] doubles, zeroed by the caller; null: off)
+extern "C" void emul_set_conflict(double *buf, int stride) {
+    g_conflict = buf;
+    g_conflict_stride = stride;
+}
+
+// the product's host functions of the reference's failure path (csrc/model_rows.hpp), without a device context
+static bool emul_model(const dlscqp_config *cfg, dlscqp::HostTables &tb) {
+    std::string err;
+    return dlscqp::build_tables(*cfg, cfg->world_dimension, cfg->M, cfg->n, cfg->phi, cfg->dt, tb, err);
+}
+extern "C" int emul_write_lp(const dlscqp_config *cfg, const dlscqp_agent *agent, const dlscqp_lsc_row *rows, int n_rows, const float *sfc,
+                             int max_slack_obs, const float *goal, const char *path) {
+    using namespace dlscqp;
+    HostTables tb;
+    if (!emul_model(cfg, tb)) return -1;
+    HostModel md;
+    std::string err;
+    if (!build_host_model(*cfg, tb.kp, *agent, rows, n_rows, sfc, max_slack_obs, goal, md, err) || !write_lp(md, path, err)) return -2;
+    return 0;
+}
+extern "C" int emul_conflict_decode(const dlscqp_config *cfg, const dlscqp_agent *agent, const dlscqp_lsc_row *rows, int n_rows, const float *sfc,
+                                    int max_slack_obs, const float *goal, const double *record, dlscqp_conflict_member *out, int capacity,
+                                    int *n_out, int *n_con_out, double *gap_out) {
+    using namespace dlscqp;
+    HostTables tb;
+    if (!emul_model(cfg, tb)) return -1;
+    HostModel md;
+    std::string err;
+    if (!build_host_model(*cfg, tb.kp, *agent, rows, n_rows, sfc, max_slack_obs, goal, md, err)) return -2;
+    *n_con_out = (int)md.con.size();
+    const int n = (int)record[0];
+    *n_out = 0;
+    *gap_out = n > 0 ? record[1] : 0.0;
+    if (n > capacity) return -3;
+    for (int t = 0; t < n; t++) {
+        double scale = 1.0;
+        if (!conflict_member(*cfg, tb.kp, tb.slots.data(), md, sfc, (uint32_t)record[4 + 2 * t], out[t], scale, err)) return -4;
+        out[t].lambda = record[5 + 2 * t] / scale;
+    }
+    *n_out = n;
     return 0;
 }
 
@@ -507,7 +556,7 @@ extern "C" int emul_throughput(const dlscqp_config *cfg, int n_agents, const dls
     if (ic.id < 0) return -2;
     typedef void (*fn_t)(const WaveCpu &, const KParams &, const MemLayout &, unsigned char *, double *, const dlscqp_agent *,
                          const RowsView &, int, int, const float *, int, int, int, float *, int *, float *, double *,
-                         double *, double *, int *, int *, int *);
+                         double *, double *, int *, int *, int *, double *);
     fn_t fn = nullptr;
     switch (ic.id) {
 #define DQ_CASE(ID, RC, DIMS, FS, MS, KU, SU, SLK) \
@@ -535,7 +584,7 @@ extern "C" int emul_throughput(const dlscqp_config *cfg, int n_agents, const dls
         for (;;) {
             fn(w, kp, lay, mem.data(), nullptr, agents + a, rv, (int)row_offsets[a], (int)(row_offsets[a + 1] - row_offsets[a]),
                sfc ? sfc + (size_t)a * M * 6 : nullptr, max_slack_obs, 1, 1, goal, &gst, ctrl.data(), nullptr, &cost,
-               max_slack_obs ? slack.data() : nullptr, &st, it, nullptr);
+               max_slack_obs ? slack.data() : nullptr, &st, it, nullptr, nullptr);
             done[t]++;
             if (++a == hi) a = lo;
             if ((done[t] & 15) == 0 &&

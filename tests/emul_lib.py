@@ -34,7 +34,45 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-def plan_batch(cfg, agents, row_offsets, rows, sfc=None, max_slack_obs=0, do_goal=True, do_traj=True):
+def conflict_doubles(cfg, max_slack_obs=0):
+    f = table_info(cfg, max_slack_obs, 0)["f"]
+    return 4 + 2 * (cfg.world_dimension * f + cfg.M * max_slack_obs + 1)
+
+
+def write_lp(cfg, agent, rows, path, sfc=None, max_slack_obs=0, goal=None):
+    """csrc/model_rows.hpp: the agent's model as a CPLEX-LP file (the product's dlscqp_write_lp without a device context)"""
+    agent = np.ascontiguousarray(agent, dtype=abi.AGENT_DTYPE).reshape(1)
+    rows = np.ascontiguousarray(rows, dtype=abi.ROW_DTYPE)
+    sfc = None if sfc is None else np.ascontiguousarray(sfc, dtype=np.float32)
+    goal = None if goal is None else np.ascontiguousarray(goal, dtype=np.float32)
+    rc = lib().emul_write_lp(C.byref(cfg), _ptr(agent), _ptr(rows) if len(rows) else None, len(rows), _ptr(sfc), max_slack_obs, _ptr(goal), str(path).encode())
+    if rc != 0:
+        raise ValueError("emul_write_lp failed (%d)" % rc)
+
+
+def conflict_decode(cfg, agent, rows, record, sfc=None, max_slack_obs=0, goal=None):
+    """csrc/model_rows.hpp: one out_conflict record -> (members, n_con, gap), like BatchTrajOptimizer.conflict_decode"""
+    agent = np.ascontiguousarray(agent, dtype=abi.AGENT_DTYPE).reshape(1)
+    rows = np.ascontiguousarray(rows, dtype=abi.ROW_DTYPE)
+    sfc = None if sfc is None else np.ascontiguousarray(sfc, dtype=np.float32)
+    goal = None if goal is None else np.ascontiguousarray(goal, dtype=np.float32)
+    record = np.ascontiguousarray(record, dtype=np.float64)
+    cap = max(int(record[0]), 1)
+    out = (abi.ConflictMember * cap)()
+    n, ncon, gap = C.c_int32(0), C.c_int32(0), C.c_double(0.0)
+    L = lib()
+    L.emul_conflict_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.POINTER(abi.ConflictMember), C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    rc = L.emul_conflict_decode(C.byref(cfg), _ptr(agent), _ptr(rows) if len(rows) else None, len(rows), _ptr(sfc), max_slack_obs, _ptr(goal),
+                                _ptr(record), out, cap, C.byref(n), C.byref(ncon), C.byref(gap))
+    if rc != 0:
+        raise ValueError("emul_conflict_decode failed (%d)" % rc)
+    mem = [dict(ref_index=int(m.ref_index), kind=abi.MODEL_KINDS[m.kind], var=[int(m.var[t]) for t in range(m.n)],
+                coef=[float(m.coef[t]) for t in range(m.n)], lo=float(m.lo), hi=float(m.hi), lam=float(m.lam)) for m in out[:n.value]]
+    return mem, int(ncon.value), float(gap.value)
+
+
+def plan_batch(cfg, agents, row_offsets, rows, sfc=None, max_slack_obs=0, do_goal=True, do_traj=True, want_conflict=False):
     L = lib()
     agents = np.ascontiguousarray(agents, dtype=abi.AGENT_DTYPE)
     rows = np.ascontiguousarray(rows, dtype=abi.ROW_DTYPE)
@@ -47,13 +85,26 @@ def plan_batch(cfg, agents, row_offsets, rows, sfc=None, max_slack_obs=0, do_goa
                ctrl=np.zeros((N, M, n + 1, 3), np.float32), x=np.zeros((N, nx)), cost=np.zeros(N),
                slack_cost=np.zeros((N, max(max_slack_obs, 1))), status=np.full(N, -1, np.int32),
                iters=np.zeros((N, 4), np.int32))
+    if want_conflict:  # dlscqp_device_batch.out_conflict: certificates of the INFEASIBLE verdicts
+        out["conflict"] = np.zeros((N, conflict_doubles(cfg, max_slack_obs)))
+        L.emul_set_conflict.argtypes = [C.c_void_p, C.c_int]
+        L.emul_set_conflict(_ptr(out["conflict"]), out["conflict"].shape[1])
+    try:
+        rc = _emul_plan(L, cfg, N, agents, row_offsets, rows, sfc, max_slack_obs, do_goal, do_traj, out)
+    finally:
+        if want_conflict:
+            L.emul_set_conflict(None, 0)
+    if rc != 0:
+        raise ValueError("emul_plan_batch: invalid configuration")
+    return out
+
+
+def _emul_plan(L, cfg, N, agents, row_offsets, rows, sfc, max_slack_obs, do_goal, do_traj, out):
     rc = L.emul_plan_batch(C.byref(cfg), N, _ptr(agents), _ptr(row_offsets), _ptr(rows), _ptr(sfc),
                            max_slack_obs, int(do_goal), int(do_traj), _ptr(out["goal"]),
                            _ptr(out["goal_status"]), _ptr(out["ctrl"]), _ptr(out["x"]), _ptr(out["cost"]),
                            _ptr(out["slack_cost"]) if max_slack_obs else None, _ptr(out["status"]), _ptr(out["iters"]))
-    if rc != 0:
-        raise ValueError("emul_plan_batch: invalid configuration")
-    return out
+    return rc
 
 
 def neighbours(cfg, position, pitch, local_ids=None, n_dyn=0):
