@@ -90,6 +90,22 @@ def algorithmic_bytes_per_qp(dim, M, n, K, use_sfc, n_dyn):
     return b
 
 
+def scaling_model(step_ms_one_rank, n_agents_per_rank):
+    """What a 2 / 4 / 8-GPU run of this bench should show, so that a measured SCALE file can be read against it (no node with more than
+    one GPU was available to measure it): weak scaling, every rank plans its own agents; ONE all-gather of 376 B per agent per step whose
+    transfer runs beside the next step's launches (pipelined: no agent of S64 reads a remote plan):
+        step(n) = max(step(1) + post, transfer(n)),   transfer(n) = latency + (n - 1) N 376 B / ring bandwidth"""
+    post, lat, ring = 0.05, 0.03, 300e9
+    ms = [max(step_ms_one_rank + (0.0 if g == 1 else post), 0.0 if g == 1 else lat + (g - 1) * n_agents_per_rank * 376 / ring * 1e3) for g in (1, 2, 4, 8)]
+    return {"n_gpus": [1, 2, 4, 8], "ms_per_step": ms, "qp_per_s": [g * n_agents_per_rank / t * 1e3 for g, t in zip((1, 2, 4, 8), ms)],
+            "speedup_over_one_gpu": [g * ms[0] / t for g, t in zip((1, 2, 4, 8), ms)],
+            "assumptions": {"step_ms_one_rank": step_ms_one_rank, "post_ms": post, "exchange_latency_ms": lat, "ring_GBps": ring / 1e9, "bytes_per_agent": 376,
+                            "note": "post_ms: what queueing the exchange costs a step on one rank (--force-dist, two groups, against the same loop "
+                                    "without a process group); ring_GBps: bus bandwidth of RCCL's ring all-gather over xGMI (7 links x ~153 GB/s "
+                                    "per GPU, point to point: a ring is bound by one link each way; DESIGN.md section 5); the transfer is hidden "
+                                    "behind the next step's launches while it is shorter than a step"}}
+
+
 def host_cores():
     cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     for fq, fp in (("/sys/fs/cgroup/cpu.max", None), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
@@ -912,7 +928,7 @@ def main():
                     return self.spare.pop(i)
             return torch.cuda.Stream(dev)
 
-        def make_exchange(self):
+        def make_exchange(self, force_torch=False):
             # per agent: control points, sub-goal, status (376 B at S64) -- the broadcast payload of the reference.  ONE exchange
             # per step for all groups: the groups' batches of a step write slices of one output table, a stream of its own
             # (`join`) waits for the groups' launches of the step and posts the table; no group's stream waits for another
@@ -921,7 +937,18 @@ def main():
             shape1 = tuple(self.dbs[0][0].out_ctrl.shape[1:])
             # the library's own exchange (ncclAllGather called from C on a stream it owns) wherever RCCL can run; torch.distributed
             # only for the two-ranks-on-one-device test hook (gloo)
-            self.xchg = sharding.make_exchange(opt, dist, rank, world, N, dev)
+            if force_torch:  # the fallback: torch.distributed's own all-gather (verify_exchange found the library's exchange wrong)
+                if self.xchg is not None:
+                    try:
+                        self.xchg.close()
+                    except Exception:  # noqa: BLE001
+                        pass
+                E0 = int(np.prod(shape1))
+                self.xchg = sharding.PlanExchange(dist, world, N, (E0, 3, 1), dev)
+                self.xchg.issued_by = "torch.distributed"
+                self.cargs = None
+            else:
+                self.xchg = sharding.make_exchange(opt, dist, rank, world, N, dev)
             self.native = isinstance(self.xchg, sharding.NativeExchange)
             if not self.native:
                 self.xchg.comm = self.spare_stream()  # (not one that shares a hardware queue with a group's launches)
@@ -938,6 +965,32 @@ def main():
             for g in range(self.G):
                 for j in range(B):
                     self.dbs[g][j].use_records(self.rec[j][g * per:(g + 1) * per])
+
+        def verify_exchange(self):
+            """The gathered table of the LAST posted step, WHOLE, against torch.distributed's own all-gather of the same records (every
+            rank's block, not only this rank's own: the library's exchange -- ncclAllGather bound by hand -- has never run with more
+            than one rank on the boxes this repository is built on).  All ranks agree on the answer.  Returns (ok, reason)."""
+            j = (self.counter - 1) % B
+            ok, why = 1, ""
+            try:
+                table = self.xchg.table()
+                torch.cuda.synchronize(dev)
+                got = table.reshape(world * N, -1).clone()
+                if os.environ.get("DLSCQP_BENCH_CORRUPT_EXCHANGE") == "1" and getattr(self, "native", False):
+                    got[(world * N) // 2, 3] += 1.0  # TEST HOOK (tests/test_gpu_bench.py): a table that differs in one word
+                ref = torch.empty_like(got)
+                dist.all_gather_into_tensor(ref, self.rec[j].reshape(N, -1).contiguous())
+                torch.cuda.synchronize(dev)
+                if not torch.equal(ref.view(torch.int32), got.view(torch.int32)):
+                    bad = int((ref.view(torch.int32) != got.view(torch.int32)).any(dim=1).sum())
+                    ok, why = 0, "%d of %d records of the gathered table differ from torch.distributed's all-gather of the same records" % (bad, world * N)
+            except Exception as e:  # noqa: BLE001
+                ok, why = 0, "exchange check failed: %s" % e
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and ok:
+                why = "another rank's gathered table is wrong"
+            return bool(int(flag.item())), why
 
         def step_args(self):
             """One dlscqp_step_args per batch of the rotation: the whole step -- every group's launch on its stream and, with an
@@ -1110,8 +1163,37 @@ def main():
     head_pipelined = use_dist and pipelined_ok and args.exchange == "pipelined"
     if use_dist:
         assert B >= 3, "the pipelined exchange reads a step's output table while the next steps write other tables"
+    # N > 1: the exchange is CHECKED around the timed loop -- the whole gathered table against torch.distributed's own all-gather of the
+    # same records, once before and once after.  If the library's exchange fails either check the run falls back to torch.distributed
+    # (config.exchange_issued_by says so) and the headline is timed with that: a multi-GPU line must not rest on a path that only
+    # ever ran with one rank.
+    exchange_check = None
+    if use_dist:
+        exchange_check = {"before": None, "after": None, "fallback": None}
+        loop.timed(B, head_pipelined, "kernel")
+        okx, whyx = loop.verify_exchange()
+        exchange_check["before"] = "ok" if okx else whyx
+        if not okx:
+            if not loop.native:
+                raise SystemExit("bench.py: torch.distributed's exchange does not gather the records it was given: %s" % whyx)
+            print("bench.py: the library's own exchange failed its check before the timed loop (%s): torch.distributed instead" % whyx, file=sys.stderr)
+            exchange_check["fallback"] = whyx
+            loop.make_exchange(force_torch=True)
     elapsed = loop.timed(args.steps, head_pipelined, "kernel", record_kernel_times=True)
     kms = loop.kernel_times_ms(args.steps)
+    if use_dist:
+        okx, whyx = loop.verify_exchange()
+        exchange_check["after"] = "ok" if okx else whyx
+        if not okx and loop.native:
+            print("bench.py: the library's own exchange failed its check after the timed loop (%s): torch.distributed instead, timed again" % whyx, file=sys.stderr)
+            exchange_check["fallback"] = whyx
+            loop.make_exchange(force_torch=True)
+            elapsed = loop.timed(args.steps, head_pipelined, "kernel", record_kernel_times=True)
+            kms = loop.kernel_times_ms(args.steps)
+            okx, whyx = loop.verify_exchange()
+            exchange_check["after"] = "ok (torch.distributed)" if okx else whyx
+        if not okx:
+            raise SystemExit("bench.py: the gathered table is wrong after the timed loop: %s" % whyx)
     # A bracket shorter than 50 ms (the driver's --steps 20: 4.5 ms) carries a fixed ~0.2 ms of its own -- first launches, the slowest
     # group's tail, the last synchronisation -- i.e. 4-5 % of 20 steps and 0.2 % of 400.  Then the same `steps`-long loop runs R times
     # back to back between two synchronisations, with an event per group stream at every boundary; ms_per_step = the MEDIAN repeat
@@ -1405,10 +1487,14 @@ def main():
                              "one RCCL all-gather of control points, sub-goal and status per step, posted on a communication stream: runs "
                              "while the next step plans the agents without remote neighbours (all of them here)"
                              if head_pipelined else "one RCCL all-gather of control points, sub-goal and status per step, after the launch"),
+                # the whole gathered table against torch.distributed's own all-gather of the same records, before and after the timed loop
+                # ("ok", or what differed); fallback: why the library's exchange was replaced by torch.distributed for this run
+                "exchange_check": exchange_check,
                 "exchange_issued_by": (None if not use_dist else
                                        "the library (dlscqp_exchange_post: ncclAllGather from librccl on a communication stream the exchange owns); "
                                        "the whole step -- every group's launch and the post -- is one call, dlscqp_step_device" if native_xchg
-                                       else "torch.distributed.all_gather_into_tensor (gloo test hook)"),
+                                       else ("torch.distributed.all_gather_into_tensor (FALLBACK: the library's own exchange failed its check: %s)" % exchange_check["fallback"]
+                                             if exchange_check and exchange_check.get("fallback") else "torch.distributed.all_gather_into_tensor (gloo test hook, or DLSCQP_NATIVE_EXCHANGE=0)")),
                 "exchange_modes_ms_per_step": exch,
                 "ms_per_step_exchange_restricted_to_halo_consumers": None if el_halo_only is None else el_halo_only / side_steps * 1e3,
                 "exchange_restricted_note": "the reference broadcasts every plan to every agent (multi_sync_simulator.cpp:468-514) and the "
@@ -1438,6 +1524,7 @@ def main():
             # the figure that compares like for like with rounds 1-2 (ONE launch of all the GPU's agents per step, in lockstep); `value`
             # is the swarm groups advancing independently on their own streams (config.swarm_groups_note)
             "at_512_swarms": at_512,
+            "scaling_model": scaling_model(elapsed / args.steps * 1e3 - (0.05 if use_dist else 0.0), N),
             "one_launch_per_step": None if not isinstance(one_launch, dict) or not one_launch.get("kernel_order") else
                                    {"ms_per_step": one_launch["kernel_order"], "qp_per_s": world * N / one_launch["kernel_order"] * 1e3},
             "per_rank_ms": rank_breakdown,

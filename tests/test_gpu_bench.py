@@ -77,6 +77,21 @@ def test_multi_gpu_code_path_with_one_rank(gpu_required, mode):
         assert e60["per_rank_ms"][k]["mean"] > 0, k  # the wait for the table is real here: every agent is a halo agent
 
 
+def test_exchange_is_checked_whole_and_falls_back(gpu_required, monkeypatch):
+    """the first multi-rank run must not rest on the least-tested code.  With N > 1 (here: a one-rank group) the whole
+    gathered table is compared with torch.distributed's own all-gather of the same records before and after the timed loop; a table
+    that differs in ONE word (test hook) makes the run fall back to torch.distributed, say so, and finish with exit code 0."""
+    d = _bench("--force-dist", "--no-cpu-baseline", "--headline-only")
+    assert d["config"]["exchange_check"] == {"before": "ok", "after": "ok", "fallback": None}
+    assert d["config"]["exchange_issued_by"].startswith("the library")
+    assert d["scaling_model"]["n_gpus"] == [1, 2, 4, 8] and all(v > 0 for v in d["scaling_model"]["ms_per_step"])
+    monkeypatch.setenv("DLSCQP_BENCH_CORRUPT_EXCHANGE", "1")
+    d = _bench("--force-dist", "--no-cpu-baseline", "--headline-only")
+    c = d["config"]["exchange_check"]
+    assert "1 of" in c["before"] and "differ" in c["before"] and c["fallback"] == c["before"] and c["after"] == "ok"
+    assert "FALLBACK" in d["config"]["exchange_issued_by"] and d["value"] > 0
+
+
 def test_gpus_flag_starts_the_ranks_itself(gpu_required):
     """`bench.py --gpus 2` without RANK in the environment must not silently measure one GPU: it starts the ranks as child
     processes (torch.distributed.run).  On a one-GPU box the second rank cannot get a device, so the run fails -- loudly."""
