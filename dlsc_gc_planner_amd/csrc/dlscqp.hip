@@ -296,7 +296,12 @@ struct AdvanceArgs {
 
 // one wavefront per agent; E = M (n+1) 3 floats of a plan, lane l owns elements l, l + 64, ...
 // (shared by dlscqp_advance_kernel and the plan kernel's epilogue: dlscqp_device_batch.advance_after)
-__device__ __forceinline__ void advance_agent(const AdvanceArgs &g, int ag, int l) {
+// stage: E floats of LDS that are this wavefront's (round 6).  The new plan goes to memory AND to `stage`; everything that is derived
+// from other lanes' elements of it -- the initial trajectory of the next step (the plan shifted by a segment), the boxes around that,
+// the state at dt -- is read from there.  Before, each of those was a store, a wait for it to land, and a dependent load from L2:
+// eight load-wait-store pairs one after the other for the initial trajectory alone (the compiler cannot batch loads of `plan` across
+// stores to `initial_traj`: for all it knows they alias), ~6 us per agent behind every solve of a closed loop.
+__device__ __forceinline__ void advance_agent(const AdvanceArgs &g, int ag, int l, float *stage) {
     const dlscqp_advance &a = g.a;
     const int M = g.M, n1 = g.n1, seg = n1 * 3, E = M * seg;
     float *plan = a.plans + (size_t)ag * E;
@@ -317,9 +322,15 @@ __device__ __forceinline__ void advance_agent(const AdvanceArgs &g, int ag, int 
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int e = l + 64 * u;
-        if (e < E) plan[e] = v[u];  // ... the first write (one wavefront: memory operations in program order)
+        if (e < E) {
+            plan[e] = v[u];  // ... the first write (one wavefront: memory operations in program order)
+            stage[e] = v[u];
+        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the new plan is in memory before other lanes' elements are read back
+    // (one wavefront: its LDS operations are performed in order; the compiler is told not to move them across this point)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (a.out_host_pack) {  // uniform: the plan and the alerts for the host-side waypoint planner (pinned host memory)
         float *hp = a.out_host_pack + (size_t)a.n_agents * 6;
 #pragma unroll
@@ -336,15 +347,14 @@ __device__ __forceinline__ void advance_agent(const AdvanceArgs &g, int ag, int 
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int e = l + 64 * u;
-            if (e < E) init[e] = plan[shifted(e)];
+            if (e < E) init[e] = stage[shifted(e)];
         }
         if (a.out_boxes) {  // uniform
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the initial trajectory is in memory before it is read back
             for (int j = l; j < M * 3; j += 64) {  // face (segment m, axis k): minimum and maximum over the segment's control points
                 const int m = j / 3, k = j - 3 * m;
-                float mn = init[m * seg + k], mx = mn;
+                float mn = stage[shifted(m * seg + k)], mx = mn;  // (the initial trajectory's element, from the new plan)
                 for (int i = 1; i < n1; i++) {
-                    const float v = init[m * seg + 3 * i + k];
+                    const float v = stage[shifted(m * seg + 3 * i + k)];
                     mn = v < mn ? v : mn;
                     mx = v > mx ? v : mx;
                 }
@@ -362,7 +372,7 @@ __device__ __forceinline__ void advance_agent(const AdvanceArgs &g, int ag, int 
         a.current_goal[(size_t)ag * 3 + k] = cg;
         // state at dt: first three control points of segment 1 (M >= 2, dlscqp_create)
         const int b = seg;
-        const float c0 = plan[b + k], c1 = plan[b + 3 + k], c2 = plan[b + 6 + k];
+        const float c0 = stage[b + k], c1 = stage[b + 3 + k], c2 = stage[b + 6 + k];
         const float v0 = (c1 - c0) * g.s1, v1 = (c2 - c1) * g.s1;
         const float p = c0, vel = v0, acc = (v1 - v0) * g.s2;
         dlscqp_agent *rec = a.agents + ag;
@@ -381,7 +391,7 @@ __device__ __forceinline__ void advance_agent(const AdvanceArgs &g, int ag, int 
             // the other two axes of the new position: recomputed by this lane (three lanes, three axes each)
             float d3[3], p3[3];
             for (int j = 0; j < 3; j++) {
-                p3[j] = plan[b + j];
+                p3[j] = stage[b + j];
                 d3[j] = dg[j] - p3[j];
             }
             const double dist = dlscqp::f32_norm3(d3[0], d3[1], d3[2]);
@@ -698,7 +708,8 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
         // what dlscqp_advance_device would do for this agent in a launch of its own: it reads the verdicts and the plan this wavefront
         // has just stored (a wavefront's memory operations are performed in program order) and touches this agent's entries only
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        advance_agent(a.adv, ag, w.lane);
+        // (its staging buffer: the column records' place in the working set, free now -- one record is longer than a plan)
+        advance_agent(a.adv, ag, w.lane, reinterpret_cast<float *>(reinterpret_cast<double *>(smem) + lay.oC));
     }
 #ifdef DLSCQP_STAMPS
     if (a.out_stamps && threadIdx.x == 0)
@@ -2312,7 +2323,10 @@ extern "C" int dlscqp_hint_order_preview_device(dlscqp_ctx *c, const int32_t *co
 // between two launches (include/dlscqp.h: dlscqp_advance)
 // ---------------------------------------------------------------------------------------------
 namespace {
-__global__ __launch_bounds__(64) void dlscqp_advance_kernel(AdvanceArgs g) { advance_agent(g, (int)blockIdx.x, (int)threadIdx.x); }
+__global__ __launch_bounds__(64) void dlscqp_advance_kernel(AdvanceArgs g) {
+    __shared__ float stage[512];  // advance_args: a plan has at most 512 floats
+    advance_agent(g, (int)blockIdx.x, (int)threadIdx.x, stage);
+}
 }  // namespace
 
 extern "C" int dlscqp_advance_device(dlscqp_ctx *c, const dlscqp_advance *adv, void *stream) {

@@ -1871,8 +1871,11 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         const uint32_t pk_new = new_line ? ((uint32_t)np0 | ((uint32_t)np1 << 8) | ((uint32_t)np2 << 16) | ((uint32_t)new_axis << 24) | (1u << 26))
                                          : (uint32_t)np0 * 0x010101u;
         DQ_TRACE(1, (double)ip, viol, top, (double)q);
-        const double sig_row = kp.sigma[(sidx_row < 0 ? 0 : sidx_row) % M];
-        const double sig2_row = sidx_row >= 0 ? sig_row * sig_row : 0.0;
+        double sig2_row = 0.0;  // (a build without slack variables has none: no dependent scalar load in front of the rows of G)
+        if (SLK != 0) {
+            const double sig_row = kp.sigma[(sidx_row < 0 ? 0 : sidx_row) % M];
+            sig2_row = sidx_row >= 0 ? sig_row * sig_row : 0.0;
+        }
         // ---- the rows of G_T at the control points the new row touches (G a: lane p holds control point p) --------------------
         // requested HERE and used after d1 and rv below: their trip to L2 runs under those two.  The Gram table is never copied:
         // an iteration needs one row of it (POINT row) or three (LINE row), 8 P bytes each, coalesced.
@@ -1880,15 +1883,12 @@ DQ_FN void plan_agent(const W &w, const KParams &kp, const MemLayout &lay, unsig
         if (P64) {
             w.each([&](int l) {
                 const int pc = l < P ? l : P - 1;
-                const double g0 = G[np0 * ldg + pc];
-                gq[0].at(l) = g0;
-                if (new_line) {  // uniform
-                    gq[1].at(l) = G[np1 * ldg + pc];
-                    gq[2].at(l) = G[np2 * ldg + pc];
-                } else {
-                    gq[1].at(l) = g0;
-                    gq[2].at(l) = g0;
-                }
+                // (three loads whatever the row: np1 = np2 = np0 for a POINT row, whose second and third read hit the line the first
+                // one brings.  Copies of the first register instead made the wavefront wait for it HERE, a whole trip to L2, where the
+                // point of asking early is that d1 and rv run under that trip -- found in the ISA in round 6.)
+                gq[0].at(l) = G[np0 * ldg + pc];
+                gq[1].at(l) = G[np1 * ldg + pc];
+                gq[2].at(l) = G[np2 * ldg + pc];
             });
         }
         // where the new row's entries sit in a Z column (x-space index = axis P + control point), as z_squared() has them: a POINT

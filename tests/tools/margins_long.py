@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool (CPU only): tests/test_dependency_margins.py over a range of seeds, margins appended to a log.
-    python tests/tools/margins_long.py 100 300 profiles/r05_fuzz_dependency_margins.log [workers]
+    python tests/tools/margins_long.py 100 300 profiles/r05_fuzz_dependency_margins.log [workers [configuration,...]]
 Every (configuration, seed) is one call of the test function with the margin assertions BINDING (FUZZ_SEED set); a shortfall or a
 misclassification is reported in the log line of that run ("FAILED: ...") and counted, the sweep goes on."""
 import multiprocessing as mp
@@ -46,7 +46,8 @@ if __name__ == "__main__":
     import subprocess
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tests", "emul"), "libdlscqp_emul_trace.so"])
     import test_dependency_margins as T
-    jobs = [(s, n) for s in range(lo, hi) for n in T.NAMES]
+    names = sys.argv[5].split(",") if len(sys.argv) > 5 else T.NAMES  # (round 6: a long sweep of the thin-corner shape alone)
+    jobs = [(s, n) for s in range(lo, hi) for n in names]
     bad = 0
     with mp.Pool(workers) as pool, open(out, "w") as fh:
         fh.write("# tests/tools/margins_long.py %d %d: tests/test_dependency_margins.py with the margin assertions binding, trace build of the kernel "
