@@ -769,9 +769,9 @@ constexpr int LSC_THREADS = 128;
 #ifndef DQ_LSC_OCC_FEW
 #define DQ_LSC_OCC_FEW 2
 #endif
-template <int THREADS, int OCC = DQ_LSC_OCC>
-__global__ __launch_bounds__(THREADS, OCC) void dlscqp_lsc_kernel(LscGenArgs g) {
-    const int k = blockIdx.x;
+// (the body of dlscqp_lsc_kernel as a device function of a workgroup of THREADS threads: also a stage of dlscqp_fused_kernel)
+template <int THREADS>
+__device__ __forceinline__ void lsc_agent(const LscGenArgs &g, const int k) {
     if (k >= g.n_local) return;
     const int self = g.local_ids ? g.local_ids[k] : k;
     const int p0 = g.nbr_offsets[k], p1 = g.nbr_counts ? p0 + g.nbr_counts[k] : g.nbr_offsets[k + 1];
@@ -849,6 +849,8 @@ __global__ __launch_bounds__(THREADS, OCC) void dlscqp_lsc_kernel(LscGenArgs g) 
         lsc_dyn_item(g, self, o, m, (size_t)per * (pair0 + nn + o));
     }
 }
+template <int THREADS, int OCC = DQ_LSC_OCC>
+__global__ __launch_bounds__(THREADS, OCC) void dlscqp_lsc_kernel(LscGenArgs g) { lsc_agent<THREADS>(g, (int)blockIdx.x); }
 
 // Two agents per wavefront, for lists so short that one agent leaves most of a wavefront without an item (the synthetic swarms of
 // BASELINE.json configs[1]: 4 x 5 + 2 = 22 items -- with a wavefront per agent three fifths of the lanes of the S64 closed loop's
@@ -920,9 +922,9 @@ struct TrapArgs {
     int32_t *out_released;
     double horizon;
 };
-__global__ __launch_bounds__(64) void dlscqp_trap_kernel(TrapArgs t) {
+// (one wavefront; `lane` = its lane.  Also a stage of dlscqp_fused_kernel.)
+__device__ __forceinline__ void trap_agent(const TrapArgs &t, const int k, const int lane) {
     const LscGenArgs &g = t.g;
-    const int k = blockIdx.x;
     if (k >= g.n_local) return;
     const int per = g.M * g.n1 - g.phi;
     const int p0 = g.nbr_offsets[k], p1 = g.nbr_counts ? p0 + g.nbr_counts[k] : g.nbr_offsets[k + 1];
@@ -933,7 +935,7 @@ __global__ __launch_bounds__(64) void dlscqp_trap_kernel(TrapArgs t) {
     const dlscqp_agent *ag = t.agents + k;
     const float *cg = ag->current_goal_point, *wp = ag->next_waypoint;
     bool out = false;
-    for (int j = threadIdx.x; j < n_rows; j += 64) out |= trap_row_excludes(g, row0 + j, cg, wp);
+    for (int j = lane; j < n_rows; j += 64) out |= trap_row_excludes(g, row0 + j, cg, wp);
     const float *box = t.sfc ? t.sfc + ((size_t)k * g.M + (g.M - 1)) * 6 : nullptr;
     bool trapped = __ballot(out) != 0ull;
     trapped = trapped || !point_in_boxes(g, box, wp, cg) || !point_in_boxes(g, box, wp, wp);
@@ -944,14 +946,15 @@ __global__ __launch_bounds__(64) void dlscqp_trap_kernel(TrapArgs t) {
                                   t.horizon, g.dyn_uncertainty_horizon))
                 continue;
             released++;
-            for (int j = threadIdx.x; j < n_rows; j += 64) {  // the rows of obstacle o: dynamic flag, slack variable o
+            for (int j = lane; j < n_rows; j += 64) {  // the rows of obstacle o: dynamic flag, slack variable o
                 const uint32_t key = g.key[row0 + j];
                 if (((key >> 12) & 1) && (int)(key >> 16) == o) trap_empty_row(g, row0 + j);
             }
         }
     }
-    if (t.out_released && threadIdx.x == 0) t.out_released[k] = released;
+    if (t.out_released && lane == 0) t.out_released[k] = released;
 }
+__global__ __launch_bounds__(64) void dlscqp_trap_kernel(TrapArgs t) { trap_agent(t, (int)blockIdx.x, (int)threadIdx.x); }
 
 // one WORKGROUP of SFC_THREADS threads per agent grows / shifts its corridor boxes (sfc_core.hpp).
 // Control flow is workgroup-uniform (every decision comes out of any_of); the threads share the lattice points of the slab
@@ -1113,9 +1116,9 @@ struct SfcGenArgs {
     int32_t *out_code;
 };
 
+// (the body of dlscqp_sfc_kernel as a device function of a workgroup of SFC_T threads: also a stage of dlscqp_fused_kernel)
 template <int SFC_T>
-__global__ __launch_bounds__(SFC_T) void dlscqp_sfc_kernel(SfcGenArgs a) {
-    const int ag = blockIdx.x;
+__device__ __forceinline__ void sfc_agent(const SfcGenArgs a, const int ag) {  // (by value: by reference this compiler's register allocator crashed on the 64-thread instantiation)
     if (ag >= a.n_agents) return;
     __shared__ int sfc_flags[2 * (SFC_T / 64)];
     __shared__ uint32_t sfc_axis[(SFC_T / 64) * 3 * SFC_AXIS_CAP];
@@ -1143,6 +1146,8 @@ __global__ __launch_bounds__(SFC_T) void dlscqp_sfc_kernel(SfcGenArgs a) {
     }
     if (a.out_code) a.out_code[ag] = code;  // every lane, same word
 }
+template <int SFC_T>
+__global__ __launch_bounds__(SFC_T) void dlscqp_sfc_kernel(SfcGenArgs a) { sfc_agent<SFC_T>(a, (int)blockIdx.x); }
 
 typedef void (*kernel_t)(KParams, MemLayout, KernelArgs);
 struct KernelChoice {
@@ -1925,10 +1930,13 @@ __global__ __launch_bounds__(256) void dlscqp_nbr_scatter_kernel(NbrArgs a) {
 // contiguous in by_cell), LInfinityDistance test, compaction into LDS, rank sort by id, the first `pitch` ids out
 constexpr int NBR_LIST_CAP = 4096;
 constexpr int NBR_DIRECT_MAX = 256;  // (DLSCQP_NBR_DIRECT_MAX in the environment: tests compare the two ways on the same agents)
-__global__ __launch_bounds__(64) void dlscqp_nbr_gather_kernel(NbrArgs a) {
+// (one wavefront does the work -- threads tid < 64 of the workgroup; the others only keep the barrier company: dlscqp_fused_kernel
+// calls this with 256 threads)
+__device__ __forceinline__ void nbr_gather_agent(const NbrArgs &a, const int k, const int tid) {
     __shared__ int list[NBR_LIST_CAP];
-    const int k = (int)blockIdx.x, lane = (int)threadIdx.x;
-    if (k >= a.ns.n_local) return;
+    const int lane = tid & 63;
+    const bool act = tid < 64;
+    if (k >= a.ns.n_local) return;  // (the whole workgroup)
     const int self = a.ns.local_ids ? a.ns.local_ids[k] : k;
     const float *ps = a.ns.position + (size_t)self * a.ns.position_stride;
     const float sx = ps[0], sy = ps[1], sz = ps[2];
@@ -1949,7 +1957,9 @@ __global__ __launch_bounds__(64) void dlscqp_nbr_gather_kernel(NbrArgs a) {
             count += __popcll(m);
         }
     };
-    if (a.range > 0 && !a.direct) {
+    if (!act) {
+        // (wavefronts beyond the first: nothing to gather)
+    } else if (a.range > 0 && !a.direct) {
         int c3[3];
         nbr_cell_of(a.grid, ps, c3);
         for (int dz = -1; dz <= 1; dz++) {
@@ -1969,9 +1979,10 @@ __global__ __launch_bounds__(64) void dlscqp_nbr_gather_kernel(NbrArgs a) {
     // the cell counts back to zero for the next search (their last reader, the prefix sum, ran before this kernel): the search
     // has no memset of its own -- a memset node inside a captured step was seen to leave the counts standing on the second
     // replay of the graph (round 4's memory access fault: slots beyond a cell's run, a scatter out of bounds)
-    if (!a.direct)
+    if (!a.direct && act)
         for (int e = k * 64 + lane; e <= a.n_cells; e += a.ns.n_local * 64) a.cell_count[e] = 0;
     __syncthreads();
+    if (!act) return;
     const int kept = count < NBR_LIST_CAP ? count : NBR_LIST_CAP;
     for (int e = lane; e < kept; e += 64) {
         const int id = list[e];
@@ -1986,6 +1997,7 @@ __global__ __launch_bounds__(64) void dlscqp_nbr_gather_kernel(NbrArgs a) {
         if (a.ns.out_overflow && (count > a.ns.pitch || count > NBR_LIST_CAP)) *a.ns.out_overflow = 1;
     }
 }
+__global__ __launch_bounds__(64) void dlscqp_nbr_gather_kernel(NbrArgs a) { nbr_gather_agent(a, (int)blockIdx.x, (int)threadIdx.x); }
 }  // namespace
 
 extern "C" int dlscqp_neighbours_device(dlscqp_ctx *c, const dlscqp_neighbour_search *ns, void *stream) {

@@ -13,8 +13,8 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# the product's scheduling strategy (iterative-ilp) crashes this compiler's register allocator on the S64 kernel once the diagnostic
-# statements are in it (round 6: ROCm 7.2 clang 22, "Greedy Register Allocator"): the diagnostic builds take the default strategy
+# the product's flags (__graft_entry__.HIPCC_FLAGS: the compiler's default scheduling strategy since round 6; DLSCQP_DIAG_ILP=1: rounds
+# 2-5's iterative-ilp, with which this compiler's register allocator crashes on the S64 kernel once the diagnostic statements are in it)
 DIAG_SCHED = ["-Wno-pass-failed"] if not os.environ.get("DLSCQP_DIAG_ILP") else ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, "dlsc_gc_planner_amd", "csrc")

@@ -19,7 +19,7 @@ def regions(extra_flags=()):
     """{kernel name: Counter{(file, line): count}} for the plan kernels."""
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "k.s")
-        cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "--cuda-device-only",
+        cmd = ["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "--cuda-device-only",
                "-gline-tables-only", "-S", "-o", out, "dlscqp.hip"] + list(extra_flags)
         subprocess.run(cmd, cwd=CSRC, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         lines = open(out).read().split("\n")

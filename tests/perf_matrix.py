@@ -4,7 +4,7 @@ src = "/root/repo/dlsc_gc_planner_amd/csrc"
 V = [l.rstrip("\n") for l in open(sys.argv[1]) if l.strip() and not l.startswith("#")]
 for i, flags in enumerate(V):
     so = "/tmp/p%d.so" % i
-    cmd = "cd %s && hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -ffp-contract=off -mllvm -amdgpu-sched-strategy=iterative-ilp %s -o %s dlscqp.hip qp_tables.cpp sfc_world.cpp" % (src, flags, so)
+    cmd = "cd %s && hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -ffp-contract=off %s -o %s dlscqp.hip qp_tables.cpp sfc_world.cpp" % (src, flags, so)
     p = subprocess.run(cmd, shell=True, capture_output=True, text=True)
     if p.returncode != 0:
         print("[%2d] %-70s COMPILE-FAIL %s" % (i, flags, [l for l in p.stderr.splitlines() if "error" in l][:1])); continue

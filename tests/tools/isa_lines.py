@@ -13,7 +13,7 @@ kern = sys.argv[1] if len(sys.argv) > 1 else "dlscqp_lsc_kernel"
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 with tempfile.TemporaryDirectory() as tmp:
     out = os.path.join(tmp, "k.s")
-    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
+    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", 
                     "--cuda-device-only", "-gline-tables-only", "-I" + os.path.join(ROOT, "include"), "-S", "-o", out, "dlscqp.hip"], cwd=CSRC, check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     lines = open(out).read().split("\n")

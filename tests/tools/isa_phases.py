@@ -18,7 +18,7 @@ args = [a for a in sys.argv[1:] if not a.startswith("--")]
 frag = args[0] if args else "plan_kernelILi1ELi3ELi13ELi5ELi2ELi0ELi0ELi0ELb0ELi1"
 asm = "/tmp/isa_phases.s"
 if "--reuse" not in sys.argv or not os.path.exists(asm):
-    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-mllvm", "-amdgpu-sched-strategy=iterative-ilp",
+    subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", 
                     "--cuda-device-only", "-DDLSCQP_ISA_MARKS", "-I" + os.path.join(ROOT, "include"), "-S", "-o", asm, "dlscqp.hip"], cwd=CSRC, check=True,
                    stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
 lines = open(asm).read().split("\n")

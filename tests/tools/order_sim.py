@@ -21,7 +21,7 @@ def record(swarms, out):
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".cpp"))]
     if not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                               "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-DDLSCQP_TIMELINE", "-I" + os.path.join(ROOT, "include"), "-o", LIB]
+                               "-DDLSCQP_TIMELINE", "-I" + os.path.join(ROOT, "include"), "-o", LIB]
                               + [os.path.join(CSRC, f) for f in ("dlscqp.hip", "qp_tables.cpp", "sfc_world.cpp", "grid_mapf.cpp")])
     os.environ["DLSCQP_LIB"] = LIB
     import torch

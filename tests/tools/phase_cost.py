@@ -25,7 +25,7 @@ def main():
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".cpp"))]
     if not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                               "-mllvm", "-amdgpu-sched-strategy=iterative-ilp", "-DDQ_PHASE_PROFILE", "-o", lib] +
+                               "-DDQ_PHASE_PROFILE", "-o", lib] +
                               [os.path.join(CSRC, f) for f in ("dlscqp.hip", "qp_tables.cpp", "sfc_world.cpp", "grid_mapf.cpp")])
     import numpy as np
     import torch

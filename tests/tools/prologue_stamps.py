@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: where an agent that never iterates spends its cycles BEFORE the first pricing pass.  A -DDLSCQP_STAMPS -DDQ_PROLOGUE_STAMPS
 build puts extra stamps into plan_agent's prologue, in the slots of the iteration's phases (which such an agent never reaches):
-    cd dlsc_gc_planner_amd/csrc && hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -ffp-contract=off -mllvm -amdgpu-sched-strategy=iterative-ilp \
+    cd dlsc_gc_planner_amd/csrc && hipcc -O3 --offload-arch=gfx950 -std=c++17 -fPIC -shared -ffp-contract=off \
         -DDLSCQP_STAMPS -DDQ_PROLOGUE_STAMPS -I../../include -o libdlscqp_stamps.so dlscqp.hip qp_tables.cpp sfc_world.cpp grid_mapf.cpp
     python tests/tools/prologue_stamps.py        (bench.py's S64 batch, 32 768 agents)"""
 import os, sys

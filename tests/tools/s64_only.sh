@@ -5,7 +5,7 @@
 #   tests/tools/s64_only.sh lib  /tmp/x.so  [-D...]
 mode=$1; out=$2; shift 2
 cd "$(dirname "$0")/../../dlsc_gc_planner_amd/csrc" || exit 1
-F="-O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -mllvm -amdgpu-sched-strategy=iterative-ilp -Wno-pass-failed -I../../include -DDLSCQP_ONLY_S64"
+F="-O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -Wno-pass-failed -I../../include -DDLSCQP_ONLY_S64"
 if [ "$mode" = asm ]; then
   /opt/rocm/bin/hipcc $F --cuda-device-only -save-temps=obj -c "$@" -o "${out%.s}.o" dlscqp.hip 2>&1 | grep -v "hip-link\|^ "; mv "$(dirname "$out")"/dlscqp-hip-amdgcn-amd-amdhsa-gfx950.s "$out"
   python3 - "$out" <<'PY'
