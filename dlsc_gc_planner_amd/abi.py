@@ -356,6 +356,9 @@ def load_library():
     lib.dlscqp_last_error.restype = C.c_char_p
     lib.dlscqp_lds_bytes.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
     lib.dlscqp_lds_bytes.restype = C.c_int64
+    if hasattr(lib, "dlscqp_fused_step_device"):  # (round 6)
+        lib.dlscqp_fused_step_device.argtypes = [C.c_void_p] * 8
+        lib.dlscqp_fused_step_device.restype = C.c_int
     if hasattr(lib, "dlscqp_conflict_doubles"):  # (round 6; tests/tools/ab.py also loads libraries built from earlier rounds' sources)
         lib.dlscqp_conflict_doubles.argtypes = [C.c_void_p, C.c_int32]
         lib.dlscqp_conflict_doubles.restype = C.c_int32
@@ -458,5 +461,5 @@ EXPORTED_SYMBOLS = [
     "dlscqp_exchange_unique_id", "dlscqp_exchange_create", "dlscqp_exchange_destroy", "dlscqp_exchange_post", "dlscqp_exchange_post_records",
     "dlscqp_exchange_before_overwrite", "dlscqp_exchange_wait", "dlscqp_exchange_set_timing", "dlscqp_exchange_get_times",
     "dlscqp_step_device", "dlscqp_neighbours_knn_device", "dlscqp_workspace_bytes", "dlscqp_mask_order_preview_device", "dlscqp_exchange_wait_packed",
-    "dlscqp_conflict_doubles", "dlscqp_write_lp", "dlscqp_conflict_decode", "dlscqp_solve_batch_conflict",
+    "dlscqp_conflict_doubles", "dlscqp_write_lp", "dlscqp_conflict_decode", "dlscqp_solve_batch_conflict", "dlscqp_fused_step_device",
 ]

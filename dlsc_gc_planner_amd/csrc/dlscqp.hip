@@ -140,6 +140,7 @@ struct WaveGpuT {
     // + constant), row codes, clamped indices -- is then computed where it is used, one or two instructions each, instead of being
     // hoisted in front of the iteration loop and kept in registers across it: in the S64 instantiation that was ~45 of 250 vector
     // registers (tests/tools/isa_liveness.py), the difference between two and three wavefronts per SIMD.
+    unsigned int grid_gen = 0;  // dlscqp_fused_kernel: the generation of the grid barrier this workgroup read before it arrived
     template <class F>
     __device__ __forceinline__ void each(F f) const {
         int l = lane;
@@ -435,6 +436,9 @@ struct KernelArgs {
     const unsigned long long *mask_in;  // launch order from class masks (masked_agent): [n_blocks][8], written by the previous step's launch
     unsigned long long *mask_out;       // ... this launch's own: every agent sets its bit in the mask of its class
     unsigned long long *mask_zero;      // ... and a third table that this launch clears (for a later launch to write)
+    unsigned int *grid;                 // dlscqp_fused_kernel: [0] arrivals, [1] generation of the grid-wide barrier in front of the epilogue, or null
+    int grid_n;                         // ... workgroups of the launch
+    int fresh_inputs;                   // ... the agent's row counts were written by THIS kernel: no load through the scalar cache
     double *out_conflict;               // dlscqp_device_batch.out_conflict: [n_agents][conflict_stride] doubles, or null
     int conflict_stride;
     int adv_on;                         // dlscqp_device_batch.advance_after: the planning wavefront also does the agent's bookkeeping between
@@ -575,32 +579,19 @@ enum { WS_LDS = 0, WS_HBM = 1 };
 // that price their share of the rows beyond the planning wavefront's register cache, once per pricing pass, between two
 // workgroup barriers (WaveGpu::pass_begin / pass_end).  Same arithmetic per row, same maximum: the answers do not depend on
 // WPA (tests/test_gpu_wide_builds.py).
-template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK, int WS = WS_LDS, bool WIDE = false, int WPA = 1>
-__global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, KernelArgs a) {
-    extern __shared__ __align__(16) unsigned char lds[];
-    if ((int)blockIdx.x >= a.n_slots_launch) return;
-    const int slot = a.slot0 + (int)blockIdx.x;
-    unsigned char *smem;
-    if constexpr (WS == WS_HBM) smem = a.work + (size_t)slot * a.work_stride;
-    else smem = lds;
-    // the instantiation whose rows are all in registers (S64) is compiled for three wavefronts per SIMD: gi_core.hpp "LEAN"
-    constexpr bool LEAN_K = DIMS > 0 && KU == 2 && SU == 0 && SLK == 0 && !WIDE && WPA == 1 && WS == WS_LDS;
-#ifndef DQ_FRESH_LANE_ALL  // 1: every instantiation starts its each() blocks from a fresh lane number (measured per instantiation: DESIGN.md section 8)
-#define DQ_FRESH_LANE_ALL 0
-#endif
-    typedef WaveGpuT<LEAN_K || DQ_FRESH_LANE_ALL != 0> Wave;
-    Wave w;
-    w.lane = (int)threadIdx.x & 63;
-    int cls_in = 0;
-    // (wave-uniform by construction -- ballots and scalar loads; said aloud: it indexes scalar loads below)
-    const int ag = __builtin_amdgcn_readfirstlane(a.order ? a.order[slot] : (a.mask_in ? masked_agent(a.mask_in, a.n_blocks, a.blocks_magic, a.n_agents, slot, w.lane, cls_in)
-                                                                                      : (a.hint[0] ? hinted_agent(a, slot, w.lane) : slot)));
-    if (a.mask_zero && slot < a.n_blocks) a.mask_zero[(size_t)slot * 8 + (threadIdx.x & 7)] = 0ull;  // (uniform condition; every lane stores, eight lanes to a word: no lane-guarded store)
-    if (ag < 0 || ag >= a.n_agents) return;  // the whole workgroup
+// One launch slot's agent: goal LP + trajectory QP + the epilogues (the body of dlscqp_plan_kernel; also the last stage of
+// dlscqp_fused_kernel).  `w`: the wavefront (lane set); smem: the working set (LDS, or the slot's HBM buffer).
+template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK, int WS, bool WIDE, int WPA, class Wave>
+__device__ __forceinline__ void plan_slot(const KParams &kp, const MemLayout &lay, const KernelArgs &a, unsigned char *smem, Wave &w,
+                                          const int slot, const int ag, const int cls_in) {
     // the agent's rows: [rb, rb + nrows_ag).  Scalar loads, both offsets in one (the compiler reads them with vector loads, one
     // dependent trip to L2 each, although the index is uniform: it cannot tell that no store of this kernel touches them)
     int rb, nrows_ag;
-    if (a.row_pitch > 0) {
+    if (a.fresh_inputs) {  // uniform (dlscqp_fused_kernel: this kernel's own stores; the scalar cache may hold an older line)
+        rb = a.row_pitch > 0 ? ag * a.row_pitch : __builtin_amdgcn_readfirstlane(a.row_offsets[ag]);
+        const int re = a.row_pitch > 0 ? rb + a.row_pitch : __builtin_amdgcn_readfirstlane(a.row_offsets[ag + 1]);
+        nrows_ag = a.row_counts ? __builtin_amdgcn_readfirstlane(__builtin_nontemporal_load(a.row_counts + ag)) : re - rb;
+    } else if (a.row_pitch > 0) {
         rb = ag * a.row_pitch;
         nrows_ag = a.row_counts ? scalar_load_i32(a.row_counts, ag) : a.row_pitch;
     } else {
@@ -708,6 +699,12 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
         // what dlscqp_advance_device would do for this agent in a launch of its own: it reads the verdicts and the plan this wavefront
         // has just stored (a wavefront's memory operations are performed in program order) and touches this agent's entries only
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (a.grid) {
+            // dlscqp_fused_kernel: the epilogue overwrites this agent's plan, sub-goal and state, which the OTHER agents' half-space and
+            // neighbour stages of this very launch read -- it waits until every workgroup has arrived behind those stages (they did
+            // so before their solves: the wait is the slowest agent's, which the step waits for anyway)
+            while (__hip_atomic_load(a.grid + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == w.grid_gen) __builtin_amdgcn_s_sleep(8);
+        }
         // (its staging buffer: the column records' place in the working set, free now -- one record is longer than a plan)
         advance_agent(a.adv, ag, w.lane, reinterpret_cast<float *>(reinterpret_cast<double *>(smem) + lay.oC));
     }
@@ -747,6 +744,31 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
         for (int i = threadIdx.x; i < nd; i += 64) o[16 + i] = src[i];
     }
 #endif
+}
+
+template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK, int WS = WS_LDS, bool WIDE = false, int WPA = 1>
+__global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, KernelArgs a) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    if ((int)blockIdx.x >= a.n_slots_launch) return;
+    const int slot = a.slot0 + (int)blockIdx.x;
+    unsigned char *smem;
+    if constexpr (WS == WS_HBM) smem = a.work + (size_t)slot * a.work_stride;
+    else smem = lds;
+    // the instantiation whose rows are all in registers (S64) is compiled for three wavefronts per SIMD: gi_core.hpp "LEAN"
+    constexpr bool LEAN_K = DIMS > 0 && KU == 2 && SU == 0 && SLK == 0 && !WIDE && WPA == 1 && WS == WS_LDS;
+#ifndef DQ_FRESH_LANE_ALL  // 1: every instantiation starts its each() blocks from a fresh lane number (measured per instantiation: DESIGN.md section 8)
+#define DQ_FRESH_LANE_ALL 0
+#endif
+    typedef WaveGpuT<LEAN_K || DQ_FRESH_LANE_ALL != 0> Wave;
+    Wave w;
+    w.lane = (int)threadIdx.x & 63;
+    int cls_in = 0;
+    // (wave-uniform by construction -- ballots and scalar loads; said aloud: it indexes scalar loads below)
+    const int ag = __builtin_amdgcn_readfirstlane(a.order ? a.order[slot] : (a.mask_in ? masked_agent(a.mask_in, a.n_blocks, a.blocks_magic, a.n_agents, slot, w.lane, cls_in)
+                                                                                      : (a.hint[0] ? hinted_agent(a, slot, w.lane) : slot)));
+    if (a.mask_zero && slot < a.n_blocks) a.mask_zero[(size_t)slot * 8 + (threadIdx.x & 7)] = 0ull;  // (uniform condition; every lane stores, eight lanes to a word: no lane-guarded store)
+    if (ag < 0 || ag >= a.n_agents) return;  // the whole workgroup
+    plan_slot<RC, DIMS, FS, MS, KU, SU, SLK, WS, WIDE, WPA>(kp, lay, a, smem, w, slot, ag, cls_in);
 }
 
 // one workgroup of LSC_THREADS threads per local agent, threads over its (neighbour, segment) items; every
@@ -1244,6 +1266,8 @@ struct dlscqp_ctx {
     int force_build = 0;     // dlscqp_selftest: 1 = the standard build of the instantiation, 2 = its WIDE build, 3 = the build with helper wavefronts
     int32_t *nbr_scratch = nullptr;  // dlscqp_neighbours_device: cell counts / starts, agents' cells and slots, agents by cell
     size_t nbr_scratch_ints = 0;
+    unsigned int *fused_grid = nullptr;  // dlscqp_fused_step_device: the grid barrier's two words (arrivals, generation)
+    int fused_dyn_lds[DQ_N_INSTANCES + 1] = {};
     int nbr_cells_clean = -1;  // cell counts [0, nbr_cells_clean] of nbr_scratch are zero (what the last complete search left); -1: unknown
     size_t work_bytes = 0;
     void *spill = nullptr;  // spill records of a launch whose batch names no workspace (grown on demand, never inside a stream capture)
@@ -1309,6 +1333,8 @@ extern "C" int dlscqp_create(const dlscqp_config *cfg, dlscqp_ctx **out_ctx) {
     if (!hip_ok(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate")) { delete c; return DLSCQP_ERR_HIP; }
     int rc = upload_tables(c);
     if (rc != DLSCQP_SUCCESS) { dlscqp_destroy(c); return rc; }
+    // (dlscqp_fused_step_device's grid barrier: two words, zero; here, so that the first fused step may already be a captured one)
+    if (!hip_ok(hipMalloc((void **)&c->fused_grid, 256), "hipMalloc") || !hip_ok(hipMemset(c->fused_grid, 0, 256), "hipMemset")) { dlscqp_destroy(c); return DLSCQP_ERR_HIP; }
     if (!std::getenv("DLSCQP_NO_SELFTEST")) {
         rc = dlscqp_selftest(c);
         if (rc != DLSCQP_SUCCESS) {
@@ -1342,6 +1368,7 @@ extern "C" void dlscqp_destroy(dlscqp_ctx *c) {
     if (c->spill) (void)hipFree(c->spill);
     if (c->d_order_scratch) (void)hipFree(c->d_order_scratch);
     if (c->nbr_scratch) (void)hipFree(c->nbr_scratch);
+    if (c->fused_grid) (void)hipFree(c->fused_grid);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1492,10 +1519,10 @@ struct LayoutChoice {
     int budget;
 };
 static LayoutChoice choose_layout(const KParams &kp, const dlscqp_device_batch *b, const KernelChoice &kc, int n_slots, int max_per_cu,
-                                  bool rows_in_lds) {
+                                  bool rows_in_lds, int64_t lds_limit = LDS_LIMIT) {
     int per_cu = (n_slots + 255) / 256;
     per_cu = per_cu < 1 ? 1 : (per_cu > max_per_cu ? max_per_cu : per_cu);
-    const int budget = (int)(LDS_LIMIT / per_cu) - 512;
+    const int budget = (int)(lds_limit / per_cu) - 512;
     const bool cold = b->max_rows_per_agent > 64 * kc.KU;
     const int row_budget = (cold && rows_in_lds) ? budget : 0;
     static const char *qz_env = getenv("DLSCQP_QZ");  // records in the working set: 0 = all of them, whatever the occupancy
@@ -1533,7 +1560,17 @@ static int advance_args(const dlscqp_ctx *c, const dlscqp_advance *adv, AdvanceA
     return DLSCQP_SUCCESS;
 }
 
-static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t stream) {
+// dlscqp_fused_step_device: the plan stage of the fused kernel is prepared by launch() -- same checks, same layout rules, same arguments --
+// and handed back instead of being launched
+struct FusedPlan {
+    int id = -1;         // instantiation (DQ_INSTANCES)
+    int static_lds = 0;  // LDS the fused kernel's other stages hold (in): the working set gets what is left of a CU's
+    KParams kp;
+    MemLayout lay;
+    KernelArgs a;
+};
+
+static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t stream, FusedPlan *fused = nullptr) {
     if (b->n_agents <= 0) return DLSCQP_SUCCESS;
     if (b->max_slack_obs < 0 || b->max_rows_per_agent < 0) { g_last_error = "negative size"; return DLSCQP_ERR_INVALID_ARGUMENT; }
     if (c->kp.use_sfc && !b->sfc_boxes) {  // same rule as the host-buffer entry points: never plan without the corridor rows
@@ -1645,6 +1682,11 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
     if (c->force_build == 1) { wpa = false; wide = false; }
     else if (c->force_build == 2) { wpa = false; wide = kc.fn_wide != nullptr; }
     else if (c->force_build == 3) { wpa = !ws_hbm && kc.fn_wpa != nullptr; wide = !wpa && wide; }
+    if (fused) {  // the fused kernel's plan stage is the build with helper wavefronts (256 threads, like its other stages)
+        if (ws_hbm || !kc.fn_wpa) { g_last_error = "fused step: no build with helper wavefronts for this shape"; return DLSCQP_ERR_UNSUPPORTED; }
+        wpa = true;
+        wide = false;
+    }
     kernel_t kfn = wpa ? kc.fn_wpa : (wide ? kc.fn_wide : kc.fn);
     if (!ws_hbm) {
         // Rows beyond the register cache: what the working set leaves of the agent's LDS budget holds them (gi_core.hpp: "rows in
@@ -1653,7 +1695,8 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         static const bool rows_in_lds = !(getenv("DLSCQP_ROWS_IN_LDS") && getenv("DLSCQP_ROWS_IN_LDS")[0] == '0');
         const bool one_per_simd = wide || (kc.id == 3 && DQ_M10_2D_ONE) || kc.id == 4 || kc.id == 5;
         const int max_per_cu = wpa ? (DQ_WPA_OCC * 4) / DQ_WPA : (one_per_simd ? 4 : 4 * (kc.id == 0 ? DQ_S64_OCC : DQ_PLAN_OCC));
-        const LayoutChoice lc = choose_layout(c->kp, b, kc, a.n_slots_launch, max_per_cu < 1 ? 1 : max_per_cu, rows_in_lds);
+        const LayoutChoice lc = choose_layout(c->kp, b, kc, a.n_slots_launch, max_per_cu < 1 ? 1 : max_per_cu, rows_in_lds,
+                                              fused ? LDS_LIMIT - fused->static_lds : LDS_LIMIT);
         lay = lc.lay;
         if (lay.bytes > LDS_LIMIT) { g_last_error = "working set exceeds the LDS of a CU"; return DLSCQP_ERR_UNSUPPORTED; }  // (ws_hbm above rules it out)
         if (lay.spill_doubles > 0) {
@@ -1683,7 +1726,7 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         }
     }
     const int attr_slot = kc.id + (wpa ? 2 * (DQ_N_INSTANCES + 1) : (wide ? DQ_N_INSTANCES + 1 : 0));
-    if (!ws_hbm && lay.bytes > c->max_dyn_lds[attr_slot]) {
+    if (!fused && !ws_hbm && lay.bytes > c->max_dyn_lds[attr_slot]) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, lay.bytes));
         c->max_dyn_lds[attr_slot] = lay.bytes;
     }
@@ -1709,6 +1752,9 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
     a.out_iters = b->out_iters;
     a.order = b->agent_order;
     a.out_stamps = (unsigned long long *)b->debug_stamps;
+    a.grid = nullptr;
+    a.grid_n = 0;
+    a.fresh_inputs = 0;
     a.out_conflict = nullptr;
     a.conflict_stride = 0;
     if (b->out_conflict) {
@@ -1719,6 +1765,13 @@ static int launch(dlscqp_ctx *c, const dlscqp_device_batch *b, hipStream_t strea
         a.out_conflict = b->out_conflict;
         a.conflict_stride = b->conflict_stride;
         HIP_TRY(hipMemsetAsync(b->out_conflict, 0, (size_t)b->n_agents * (size_t)b->conflict_stride * sizeof(double), stream));
+    }
+    if (fused) {
+        fused->id = kc.id;
+        fused->kp = c->kp;
+        fused->lay = lay;
+        fused->a = a;
+        return DLSCQP_SUCCESS;
     }
     const bool timed = c->ev_used < (int)c->ev0.size();
     if (timed) HIP_TRY(hipEventRecord(c->ev0[c->ev_used], stream));
@@ -2000,16 +2053,13 @@ __device__ __forceinline__ void nbr_gather_agent(const NbrArgs &a, const int k, 
 __global__ __launch_bounds__(64) void dlscqp_nbr_gather_kernel(NbrArgs a) { nbr_gather_agent(a, (int)blockIdx.x, (int)threadIdx.x); }
 }  // namespace
 
-extern "C" int dlscqp_neighbours_device(dlscqp_ctx *c, const dlscqp_neighbour_search *ns, void *stream) {
-    g_last_error.clear();
-    if (!c || !ns) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
-    if (ns->n_local <= 0 || ns->n_total <= 0) return DLSCQP_SUCCESS;
+// dlscqp_neighbour_search -> the kernels' argument block (the cell scratch pointers are the caller's to fill in)
+static int nbr_build_args(dlscqp_ctx *c, const dlscqp_neighbour_search *ns, NbrArgs &a) {
     if (!ns->position || !ns->out_nbr_ids || !ns->out_nbr_counts || ns->pitch <= 0 || ns->position_stride < 3 || ns->n_dyn < 0) {
         g_last_error = "null buffer or invalid size";
         return DLSCQP_ERR_INVALID_ARGUMENT;
     }
     HIP_TRY(hipSetDevice(c->cfg.device));
-    NbrArgs a;
     a.ns = *ns;
     a.range = c->cfg.communication_range;
     a.per = c->M * (c->n + 1) - c->phi;
@@ -2027,12 +2077,25 @@ extern "C" int dlscqp_neighbours_device(dlscqp_ctx *c, const dlscqp_neighbour_se
         a.grid.n[k] = a.range > 0 ? std::max(1, (int)std::floor(ext / cell) + 1) : 1;
         a.n_cells *= a.grid.n[k];
     }
-    hipStream_t st = (hipStream_t)stream;
     // Few agents (every mission of the reference): the cells cost four launches to spare each agent a look at a handful of others.
     // The candidates are everybody, the test and the order of the list are the same: the same lists (tests/test_gpu_neighbours.py).
     const char *direct_env = std::getenv("DLSCQP_NBR_DIRECT_MAX");
     const int direct_max = direct_env ? std::atoi(direct_env) : NBR_DIRECT_MAX;
     a.direct = ns->n_total <= direct_max ? 1 : 0;
+    a.cell_count = a.cell_start = a.agent_cell = a.agent_slot = a.by_cell = nullptr;
+    return DLSCQP_SUCCESS;
+}
+
+extern "C" int dlscqp_neighbours_device(dlscqp_ctx *c, const dlscqp_neighbour_search *ns, void *stream) {
+    g_last_error.clear();
+    if (!c || !ns) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (ns->n_local <= 0 || ns->n_total <= 0) return DLSCQP_SUCCESS;
+    NbrArgs a;
+    {
+        const int rc = nbr_build_args(c, ns, a);
+        if (rc != DLSCQP_SUCCESS) return rc;
+    }
+    hipStream_t st = (hipStream_t)stream;
     if (a.direct) {
         a.cell_count = a.cell_start = a.agent_cell = a.agent_slot = a.by_cell = nullptr;
         hipLaunchKernelGGL(dlscqp_nbr_gather_kernel, dim3(ns->n_local), dim3(64), 0, st, a);
@@ -2494,10 +2557,8 @@ extern "C" void dlscqp_world_destroy(dlscqp_world *w) {
     delete w;
 }
 
-extern "C" int dlscqp_generate_sfc_device(dlscqp_ctx *c, const dlscqp_world *world, const dlscqp_sfc_gen *gen, void *stream) {
-    g_last_error.clear();
-    if (!c || !world || !gen) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
-    if (gen->n_agents <= 0) return DLSCQP_SUCCESS;
+// dlscqp_sfc_gen -> the corridor kernel's argument block (the world's summed-volume tables are made ready on `stream`)
+static int sfc_build_args(dlscqp_ctx *c, const dlscqp_world *world, const dlscqp_sfc_gen *gen, void *stream, SfcGenArgs &a) {
     if (!gen->radius || !gen->max_vel || !gen->sfcs ||
         (gen->initialize ? !gen->position : (!gen->initial_traj || !gen->goals || !gen->waypoints))) {
         g_last_error = "null buffer";
@@ -2508,7 +2569,6 @@ extern "C" int dlscqp_generate_sfc_device(dlscqp_ctx *c, const dlscqp_world *wor
         const int rc = world_prepare_svt(world, gen->radius, gen->n_agents, (hipStream_t)stream);
         if (rc != DLSCQP_SUCCESS) return rc;
     }
-    SfcGenArgs a;
     a.world = world->view;
     a.n_agents = gen->n_agents; a.initialize = gen->initialize;
     a.M = c->M; a.n1 = c->n + 1;
@@ -2516,6 +2576,23 @@ extern "C" int dlscqp_generate_sfc_device(dlscqp_ctx *c, const dlscqp_world *wor
     a.radius = gen->radius; a.max_vel = gen->max_vel;
     a.position = gen->position; a.initial_traj = gen->initial_traj; a.goals = gen->goals; a.waypoints = gen->waypoints;
     a.sfcs = gen->sfcs; a.out_code = gen->out_code;
+    return DLSCQP_SUCCESS;
+}
+
+extern "C" int dlscqp_generate_sfc_device(dlscqp_ctx *c, const dlscqp_world *world, const dlscqp_sfc_gen *gen, void *stream) {
+    g_last_error.clear();
+    if (!c || !world || !gen) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    if (gen->n_agents <= 0) return DLSCQP_SUCCESS;
+    if (!gen->radius || !gen->max_vel || !gen->sfcs ||
+        (gen->initialize ? !gen->position : (!gen->initial_traj || !gen->goals || !gen->waypoints))) {
+        g_last_error = "null buffer";
+        return DLSCQP_ERR_INVALID_ARGUMENT;
+    }
+    SfcGenArgs a;
+    {
+        const int rc = sfc_build_args(c, world, gen, stream, a);
+        if (rc != DLSCQP_SUCCESS) return rc;
+    }
     static const int sfc_threads = std::getenv("DLSCQP_SFC_THREADS") ? std::atoi(std::getenv("DLSCQP_SFC_THREADS")) : SFC_THREADS;
     if (sfc_threads == 64) hipLaunchKernelGGL(dlscqp_sfc_kernel<64>, dim3(gen->n_agents), dim3(64), 0, (hipStream_t)stream, a);
     else if (sfc_threads == 128) hipLaunchKernelGGL(dlscqp_sfc_kernel<128>, dim3(gen->n_agents), dim3(128), 0, (hipStream_t)stream, a);
@@ -2533,6 +2610,167 @@ extern "C" void dlscqp_rows_to_soa(const dlscqp_lsc_row *rows, int64_t n_rows, f
         d[i] = rows[i].d;
         key[i] = DLSCQP_KEY(rows[i].m, rows[i].i, rows[i].slack, rows[i].flags & DLSCQP_ROW_DYNAMIC);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// one launch per replanning step (include/dlscqp.h: dlscqp_fused_step_device)
+// ---------------------------------------------------------------------------------------------
+// A mission of the reference is ten agents: its replanning step was four or five launches of a few microseconds each, one behind
+// the other (neighbour lists, corridor boxes, half-spaces, waypoint trap, goal LP + QP with the state update in its epilogue), and
+// the launches' gaps were most of the step.  Here the stages are device functions of ONE kernel: a workgroup of 256 threads per
+// agent runs them one after the other -- the agent's lists, boxes and rows go through memory as before (they stay in L2), the
+// workgroup's own barrier orders them.  What crosses agents is read-only until the epilogue: every stage reads the OTHER agents'
+// positions, previous plans and sub-goals of the step before (multi_sync_simulator.cpp:468-524: every agent plans on step k - 1's
+// messages), and only the epilogue (dlscqp_advance) overwrites them.  So ONE grid-wide barrier, in front of the epilogue: a
+// workgroup arrives when its last read of other agents' data is done -- before its solve -- and waits after its solve, i.e. for
+// the slowest agent's stages, which the step waits for anyway.  All workgroups are resident (at most one per CU, checked at launch).
+// The barrier is sense-reversing (arrivals, generation): nothing on the host has to count launches, a captured launch replays.
+namespace {
+struct FusedArgs {  // the stages in front of the plan stage (whose arguments are the plan kernel's three)
+    NbrArgs nbr;
+    SfcGenArgs sfc;
+    LscGenArgs lsc;
+    TrapArgs trap;
+    int have_nbr, have_sfc, have_trap;
+};
+constexpr int FUSED_THREADS = 256;
+constexpr int FUSED_WPA = FUSED_THREADS / 64;
+
+template <int RC, int DIMS, int FS, int MS, int KU, int SU, int SLK>
+__global__ __launch_bounds__(FUSED_THREADS, 1) void dlscqp_fused_kernel(KParams kp, MemLayout lay, KernelArgs a, FusedArgs f) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int k = (int)blockIdx.x, tid = (int)threadIdx.x;
+    // (read before this workgroup arrives: the generation cannot change until it has)
+    const unsigned int gen = a.grid ? __hip_atomic_load(a.grid + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    if (f.have_nbr) {  // uniform
+        nbr_gather_agent(f.nbr, k, tid);
+        __syncthreads();
+    }
+    if (f.have_sfc) {
+        sfc_agent<FUSED_THREADS>(f.sfc, k);
+        __syncthreads();
+    }
+    lsc_agent<FUSED_THREADS>(f.lsc, k);
+    __syncthreads();
+    if (f.have_trap) {
+        if (tid < 64) trap_agent(f.trap, k, tid);
+        __syncthreads();
+    }
+    if (a.grid && tid == 0) {
+        // every read this workgroup makes of OTHER agents' positions, plans and sub-goals has returned (the barriers above waited
+        // for them): arrive.  The last one to arrive opens the next generation.
+        __threadfence();
+        const unsigned int old = __hip_atomic_fetch_add(a.grid, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == (unsigned int)a.grid_n) {
+            __hip_atomic_store(a.grid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(a.grid + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    WaveGpuT<false> w;
+    w.lane = tid & 63;
+    w.grid_gen = gen;
+    plan_slot<RC, DIMS, FS, MS, KU, SU, SLK, WS_LDS, false, FUSED_WPA>(kp, lay, a, lds, w, k, k, 0);
+}
+
+typedef void (*fused_kernel_t)(KParams, MemLayout, KernelArgs, FusedArgs);
+// the instantiations the reference's missions use (3-D M = 5, 2-D M = 10, 3-D M = 10; with and without slack obstacles)
+fused_kernel_t fused_kernel_for(int id) {
+    switch (id) {
+#define DQ_CASE(ID, RC, DIMS, FS, MS, KU, SU, SLK) \
+    case ID:                                       \
+        if constexpr ((DIMS) > 0 && !((KU) == 2 && (SU) == 0)) return dlscqp_fused_kernel<RC, DIMS, FS, MS, KU, SU, SLK>; \
+        else return nullptr;
+        DQ_INSTANCES(DQ_CASE)
+#undef DQ_CASE
+    default: return nullptr;
+    }
+}
+}  // namespace
+
+extern "C" int dlscqp_fused_step_device(dlscqp_ctx *c, const dlscqp_neighbour_search *ns, const dlscqp_world *world, const dlscqp_sfc_gen *sfc,
+                                        const dlscqp_lsc_gen *gen, const dlscqp_waypoint_trap *trap, const dlscqp_device_batch *b, void *stream) {
+    g_last_error.clear();
+    if (!c || !gen || !b) { g_last_error = "null argument"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    const int N = b->n_agents;
+    if (N <= 0) return DLSCQP_SUCCESS;
+    (void)hipSetDevice(c->cfg.device);
+    // one workgroup per agent, every workgroup resident: at most one per CU
+    static int n_cu = 0;
+    if (!n_cu) {
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, c->cfg.device));
+        n_cu = prop.multiProcessorCount;
+    }
+    if (N > DLSCQP_FUSED_MAX_AGENTS || N > n_cu) { g_last_error = "fused step: more agents than workgroups that are resident at once"; return DLSCQP_ERR_UNSUPPORTED; }
+    if (gen->n_local != N || gen->local_ids || (ns && (ns->n_local != N || ns->n_total != N || ns->local_ids)) || (sfc && sfc->n_agents != N)) {
+        g_last_error = "fused step: every stage over the same agents, all of them local";
+        return DLSCQP_ERR_UNSUPPORTED;
+    }
+    if (b->agent_order || b->hint_steps != 0 || b->launch_count > 0 || !b->do_goal || !b->do_traj || !b->agents || !b->out_status ||
+        (!b->row_offsets && b->row_pitch <= 0)) {
+        g_last_error = "fused step: a plain launch of goal LP + QP over all agents";
+        return DLSCQP_ERR_UNSUPPORTED;
+    }
+    if (sfc && (!world || sfc->initialize)) { g_last_error = "fused step: corridor boxes are shifted, not initialised, in a fused step"; return DLSCQP_ERR_UNSUPPORTED; }
+    FusedArgs f;
+    std::memset(&f.nbr, 0, sizeof f.nbr);
+    std::memset(&f.sfc, 0, sizeof f.sfc);
+    std::memset(&f.trap, 0, sizeof f.trap);
+    f.have_nbr = f.have_sfc = f.have_trap = 0;
+    int rc;
+    if (ns) {
+        rc = nbr_build_args(c, ns, f.nbr);
+        if (rc != DLSCQP_SUCCESS) return rc;
+        if (!f.nbr.direct) { g_last_error = "fused step: the neighbour search through cells is several launches"; return DLSCQP_ERR_UNSUPPORTED; }
+        f.have_nbr = 1;
+    }
+    if (sfc) {
+        rc = sfc_build_args(c, world, sfc, stream, f.sfc);
+        if (rc != DLSCQP_SUCCESS) return rc;
+        f.have_sfc = 1;
+    }
+    rc = lsc_gen_args(c, gen, &f.lsc);
+    if (rc != DLSCQP_SUCCESS) return rc;
+    if (trap && gen->n_dyn > 0) {
+        if (!trap->agents || (c->kp.use_sfc && !trap->sfc_boxes)) { g_last_error = "null buffer"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+        f.trap.g = f.lsc;
+        f.trap.agents = trap->agents;
+        f.trap.sfc = c->kp.use_sfc ? trap->sfc_boxes : nullptr;
+        f.trap.out_released = trap->out_released;
+        f.trap.horizon = c->M * c->dt;
+        f.have_trap = 1;
+    }
+    // the plan stage: prepared by launch() -- the build with helper wavefronts, a working set in what the other stages leave of the LDS
+    FusedPlan fp;
+    {
+        const KernelChoice kc0 = select_kernel(c->kp, b->max_slack_obs, b->max_rows_per_agent, false);
+        fused_kernel_t probe = kc0.fn ? fused_kernel_for(kc0.id) : nullptr;
+        if (!probe) { g_last_error = "fused step: no fused build for this shape"; return DLSCQP_ERR_UNSUPPORTED; }
+        hipFuncAttributes fa;
+        HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(probe)));
+        fp.static_lds = (int)fa.sharedSizeBytes + 1024;
+    }
+    dlscqp_device_batch bb = *b;
+    bb.hint_mask_in = nullptr;  // (every agent starts at once: there is no order to find)
+    bb.hint_mask_out = nullptr;
+    bb.hint_mask_zero = nullptr;
+    rc = launch(c, &bb, (hipStream_t)stream, &fp);
+    if (rc != DLSCQP_SUCCESS) return rc;
+    fused_kernel_t kfn = fused_kernel_for(fp.id);
+    if (!kfn) { g_last_error = "fused step: no fused build for this shape"; return DLSCQP_ERR_UNSUPPORTED; }
+    if (fp.lay.bytes + fp.static_lds > LDS_LIMIT) { g_last_error = "fused step: the working set and the stages' buffers exceed the LDS of a CU"; return DLSCQP_ERR_UNSUPPORTED; }
+    fp.a.fresh_inputs = 1;
+    if (fp.a.adv_on) {  // (without the epilogue nothing that other agents read is written: no barrier)
+        fp.a.grid = c->fused_grid;
+        fp.a.grid_n = N;
+    }
+    if (fp.lay.bytes > c->fused_dyn_lds[fp.id]) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, fp.lay.bytes));
+        c->fused_dyn_lds[fp.id] = fp.lay.bytes;
+    }
+    hipLaunchKernelGGL(kfn, dim3(N), dim3(FUSED_THREADS), fp.lay.bytes, (hipStream_t)stream, fp.kp, fp.lay, fp.a, f);
+    HIP_TRY(hipGetLastError());
+    return DLSCQP_SUCCESS;
 }
 
 // ---------------------------------------------------------------------------------------------

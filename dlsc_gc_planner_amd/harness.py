@@ -290,6 +290,14 @@ class ClosedLoop:
         # ... and the plan kernel does that bookkeeping itself, in its epilogue: one launch less per step (DLSCQP_FUSED_ADVANCE=0: the
         # launch of its own, as rounds 2-5 had it)
         self.fused_advance = os.environ.get("DLSCQP_FUSED_ADVANCE", "1") != "0" and self.heavy_ranks == 0
+        # ONE launch per steady-state step where the library has a fused build for the mission (dlscqp_fused_step_device: at most 256
+        # agents, the reference's launch-file shapes); the first unsupported answer switches back to the chain of launches for good.
+        # OFF unless DLSCQP_FUSED_STEP=1: measured in round 6 (tests/tools/fused_time.py, one MI355X) the fused step is bit-equal and
+        # NOT faster -- empty10 0.0448 against 0.0440 ms p50, empty60 0.0746 against 0.0683, maze10 0.1486 against 0.1503, the same as
+        # HIP graphs: a step's stages are chains of dependent trips to L2 / HBM whichever kernel they are in, and the gaps between
+        # launches that are queued ahead are not what a step waits for
+        self.fused_step = os.environ.get("DLSCQP_FUSED_STEP", "0") == "1" and self.fused_advance and N <= 256
+        self.fused_steps_done = 0
         if self.fused_advance:
             self.batch.set_advance_after(self.advance)
         if world is not None and world.get("prune", True) and not prune:
@@ -436,6 +444,22 @@ class ClosedLoop:
         what enable_graph() captures."""
         cfg = self.cfg
         dkw = dict(dyn_position=self.dyn_pos, dyn_velocity=self.dyn_vel) if self.D else {}
+        if (self.fused_step and not first and not self.keep_inputs and getattr(self, "_stage_ev", None) is None
+                and (self.box_margin is None or self.box_in_advance) and (self.nbr is None or hasattr(self.nbr, "direct"))):
+            # the same structures, filled the same way, handed over in one call: neighbour lists, corridor boxes, half-spaces, waypoint
+            # trap, goal LP + QP and the state update are stages of ONE kernel (dlscqp_fused_step_device)
+            if self.sfc is not None:
+                self.sfc.update(self.init_buf, self.cur_goal, self.wp, launch=False)
+            if self.nbr is not None:
+                self.nbr.search(self.pos, launch=False)
+            self.gen.generate(self.cur_goal, plans=self.plans, launch=False, **dkw)
+            trap = bool(self.D and self.world is not None)
+            if trap:
+                self.gen.waypoint_trap(self.batch.t["agents"], None if self.sfc is None else self.sfc.sfcs, self.released, launch=False)
+            if self.opt.fused_step(self.batch, self.gen, nbr=self.nbr, sfc=self.sfc, trap=trap):
+                self.fused_steps_done += 1
+                return
+            self.fused_step = False  # no fused build for this mission: the chain below, from now on
         # the corridor boxes do not depend on the half-spaces (constructLSC and constructSFC of TrajPlanner::planImpl are
         # independent), so they come first here: the half-space generator can then drop the rows that the step's boxes imply
         if first:

@@ -98,6 +98,22 @@ class BatchTrajOptimizer:
                     coef=[float(m.coef[t]) for t in range(m.n)], lo=float(m.lo), hi=float(m.hi), lam=float(m.lam)) for m in out[:n.value]]
         return mem, int(ncon.value), float(gap.value)
 
+    def fused_step(self, batch, gen, nbr=None, sfc=None, trap=False, stream=None):
+        """dlscqp_fused_step_device: the steady-state step of a small mission as ONE launch.  `batch`: DeviceBatch (with its
+        advance_after), `gen`: LscGenerator, `nbr`: NeighbourSearch or None, `sfc`: SfcGenerator or None -- each prepared with
+        launch=False --, trap: the generator's waypoint trap (prepared the same way).  Returns False, with nothing launched, where
+        the library has no fused build for the case (the caller then makes the calls one by one)."""
+        torch = batch.torch
+        s = torch.cuda.current_stream(batch.device) if stream is None else stream
+        batch.c.do_goal, batch.c.do_traj, batch.c.launch_offset, batch.c.launch_count = 1, 1, 0, 0
+        rc = self.lib.dlscqp_fused_step_device(self.handle, None if nbr is None else C.byref(nbr.c), None if sfc is None else sfc.world,
+                                               None if sfc is None else C.byref(sfc.c), C.byref(gen.c),
+                                               C.byref(gen.trap_c) if trap else None, C.byref(batch.c), C.c_void_p(s.cuda_stream))
+        if rc == abi.ERR_UNSUPPORTED:
+            return False
+        self._check(rc, "dlscqp_fused_step_device")
+        return True
+
     def lds_bytes(self, max_slack_obs=0, max_rows=0):
         return int(self.lib.dlscqp_lds_bytes(self.handle, max_slack_obs, max_rows))
 
@@ -566,7 +582,7 @@ class LscGenerator:
         self.row_offsets = self.per * pairs
         return self.row_offsets
 
-    def waypoint_trap(self, agents, sfcs=None, out_released=None, stream=None):
+    def waypoint_trap(self, agents, sfcs=None, out_released=None, stream=None, launch=True):
         """TrajPlanner::checkWaypointTrap on the rows of the last generate(): `agents` the uint8 tensor of the local agents'
         records (DeviceBatch.t["agents"]), `sfcs` the corridor tensor [n_local, M, 6] or None, `out_released` an optional
         int32 tensor [n_local].  Asynchronous; a no-op without dynamic obstacles."""
@@ -574,6 +590,9 @@ class LscGenerator:
         t.agents = agents.data_ptr()
         t.sfc_boxes = None if sfcs is None else sfcs.data_ptr()
         t.out_released = None if out_released is None else out_released.data_ptr()
+        self.trap_c = t
+        if not launch:
+            return
         s = self.torch.cuda.current_stream(self.device) if stream is None else stream
         rc = self.opt.lib.dlscqp_waypoint_trap_device(self.opt.handle, C.byref(self.c), C.byref(t), C.c_void_p(s.cuda_stream))
         self.opt._check(rc, "dlscqp_waypoint_trap_device")
@@ -595,7 +614,7 @@ class LscGenerator:
         return self.row_counts
 
     def generate(self, goals, plans=None, position=None, velocity=None, stream=None, dyn_position=None, dyn_velocity=None,
-                 observed_position=None, reset_threshold=0.0):
+                 observed_position=None, reset_threshold=0.0, launch=True):
         """goals [n_total,3] f32 and either plans [n_total,M,n+1,3] f32 (previous plans) or position/velocity
         (first replanning step); dyn_position / dyn_velocity [n_dyn,3] f32 when the generator has dynamic obstacles;
         observed_position [n_total,3] f32 + reset_threshold: TrajPlanner::checkObstacleDisturbance: CUDA tensors.  Asynchronous."""
@@ -621,6 +640,8 @@ class LscGenerator:
         g.velocity = None if velocity is None else velocity.data_ptr()
         g.goals = goals.data_ptr()
         self._keep = (goals, plans, position, velocity)
+        if not launch:  # (the structure is ready for BatchTrajOptimizer.fused_step)
+            return
         s = self.torch.cuda.current_stream(self.device) if stream is None else stream
         rc = self.opt.lib.dlscqp_generate_lsc_device(self.opt.handle, C.byref(g), C.c_void_p(s.cuda_stream))
         self.opt._check(rc, "dlscqp_generate_lsc_device")
@@ -678,12 +699,14 @@ class NeighbourSearch:
         import os
         self.direct = gen.n_total <= int(os.environ.get("DLSCQP_NBR_DIRECT_MAX", "256"))
 
-    def search(self, position, stream=None):
+    def search(self, position, stream=None, launch=True):
         """position: CUDA float32 tensor [n_total, >= 3] whose rows are `position.stride(0)` floats apart (a dense table or a
         view into the agent records).  Asynchronous."""
         assert position.dtype == self.torch.float32 and position.stride(1) == 1
         self.c.position, self.c.position_stride = position.data_ptr(), int(position.stride(0))
         self._keep = position
+        if not launch:
+            return
         s = self.torch.cuda.current_stream(self.device) if stream is None else stream
         rc = self.opt.lib.dlscqp_neighbours_device(self.opt.handle, C.byref(self.c), C.c_void_p(s.cuda_stream))
         self.opt._check(rc, "dlscqp_neighbours_device")
@@ -779,12 +802,14 @@ class SfcGenerator:
         self._keep = (position,)
         self._launch(stream)
 
-    def update(self, initial_traj, goals, waypoints, stream=None):
+    def update(self, initial_traj, goals, waypoints, stream=None, launch=True):
         """initial_traj [N,M,n+1,3], goals, waypoints [N,3] f32 CUDA tensors: one constructSFCFromInitialTraj step."""
         initial_traj, goals, waypoints = initial_traj.contiguous(), goals.contiguous(), waypoints.contiguous()
         self.c.initialize = 0
         self.c.initial_traj, self.c.goals, self.c.waypoints = initial_traj.data_ptr(), goals.data_ptr(), waypoints.data_ptr()
         self._keep = (initial_traj, goals, waypoints)
+        if not launch:
+            return
         self._launch(stream)
 
     def close(self):

@@ -743,6 +743,23 @@ void dlscqp_rows_to_soa(const dlscqp_lsc_row *rows, int64_t n_rows, float *nx, f
 int dlscqp_set_timing(dlscqp_ctx *ctx, int32_t capacity);
 int dlscqp_get_kernel_times(dlscqp_ctx *ctx, float *ms_out, int32_t capacity, int32_t *n_out);
 
+/* ---- one launch per replanning step (small missions) ----------------------------------------------------------------------
+ * The steady-state step of a closed loop -- neighbour lists (dlscqp_neighbours_device), corridor boxes (dlscqp_generate_sfc_device,
+ * the shift of a step, not the initialisation), half-spaces (dlscqp_generate_lsc_device), waypoint trap (dlscqp_waypoint_trap_device),
+ * goal LP + QP with dlscqp_device_batch.advance_after -- as ONE kernel: a workgroup of 256 threads per agent runs the stages one
+ * after the other, one grid-wide barrier separates every agent's reads of the others' previous plans from the epilogue that
+ * overwrites them (the reference plans every agent on the messages of the step before, multi_sync_simulator.cpp:468-524).  Same
+ * structures as the single entry points (ns, world + sfc, trap: NULL = stage not run), same buffers, same results bit for bit.
+ * For missions of the reference's size: at most DLSCQP_FUSED_MAX_AGENTS agents and one workgroup per CU, every stage over all agents
+ * (no local_ids), lists short enough for the one-launch neighbour search, a static-shape instantiation with rows beyond its register
+ * cache or communication-range rows (every launch file of the reference).  DLSCQP_ERR_UNSUPPORTED otherwise, with nothing launched:
+ * the caller then makes the calls one by one. */
+#define DLSCQP_FUSED_MAX_AGENTS 256
+int dlscqp_fused_step_device(dlscqp_ctx *ctx, const dlscqp_neighbour_search *ns, const dlscqp_world *world,
+                             const dlscqp_sfc_gen *sfc, const dlscqp_lsc_gen *gen, const dlscqp_waypoint_trap *trap,
+                             const dlscqp_device_batch *batch, void *stream);
+
+
 #ifdef __cplusplus
 }
 #endif

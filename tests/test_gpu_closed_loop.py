@@ -337,6 +337,61 @@ def test_hip_graph_step_equals_eager_step(gpu_required, with_world):
     assert moved.mean() > (1.0 if with_world != "crowd" else 0.5)  # the agents did fly (the crowd: 14 steps)
 
 
+@pytest.mark.parametrize("with_world", [False, "reference", "forest"])
+def test_fused_step_equals_the_chain_of_launches(gpu_required, with_world, monkeypatch):
+    """dlscqp_fused_step_device (round 6): the steady-state step of a small mission as ONE kernel -- neighbour lists, corridor boxes,
+    half-spaces, waypoint trap, goal LP + QP, state update as stages of a workgroup per agent, one grid-wide barrier in front of the
+    epilogue -- gives the same plans, states, sub-goals and verdicts, bit for bit, as the four or five launches it replaces: the
+    empty world, the maze as the reference's mission runs it (lists rebuilt every step, corridors), the forest (dynamic obstacles,
+    slack variables, waypoint trap); eager and replayed as a HIP graph."""
+    import torch
+    if with_world == "forest":
+        from dlsc_gc_planner_amd.harness import SpinObstacles
+        m = json.load(open(os.path.join(HERE, "golden", "world_forest1.json")))
+        cfg = abi.make_config(dim=m["dim"], M=m["M"], dt=m["dt"], control_input_weight=0.01, terminal_weight=1.0,
+                              communication_range=m["communication_range"], slack_collision_weight=m["slack_collision_weight"],
+                              world_use_octomap=True, world_min=tuple(m["world"][:3]), world_max=tuple(m["world"][3:]))
+        world = dict(boxes=m["boxes"], resolution=m["world_resolution"], grid_resolution=m["grid_resolution"], pibt="reference",
+                     uncertainty_horizon=m["uncertainty_horizon"])
+        kw = dict(radius=m["radius"], downwash=m["downwash"], max_vel=m["max_vel"], max_acc=m["max_acc"], nominal_velocity=1.0,
+                  waypoint_step=m["grid_resolution"], world=world)
+        kw_dyn = lambda: SpinObstacles(m["obstacles"]).dyn(size_prediction=1, horizon=m["uncertainty_horizon"], duration=m["obs_duration"])  # noqa: E731
+        start, goal = np.array(m["start"], np.float32), np.array(m["goal"], np.float32)
+    elif with_world:
+        m, cfg, world = _maze()
+        kw = dict(radius=m["radius"], downwash=2.0, max_vel=m["max_vel"], max_acc=m["max_acc"], nominal_velocity=1.0,
+                  waypoint_step=m["grid_resolution"], world=dict(world, pibt="reference"))
+        start, goal = np.array(m["start"], np.float32), np.array(m["goal"], np.float32)
+    else:
+        cfg, m = _mission("empty10_1")
+        kw = dict(radius=m["radius"], downwash=m["downwash"], max_vel=m["max_vel"], max_acc=m["max_acc"],
+                  nominal_velocity=m["nominal_velocity"])
+        start, goal = np.array(m["start"], np.float32), np.array(m["goal"], np.float32)
+    runs = []
+    for fused, use_graph in (("0", False), ("1", False), ("1", True)):
+        monkeypatch.setenv("DLSCQP_FUSED_STEP", fused)
+        sim = ClosedLoop(cfg, start, goal, **(dict(kw, dyn=kw_dyn()) if with_world == "forest" else kw))
+        try:
+            hist = []
+            for k in range(40):
+                if use_graph and k == 3:
+                    sim.enable_graph()
+                status, iters = sim.step()
+                hist.append((sim.plans.cpu().numpy().copy(), sim.pos.cpu().numpy().copy(), sim.cur_goal.cpu().numpy().copy(),
+                             status.cpu().numpy().copy()))
+            # every steady-state step was ONE launch (or none was)
+            assert sim.fused_steps_done == (0 if fused == "0" else (39 if not use_graph else sim.fused_steps_done)) and (fused == "0" or sim.fused_steps_done >= 3)
+            assert sim.fused_step == (fused == "1")
+        finally:
+            sim.close()
+        runs.append(hist)
+    for other in runs[1:]:
+        for k, (e, g) in enumerate(zip(runs[0], other)):
+            for x, y in zip(e, g):
+                assert np.array_equal(x, y), k
+    assert np.linalg.norm(runs[1][-1][1] - start, axis=1).mean() > 1.0  # the agents did fly
+
+
 @pytest.mark.parametrize("mission", ["empty", "maze", "forest", "crowd"])
 def test_bookkeeping_in_the_plan_kernels_epilogue_equals_the_advance_launch(gpu_required, mission, monkeypatch):
     """dlscqp_device_batch.advance_after: the wavefront that planned an agent also applies dlscqp_advance to it (fail-safe, sub-goal,
