@@ -533,6 +533,10 @@ class ClosedLoop:
         # cause was the search's memset node -- the cell counts were not cleared again on replay, the slots ran past their cells'
         # runs and the scatter wrote out of bounds; the search now clears its counts itself, in its last kernel)
         torch.cuda.synchronize(self.dev)
+        # (the graphs hold raw pointers: spill records in a buffer of the batch's own, not in the context's, which a later, larger
+        # launch on the same context would free and allocate again under them)
+        if getattr(self.batch, "_workspace", None) is None:
+            self.batch.use_workspace()
         state = [self.batch.t["agents"], self.cur_goal, self.plans, self.init_buf]
         if self.sfc is not None:
             state.append(self.sfc.sfcs)  # the corridor boxes are shifted in place every step

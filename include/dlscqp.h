@@ -244,8 +244,10 @@ typedef struct dlscqp_device_batch {
                                        launch that activate more rows keep the others here, in HBM.  dlscqp_workspace_bytes() says how
                                        much a launch can need.  NULL (or too small): the library uses a buffer of the CONTEXT, grown
                                        on demand -- which launches of the same context on different streams would share (do not
-                                       overlap them) and which cannot grow inside a stream capture.  Launches small enough to give
-                                       every agent the LDS for all its records need neither.  Contents are scratch.              */
+                                       overlap them), which cannot grow inside a stream capture, and whose growth LATER (another
+                                       batch of the context, a larger launch) frees the buffer a graph captured earlier still
+                                       points at: give a batch that is captured into a graph a workspace of its own.  Launches small
+                                       enough to give every agent the LDS for all its records need neither.  Contents are scratch. */
     int64_t workspace_bytes;
     const uint64_t *hint_mask_in;   /* LAUNCH ORDER FROM CLASS MASKS (preferred over hint_iters: no load of 64 keys in front of every agent's
                                        record).  Three tables of [ceil(n_agents / 64)][8] 64-bit words.  A launch with hint_mask_out
@@ -357,10 +359,10 @@ int dlscqp_launch_order_history_device(dlscqp_ctx *ctx, const int32_t *const *it
 /* The launch order a dlscqp_device_batch with these hint_iters gets, written out (tests, diagnostics): order_out[s] = the agent
  * launch slot s plans, s < 64 * ceil(n_agents / 64), or -1 for a slot beyond its block's agents.  Same device function as the
  * plan kernel's.  iters: 1..3 device arrays [n_agents][4], newest first; order_out: device array. */
-/* the same for hint_mask_in: masks [ceil(n_agents / 64)][8] */
-int dlscqp_mask_order_preview_device(dlscqp_ctx *ctx, const uint64_t *masks, int32_t n_agents, int32_t *order_out, void *stream);
 int dlscqp_hint_order_preview_device(dlscqp_ctx *ctx, const int32_t *const *iters, int32_t n_steps, int32_t n_agents, int32_t *order_out,
                                      void *stream);
+/* the same for hint_mask_in: masks [ceil(n_agents / 64)][8] */
+int dlscqp_mask_order_preview_device(dlscqp_ctx *ctx, const uint64_t *masks, int32_t n_agents, int32_t *order_out, void *stream);
 
 /* ---- DLSC-GC half-space generation on the device --------------------------------------
  * TrajPlanner::generateDLSCGC for neighbouring AGENTS (traj_planner.cpp:603-666) together with the shift of the

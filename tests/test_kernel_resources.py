@@ -1,0 +1,61 @@
+"""CPU tier: what the compiler made of the S64 plan kernel in the library that ships (read from its code object).
+
+DESIGN.md section 8a: the instantiation whose rows are all in registers is compiled for THREE wavefronts per SIMD -- at most 168
+registers, none spilled.  The code object declares 68 bytes of private segment per lane all the same: a 64-byte spill slot the register
+allocator made for a 16-register tuple and then did not use (+ 4 bytes it keeps for emergencies).  No instruction of the kernel touches
+scratch, which is what this test pins (declared empty in a patched copy of the library the kernel is as fast: tests/tools/noscratch_patch.py)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "dlsc_gc_planner_amd", "csrc", "libdlscqp.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+S64 = "dlscqp_plan_kernelILi1ELi3ELi13ELi5ELi2ELi0ELi0ELi0ELb0ELi1E"
+
+pytestmark = pytest.mark.skipif(not os.path.exists(LIB) or shutil.which("objcopy") is None or not os.path.exists(LLVM + "/clang-offload-bundler"),
+                                reason="needs the built library and the ROCm binutils")
+
+
+@pytest.fixture(scope="module")
+def code_object(tmp_path_factory):
+    d = tmp_path_factory.mktemp("co")
+    fat, co = str(d / "fat.bin"), str(d / "gfx950.o")
+    subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", LIB, fat], check=True)
+    subprocess.run([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + fat,
+                    "--output=" + co], check=True)
+    return co
+
+
+def kernel_notes(co):
+    notes = subprocess.run([LLVM + "/llvm-readelf", "--notes", co], check=True, capture_output=True).stdout.decode()
+    out = {}
+    for e in notes.split("- .agpr_count")[1:]:
+        d = dict(re.findall(r"\.(\w+):\s+(\S+)", "  .agpr_count" + e))
+        out[d["name"]] = d
+    return out
+
+
+def test_the_s64_kernel_runs_three_wavefronts_per_simd_and_touches_no_scratch(code_object):
+    notes = kernel_notes(code_object)
+    name = next(n for n in notes if S64 in n)
+    k = notes[name]
+    assert int(k["vgpr_count"]) + int(k["agpr_count"]) <= 168, k  # 512 registers per SIMD lane / 3, in blocks of 8
+    assert int(k["vgpr_spill_count"]) == 0, k
+    assert int(k["group_segment_fixed_size"]) == 0, k  # its working set is dynamic LDS, sized per launch (choose_layout)
+    dis = subprocess.run([LLVM + "/llvm-objdump", "-d", "--disassemble-symbols=" + name, code_object], check=True, capture_output=True).stdout.decode()
+    lines = dis.split("\n")
+    assert len(lines) > 5000
+    touching = [l for l in lines if "scratch_" in l or "flat_scratch" in l or (re.search(r"\bbuffer_(load|store|atomic)", l) is not None)]
+    assert not touching, touching[:5]
+    assert int(k["private_segment_fixed_size"]) <= 68, k  # (the dead slot; 0 once the allocator stops leaving it behind)
+
+
+def test_no_kernel_of_the_library_uses_matrix_instructions(code_object):
+    """bench.py's roofline.mfma_insts is a counter; this is the same fact read from the code (no GEMM-shaped work: DESIGN.md section 4)."""
+    dis = subprocess.run([LLVM + "/llvm-objdump", "-d", code_object], check=True, capture_output=True).stdout.decode()
+    assert dis.count("\n") > 100000
+    assert "v_mfma" not in dis and "v_smfmac" not in dis
