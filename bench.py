@@ -61,6 +61,7 @@ def parse_args():
     ap.add_argument("--headline-only", action="store_true",
                     help="(profiling) stop after the headline loop: the last --steps launches of the process are the timed ones")
     ap.add_argument("--force-dist", action="store_true", help="(test) create the process group even for one rank")
+    ap.add_argument("--lockstep-exchange", action="store_true", help="(measurement) rounds 3-5: a launch waits for the collective of the step before last instead of for the one that read the table it overwrites")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic_latest.json"))
     return ap.parse_args()
 
@@ -95,13 +96,14 @@ def scaling_model(step_ms_one_rank, n_agents_per_rank):
     one GPU was available to measure it): weak scaling, every rank plans its own agents; ONE all-gather of 376 B per agent per step whose
     transfer runs beside the next step's launches (pipelined: no agent of S64 reads a remote plan):
         step(n) = max(step(1) + post, transfer(n)),   transfer(n) = latency + (n - 1) N 376 B / ring bandwidth"""
-    post, lat, ring = 0.05, 0.03, 300e9
+    post, lat, ring = 0.02, 0.03, 300e9
     ms = [max(step_ms_one_rank + (0.0 if g == 1 else post), 0.0 if g == 1 else lat + (g - 1) * n_agents_per_rank * 376 / ring * 1e3) for g in (1, 2, 4, 8)]
     return {"n_gpus": [1, 2, 4, 8], "ms_per_step": ms, "qp_per_s": [g * n_agents_per_rank / t * 1e3 for g, t in zip((1, 2, 4, 8), ms)],
             "speedup_over_one_gpu": [g * ms[0] / t for g, t in zip((1, 2, 4, 8), ms)],
             "assumptions": {"step_ms_one_rank": step_ms_one_rank, "post_ms": post, "exchange_latency_ms": lat, "ring_GBps": ring / 1e9, "bytes_per_agent": 376,
-                            "note": "post_ms: what queueing the exchange costs a step on one rank (--force-dist, two groups, against the same loop "
-                                    "without a process group); ring_GBps: bus bandwidth of RCCL's ring all-gather over xGMI (7 links x ~153 GB/s "
+                            "note": "post_ms: what the exchange costs a step on one rank before any byte crosses xGMI (--force-dist, its two groups: "
+                                    "0.3585 ms, against the same 1 024 swarms in four groups without a process group: 0.3396; "
+                                    "profiles/r06_force_dist_trace.md); ring_GBps: bus bandwidth of RCCL's ring all-gather over xGMI (7 links x ~153 GB/s "
                                     "per GPU, point to point: a ring is bound by one link each way; DESIGN.md section 5); the transfer is hidden "
                                     "behind the next step's launches while it is shorter than a step"}}
 
@@ -1010,6 +1012,7 @@ def main():
                 if self.xchg is not None and getattr(self, "native", False):
                     a.exchange = self.xchg.handle
                     a.records = self.rec[j].data_ptr()
+                    a.rotation = B if 3 <= B <= 8 and not args.lockstep_exchange else 0
                 self.cargs.append((a, groups))
 
         def step(self, pipelined):
@@ -1032,7 +1035,7 @@ def main():
                 if use_dist and pipelined:
                     # the exchange of step k (packing included) runs on the communication stream while step k+1 writes another
                     # batch's outputs (B >= 3 batches rotate: the table a launch writes was posted B steps ago)
-                    self.xchg.before_overwrite(st)
+                    self.xchg.before_overwrite(st, tables=B if 3 <= B <= 8 and not args.lockstep_exchange else None)
                 elif use_dist and self.table_ready is not None:
                     st.wait_event(self.table_ready)  # serial mode: the next launch waits for the exchange
                 db.launch(True, True, stream=st)
@@ -1524,7 +1527,7 @@ def main():
             # the figure that compares like for like with rounds 1-2 (ONE launch of all the GPU's agents per step, in lockstep); `value`
             # is the swarm groups advancing independently on their own streams (config.swarm_groups_note)
             "at_512_swarms": at_512,
-            "scaling_model": scaling_model(elapsed / args.steps * 1e3 - (0.05 if use_dist else 0.0), N),
+            "scaling_model": scaling_model(elapsed / args.steps * 1e3 - (0.02 if use_dist else 0.0), N),
             "one_launch_per_step": None if not isinstance(one_launch, dict) or not one_launch.get("kernel_order") else
                                    {"ms_per_step": one_launch["kernel_order"], "qp_per_s": world * N / one_launch["kernel_order"] * 1e3},
             "per_rank_ms": rank_breakdown,

@@ -257,7 +257,8 @@ class StepGroup(C.Structure):  # dlscqp_step_group
 
 class StepArgs(C.Structure):  # dlscqp_step_args
     _fields_ = [("n_groups", C.c_int32), ("exchange_mode", C.c_int32), ("groups", C.POINTER(StepGroup)), ("exchange", C.c_void_p),
-                ("ctrl", C.c_void_p), ("goal", C.c_void_p), ("status", C.c_void_p), ("records", C.c_void_p)]
+                ("ctrl", C.c_void_p), ("goal", C.c_void_p), ("status", C.c_void_p), ("records", C.c_void_p),
+                ("rotation", C.c_int32), ("reserved_", C.c_int32)]
 
 
 EXCHANGE_NONE, EXCHANGE_PIPELINED, EXCHANGE_SERIAL = 0, 1, 2
@@ -422,6 +423,8 @@ def load_library():
         lib.dlscqp_exchange_post_records.restype = C.c_int
         lib.dlscqp_exchange_before_overwrite.argtypes = [vp, vp]
         lib.dlscqp_exchange_before_overwrite.restype = C.c_int
+        lib.dlscqp_exchange_before_overwrite_rotating.argtypes = [vp, vp, C.c_int32]
+        lib.dlscqp_exchange_before_overwrite_rotating.restype = C.c_int
         if hasattr(lib, "dlscqp_exchange_wait_packed"):
             lib.dlscqp_exchange_wait_packed.argtypes = [vp, vp]
             lib.dlscqp_exchange_wait_packed.restype = C.c_int
@@ -462,4 +465,5 @@ EXPORTED_SYMBOLS = [
     "dlscqp_exchange_before_overwrite", "dlscqp_exchange_wait", "dlscqp_exchange_set_timing", "dlscqp_exchange_get_times",
     "dlscqp_step_device", "dlscqp_neighbours_knn_device", "dlscqp_workspace_bytes", "dlscqp_mask_order_preview_device", "dlscqp_exchange_wait_packed",
     "dlscqp_conflict_doubles", "dlscqp_write_lp", "dlscqp_conflict_decode", "dlscqp_solve_batch_conflict", "dlscqp_fused_step_device",
+    "dlscqp_exchange_before_overwrite_rotating",
 ]

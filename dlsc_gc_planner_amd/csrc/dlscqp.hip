@@ -3089,6 +3089,10 @@ struct dlscqp_exchange {
     hipEvent_t ready[2] = {nullptr, nullptr}, packed[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
     bool posted[2] = {false, false};
     long long k = 0;                         // exchanges posted so far
+    // "the communication stream has read what post k sent" for the last SRC_RING posts (post k: src_read[k % SRC_RING]): a caller that
+    // rotates through B tables overwrites, at step k, the table post k - B read (dlscqp_exchange_before_overwrite_rotating)
+    static constexpr int SRC_RING = 8;
+    hipEvent_t src_read[SRC_RING] = {};
     int last = -1;
     std::vector<hipEvent_t> planned;         // dlscqp_step_device: one per group
     hipEvent_t table_ready = nullptr;        // serial mode of dlscqp_step_device
@@ -3119,6 +3123,8 @@ extern "C" void dlscqp_exchange_destroy(dlscqp_exchange *x) {
         if (x->packed[b]) (void)hipEventDestroy(x->packed[b]);
         if (x->done[b]) (void)hipEventDestroy(x->done[b]);
     }
+    for (auto e : x->src_read)
+        if (e) (void)hipEventDestroy(e);
     for (auto e : x->planned) (void)hipEventDestroy(e);
     for (auto e : x->tev) (void)hipEventDestroy(e);
     if (x->table_ready) (void)hipEventDestroy(x->table_ready);
@@ -3162,6 +3168,8 @@ extern "C" int dlscqp_exchange_create(dlscqp_ctx *c, const dlscqp_exchange_confi
             hipEventCreateWithFlags(&x->done[b], hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate"; return fail(DLSCQP_ERR_HIP); }
     }
     if (hipEventCreateWithFlags(&x->table_ready, hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate"; return fail(DLSCQP_ERR_HIP); }
+    for (auto &e : x->src_read)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { g_last_error = "hipEventCreate"; return fail(DLSCQP_ERR_HIP); }
     *out = x;
     return DLSCQP_SUCCESS;
 }
@@ -3205,6 +3213,21 @@ extern "C" int dlscqp_exchange_before_overwrite(dlscqp_exchange *x, void *stream
     return DLSCQP_SUCCESS;
 }
 
+// The same for a caller that rotates through `tables` output tables (step k writes table k mod tables): the table the next step writes was
+// read by post k - tables, not by post k - 2.  With two tables a launch of step k waits until the collective of step k - 2 has run -- and
+// that collective waited for EVERY group's launch of step k - 2, then for room on a GPU that the launches of step k - 1 fill: measured on
+// one MI355X (four groups of 16 384 agents, kernel trace in profiles/r06_force_dist_trace.md) the copy of step k - 2 starts ~250 us into
+// step k - 1 and every group starts step k in lockstep behind it -- the groups' independence is gone, 0.338 -> 0.469 ms
+// per step.  With the rotation's real length the wait refers to a collective that finished steps ago.
+extern "C" int dlscqp_exchange_before_overwrite_rotating(dlscqp_exchange *x, void *stream, int32_t tables) {
+    g_last_error.clear();
+    if (!x) return DLSCQP_ERR_INVALID_ARGUMENT;
+    if (tables < 2 || tables > dlscqp_exchange::SRC_RING) { g_last_error = "before_overwrite_rotating: 2 <= tables <= 8"; return DLSCQP_ERR_INVALID_ARGUMENT; }
+    const long long k = x->k - tables;  // the post that read the table the next step writes
+    if (k >= 0) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, x->src_read[k % dlscqp_exchange::SRC_RING], 0));
+    return DLSCQP_SUCCESS;
+}
+
 // `stream` waits until the communication stream has read the arrays of the post just made (a caller that rewrites them right away)
 extern "C" int dlscqp_exchange_wait_packed(dlscqp_exchange *x, void *stream) {
     g_last_error.clear();
@@ -3230,6 +3253,7 @@ extern "C" int dlscqp_exchange_post_records(dlscqp_exchange *x, const float *rec
 static int exchange_post(dlscqp_exchange *x, const float *ctrl, const float *goal, const int32_t *status, const float *records, void *ready_stream) {
     HIP_TRY(hipSetDevice(x->device));
     const int b = (int)(x->k & 1);
+    hipEvent_t src_read = x->src_read[x->k % dlscqp_exchange::SRC_RING];
     x->k++;
     const bool timed = x->t_used < x->t_cap;
     hipEvent_t *te = timed ? &x->tev[4 * (size_t)x->t_used] : nullptr;
@@ -3247,7 +3271,10 @@ static int exchange_post(dlscqp_exchange *x, const float *ctrl, const float *goa
         hipLaunchKernelGGL(dlscqp_pack_kernel, dim3(grid), dim3(256), 0, x->comm_stream, ctrl, goal, status, x->send[b], x->n_local, x->E);
     }
     HIP_TRY(hipGetLastError());
-    if (!records) HIP_TRY(hipEventRecord(x->packed[b], x->comm_stream));  // the caller's three arrays have been read
+    if (!records) {  // the caller's three arrays have been read
+        HIP_TRY(hipEventRecord(x->packed[b], x->comm_stream));
+        HIP_TRY(hipEventRecord(src_read, x->comm_stream));
+    }
     if (timed) HIP_TRY(hipEventRecord(te[2], x->comm_stream));
     if (x->local_only) {
         HIP_TRY(hipMemcpyAsync(x->recv[b], src, (size_t)x->n_local * x->W * sizeof(float), hipMemcpyDeviceToDevice, x->comm_stream));
@@ -3255,7 +3282,10 @@ static int exchange_post(dlscqp_exchange *x, const float *ctrl, const float *goa
         if (!rccl_ok(g_rccl.AllGather(src, x->recv[b], (size_t)x->n_local * x->W, /* ncclFloat32 */ 7, x->comm, x->comm_stream), "ncclAllGather")) return DLSCQP_ERR_HIP;
     }
     HIP_TRY(hipEventRecord(x->done[b], x->comm_stream));
-    if (records) HIP_TRY(hipEventRecord(x->packed[b], x->comm_stream));  // sent as they lie: read when the collective is through
+    if (records) {  // sent as they lie: read when the collective is through
+        HIP_TRY(hipEventRecord(x->packed[b], x->comm_stream));
+        HIP_TRY(hipEventRecord(src_read, x->comm_stream));
+    }
     if (timed) { HIP_TRY(hipEventRecord(te[3], x->comm_stream)); x->t_used++; }
     x->posted[b] = true;
     x->last = b;
@@ -3293,7 +3323,7 @@ extern "C" int dlscqp_step_device(const dlscqp_step_args *s) {
         if (mode == DLSCQP_EXCHANGE_PIPELINED) {
             // the exchange of step k (packing included) runs on the communication stream while step k + 1 writes another table of
             // the caller's rotation: a launch only waits until the table it is about to overwrite has been packed
-            const int rc = dlscqp_exchange_before_overwrite(x, st);
+            const int rc = s->rotation > 2 ? dlscqp_exchange_before_overwrite_rotating(x, st, s->rotation) : dlscqp_exchange_before_overwrite(x, st);
             if (rc != DLSCQP_SUCCESS) return rc;
         } else if (mode == DLSCQP_EXCHANGE_SERIAL && x->have_table_ready) {
             HIP_TRY(hipStreamWaitEvent(st, x->table_ready, 0));  // the next launch waits for the exchange
@@ -3305,6 +3335,9 @@ extern "C" int dlscqp_step_device(const dlscqp_step_args *s) {
     if (mode == DLSCQP_EXCHANGE_NONE) return DLSCQP_SUCCESS;
     // the communication stream itself waits for the groups' launches of the step (no stream in between: streams share a few
     // hardware queues, and a stream that only waits can hold up the queue of a group it shares one with)
+    // (measured, round 6, one rank, four groups of 16 384 agents: these four waits are 0.07 ms of a 0.44 ms step -- without them, which
+    // is wrong, 0.369; with one, 0.404; hipStreamWriteValue64 / hipStreamWaitValue64 on signal memory instead of events: 0.535.  A wait
+    // across hardware queues costs the waited-for queue too on this runtime)
     for (int g = 0; g < s->n_groups; g++) HIP_TRY(hipStreamWaitEvent(x->comm_stream, x->planned[g], 0));
     int rc = s->records ? dlscqp_exchange_post_records(x, s->records, x->comm_stream) : dlscqp_exchange_post(x, s->ctrl, s->goal, s->status, x->comm_stream);
     if (rc != DLSCQP_SUCCESS) return rc;

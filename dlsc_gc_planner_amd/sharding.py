@@ -84,6 +84,7 @@ class PlanExchange:
         self.done = [None, None]  # CUDA: event on the communication stream; CPU: Work handle
         self.packed = [None, None]  # CUDA, pack_on_comm: the inputs of post k have been read
         self._reuse = [None, None]
+        self._src_read = [None] * 8  # post k: "its tensors have been read" (before_overwrite with a rotation of tables)
         self.comm = torch.cuda.Stream(device) if self.cuda else None
         self.k = 0
         self.last = None
@@ -121,9 +122,16 @@ class PlanExchange:
             flat.append(p)
         torch.cat(flat, dim=1, out=self.send[b])
 
-    def before_overwrite(self, stream=None):
-        """pack_on_comm: make `stream` (default: the current one) wait until the tensors of the post before last have been read."""
-        e = self.packed[self.k & 1]
+    def before_overwrite(self, stream=None, tables=None):
+        """pack_on_comm: make `stream` (default: the current one) wait until the tensors of the post before last have been read --
+        or, for a caller that rotates through `tables` (3..8) output tables, of the post that read the table the next step writes
+        (post k - tables: include/dlscqp.h, dlscqp_exchange_before_overwrite_rotating)."""
+        if tables is not None and tables > 2:
+            assert tables <= len(self._src_read)
+            k = self.k - tables
+            e = self._src_read[k % len(self._src_read)] if k >= 0 else None
+        else:
+            e = self.packed[self.k & 1]
         if e is not None:
             (self.torch.cuda.current_stream(self.device) if stream is None else stream).wait_event(e)
 
@@ -149,6 +157,10 @@ class PlanExchange:
                     t0.record(self.comm)
                 self._pack(b, parts)
                 self.packed[b].record(self.comm)
+                slot = (self.k - 1) % len(self._src_read)
+                if self._src_read[slot] is None:
+                    self._src_read[slot] = torch.cuda.Event()
+                self._src_read[slot].record(self.comm)
                 self.dist.all_gather_into_tensor(self.recv[b], self.send[b])
                 self.done[b].record(self.comm)
             if timed:
@@ -306,8 +318,11 @@ class NativeExchange:
         self.last = self.k & 1
         self.k += 1
 
-    def before_overwrite(self, stream=None):
-        self._check(self.lib.dlscqp_exchange_before_overwrite(self.handle, self._stream(stream)), "dlscqp_exchange_before_overwrite")
+    def before_overwrite(self, stream=None, tables=None):
+        if tables is not None and tables > 2:
+            self._check(self.lib.dlscqp_exchange_before_overwrite_rotating(self.handle, self._stream(stream), int(tables)), "dlscqp_exchange_before_overwrite_rotating")
+        else:
+            self._check(self.lib.dlscqp_exchange_before_overwrite(self.handle, self._stream(stream)), "dlscqp_exchange_before_overwrite")
 
     def table(self, stream=None):
         """Make `stream` (default: the current one) wait for the exchange posted last; returns the gathered [world * n_local, W] table."""

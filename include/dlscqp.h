@@ -694,6 +694,11 @@ void dlscqp_exchange_destroy(dlscqp_exchange *x);
  * it ahead of the launch after next: it refers to the post before last).  Asynchronous; no host synchronisation. */
 int dlscqp_exchange_post(dlscqp_exchange *x, const float *ctrl, const float *goal, const int32_t *status, void *ready_stream);
 int dlscqp_exchange_before_overwrite(dlscqp_exchange *x, void *stream);
+/* The same for a caller that rotates through `tables` (2..8) output tables, step k writing table k mod tables: `stream` waits for the
+ * post that READ the table the next step writes -- post k - tables, a collective that ran steps ago -- instead of for the post before
+ * last.  With several swarm groups per GPU this is what keeps them independent: a wait for the collective of step k - 2 starts every
+ * group's step k in lockstep behind a transfer that itself waited for all groups (measured on one rank with four groups: 0.471 -> 0.441 ms per step; profiles/r06_force_dist_trace.md). */
+int dlscqp_exchange_before_overwrite_rotating(dlscqp_exchange *x, void *stream, int32_t tables);
 /* `stream` waits until the communication stream has read the arrays (or records) of the post just made: for a caller that goes on
  * to rewrite them on `stream` at once instead of rotating its tables (dlscqp_exchange_before_overwrite) */
 int dlscqp_exchange_wait_packed(dlscqp_exchange *x, void *stream);
@@ -731,6 +736,11 @@ typedef struct dlscqp_step_args {
     const int32_t *status;
     const float *records;               /* ... or the table as records (out_record_stride): posted without a packing pass;
                                            ctrl / goal / status are then not read                                   */
+    /* ---- round 6 (appended, zero = the behaviour of before) */
+    int32_t rotation;                   /* DLSCQP_EXCHANGE_PIPELINED: how many output tables the caller rotates through (step k writes
+                                           table k mod rotation; 3..8): the launches wait for post k - rotation
+                                           (dlscqp_exchange_before_overwrite_rotating).  0 or 2: for the post before last.          */
+    int32_t reserved_;
 } dlscqp_step_args;
 int dlscqp_step_device(const dlscqp_step_args *step);
 

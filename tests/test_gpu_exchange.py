@@ -217,3 +217,43 @@ def test_a_post_that_does_not_pack_on_the_communication_stream_may_be_overwritte
         x.close()
     finally:
         opt.close()
+
+
+@pytest.mark.parametrize("tables", [3, 4, 8])
+def test_a_rotation_of_tables_waits_for_the_post_that_read_the_table(gpu_required, tables):
+    """dlscqp_exchange_before_overwrite_rotating: a caller that rotates through B record tables rewrites table k mod B at step k once
+    post k - B has read it -- not earlier (the gathered tables are the posted ones although every table is rewritten as soon as the
+    wait lets the stream go, with the posts held back by slow producers) and without waiting for the post before last (the event it
+    waits for is the one of post k - B: checked through the argument range and the first B steps, which wait for nothing)."""
+    cfg = workloads.s64_config()
+    opt = BatchTrajOptimizer(cfg)
+    try:
+        N, W = 8192, cfg.M * (cfg.n + 1) * 3 + 4
+        x = sharding.NativeExchange(opt, 0, 1, N, None, local_only=True)
+        assert opt.lib.dlscqp_exchange_before_overwrite_rotating(x.handle, None, 1) == abi.ERR_INVALID_ARGUMENT
+        assert opt.lib.dlscqp_exchange_before_overwrite_rotating(x.handle, None, 9) == abi.ERR_INVALID_ARGUMENT
+        rec = [torch.zeros((N, W), device="cuda") for _ in range(tables)]
+        big = torch.zeros(32 << 20, dtype=torch.float32, device="cuda")
+        st, side = torch.cuda.Stream(), torch.cuda.Stream()
+        got, cloned = [], None
+        for step in range(3 * tables + 2):
+            j = step % tables
+            with torch.cuda.stream(st):
+                x.before_overwrite(st, tables=tables)
+                rec[j].fill_(float(step + 1))  # (what the plan kernel of step `step` writes)
+                for _ in range(2):
+                    big.add_(1.0)              # a slow producer: the post's ready event comes late, the next steps' writes are queued behind
+            if cloned is not None:
+                st.wait_event(cloned)  # (a gathered table is valid until the post after next: the consumer has copied the previous one)
+            x.post_records(rec[j], stream=st)
+            t = x.table(side)
+            with torch.cuda.stream(side):
+                got.append(t.clone())
+                cloned = torch.cuda.Event()
+                cloned.record(side)
+        torch.cuda.synchronize()
+        for step, g in enumerate(got):
+            assert float(g.min()) == float(g.max()) == float(step + 1), (step, float(g.min()), float(g.max()))
+        x.close()
+    finally:
+        opt.close()
