@@ -33,7 +33,7 @@ def regions(extra_flags=()):
         if m:
             files[m.group(1)] = os.path.basename(m.group(3) or m.group(2))
             continue
-        m = re.match(r'(_Z\w*dlscqp_(?:plan|sfc)_kernel\w*):', l)
+        m = re.match(r'(_Z\w*dlscqp_(?:plan|sfc|advance)_kernel\w*):', l)
         if m:
             kernel = m.group(1)
             res[kernel] = Counter()

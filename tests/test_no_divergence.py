@@ -13,6 +13,14 @@ ALLOWED = ("if (in) out_ctrl[j] = v;", "if (in) out_x[j] = v;", "if (in) out_sla
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not available")
 def test_only_the_final_stores_are_lane_guarded():
     res = divergence_check.regions()
+    adv = [k for k in res if "dlscqp_advance_kernel" in k]
+    assert len(adv) == 1
+    # the lane-strided loops of advance_agent carry compiler-made guards attributed to line 0: as many as the stand-alone
+    # dlscqp_advance_kernel (the same function) shows bound what a plan kernel may show -- a guard the compiler adds anywhere else in the
+    # kernel's wrapper (mask and atomic epilogue, helper loop, future code) comes on top of the epilogue's and is then seen
+    adv_line0 = sum(n for (f, line), n in res[adv[0]].items() if f == "dlscqp.hip" and line == 0)
+    assert 0 < adv_line0 <= 24, adv_line0
+    res = {k: v for k, v in res.items() if k != adv[0]}
     assert len(res) == 23, sorted(res)  # the 8 instantiations of dlscqp_plan_kernel (DQ_INSTANCES), 3 one-wavefront-per-SIMD builds for small launches, 7 builds with helper wavefronts, the variant with its working set in HBM, four thread counts of dlscqp_sfc_kernel
     offenders = []
     # source range of the exit_stores lambda of plan_agent: its marker line up to the lambda's closing brace
@@ -27,6 +35,9 @@ def test_only_the_final_stores_are_lane_guarded():
     adv_hi = next(i for i in range(adv_lo, len(hip_lines)) if hip_lines[i] == "}") + 1
     assert 40 < adv_hi - adv_lo < 140
     for kernel, counts in res.items():
+        if "dlscqp_plan_kernel" in kernel:
+            line0 = sum(n for (f, line), n in counts.items() if f == "dlscqp.hip" and line == 0)
+            assert line0 <= adv_line0, (kernel[-60:], line0, adv_line0)
         for (f, line), n in counts.items():
             if f == "exit_stores":  # lane-0 stores that every exit path issues as its last action
                 continue
