@@ -19,6 +19,16 @@
 #define DQ_FN __host__ __device__ __forceinline__
 #if defined(__HIP_DEVICE_COMPILE__)
 #define DQ_WAVE_ALL(c) (__ballot(!(c)) == 0ull)
+// a double every lane computes from wave-uniform inputs, moved to a scalar register pair: a division's result is a vector register
+// to the compiler whatever went in, and a handful of such quotients hoisted in front of a loop are registers the loop cannot use
+namespace {
+__device__ __forceinline__ double dq_uniform_f64(double x) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)b), hi = __builtin_amdgcn_readfirstlane((unsigned int)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+}  // namespace
+#define DQ_UNIFORM_F64(x) dq_uniform_f64(x)
 #endif
 #define DQ_KEEP(v) asm volatile("" : "+v"(v))
 #define DQ_MARK(text) asm volatile("; " text)
@@ -817,12 +827,17 @@ __device__ __forceinline__ void lsc_agent(const LscGenArgs &g, const int k) {
         // presolve: rows implied by the agent's own box rows are dropped, the others written contiguously in their original
         // order -- per round of THREADS items an exclusive prefix sum of the kept-row counts over the workgroup (LDS)
         __shared__ int wave_rows[2][THREADS / 64];
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
         const size_t row0 = (size_t)per * pair0;
         const int all = items + g.n_dyn * g.M;
         int base = 0;  // rows the previous rounds kept (every thread carries its own copy)
         for (int it0 = 0, round = 0; it0 < all; it0 += THREADS, round ^= 1) {
-            const int it = it0 + (int)threadIdx.x;
+            // (every round derives its addresses from a thread number that went through an empty statement: what is derived from it is
+            // computed in the round instead of hoisted in front of the loop and kept in registers -- dlscqp_lsc_pair_kernel says more)
+            int tid = (int)threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const int lane = tid & 63, wave = tid >> 6;
+            const HullStore hull = {hull_pts + tid, THREADS};
+            const int it = it0 + tid;
             LscRows r;
             r.i0 = 6;
             bool keep[6] = {false, false, false, false, false, false};
@@ -903,6 +918,16 @@ __global__ __launch_bounds__(64, DQ_LSC_PAIR_OCC) void dlscqp_lsc_pair_kernel(Ls
     const int rounds_to = all0 > all1 ? all0 : all1;  // wave-uniform: both halves walk as many rounds as the longer list needs
     int base = 0;  // rows the previous rounds of this agent kept
     for (int it0 = 0; it0 < rounds_to; it0 += 32) {
+#ifndef DQ_LSC_FRESH
+#define DQ_LSC_FRESH 1  // every round derives its addresses from a thread number and an agent number that went through an empty statement:
+#endif                  // what is derived from them is computed in the round instead of hoisted in front of the loop and kept in registers
+#if DQ_LSC_FRESH
+        int tid = (int)threadIdx.x, kcl = kc;
+        asm volatile("" : "+v"(tid), "+v"(kcl));
+        const int half = tid >> 5, l32 = tid & 31, kc = kcl;
+        const HullStore hull = {hull_pts + tid, 64};
+        const int self = g.local_ids ? g.local_ids[kc] : kc;
+#endif
         const int it = it0 + l32;
         LscRows r;
         r.i0 = 6;

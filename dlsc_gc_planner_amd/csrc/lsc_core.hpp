@@ -28,6 +28,10 @@
 #ifndef DQ_WAVE_ALL
 #define DQ_WAVE_ALL(c) (c)
 #endif
+// DQ_UNIFORM_F64(x): x is computed from wave-uniform inputs only (the GPU build keeps it in scalar registers); host: x itself
+#ifndef DQ_UNIFORM_F64
+#define DQ_UNIFORM_F64(x) (x)
+#endif
 
 namespace dlscqp {
 
@@ -373,7 +377,8 @@ DQ_FN F3 initial_point(const LscGenArgs &g, int id, int m, int i) {
         const float *p = g.position + 3 * (size_t)id, *v = g.velocity + 3 * (size_t)id;
         double time = 0;
         const int steps = m * g.n1 + i;
-        for (int s = 0; s < steps; s++) time += g.dt / n;
+        const double tick = DQ_UNIFORM_F64(g.dt / n);
+        for (int s = 0; s < steps; s++) time += tick;
         const float tf = (float)time;
         return f3(p[0] + v[0] * tf, p[1] + v[1] * tf, p[2] + v[2] * tf);
     }
@@ -509,7 +514,8 @@ DQ_FN void lsc_item(const LscGenArgs &g, int self, int other, int m, size_t row0
 DQ_FN F3 const_vel_point(const float *p, const float *v, double dt, int n1, int m, int i) {
     double time = 0;
     const int steps = m * n1 + i;
-    for (int s = 0; s < steps; s++) time += dt / (n1 - 1);
+    const double tick = DQ_UNIFORM_F64(dt / (n1 - 1));
+    for (int s = 0; s < steps; s++) time += tick;
     const float tf = (float)time;
     return f3(p[0] + v[0] * tf, p[1] + v[1] * tf, p[2] + v[2] * tf);
 }
@@ -557,11 +563,11 @@ DQ_FN void lsc_dyn_item_rows(const LscGenArgs &g, int self, int o, int m, LscRow
         if (g.dyn_size_prediction) {
             if (m < Mu) {
                 const double mt = m * g.dt;
-                const double c0 = 0.5 * amax * (mt * mt), c1 = amax * m * g.dt * g.dt, c2 = 0.5 * amax * (g.dt * g.dt);
-                size = r_obs + (c0 + c1 * ((double)i / n) + c2 * ((double)(i * (i - 1)) / (double)(n * (n - 1))));
+                const double c0 = 0.5 * amax * (mt * mt), c1 = amax * m * g.dt * g.dt, c2 = 0.5 * amax * DQ_UNIFORM_F64(g.dt * g.dt);
+                size = r_obs + (c0 + c1 * DQ_UNIFORM_F64((double)i / n) + c2 * DQ_UNIFORM_F64((double)(i * (i - 1)) / (double)(n * (n - 1))));
             } else {
-                const double mt = Mu * g.dt;
-                size = r_obs + 0.5 * amax * (mt * mt);
+                const double mt = DQ_UNIFORM_F64(Mu * g.dt);
+                size = r_obs + 0.5 * amax * DQ_UNIFORM_F64(mt * mt);
             }
         }
         const F3 pt = const_vel_point(op, ov, g.dt, g.n1, m, i);

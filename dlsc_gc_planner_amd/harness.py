@@ -418,7 +418,10 @@ class ClosedLoop:
         self._stage_ev.append((name, ev))
 
     def stage_times(self):
-        """dict stage -> array of ms per step (steps since enable_stage_timers)."""
+        """dict stage -> array of ms per step (steps since enable_stage_timers).
+        With the bookkeeping between two plans done by the plan kernel's own epilogue (fused_advance, the default:
+        dlscqp_device_batch.advance_after) it is part of traj_optimization_time and state_update_time reads ~0 -- to compare the columns
+        with the reference's summary file (multi_sync_simulator.cpp:863-871) stage by stage, run with DLSCQP_FUSED_ADVANCE=0."""
         self.torch.cuda.synchronize(self.dev)
         out = {k: [] for k in self.STAGES}
         ev = self._stage_ev
