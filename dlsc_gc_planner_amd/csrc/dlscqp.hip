@@ -29,6 +29,7 @@ __device__ __forceinline__ double dq_uniform_f64(double x) {
 }
 }  // namespace
 #define DQ_UNIFORM_F64(x) dq_uniform_f64(x)
+#define DQ_FRESH_INT(i) asm volatile("" : "+v"(i))
 #endif
 #define DQ_KEEP(v) asm volatile("" : "+v"(v))
 #define DQ_MARK(text) asm volatile("; " text)
@@ -895,7 +896,7 @@ __global__ __launch_bounds__(THREADS, OCC) void dlscqp_lsc_kernel(LscGenArgs g) 
 // presolve's scan runs over the half-wavefront.  Same items in the same order: the same rows at the same places.  The odd agent
 // out repeats the last agent's work and writes nothing.  Presolve path only (row_counts).
 #ifndef DQ_LSC_PAIR_OCC
-#define DQ_LSC_PAIR_OCC 3  // (measured: 4 wavefronts per SIMD spill 248 B a lane here -- generator stage 0.190 against 0.175 ms)
+#define DQ_LSC_PAIR_OCC 4  // (rounds 4-5: 3, four wavefronts per SIMD spilled 248 B a lane; round 6: 114 registers with the other agent's points read again, lsc_core.hpp)
 #endif
 __global__ __launch_bounds__(64, DQ_LSC_PAIR_OCC) void dlscqp_lsc_pair_kernel(LscGenArgs g) {
     const int half = (int)threadIdx.x >> 5, l32 = (int)threadIdx.x & 31;
@@ -938,7 +939,7 @@ __global__ __launch_bounds__(64, DQ_LSC_PAIR_OCC) void dlscqp_lsc_pair_kernel(Ls
             const int j = it / g.M;
             m = it - j * g.M;
             tail_skip = g.tail_segments > 0 && j >= g.tail_from && m < g.M - g.tail_segments;
-            if (!tail_skip) lsc_item_rows(g, self, g.nbr_ids[p0 + j], m, r, hull, j < 32 ? &last_geo[half][j] : nullptr);
+            if (!tail_skip) lsc_item_rows(g, self, g.nbr_ids[p0 + j], m, r, hull, j < 32 ? &last_geo[half][j] : nullptr, true);
         } else if (it < all) {
             const int q = it - items, o = q / g.M;
             m = q - o * g.M;

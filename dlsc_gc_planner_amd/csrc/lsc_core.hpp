@@ -32,6 +32,11 @@
 #ifndef DQ_UNIFORM_F64
 #define DQ_UNIFORM_F64(x) (x)
 #endif
+// DQ_FRESH_INT(i): (GPU build) the compiler forgets what it knows about i -- loads through addresses derived from it are issued again
+// instead of their earlier results being kept in registers across the code in between; host: nothing
+#ifndef DQ_FRESH_INT
+#define DQ_FRESH_INT(i) ((void)0)
+#endif
 
 namespace dlscqp {
 
@@ -445,7 +450,11 @@ DQ_FN LscLast lsc_last_geometry(const LscGenArgs &g, int self, int other) {
 // if the caller has computed it beforehand (the GPU kernel does, for all pairs of an agent at once: among the items of a
 // wavefront one in M is a last segment, and computed in place it sends the whole wavefront through the segment-to-segment
 // code), else null.
-DQ_FN void lsc_item_rows(const LscGenArgs &g, int self, int other, int m, LscRows &out, const HullStore &hull, const LscLast *last = nullptr) {
+// reload_pred (a constant at every call site): see below -- measured on one MI355X: the two-agents-per-wavefront kernel of the S64 closed
+// loop gains (147 -> 114 registers, a fourth wavefront per SIMD: one loop's step 0.499 -> 0.487 ms), the many-items kernel of the crowd
+// loses (0.0563 -> 0.0595 ms for the stress batch's rows, also with a fifth wavefront per SIMD), so only the former asks for it
+DQ_FN void lsc_item_rows(const LscGenArgs &g, int self, int other, int m, LscRows &out, const HullStore &hull, const LscLast *last = nullptr,
+                         const bool reload_pred = false) {
     const int M = g.M;
     const double r_self = g.radius[self], r_oth = g.radius[other];
     const double collision_dist = r_oth + r_self;                                                       // :605
@@ -482,6 +491,12 @@ DQ_FN void lsc_item_rows(const LscGenArgs &g, int self, int other, int m, LscRow
         const F3 nt = normalized(cp);
         const F3 nrm = f3(nt.x, nt.y, (float)((double)nt.z / downwash));  // :634-636
         out.nx = nrm.x; out.ny = nrm.y; out.nz = nrm.z;
+        if (reload_pred) {
+            // the other agent's points are read again (L1 / L2) instead of held in eighteen registers across the closest-point iteration
+            DQ_FRESH_INT(other);
+#pragma unroll
+            for (int i = 0; i < 6; i++) pred[i] = predicted_point(g, other, m, i);
+        }
 #pragma unroll
         for (int i = 0; i < 6; i++) {  // entries below i0 are computed too and never stored
             out.px[i] = pred[i].x; out.py[i] = pred[i].y; out.pz[i] = pred[i].z;
