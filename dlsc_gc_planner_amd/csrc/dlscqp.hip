@@ -1045,7 +1045,10 @@ struct WaveSfcT {
     template <class F>
     __device__ __forceinline__ bool any_of(int n, F f) const {
         bool acc = false;
-#pragma unroll 4
+#ifndef SFC_ANY_UNROLL
+#define SFC_ANY_UNROLL 4
+#endif
+#pragma unroll SFC_ANY_UNROLL
         for (int base = 0; base < n; base += SFC_T) {
             const int idx = base + lane;
             acc |= f(idx < n ? idx : n - 1) & (idx < n);  // every thread evaluates a valid point
