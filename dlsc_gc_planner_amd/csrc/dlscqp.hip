@@ -1046,8 +1046,8 @@ struct WaveSfcT {
     __device__ __forceinline__ bool any_of(int n, F f) const {
         bool acc = false;
 #ifndef SFC_ANY_UNROLL
-#define SFC_ANY_UNROLL 4
-#endif
+#define SFC_ANY_UNROLL 1  // (rounds 2-5: 4.  The point test is ~200 instructions and any_of has a dozen call sites: unrolled four times the
+#endif                    // kernel was 70 k instructions of which a ten-workgroup launch fetches most cold; 1: corridor stage of the maze / forest step 0.038 -> 0.035 ms, library 2.8 MB smaller)
 #pragma unroll SFC_ANY_UNROLL
         for (int base = 0; base < n; base += SFC_T) {
             const int idx = base + lane;
