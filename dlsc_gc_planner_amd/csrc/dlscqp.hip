@@ -767,9 +767,9 @@ __global__ DQ_KERNEL_ATTR void dlscqp_plan_kernel(KParams kp, MemLayout lay, Ker
     else smem = lds;
     // the instantiation whose rows are all in registers (S64) is compiled for three wavefronts per SIMD: gi_core.hpp "LEAN"
     constexpr bool LEAN_K = DIMS > 0 && KU == 2 && SU == 0 && SLK == 0 && !WIDE && WPA == 1 && WS == WS_LDS;
-#ifndef DQ_FRESH_LANE_ALL  // 1: every instantiation starts its each() blocks from a fresh lane number (measured per instantiation: DESIGN.md section 8)
-#define DQ_FRESH_LANE_ALL 0
-#endif
+#ifndef DQ_FRESH_LANE_ALL  // 1: every instantiation starts its each() blocks from a fresh lane number, not only the one that needs it for its third wavefront
+#define DQ_FRESH_LANE_ALL 1  // per SIMD.  Measured at the end of round 6: the crowd's kernel 406 -> 376 registers and 100 -> 20 B of scratch, the two-per-SIMD
+#endif                       // builds spill 29-90 registers instead of 56-124; crowd step 0.2983 -> 0.2938 ms, empty60's LP + QP launch 0.0427 -> 0.0405
     typedef WaveGpuT<LEAN_K || DQ_FRESH_LANE_ALL != 0> Wave;
     Wave w;
     w.lane = (int)threadIdx.x & 63;
