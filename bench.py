@@ -15,11 +15,15 @@ What is timed, and how the line avoids flattering itself:
   * the timed loop rotates through `--batches` (4) DIFFERENT batches: the same agents at consecutive replanning steps of
     the closed-loop workload generator, 0.2 s apart;
   * agents are launched most-expensive-first by the iteration counts of the PREVIOUS batch (what a closed loop knows when
-    it plans a step), and the order is computed where a closed loop computes it: on the device, by
-    dlscqp_launch_order_device after every step, INSIDE the timed loop; the same loop in plain id order
-    (`ms_per_step_no_order_hint`) and with orders prepared on the host before the loop (`ms_per_step_host_order`) are timed
-    right after and reported beside it;
-  * a "hard" batch made only of agents with at least five active rows at their solution is timed too (`hard_batch`).
+    it plans a step), and the order is found where a closed loop finds it: on the device, INSIDE the timed loop, by the plan
+    kernel itself from the class masks the previous launch of the same agents left behind (round 5; rounds 1-3: sort kernels
+    after every step, `ms_per_step_sorted_on_device`); the same loop in plain id order (`ms_per_step_no_order_hint`) and with
+    orders prepared on the host before the loop (`ms_per_step_host_order`) are timed right after and reported beside it;
+  * a "hard" batch made only of agents with at least five active rows at their solution is timed too (`hard_batch`);
+  * a bracket of `--steps` steps shorter than 50 ms is repeated back to back and the MEDIAN repeat is the line's value
+    (`timing`): the line does not depend on `--steps` (round 6);
+  * `--swarms` defaults to 1 024 since round 6 (a step cannot be shorter than its slowest agent's 35-46 iterations, which 512
+    swarms ran into once the kernel held three wavefronts per SIMD); the 512-swarm loop is reported as `at_512_swarms`.
 Rank 0 prints one JSON line.  `value` = agent-QPs of all ranks / max-over-ranks wall time of the K timed steps.
 """
 import argparse
